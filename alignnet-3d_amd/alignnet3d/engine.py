@@ -1,0 +1,217 @@
+"""Engine: the session-like object the drop-in train.py drives.
+
+It plays the role of the TF graph + Session of the reference: construction =
+train.py:190-227 (placeholders, get_model, get_loss, optimizer), `forward` = the eval
+`sess.run` (train.py:447-449), `train_step` = the train `sess.run` (train.py:368).
+All arithmetic happens in libalignnet_hip.so on the GPU; this file only marshals."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+OUTPUT_NAMES = ("pred_translations", "pred_remaining_angle_logits", "pred_s1_pc1centers", "pred_s1_pc2centers",
+                "pred_s2_pc1centers", "pred_s2_pc2centers", "pred_pc1angle_logits", "pred_pc2angle_logits")
+
+SUMMARY_NAMES = (
+    "losses/translation", "losses/angle",
+    "losses_stages/stage1_pc1_transl_loss", "losses_stages/stage1_pc2_transl_loss",
+    "losses_stages/stage2_pc1_transl_loss", "losses_stages/stage2_pc2_transl_loss",
+    "losses_stages/stage3_transl_loss",
+    "losses_stages/stage2_pc1_angle_loss", "losses_stages/stage2_pc1_angle_class_loss",
+    "losses_stages/stage2_pc1_angle_residual_loss",
+    "losses_stages/stage2_pc2_angle_loss", "losses_stages/stage2_pc2_angle_class_loss",
+    "losses_stages/stage2_pc2_angle_residual_loss",
+    "losses_stages/stage3_angle_loss", "losses_stages/stage3_angle_class_loss",
+    "losses_stages/stage3_angle_residual_loss")  # models/tp8.py:336-353 order
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def default_model_config():
+    """The SynthCars layer widths (reference configs/SynthCars.json:12-15) at N=1024 -- the
+    operating point of BASELINE.json.  Same nesting as the merged reference config."""
+    return {
+        "data": {"num_channels": 3, "ntrain": 0},
+        "model": {
+            "backbone": "pointnet", "num_points": 1024,
+            "options": {
+                "angle_factor": 1.0, "early_stage_factor": 0.5,
+                "s1transformer": [[64, 128, 256], [[512, 256], 0.7]],
+                "s2transformer": [[64, 128, 512], [[512, 256], 0.7]],
+                "embedding": [64, 128, 1024],
+                "remaining_transform_prediction": [[512, 256], 0.7],
+            },
+            "angles": {"num_bins": 50, "accept_inverted_angle": True},
+        },
+        "training": {
+            "batch_size": 128, "learning_rate": 0.005,
+            "optimizer": {"optimizer": "adam"},
+            "lr_extension": {"mode": "decay", "per": "epoch", "step": 30, "rate": 0.5},
+            "bn_extension": {"mode": "decay", "per": "epoch", "step": 30, "rate": 0.5, "init": 0.5, "clip": 0.99},
+        },
+        "gpu_index": 0,
+    }
+
+
+def _to_dict(cfg):
+    """Accept a plain dict or the config NameSpace (config.py:9-29)."""
+    if isinstance(cfg, dict):
+        return cfg
+    out = {}
+    for k, v in cfg.__dict__.items():
+        out[k] = _to_dict(v) if hasattr(v, "__dict__") and not isinstance(v, (list, tuple, str)) else v
+    return out
+
+
+def make_c_config(cfg, device=None, seed=0):
+    d = _to_dict(cfg)
+    m, o, t = d["model"], d["model"]["options"], d.get("training", {})
+    c = _capi.Config()
+    c.abi_version = _capi.ABI_VERSION
+    c.device = int(d.get("gpu_index", 0) if device is None else device)
+    c.num_points = int(m["num_points"])
+    c.num_channels = int(d["data"]["num_channels"])
+    c.num_bins = int(m["angles"]["num_bins"])
+    bk = m["backbone"]
+    if bk not in ("pointnet", "dgcnn"):
+        raise AssertionError(bk)  # models/tp8.py:68
+    c.backbone = 0 if bk == "pointnet" else 1
+    c.s1_conv, c.s1_fc = _capi.Widths.of(o["s1transformer"][0]), _capi.Widths.of(o["s1transformer"][1][0])
+    c.s2_conv, c.s2_fc = _capi.Widths.of(o["s2transformer"][0]), _capi.Widths.of(o["s2transformer"][1][0])
+    c.emb_conv = _capi.Widths.of(o["embedding"])
+    c.rem_fc = _capi.Widths.of(o["remaining_transform_prediction"][0])
+    keep = lambda v: -1.0 if v is None else float(v)
+    c.s1_keep, c.s2_keep = keep(o["s1transformer"][1][1]), keep(o["s2transformer"][1][1])
+    c.rem_keep = keep(o["remaining_transform_prediction"][1])
+    c.angle_factor, c.early_stage_factor = float(o["angle_factor"]), float(o["early_stage_factor"])
+    c.accept_inverted_angle = int(bool(m["angles"]["accept_inverted_angle"]))
+    c.batch_size = int(t.get("batch_size", 1))
+    c.ntrain = int(d["data"].get("ntrain", 0))
+    c.learning_rate = float(t.get("learning_rate", 0.001))
+    lr, bn = t.get("lr_extension", {}), t.get("bn_extension", {})
+    c.lr_step, c.lr_rate = int(lr.get("step", 0)), float(lr.get("rate", 1.0))
+    c.lr_per_epoch = int(lr.get("per", "epoch") == "epoch")
+    c.bn_init, c.bn_rate, c.bn_clip = float(bn.get("init", 0.5)), float(bn.get("rate", 0.5)), float(bn.get("clip", 0.99))
+    c.bn_step, c.bn_per_epoch = int(bn.get("step", 0)), int(bn.get("per", "epoch") == "epoch")
+    opt = t.get("optimizer", {}).get("optimizer", "adam")
+    if opt not in ("adam", "momentum"):
+        raise AssertionError("Invalid optimizer")  # train.py:216
+    c.optimizer = 0 if opt == "adam" else 1
+    c.momentum = float(t.get("optimizer", {}).get("momentum", 0.9))
+    c.seed = int(seed)
+    return c
+
+
+def _fp(a):
+    return a.ctypes.data_as(_capi.FP)
+
+
+class Engine:
+    def __init__(self, cfg=None, device=None, seed=0):
+        self._lib = _capi.load_library()
+        self._h = _capi.H()
+        self.cfg = _to_dict(cfg) if cfg is not None else default_model_config()
+        self._c = make_c_config(self.cfg, device, seed)
+        if self._lib.alignnet_create(C.byref(self._c), C.byref(self._h)) != 0:
+            raise EngineError(self._lib.alignnet_last_error(None).decode())
+        self.num_points = self._c.num_points
+        self.num_bins = self._c.num_bins
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.alignnet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self._lib.alignnet_last_error(self._h).decode())
+
+    # ---- variables ---------------------------------------------------------
+    def variables(self):
+        """[(name, (rows, cols), trainable)] in graph-construction order."""
+        out = []
+        name, r, c, t = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        for i in range(self._lib.alignnet_num_params(self._h)):
+            self._check(self._lib.alignnet_param_info(self._h, i, C.byref(name), C.byref(r), C.byref(c), C.byref(t)))
+            out.append((name.value.decode(), (r.value, c.value), bool(t.value)))
+        return out
+
+    def get_variable(self, name):
+        shp = dict((n, s) for n, s, _ in self.variables())[name]
+        a = np.empty(shp[0] * shp[1], np.float32)
+        self._check(self._lib.alignnet_get_param(self._h, name.encode(), _fp(a), a.size))
+        return a.reshape(shp) if shp[0] > 1 else a
+
+    def set_variable(self, name, value):
+        a = np.ascontiguousarray(value, np.float32).ravel()
+        self._check(self._lib.alignnet_set_param(self._h, name.encode(), _fp(a), a.size))
+
+    def set_variables(self, d):
+        for k, v in d.items():
+            self.set_variable(k, v)
+
+    def init_variables(self, seed=0):
+        self._check(self._lib.alignnet_init_params(self._h, seed))
+
+    # ---- eval sess.run (train.py:447-449) -----------------------------------
+    def _alloc_outputs(self, B):
+        nb2 = 2 * self.num_bins
+        widths = dict(pred_translations=3, pred_remaining_angle_logits=nb2, pred_s1_pc1centers=3, pred_s1_pc2centers=3,
+                      pred_s2_pc1centers=3, pred_s2_pc2centers=3, pred_pc1angle_logits=nb2, pred_pc2angle_logits=nb2)
+        arrs = {k: np.empty((B, widths[k]), np.float32) for k in OUTPUT_NAMES}
+        o = _capi.Outputs()
+        for k in OUTPUT_NAMES:
+            setattr(o, k, _fp(arrs[k]))
+        return arrs, o
+
+    def _check_pcs(self, pcs1, pcs2):
+        # the feed is float64 in the reference (provider.py:110-119) and cast to the float32 placeholder
+        p1 = np.ascontiguousarray(pcs1, np.float32)
+        p2 = np.ascontiguousarray(pcs2, np.float32)
+        if p1.ndim != 3 or p1.shape != p2.shape or p1.shape[1] != self.num_points or p1.shape[2] != 3:
+            raise ValueError(f"pcs must be [B,{self.num_points},3] and equal-shaped, got {p1.shape} and {p2.shape}")
+        return p1, p2
+
+    def forward(self, pcs1, pcs2):
+        p1, p2 = self._check_pcs(pcs1, pcs2)
+        arrs, o = self._alloc_outputs(p1.shape[0])
+        self._check(self._lib.alignnet_forward(self._h, _fp(p1), _fp(p2), p1.shape[0], C.byref(o)))
+        return arrs
+
+    def forward_device(self, d_pcs1, d_pcs2, B, d_out_ptrs=None):
+        """Device pointers (ints); d_out_ptrs: dict name -> device pointer, or None to skip copies out."""
+        o = _capi.Outputs()
+        for k in OUTPUT_NAMES:
+            p = (d_out_ptrs or {}).get(k)
+            setattr(o, k, C.cast(C.c_void_p(p), _capi.FP) if p else None)
+        self._check(self._lib.alignnet_forward_device(self._h, C.c_void_p(d_pcs1), C.c_void_p(d_pcs2), B, C.byref(o)))
+
+    def synchronize(self):
+        self._check(self._lib.alignnet_synchronize(self._h))
+
+    # ---- state -----------------------------------------------------------------
+    def state(self):
+        st = _capi.State()
+        self._check(self._lib.alignnet_get_state(self._h, C.byref(st)))
+        return dict(step=st.step, learning_rate=st.learning_rate, bn_decay=st.bn_decay)
+
+    def set_step(self, step):
+        self._check(self._lib.alignnet_set_step(self._h, int(step)))
+
+    # ---- profiling hook ----------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.alignnet_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms, n, tot = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self._lib.alignnet_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(tot), int(reset)))
+        return dict(backbone_ms=ms.value, backbone_launches=n.value, total_ms=tot.value)

@@ -1,0 +1,587 @@
+// C ABI of libalignnet_hip.so (include/alignnet_hip.h): handle lifetime, parameter table,
+// eval-mode forward orchestration.  gfx950 only; no CPU fallback by design -- every entry
+// point fails with an error when HIP is unavailable.
+#include "engine.h"
+#include "kernels_infer.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+using namespace alignnet;
+
+static thread_local std::string g_create_err;
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+      return 1;                                                                                  \
+    }                                                                                            \
+  } while (0)
+
+static int fail(const alignnet_handle* h, const std::string& m)
+{
+  h->err = m;
+  return 1;
+}
+
+// ---------------------------------------------------------------------------------
+// graph description -> layer + parameter tables (models/tp8.py:101-158; names SURVEY 8.A2)
+// ---------------------------------------------------------------------------------
+static const char* kTower[2] = {"siamese", "siamese_1"};
+
+static int add_param(alignnet_handle* h, const std::string& name, int rows, int cols, bool trainable)
+{
+  ParamInfo p{name, rows, cols, trainable, 0};
+  h->params.push_back(p);
+  h->by_name[name] = (int)h->params.size() - 1;
+  return (int)h->params.size() - 1;
+}
+
+static void add_layer(alignnet_handle* h, const std::string& name, int cin, int cout, bool bn, bool siamese, bool conv,
+                      bool first_conv, int fan_in, int fan_out)
+{
+  Layer L;
+  L.name = name; L.cin = cin; L.cout = cout; L.bn = bn; L.siamese = siamese; L.conv = conv; L.first_conv = first_conv;
+  L.fan_in = fan_in; L.fan_out = fan_out;
+  const std::string base = siamese ? "siamese/" + name : name;
+  L.p_w = add_param(h, base + "/weights", cin, cout, true);
+  L.p_b = add_param(h, base + "/biases", 1, cout, true);
+  for (int s = 0; s < 2; ++s) for (int k = 0; k < 4; ++k) L.p_bn[s][k] = -1;
+  if (bn) {
+    static const char* leaf[4] = {"beta", "gamma", "moving_mean", "moving_var"};
+    const int nsets = siamese ? 2 : 1;
+    for (int s = 0; s < nsets; ++s) {
+      const std::string b = siamese ? std::string(kTower[s]) + "/" + name : name;
+      for (int k = 0; k < 4; ++k) L.p_bn[s][k] = add_param(h, b + "/bn/" + leaf[k], 1, cout, k < 2);
+    }
+  }
+  h->layers.push_back(L);
+}
+
+static Stack conv_stack(alignnet_handle* h, const std::string& prefix, const alignnet_widths& w)
+{
+  Stack st{(int)h->layers.size(), w.n};
+  const bool dg = h->cfg.backbone == 1;
+  int cin = dg ? 2 * h->cfg.num_channels : h->cfg.num_channels;
+  for (int i = 0; i < w.n; ++i) {
+    const bool first = (i == 0) && !dg;
+    // utils/tf_util.py:148-152: fan = kh*kw*channels; first PointNet conv has kernel [1, num_channels] on 1 channel
+    const int fi = first ? h->cfg.num_channels : cin, fo = first ? h->cfg.num_channels * w.w[i] : w.w[i];
+    add_layer(h, prefix + "/conv" + std::to_string(i + 1), cin, w.w[i], true, true, true, first, fi, fo);
+    cin = w.w[i];
+  }
+  return st;
+}
+
+static Stack fc_stack(alignnet_handle* h, const std::string& prefix, int cin, const alignnet_widths& w, int out, bool siamese)
+{
+  Stack st{(int)h->layers.size(), w.n + 1};
+  for (int j = 0; j <= w.n; ++j) {
+    const int c = j < w.n ? w.w[j] : out;
+    const std::string nm = (prefix.empty() ? "" : prefix + "/") + "fc" + std::to_string(j + 1);
+    add_layer(h, nm, cin, c, j < w.n, siamese, false, false, cin, c);
+    cin = c;
+  }
+  return st;
+}
+
+static bool check_widths(const alignnet_widths& w, int lo)
+{
+  if (w.n < lo || w.n > ALIGNNET_MAX_WIDTHS) return false;
+  for (int i = 0; i < w.n; ++i) if (w.w[i] <= 0) return false;
+  return true;
+}
+
+extern "C" int alignnet_abi_version(void) { return ALIGNNET_ABI_VERSION; }
+
+extern "C" const char* alignnet_last_error(const alignnet_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int alignnet_create(const alignnet_config* cfg, alignnet_handle** out)
+{
+  if (!cfg || !out) { g_create_err = "alignnet_create: null argument"; return 1; }
+  *out = nullptr;
+  if (cfg->abi_version != ALIGNNET_ABI_VERSION) { g_create_err = "alignnet_create: abi_version mismatch"; return 1; }
+  if (cfg->num_channels != 3) { g_create_err = "alignnet_create: num_channels must be 3 (provider.py:123 feeds xyz)"; return 1; }
+  if (cfg->num_points < 1 || cfg->num_bins < 1) { g_create_err = "alignnet_create: bad num_points/num_bins"; return 1; }
+  if (cfg->backbone != 0 && cfg->backbone != 1) { g_create_err = "alignnet_create: backbone must be 0 (pointnet) or 1 (dgcnn)"; return 1; }
+  if (!check_widths(cfg->s1_conv, 2) || !check_widths(cfg->s2_conv, 2) || !check_widths(cfg->emb_conv, 2) ||
+      !check_widths(cfg->s1_fc, 1) || !check_widths(cfg->s2_fc, 1) || !check_widths(cfg->rem_fc, 1)) {
+    g_create_err = "alignnet_create: width lists need >=2 conv / >=1 fc entries, at most ALIGNNET_MAX_WIDTHS, all > 0";
+    return 1;
+  }
+  if (cfg->s1_conv.n > kMaxConv || cfg->s2_conv.n > kMaxConv || cfg->emb_conv.n > kMaxConv) {
+    g_create_err = "alignnet_create: at most 6 conv layers per backbone"; return 1;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("alignnet_create: no HIP device available (") + hipGetErrorString(e) +
+                   "); this library has no CPU fallback";
+    return 1;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "alignnet_create: device ordinal out of range"; return 1; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return 1; }
+
+  alignnet_handle* h = new alignnet_handle();
+  h->cfg = *cfg;
+  const int nb2 = 2 * cfg->num_bins;
+  h->s1_conv = conv_stack(h, "transformer1/embedding", cfg->s1_conv);
+  h->s1_fc = fc_stack(h, "transformer1/mlp", cfg->s1_conv.w[cfg->s1_conv.n - 1], cfg->s1_fc, 3, true);
+  h->s2_conv = conv_stack(h, "transformer2/embedding", cfg->s2_conv);
+  h->s2_fc = fc_stack(h, "transformer2/mlp", cfg->s2_conv.w[cfg->s2_conv.n - 1], cfg->s2_fc, 3 + nb2, true);
+  h->emb_conv = conv_stack(h, "embedding", cfg->emb_conv);   // scope 'final_embedding' ignored: tp8.py:62-66
+  h->rem_fc = fc_stack(h, "", 2 * cfg->emb_conv.w[cfg->emb_conv.n - 1], cfg->rem_fc, 3 + nb2, false);
+
+  // hidden FC widths must be multiples of 8 (k-group of the MFMA weight image)
+  for (const Layer& L : h->layers)
+    if (!L.first_conv && (L.cin % 8) != 0) {
+      g_create_err = "alignnet_create: layer " + L.name + " has input width " + std::to_string(L.cin) + ", not a multiple of 8";
+      delete h; return 1;
+    }
+
+  // flat parameter buffer: trainable first (one contiguous block = the all-reduce / Adam vector), then EMA
+  size_t off = 0;
+  for (auto& p : h->params) if (p.trainable) { p.offset = off; off += p.count(); }
+  h->n_trainable = off;
+  for (auto& p : h->params) if (!p.trainable) { p.offset = off; off += p.count(); }
+  h->n_total = off;
+
+  size_t wp = 0, ss = 0;
+  for (Layer& L : h->layers) {
+    L.off_ss = ss; ss += 2 * (size_t)L.cout;
+    L.off_wp = wp;
+    if (!L.first_conv) wp += (size_t)((L.cout + 31) / 32) * ((L.cin + 7) / 8) * 256;
+  }
+  h->n_wp = wp; h->n_ss = ss;
+
+  auto bail = [&](const char* what, hipError_t er) {
+    g_create_err = std::string(what) + ": " + hipGetErrorString(er);
+    alignnet_destroy(h);
+    return 1;
+  };
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipMalloc(&h->d_params, h->n_total * sizeof(float))) != hipSuccess) return bail("hipMalloc params", e);
+  if ((e = hipMalloc(&h->d_wp, std::max<size_t>(wp, 1) * sizeof(float))) != hipSuccess) return bail("hipMalloc wp", e);
+  if ((e = hipMalloc(&h->d_scale, ss * sizeof(float))) != hipSuccess) return bail("hipMalloc scale", e);
+  if ((e = hipMalloc(&h->d_shift, ss * sizeof(float))) != hipSuccess) return bail("hipMalloc shift", e);
+  if ((e = hipMemset(h->d_params, 0, h->n_total * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
+  hipEventCreate(&h->ev[0]);
+  hipEventCreate(&h->ev[1]);
+  *out = h;
+  if (alignnet_init_params(h, cfg->seed) != 0) { g_create_err = h->err; alignnet_destroy(h); *out = nullptr; return 1; }
+  return 0;
+}
+
+static void free_ws(alignnet_handle* h)
+{
+  for (int t = 0; t < 2; ++t) if (h->ws.d_pcs[t]) { hipFree(h->ws.d_pcs[t]); h->ws.d_pcs[t] = nullptr; }
+  if (h->ws.d_all) { hipFree(h->ws.d_all); h->ws.d_all = nullptr; }
+  h->ws.cap = 0;
+}
+
+extern "C" void alignnet_destroy(alignnet_handle* h)
+{
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_ws(h);
+  for (auto& pr : h->prof_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (auto& pr : h->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  if (h->ev[0]) hipEventDestroy(h->ev[0]);
+  if (h->ev[1]) hipEventDestroy(h->ev[1]);
+  if (h->d_params) hipFree(h->d_params);
+  if (h->d_wp) hipFree(h->d_wp);
+  if (h->d_scale) hipFree(h->d_scale);
+  if (h->d_shift) hipFree(h->d_shift);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// ---------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------
+extern "C" int alignnet_init_params(alignnet_handle* h, uint64_t seed)
+{
+  if (!h) return 1;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::vector<float> host(h->n_total, 0.f);
+  std::mt19937_64 rng(seed);
+  for (const Layer& L : h->layers) {
+    // tf.contrib.layers.xavier_initializer(): uniform(-limit, limit), limit = sqrt(6/(fan_in+fan_out))
+    const float limit = std::sqrt(6.0f / (float)(L.fan_in + L.fan_out));
+    std::uniform_real_distribution<float> U(-limit, limit);
+    const ParamInfo& w = h->params[L.p_w];
+    for (size_t i = 0; i < w.count(); ++i) host[w.offset + i] = U(rng);
+    // biases 0 (tf_util.py:159), beta 0, gamma 1 (tf_util.py:470-473), EMA shadows 0
+    for (int s = 0; s < 2; ++s)
+      if (L.p_bn[s][1] >= 0) {
+        const ParamInfo& g = h->params[L.p_bn[s][1]];
+        for (size_t i = 0; i < g.count(); ++i) host[g.offset + i] = 1.f;
+      }
+  }
+  HIP_TRY(h, hipMemcpy(h->d_params, host.data(), h->n_total * sizeof(float), hipMemcpyHostToDevice));
+  h->folded = false;
+  return 0;
+}
+
+extern "C" int alignnet_num_params(const alignnet_handle* h) { return h ? (int)h->params.size() : -1; }
+
+extern "C" int alignnet_param_info(const alignnet_handle* h, int index, const char** name, int32_t* rows, int32_t* cols,
+                                   int32_t* trainable)
+{
+  if (!h) return 1;
+  if (index < 0 || index >= (int)h->params.size()) return fail(h, "alignnet_param_info: index out of range");
+  const ParamInfo& p = h->params[index];
+  if (name) *name = p.name.c_str();
+  if (rows) *rows = p.rows;
+  if (cols) *cols = p.cols;
+  if (trainable) *trainable = p.trainable;
+  return 0;
+}
+
+static const ParamInfo* find_param(alignnet_handle* h, const char* name, size_t count, const char* who)
+{
+  if (!name) { h->err = std::string(who) + ": null name"; return nullptr; }
+  auto it = h->by_name.find(name);
+  if (it == h->by_name.end()) { h->err = std::string(who) + ": unknown variable '" + name + "'"; return nullptr; }
+  const ParamInfo& p = h->params[it->second];
+  if (p.count() != count) {
+    h->err = std::string(who) + ": '" + name + "' has " + std::to_string(p.count()) + " elements, caller passed " + std::to_string(count);
+    return nullptr;
+  }
+  return &p;
+}
+
+extern "C" int alignnet_get_param(alignnet_handle* h, const char* name, float* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!dst) return fail(h, "alignnet_get_param: null dst");
+  const ParamInfo* p = find_param(h, name, count, "alignnet_get_param");
+  if (!p) return 1;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(dst, h->d_params + p->offset, count * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int alignnet_set_param(alignnet_handle* h, const char* name, const float* src, size_t count)
+{
+  if (!h) return 1;
+  if (!src) return fail(h, "alignnet_set_param: null src");
+  const ParamInfo* p = find_param(h, name, count, "alignnet_set_param");
+  if (!p) return 1;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(h->d_params + p->offset, src, count * sizeof(float), hipMemcpyHostToDevice));
+  h->folded = false;
+  return 0;
+}
+
+// eval-mode preparation: BN fold + MFMA weight images, re-done whenever a variable changed
+static int fold_for_eval(alignnet_handle* h)
+{
+  if (h->folded) return 0;
+  for (const Layer& L : h->layers) {
+    const float* bias = h->d_params + h->params[L.p_b].offset;
+    for (int s = 0; s < 2; ++s) {
+      const int src = (L.bn && L.p_bn[s][0] < 0) ? 0 : s;   // single-set layers replicate set 0
+      const float *beta = nullptr, *gamma = nullptr, *mean = nullptr, *var = nullptr;
+      if (L.bn) {
+        beta = h->d_params + h->params[L.p_bn[src][0]].offset;
+        gamma = h->d_params + h->params[L.p_bn[src][1]].offset;
+        mean = h->d_params + h->params[L.p_bn[src][2]].offset;
+        var = h->d_params + h->params[L.p_bn[src][3]].offset;
+      }
+      hipLaunchKernelGGL(fold_bn_kernel, dim3((L.cout + 255) / 256), dim3(256), 0, h->stream, bias, beta, gamma, mean, var,
+                         L.cout, h->d_scale + L.off_ss + (size_t)s * L.cout, h->d_shift + L.off_ss + (size_t)s * L.cout);
+    }
+    if (!L.first_conv) {
+      const size_t total = (size_t)((L.cout + 31) / 32) * ((L.cin + 7) / 8) * 256;
+      hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                         h->stream, h->d_params + h->params[L.p_w].offset, L.cin, L.cout, h->d_wp + L.off_wp);
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  h->folded = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------
+static int max_fc_hidden(const alignnet_handle* h)
+{
+  int m = 8;
+  for (const Layer& L : h->layers) if (!L.conv) m = std::max(m, L.cout);
+  return m;
+}
+
+static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
+{
+  Workspace& w = h->ws;
+  const int N = h->cfg.num_points;
+  if (B > w.cap) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_ws(h);
+    const int nb2 = 2 * h->cfg.num_bins;
+    const int C1 = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
+    const int C2 = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout;
+    const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
+    const int H = max_fc_hidden(h);
+    const size_t B2 = 2 * (size_t)B;
+    auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    size_t tot = 0;
+    const size_t o_xform = tot; tot += al(B2 * 12);
+    const size_t o_cm = tot; tot += al(B2 * 3);
+    const size_t o_s1c = tot; tot += al(B2 * 3);
+    const size_t o_s2c = tot; tot += al(B2 * 3);
+    const size_t o_theta = tot; tot += al(B2);
+    const size_t o_cls = tot; tot += al(B2);
+    const size_t o_p1 = tot; tot += al(B2 * C1);
+    const size_t o_p2 = tot; tot += al(B2 * C2);
+    const size_t o_emb = tot; tot += al(B2 * CE);
+    const size_t o_ha = tot; tot += al(B2 * H);
+    const size_t o_hb = tot; tot += al(B2 * H);
+    const size_t o_o1 = tot; tot += al(B2 * 3);
+    const size_t o_o2 = tot; tot += al(B2 * (3 + nb2));
+    const size_t o_o3 = tot; tot += al((size_t)B * (3 + nb2));
+    size_t o_out[8];
+    const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+    for (int i = 0; i < 8; ++i) { o_out[i] = tot; tot += al((size_t)B * widths[i]); }
+    HIP_TRY(h, hipMalloc(&w.d_all, tot * sizeof(float)));
+    float* base = w.d_all;
+    w.xform = base + o_xform; w.center_mean = base + o_cm; w.s1c = base + o_s1c; w.s2c = base + o_s2c;
+    w.theta = base + o_theta; w.cls = reinterpret_cast<int*>(base + o_cls);
+    w.pool1 = base + o_p1; w.pool2 = base + o_p2; w.emb = base + o_emb;
+    w.hid_a = base + o_ha; w.hid_b = base + o_hb;
+    w.o1 = base + o_o1; w.o2 = base + o_o2; w.o3 = base + o_o3;
+    for (int i = 0; i < 8; ++i) w.outs[i] = base + o_out[i];
+    w.cap = B;
+  }
+  if (need_inputs && !w.d_pcs[0]) {
+    for (int t = 0; t < 2; ++t) HIP_TRY(h, hipMalloc(&w.d_pcs[t], (size_t)w.cap * N * 3 * sizeof(float)));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+static size_t backbone_lds_bytes(const alignnet_handle* h, const Stack& st, int ld[2])
+{
+  int w[2] = {8, 8};
+  for (int i = 0; i < st.n - 1; ++i) w[i & 1] = std::max(w[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
+  ld[0] = w[0] + 4; ld[1] = w[1] + 4;
+  return ((size_t)kTilePts * 4 + (size_t)kTilePts * (ld[0] + ld[1])) * sizeof(float);
+}
+
+static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, const float* p2, int B, float* pooled,
+                        long tower_stride, long row_stride, size_t pooled_floats)
+{
+  BackboneArgs a;
+  a.pcs[0] = p1; a.pcs[1] = p2; a.xform = h->ws.xform; a.pooled = pooled;
+  a.tower_stride = tower_stride; a.row_stride = row_stride;
+  a.B = B; a.N = h->cfg.num_points; a.nlayers = st.n;
+  const size_t lds = backbone_lds_bytes(h, st, a.ld);
+  if (lds > 160 * 1024) return fail(h, "backbone hidden widths need more than 160 KiB of LDS per 128-point tile");
+  for (int i = 0; i < st.n; ++i) {
+    const Layer& L = h->layers[st.first + i];
+    a.L[i].w = L.first_conv ? h->d_params + h->params[L.p_w].offset : h->d_wp + L.off_wp;
+    a.L[i].scale = h->d_scale + L.off_ss;
+    a.L[i].shift = h->d_shift + L.off_ss;
+    a.L[i].cin = L.cin; a.L[i].cout = L.cout;
+  }
+  HIP_TRY(h, hipMemsetAsync(pooled, 0, pooled_floats * sizeof(float), h->stream));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid((a.N + kTilePts - 1) / kTilePts, 2 * B);
+  std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
+  if (h->prof) {
+    if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
+    else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
+    hipEventRecord(evp.first, h->stream);
+  }
+  hipLaunchKernelGGL(pointnet_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+  if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+static int run_fc(alignnet_handle* h, const Layer& L, const float* in, long ldin, float* out, long ldout, int M,
+                  int rows_per_set, bool relu)
+{
+  FcArgs a;
+  a.in = in; a.ldin = ldin; a.wp = h->d_wp + L.off_wp; a.scale = h->d_scale + L.off_ss; a.shift = h->d_shift + L.off_ss;
+  a.out = out; a.ldout = ldout; a.M = M; a.K = L.cin; a.Nout = L.cout; a.relu = relu; a.rows_per_set = rows_per_set;
+  hipLaunchKernelGGL(fc_mfma, dim3((L.cout + 31) / 32, (M + 31) / 32), dim3(256), 0, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// head MLP (models/tp8.py:75-82) in eval mode: dropout is the identity (tf_util.py:571-574)
+static int run_head(alignnet_handle* h, const Stack& st, const float* in, long ldin, float* out, long ldout, int M, int rows_per_set)
+{
+  const float* cur = in; long ldc = ldin;
+  float* pp[2] = {h->ws.hid_a, h->ws.hid_b};
+  for (int j = 0; j < st.n; ++j) {
+    const Layer& L = h->layers[st.first + j];
+    const bool last = j == st.n - 1;
+    float* dst = last ? out : pp[j & 1];
+    const long ldd = last ? ldout : L.cout;
+    if (run_fc(h, L, cur, ldc, dst, ldd, M, rows_per_set, !last)) return 1;
+    cur = dst; ldc = ldd;
+  }
+  return 0;
+}
+
+static int forward_device(alignnet_handle* h, const float* p1, const float* p2, int B, float* const outs[8])
+{
+  if (h->cfg.backbone != 0) return fail(h, "alignnet_forward: dgcnn backbone is not implemented in this build");
+  if (fold_for_eval(h)) return 1;
+  Workspace& w = h->ws;
+  const int N = h->cfg.num_points, nb = h->cfg.num_bins, nb2 = 2 * nb;
+  const int C1 = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
+  const int C2 = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout;
+  const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
+  const int B2 = 2 * B;
+  if (h->prof) hipEventRecord(h->ev[0], h->stream);
+  hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
+  // stage 1 (tp8.py:108-109)
+  if (run_backbone(h, h->s1_conv, p1, p2, B, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
+  if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B)) return 1;
+  hipLaunchKernelGGL(stage1_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o1, w.center_mean, B, w.s1c,
+                     w.xform, outs[2], outs[3]);
+  // stage 2 (tp8.py:113-125)
+  if (run_backbone(h, h->s2_conv, p1, p2, B, w.pool2, (long)B * C2, C2, (size_t)B2 * C2)) return 1;
+  if (run_head(h, h->s2_fc, w.pool2, C2, w.o2, 3 + nb2, B2, B)) return 1;
+  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o2, 3 + nb2, w.s1c, B, nb, w.s2c,
+                     w.xform, w.theta, w.cls, outs[4], outs[5], outs[6], outs[7]);
+  // stage 3: embedding of the normalised clouds, concat (tp8.py:130,144,153) = row b holds [emb1 | emb2]
+  if (run_backbone(h, h->emb_conv, p1, p2, B, w.emb, CE, 2L * CE, (size_t)B2 * CE)) return 1;
+  if (run_head(h, h->rem_fc, w.emb, 2L * CE, w.o3, 3 + nb2, B, B)) return 1;
+  hipLaunchKernelGGL(final_finish_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, w.o3, 3 + nb2, w.s2c, B, nb, outs[0], outs[1]);
+  if (h->prof) hipEventRecord(h->ev[1], h->stream);
+  HIP_TRY(h, hipGetLastError());
+  h->last_B = B;
+  return 0;
+}
+
+static int drain_profile(alignnet_handle* h)
+{
+  if (!h->prof) return 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (auto& pr : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { h->prof_backbone_ms += ms; h->prof_backbone_launches++; }
+    h->prof_pool.push_back(pr);
+  }
+  h->prof_pending.clear();
+  return 0;
+}
+
+extern "C" int alignnet_forward_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2, int32_t B,
+                                       const alignnet_outputs* d_out)
+{
+  if (!h) return 1;
+  if (!d_pcs1 || !d_pcs2 || !d_out) return fail(h, "alignnet_forward_device: null argument");
+  if (B < 1) return fail(h, "alignnet_forward_device: B must be >= 1");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (ensure_ws(h, B, false)) return 1;
+  float* outs[8] = {d_out->pred_translations, d_out->pred_remaining_angle_logits, d_out->pred_s1_pc1centers,
+                    d_out->pred_s1_pc2centers, d_out->pred_s2_pc1centers, d_out->pred_s2_pc2centers,
+                    d_out->pred_pc1angle_logits, d_out->pred_pc2angle_logits};
+  if (h->prof_pending.size() > 4096 && drain_profile(h)) return 1;
+  return forward_device(h, d_pcs1, d_pcs2, B, outs);
+}
+
+extern "C" int alignnet_forward(alignnet_handle* h, const float* pcs1, const float* pcs2, int32_t B, const alignnet_outputs* out)
+{
+  if (!h) return 1;
+  if (!pcs1 || !pcs2 || !out) return fail(h, "alignnet_forward: null argument");
+  if (B < 1) return fail(h, "alignnet_forward: B must be >= 1");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (ensure_ws(h, B, true)) return 1;
+  Workspace& w = h->ws;
+  const size_t nin = (size_t)B * h->cfg.num_points * 3 * sizeof(float);
+  HIP_TRY(h, hipMemcpyAsync(w.d_pcs[0], pcs1, nin, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(w.d_pcs[1], pcs2, nin, hipMemcpyHostToDevice, h->stream));
+  if (forward_device(h, w.d_pcs[0], w.d_pcs[1], B, w.outs)) return 1;
+  float* host[8] = {out->pred_translations, out->pred_remaining_angle_logits, out->pred_s1_pc1centers, out->pred_s1_pc2centers,
+                    out->pred_s2_pc1centers, out->pred_s2_pc2centers, out->pred_pc1angle_logits, out->pred_pc2angle_logits};
+  const int nb2 = 2 * h->cfg.num_bins;
+  const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+  for (int i = 0; i < 8; ++i)
+    if (host[i]) HIP_TRY(h, hipMemcpyAsync(host[i], w.outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return drain_profile(h);
+}
+
+extern "C" int alignnet_synchronize(alignnet_handle* h)
+{
+  if (!h) return 1;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// profiling hook (bench.py roofline leg)
+// ---------------------------------------------------------------------------------
+extern "C" int alignnet_profile_enable(alignnet_handle* h, int32_t on)
+{
+  if (!h) return 1;
+  if (drain_profile(h)) return 1;
+  h->prof = on != 0;
+  return 0;
+}
+
+extern "C" int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches, double* total_ms,
+                                     int32_t reset)
+{
+  if (!h) return 1;
+  if (drain_profile(h)) return 1;
+  if (backbone_ms) *backbone_ms = h->prof_backbone_ms;
+  if (backbone_launches) *backbone_launches = h->prof_backbone_launches;
+  if (total_ms) *total_ms = h->prof_total_ms;
+  if (reset) { h->prof_backbone_ms = 0; h->prof_total_ms = 0; h->prof_backbone_launches = 0; }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// schedules (train.py:133-174)
+// ---------------------------------------------------------------------------------
+static double staircase(double base, double gstep, double decay_steps, double rate)
+{
+  return base * std::pow(rate, std::floor(gstep / decay_steps));
+}
+
+extern "C" int alignnet_get_state(alignnet_handle* h, alignnet_state* st)
+{
+  if (!h || !st) return 1;
+  const alignnet_config& c = h->cfg;
+  const double bs = c.batch_size > 0 ? c.batch_size : 1;
+  const double per_epoch = bs * (double)(c.ntrain / (c.batch_size > 0 ? c.batch_size : 1));
+  const double lr_ds = (double)c.lr_step * (c.lr_per_epoch ? per_epoch : 1.0);
+  const double bn_ds = (double)c.bn_step * (c.bn_per_epoch ? per_epoch : 1.0);
+  const double g = (double)h->step * bs;
+  st->step = h->step;
+  st->learning_rate = (float)std::max(lr_ds > 0 ? staircase(c.learning_rate, g, lr_ds, c.lr_rate) : (double)c.learning_rate, 1e-5);
+  st->bn_decay = (float)std::min((double)c.bn_clip, 1.0 - (bn_ds > 0 ? staircase(c.bn_init, g, bn_ds, c.bn_rate) : (double)c.bn_init));
+  return 0;
+}
+
+extern "C" int alignnet_set_step(alignnet_handle* h, int64_t step)
+{
+  if (!h) return 1;
+  if (step < 0) return fail(h, "alignnet_set_step: negative step");
+  h->step = step;
+  return 0;
+}

@@ -1,0 +1,74 @@
+// Host-side engine state behind the opaque C handle (include/alignnet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/alignnet_hip.h"
+
+namespace alignnet {
+
+struct ParamInfo {
+  std::string name;
+  int rows, cols;
+  bool trainable;
+  size_t offset;   // floats into d_params
+  size_t count() const { return (size_t)rows * cols; }
+};
+
+// One conv / fc layer of the graph (models/tp8.py:101-158 construction order).
+struct Layer {
+  std::string name;      // scope path below the tower prefix, e.g. "transformer1/embedding/conv1"
+  int cin, cout;
+  bool bn, siamese, conv, first_conv;
+  int fan_in, fan_out;
+  int p_w, p_b;          // indices into params
+  int p_bn[2][4];        // [set][beta,gamma,moving_mean,moving_var]; -1 when absent
+  size_t off_wp;         // packed MFMA weight image (floats into d_wp); first conv: unused
+  size_t off_ss;         // scale/shift [2][cout] (floats into d_scale/d_shift)
+};
+
+struct Stack { int first, n; };   // range of layers
+
+struct Workspace {
+  int cap = 0;                     // pairs
+  float* d_pcs[2] = {nullptr, nullptr};
+  float* d_all = nullptr;          // everything else, carved below
+  float *xform, *center_mean, *s1c, *s2c, *theta;
+  int* cls;
+  float *pool1, *pool2, *emb;      // [2B][C1], [2B][C2], [B][2*Cemb]
+  float *hid_a, *hid_b;            // head hidden activations
+  float *o1, *o2, *o3;             // head outputs [2B][3], [2B][3+2nb], [B][3+2nb]
+  float* outs[8];                  // device copies of the 8 prediction tensors
+};
+
+}  // namespace alignnet
+
+struct alignnet_handle {
+  alignnet_config cfg;
+  std::vector<alignnet::Layer> layers;
+  alignnet::Stack s1_conv, s1_fc, s2_conv, s2_fc, emb_conv, rem_fc;
+  std::vector<alignnet::ParamInfo> params;
+  std::map<std::string, int> by_name;
+  size_t n_trainable = 0, n_total = 0;
+  float* d_params = nullptr;       // [trainable | EMA shadows]
+  float* d_wp = nullptr;
+  float* d_scale = nullptr;
+  float* d_shift = nullptr;
+  size_t n_wp = 0, n_ss = 0;
+  bool folded = false;             // eval-mode scale/shift + packed weights are current
+  alignnet::Workspace ws;
+  hipStream_t stream = nullptr;
+  int64_t step = 0;
+  int last_B = 0;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  double prof_backbone_ms = 0, prof_total_ms = 0;
+  int64_t prof_backbone_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  mutable std::string err;
+};

@@ -1,0 +1,390 @@
+// Inference kernels of the AlignNet-3D tp8 engine, written for gfx950 (CDNA4) only.
+//
+//   pointnet_fused   models/tp8.py:49-59 (+ the re-centre / rotate prologue of
+//                    :106,113,122-127): shared per-point MLP + max over points, fused.
+//   fc_mfma          models/tp8.py:75-82 via utils/tf_util.py:311-347: head MLP layers.
+//   centroid/finish  models/tp8.py:104,109,117-125,155-156 and :294-301 (yaw decode).
+//
+// BatchNorm in eval mode is a fixed per-channel affine; it is applied in the
+// accumulator epilogue as  relu(acc * scale + shift)  with
+//   scale = gamma * rsqrt(moving_var + 1e-3),  shift = (bias - moving_mean) * scale + beta
+// (utils/tf_util.py:488-491), one (scale, shift) pair PER TOWER because beta/gamma and
+// the EMA shadows are per tower while conv/fc weights are shared.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace alignnet {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kTilePts = 128;     // points per workgroup
+constexpr int kWaves = 8;         // 512 threads, two waves per SIMD
+constexpr int kMaxConv = 6;
+constexpr float kBnEps = 1e-3f;   // utils/tf_util.py:491
+
+// ---------------------------------------------------------------------------------
+// Weight image for the MFMA layers.  v_mfma_f32_32x32x2_f32 takes, per lane l,
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  A k-group is 8 consecutive k;
+// lane (j, half) keeps k = 8*kg + 4*half + s (s = 0..3) in one float4, so one
+// coalesced 1 KiB load feeds four MFMAs:
+//   Wp[((ct * KG + kg) * 64 + lane) * 4 + s] = W[8*kg + 4*(lane>>5) + s][32*ct + (lane&31)]
+// Out-of-range k / channel entries are zero.
+// ---------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, float* __restrict__ Wp)
+{
+  const int KG = (K + 7) >> 3, CT = (C + 31) >> 5;
+  const size_t total = (size_t)CT * KG * 256;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int s = idx & 3, lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int kg = t % KG, ct = t / KG;
+    const int k = 8 * kg + 4 * (lane >> 5) + s, c = 32 * ct + (lane & 31);
+    Wp[idx] = (k < K && c < C) ? W[(size_t)k * C + c] : 0.f;
+  }
+}
+
+// scale/shift for one layer and one BN set; bn == nullptr -> plain bias.
+__global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
+                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                               const float* __restrict__ var, int C, float* __restrict__ scale,
+                               float* __restrict__ shift)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (beta) {
+    const float inv = gamma[c] * (1.0f / sqrtf(var[c] + kBnEps));
+    scale[c] = inv;
+    shift[c] = (bias[c] - mean[c]) * inv + beta[c];
+  } else {
+    scale[c] = 1.f;
+    shift[c] = bias[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// centroid: models/tp8.py:104.  One workgroup per cloud.  Writes the stage-1 frame
+// (centre = mean, rotation = identity) and keeps the mean for tp8.py:109.
+// xform layout per cloud: c[3], R[9] row-major (p' = (p - c) @ R).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                      int B, int N, float* __restrict__ xform,
+                                                      float* __restrict__ center_mean)
+{
+  const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B;
+  const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    s[0] += pc[n * 3 + 0];
+    s[1] += pc[n * 3 + 1];
+    s[2] += pc[n * 3 + 2];
+  }
+  __shared__ float red[4][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float v = s[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float m = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)N;
+    center_mean[cloud * 3 + threadIdx.x] = m;
+    xform[cloud * 12 + threadIdx.x] = m;
+  }
+  if (threadIdx.x < 9) xform[cloud * 12 + 3 + threadIdx.x] = (threadIdx.x % 4 == 0) ? 1.f : 0.f;
+}
+
+// ---------------------------------------------------------------------------------
+// pointnet_fused
+// ---------------------------------------------------------------------------------
+struct ConvLayerDev {
+  const float* w;      // layer 0: [3][cout] row-major; others: packed image (see above)
+  const float* scale;  // [2][cout]  (tower-major)
+  const float* shift;  // [2][cout]
+  int cin, cout;
+};
+
+struct BackboneArgs {
+  const float* pcs[2];   // [B][N][3] per tower
+  const float* xform;    // [2B][12]
+  float* pooled;         // zero-initialised; element (tower, b, c) at tower*tower_stride + b*row_stride + c
+  long tower_stride, row_stride;
+  int B, N, nlayers;
+  int ld[2];             // leading dimensions (floats) of the two LDS activation buffers
+  ConvLayerDev L[kMaxConv];
+};
+
+template <int MR>
+__device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp,
+                                          int KG, int lane, f32x16 (&acc)[MR])
+{
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
+  f32x4 bcur = Wp[lane];
+  for (int kg = 0; kg < KG; ++kg) {
+    const f32x4 bnext = Wp[(kg + 1 < KG ? kg + 1 : kg) * 64 + lane];
+    f32x4 av[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * lda + kg * 8);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bcur[s], acc[m], 0, 0, 0);
+    bcur = bnext;
+  }
+}
+
+// hidden layer: out[row][col] = relu(acc*scale+shift) for this item's MR row tiles x one channel tile
+template <int MR>
+__device__ __forceinline__ void hidden_item(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
+                                            const ConvLayerDev& L, int tower, int ct, int rg, int lane)
+{
+  const int KG = (L.cin + 7) >> 3;
+  f32x16 acc[MR];
+  mfma_rows<MR>(in + rg * MR * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+  const int col = ct * 32 + (lane & 31);
+  const bool live = col < L.cout;
+  const float sc = live ? L.scale[tower * L.cout + col] : 0.f;
+  const float sh = live ? L.shift[tower * L.cout + col] : 0.f;
+  if (col < ldo - 4) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (rg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[row * ldo + col] = fmaxf(fmaf(acc[m][r], sc, sh), 0.f);
+      }
+  }
+}
+
+template <int MR>
+__device__ __forceinline__ void hidden_layer(const float* in, int ldi, float* out, int ldo, const ConvLayerDev& L,
+                                             int tower, int wave, int lane)
+{
+  constexpr int RG = (kTilePts / 32) / MR;
+  const int CT = (L.cout + 31) >> 5;
+  for (int item = wave; item < CT * RG; item += kWaves) hidden_item<MR>(in, ldi, out, ldo, L, tower, item / RG, item % RG, lane);
+}
+
+__global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.y, tile = blockIdx.x;
+  const int tower = cloud >= a.B, b = cloud - tower * a.B;
+  float* xs = smem;                       // [kTilePts][4]
+  float* buf[2] = {smem + kTilePts * 4, smem + kTilePts * 4 + kTilePts * a.ld[0]};
+
+  // ---- prologue: p' = (p - c) @ R   (models/tp8.py:106,113,122,127) ----
+  if (tid < kTilePts) {
+    const int n = min(tile * kTilePts + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
+    const float* p = a.pcs[tower] + ((size_t)b * a.N + n) * 3;
+    const float* xf = a.xform + (size_t)cloud * 12;
+    const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+    xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+    xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+    xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+  }
+  __syncthreads();
+
+  // ---- layer 0: K = 3 lift on the VALU (not a dense GEMM) ----
+  {
+    const ConvLayerDev& L = a.L[0];
+    float* out = buf[0];
+    const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;   // a 32-lane group writes one row, 32 consecutive channels
+    for (int c = c0; c < ldo - 4; c += 32) {
+      const bool live = c < L.cout;
+      const float w0 = live ? L.w[c] : 0.f, w1 = live ? L.w[L.cout + c] : 0.f, w2 = live ? L.w[2 * L.cout + c] : 0.f;
+      const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < kTilePts / 16; ++rr) {
+        const int row = rr * 16 + r0;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float acc = fmaf(p[2], w2, fmaf(p[1], w1, p[0] * w0));
+        out[row * ldo + c] = fmaxf(fmaf(acc, sc, sh), 0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- hidden MFMA layers 1 .. nlayers-2 ----
+  for (int l = 1; l < a.nlayers - 1; ++l) {
+    const ConvLayerDev& L = a.L[l];
+    const int CT = (L.cout + 31) >> 5;
+    const float* in = buf[(l - 1) & 1];
+    float* out = buf[l & 1];
+    const int ldi = a.ld[(l - 1) & 1], ldo = a.ld[l & 1];
+    if (CT >= kWaves) hidden_layer<4>(in, ldi, out, ldo, L, tower, wave, lane);
+    else if (CT * 2 >= kWaves) hidden_layer<2>(in, ldi, out, ldo, L, tower, wave, lane);
+    else hidden_layer<1>(in, ldi, out, ldo, L, tower, wave, lane);
+    __syncthreads();
+  }
+
+  // ---- last layer + max over the tile's points (utils/tf_util.py:350-373) ----
+  {
+    const int l = a.nlayers - 1;
+    const ConvLayerDev& L = a.L[l];
+    const float* in = buf[(l - 1) & 1];
+    const int ldi = a.ld[(l - 1) & 1];
+    const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
+    float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
+    for (int ct = wave; ct < CT; ct += kWaves) {
+      f32x16 acc[4];
+      mfma_rows<4>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < L.cout;
+      const float sc = live ? L.scale[tower * L.cout + col] : 0.f;
+      const float sh = live ? L.shift[tower * L.cout + col] : 0.f;
+      float mx = 0.f;   // relu folded into the max: max_n relu(v_n) = max(0, max_n v_n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      // values are >= 0, so the IEEE bit pattern is monotone as a signed int
+      if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// fc_mfma: out[M][Nout] = act((in[M][K] @ W[K][Nout]) * scale + shift), one 32x32 output
+// tile per workgroup, the four waves split K and reduce through LDS.
+// rows_per_set: rows [0, rows_per_set) use BN set 0, the rest set 1 (siamese heads).
+// ---------------------------------------------------------------------------------
+struct FcArgs {
+  const float* in; long ldin;
+  const float* wp; const float* scale; const float* shift;
+  float* out; long ldout;
+  int M, K, Nout, relu, rows_per_set;
+};
+
+__global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
+{
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ct = blockIdx.x, mt = blockIdx.y;
+  const int KG = a.K >> 3;   // K % 8 == 0 checked on the host
+  const int row_in = min(mt * 32 + (lane & 31), a.M - 1);
+  const float* arow = a.in + (size_t)row_in * a.ldin + (lane >> 5) * 4;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp) + (size_t)ct * KG * 64 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int per = (KG + 3) >> 2, k0 = wave * per, k1 = min(KG, k0 + per);
+#pragma unroll 2
+  for (int kg = k0; kg < k1; ++kg) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8);
+    const f32x4 bv = wp[(size_t)kg * 64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int col = ct * 32 + (lane & 31);
+    if (col < a.Nout) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < a.M) {
+          const int set = row >= a.rows_per_set;
+          float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+          v = fmaf(v, a.scale[set * a.Nout + col], a.shift[set * a.Nout + col]);
+          a.out[(size_t)row * a.ldout + col] = a.relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// stage finish kernels (one thread per cloud / pair)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float floor_modf(float x, float y)   // tf.mod
+{
+  float r = fmodf(x, y);
+  if (r != 0.f && ((r < 0.f) != (y < 0.f))) r += y;
+  return r;
+}
+
+// models/tp8.py:109: s1 = head + center_mean; next frame = (s1, I)
+__global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
+                                     float* __restrict__ s1c, float* __restrict__ xform,
+                                     float* __restrict__ out_c1, float* __restrict__ out_c2)
+{
+  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloud >= 2 * B) return;
+  const int tower = cloud >= B, b = cloud - tower * B;
+  float* oc = tower ? out_c2 : out_c1;
+  for (int d = 0; d < 3; ++d) {
+    const float v = o1[cloud * 3 + d] + center_mean[cloud * 3 + d];
+    s1c[cloud * 3 + d] = v;
+    xform[cloud * 12 + d] = v;
+    if (oc) oc[b * 3 + d] = v;
+  }
+  for (int i = 0; i < 9; ++i) xform[cloud * 12 + 3 + i] = (i % 4 == 0) ? 1.f : 0.f;
+}
+
+// models/tp8.py:117-125 + :294-301,202-212: s2 centre, logits, in-graph yaw decode,
+// R = rot_z(-theta) (tp8.py:26-27), next frame = (s2, R)
+__global__ void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
+                                     float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
+                                     int* __restrict__ cls_out,
+                                     float* __restrict__ out_c1, float* __restrict__ out_c2,
+                                     float* __restrict__ out_l1, float* __restrict__ out_l2)
+{
+  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloud >= 2 * B) return;
+  const int tower = cloud >= B, b = cloud - tower * B;
+  const float* o = o2 + (size_t)cloud * ldo;
+  float* oc = tower ? out_c2 : out_c1;
+  float* ol = tower ? out_l2 : out_l1;
+  for (int d = 0; d < 3; ++d) {
+    const float v = o[d] + s1c[cloud * 3 + d];
+    s2c[cloud * 3 + d] = v;
+    xform[cloud * 12 + d] = v;
+    if (oc) oc[b * 3 + d] = v;
+  }
+  const float* lg = o + 3;
+  int cls = 0;
+  float best = lg[0];
+  for (int i = 1; i < nb; ++i)
+    if (lg[i] > best) { best = lg[i]; cls = i; }   // first maximum wins, as tf.argmax
+  if (ol) for (int i = 0; i < 2 * nb; ++i) ol[(size_t)b * 2 * nb + i] = lg[i];
+  const float pi = 3.14159274101257324f;   // np.float32(np.pi), tf.constant(np.pi)
+  const float res = lg[nb + cls] * (pi / (float)nb);
+  const float apc = 2.0f * pi / (float)nb;
+  const float ang = (float)cls * apc + res;
+  const float th = floor_modf(ang + pi, 2.0f * pi) - pi;
+  if (theta_out) theta_out[cloud] = th;
+  if (cls_out) cls_out[cloud] = cls;
+  const float a = -th, c = cosf(a), s = sinf(a);
+  float* R = xform + cloud * 12 + 3;
+  R[0] = c;  R[1] = -s; R[2] = 0.f;
+  R[3] = s;  R[4] = c;  R[5] = 0.f;
+  R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+}
+
+// models/tp8.py:155-156
+__global__ void final_finish_kernel(const float* __restrict__ net, int ldn, const float* __restrict__ s2c, int B, int nb,
+                                    float* __restrict__ out_t, float* __restrict__ out_l)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* o = net + (size_t)b * ldn;
+  if (out_t) for (int d = 0; d < 3; ++d) out_t[b * 3 + d] = o[d] + (s2c[(B + b) * 3 + d] - s2c[b * 3 + d]);
+  if (out_l) for (int i = 0; i < 2 * nb; ++i) out_l[(size_t)b * 2 * nb + i] = o[3 + i];
+}
+
+}  // namespace alignnet

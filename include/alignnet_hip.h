@@ -1,0 +1,189 @@
+/*
+ * alignnet_hip.h -- C ABI of libalignnet_hip.so, the MI355X (gfx950) engine for the
+ * AlignNet-3D `tp8` network.
+ *
+ * The reference (grossjohannes/AlignNet-3D) has no FFI: the seam its hot path sits
+ * behind is the Python module API consumed by train.py plus tf.Session.run.  Each
+ * entry point below names the reference call site it replaces (paths relative to the
+ * reference repository root).  Plain C types only; row-major float32 everywhere.
+ *
+ * Ownership: the caller owns every buffer it passes in; the library owns device
+ * memory, parameters and optimiser state behind the opaque handle.
+ * Errors: every call returns 0 on success, non-zero on failure; the message is
+ * available from alignnet_last_error().  (The reference asserts / raises and aborts:
+ * train.py:55,143,216,251 -- the Python wrapper raises on a non-zero status.)
+ * Threading: one handle per GPU/process, calls on a handle are serialised by the
+ * caller (the reference issues one blocking sess.run at a time).
+ */
+#ifndef ALIGNNET_HIP_H
+#define ALIGNNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALIGNNET_MAX_WIDTHS 8
+#define ALIGNNET_ABI_VERSION 1
+
+typedef struct alignnet_handle alignnet_handle;
+
+/* A conv / fc width list as written in the JSON configs (model.options). */
+typedef struct {
+  int32_t n;
+  int32_t w[ALIGNNET_MAX_WIDTHS];
+} alignnet_widths;
+
+/* Everything models/tp8.py reads from `cfg` at graph-build time (tp8.py:10,14,98,154,
+ * 307-308,318) plus what train.py:133-174,211-217 reads for the schedules/optimiser. */
+typedef struct {
+  int32_t abi_version;   /* must be ALIGNNET_ABI_VERSION */
+  int32_t device;        /* HIP device ordinal (train.py:189 cfg.gpu_index) */
+  int32_t num_points;    /* cfg.model.num_points */
+  int32_t num_channels;  /* cfg.data.num_channels (3) */
+  int32_t num_bins;      /* cfg.model.angles.num_bins */
+  int32_t backbone;      /* 0 = "pointnet", 1 = "dgcnn" (cfg.model.backbone) */
+  alignnet_widths s1_conv, s1_fc;   /* options.s1transformer = [conv, [fc, keep]] */
+  alignnet_widths s2_conv, s2_fc;   /* options.s2transformer */
+  alignnet_widths emb_conv;         /* options.embedding */
+  alignnet_widths rem_fc;           /* options.remaining_transform_prediction[0] */
+  float s1_keep, s2_keep, rem_keep; /* dropout keep_prob; <= 0 means "None" (tp8.py:80) */
+  float angle_factor;               /* options.angle_factor */
+  float early_stage_factor;         /* options.early_stage_factor */
+  int32_t accept_inverted_angle;    /* cfg.model.angles.accept_inverted_angle */
+  /* training (train.py:133-174,211-217) */
+  int32_t batch_size;               /* cfg.training.batch_size (global, drives schedules) */
+  int32_t ntrain;                   /* cfg.data.ntrain */
+  float learning_rate;              /* cfg.training.learning_rate */
+  int32_t lr_step;                  /* lr_extension.step */
+  float lr_rate;                    /* lr_extension.rate */
+  int32_t lr_per_epoch;             /* lr_extension.per == "epoch" */
+  float bn_init, bn_rate, bn_clip;  /* bn_extension.{init,rate,clip} */
+  int32_t bn_step;                  /* bn_extension.step */
+  int32_t bn_per_epoch;             /* bn_extension.per == "epoch" */
+  int32_t optimizer;                /* 0 = adam, 1 = momentum (train.py:211-216) */
+  float momentum;                   /* cfg.training.optimizer.momentum */
+  uint64_t seed;                    /* dropout / init RNG stream */
+} alignnet_config;
+
+/* The nine prediction tensors tf.Session.run returns in eval (train.py:448) minus the
+ * summary: all float32, caller-allocated, any of them may be NULL to skip it.
+ * B rows each; widths: centres/translations 3, logits 2*num_bins. */
+typedef struct {
+  float* pred_translations;            /* [B,3]   tp8.py:155 */
+  float* pred_remaining_angle_logits;  /* [B,2nb] tp8.py:156 */
+  float* pred_s1_pc1centers;           /* [B,3]   tp8.py:146 */
+  float* pred_s1_pc2centers;           /* [B,3]   tp8.py:147 */
+  float* pred_s2_pc1centers;           /* [B,3]   tp8.py:148 */
+  float* pred_s2_pc2centers;           /* [B,3]   tp8.py:149 */
+  float* pred_pc1angle_logits;         /* [B,2nb] tp8.py:150 */
+  float* pred_pc2angle_logits;         /* [B,2nb] tp8.py:151 */
+} alignnet_outputs;
+
+/* The six label tensors of placeholder_inputs (tp8.py:16-22). */
+typedef struct {
+  const float* translations;  /* [B,3] */
+  const float* rel_angles;    /* [B,1] */
+  const float* pc1_centers;   /* [B,3] */
+  const float* pc2_centers;   /* [B,3] */
+  const float* pc1_angles;    /* [B,1] */
+  const float* pc2_angles;    /* [B,1] */
+} alignnet_labels;
+
+/* The scalars a train-mode sess.run returns (train.py:368) + the 16 summaries of
+ * tp8.py:336-353 in declaration order + the two schedule scalars (train.py:197,210). */
+typedef struct {
+  int64_t step;          /* value of `batch` after the update */
+  float loss;            /* per_transform_loss, tp8.py:334 */
+  float learning_rate;   /* train.py:155 */
+  float bn_decay;        /* train.py:173 */
+  float summaries[16];   /* tp8.py:336-353 */
+} alignnet_step_result;
+
+typedef struct {
+  int64_t step;
+  float learning_rate;
+  float bn_decay;
+} alignnet_state;
+
+/* ---- lifetime: replaces graph construction, train.py:190-227 ------------------ */
+int alignnet_create(const alignnet_config* cfg, alignnet_handle** out);
+void alignnet_destroy(alignnet_handle* h);
+/* Message of the most recent failure on this handle (h may be NULL for create()). */
+const char* alignnet_last_error(const alignnet_handle* h);
+int alignnet_abi_version(void);
+
+/* ---- parameters: replaces sess.run(init) train.py:241 and tf.train.Saver
+ *      get/set of individual variables (train.py:220,252,268,281) ----------------- */
+int alignnet_init_params(alignnet_handle* h, uint64_t seed);   /* utils/tf_util.py:10-49 */
+int alignnet_num_params(const alignnet_handle* h);
+/* name: variable name (DESIGN.md section "variables"); rows*cols floats; trainable flag. */
+int alignnet_param_info(const alignnet_handle* h, int index, const char** name,
+                        int32_t* rows, int32_t* cols, int32_t* trainable);
+int alignnet_get_param(alignnet_handle* h, const char* name, float* dst, size_t count);
+int alignnet_set_param(alignnet_handle* h, const char* name, const float* src, size_t count);
+
+/* ---- inference: replaces the eval sess.run, train.py:447-449 (is_training=False) -- */
+/* Host buffers; any B >= 1 (no padding to a static batch needed, cf. train.py:451-452). */
+int alignnet_forward(alignnet_handle* h, const float* pcs1, const float* pcs2, int32_t B,
+                     const alignnet_outputs* out);
+/* Device buffers already resident in HBM; asynchronous on the handle's stream.
+ * Follow with alignnet_synchronize() before reading the outputs. */
+int alignnet_forward_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2,
+                            int32_t B, const alignnet_outputs* d_out);
+/* Eval-mode loss on the last forward's predictions (train.py:448 `loss` fetch). */
+int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels* labels, int32_t B,
+                       float* loss, float summaries[16]);
+int alignnet_synchronize(alignnet_handle* h);
+
+/* ---- training: replaces the train sess.run, train.py:368 (is_training=True):
+ *      forward with batch statistics, loss, backward, (all-reduce), Adam, EMA, step++ */
+/* dropout_u: optional host array of uniforms [0,1) used for the dropout masks, laid out
+ * [s1 tower0 | s2 tower0 | s1 tower1 | s2 tower1 | pair head], each B x last-hidden-width;
+ * NULL = draw on the device from cfg.seed and the step counter. */
+int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
+                        const alignnet_labels* labels, int32_t B, const float* dropout_u,
+                        alignnet_step_result* result, const alignnet_outputs* out);
+/* Split form used for data-parallel training: forward+backward only (gradients stay on
+ * the device), then the optimiser.  alignnet_grad_buffer exposes the flat gradient
+ * (device pointer, float count) for an external all-reduce when the built-in RCCL
+ * communicator is not used. */
+int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const float* pcs2,
+                                    const alignnet_labels* labels, int32_t B,
+                                    const float* dropout_u, alignnet_step_result* result,
+                                    const alignnet_outputs* out);
+int alignnet_grad_buffer(alignnet_handle* h, float** d_grad, size_t* count);
+int alignnet_apply_gradients(alignnet_handle* h, float grad_scale);
+/* Debug/parity: copy the flat gradient of one variable to the host. */
+int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t count);
+
+/* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
+ *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */
+int alignnet_comm_unique_id(uint8_t id[128]);
+int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
+int alignnet_comm_allreduce_grads(alignnet_handle* h);
+
+/* ---- schedule read-back: sess.run([learning_rate, bn_decay]) train.py:298,
+ *      sess.run(batch) train.py:261,272 */
+int alignnet_get_state(alignnet_handle* h, alignnet_state* st);
+int alignnet_set_step(alignnet_handle* h, int64_t step);
+
+/* ---- checkpoints: saver.save / saver.restore, train.py:252,268,281,317,321.
+ *      Own container format; skip_step mirrors the pre-training restore
+ *      that excludes `batch` (train.py:278-281). */
+int alignnet_save(alignnet_handle* h, const char* path);
+int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_step);
+
+/* ---- measurement hook for bench.py: HIP-event time (ms) of the dominant kernel
+ *      (the fused shared-MLP backbone) accumulated since the last reset, and the
+ *      number of launches, measured on the handle's own stream. */
+int alignnet_profile_enable(alignnet_handle* h, int32_t on);
+int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches,
+                          double* total_ms, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNNET_HIP_H */

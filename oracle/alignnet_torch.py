@@ -1,0 +1,192 @@
+"""CPU oracle #2: torch-CPU autograd restatement of the `tp8` hot path.
+
+TEST INFRASTRUCTURE ONLY (same rules as `oracle/alignnet_ref.py`): never
+imported by the product path.  **parity unpinned** against TensorFlow (absent,
+SURVEY.md 8c); this file exists so that two restatements written separately --
+this one from the reference sources with torch's own primitives
+(`F.batch_norm`, `F.huber_loss`, `F.cross_entropy`, `torch.remainder`), the
+other in NumPy from SURVEY 8.A -- must agree, and so that the analytic backward
+of the HIP path has an autograd reference.
+
+Reference lines followed: models/tp8.py:26-27,49-59,75-158 (forward),
+:173-354 (loss), utils/tf_util.py:112-169,311-373,455-575 (layers),
+train.py:211-217 (Adam).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .alignnet_ref import NetSpec, TOWER_PREFIX, BN_EPS
+
+
+def to_torch(P: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in P.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and not k.endswith(("moving_mean", "moving_var")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+class TorchTp8:
+    """Eager re-statement; `P` is a name->tensor dict using the oracle's names."""
+
+    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor]):
+        self.spec, self.P = spec, P
+        self.ema_updates: Dict[str, torch.Tensor] = {}
+
+    # -- layers ---------------------------------------------------------
+    def _bn(self, z, base, training, decay):
+        P = self.P
+        g, b = P[base + "/gamma"], P[base + "/beta"]
+        if training:
+            # F.batch_norm(training=True) normalises with the biased batch variance,
+            # which is tf.nn.moments' variance (utils/tf_util.py:474).
+            y = F.batch_norm(z, None, None, g, b, True, 0.0, BN_EPS)
+            with torch.no_grad():
+                d = 0.9 if decay is None else decay
+                m = z.mean(0)
+                v = z.var(0, unbiased=False)
+                self.ema_updates[base + "/moving_mean"] = d * P[base + "/moving_mean"] + (1 - d) * m
+                self.ema_updates[base + "/moving_var"] = d * P[base + "/moving_var"] + (1 - d) * v
+            return y
+        return F.batch_norm(z, P[base + "/moving_mean"], P[base + "/moving_var"], g, b, False, 0.0, BN_EPS)
+
+    def _layer(self, x, wbase, bnbase, training, decay, act=True):
+        z = F.linear(x, self.P[wbase + "/weights"].t(), self.P[wbase + "/biases"])
+        if bnbase is not None:
+            z = self._bn(z, bnbase, training, decay)
+        return torch.relu(z) if act else z
+
+    def _pointnet(self, x, scope, widths, tower, training, decay):
+        B, N, _ = x.shape
+        h = x.reshape(B * N, -1)
+        for i in range(len(widths)):
+            nm = f"{scope}/conv{i+1}"
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+        return h.reshape(B, N, -1).amax(dim=1)
+
+    def _dgcnn(self, x, scope, widths, tower, training, decay):
+        B, N, D = x.shape
+        k = self.spec.knn_k
+        with torch.no_grad():
+            xx = (x * x).sum(-1, keepdim=True)
+            adj = xx - 2 * x @ x.transpose(1, 2) + xx.transpose(1, 2)
+            idx = torch.sort(adj, dim=-1, stable=True).indices[..., :k]
+        nbr = torch.gather(x[:, None].expand(B, N, N, D), 2, idx[..., None].expand(B, N, k, D))
+        cen = x[:, :, None, :].expand_as(nbr)
+        h = torch.cat([cen, nbr - cen], -1).reshape(B * N * k, 2 * D)
+        for i in range(len(widths) - 1):
+            nm = f"{scope}/conv{i+1}"
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+        h = h.reshape(B * N, k, -1).amax(dim=1)
+        nm = f"{scope}/conv{len(widths)}"
+        h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+        return h.reshape(B, N, -1).amax(dim=1)
+
+    def _backbone(self, *a):
+        return (self._pointnet if self.spec.backbone == "pointnet" else self._dgcnn)(*a)
+
+    def _mlp(self, x, scope, widths, tower, keep, training, decay, u):
+        h = x
+        for j in range(len(widths) - 1):
+            nm = f"{scope}/fc{j+1}" if scope else f"fc{j+1}"
+            if tower is None:
+                h = self._layer(h, nm, nm + "/bn", training, decay)
+            else:
+                h = self._layer(h, "siamese/" + nm, f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+        if keep is not None and training:
+            h = h / keep * torch.floor(keep + u)
+        nm = f"{scope}/fc{len(widths)}" if scope else f"fc{len(widths)}"
+        return self._layer(h, nm if tower is None else "siamese/" + nm, None, training, decay, act=False)
+
+    # -- decode -----------------------------------------------------------
+    def angles(self, logits):
+        nb = self.spec.num_bins
+        pi = torch.tensor(np.float32(np.pi), dtype=logits.dtype)
+        cls = torch.argmax(logits[:, :nb], dim=1)
+        res = (logits[:, nb:] * (pi / nb)).gather(1, cls[:, None])[:, 0]
+        a = cls.to(logits.dtype) * (2.0 * pi / nb) + res
+        return torch.remainder(a + pi, 2.0 * pi) - pi
+
+    def _tower(self, pcs, tower, training, decay, u):
+        s = self.spec
+        cm = pcs.mean(1)
+        f1 = self._backbone(pcs - cm[:, None], "transformer1/embedding", s.s1_conv, tower, training, decay)
+        s1c = self._mlp(f1, "transformer1/mlp", list(s.s1_fc) + [3], tower, s.s1_keep, training, decay,
+                        None if u is None else u[f"s1_{tower}"]) + cm
+        f2 = self._backbone(pcs - s1c[:, None], "transformer2/embedding", s.s2_conv, tower, training, decay)
+        o2 = self._mlp(f2, "transformer2/mlp", list(s.s2_fc) + [s.out_s2], tower, s.s2_keep, training, decay,
+                       None if u is None else u[f"s2_{tower}"])
+        s2c, lg = o2[:, :3] + s1c, o2[:, 3:]
+        a = -self.angles(lg)
+        c, sn, z, o = torch.cos(a), torch.sin(a), torch.zeros_like(a), torch.ones_like(a)
+        R = torch.stack([c, -sn, z, sn, c, z, z, z, o], -1).reshape(-1, 3, 3)
+        emb = self._backbone(torch.bmm(pcs - s2c[:, None], R), "embedding", s.emb_conv, tower, training, decay)
+        return emb, s1c, s2c, lg
+
+    def forward(self, pcs1, pcs2, training=False, decay=None, u=None):
+        s = self.spec
+        self.ema_updates = {}
+        e1, a1, b1, l1 = self._tower(pcs1, 0, training, decay, u)
+        e2, a2, b2, l2 = self._tower(pcs2, 1, training, decay, u)
+        net = self._mlp(torch.cat([e1, e2], 1), "", list(s.rem_fc) + [s.out_s2], None, s.rem_keep, training, decay,
+                        None if u is None else u["rem"])
+        return {
+            "pred_s1_pc1centers": a1, "pred_s1_pc2centers": a2,
+            "pred_s2_pc1centers": b1, "pred_s2_pc2centers": b2,
+            "pred_pc1angle_logits": l1, "pred_pc2angle_logits": l2,
+            "pred_translations": net[:, :3] + (b2 - b1),
+            "pred_remaining_angle_logits": net[:, 3:],
+        }
+
+    # -- loss ---------------------------------------------------------------
+    def _angle_loss(self, logits, target):
+        nb = self.spec.num_bins
+        twopi = torch.tensor(np.float32(2 * np.pi), dtype=logits.dtype)
+        apc = twopi / nb
+        sh = torch.remainder(torch.remainder(target, twopi) + apc / 2, twopi)
+        cls = (sh / apc).to(torch.int32)
+        res = sh - (cls.to(logits.dtype) * apc + apc / 2)
+        cls0 = cls[:, 0].long()
+        ce = F.cross_entropy(logits[:, :nb], cls0)
+        pick = (logits[:, nb:] * F.one_hot(cls0, nb).to(logits.dtype)).sum(1)  # [B]
+        lab = res / (np.pi / nb)  # [B,1] or [B,B]
+        err = pick - lab  # broadcast to [B,B], as in the reference
+        rl = F.huber_loss(err, torch.zeros_like(err), delta=1.0)
+        return torch.stack([ce + 20.0 * rl, ce, rl])
+
+    def _angle_losses(self, logits, target):
+        a = self._angle_loss(logits, target)
+        if self.spec.accept_inverted_angle:
+            b = self._angle_loss(logits, target + np.pi)
+            return a if bool(a[0] > b[0]) else b
+        return a
+
+    def loss(self, ep, translations, rel_angles, c1, c2, ang1, ang2):
+        s = self.spec
+        hub = lambda e, d: F.huber_loss(e, torch.zeros_like(e), delta=d)
+        s1 = (hub(ep["pred_s1_pc1centers"] - c1, 1.0) + hub(ep["pred_s1_pc2centers"] - c2, 1.0)) / 2
+        s2 = (hub(ep["pred_s2_pc1centers"] - c1, 1.0) + hub(ep["pred_s2_pc2centers"] - c2, 1.0)) / 2
+        la1 = self._angle_losses(ep["pred_pc1angle_logits"], ang1)
+        la2 = self._angle_losses(ep["pred_pc2angle_logits"], ang2)
+        s3t = hub(ep["pred_translations"] - translations, 2.0)
+        p1, p2 = self.angles(ep["pred_pc1angle_logits"]), self.angles(ep["pred_pc2angle_logits"])
+        tgt = (ang2 - ang1) - (p2 - p1)  # [B,1]-[B] -> [B,B]
+        la3 = self._angle_losses(ep["pred_remaining_angle_logits"], tgt)
+        lt = s.early_stage_factor * (s1 + s2) + s3t
+        la = s.early_stage_factor * ((la1[0] + la2[0]) / 2) + la3[0]
+        return (lt + s.angle_factor * la) / translations.shape[0]
+
+
+def tf_adam(w, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    return w - lr_t * m / (v.sqrt() + eps), m, v

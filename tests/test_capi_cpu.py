@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library is built, loads, and exports every symbol include/alignnet_hip.h
+declares.  No compute calls here (there is no GPU and no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import alignnet3d
+from alignnet3d import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "alignnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(alignnet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_built_and_exports_every_declared_symbol():
+    lib = alignnet3d.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/alignnet_hip.h but not exported"
+    assert sorted(_capi.SYMBOLS) == declared, "ctypes table out of sync with the header"
+    assert lib.alignnet_abi_version() == _capi.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    import ctypes as C
+    # alignnet_widths = int32 n + int32[8]; config field order is asserted by size arithmetic
+    assert C.sizeof(_capi.Widths) == 4 * 9
+    assert C.sizeof(_capi.Outputs) == 8 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_capi.Labels) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_capi.StepResult) == 8 + 4 * 3 + 4 * 16 + 4  # + tail padding to 8
+    assert _capi.Config.seed.offset % 8 == 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(alignnet3d.EngineError, match="no CPU fallback"):
+        alignnet3d.Engine()
+
+
+def test_config_marshalling():
+    from alignnet3d.engine import make_c_config, default_model_config
+    c = make_c_config(default_model_config())
+    assert (c.num_points, c.num_bins, c.backbone) == (1024, 50, 0)
+    assert list(c.emb_conv.w[: c.emb_conv.n]) == [64, 128, 1024]
+    assert abs(c.s1_keep - 0.7) < 1e-7 and c.accept_inverted_angle == 1
+    bad = default_model_config()
+    bad["model"]["backbone"] = "voxel"
+    with pytest.raises(AssertionError):
+        make_c_config(bad)

@@ -1,0 +1,85 @@
+"""GPU parity: HIP eval-mode forward through the C ABI vs the fp64 oracle on the same
+fp32-representable parameters and inputs.  Bar: 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import alignnet3d
+from oracle import alignnet_ref as R
+from tests.helpers import small_cfg, oracle_params, compare_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, B, seed=1234):
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    d = R.synth_pairs(B, spec.num_points, seed=seed, dtype=np.float32)
+    ep = eng.forward(d["pcs1"], d["pcs2"])
+    P64 = {k: v.astype(np.float64) for k, v in P32.items()}
+    ref, _, _ = R.get_model(P64, spec, d["pcs1"].astype(np.float64), d["pcs2"].astype(np.float64))
+    eng.close()
+    return ep, ref, spec
+
+
+@pytest.mark.parametrize("N,B", [(128, 5), (100, 3), (256, 33), (37, 1)])
+def test_forward_small_widths(gpu_required, N, B):
+    cfg = small_cfg(N=N)
+    ep, ref, spec = _run(cfg, B)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    print("worst abs err", worst, "unstable pairs", unstable)
+    assert unstable <= max(1, B // 4)
+
+
+def test_forward_synthcars_widths_n1024(gpu_required):
+    cfg = alignnet3d.default_model_config()
+    ep, ref, spec = _run(cfg, 8)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    print("worst abs err", worst, "unstable pairs", unstable)
+    assert unstable <= 2
+
+
+def test_forward_default_json_widths(gpu_required):
+    # reference configs/default.json widths: 5-layer backbones, 36 bins
+    cfg = alignnet3d.default_model_config()
+    o = cfg["model"]["options"]
+    o["s1transformer"] = [[128, 128, 256], [[512, 256], 0.7]]
+    o["s2transformer"] = [[64, 64, 64, 128, 1024], [[512, 256], 0.7]]
+    o["embedding"] = [64, 64, 64, 128, 1024]
+    cfg["model"]["angles"]["num_bins"] = 36
+    cfg["model"]["num_points"] = 512
+    ep, ref, spec = _run(cfg, 4)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    print("worst abs err", worst, "unstable pairs", unstable)
+
+
+def test_get_set_roundtrip_and_errors(gpu_required):
+    eng = alignnet3d.Engine(small_cfg())
+    names = eng.variables()
+    assert len(names) == len(R.param_names(R.NetSpec.from_cfg(small_cfg())))
+    name, shp, _ = names[0]
+    v = np.arange(shp[0] * shp[1], dtype=np.float32).reshape(shp) / 7
+    eng.set_variable(name, v)
+    np.testing.assert_array_equal(eng.get_variable(name), v)
+    with pytest.raises(alignnet3d.EngineError, match="unknown variable"):
+        eng.set_variable("nope/weights", v)
+    with pytest.raises(alignnet3d.EngineError, match="elements"):
+        eng.set_variable(name, v.ravel()[:-1])
+    with pytest.raises(ValueError):
+        eng.forward(np.zeros((2, 7, 3), np.float32), np.zeros((2, 7, 3), np.float32))
+    eng.close()
+
+
+def test_batch_independence_and_determinism(gpu_required):
+    cfg = small_cfg(N=128)
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    d = R.synth_pairs(9, 128, dtype=np.float32)
+    full = eng.forward(d["pcs1"], d["pcs2"])
+    again = eng.forward(d["pcs1"], d["pcs2"])
+    part = eng.forward(d["pcs1"][2:5], d["pcs2"][2:5])
+    for k in full:
+        np.testing.assert_array_equal(full[k], again[k])          # bit-reproducible
+        np.testing.assert_array_equal(full[k][2:5], part[k])      # eval-mode pairs are independent
+    eng.close()
