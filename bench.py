@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AlignNet-3D point-cloud pairs/sec at N=1024 on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B]
+
+A "step" is one pass of the hot path (models/tp8.py get_model, eval mode, i.e. the
+reference's timed `sess.run`, train.py:447-449) over one batch of synthetic pairs that is
+already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: SynthCars widths,
+batch 256, N=1024, fp32.  With --gpus N (launched under torch.distributed.run, one rank per
+GPU) every rank processes its own batch of 256 pairs (weak scaling; pairs are independent in
+eval mode so there is no data-path collective); value = all pairs / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel = pointnet_fused (the fused shared-MLP backbone).  achieved =
+               algorithmic FLOPs per step of that kernel (2 * 260,636,672 MAC per
+               cloud-triple * 2 clouds per pair) / its HIP-event time on the engine's stream,
+               measured inside the timed region.  peak = 157.3 TFLOP/s fp32 MFMA
+               (MI355X_MICROARCH.md).  traffic = HBM bytes per step from rocprofv3 PMC
+               (profiles/*_pmc_traffic.json, collected in separate --pmc passes), else null.
+  cpu_baseline the oracle ("port": unfused op-by-op NumPy fp32 restatement, eval mode) timed on
+               this box's host cores on a bounded sample (batch 32, repeated ~10-20 s).
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "alignnet-3d_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+# algorithmic work (SURVEY.md 8d / BASELINE.md 2), SynthCars widths, N=1024, nb=50
+FLOPS_PER_PAIR_TOTAL = 1_047_688_704
+N_POINTS = 1024
+
+
+def backbone_macs_per_cloud(cfg):
+    """MACs of the three fused backbones for one cloud (the dominant kernel's algorithmic work)."""
+    o = cfg["model"]["options"]
+    n = cfg["model"]["num_points"]
+    tot = 0
+    for widths in (o["s1transformer"][0], o["s2transformer"][0], o["embedding"]):
+        cin = 3
+        for c in widths:
+            tot += cin * c
+            cin = c
+    return tot * n
+
+
+def cpu_baseline(cfg, seconds=12.0):
+    from oracle import alignnet_ref as R
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    spec = R.NetSpec.from_cfg(cfg)
+    P = R.init_params(spec, 0, np.float32)
+    for k in P:  # plausible eval-mode shadows: mean 0, var 1
+        if k.endswith("moving_var"):
+            P[k] = np.ones_like(P[k])
+    B = 32  # the reference's own timing mode uses bs=32 (train.py:557)
+    d = R.synth_pairs(B, spec.num_points, seed=1234, dtype=np.float32)
+    R.get_model(P, spec, d["pcs1"], d["pcs2"])  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.get_model(P, spec, d["pcs1"], d["pcs2"])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {"value": round(B * n / dt, 2), "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} x batch {B} (N={spec.num_points}, SynthCars widths, eval mode), unfused NumPy fp32 oracle, "
+                      f"{dt:.1f} s wall, forward only (cf. reference train.py:447-449)"}
+
+
+def pmc_traffic():
+    """HBM bytes per step from a committed rocprofv3 PMC summary, if one exists."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get("hbm_bytes_per_step")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import alignnet3d
+    from oracle import alignnet_ref as R  # synthetic input generator only (SURVEY 8d recipe)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = alignnet3d.default_model_config()
+    cfg["training"]["batch_size"] = args.batch * world
+    B = args.batch
+    eng = alignnet3d.Engine(cfg, device=local_rank, seed=0)
+    # eval-mode shadows: mean 0 / var 1 (a freshly initialised net has var 0 -> degenerate scale)
+    for name, shp, _ in eng.variables():
+        if name.endswith("moving_var"):
+            eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
+
+    d = R.synth_pairs(B, N_POINTS, seed=1234 + rank, dtype=np.float32)
+    p1 = torch.from_numpy(d["pcs1"]).to(dev)
+    p2 = torch.from_numpy(d["pcs2"]).to(dev)
+    nb2 = 2 * cfg["model"]["angles"]["num_bins"]
+    outs = {k: torch.empty(B, nb2 if "logits" in k else 3, device=dev) for k in alignnet3d.OUTPUT_NAMES}
+    ptrs = {k: v.data_ptr() for k, v in outs.items()}
+
+    if args.mode == "train":
+        raise SystemExit("train mode: see bench_train.py once the training path lands")
+
+    def step():
+        eng.forward_device(p1.data_ptr(), p2.data_ptr(), B, ptrs)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        bb_flops_per_step = 2.0 * backbone_macs_per_cloud(cfg) * 2 * B
+        bb_ms_per_step = prof["backbone_ms"] / args.steps
+        achieved = bb_flops_per_step / (bb_ms_per_step * 1e-3) / 1e12 if bb_ms_per_step > 0 else None
+        peak = 157.3
+        line = {
+            "metric": "point-cloud pairs/sec at N=1024 (inference, eval-mode forward)",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SynthCars widths inference, batch=256 pairs/GPU, N=1024, fp32 (BASELINE.json configs[1])",
+                       "pairs_per_gpu": B, "num_points": N_POINTS, "parallelism": f"batch-split x{world} (no collective)"},
+            "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
+                         "traffic": pmc_traffic(), "kernel": "pointnet_fused",
+                         "launches_per_step": prof["backbone_launches"] / args.steps,
+                         "kernel_ms_per_step": round(bb_ms_per_step, 4),
+                         "algorithmic_flops_per_step": bb_flops_per_step},
+            "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2) if world == 1 else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

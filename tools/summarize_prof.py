@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 rocpd databases (gpurun_out/prof_<tag>) into small text files for profiles/.
+Usage: tools/summarize_prof.py gpurun_out/prof_r01 r01 [dest_dir]"""
+import glob, json, os, sqlite3, sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(out, "summary")
+os.makedirs(dst, exist_ok=True)
+
+def short(n):
+    return n.split("(")[0].replace("alignnet::", "")
+
+# 1. kernel-trace stats (rocprofv3 --kernel-trace --stats)
+for db in glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as g:
+        g.write("# rocprofv3 --kernel-trace --stats -- python bench.py (durations in microseconds)\n")
+        g.write("kernel,calls,total_us,average_us,percent\n")
+        for n, calls, tot, avg, pct in rows:
+            g.write(f"{short(n)},{calls},{tot:.3f},{avg:.3f},{pct:.3f}\n")
+    # per-launch detail of the dominant kernel (three launch shapes per step)
+    det = defaultdict(list)
+    try:
+        for name, gx, dur in c.execute("select name, grid_size, (end-start) from kernels"):
+            det[(short(name), gx)].append(dur)
+        with open(os.path.join(dst, f"{tag}_kernel_by_grid.csv"), "w") as g:
+            g.write("kernel,grid_size,calls,average_us,min_us,max_us\n")
+            for (n, gx), v in sorted(det.items(), key=lambda kv: -sum(kv[1])):
+                g.write(f"{n},{gx},{len(v)},{sum(v)/len(v)/1e3:.3f},{min(v)/1e3:.3f},{max(v)/1e3:.3f}\n")
+    except sqlite3.Error as e:
+        print("kernels view:", e)
+    break
+
+# 2. PMC passes (each in its own run, no tracing flags)
+pmc = defaultdict(dict)
+for db in glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True):
+    c = sqlite3.connect(db)
+    acc, cnt = defaultdict(float), defaultdict(set)
+    for name, ctr, val, did in c.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        acc[(short(name), ctr)] += val; cnt[(short(name), ctr)].add(did)
+    for (k, ctr), v in acc.items():
+        pmc[k][ctr] = {"sum": v, "dispatches": len(cnt[(k, ctr)])}
+json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_by_kernel.json"), "w"), indent=1, sort_keys=True)
+
+# 3. HBM traffic per bench step.  FETCH_SIZE / WRITE_SIZE are KiB.  gfx950: FETCH_SIZE tallies a 128-B
+#    request as 64 B on wide coalesced streams (MI355X_MICROARCH.md, HBM) -> x2 on the read side.
+steps = None
+for line in open(os.path.join(out, "bench_trace.log")):
+    if line.startswith("{"):
+        j = json.loads(line); steps = j["steps"] + j["warmup"]
+if steps:
+    fetch = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in pmc.values())
+    write = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in pmc.values())
+    bb = pmc.get("pointnet_fused", {})
+    bf, bw = bb.get("FETCH_SIZE", {}).get("sum", 0), bb.get("WRITE_SIZE", {}).get("sum", 0)
+    nbb = max(bb.get("FETCH_SIZE", {}).get("dispatches", 1), 1)
+    json.dump({"tag": tag, "steps_profiled": steps,
+               "hbm_bytes_per_step": (2 * fetch + write) * 1024 / steps,
+               "backbone_hbm_bytes_per_launch": (2 * bf + bw) * 1024 / nbb,
+               "backbone_hbm_bytes_per_step": (2 * bf + bw) * 1024 / steps,
+               "raw_KiB": {"FETCH_SIZE_all": fetch, "WRITE_SIZE_all": write, "FETCH_SIZE_backbone": bf, "WRITE_SIZE_backbone": bw},
+               "note": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024; the x2 is the gfx950 FETCH_SIZE correction for wide coalesced "
+                       "reads (an upper bound for narrow reads). Separate --pmc passes, warm-up steps included on both sides."},
+              open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print("summary files:", sorted(os.listdir(dst)))
