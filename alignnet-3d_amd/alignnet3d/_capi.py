@@ -75,6 +75,7 @@ SYMBOLS = {
     "alignnet_eval_loss": (C.c_int, [H, C.POINTER(Labels), C.c_int32, FP, FP]),
     "alignnet_synchronize": (C.c_int, [H]),
     "alignnet_train_step": (C.c_int, [H, FP, FP, C.POINTER(Labels), C.c_int32, FP, C.POINTER(StepResult), C.POINTER(Outputs)]),
+    "alignnet_train_step_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(Labels), C.c_int32, C.POINTER(StepResult)]),
     "alignnet_train_forward_backward": (C.c_int, [H, FP, FP, C.POINTER(Labels), C.c_int32, FP, C.POINTER(StepResult), C.POINTER(Outputs)]),
     "alignnet_grad_buffer": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "alignnet_apply_gradients": (C.c_int, [H, C.c_float]),

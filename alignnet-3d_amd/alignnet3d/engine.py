@@ -198,6 +198,93 @@ class Engine:
     def synchronize(self):
         self._check(self._lib.alignnet_synchronize(self._h))
 
+    # ---- loss on the last eval forward (train.py:448 `loss` fetch) --------------
+    def _labels(self, labels, B):
+        keys = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
+        widths = (3, 1, 3, 3, 1, 1)
+        arrs, L = [], _capi.Labels()
+        for k, w in zip(keys, widths):
+            a = np.ascontiguousarray(labels[k], np.float32).reshape(B, w)
+            arrs.append(a)
+            setattr(L, k, _fp(a))
+        return arrs, L
+
+    def eval_loss(self, labels, B):
+        keep, L = self._labels(labels, B)
+        loss, summ = C.c_float(), (C.c_float * 16)()
+        self._check(self._lib.alignnet_eval_loss(self._h, C.byref(L), B, C.byref(loss), summ))
+        return loss.value, dict(zip(SUMMARY_NAMES, list(summ)))
+
+    # ---- train sess.run (train.py:368) -------------------------------------------
+    def _train_call(self, fn, pcs1, pcs2, labels, dropout_u):
+        p1, p2 = self._check_pcs(pcs1, pcs2)
+        B = p1.shape[0]
+        keep, L = self._labels(labels, B)
+        arrs, o = self._alloc_outputs(B)
+        res = _capi.StepResult()
+        u = None
+        if dropout_u is not None:
+            u = np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32).ravel() for x in dropout_u]), np.float32)
+        self._check(fn(self._h, _fp(p1), _fp(p2), C.byref(L), B, _fp(u) if u is not None else None, C.byref(res), C.byref(o)))
+        out = dict(step=res.step, loss=res.loss, learning_rate=res.learning_rate, bn_decay=res.bn_decay,
+                   summaries=dict(zip(SUMMARY_NAMES, list(res.summaries))))
+        out.update(arrs)
+        return out
+
+    def train_forward_backward(self, pcs1, pcs2, labels, dropout_u=None):
+        """Forward (batch statistics, EMA update), loss and backward; gradients stay on the device.
+        dropout_u: optional list [s1 tower0, s2 tower0, s1 tower1, s2 tower1, pair head] of uniforms."""
+        return self._train_call(self._lib.alignnet_train_forward_backward, pcs1, pcs2, labels, dropout_u)
+
+    def train_step(self, pcs1, pcs2, labels, dropout_u=None):
+        return self._train_call(self._lib.alignnet_train_step, pcs1, pcs2, labels, dropout_u)
+
+    def train_step_device(self, d_pcs1, d_pcs2, d_labels, B, want_result=False):
+        """d_labels: dict name -> device pointer (int)."""
+        L = _capi.Labels()
+        for k in ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"):
+            setattr(L, k, C.cast(C.c_void_p(d_labels[k]), _capi.FP))
+        res = _capi.StepResult()
+        self._check(self._lib.alignnet_train_step_device(self._h, C.c_void_p(d_pcs1), C.c_void_p(d_pcs2), C.byref(L), B,
+                                                         C.byref(res) if want_result else None))
+        return dict(step=res.step, loss=res.loss) if want_result else None
+
+    def apply_gradients(self, grad_scale=1.0):
+        self._check(self._lib.alignnet_apply_gradients(self._h, float(grad_scale)))
+
+    def get_gradient(self, name):
+        shp = dict((n, s) for n, s, _ in self.variables())[name]
+        a = np.empty(shp[0] * shp[1], np.float32)
+        self._check(self._lib.alignnet_get_grad(self._h, name.encode(), _fp(a), a.size))
+        return a.reshape(shp) if shp[0] > 1 else a
+
+    def grad_buffer(self):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.alignnet_grad_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    # ---- multi-GPU (RCCL over xGMI) ---------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        if _capi.load_library().alignnet_comm_unique_id(buf) != 0:
+            raise EngineError("alignnet_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.alignnet_comm_init(self._h, rank, world, buf))
+
+    def comm_allreduce_grads(self):
+        self._check(self._lib.alignnet_comm_allreduce_grads(self._h))
+
+    # ---- checkpoints (tf.train.Saver, train.py:220,252,268,281,317,321) -----------
+    def save(self, path):
+        self._check(self._lib.alignnet_save(self._h, str(path).encode()))
+
+    def load(self, path, skip_step=False):
+        self._check(self._lib.alignnet_load(self._h, str(path).encode(), int(skip_step)))
+
     # ---- state -----------------------------------------------------------------
     def state(self):
         st = _capi.State()

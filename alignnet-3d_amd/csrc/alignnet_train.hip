@@ -1,23 +1,935 @@
-// Training-side C ABI (include/alignnet_hip.h).  Filled in by the training milestone; until
-// then each entry point reports "not implemented" rather than silently doing nothing.
+// Training side of the C ABI (include/alignnet_hip.h): the train-mode sess.run of the reference
+// (train.py:368) = forward with batch statistics + loss + backward + optimiser + EMA + step++.
 #include "engine.h"
+#include "kernels_train_fwd.h"
+#include "kernels_train_head.h"
+#include "kernels_train_bwd.h"
 
-static int nyi(alignnet_handle* h, const char* what)
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+
+using namespace alignnet;
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+      return 1;                                                                                  \
+    }                                                                                            \
+  } while (0)
+
+static int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1; }
+
+namespace alignnet {
+
+struct HeadLayerWS { float *z, *y, *mean, *var, *dz; };   // per hidden FC layer (with BN)
+
+struct StageWS {                 // one backbone stage (T1, T2, embedding)
+  float* xform;                  // [2B][12] input frame of this stage
+  float *mean[3], *var[3], *scale[3], *shift[3];   // [2][C_l]
+  float* sgn3;                   // [2][C3]
+  float* ext; int* idx2;          // [2B][2 halves][C3] per-half extremes
+  int* idx; float* zhat_star;     // [2B][C3] final arg-extreme index, zhat at the extreme
+  float* h2;                     // [2B*N][C2]
+  float *gram2, *s2, *m2;        // [2][C2*C2], [2][C2], [2][C2]
+  float* pooled; long tower_stride, row_stride;    // forward output (layout of the consumer)
+  float* dP;                     // dL/dpooled, same layout
+  float *gx, *grot;              // [2B][3], [2B]
+};
+
+struct TrainWS {
+  int cap = 0;
+  char* base = nullptr; size_t bytes = 0;
+  float* d_pcs[2] = {nullptr, nullptr};
+  float* labels[6];              // device copies of the label tensors
+  float* dropout_u;              // host-supplied uniforms (device copy), [sum over heads]
+  float* center_mean; float* s1c; float* s2c; float* theta; int* cls;
+  StageWS st[3];
+  HeadLayerWS hl[3][ALIGNNET_MAX_WIDTHS];
+  float* o[3]; float* d_o[3];    // head outputs [2B][3], [2B][3+2nb], [B][3+2nb] and their gradients
+  float *d_s1c, *d_s2c;          // [2B][3]
+  float* loss_out;               // [17]
+  float* loss_scratch;
+  float* head_din[3];            // gradient wrt the head input (= dP of the stage)
+  // transient backward buffers (shared by the stages)
+  double* stat_part; float* gram_part; double* colsum_part;
+  float *dy2, *dy1;
+  double *dbg2_part, *dbg1_part, *s1_part; float *u2_part, *g1_part, *p_part;
+  float *dbg2, *dbg1, *u2, *g1, *s1, *m1;
+  float *E3, *kdb3, *gs, *Sp, *GW, *W3E, *W3T, *Q3, *q3b, *q3img;
+  float *E2, *kdb2, *k2, *rstd2, *W2E, *V2, *Q2, *q2b, *v2img, *q2img, *GW2;
+  float *k1, *rstd1;
+  float* outs[8];
+  // optimiser
+  float *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+};
+
+}  // namespace alignnet
+
+static TrainWS* tws(alignnet_handle* h)
 {
-  if (h) h->err = std::string(what) + ": not implemented in this build";
-  return 2;
+  if (!h->train_ws) h->train_ws = new TrainWS();
+  return static_cast<TrainWS*>(h->train_ws);
 }
 
-extern "C" int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels*, int32_t, float*, float*) { return nyi(h, "alignnet_eval_loss"); }
-extern "C" int alignnet_train_step(alignnet_handle* h, const float*, const float*, const alignnet_labels*, int32_t, const float*,
-                                   alignnet_step_result*, const alignnet_outputs*) { return nyi(h, "alignnet_train_step"); }
-extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float*, const float*, const alignnet_labels*, int32_t,
-                                               const float*, alignnet_step_result*, const alignnet_outputs*) { return nyi(h, "alignnet_train_forward_backward"); }
-extern "C" int alignnet_grad_buffer(alignnet_handle* h, float**, size_t*) { return nyi(h, "alignnet_grad_buffer"); }
-extern "C" int alignnet_apply_gradients(alignnet_handle* h, float) { return nyi(h, "alignnet_apply_gradients"); }
-extern "C" int alignnet_get_grad(alignnet_handle* h, const char*, float*, size_t) { return nyi(h, "alignnet_get_grad"); }
-extern "C" int alignnet_comm_unique_id(uint8_t*) { return 2; }
-extern "C" int alignnet_comm_init(alignnet_handle* h, int32_t, int32_t, const uint8_t*) { return nyi(h, "alignnet_comm_init"); }
-extern "C" int alignnet_comm_allreduce_grads(alignnet_handle* h) { return nyi(h, "alignnet_comm_allreduce_grads"); }
-extern "C" int alignnet_save(alignnet_handle* h, const char*) { return nyi(h, "alignnet_save"); }
-extern "C" int alignnet_load(alignnet_handle* h, const char*, int32_t) { return nyi(h, "alignnet_load"); }
+extern "C" void alignnet_train_ws_free(alignnet_handle* h)
+{
+  if (!h->train_ws) return;
+  TrainWS* w = static_cast<TrainWS*>(h->train_ws);
+  if (w->base) hipFree(w->base);
+  for (int t = 0; t < 2; ++t) if (w->d_pcs[t]) hipFree(w->d_pcs[t]);
+  if (w->grad) hipFree(w->grad);
+  if (w->adam_m) hipFree(w->adam_m);
+  if (w->adam_v) hipFree(w->adam_v);
+  delete w;
+  h->train_ws = nullptr;
+}
+
+static const Stack& conv_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_conv : s == 1 ? h->s2_conv : h->emb_conv; }
+static const Stack& fc_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_fc : s == 1 ? h->s2_fc : h->rem_fc; }
+static float keep_of(const alignnet_handle* h, int s) { return s == 0 ? h->cfg.s1_keep : s == 1 ? h->cfg.s2_keep : h->cfg.rem_keep; }
+static float* P(alignnet_handle* h, int pidx) { return h->d_params + h->params[pidx].offset; }
+static float* G(alignnet_handle* h, TrainWS* w, int pidx) { return w->grad + h->params[pidx].offset; }
+
+static int check_trainable_shape(alignnet_handle* h)
+{
+  if (h->cfg.backbone != 0) return fail(h, "training: dgcnn backbone is not implemented in this build");
+  for (int s = 0; s < 3; ++s) {
+    const Stack& st = conv_of(h, s);
+    if (st.n != 3) return fail(h, "training supports 3-conv-layer backbones (all shipped dataset configs); got " + std::to_string(st.n));
+    const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
+    if (C1 % 32 || C2 % 32 || C3 % 32) return fail(h, "training: conv widths must be multiples of 32");
+    if (C1 > 128 || C2 > 128 || C3 > 1024) return fail(h, "training: conv widths limited to C1,C2 <= 128, C3 <= 1024");
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------
+static int ensure_train_ws(alignnet_handle* h, int B)
+{
+  TrainWS* w = tws(h);
+  if (!w->grad) {
+    HIP_TRY(h, hipMalloc(&w->grad, h->n_trainable * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&w->adam_m, h->n_trainable * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&w->adam_v, h->n_trainable * sizeof(float)));
+    HIP_TRY(h, hipMemset(w->grad, 0, h->n_trainable * sizeof(float)));
+    HIP_TRY(h, hipMemset(w->adam_m, 0, h->n_trainable * sizeof(float)));
+    HIP_TRY(h, hipMemset(w->adam_v, 0, h->n_trainable * sizeof(float)));
+  }
+  if (B <= w->cap) return 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (w->base) { hipFree(w->base); w->base = nullptr; }
+  for (int t = 0; t < 2; ++t) if (w->d_pcs[t]) { hipFree(w->d_pcs[t]); w->d_pcs[t] = nullptr; }
+  const int N = h->cfg.num_points, nb2 = 2 * h->cfg.num_bins;
+  const size_t B2 = 2 * (size_t)B, MN = B2 * N;
+  int maxC = 8, maxC1 = 8, maxC2 = 8, maxC3 = 8, maxH = 8;
+  for (int s = 0; s < 3; ++s) {
+    const Stack& st = conv_of(h, s);
+    maxC1 = std::max(maxC1, h->layers[st.first].cout);
+    maxC2 = std::max(maxC2, h->layers[st.first + 1].cout);
+    maxC3 = std::max(maxC3, h->layers[st.first + 2].cout);
+    const Stack& fs = fc_of(h, s);
+    for (int j = 0; j < fs.n; ++j) maxH = std::max(maxH, h->layers[fs.first + j].cout);
+  }
+  maxC = std::max(maxC1, std::max(maxC2, maxC3));
+  // two passes over the same carve code: size, then assign
+  for (int pass = 0; pass < 2; ++pass) {
+    size_t off = 0;
+    auto take = [&](size_t nbytes) -> char* {
+      char* p = pass ? w->base + off : nullptr;
+      off += (nbytes + 255) & ~(size_t)255;
+      return p;
+    };
+    auto F = [&](size_t n) { return reinterpret_cast<float*>(take(n * sizeof(float))); };
+    auto D = [&](size_t n) { return reinterpret_cast<double*>(take(n * sizeof(double))); };
+    auto I = [&](size_t n) { return reinterpret_cast<int*>(take(n * sizeof(int))); };
+    const int lw[6] = {3, 1, 3, 3, 1, 1};
+    for (int i = 0; i < 6; ++i) w->labels[i] = F((size_t)B * lw[i]);
+    w->dropout_u = F(5 * (size_t)B * maxH);
+    w->center_mean = F(B2 * 3); w->s1c = F(B2 * 3); w->s2c = F(B2 * 3); w->theta = F(B2); w->cls = I(B2);
+    for (int s = 0; s < 3; ++s) {
+      const Stack& st = conv_of(h, s);
+      const int C[3] = {h->layers[st.first].cout, h->layers[st.first + 1].cout, h->layers[st.first + 2].cout};
+      StageWS& S = w->st[s];
+      S.xform = F(B2 * 12);
+      for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); }
+      S.sgn3 = F(2 * C[2]);
+      S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
+      S.h2 = F(MN * C[1]);
+      S.gram2 = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
+      S.pooled = F(B2 * C[2]); S.dP = F(B2 * C[2]);
+      if (s < 2) { S.tower_stride = (long)B * C[2]; S.row_stride = C[2]; }
+      else { S.tower_stride = C[2]; S.row_stride = 2L * C[2]; }
+      S.gx = F(B2 * 3); S.grot = F(B2);
+      const Stack& fs = fc_of(h, s);
+      const size_t M = s < 2 ? B2 : (size_t)B;
+      for (int j = 0; j < fs.n - 1; ++j) {
+        const int wd = h->layers[fs.first + j].cout;
+        HeadLayerWS& L = w->hl[s][j];
+        L.z = F(M * wd); L.y = F(M * wd); L.dz = F(M * wd); L.mean = F(2 * wd); L.var = F(2 * wd);
+      }
+      const int ow = h->layers[fs.first + fs.n - 1].cout;
+      w->o[s] = F(M * ow); w->d_o[s] = F(M * ow);
+      w->head_din[s] = S.dP;
+    }
+    w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
+    w->loss_out = F(32); w->loss_scratch = F(32 * (size_t)B + 64);
+    w->stat_part = D(B2 * 2 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 2 * maxC2);
+    w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
+    w->dbg2_part = D(B2 * 2 * maxC2 * 2); w->dbg1_part = D(B2 * 8 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
+    w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
+    w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
+    w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
+    w->E3 = F(2 * maxC3); w->kdb3 = F(2 * maxC3); w->gs = F(B2 * maxC3);
+    w->Sp = F(2 * (size_t)maxC2 * maxC3); w->GW = F(2 * (size_t)maxC2 * maxC3); w->W3E = F(2 * (size_t)maxC2 * maxC3);
+    w->W3T = F((size_t)maxC2 * maxC3); w->Q3 = F(2 * (size_t)maxC2 * maxC2); w->q3b = F(2 * maxC2);
+    w->q3img = F(2 * (size_t)maxC2 * maxC2 + 1024);
+    w->E2 = F(2 * maxC2); w->kdb2 = F(2 * maxC2); w->k2 = F(2 * maxC2); w->rstd2 = F(2 * maxC2);
+    w->W2E = F(2 * (size_t)maxC1 * maxC2); w->V2 = F(2 * (size_t)maxC1 * maxC2); w->Q2 = F(2 * (size_t)maxC1 * maxC1);
+    w->q2b = F(2 * maxC1); w->v2img = F(2 * (size_t)maxC1 * maxC2 + 1024); w->q2img = F(2 * (size_t)maxC1 * maxC1 + 1024);
+    w->GW2 = F(2 * (size_t)maxC1 * maxC2);
+    w->k1 = F(2 * maxC1); w->rstd1 = F(2 * maxC1);
+    const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+    for (int i = 0; i < 8; ++i) w->outs[i] = F((size_t)B * widths[i]);
+    if (!pass) {
+      w->bytes = off;
+      HIP_TRY(h, hipMalloc(&w->base, off));
+      HIP_TRY(h, hipMemset(w->base, 0, off));
+    }
+  }
+  for (int t = 0; t < 2; ++t) HIP_TRY(h, hipMalloc(&w->d_pcs[t], (size_t)B * N * 3 * sizeof(float)));
+  w->cap = B;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------
+static void launch_gemm(alignnet_handle* h, const float* A, long sai, long sak, const float* Bm, long sbk, long sbj, float* C,
+                        long sci, long scj, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f, int acc = 0)
+{
+  GemmArgs g{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, bias, alpha, acc};
+  hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, h->stream, g);
+}
+
+static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float* img)
+{
+  const size_t total = (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, h->stream, W, K, C, img);
+}
+
+static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
+
+static int pack_all_weights(alignnet_handle* h)
+{
+  for (const Layer& L : h->layers)
+    if (!L.first_conv) launch_pack(h, P(h, L.p_w), L.cin, L.cout, h->d_wp + L.off_wp);
+  h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
+  return 0;
+}
+
+static size_t lds_train(int ld0, int ldb_or_ld1) { return ((size_t)kTilePts * 4 + (size_t)kTilePts * (ld0 + ldb_or_ld1)) * sizeof(float); }
+
+static int set_lds_attrs(alignnet_handle* h)
+{
+  static bool done = false;
+  if (done) return 0;
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// backbone forward (training mode) for stage s
+// ---------------------------------------------------------------------------------
+static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema)
+{
+  TrainWS* w = tws(h);
+  StageWS& S = w->st[s];
+  const Stack& st = conv_of(h, s);
+  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + 1], &h->layers[st.first + 2]};
+  const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
+  TrainFwdArgs a;
+  a.pcs[0] = p1; a.pcs[1] = p2; a.xform = S.xform; a.B = B; a.N = N; a.C1 = C1; a.C2 = C2; a.C3 = C3;
+  a.ld[0] = ((C1 + 7) & ~7) + 4; a.ld[1] = ((C2 + 7) & ~7) + 4;
+  a.w1 = P(h, L[0]->p_w); a.wp2 = h->d_wp + L[1]->off_wp; a.wp3 = h->d_wp + L[2]->off_wp;
+  a.b1 = P(h, L[0]->p_b); a.b2 = P(h, L[1]->p_b); a.b3 = P(h, L[2]->p_b);
+  a.sc1 = S.scale[0]; a.sh1 = S.shift[0]; a.sc2 = S.scale[1]; a.sh2 = S.shift[1]; a.sgn3 = S.sgn3;
+  a.stat_part = w->stat_part; a.ext = S.ext; a.idx = S.idx2; a.gram_part = w->gram_part; a.colsum_part = w->colsum_part;
+  a.h2_store = S.h2;
+  const double count = (double)B * N;
+  auto finish = [&](int l, int C, int slices) {
+    StatFinishArgs f;
+    f.part = w->stat_part; f.B = B; f.C = C; f.slices = slices; f.count = count; f.bias = P(h, L[l]->p_b);
+    for (int t = 0; t < 2; ++t) {
+      f.beta[t] = P(h, L[l]->p_bn[t][0]); f.gamma[t] = P(h, L[l]->p_bn[t][1]);
+      f.mov_mean[t] = P(h, L[l]->p_bn[t][2]); f.mov_var[t] = P(h, L[l]->p_bn[t][3]);
+    }
+    f.bn_decay = bn_decay; f.update_ema = update_ema;
+    f.mean = S.mean[l]; f.var = S.var[l]; f.scale = S.scale[l]; f.shift = S.shift[l];
+    f.sgn = l == 2 ? S.sgn3 : nullptr;
+    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 255) / 256, 2), dim3(256), 0, h->stream, f);
+  };
+  hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
+  finish(0, C1, 1);
+  hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  finish(1, C2, 2);
+  // sgn3 from gamma (per tower)
+  for (int t = 0; t < 2; ++t)
+    hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + t * C3);
+  hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  finish(2, C3, 2);
+  hipLaunchKernelGGL((reduce_clouds_kernel<float>), dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, w->gram_part, B, (long)C2 * C2, S.gram2);
+  hipLaunchKernelGGL((reduce_clouds_kernel<double>), dim3((C2 + 255) / 256, 2), dim3(256), 0, h->stream, w->colsum_part, 2 * B, (long)C2, S.s2);
+  hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
+  const size_t tot = (size_t)2 * B * C3;
+  hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),
+                     S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled, S.tower_stride, S.row_stride, S.zhat_star, S.idx);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// head MLP forward / backward (training mode)
+// ---------------------------------------------------------------------------------
+static BnRowsArgs bn_args(alignnet_handle* h, TrainWS* w, int s, int j, int M, int rows_per_set, float bn_decay, int update_ema,
+                          const float* u_dev)
+{
+  const Stack& fs = fc_of(h, s);
+  const Layer& L = h->layers[fs.first + j];
+  HeadLayerWS& HL = w->hl[s][j];
+  BnRowsArgs a{};
+  a.z = HL.z; a.y = HL.y; a.M = M; a.C = L.cout; a.rows_per_set = rows_per_set;
+  for (int t = 0; t < 2; ++t) {
+    const int src = L.p_bn[t][0] >= 0 ? t : 0;
+    a.beta[t] = P(h, L.p_bn[src][0]); a.gamma[t] = P(h, L.p_bn[src][1]);
+    a.mov_mean[t] = P(h, L.p_bn[src][2]); a.mov_var[t] = P(h, L.p_bn[src][3]);
+  }
+  a.bn_decay = bn_decay; a.update_ema = update_ema; a.mean = HL.mean; a.var = HL.var;
+  const bool last_hidden = j == fs.n - 2;
+  a.keep = last_hidden ? keep_of(h, s) : -1.f;
+  // dropout uniforms layout (include/alignnet_hip.h): [s1 t0 | s2 t0 | s1 t1 | s2 t1 | pair], each B x width
+  const size_t blk = (size_t)rows_per_set * L.cout;
+  if (u_dev && last_hidden) {
+    if (s < 2) { a.u = u_dev + (size_t)s * blk; a.u_set_stride = 2 * (long)blk; }
+    else { a.u = u_dev + 4 * (size_t)rows_per_set * h->layers[fc_of(h, 0).first + fc_of(h, 0).n - 2].cout; a.u_set_stride = 0; }
+  }
+  a.seed = h->cfg.seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->step * 16 + s * 4;
+  return a;
+}
+
+static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin, int M, int rows_per_set, float bn_decay,
+                          int update_ema, const float* u_dev)
+{
+  TrainWS* w = tws(h);
+  const Stack& fs = fc_of(h, s);
+  const float* cur = in; long ldc = ldin;
+  const int nsets = M > rows_per_set ? 2 : 1;
+  for (int j = 0; j < fs.n; ++j) {
+    const Layer& L = h->layers[fs.first + j];
+    if (j < fs.n - 1) {
+      HeadLayerWS& HL = w->hl[s][j];
+      launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
+      BnRowsArgs a = bn_args(h, w, s, j, M, rows_per_set, bn_decay, update_ema, u_dev);
+      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + 63) / 64, nsets), dim3(256), 0, h->stream, a);
+      cur = HL.y; ldc = L.cout;
+    } else {
+      launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, w->o[s], L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// d_out = w->d_o[s]  ->  parameter gradients + gradient wrt the head input (din, same layout as the input)
+static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin, float* din, int M, int rows_per_set, const float* u_dev)
+{
+  TrainWS* w = tws(h);
+  const Stack& fs = fc_of(h, s);
+  const int nsets = M > rows_per_set ? 2 : 1;
+  const float* dcur = w->d_o[s];
+  for (int j = fs.n - 1; j >= 0; --j) {
+    const Layer& L = h->layers[fs.first + j];
+    const float* xin = j == 0 ? in : w->hl[s][j - 1].y;
+    const long ldx = j == 0 ? ldin : L.cin;
+    if (j < fs.n - 1) {
+      // dcur is d(y_j): through dropout / relu / BN
+      HeadLayerWS& HL = w->hl[s][j];
+      BnRowsBwdArgs b{};
+      b.f = bn_args(h, w, s, j, M, rows_per_set, 0.f, 0, u_dev);
+      b.dy = dcur; b.dz = HL.dz;
+      for (int t = 0; t < 2; ++t) {
+        const int src = L.p_bn[t][0] >= 0 ? t : 0;
+        b.dbeta[t] = G(h, w, L.p_bn[src][0]); b.dgamma[t] = G(h, w, L.p_bn[src][1]);
+      }
+      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + 63) / 64, nsets), dim3(256), 0, h->stream, b);
+      dcur = HL.dz;
+      // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here)
+      HIP_TRY(h, hipMemsetAsync(G(h, w, L.p_b), 0, L.cout * sizeof(float), h->stream));
+    } else {
+      hipLaunchKernelGGL(colsum_kernel, dim3((L.cout + 127) / 128), dim3(128), 0, h->stream, dcur, (long)L.cout, M, L.cout, G(h, w, L.p_b), 1.f, 0);
+    }
+    // dW = x^T dz  (TN)
+    launch_gemm(h, xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M);
+    // dx = dz W^T  (NT).  d(y_{j-1}) overwrites y_{j-1}: after the dW GEMM above y_{j-1} is dead (the BN backward of
+    // layer j-1 rebuilds the relu mask from z_{j-1}); the stream orders the two GEMMs.
+    float* dx = j == 0 ? din : w->hl[s][j - 1].y;
+    launch_gemm(h, dcur, L.cout, 1, P(h, L.p_w), 1, L.cout, dx, j == 0 ? ldin : L.cin, 1, M, L.cin, L.cout);
+    dcur = dx;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// backbone backward for stage s: consumes S.dP, produces parameter gradients + S.gx / S.grot
+// ---------------------------------------------------------------------------------
+static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B)
+{
+  TrainWS* w = tws(h);
+  StageWS& S = w->st[s];
+  const Stack& st = conv_of(h, s);
+  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + 1], &h->layers[st.first + 2]};
+  const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
+  const double M = (double)B * N;
+  const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
+  auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  auto g256t = [](size_t n) { return dim3((unsigned)((n + 255) / 256), 2); };
+
+  // ---- layer 3 (sparse + Gram identities) ----
+  Prep3Args p3;
+  p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
+  for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
+  p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
+  hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 127) / 128, 2), dim3(128), 0, h->stream, p3);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp);
+  for (int t = 0; t < 2; ++t)   // GW[t] = Ghat2[t] W3
+    launch_gemm(h, S.gram2 + (size_t)t * C2 * C2, C2, 1, W3, C3, 1, w->GW + (size_t)t * C2 * C3, C3, 1, C2, C3, C2);
+  hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
+                     w->E3, C2, C3, G(h, w, L[2]->p_w));
+  HIP_TRY(h, hipMemsetAsync(G(h, w, L[2]->p_b), 0, C3 * sizeof(float), h->stream));
+  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0);
+  hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 1), dim3(256), 0, h->stream, W3, C2, C3,
+                     (const float*)nullptr, w->W3T, 1);
+  const size_t qimg = img_floats(C2, C2);
+  for (int t = 0; t < 2; ++t) {   // Q3[t] = W3 (W3E[t])^T
+    launch_gemm(h, W3, C3, 1, w->W3E + (size_t)t * C2 * C3, 1, C3, w->Q3 + (size_t)t * C2 * C2, C2, 1, C2, C2, C3);
+    launch_pack(h, w->Q3 + (size_t)t * C2 * C2, C2, C2, w->q3img + t * qimg);
+  }
+  hipLaunchKernelGGL(qbias_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+  hipLaunchKernelGGL(rstd_k_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, S.var[1], P(h, L[1]->p_bn[0][1]), P(h, L[1]->p_bn[1][1]),
+                     C2, w->rstd2, w->k2);
+
+  // ---- pass B2 ----
+  BwdB2Args b2;
+  b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
+  b2.ld0 = ((C1 + 7) & ~7) + 4; b2.ldb = ((std::max(C1, C2) + 7) & ~7) + 4;
+  b2.w1 = P(h, L[0]->p_w); b2.wp2 = h->d_wp + L[1]->off_wp;
+  b2.sc1 = S.scale[0]; b2.sh1 = S.shift[0]; b2.sc2 = S.scale[1]; b2.sh2 = S.shift[1];
+  b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = w->rstd2;
+  b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
+  b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
+  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kWaves * 64), lds_train(b2.ldb, b2.ldb), h->stream, b2);
+
+  // ---- layer 2 parameter gradients + operators for B1 ----
+  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C2 * 2), dim3(256), 0, h->stream, w->dbg2_part, 2 * B, (long)C2 * 2, w->dbg2);
+  hipLaunchKernelGGL((reduce_clouds_kernel<float>), g256t((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2_part, B, (long)C1 * C2, w->u2);
+  hipLaunchKernelGGL((reduce_clouds_kernel<float>), g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1_part, B, (long)C1 * C1, w->g1);
+  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C1), dim3(256), 0, h->stream, w->s1_part, B, (long)C1, w->s1);
+  hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, M, w->m1);
+  hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
+                     P(h, L[1]->p_bn[1][1]), C2, M, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
+                     G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
+  for (int t = 0; t < 2; ++t)   // GW2[t] = Ghat1[t] W2
+    launch_gemm(h, w->g1 + (size_t)t * C1 * C1, C1, 1, W2, C2, 1, w->GW2 + (size_t)t * C1 * C2, C2, 1, C1, C2, C1);
+  hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
+                     G(h, w, L[1]->p_w));
+  HIP_TRY(h, hipMemsetAsync(G(h, w, L[1]->p_b), 0, C2 * sizeof(float), h->stream));
+  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
+  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
+  const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
+  for (int t = 0; t < 2; ++t) {
+    launch_gemm(h, W2, C2, 1, w->W2E + (size_t)t * C1 * C2, 1, C2, w->Q2 + (size_t)t * C1 * C1, C1, 1, C1, C1, C2);
+    launch_pack(h, w->Q2 + (size_t)t * C1 * C1, C1, C1, w->q2img + t * q2img);
+    launch_pack(h, w->V2 + (size_t)t * C1 * C2, C2, C1, w->v2img + t * vimg);
+  }
+  hipLaunchKernelGGL(qbias_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
+  hipLaunchKernelGGL(rstd_k_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, S.var[0], P(h, L[0]->p_bn[0][1]), P(h, L[0]->p_bn[1][1]),
+                     C1, w->rstd1, w->k1);
+
+  // ---- pass B1 ----
+  BwdB1Args b1;
+  b1.pcs[0] = p1; b1.pcs[1] = p2; b1.xform = S.xform; b1.B = B; b1.N = N; b1.C1 = C1; b1.C2 = C2;
+  b1.ld0 = ((C1 + 7) & ~7) + 4; b1.ldb = ((C2 + 7) & ~7) + 4;
+  b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = w->rstd1;
+  b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
+  b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
+  hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kWaves * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C1 * 2), dim3(256), 0, h->stream, w->dbg1_part, 8 * B, (long)C1 * 2, w->dbg1);
+  hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
+                     P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),
+                     G(h, w, L[0]->p_bn[1][1]), (float*)nullptr, (float*)nullptr, w->k1, w->rstd1);
+
+  // ---- pass B0 ----
+  BwdB0Args b0;
+  b0.pcs[0] = p1; b0.pcs[1] = p2; b0.xform = S.xform; b0.B = B; b0.N = N; b0.C1 = C1;
+  b0.w1 = P(h, L[0]->p_w); b0.b1 = P(h, L[0]->p_b); b0.mean1 = S.mean[0]; b0.rstd1 = w->rstd1; b0.k1 = w->k1; b0.dbg1 = w->dbg1;
+  b0.count = M; b0.dy1_store = w->dy1; b0.p_part = w->p_part; b0.gx = S.gx; b0.grot = S.grot;
+  hipLaunchKernelGGL(train_bwd_b0, dim3(2 * B), dim3(256), 1024 * 4 * sizeof(float) + 256 * 4 * sizeof(double) + (size_t)C1 * 4 * sizeof(float),
+                     h->stream, b0);
+  hipLaunchKernelGGL(sum_p_kernel, dim3((3 * C1 + 127) / 128), dim3(128), 0, h->stream, w->p_part, 2 * B, 3 * C1, G(h, w, L[0]->p_w));
+  HIP_TRY(h, hipMemsetAsync(G(h, w, L[0]->p_b), 0, C1 * sizeof(float), h->stream));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// full forward + backward on device buffers
+// ---------------------------------------------------------------------------------
+static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, const float* const lab[6], int B, const float* u_dev,
+                          int do_backward, int update_ema)
+{
+  TrainWS* w = tws(h);
+  const int N = h->cfg.num_points, nb = h->cfg.num_bins, nb2 = 2 * nb, B2 = 2 * B;
+  alignnet_state stt;
+  alignnet_get_state(h, &stt);
+  const float bn_decay = stt.bn_decay;
+  if (set_lds_attrs(h)) return 1;
+  pack_all_weights(h);
+  hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
+  // stage 1
+  if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
+  if (head_fwd_train(h, 0, w->st[0].pooled, w->st[0].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
+  hipLaunchKernelGGL(stage1_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->o[0], w->center_mean, B, w->s1c,
+                     w->st[1].xform, w->outs[2], w->outs[3]);
+  // stage 2
+  if (backbone_fwd_train(h, 1, p1, p2, B, bn_decay, update_ema)) return 1;
+  if (head_fwd_train(h, 1, w->st[1].pooled, w->st[1].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
+  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->o[1], 3 + nb2, w->s1c, B, nb, w->s2c,
+                     w->st[2].xform, w->theta, w->cls, w->outs[4], w->outs[5], w->outs[6], w->outs[7]);
+  // stage 3
+  if (backbone_fwd_train(h, 2, p1, p2, B, bn_decay, update_ema)) return 1;
+  if (head_fwd_train(h, 2, w->st[2].pooled, w->st[2].row_stride, B, B, bn_decay, update_ema, u_dev)) return 1;
+  hipLaunchKernelGGL(final_finish_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, w->o[2], 3 + nb2, w->s2c, B, nb, w->outs[0], w->outs[1]);
+  // loss (+ gradient wrt the end points)
+  LossArgs la;
+  la.B = B; la.nb = nb; la.esf = h->cfg.early_stage_factor; la.af = h->cfg.angle_factor; la.accept_inverted = h->cfg.accept_inverted_angle;
+  la.s1c = w->s1c; la.s2c = w->s2c; la.o2 = w->o[1]; la.ldo2 = 3 + nb2; la.o3 = w->o[2]; la.ldo3 = 3 + nb2; la.theta = w->theta; la.pcls = w->cls;
+  la.tr = lab[0]; la.c1 = lab[2]; la.c2 = lab[3]; la.a1 = lab[4]; la.a2 = lab[5];
+  la.out = w->loss_out; la.d_s1c = w->d_s1c; la.d_s2c = w->d_s2c; la.d_o2 = w->d_o[1]; la.d_o3 = w->d_o[2]; la.scratch = w->loss_scratch;
+  la.want_grad = do_backward;
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, h->stream, la);
+  HIP_TRY(h, hipGetLastError());
+  if (!do_backward) return 0;
+
+  // ---- backward ----
+  const int CE = h->layers[h->emb_conv.first + 2].cout;
+  if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
+  if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
+  hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
+                     B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
+  hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
+  const int C2l = h->layers[h->s2_conv.first + 2].cout, C1l = h->layers[h->s1_conv.first + 2].cout;
+  if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
+  if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
+  hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
+  // s1c = o1 + center_mean  ->  d_o1 = d_s1c
+  HIP_TRY(h, hipMemcpyAsync(w->d_o[0], w->d_s1c, (size_t)B2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
+  if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// optimiser (train.py:211-217): tf.train.AdamOptimizer / MomentumOptimizer
+// ---------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float gscale, float lr_t, float b1, float b2, float eps)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  w[i] -= lr_t * mi / (sqrtf(vi) + eps);   // epsilon outside the bias correction (TF form)
+}
+
+__global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ acc, size_t n, float gscale,
+                                float lr, float mom)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = mom * acc[i] + g[i] * gscale;
+  acc[i] = a;
+  w[i] -= lr * a;
+}
+
+extern "C" int alignnet_apply_gradients(alignnet_handle* h, float grad_scale)
+{
+  if (!h) return 1;
+  TrainWS* w = tws(h);
+  if (!w->grad) return fail(h, "alignnet_apply_gradients: no gradients computed yet");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  alignnet_state st;
+  alignnet_get_state(h, &st);   // schedules use the pre-increment step (train.py:145-150,172)
+  const size_t n = h->n_trainable;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (h->cfg.optimizer == 0) {
+    const double t = (double)(h->step + 1);
+    const float lr_t = (float)((double)st.learning_rate * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
+    hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, w->adam_v, n, grad_scale, lr_t, 0.9f, 0.999f, 1e-8f);
+  } else {
+    hipLaunchKernelGGL(momentum_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, n, grad_scale, st.learning_rate, h->cfg.momentum);
+  }
+  HIP_TRY(h, hipGetLastError());
+  h->step += 1;
+  h->folded = false;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------
+static int stage_inputs(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int B,
+                        const float* dropout_u, const float** u_dev)
+{
+  TrainWS* w = tws(h);
+  const size_t nin = (size_t)B * h->cfg.num_points * 3 * sizeof(float);
+  HIP_TRY(h, hipMemcpyAsync(w->d_pcs[0], pcs1, nin, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(w->d_pcs[1], pcs2, nin, hipMemcpyHostToDevice, h->stream));
+  const float* src[6] = {labels->translations, labels->rel_angles, labels->pc1_centers, labels->pc2_centers, labels->pc1_angles, labels->pc2_angles};
+  const int lw[6] = {3, 1, 3, 3, 1, 1};
+  for (int i = 0; i < 6; ++i) {
+    if (!src[i]) return fail(h, "training: all six label tensors are required");
+    HIP_TRY(h, hipMemcpyAsync(w->labels[i], src[i], (size_t)B * lw[i] * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  *u_dev = nullptr;
+  if (dropout_u) {
+    const int w1 = h->layers[h->s1_fc.first + h->s1_fc.n - 2].cout, w2 = h->layers[h->s2_fc.first + h->s2_fc.n - 2].cout;
+    const int w3 = h->layers[h->rem_fc.first + h->rem_fc.n - 2].cout;
+    if (w1 != w2) return fail(h, "explicit dropout uniforms need equal last-hidden widths in the s1/s2 heads");
+    const size_t n = (size_t)B * (4 * (size_t)w1 + w3);
+    HIP_TRY(h, hipMemcpyAsync(w->dropout_u, dropout_u, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    *u_dev = w->dropout_u;
+  }
+  return 0;
+}
+
+static int fetch_result(alignnet_handle* h, alignnet_step_result* result, const alignnet_outputs* out, int B, const alignnet_state& pre)
+{
+  TrainWS* w = tws(h);
+  float lo[17];
+  HIP_TRY(h, hipMemcpyAsync(lo, w->loss_out, sizeof(lo), hipMemcpyDeviceToHost, h->stream));
+  if (out) {
+    float* host[8] = {out->pred_translations, out->pred_remaining_angle_logits, out->pred_s1_pc1centers, out->pred_s1_pc2centers,
+                      out->pred_s2_pc1centers, out->pred_s2_pc2centers, out->pred_pc1angle_logits, out->pred_pc2angle_logits};
+    const int nb2 = 2 * h->cfg.num_bins;
+    const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+    for (int i = 0; i < 8; ++i)
+      if (host[i]) HIP_TRY(h, hipMemcpyAsync(host[i], w->outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (result) {
+    result->step = h->step;
+    result->loss = lo[0];
+    result->learning_rate = pre.learning_rate;
+    result->bn_decay = pre.bn_decay;
+    for (int i = 0; i < 16; ++i) result->summaries[i] = lo[1 + i];
+  }
+  return 0;
+}
+
+extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
+                                               int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+{
+  if (!h) return 1;
+  if (!pcs1 || !pcs2 || !labels) return fail(h, "alignnet_train_forward_backward: null argument");
+  if (B < 2) return fail(h, "training needs B >= 2 (batch statistics)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (check_trainable_shape(h)) return 1;
+  if (ensure_train_ws(h, B)) return 1;
+  TrainWS* w = tws(h);
+  const float* u_dev = nullptr;
+  if (stage_inputs(h, pcs1, pcs2, labels, B, dropout_u, &u_dev)) return 1;
+  alignnet_state pre;
+  alignnet_get_state(h, &pre);
+  if (fwd_bwd_device(h, w->d_pcs[0], w->d_pcs[1], w->labels, B, u_dev, 1, 1)) return 1;
+  return fetch_result(h, result, out, B, pre);
+}
+
+extern "C" int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
+                                   const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+{
+  if (!h) return 1;
+  if (alignnet_train_forward_backward(h, pcs1, pcs2, labels, B, dropout_u, nullptr, nullptr)) return 1;
+  alignnet_state pre;
+  alignnet_get_state(h, &pre);
+  float scale = 1.f;
+  if (h->comm) {
+    if (alignnet_comm_allreduce_grads(h)) return 1;
+    scale = 1.f / (float)h->comm_world;
+  }
+  if (alignnet_apply_gradients(h, scale)) return 1;
+  return fetch_result(h, result, out, B, pre);
+}
+
+extern "C" int alignnet_train_step_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2, const alignnet_labels* d_labels,
+                                          int32_t B, alignnet_step_result* result)
+{
+  if (!h) return 1;
+  if (!d_pcs1 || !d_pcs2 || !d_labels) return fail(h, "alignnet_train_step_device: null argument");
+  if (B < 2) return fail(h, "training needs B >= 2 (batch statistics)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (check_trainable_shape(h)) return 1;
+  if (ensure_train_ws(h, B)) return 1;
+  const float* lab[6] = {d_labels->translations, d_labels->rel_angles, d_labels->pc1_centers, d_labels->pc2_centers, d_labels->pc1_angles,
+                         d_labels->pc2_angles};
+  alignnet_state pre;
+  alignnet_get_state(h, &pre);
+  if (fwd_bwd_device(h, d_pcs1, d_pcs2, lab, B, nullptr, 1, 1)) return 1;
+  float scale = 1.f;
+  if (h->comm) {
+    if (alignnet_comm_allreduce_grads(h)) return 1;
+    scale = 1.f / (float)h->comm_world;
+  }
+  if (alignnet_apply_gradients(h, scale)) return 1;
+  if (result) return fetch_result(h, result, nullptr, B, pre);
+  return 0;
+}
+
+extern "C" int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels* labels, int32_t B, float* loss, float* summaries)
+{
+  if (!h) return 1;
+  if (!labels) return fail(h, "alignnet_eval_loss: null labels");
+  if (B != h->last_B || B < 1) return fail(h, "alignnet_eval_loss: B must equal the batch of the preceding alignnet_forward");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  Workspace& ws = h->ws;
+  const int nb = h->cfg.num_bins, nb2 = 2 * nb;
+  // label + scratch staging
+  float* stage = nullptr;
+  const size_t nlab = (size_t)B * 12, nscr = 32 * (size_t)B + 64 + 32;
+  HIP_TRY(h, hipMalloc(&stage, (nlab + nscr) * sizeof(float)));
+  const float* src[6] = {labels->translations, labels->rel_angles, labels->pc1_centers, labels->pc2_centers, labels->pc1_angles, labels->pc2_angles};
+  const int lw[6] = {3, 1, 3, 3, 1, 1};
+  float* dl[6]; size_t off = 0;
+  for (int i = 0; i < 6; ++i) {
+    dl[i] = stage + off; off += (size_t)B * lw[i];
+    if (!src[i]) { hipFree(stage); return fail(h, "alignnet_eval_loss: all six label tensors are required"); }
+    hipMemcpyAsync(dl[i], src[i], (size_t)B * lw[i] * sizeof(float), hipMemcpyHostToDevice, h->stream);
+  }
+  LossArgs la{};
+  la.B = B; la.nb = nb; la.esf = h->cfg.early_stage_factor; la.af = h->cfg.angle_factor; la.accept_inverted = h->cfg.accept_inverted_angle;
+  la.s1c = ws.s1c; la.s2c = ws.s2c; la.o2 = ws.o2; la.ldo2 = 3 + nb2; la.o3 = ws.o3; la.ldo3 = 3 + nb2; la.theta = ws.theta; la.pcls = ws.cls;
+  la.tr = dl[0]; la.c1 = dl[2]; la.c2 = dl[3]; la.a1 = dl[4]; la.a2 = dl[5];
+  la.out = stage + nlab; la.scratch = stage + nlab + 32; la.want_grad = 0;
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, h->stream, la);
+  float lo[17];
+  hipMemcpyAsync(lo, la.out, sizeof(lo), hipMemcpyDeviceToHost, h->stream);
+  hipError_t e = hipStreamSynchronize(h->stream);
+  hipFree(stage);
+  if (e != hipSuccess) return fail(h, std::string("alignnet_eval_loss: ") + hipGetErrorString(e));
+  if (loss) *loss = lo[0];
+  if (summaries) for (int i = 0; i < 16; ++i) summaries[i] = lo[1 + i];
+  return 0;
+}
+
+extern "C" int alignnet_grad_buffer(alignnet_handle* h, float** d_grad, size_t* count)
+{
+  if (!h) return 1;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  TrainWS* w = tws(h);
+  if (!w->grad && ensure_train_ws(h, 0)) return 1;
+  if (d_grad) *d_grad = w->grad;
+  if (count) *count = h->n_trainable;
+  return 0;
+}
+
+extern "C" int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!name || !dst) return fail(h, "alignnet_get_grad: null argument");
+  auto it = h->by_name.find(name);
+  if (it == h->by_name.end()) return fail(h, std::string("alignnet_get_grad: unknown variable '") + name + "'");
+  const ParamInfo& p = h->params[it->second];
+  if (!p.trainable) return fail(h, "alignnet_get_grad: variable is not trainable");
+  if (p.count() != count) return fail(h, "alignnet_get_grad: element count mismatch");
+  TrainWS* w = tws(h);
+  if (!w->grad) return fail(h, "alignnet_get_grad: no gradients computed yet");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(dst, w->grad + p.offset, count * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// RCCL (loaded lazily so that single-GPU use does not depend on librccl)
+// ---------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId passed by value = 128-byte struct
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char internal[128]; };
+Rccl g_rccl;
+bool load_rccl(std::string& err)
+{
+  if (g_rccl.lib) return true;
+  void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!l) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+  g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(l, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(l, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { err = "librccl.so lacks the expected nccl* symbols"; return false; }
+  g_rccl.lib = l;
+  return true;
+}
+}  // namespace
+
+// ncclCommInitRank takes ncclUniqueId BY VALUE; declare the real prototype for the call
+typedef int (*InitRankByValue)(void**, int, UniqueId, int);
+
+extern "C" int alignnet_comm_unique_id(uint8_t id[128])
+{
+  std::string err;
+  if (!id || !load_rccl(err)) return 1;
+  UniqueId u;
+  if (g_rccl.GetUniqueId(&u) != 0) return 1;
+  std::memcpy(id, u.internal, 128);
+  return 0;
+}
+
+extern "C" int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128])
+{
+  if (!h) return 1;
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, "alignnet_comm_init: bad arguments");
+  std::string err;
+  if (!load_rccl(err)) return fail(h, err);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  UniqueId u;
+  std::memcpy(u.internal, id, 128);
+  void* comm = nullptr;
+  const int rc = reinterpret_cast<InitRankByValue>(g_rccl.CommInitRank)(&comm, world, u, rank);
+  if (rc != 0) return fail(h, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  h->comm = comm; h->comm_world = world; h->comm_rank = rank;
+  return 0;
+}
+
+extern "C" void alignnet_comm_free(alignnet_handle* h)
+{
+  if (h && h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+}
+
+extern "C" int alignnet_comm_allreduce_grads(alignnet_handle* h)
+{
+  if (!h) return 1;
+  if (!h->comm) return fail(h, "alignnet_comm_allreduce_grads: communicator not initialised");
+  TrainWS* w = tws(h);
+  if (!w->grad) return fail(h, "alignnet_comm_allreduce_grads: no gradients computed yet");
+  // one bucket: the whole trainable vector (8.66 MB fp32 for the SynthCars widths), ncclFloat = 7, ncclSum = 0
+  const int rc = g_rccl.AllReduce(w->grad, w->grad, h->n_trainable, 7, 0, h->comm, h->stream);
+  if (rc != 0) return fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// checkpoints: own container ("ALN3" + version, step, then name/shape/data records for every variable and
+// the optimiser slots) -- replaces tf.train.Saver (train.py:220,252,268,281,317,321)
+// ---------------------------------------------------------------------------------
+extern "C" int alignnet_save(alignnet_handle* h, const char* path)
+{
+  if (!h) return 1;
+  if (!path) return fail(h, "alignnet_save: null path");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<float> host(h->n_total), m(h->n_trainable, 0.f), v(h->n_trainable, 0.f);
+  HIP_TRY(h, hipMemcpy(host.data(), h->d_params, h->n_total * sizeof(float), hipMemcpyDeviceToHost));
+  TrainWS* w = tws(h);
+  if (w->adam_m) {
+    HIP_TRY(h, hipMemcpy(m.data(), w->adam_m, h->n_trainable * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(v.data(), w->adam_v, h->n_trainable * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return fail(h, std::string("alignnet_save: cannot open ") + tmp);
+  const char magic[8] = {'A', 'L', 'N', '3', 'C', 'K', 'P', '1'};
+  const int64_t step = h->step;
+  const int32_t nvars = (int32_t)h->params.size();
+  bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(&step, 8, 1, f) == 1 && std::fwrite(&nvars, 4, 1, f) == 1;
+  for (const ParamInfo& p : h->params) {
+    const int32_t len = (int32_t)p.name.size(), dims[3] = {p.rows, p.cols, p.trainable ? 1 : 0};
+    ok = ok && std::fwrite(&len, 4, 1, f) == 1 && std::fwrite(p.name.data(), 1, len, f) == (size_t)len && std::fwrite(dims, 4, 3, f) == 3;
+    ok = ok && std::fwrite(host.data() + p.offset, 4, p.count(), f) == p.count();
+    if (p.trainable) {
+      ok = ok && std::fwrite(m.data() + p.offset, 4, p.count(), f) == p.count();
+      ok = ok && std::fwrite(v.data() + p.offset, 4, p.count(), f) == p.count();
+    }
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path) != 0) return fail(h, std::string("alignnet_save: write failed for ") + path);
+  return 0;
+}
+
+extern "C" int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_step)
+{
+  if (!h) return 1;
+  if (!path) return fail(h, "alignnet_load: null path");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(h, std::string("alignnet_load: cannot open ") + path);
+  char magic[8]; int64_t step = 0; int32_t nvars = 0;
+  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "ALN3CKP1", 8) == 0 && std::fread(&step, 8, 1, f) == 1 &&
+            std::fread(&nvars, 4, 1, f) == 1;
+  if (!ok) { std::fclose(f); return fail(h, "alignnet_load: not an ALN3CKP1 checkpoint"); }
+  if (ensure_train_ws(h, 0)) { std::fclose(f); return 1; }
+  TrainWS* w = tws(h);
+  std::vector<float> host(h->n_total), m(h->n_trainable, 0.f), v(h->n_trainable, 0.f);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(host.data(), h->d_params, h->n_total * sizeof(float), hipMemcpyDeviceToHost));
+  int matched = 0;
+  for (int i = 0; i < nvars && ok; ++i) {
+    int32_t len = 0, dims[3];
+    ok = std::fread(&len, 4, 1, f) == 1 && len > 0 && len < 4096;
+    std::string name(ok ? len : 0, '\0');
+    ok = ok && std::fread(&name[0], 1, len, f) == (size_t)len && std::fread(dims, 4, 3, f) == 3;
+    if (!ok) break;
+    const size_t cnt = (size_t)dims[0] * dims[1];
+    std::vector<float> buf(cnt), bm, bv;
+    ok = std::fread(buf.data(), 4, cnt, f) == cnt;
+    if (ok && dims[2]) { bm.resize(cnt); bv.resize(cnt); ok = std::fread(bm.data(), 4, cnt, f) == cnt && std::fread(bv.data(), 4, cnt, f) == cnt; }
+    auto it = h->by_name.find(name);
+    if (!ok || it == h->by_name.end()) continue;
+    const ParamInfo& p = h->params[it->second];
+    if (p.count() != cnt) { std::fclose(f); return fail(h, "alignnet_load: shape mismatch for " + name); }
+    std::memcpy(host.data() + p.offset, buf.data(), cnt * 4);
+    if (p.trainable && dims[2]) { std::memcpy(m.data() + p.offset, bm.data(), cnt * 4); std::memcpy(v.data() + p.offset, bv.data(), cnt * 4); }
+    ++matched;
+  }
+  std::fclose(f);
+  if (!ok) return fail(h, "alignnet_load: truncated checkpoint");
+  if (matched != (int)h->params.size()) return fail(h, "alignnet_load: checkpoint does not hold every variable of this graph");
+  HIP_TRY(h, hipMemcpy(h->d_params, host.data(), h->n_total * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(w->adam_m, m.data(), h->n_trainable * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(w->adam_v, v.data(), h->n_trainable * sizeof(float), hipMemcpyHostToDevice));
+  if (!skip_step) h->step = step;   // the pre-training restore excludes `batch` (train.py:278-281)
+  h->folded = false;
+  return 0;
+}

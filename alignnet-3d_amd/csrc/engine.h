@@ -70,5 +70,9 @@ struct alignnet_handle {
   int64_t prof_backbone_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  // training / multi-GPU state (alignnet_train.hip)
+  void* train_ws = nullptr;
+  void* comm = nullptr;
+  int comm_world = 1, comm_rank = 0;
   mutable std::string err;
 };

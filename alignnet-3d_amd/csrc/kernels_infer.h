@@ -32,7 +32,7 @@ constexpr float kBnEps = 1e-3f;   // utils/tf_util.py:491
 //   Wp[((ct * KG + kg) * 64 + lane) * 4 + s] = W[8*kg + 4*(lane>>5) + s][32*ct + (lane&31)]
 // Out-of-range k / channel entries are zero.
 // ---------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, float* __restrict__ Wp)
+static __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, float* __restrict__ Wp)
 {
   const int KG = (K + 7) >> 3, CT = (C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 256;
@@ -46,7 +46,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, f
 }
 
 // scale/shift for one layer and one BN set; bn == nullptr -> plain bias.
-__global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
+static __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ var, int C, float* __restrict__ scale,
                                float* __restrict__ shift)
@@ -68,7 +68,7 @@ __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __re
 // (centre = mean, rotation = identity) and keeps the mean for tp8.py:109.
 // xform layout per cloud: c[3], R[9] row-major (p' = (p - c) @ R).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+static __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                       int B, int N, float* __restrict__ xform,
                                                       float* __restrict__ center_mean)
 {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void hidden_layer(const float* in, int ldi, float* ou
   for (int item = wave; item < CT * RG; item += kWaves) hidden_item<MR>(in, ldi, out, ldo, L, tower, item / RG, item % RG, lane);
 }
 
-__global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
+static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -266,7 +266,7 @@ struct FcArgs {
   int M, K, Nout, relu, rows_per_set;
 };
 
-__global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
+static __global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
 {
   __shared__ float red[3][16][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,7 +319,7 @@ __device__ __forceinline__ float floor_modf(float x, float y)   // tf.mod
 }
 
 // models/tp8.py:109: s1 = head + center_mean; next frame = (s1, I)
-__global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
+static __global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
                                      float* __restrict__ s1c, float* __restrict__ xform,
                                      float* __restrict__ out_c1, float* __restrict__ out_c2)
 {
@@ -338,7 +338,7 @@ __global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* 
 
 // models/tp8.py:117-125 + :294-301,202-212: s2 centre, logits, in-graph yaw decode,
 // R = rot_z(-theta) (tp8.py:26-27), next frame = (s2, R)
-__global__ void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
+static __global__ void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
                                      float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
                                      int* __restrict__ cls_out,
                                      float* __restrict__ out_c1, float* __restrict__ out_c2,
@@ -377,7 +377,7 @@ __global__ void stage2_finish_kernel(const float* __restrict__ o2, int ldo, cons
 }
 
 // models/tp8.py:155-156
-__global__ void final_finish_kernel(const float* __restrict__ net, int ldn, const float* __restrict__ s2c, int B, int nb,
+static __global__ void final_finish_kernel(const float* __restrict__ net, int ldn, const float* __restrict__ s2c, int B, int nb,
                                     float* __restrict__ out_t, float* __restrict__ out_l)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

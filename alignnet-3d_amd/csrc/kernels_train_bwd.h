@@ -1,0 +1,570 @@
+// Backward of the shared-MLP backbone in training mode (autodiff of models/tp8.py:49-59 through
+// utils/tf_util.py:455-492 batch-statistics BN and the max-pool), gfx950 only.
+//
+// Notation per tower and layer l: z = h_prev W + b, mu/var batch moments over the M = B*N rows,
+// r = rsqrt(var+eps), zhat = (z-mu) r, y = gamma zhat + beta, h = relu(y), k = gamma r.
+// BN backward:  dz = k (dy - dbeta/M - zhat dgamma/M),  dbeta = sum dy,  dgamma = sum dy zhat.
+//
+// Two exact identities remove the dense backward through the widest layer (conv3, 90 % of the FLOPs):
+//  (1) max-pool: dy3 is non-zero only at the arg-extreme point n*(b,c) of each (cloud, channel);
+//  (2) the remaining (BN-statistics) part of dz3 is per-channel affine in z3:  A_c + E_c z3[n,c],
+//      E = -k r dgamma/M, so with Ghat = h2^T h2 - s2 s2^T/M (centred Gram) and m2 = s2/M
+//        dW3 = Sp - m2 (k*dbeta)^T + (Ghat W3) diag(E),      Sp[:,c] = sum_b k g0[b,c] h2[b,n*,:]
+//        dh2 = (h2 - m2) Q3 - W3 (k*dbeta)/M + sparse rows,  Q3 = W3 diag(E) W3^T   (C2 x C2)
+// The same identity handles the statistics part of layer 2 (Q2, centred Gram of h1).
+// Passes (one workgroup per cloud, walking its 128-point tiles, recomputing h1/h2 from xyz):
+//   B2: dh2 -> dy2 (stored), dbeta2/dgamma2, U2 = h1^T dy2, Gram/colsum of h1
+//   B1: dh1 = dy2 V2 + (h1 - m1) Q2 + ... -> dy1 (stored), dbeta1/dgamma1
+//   B0: dz1 -> dW1 partials and the per-cloud input gradients (centre / yaw paths)
+#pragma once
+#include "kernels_train_fwd.h"
+
+namespace alignnet {
+
+constexpr int kZ2Slots = 1;   // C2 <= 8 waves * 32 = 256 columns of z2 kept in registers
+
+struct BwdB2Args {
+  const float* pcs[2]; const float* xform; int B, N, C1, C2, C3;
+  int ld0, ldb;                 // LDS leading dims: h1 view, and the two big buffers
+  const float* w1; const float* wp2;
+  const float *sc1, *sh1;       // [2][C1]
+  const float *sc2, *sh2;       // [2][C2]
+  const float* b2; const float *mean2, *rstd2;   // [C2], [2][C2], [2][C2]
+  const float* q3img;           // per tower: MFMA image of Q3 [C2][C2]; tower stride q3img_stride floats
+  long q3img_stride;
+  const float* q3b;             // [2][C2]: -m2 Q3 - W3 (k*dbeta)/M
+  const float* gs;              // [2B][C3]  k3 * g0
+  const int* idx;               // [2B][C3]
+  const float* w3t;             // [C3][C2]
+  float* dy2_store;             // [2B*N][C2]
+  double* dbg2_part;            // [2B][2 halves][C2][2]  (dbeta2, dgamma2)
+  float* u2_part;               // [2B][C1*C2]
+  float* g1_part;               // [2B][C1*C1]
+  double* s1_part;              // [2B][C1]
+};
+
+__global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;
+  float* X = smem + kTilePts * 4;
+  float* Y = X + kTilePts * a.ldb;
+  const int ld0 = a.ld0, ldb = a.ldb;
+  const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
+  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
+
+  const int half = lane >> 5;
+  double* my_dbg = a.dbg2_part + ((size_t)cloud * 2 + half) * a.C2 * 2;   // lane-owned slices (see kernels_train_fwd.h)
+  float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
+  float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const bool first = tile == 0;
+    __syncthreads();
+    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    __syncthreads();
+    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    __syncthreads();
+
+    // ---- layer 2 forward: keep z2 (pre-BN, minus bias) in registers, h2 -> Y ----
+    f32x16 z2[kZ2Slots][4];
+#pragma unroll
+    for (int s = 0; s < kZ2Slots; ++s) {
+      const int ct = wave + s * kWaves;
+      if (ct < CT2) {
+        mfma_rows<4>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2[s]);
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C2;
+        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        if (col < ((a.C2 + 7) & ~7)) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = acc_row(m, r, lane);
+              Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[s][m][r], sc, sh), 0.f) : 0.f;
+            }
+        }
+      }
+    }
+    // Gram / column sums of h1 (X) -- needed by the statistics part of layer 2's backward
+    for (int item = kWaves - 1 - wave; item < CT1 * CT1; item += kWaves) {   // waves without a z2 tile go first
+      const int it = item / CT1, jt = item % CT1;
+      const float* pa = X + half * ld0 + it * 32 + (lane & 31);
+      const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
+      const int j = jt * 32 + (lane & 31);
+      if (j < a.C1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = it * 32 + acc_row(0, r, lane);
+          if (i < a.C1) { float* d = my_g1 + (size_t)i * a.C1 + j; *d = first ? g[r] : *d + g[r]; }
+        }
+      }
+    }
+    if (tid < a.C1) {
+      float sm = 0.f;
+      for (int r = 0; r < kTilePts; ++r) sm += X[r * ld0 + tid];
+      double* d = a.s1_part + (size_t)cloud * a.C1 + tid;
+      *d = first ? (double)sm : *d + (double)sm;
+    }
+    __syncthreads();
+
+    // ---- sparse rows of dh2: X <- 0, then X[n*-tile0][:] += gs[b,c] * W3[:,c]  (deterministic: wave w owns rows = w mod 8) ----
+    for (int i = tid; i < kTilePts * ldb; i += kWaves * 64) X[i] = 0.f;
+    __syncthreads();
+    for (int base = 0; base < a.C3; base += 64) {
+      const int c = base + lane;
+      const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTilePts : -1;
+      const bool hit = rel >= 0 && rel < nvalid && (rel & (kWaves - 1)) == wave;
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int row = __shfl(rel, l);
+        const int cc = base + l;
+        const float g = a.gs[(size_t)cloud * a.C3 + cc];
+        for (int k = lane; k < a.C2; k += 64) X[row * ldb + k] += g * a.w3t[(size_t)cc * a.C2 + k];
+      }
+    }
+    __syncthreads();
+
+    // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
+#pragma unroll
+    for (int s = 0; s < kZ2Slots; ++s) {
+      const int ct = wave + s * kWaves;
+      if (ct < CT2) {
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C2;
+        const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
+        f32x16 acc[4];
+        {
+          // accumulate h2 Q3 on top of the sparse rows
+          const f32x4* Wp = q3img + (size_t)ct * KGq * 64;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
+          const float* arow = Y + (lane & 31) * ldb + (lane >> 5) * 4;
+          for (int kg = 0; kg < KGq; ++kg) {
+            const f32x4 bv = Wp[kg * 64 + lane];
+            f32x4 av[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ldb + kg * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[q], acc[m], 0, 0, 0);
+          }
+        }
+        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
+        const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
+        float lb = 0.f, lg = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(m, r, lane);
+            const bool on = row < nvalid && fmaf(z2[s][m][r], sc, sh) > 0.f;
+            const float dy = on ? acc[m][r] : 0.f;
+            const float zh = (z2[s][m][r] + bias - mu) * rs;
+            lb += dy; lg += dy * zh;
+            z2[s][m][r] = dy;   // reuse the registers for dy2
+          }
+        if (live) {
+          my_dbg[col * 2] = first ? (double)lb : my_dbg[col * 2] + (double)lb;
+          my_dbg[col * 2 + 1] = first ? (double)lg : my_dbg[col * 2 + 1] + (double)lg;
+        }
+      }
+    }
+    __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
+
+    // ---- dy2 -> Y ; h1 -> X again ----
+#pragma unroll
+    for (int s = 0; s < kZ2Slots; ++s) {
+      const int ct = wave + s * kWaves;
+      if (ct < CT2) {
+        const int col = ct * 32 + (lane & 31);
+        if (col < ((a.C2 + 7) & ~7)) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[s][m][r] : 0.f;
+        }
+      }
+    }
+    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    __syncthreads();
+
+    // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
+    {
+      float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      const int c4 = a.C2 >> 2;   // C2 % 4 == 0 (multiple of 32 enforced on the host)
+      for (int i = tid; i < nvalid * c4; i += kWaves * 64) {
+        const int row = i / c4, q = i % c4;
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
+      }
+      for (int item = wave; item < CT1 * CT2; item += kWaves) {
+        const int it = item / CT2, jt = item % CT2;
+        const float* pa = X + half * ld0 + it * 32 + (lane & 31);
+        const float* pb = Y + half * ldb + jt * 32 + (lane & 31);
+        f32x16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < kTilePts; r += 2) u = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldb], u, 0, 0, 0);
+        const int j = jt * 32 + (lane & 31);
+        if (j < a.C2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = it * 32 + acc_row(0, r, lane);
+            if (i < a.C1) { float* d = my_u2 + (size_t)i * a.C2 + j; *d = first ? u[r] : *d + u[r]; }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// B1: dh1 = dy2 V2 + h1 Q2 + q2b ; dy1 = dh1 * [h1 > 0] (stored) ; dbeta1 / dgamma1 partials
+// ---------------------------------------------------------------------------------
+struct BwdB1Args {
+  const float* pcs[2]; const float* xform; int B, N, C1, C2;
+  int ld0, ldb;
+  const float* w1; const float *sc1, *sh1;
+  const float* b1; const float *mean1, *rstd1;      // [C1], [2][C1], [2][C1]
+  const float* v2img; const float* q2img; long v2img_stride, q2img_stride;   // per-tower MFMA images: V2 [C2][C1], Q2 [C1][C1]
+  const float* q2b;                                  // [2][C1]
+  const float* dy2_store;
+  float* dy1_store;                                  // [2B*N][C1]
+  double* dbg1_part;                                 // [2B][8 = 4 row groups x 2 halves][C1][2]
+};
+
+__global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b1(const BwdB1Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;
+  float* X = smem + kTilePts * 4;            // h1   [128][ld0]
+  float* Y = X + kTilePts * a.ld0;           // dy2  [128][ldb]
+  const int ld0 = a.ld0, ldb = a.ldb;
+  const int CT1 = (a.C1 + 31) >> 5, KGv = (a.C2 + 7) >> 3, KGq = (a.C1 + 7) >> 3;
+  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
+  const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
+  // items: (column tile ct, row group rg of 32 rows); item = wave + s*8 ; at most kStatSlots per wave (C1 <= 256)
+  const int nitems = CT1 * 4;
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const bool first = tile == 0;
+    __syncthreads();
+    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    {
+      const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      const int c4 = a.C2 >> 2;
+      for (int i = tid; i < kTilePts * c4; i += kWaves * 64) {
+        const int row = i / c4, q = i % c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
+      }
+    }
+    __syncthreads();
+    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    __syncthreads();
+    for (int item = wave; item < nitems; item += kWaves) {
+      {
+        const int ct = item >> 2, rg = item & 3;
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C1;
+        f32x16 acc;
+        const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = qb;
+        {
+          const float* arow = Y + (rg * 32 + (lane & 31)) * ldb + (lane >> 5) * 4;
+          const f32x4* Wp = v2img + (size_t)ct * KGv * 64;
+          for (int kg = 0; kg < KGv; ++kg) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8), bv = Wp[kg * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+          }
+        }
+        {
+          const float* arow = X + (rg * 32 + (lane & 31)) * ld0 + (lane >> 5) * 4;
+          const f32x4* Wp = q2img + (size_t)ct * KGq * 64;
+          for (int kg = 0; kg < KGq; ++kg) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8), bv = Wp[kg * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+          }
+        }
+        const float w0 = live ? a.w1[col] : 0.f, wa = live ? a.w1[a.C1 + col] : 0.f, wb = live ? a.w1[2 * a.C1 + col] : 0.f;
+        const float bias = live ? a.b1[col] : 0.f, mu = live ? a.mean1[tower * a.C1 + col] : 0.f;
+        const float rs = live ? a.rstd1[tower * a.C1 + col] : 0.f;
+        float lb = 0.f, lg = 0.f;
+        float* dst = a.dy1_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
+          const float dy = on ? acc[r] : 0.f;
+          const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+          const float z = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0)) + bias;
+          lb += dy; lg += dy * ((z - mu) * rs);
+          if (live && row < nvalid) dst[(size_t)row * a.C1 + col] = dy;
+        }
+        if (live) {   // slice (rg, half) of this cloud
+          double* d = a.dbg1_part + (((size_t)cloud * 8 + rg * 2 + (lane >> 5)) * a.C1 + col) * 2;
+          d[0] = first ? (double)lb : d[0] + (double)lb;
+          d[1] = first ? (double)lg : d[1] + (double)lg;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// B0: dz1 = k1 (dy1 - dbeta1/M - zhat1 dgamma1/M); per cloud: P[d][c] = sum_n x'[n,d] dz1[n,c], S[c] = sum_n dz1[n,c]
+// then  gx[d] = sum_c W1[d,c] S[c],  grot = sum_c (W1[0,c] P[1][c] - W1[1,c] P[0][c])
+// grid: 2B workgroups of 256 threads
+// ---------------------------------------------------------------------------------
+struct BwdB0Args {
+  const float* pcs[2]; const float* xform; int B, N, C1;
+  const float* w1; const float* b1; const float *mean1, *rstd1, *k1;   // k1 = gamma1*rstd1 [2][C1]
+  const float* dbg1;            // [2][C1][2] totals (dbeta1, dgamma1)
+  double count;                 // M
+  const float* dy1_store;
+  float* p_part;                // [2B][3][C1]
+  float* gx; float* grot;       // [2B][3], [2B]
+};
+
+__global__ __launch_bounds__(256) void train_bwd_b0(const BwdB0Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B, tid = threadIdx.x;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  constexpr int kChunk = 1024;
+  float* xs = smem;                                              // [kChunk][4]
+  double* red = reinterpret_cast<double*>(smem + kChunk * 4);    // [256][4]
+  float* fin = reinterpret_cast<float*>(red + 256 * 4);          // [C1][4]
+  const int C1 = a.C1;
+  float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gr = 0.f;
+  for (int c0 = 0; c0 < C1; c0 += 256) {
+    const int span = min(C1 - c0, 256), per = 256 / span;
+    const int c = c0 + tid % span, rg = tid / span;
+    const bool active = rg < per;
+    const float w0 = a.w1[c], wa = a.w1[C1 + c], wb = a.w1[2 * C1 + c], bias = a.b1[c];
+    const float mu = a.mean1[tower * C1 + c], rs = a.rstd1[tower * C1 + c], k = a.k1[tower * C1 + c];
+    const float mb = (float)((double)a.dbg1[(tower * C1 + c) * 2] / a.count), mg = (float)((double)a.dbg1[(tower * C1 + c) * 2 + 1] / a.count);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, sz = 0.0;
+    for (int base = 0; base < a.N; base += kChunk) {
+      const int cnt = min(kChunk, a.N - base);
+      __syncthreads();
+      for (int i = tid; i < cnt; i += 256) {
+        const float* p = pc + (size_t)(base + i) * 3;
+        const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+        xs[i * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+        xs[i * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+        xs[i * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+      }
+      __syncthreads();
+      if (active)
+        for (int i = rg; i < cnt; i += per) {
+          const float x0 = xs[i * 4], x1 = xs[i * 4 + 1], x2 = xs[i * 4 + 2];
+          const float zz = fmaf(x2, wb, fmaf(x1, wa, x0 * w0)) + bias;
+          const float zh = (zz - mu) * rs;
+          const float dz = k * (a.dy1_store[((size_t)cloud * a.N + base + i) * C1 + c] - mb - zh * mg);
+          p0 += (double)(x0 * dz); p1 += (double)(x1 * dz); p2 += (double)(x2 * dz); sz += (double)dz;
+        }
+    }
+    red[tid * 4 + 0] = active ? p0 : 0.0; red[tid * 4 + 1] = active ? p1 : 0.0;
+    red[tid * 4 + 2] = active ? p2 : 0.0; red[tid * 4 + 3] = active ? sz : 0.0;
+    __syncthreads();
+    if (tid < span) {
+      double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      for (int g = 0; g < per; ++g) {
+        const double* r = red + (g * span + tid) * 4;
+        t0 += r[0]; t1 += r[1]; t2 += r[2]; t3 += r[3];
+      }
+      const int cc = c0 + tid;
+      a.p_part[((size_t)cloud * 3 + 0) * C1 + cc] = (float)t0;
+      a.p_part[((size_t)cloud * 3 + 1) * C1 + cc] = (float)t1;
+      a.p_part[((size_t)cloud * 3 + 2) * C1 + cc] = (float)t2;
+      fin[cc * 4 + 0] = (float)t0; fin[cc * 4 + 1] = (float)t1; fin[cc * 4 + 2] = (float)t2; fin[cc * 4 + 3] = (float)t3;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int c = 0; c < C1; ++c) {
+      const float w0 = a.w1[c], wa = a.w1[C1 + c], wb = a.w1[2 * C1 + c];
+      gx0 += w0 * fin[c * 4 + 3]; gx1 += wa * fin[c * 4 + 3]; gx2 += wb * fin[c * 4 + 3];
+      gr += w0 * fin[c * 4 + 1] - wa * fin[c * 4 + 0];
+    }
+    a.gx[cloud * 3 + 0] = gx0; a.gx[cloud * 3 + 1] = gx1; a.gx[cloud * 3 + 2] = gx2;
+    a.grot[cloud] = gr;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// small "prep" kernels between the passes
+// ---------------------------------------------------------------------------------
+// sum of per-cloud partials over one tower's clouds: out[t][i] = sum_b part[(t*B+b)*n + i]   (fp64 accumulate)
+template <typename T>
+__global__ void reduce_clouds_kernel(const T* __restrict__ part, int B, long n, float* __restrict__ out)
+{
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) s += (double)part[(size_t)(t * B + b) * n + i];
+  out[(size_t)t * n + i] = (float)s;
+}
+
+// centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
+__global__ void centre_gram_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m)
+{
+  const int t = blockIdx.y;
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= (long)C * C) return;
+  const int i = e / C, j = e % C;
+  G[(size_t)t * C * C + e] = (float)((double)G[(size_t)t * C * C + e] - (double)s[t * C + i] * (double)s[t * C + j] / M);
+  if (j == 0) m[t * C + i] = (float)((double)s[t * C + i] / M);
+}
+
+// last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0
+struct Prep3Args {
+  const float* dP; long tower_stride, row_stride;   // dL/dpooled in the pooled layout
+  const float* pooled;                              // same layout
+  const float* zhat_star;                           // [2B][C]
+  const float* gamma[2]; const float* var;          // [2][C]
+  int B, C; double M;
+  float* dbeta[2]; float* dgamma[2];
+  float* E; float* kdb; float* gs;                  // [2][C], [2][C], [2B][C]
+};
+
+__global__ void prep3_kernel(const Prep3Args a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (c >= a.C) return;
+  const float rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps), k = a.gamma[t][c] * rs;
+  double sb = 0.0, sg = 0.0;
+  for (int b = 0; b < a.B; ++b) {
+    const size_t pi = t * a.tower_stride + b * a.row_stride + c;
+    const float g0 = a.pooled[pi] > 0.f ? a.dP[pi] : 0.f;
+    const size_t ci = (size_t)(t * a.B + b) * a.C + c;
+    sb += g0; sg += (double)g0 * a.zhat_star[ci];
+    a.gs[ci] = k * g0;
+  }
+  a.dbeta[t][c] = (float)sb;
+  a.dgamma[t][c] = (float)sg;
+  a.E[t * a.C + c] = (float)(-(double)k * rs * sg / a.M);
+  a.kdb[t * a.C + c] = (float)((double)k * sb);
+}
+
+// hidden layer (after its pass): E = -k r dgamma/M, kdb = k*dbeta, k, rstd from totals
+__global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, const float* __restrict__ var,
+                                   const float* g0p, const float* g1p, int C, double M, float* __restrict__ dbeta0,
+                                   float* __restrict__ dbeta1, float* __restrict__ dgamma0, float* __restrict__ dgamma1,
+                                   float* __restrict__ E, float* __restrict__ kdb, float* __restrict__ kk, float* __restrict__ rstd)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (c >= C) return;
+  const float gam = t ? g1p[c] : g0p[c];
+  const float rs = 1.0f / sqrtf(var[t * C + c] + kBnEps), k = gam * rs;
+  const float sb = dbg[(t * C + c) * 2], sg = dbg[(t * C + c) * 2 + 1];
+  (t ? dbeta1 : dbeta0)[c] = sb;
+  (t ? dgamma1 : dgamma0)[c] = sg;
+  if (E) E[t * C + c] = (float)(-(double)k * rs * sg / M);
+  if (kdb) kdb[t * C + c] = k * sb;
+  if (kk) kk[t * C + c] = k;
+  if (rstd) rstd[t * C + c] = rs;
+}
+
+// Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block C2 (<= 256)
+__global__ void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                 int B, int N, int C2, int C3, float* __restrict__ Sp)
+{
+  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
+  if (k >= C2) return;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const size_t cloud = (size_t)t * B + b;
+    const float g = gs[cloud * C3 + c];
+    if (g != 0.f) s += (double)g * h2[(cloud * N + idx[cloud * C3 + c]) * C2 + k];
+  }
+  Sp[((size_t)t * C2 + k) * C3 + c] = (float)s;
+}
+
+// out[t][i][j] = W[i][j] * col[t][j]   (scale columns)  /  transposed variants via strides
+__global__ void scale_cols_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ col, float* __restrict__ out,
+                                  int transpose_out)
+{
+  const int t = blockIdx.y;
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= (long)R * C) return;
+  const int i = e / C, j = e % C;
+  const float v = W[e] * (col ? col[t * C + j] : 1.f);
+  if (transpose_out) out[(size_t)t * R * C + (size_t)j * R + i] = v;
+  else out[(size_t)t * R * C + e] = v;
+}
+
+// dW[i][j] (+)= sum_t ( Sp[t][i][j]*spscale[t][j] - m[t][i]*kdb[t][j] + GW[t][i][j]*E[t][j] )
+__global__ void combine_dw_kernel(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
+                                  const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
+                                  int R, int C, float* __restrict__ dW)
+{
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= (long)R * C) return;
+  const int i = e / C, j = e % C;
+  float s = 0.f;
+  for (int t = 0; t < 2; ++t) {
+    const size_t o = (size_t)t * R * C + e;
+    s += Sp[o] * (spscale ? spscale[t * C + j] : 1.f) - m[t * R + i] * kdb[t * C + j] + GW[o] * E[t * C + j];
+  }
+  dW[e] = s;
+}
+
+// qb[t][j] = -sum_i m[t][i] Q[t][i][j] - sum_c W[j][c] kdb[t][c] / M      (W: [R=Cin][C=Cout])
+__global__ void qbias_kernel(const float* __restrict__ Q, const float* __restrict__ m, const float* __restrict__ W,
+                             const float* __restrict__ kdb, int Cin, int Cout, double M, float* __restrict__ qb)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (j >= Cin) return;
+  double s = 0.0;
+  for (int i = 0; i < Cin; ++i) s -= (double)m[t * Cin + i] * Q[((size_t)t * Cin + i) * Cin + j];
+  double w = 0.0;
+  for (int c = 0; c < Cout; ++c) w += (double)W[(size_t)j * Cout + c] * kdb[t * Cout + c];
+  qb[t * Cin + j] = (float)(s - w / M);
+}
+
+// dW1[d][c] = sum over all clouds of P ; grid covers 3*C1
+__global__ void sum_p_kernel(const float* __restrict__ p_part, int nclouds, int n, float* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nclouds; ++b) s += (double)p_part[(size_t)b * n + i];
+  out[i] = (float)s;
+}
+
+}  // namespace alignnet

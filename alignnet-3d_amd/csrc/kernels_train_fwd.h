@@ -1,0 +1,364 @@
+// Training-mode forward of the shared-MLP backbone (models/tp8.py:49-59 with is_training=True,
+// utils/tf_util.py:455-492 batch-statistics BatchNorm), gfx950 only.
+//
+// Training BN couples all B*N points of a tower, so the forward is three grid-wide phases; each phase
+// recomputes the cheap earlier layers from xyz (inputs are 12 B/point) instead of round-tripping
+// [B*N, C] activations through HBM:
+//   phase 1: statistics of z1 = x' W1 + b1                      (VALU, K = 3)
+//   phase 2: h1 = relu(bn1(z1));  statistics of z2 = h1 W2 + b2 (MFMA)
+//   phase 3: h1, h2;  z3 = h2 W3 + b3: statistics, and -- because
+//              max_n relu(g*z_n + b) = relu(g * max_n z_n + b)   for g >= 0   (min_n for g < 0)
+//            -- only the per-(cloud, channel) extreme of sign(gamma)*z3 and its point index.  z3
+//            ([B*N, 1024]) is never materialised.  The same pass accumulates the Gram matrix
+//            h2^T h2 and the column sums of h2, which is all the dense part of the conv3 backward needs
+//            (kernels_train_bwd.h), and stores h2 for the sparse (arg-max) part.
+// One workgroup per cloud walks its 128-point tiles; sums are kept in fp64 per lane (sum, sum of
+// squares -> biased variance E[z^2]-E[z]^2 without fp32 cancellation), then one partial per cloud.
+#pragma once
+#include "kernels_infer.h"
+
+namespace alignnet {
+
+
+struct TrainFwdArgs {
+  const float* pcs[2];
+  const float* xform;      // [2B][12]
+  int B, N;
+  int C1, C2, C3;
+  int ld[2];               // LDS leading dims: buf0 holds h1 ([128][C1r+4]), buf1 holds h2 ([128][C2r+4])
+  const float* w1;         // [3][C1]
+  const float* wp2;        // MFMA image of W2 [C1][C2]
+  const float* wp3;        // MFMA image of W3 [C2][C3]
+  const float *b1, *b2, *b3;       // conv biases (added before BN: utils/tf_util.py:161)
+  const float *sc1, *sh1;  // [2][C1] batch-stat scale/shift of layer 1 (phase >= 2)
+  const float *sc2, *sh2;  // [2][C2] (phase 3)
+  const float* sgn3;       // [2][C3] sign(gamma3) as +1/-1 (phase 3)
+  double* stat_part;       // [2B][2 halves][C][2] partial (sum, sumsq) of this phase's layer (phase 1: [2B][1][C][2])
+  float* ext;              // [2B][2 halves][C3] extreme of sgn*z3   (phase 3)
+  int* idx;                // [2B][2 halves][C3] its point index
+  float* gram_part;        // [2B][C2*C2]
+  double* colsum_part;     // [2B][2 halves][C2]
+  float* h2_store;         // [2B*N][C2]
+};
+
+// x' = (p - c) @ R for the tile's 128 points -> xs[128][4]; rows past N repeat the last point (masked later)
+__device__ __forceinline__ void load_tile_xform(const float* __restrict__ pc, const float* __restrict__ xf, int N,
+                                                int tile, float* __restrict__ xs, int tid)
+{
+  if (tid < kTilePts) {
+    const int n = min(tile * kTilePts + tid, N - 1);
+    const float* p = pc + (size_t)n * 3;
+    const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+    xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+    xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+    xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+  }
+}
+
+// layer 1 on the VALU: out[row][c] = relu((x' . w[:,c]) * sc + sh); rows >= nvalid are written as 0
+__device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
+                                              const float* __restrict__ sc, const float* __restrict__ sh,
+                                              float* __restrict__ out, int ldo, int nvalid, int tid)
+{
+  const int c0 = tid & 31, r0 = tid >> 5;
+  const int cw = (C1 + 7) & ~7;
+  for (int c = c0; c < cw; c += 32) {
+    const bool live = c < C1;
+    const float w0 = live ? w1[c] : 0.f, wa = live ? w1[C1 + c] : 0.f, wb = live ? w1[2 * C1 + c] : 0.f;
+    const float s = live ? sc[c] : 0.f, t = live ? sh[c] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kTilePts / 16; ++rr) {
+      const int row = rr * 16 + r0;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+      const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+      out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------
+// phase 1: statistics of z1 (one workgroup per cloud, 256 threads)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;   // [chunk][4]
+  constexpr int kChunk = 2048;
+  const int C1 = a.C1;
+  // thread -> (channel, row group): groups of C1r threads share a row stride
+  const int nthreads = blockDim.x;
+  double* red = reinterpret_cast<double*>(smem + kChunk * 4);   // [nthreads][2]
+  for (int c0 = 0; c0 < C1; c0 += nthreads) {
+    // each thread owns channel c (if < C1) and walks ALL rows when C1 >= nthreads; otherwise rows are split
+    const int per = max(1, nthreads / max(C1, 1));        // row groups
+    const int span = min(C1 - c0, nthreads);
+    const int c = c0 + (threadIdx.x % span), rg = threadIdx.x / span;
+    const bool active = rg < per && (threadIdx.x < span * per);
+    double s = 0.0, ss = 0.0;
+    const float w0 = a.w1[c], wa = a.w1[C1 + c], wb = a.w1[2 * C1 + c], bias = a.b1[c];
+    for (int base = 0; base < a.N; base += kChunk) {
+      const int cnt = min(kChunk, a.N - base);
+      __syncthreads();
+      for (int i = threadIdx.x; i < cnt; i += nthreads) {
+        const float* p = pc + (size_t)(base + i) * 3;
+        const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+        xs[i * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+        xs[i * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+        xs[i * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+      }
+      __syncthreads();
+      if (active)
+        for (int i = rg; i < cnt; i += per) {
+          const float zz = fmaf(xs[i * 4 + 2], wb, fmaf(xs[i * 4 + 1], wa, xs[i * 4] * w0)) + bias;
+          s += (double)zz;
+          ss += (double)zz * (double)zz;
+        }
+    }
+    red[threadIdx.x * 2] = active ? s : 0.0;
+    red[threadIdx.x * 2 + 1] = active ? ss : 0.0;
+    __syncthreads();
+    if (threadIdx.x < span) {
+      double ts = 0.0, tss = 0.0;
+      for (int g = 0; g < per; ++g) { ts += red[(g * span + threadIdx.x) * 2]; tss += red[(g * span + threadIdx.x) * 2 + 1]; }
+      a.stat_part[((size_t)cloud * C1 + c0 + threadIdx.x) * 2] = ts;
+      a.stat_part[((size_t)cloud * C1 + c0 + threadIdx.x) * 2 + 1] = tss;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// phases 2 and 3 (one workgroup of 8 waves per cloud).
+// Per-lane running sums live in lane-owned global slots ("slices", L2-resident, read-modify-write once per
+// tile, no atomics): every accumulator element has exactly one owner lane, so the result is deterministic.
+// Slice layout: part[(cloud * S + slice) * n + i]; the two half-waves of a column are slices 0/1.
+// ---------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;
+  float* buf0 = smem + kTilePts * 4;
+  float* buf1 = buf0 + kTilePts * a.ld[0];
+  const int ld0 = a.ld[0], ld1 = a.ld[1];
+  const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
+  const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
+  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const int Cs = PHASE == 2 ? a.C2 : a.C3;
+  double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2]
+  float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
+  int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
+  double* my_col = PHASE == 3 ? a.colsum_part + ((size_t)cloud * 2 + half) * a.C2 : nullptr;
+  float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * a.C2 * a.C2 : nullptr;
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const bool first = tile == 0;
+    __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
+    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    __syncthreads();
+    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, buf0, ld0, nvalid, tid);
+    __syncthreads();
+
+    // ---- layer 2: z2 = h1 W2 + b2 for all 128 rows ----
+    for (int ct = wave; ct < CT2; ct += kWaves) {
+      f32x16 acc[4];
+      mfma_rows<4>(buf0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < a.C2;
+      if (PHASE == 2) {
+        const float bias = live ? a.b2[col] : 0.f;
+        double ls = 0.0, lss = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (acc_row(m, r, lane) < nvalid) {
+              const double z = (double)(acc[m][r] + bias);
+              ls += z; lss += z * z;
+            }
+        }
+        if (live) {
+          my_stat[col * 2] = first ? ls : my_stat[col * 2] + ls;
+          my_stat[col * 2 + 1] = first ? lss : my_stat[col * 2 + 1] + lss;
+        }
+      } else {
+        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        float lsum = 0.f;
+        const bool wr = col < ((a.C2 + 7) & ~7);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(m, r, lane);
+            const float h = row < nvalid ? fmaxf(fmaf(acc[m][r], sc, sh), 0.f) : 0.f;
+            lsum += h;
+            if (wr) buf1[row * ld1 + col] = h;
+          }
+        if (live) my_col[col] = first ? (double)lsum : my_col[col] + (double)lsum;
+      }
+    }
+    if (PHASE == 2) continue;
+    __syncthreads();
+
+    // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
+    {
+      float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      const int c4 = a.C2 >> 2;
+      for (int i = tid; i < nvalid * c4; i += kWaves * 64) {
+        const int row = i / c4, q = i % c4;
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(buf1 + row * ld1 + q * 4);
+      }
+    }
+
+    // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's 128 rows ----
+    for (int item = wave; item < CT2 * CT2; item += kWaves) {
+      const int it = item / CT2, jt = item % CT2;
+      const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
+      const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld1], pb[r * ld1], g, 0, 0, 0);
+      const int j = jt * 32 + (lane & 31);
+      if (j < a.C2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = it * 32 + acc_row(0, r, lane);
+          if (i < a.C2) {
+            float* d = my_gram + (size_t)i * a.C2 + j;
+            *d = first ? g[r] : *d + g[r];
+          }
+        }
+      }
+    }
+
+    // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
+    for (int ct = wave; ct < CT3; ct += kWaves) {
+      f32x16 acc[4];
+      mfma_rows<4>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < a.C3;
+      const float bias = live ? a.b3[col] : 0.f;
+      const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
+      double ls = 0.0, lss = 0.0;
+      float be = (first || !live) ? -INFINITY : my_ext[col];
+      int bi = (first || !live) ? 0 : my_idx[col];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = acc_row(m, r, lane);
+          if (row < nvalid) {
+            const float z = acc[m][r] + bias;
+            const double zd = (double)z;
+            ls += zd; lss += zd * zd;
+            const float v = z * sg;
+            if (v > be) { be = v; bi = tile * kTilePts + row; }
+          }
+        }
+      }
+      if (live) {
+        my_stat[col * 2] = first ? ls : my_stat[col * 2] + ls;
+        my_stat[col * 2 + 1] = first ? lss : my_stat[col * 2 + 1] + lss;
+        my_ext[col] = be; my_idx[col] = bi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// statistics finish: partials [B clouds of one tower] -> mean / biased variance (tf.nn.moments),
+// batch-stat scale/shift for the recompute passes, EMA shadows (utils/tf_util.py:476-485),
+// and (last layer) the pooled feature  relu(gamma*inv*(z* - mean) + beta).
+// grid: (ceil(C/256), 2 towers)
+// ---------------------------------------------------------------------------------
+struct StatFinishArgs {
+  const double* part;        // [2B * slices][C][2]
+  int B, C, slices; double count;    // rows per tower = B*N
+  const float* bias;         // [C] shared
+  const float* beta[2]; const float* gamma[2];
+  float* mov_mean[2]; float* mov_var[2];
+  float bn_decay; int update_ema;
+  float* mean; float* var;   // [2][C] batch statistics (kept for the backward)
+  float* scale; float* shift;   // [2][C]: y = acc*scale + shift  (acc = z - bias)
+  float* sgn;                // [2][C] or null: sign(gamma) for the next phase
+};
+
+__global__ void stat_finish_kernel(const StatFinishArgs a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (c >= a.C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < a.B * a.slices; ++b) {
+    const double* p = a.part + ((size_t)(t * a.B * a.slices + b) * a.C + c) * 2;
+    s += p[0]; ss += p[1];
+  }
+  const double mean = s / a.count;
+  const double var = fmax(ss / a.count - mean * mean, 0.0);
+  const float mf = (float)mean, vf = (float)var;
+  a.mean[t * a.C + c] = mf;
+  a.var[t * a.C + c] = vf;
+  const float inv = a.gamma[t][c] * (1.0f / sqrtf(vf + kBnEps));
+  a.scale[t * a.C + c] = inv;
+  a.shift[t * a.C + c] = (a.bias[c] - mf) * inv + a.beta[t][c];
+  if (a.sgn) a.sgn[t * a.C + c] = a.gamma[t][c] >= 0.f ? 1.f : -1.f;
+  if (a.update_ema) {
+    // ExponentialMovingAverage.apply: shadow -= (1 - decay) * (shadow - value)
+    a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);
+    a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
+  }
+}
+
+__global__ void sign_kernel(const float* __restrict__ gamma, int C, float* __restrict__ sgn)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) sgn[c] = gamma[c] >= 0.f ? 1.f : -1.f;
+}
+
+// rstd[t][c] = rsqrt(var+eps), k[t][c] = gamma_t[c]*rstd
+__global__ void rstd_k_kernel(const float* __restrict__ var, const float* __restrict__ g0, const float* __restrict__ g1, int C,
+                              float* __restrict__ rstd, float* __restrict__ k)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (c >= C) return;
+  const float rs = 1.0f / sqrtf(var[t * C + c] + kBnEps);
+  rstd[t * C + c] = rs;
+  k[t * C + c] = (t ? g1[c] : g0[c]) * rs;
+}
+
+// pooled[t,b,c] = relu(scale*(sgn*ext - bias) + shift);  also keeps zhat* = (z* - mean)*rsqrt(var+eps) and the
+// final arg-extreme index (combining the two half-wave slices; first occurrence wins ties)
+__global__ void pool_finish_kernel(const float* __restrict__ ext, const int* __restrict__ idx2, const float* __restrict__ sgn,
+                                   const float* __restrict__ bias, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const float* __restrict__ mean,
+                                   const float* __restrict__ var, int B, int C, float* __restrict__ pooled,
+                                   long tower_stride, long row_stride, float* __restrict__ zhat_star, int* __restrict__ idx)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)2 * B * C) return;
+  const int c = i % C, cloud = i / C, t = cloud >= B, b = cloud - t * B;
+  const size_t h0 = ((size_t)cloud * 2) * C + c, h1 = h0 + C;
+  float e = ext[h0]; int bi = idx2[h0];
+  if (ext[h1] > e || (ext[h1] == e && idx2[h1] < bi)) { e = ext[h1]; bi = idx2[h1]; }
+  idx[i] = bi;
+  const float z = e * sgn[t * C + c];
+  const float y = fmaf(z - bias[c], scale[t * C + c], shift[t * C + c]);
+  pooled[t * tower_stride + b * row_stride + c] = fmaxf(y, 0.f);
+  zhat_star[i] = (z - mean[t * C + c]) * (1.0f / sqrtf(var[t * C + c] + kBnEps));
+}
+
+}  // namespace alignnet

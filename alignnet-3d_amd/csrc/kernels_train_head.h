@@ -1,0 +1,424 @@
+// Training kernels for the small dense parts: head MLPs (models/tp8.py:75-82), the glue between
+// stages (:109,117-127,155) and the `separate` loss with its gradient (:304-354).  gfx950 only.
+// These are latency-bound (M = 2B rows); the design goal is few, simple launches.
+#pragma once
+#include "kernels_infer.h"
+
+namespace alignnet {
+
+// ---------------------------------------------------------------------------------
+// gemm_small: C[i][j] (+)= alpha * sum_k A(i,k) * B(k,j) (+ bias[j]) with arbitrary strides, so
+// NN / TN / NT all map onto it.  One 32x32 tile per workgroup, 4 waves split K (fp32 MFMA).
+// ---------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A; long sa_i, sa_k;
+  const float* B; long sb_k, sb_j;
+  float* C; long sc_i, sc_j;
+  int M, N, K;
+  const float* bias;   // [N] or null
+  float alpha;
+  int accumulate;      // C += ...
+};
+
+__global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
+{
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.y * 32 + (lane & 31), j = blockIdx.x * 32 + (lane & 31), half = lane >> 5;
+  const bool iv = i < a.M, jv = j < a.N;
+  const float* pa = a.A + (size_t)(iv ? i : 0) * a.sa_i;
+  const float* pb = a.B + (size_t)(jv ? j : 0) * a.sb_j;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int steps = (a.K + 1) >> 1, per = (steps + 3) >> 2, s0 = wave * per, s1 = min(steps, s0 + per);
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
+    const int k = 2 * s + half;
+    const bool kv = k < a.K;
+    const float av = (iv && kv) ? pa[(size_t)k * a.sa_k] : 0.f;
+    const float bv = (jv && kv) ? pb[(size_t)k * a.sb_k] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0 && jv) {
+    const float bias = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < a.M) {
+        float v = (acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]) * a.alpha + bias;
+        float* dst = a.C + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
+        *dst = a.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+
+// column sums: out[j] (+)= alpha * sum_i in[i][j]
+__global__ void colsum_kernel(const float* __restrict__ in, long ld, int M, int N, float* __restrict__ out, float alpha,
+                              int accumulate)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  double s = 0.0;
+  for (int i = 0; i < M; ++i) s += (double)in[(size_t)i * ld + j];
+  const float v = (float)s * alpha;
+  out[j] = accumulate ? out[j] + v : v;
+}
+
+// counter-based uniform in [0,1) for dropout when the host supplies none (tf.nn.dropout draws
+// random_uniform; the stream cannot match TF's, only the distribution does)
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx)
+{
+  uint64_t x = seed ^ (idx * 0x9E3779B97F4A7C15ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNorm over rows for FC layers (utils/tf_util.py:495-506) + ReLU (+ dropout, tp8.py:80-81).
+// Rows [0, rows_per_set) use BN set 0, the rest set 1.  grid (ceil(C/64), nsets), block 256.
+// ---------------------------------------------------------------------------------
+struct BnRowsArgs {
+  const float* z; float* y; int M, C, rows_per_set;
+  const float* beta[2]; const float* gamma[2];
+  float* mov_mean[2]; float* mov_var[2];
+  float bn_decay; int update_ema;
+  float* mean; float* var;          // [nsets][C]
+  float keep;                       // <= 0: no dropout
+  const float* u; long u_set_stride;   // uniforms [rows][C] per set (set s at u + s*u_set_stride), or null
+  uint64_t seed;
+};
+
+__device__ __forceinline__ float dropout_scale(const BnRowsArgs& a, int set, int row_in_set, int c)
+{
+  if (a.keep <= 0.f) return 1.f;
+  const float u = a.u ? a.u[(size_t)set * a.u_set_stride + (size_t)row_in_set * a.C + c]
+                      : hash_uniform(a.seed + set, (uint64_t)row_in_set * a.C + c);
+  return floorf(a.keep + u) / a.keep;   // tf.nn.dropout: x / keep * floor(keep + u)
+}
+
+__global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const BnRowsArgs a)
+{
+  __shared__ double red[4][64][2];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, set = blockIdx.y;
+  const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
+  double s = 0.0, ss = 0.0;
+  if (c < a.C)
+    for (int r = r0 + rg; r < r1; r += 4) { const double v = a.z[(size_t)r * a.C + c]; s += v; ss += v * v; }
+  red[rg][cl][0] = s; red[rg][cl][1] = ss;
+  __syncthreads();
+  if (c >= a.C) return;
+  s = red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0];
+  ss = red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1];
+  const double mean = s / R, var = fmax(ss / R - mean * mean, 0.0);
+  const float mf = (float)mean, vf = (float)var;
+  if (rg == 0) {
+    a.mean[set * a.C + c] = mf; a.var[set * a.C + c] = vf;
+    if (a.update_ema) {
+      a.mov_mean[set][c] -= (1.f - a.bn_decay) * (a.mov_mean[set][c] - mf);
+      a.mov_var[set][c] -= (1.f - a.bn_decay) * (a.mov_var[set][c] - vf);
+    }
+  }
+  const float inv = a.gamma[set][c] * (1.0f / sqrtf(vf + kBnEps)), sh = a.beta[set][c] - mf * inv;
+  for (int r = r0 + rg; r < r1; r += 4) {
+    const float y = fmaxf(fmaf(a.z[(size_t)r * a.C + c], inv, sh), 0.f);
+    a.y[(size_t)r * a.C + c] = y * dropout_scale(a, set, r - r0, c);
+  }
+}
+
+// backward: dy (wrt the layer output after relu/dropout) -> dz, dgamma, dbeta.
+// dz = gamma*inv * (g - mean(g) - zhat*mean(g*zhat)), g = dy * dropout * [y > 0]
+struct BnRowsBwdArgs {
+  BnRowsArgs f;          // same forward description (z, stats, dropout)
+  const float* dy; float* dz;
+  float* dbeta[2]; float* dgamma[2];
+};
+
+__global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
+{
+  const BnRowsArgs& a = b.f;
+  __shared__ double red[4][64][2];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, set = blockIdx.y;
+  const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
+  float mf = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
+  if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
+  double sb = 0.0, sg = 0.0;
+  if (c < a.C)
+    for (int r = r0 + rg; r < r1; r += 4) {
+      const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
+      const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
+      sb += g; sg += (double)g * zh;
+    }
+  red[rg][cl][0] = sb; red[rg][cl][1] = sg;
+  __syncthreads();
+  if (c >= a.C) return;
+  sb = red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0];
+  sg = red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1];
+  if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; }
+  const float mb = (float)(sb / R), mg = (float)(sg / R), k = gam * rstd;
+  for (int r = r0 + rg; r < r1; r += 4) {
+    const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
+    const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
+    b.dz[(size_t)r * a.C + c] = k * (g - mb - zh * mg);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// loss `separate` forward + gradient (models/tp8.py:304-354), one workgroup.
+// Shapes follow the reference exactly, including the [B] - [B,1] -> [B,B] broadcasts of
+// tp8.py:279 and :327 (DESIGN.md quirks ix, x).
+// ---------------------------------------------------------------------------------
+struct LossArgs {
+  int B, nb;
+  float esf, af; int accept_inverted;
+  // predictions (device): cloud-major [2B] = tower 0 rows then tower 1 rows
+  const float* s1c; const float* s2c;          // [2B][3]
+  const float* o2; int ldo2;                   // [2B][3+2nb], logits at +3
+  const float* o3; int ldo3;                   // [B][3+2nb]
+  const float* theta; const int* pcls;         // [2B] decoded yaw and its arg-max class (tp8.py:294-301)
+  // labels
+  const float *tr, *c1, *c2, *a1, *a2;         // [B,3],[B,3],[B,3],[B,1],[B,1]
+  // outputs
+  float* out;                                  // [17]: loss, then the 16 summaries (tp8.py:336-353 order)
+  float* d_s1c; float* d_s2c;                  // [2B][3]   (direct loss terms; d_s2c includes the pred_translations path)
+  float* d_o2;                                 // [2B][3+2nb]: only the logits part is written ([3:]); [:3] zeroed
+  float* d_o3;                                 // [B][3+2nb]
+  float* scratch;                              // >= 8*B floats + 4*B ints worth of space
+  int want_grad;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+__device__ __forceinline__ float huberf(float e, float d)
+{
+  const float a = fabsf(e), q = fminf(a, d);
+  return 0.5f * q * q + d * (a - q);
+}
+__device__ __forceinline__ float clipf(float e, float d) { return fminf(fmaxf(e, -d), d); }
+
+// tf_angle2class (tp8.py:181-199), scalar
+__device__ __forceinline__ void angle2class(float angle, int nb, int* cls, float* res)
+{
+  const float twopi = 6.28318548202514648f;   // np.float32(2*np.pi)
+  const float a = floor_modf(angle, twopi);
+  const float apc = twopi / (float)nb;
+  const float sh = floor_modf(a + apc * 0.5f, twopi);
+  const int c = (int)(sh / apc);
+  *cls = c;
+  *res = sh - ((float)c * apc + apc * 0.5f);
+}
+
+// one angle term A(logits, target) for both variants (theta, theta+pi); see LossArgs
+struct AngleOut { float tot, ce, rl; int variant; };
+
+__global__ __launch_bounds__(1024) void loss_kernel(const LossArgs a)
+{
+  __shared__ double red[16];
+  __shared__ float sres[3][2][3];   // [term][variant][tot, ce, rl]
+  __shared__ int schosen[3];
+  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
+  const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
+  // scratch carve
+  float* lse = a.scratch;                 // [3][B] log-sum-exp of class logits per term
+  float* pick = lse + 3 * B;              // [3][2][B] picked residual logit per term/variant
+  float* lab = pick + 6 * B;              // [2][2][B] stage-2 labels per tower/variant
+  int* cls = reinterpret_cast<int*>(lab + 4 * B);   // [3][2][B]
+  float* Sj = reinterpret_cast<float*>(cls + 6 * B);   // [3][B] sum_i clip(err_ij) for the chosen variant
+
+  // ---- Huber terms (tp8.py:312-323) ----
+  double h[5] = {0, 0, 0, 0, 0};
+  for (int e = tid; e < 3 * B; e += nt) {
+    const int b = e / 3, d = e % 3;
+    const float e1a = a.s1c[b * 3 + d] - a.c1[e], e1b = a.s1c[(B + b) * 3 + d] - a.c2[e];
+    const float e2a = a.s2c[b * 3 + d] - a.c1[e], e2b = a.s2c[(B + b) * 3 + d] - a.c2[e];
+    const float pt = a.o3[(size_t)b * a.ldo3 + d] + (a.s2c[(B + b) * 3 + d] - a.s2c[b * 3 + d]);
+    const float e3 = pt - a.tr[e];
+    h[0] += huberf(e1a, 1.f); h[1] += huberf(e1b, 1.f); h[2] += huberf(e2a, 1.f); h[3] += huberf(e2b, 1.f); h[4] += huberf(e3, 2.f);
+    if (a.want_grad) {
+      const float w = 1.0f / ((float)B * 3.0f * (float)B);   // (1/B) * mean over 3B elements
+      const float g3 = w * clipf(e3, 2.f);
+      a.d_s1c[b * 3 + d] = w * a.esf * 0.5f * clipf(e1a, 1.f);
+      a.d_s1c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e1b, 1.f);
+      a.d_s2c[b * 3 + d] = w * a.esf * 0.5f * clipf(e2a, 1.f) - g3;      // pred_translations = head + (s2c2 - s2c1)
+      a.d_s2c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e2b, 1.f) + g3;
+      a.d_o3[(size_t)b * a.ldo3 + d] = g3;
+      a.d_o2[(size_t)b * a.ldo2 + d] = 0.f;
+      a.d_o2[(size_t)(B + b) * a.ldo2 + d] = 0.f;
+    }
+  }
+  float hub[5];
+  for (int k = 0; k < 5; ++k) hub[k] = (float)(block_sum(h[k], red) / (3.0 * B));
+
+  // ---- per-row class/residual targets and log-sum-exp for the three angle terms ----
+  // term 0/1: towers (targets pc1_angles / pc2_angles); term 2: remaining angle (target matrix T[i][j])
+  const int nvar = a.accept_inverted ? 2 : 1;
+  for (int i = tid; i < B; i += nt) {
+    for (int term = 0; term < 3; ++term) {
+      const float* lg = term == 0 ? a.o2 + (size_t)i * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + i) * a.ldo2 + 3 : a.o3 + (size_t)i * a.ldo3 + 3;
+      float m = lg[0];
+      for (int k = 1; k < nb; ++k) m = fmaxf(m, lg[k]);
+      float s = 0.f;
+      for (int k = 0; k < nb; ++k) s += expf(lg[k] - m);
+      lse[term * B + i] = m + logf(s);
+      // target angle of row i (term 2: column 0 of T, tp8.py:199 class_id[:, 0])
+      float tgt;
+      if (term == 0) tgt = a.a1[i];
+      else if (term == 1) tgt = a.a2[i];
+      else tgt = (a.a2[i] - a.a1[i]) - (a.theta[B + 0] - a.theta[0]);
+      for (int v = 0; v < nvar; ++v) {
+        int c; float r;
+        angle2class(tgt + (v ? pi : 0.f), nb, &c, &r);
+        cls[(term * 2 + v) * B + i] = c;
+        pick[(term * 2 + v) * B + i] = lg[nb + min(max(c, 0), nb - 1)];
+        if (term < 2) lab[(term * 2 + v) * B + i] = r / pinb;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- CE and residual-Huber means per term/variant ----
+  for (int term = 0; term < 3; ++term)
+    for (int v = 0; v < nvar; ++v) {
+      double ce = 0.0, rl = 0.0;
+      for (int i = tid; i < B; i += nt) {
+        const float* lg = term == 0 ? a.o2 + (size_t)i * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + i) * a.ldo2 + 3 : a.o3 + (size_t)i * a.ldo3 + 3;
+        const int c = min(max(cls[(term * 2 + v) * B + i], 0), nb - 1);
+        ce += (double)(lse[term * B + i] - lg[c]);
+      }
+      for (long e = tid; e < (long)B * B; e += nt) {
+        const int i = e / B, j = e % B;
+        float label;
+        if (term < 2) label = lab[(term * 2 + v) * B + i];
+        else {
+          const float T = (a.a2[i] - a.a1[i]) - (a.theta[B + j] - a.theta[j]);
+          int c; float r;
+          angle2class(T + (v ? pi : 0.f), nb, &c, &r);
+          label = r / pinb;
+        }
+        rl += (double)huberf(pick[(term * 2 + v) * B + j] - label, 1.f);
+      }
+      ce = block_sum(ce, red) / B;
+      rl = block_sum(rl, red) / ((double)B * B);
+      if (tid == 0) { sres[term][v][0] = (float)ce + 20.0f * (float)rl; sres[term][v][1] = (float)ce; sres[term][v][2] = (float)rl; }
+    }
+  __syncthreads();
+  if (tid < 3) schosen[tid] = (a.accept_inverted && !(sres[tid][0][0] > sres[tid][1][0])) ? 1 : 0;   // tf.cond picks the LARGER
+  __syncthreads();
+
+  // ---- totals ----
+  const float s1 = (hub[0] + hub[1]) * 0.5f, s2t = (hub[2] + hub[3]) * 0.5f;
+  const float A1 = sres[0][schosen[0]][0], A2 = sres[1][schosen[1]][0], A3 = sres[2][schosen[2]][0];
+  const float lt = a.esf * (s1 + s2t) + hub[4];
+  const float la = a.esf * ((A1 + A2) * 0.5f) + A3;
+  if (tid == 0) {
+    float* o = a.out;
+    o[0] = (lt + a.af * la) / (float)B;
+    o[1] = lt; o[2] = la;
+    o[3] = hub[0]; o[4] = hub[1]; o[5] = hub[2]; o[6] = hub[3]; o[7] = hub[4];
+    for (int t = 0; t < 3; ++t) for (int k = 0; k < 3; ++k) o[8 + t * 3 + k] = sres[t][schosen[t]][k];
+  }
+  if (!a.want_grad) return;
+
+  // ---- gradients of the angle terms (chosen variant only: tf.cond) ----
+  // S_j = sum_i clip(pick_j - label_ij, 1)
+  for (int term = 0; term < 3; ++term) {
+    const int v = schosen[term];
+    for (int j = tid; j < B; j += nt) {
+      const float pj = pick[(term * 2 + v) * B + j];
+      float s = 0.f;
+      for (int i = 0; i < B; ++i) {
+        float label;
+        if (term < 2) label = lab[(term * 2 + v) * B + i];
+        else {
+          const float T = (a.a2[i] - a.a1[i]) - (a.theta[B + j] - a.theta[j]);
+          int c; float r;
+          angle2class(T + (v ? pi : 0.f), nb, &c, &r);
+          label = r / pinb;
+        }
+        s += clipf(pj - label, 1.f);
+      }
+      Sj[term * B + j] = s;
+    }
+  }
+  __syncthreads();
+  const float invB = 1.0f / (float)B;
+  for (long e = tid; e < (long)B * 2 * nb; e += nt) {
+    const int j = e / (2 * nb), k = e % (2 * nb);
+    for (int term = 0; term < 3; ++term) {
+      const int v = schosen[term];
+      const float w = term < 2 ? invB * a.af * a.esf * 0.5f : invB * a.af;
+      const float* lg = term == 0 ? a.o2 + (size_t)j * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + j) * a.ldo2 + 3 : a.o3 + (size_t)j * a.ldo3 + 3;
+      float* dl = term == 0 ? a.d_o2 + (size_t)j * a.ldo2 + 3 : term == 1 ? a.d_o2 + (size_t)(B + j) * a.ldo2 + 3 : a.d_o3 + (size_t)j * a.ldo3 + 3;
+      const int c = min(max(cls[(term * 2 + v) * B + j], 0), nb - 1);
+      float g;
+      if (k < nb) g = w * invB * (expf(lg[k] - lse[term * B + j]) - (k == c ? 1.f : 0.f));
+      else g = (k - nb == c) ? w * 20.0f * invB * invB * Sj[term * B + j] : 0.f;
+      if (term < 2 && k >= nb) {
+        // the stage-3 target depends on the towers' decoded yaw (tp8.py:325-327): gradient through the
+        // gathered residual of the PREDICTED class; d(label_ij)/d(p2_j) = -1/(pi/nb), d(p)/d(logit) = pi/nb
+        const int pc = a.pcls[term * B + j];
+        if (k - nb == pc) g += (term == 1 ? 1.f : -1.f) * invB * a.af * 20.0f * invB * invB * Sj[2 * B + j];
+      }
+      dl[k] = g;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// glue backward (one thread per cloud)
+// ---------------------------------------------------------------------------------
+// x3 = (p - s2c) @ R(-theta): given per-cloud  gx = sum_n dL/dx3[n,:]  and  grot = sum_n (g0*x3_1 - g1*x3_0):
+//   dL/ds2c = -(gx @ R^T),  dL/dtheta = -grot,  dL/dlogit[nb + predcls] += dtheta * pi/nb   (tp8.py:298-301)
+__global__ void stage3_glue_bwd_kernel(const float* __restrict__ gx, const float* __restrict__ grot,
+                                       const float* __restrict__ xform, const int* __restrict__ pcls, int B, int nb,
+                                       float* __restrict__ d_s2c, float* __restrict__ d_o2, int ldo2)
+{
+  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloud >= 2 * B) return;
+  const float* R = xform + cloud * 12 + 3;
+  const float g0 = gx[cloud * 3], g1 = gx[cloud * 3 + 1], g2 = gx[cloud * 3 + 2];
+  d_s2c[cloud * 3 + 0] -= g0 * R[0] + g1 * R[1] + g2 * R[2];
+  d_s2c[cloud * 3 + 1] -= g0 * R[3] + g1 * R[4] + g2 * R[5];
+  d_s2c[cloud * 3 + 2] -= g0 * R[6] + g1 * R[7] + g2 * R[8];
+  const float pinb = (float)(3.141592653589793 / (double)nb);
+  d_o2[(size_t)cloud * ldo2 + 3 + nb + pcls[cloud]] += -grot[cloud] * pinb;
+}
+
+// s2c = o2[:, :3] + s1c (tp8.py:117): d_o2[:, :3] = d_s2c; d_s1c += d_s2c
+__global__ void stage2_glue_bwd_kernel(const float* __restrict__ d_s2c, int B, float* __restrict__ d_o2, int ldo2,
+                                       float* __restrict__ d_s1c)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * B * 3) return;
+  const int cloud = e / 3, d = e % 3;
+  d_o2[(size_t)cloud * ldo2 + d] = d_s2c[e];
+  d_s1c[e] += d_s2c[e];
+}
+
+// x2 = p - s1c (tp8.py:113): d_s1c -= sum_n dL/dx2[n,:]
+__global__ void stage1_glue_bwd_kernel(const float* __restrict__ gx, int B, float* __restrict__ d_s1c)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * B * 3) return;
+  d_s1c[e] -= gx[e];
+}
+
+}  // namespace alignnet

@@ -146,6 +146,10 @@ int alignnet_synchronize(alignnet_handle* h);
 int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
                         const alignnet_labels* labels, int32_t B, const float* dropout_u,
                         alignnet_step_result* result, const alignnet_outputs* out);
+/* Same step with inputs and labels already resident in HBM (device pointers inside d_labels); dropout
+ * masks are drawn on the device.  result may be NULL to avoid the host synchronisation. */
+int alignnet_train_step_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2,
+                               const alignnet_labels* d_labels, int32_t B, alignnet_step_result* result);
 /* Split form used for data-parallel training: forward+backward only (gradients stay on
  * the device), then the optimiser.  alignnet_grad_buffer exposes the flat gradient
  * (device pointer, float count) for an external all-reduce when the built-in RCCL

@@ -1,0 +1,157 @@
+"""GPU parity of the training path through the C ABI: train-mode forward (batch statistics, EMA),
+loss, every parameter gradient and the optimiser step vs the torch-autograd oracle (fp64) on the same
+fp32-representable parameters, inputs and dropout uniforms."""
+import numpy as np
+import pytest
+import torch
+
+import alignnet3d
+from oracle import alignnet_ref as R
+from oracle import alignnet_torch as T
+from tests.helpers import small_cfg, oracle_params
+
+pytestmark = pytest.mark.gpu
+LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
+
+
+def _oracle(cfg, P32, d, du, decay):
+    spec = R.NetSpec.from_cfg(cfg)
+    tp = T.to_torch({k: v.astype(np.float64) for k, v in P32.items()}, requires_grad=True)
+    tm = T.TorchTp8(spec, tp)
+    td = {k: torch.tensor(v.astype(np.float64)) for k, v in d.items()}
+    tu = {k: torch.tensor(v.astype(np.float64)) for k, v in du.items()}
+    ep = tm.forward(td["pcs1"], td["pcs2"], True, decay, tu)
+    loss = tm.loss(ep, *[td[k] for k in LABELS])
+    loss.backward()
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in tp.items() if v.requires_grad}
+    return ({k: v.detach().numpy() for k, v in ep.items()}, float(loss.detach()), grads,
+            {k: v.numpy() for k, v in tm.ema_updates.items()})
+
+
+def _setup(N, B, nb=12, seed=5):
+    cfg = small_cfg(N=N, nb=nb, s1=(32, 64, 96), s2=(32, 64, 128), emb=(32, 64, 160), fc=(64, 32))
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=seed)
+    # BN-preceding biases have an identically-zero gradient; keep them non-zero to test that path
+    d = R.synth_pairs(B, N, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    return cfg, spec, P32, d, du
+
+
+def _rel_err(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("N,B", [(128, 6), (200, 4)])
+def test_train_forward_loss_ema(gpu_required, N, B):
+    cfg, spec, P32, d, du = _setup(N, B)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    st = eng.state()
+    ep_ref, loss_ref, _, ema_ref = _oracle(cfg, P32, d, du, st["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    worst = 0.0
+    for k, v in ema_ref.items():
+        got = eng.get_variable(k)
+        np.testing.assert_allclose(got, v, rtol=1e-4, atol=1e-5, err_msg=k)
+        worst = max(worst, float(np.abs(got - v).max()))
+    print("loss", res["loss"], loss_ref, "worst EMA abs err", worst)
+    eng.close()
+
+
+@pytest.mark.parametrize("N,B,tol", [(256, 16, 5e-4), (128, 6, 1e-2)])
+def test_gradients_match_autograd(gpu_required, N, B, tol):
+    """Every trainable tensor.  Tolerance: relative to the tensor's largest reference entry, plus an absolute
+    floor of 1e-5 x the largest gradient entry of the whole model for tensors whose exact gradient is zero
+    (e.g. the beta of a BN whose output feeds another BN through a linear map, biases in front of a BN).
+    B = 6 is a conditioning stress case (6-row batch statistics amplify fp32 forward differences)."""
+    cfg, spec, P32, d, du = _setup(N, B)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    report, bad = {}, {}
+    bn_bias = set()
+    for L in R.layer_table(spec):
+        if L.bn:
+            bn_bias.add((f"siamese/{L.name}" if L.siamese else L.name) + "/biases")
+    for name in R.trainable_names(spec):
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        if name in bn_bias:
+            # bias in front of a BatchNorm: the exact gradient is 0 (autograd returns rounding noise, TF too)
+            assert np.abs(g).max() == 0.0 and np.abs(ref).max() < 1e-9 * gscale, name
+            continue
+        err = float(np.abs(g - ref).max())
+        report[name] = err / (float(np.abs(ref).max()) + 1e-30)
+        if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    real = {k: v for k, v in report.items() if np.abs(grads[k]).max() > 1e-6 * gscale}
+    print("worst relative gradient errors:", sorted(real.items(), key=lambda kv: -kv[1])[:5])
+    assert not bad, bad
+    eng.close()
+
+
+def test_adam_step_and_state(gpu_required):
+    cfg, spec, P32, d, du = _setup(128, 6)
+    cfg["data"]["ntrain"] = 600
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    lr = eng.state()["learning_rate"]
+    assert abs(lr - 0.005) < 1e-9
+    res = eng.train_step(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    assert res["step"] == 1 and eng.state()["step"] == 1
+    for name in ("siamese/embedding/conv3/weights", "fc1/weights", "siamese_1/transformer2/embedding/conv2/bn/gamma"):
+        w0 = P32[name].astype(np.float64)
+        g = grads[name]
+        w1, _, _ = R.adam_step(w0, g, np.zeros_like(g), np.zeros_like(g), 1, lr)
+        got = eng.get_variable(name)
+        # first Adam step ~ lr*sign(g): compare where the gradient is not tiny
+        mask = np.abs(g) > 1e-3 * np.abs(g).max()
+        np.testing.assert_allclose(got.reshape(w0.shape)[mask], w1[mask], rtol=0, atol=2e-4 * lr + 1e-7, err_msg=name)
+    eng.close()
+
+
+def test_save_load_roundtrip(gpu_required, tmp_path):
+    cfg, spec, P32, d, du = _setup(128, 4)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.train_step(d["pcs1"], d["pcs2"], d)
+    path = tmp_path / "model-0.aln3"
+    eng.save(path)
+    ref = eng.forward(d["pcs1"], d["pcs2"])
+    eng2 = alignnet3d.Engine(cfg)
+    eng2.load(path)
+    assert eng2.state()["step"] == 1
+    out = eng2.forward(d["pcs1"], d["pcs2"])
+    for k in ref:
+        np.testing.assert_array_equal(ref[k], out[k])
+    eng3 = alignnet3d.Engine(cfg)
+    eng3.load(path, skip_step=True)   # pre-training restore excludes `batch` (train.py:278-281)
+    assert eng3.state()["step"] == 0
+    with pytest.raises(alignnet3d.EngineError):
+        eng3.load(tmp_path / "missing.aln3")
+    for e in (eng, eng2, eng3):
+        e.close()
+
+
+def test_eval_loss_matches_oracle(gpu_required):
+    cfg, spec, P32, d, _ = _setup(128, 6)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.forward(d["pcs1"], d["pcs2"])
+    loss, summ = eng.eval_loss(d, 6)
+    P64 = {k: v.astype(np.float64) for k, v in P32.items()}
+    ep, _, _ = R.get_model(P64, spec, d["pcs1"].astype(np.float64), d["pcs2"].astype(np.float64))
+    lref, sref = R.get_loss(spec, ep, *[d[k].astype(np.float64) for k in LABELS])
+    assert abs(loss - lref) <= 1e-4 * max(1.0, abs(lref)), (loss, lref)
+    for k, v in sref.items():
+        assert abs(summ[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, summ[k], v)
+    eng.close()
