@@ -182,7 +182,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->loss_out = F(32); w->loss_scratch = F(32 * (size_t)B + 64);
     w->stat_part = D(B2 * 2 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 2 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
-    w->dbg2_part = D(B2 * 2 * maxC2 * 2); w->dbg1_part = D(B2 * 8 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
+    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 8 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
     w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
     w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
@@ -222,6 +222,12 @@ static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float*
 {
   const size_t total = (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, h->stream, W, K, C, img);
+}
+
+template <typename T>
+static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, float* out, int towers = 2, float alpha = 1.f, int acc = 0)
+{
+  hipLaunchKernelGGL((reduce_slices_kernel<T>), dim3((unsigned)((n + 31) / 32), towers), dim3(256), 0, h->stream, part, S, n, out, alpha, acc);
 }
 
 static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
@@ -266,6 +272,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.sc1 = S.scale[0]; a.sh1 = S.shift[0]; a.sc2 = S.scale[1]; a.sh2 = S.shift[1]; a.sgn3 = S.sgn3;
   a.stat_part = w->stat_part; a.ext = S.ext; a.idx = S.idx2; a.gram_part = w->gram_part; a.colsum_part = w->colsum_part;
   a.h2_store = S.h2;
+  a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const double count = (double)B * N;
   auto finish = [&](int l, int C, int slices) {
     StatFinishArgs f;
@@ -277,7 +284,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.bn_decay = bn_decay; f.update_ema = update_ema;
     f.mean = S.mean[l]; f.var = S.var[l]; f.scale = S.scale[l]; f.shift = S.shift[l];
     f.sgn = l == 2 ? S.sgn3 : nullptr;
-    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 255) / 256, 2), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(256), 0, h->stream, f);
   };
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);
@@ -288,8 +295,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + t * C3);
   hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(2, C3, 2);
-  hipLaunchKernelGGL((reduce_clouds_kernel<float>), dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, w->gram_part, B, (long)C2 * C2, S.gram2);
-  hipLaunchKernelGGL((reduce_clouds_kernel<double>), dim3((C2 + 255) / 256, 2), dim3(256), 0, h->stream, w->colsum_part, 2 * B, (long)C2, S.s2);
+  launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
+  launch_reduce<double>(h, w->colsum_part, 2 * B, (long)(C2), S.s2);
   hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
   const size_t tot = (size_t)2 * B * C3;
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),
@@ -376,7 +383,7 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here)
       HIP_TRY(h, hipMemsetAsync(G(h, w, L.p_b), 0, L.cout * sizeof(float), h->stream));
     } else {
-      hipLaunchKernelGGL(colsum_kernel, dim3((L.cout + 127) / 128), dim3(128), 0, h->stream, dcur, (long)L.cout, M, L.cout, G(h, w, L.p_b), 1.f, 0);
+      launch_reduce<float>(h, dcur, M, (long)L.cout, G(h, w, L.p_b), 1);
     }
     // dW = x^T dz  (TN)
     launch_gemm(h, xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M);
@@ -410,8 +417,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
-  hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 127) / 128, 2), dim3(128), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp);
+  hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(256), 0, h->stream, p3);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * 4), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp);
   for (int t = 0; t < 2; ++t)   // GW[t] = Ghat2[t] W3
     launch_gemm(h, S.gram2 + (size_t)t * C2 * C2, C2, 1, W3, C3, 1, w->GW + (size_t)t * C2 * C3, C3, 1, C2, C3, C2);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
@@ -437,14 +444,17 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.sc1 = S.scale[0]; b2.sh1 = S.shift[0]; b2.sc2 = S.scale[1]; b2.sh2 = S.shift[1];
   b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = w->rstd2;
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
+  b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
-  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kWaves * 64), lds_train(b2.ldb, b2.ldb), h->stream, b2);
+  const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kWaves * ((N + kTilePts - 1) / kTilePts + 1) + kWaves) * 4;
+  if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
+  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kWaves * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
 
   // ---- layer 2 parameter gradients + operators for B1 ----
-  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C2 * 2), dim3(256), 0, h->stream, w->dbg2_part, 2 * B, (long)C2 * 2, w->dbg2);
-  hipLaunchKernelGGL((reduce_clouds_kernel<float>), g256t((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2_part, B, (long)C1 * C2, w->u2);
-  hipLaunchKernelGGL((reduce_clouds_kernel<float>), g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1_part, B, (long)C1 * C1, w->g1);
-  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C1), dim3(256), 0, h->stream, w->s1_part, B, (long)C1, w->s1);
+  launch_reduce<double>(h, w->dbg2_part, 4 * B, (long)(C2 * 2), w->dbg2);
+  launch_reduce<float>(h, w->u2_part, B, (long)(C1 * C2), w->u2);
+  launch_reduce<float>(h, w->g1_part, B, (long)(C1 * C1), w->g1);
+  launch_reduce<double>(h, w->s1_part, B, (long)(C1), w->s1);
   hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, M, w->m1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
                      P(h, L[1]->p_bn[1][1]), C2, M, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
@@ -474,7 +484,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
   hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kWaves * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
-  hipLaunchKernelGGL((reduce_clouds_kernel<double>), g256t((size_t)C1 * 2), dim3(256), 0, h->stream, w->dbg1_part, 8 * B, (long)C1 * 2, w->dbg1);
+  launch_reduce<double>(h, w->dbg1_part, 8 * B, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
                      P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),
                      G(h, w, L[0]->p_bn[1][1]), (float*)nullptr, (float*)nullptr, w->k1, w->rstd1);
@@ -486,7 +496,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b0.count = M; b0.dy1_store = w->dy1; b0.p_part = w->p_part; b0.gx = S.gx; b0.grot = S.grot;
   hipLaunchKernelGGL(train_bwd_b0, dim3(2 * B), dim3(256), 1024 * 4 * sizeof(float) + 256 * 4 * sizeof(double) + (size_t)C1 * 4 * sizeof(float),
                      h->stream, b0);
-  hipLaunchKernelGGL(sum_p_kernel, dim3((3 * C1 + 127) / 128), dim3(128), 0, h->stream, w->p_part, 2 * B, 3 * C1, G(h, w, L[0]->p_w));
+  launch_reduce<float>(h, w->p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1);
   HIP_TRY(h, hipMemsetAsync(G(h, w, L[0]->p_b), 0, C1 * sizeof(float), h->stream));
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -21,7 +21,6 @@
 
 namespace alignnet {
 
-constexpr int kZ2Slots = 1;   // C2 <= 8 waves * 32 = 256 columns of z2 kept in registers
 
 struct BwdB2Args {
   const float* pcs[2]; const float* xform; int B, N, C1, C2, C3;
@@ -37,32 +36,96 @@ struct BwdB2Args {
   const int* idx;               // [2B][C3]
   const float* w3t;             // [C3][C2]
   float* dy2_store;             // [2B*N][C2]
-  double* dbg2_part;            // [2B][2 halves][C2][2]  (dbeta2, dgamma2)
+  double* dbg2_part;            // [2B][4 = 2 row groups x 2 halves][C2][2]  (dbeta2, dgamma2)
   float* u2_part;               // [2B][C1*C2]
   float* g1_part;               // [2B][C1*C1]
   double* s1_part;              // [2B][C1]
+  int dbg;
 };
 
+// mfma over 64 rows (two 32-row tiles) x one 32-channel tile; acc is accumulated (not cleared)
+__device__ __forceinline__ void mfma_rows2_acc(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp, int KG, int lane,
+                                               f32x16 (&acc)[2])
+{
+  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
+  f32x4 bcur = Wp[lane];
+  for (int kg = 0; kg < KG; ++kg) {
+    const f32x4 bnext = Wp[(kg + 1 < KG ? kg + 1 : kg) * 64 + lane];
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + kg * 8);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 32 * lda + kg * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bcur[q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bcur[q], acc[1], 0, 0, 0);
+    }
+    bcur = bnext;
+  }
+}
+
+// Work split: item = (channel tile ct, row group rg of 64 rows) = wave  (C2 <= 128 -> CT2*2 <= 8 items), so
+// the wave that produced z2 for (ct, rg) also owns dh2 for (ct, rg) and keeps z2 in registers in between.
+// LDS: xs | X [128][ldb] | Y [128][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
 __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
+  const int ld0 = a.ld0, ldb = a.ldb;
+  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
   float* xs = smem;
   float* X = smem + kTilePts * 4;
-  float* Y = X + kTilePts * a.ldb;
-  const int ld0 = a.ld0, ldb = a.ldb;
+  float* Y = X + kTilePts * ldb;
+  int* hit_e = reinterpret_cast<int*>(Y + kTilePts * ldb);      // [C3] entry = channel | (row-in-tile << 16)
+  float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
+  int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
+  int* wtot = hoff + kWaves * (ntiles + 1);                       // [8] segment sizes
   const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
-  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
-
-  const int half = lane >> 5;
-  double* my_dbg = a.dbg2_part + ((size_t)cloud * 2 + half) * a.C2 * 2;   // lane-owned slices (see kernels_train_fwd.h)
+  const int ct = wave >> 1, rg = wave & 1;            // this wave's z2 / dh2 item
+  const bool has_item = ct < CT2;
+  const int col = ct * 32 + (lane & 31);
+  const bool live = has_item && col < a.C2;
+  double* my_dbg = a.dbg2_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2) * 2;   // slices: (rg, half)
   float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
   float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
+
+  // ---- per-cloud hit lists: wave w owns the arg-extreme rows with (row & 7) == w, ordered by tile then channel
+  //      (fixed order => deterministic summation); built once, consumed tile by tile ----
+  {
+    int cntw = 0;
+    for (int base = 0; base < a.C3; base += 64) {
+      const int c = base + lane;
+      const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+      cntw += __popcll(__ballot(id >= 0 && (id & (kWaves - 1)) == wave));
+    }
+    if (lane == 0) wtot[wave] = cntw;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    int pos = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      if (lane == 0) hoff[wave * (ntiles + 1) + t] = woff + pos;
+      for (int base = 0; base < a.C3; base += 64) {
+        const int c = base + lane;
+        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+        const bool m = id >= 0 && (id >> 7) == t && (id & (kWaves - 1)) == wave;
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+          const int p = woff + pos + __popcll(mask & ((1ull << lane) - 1ull));
+          hit_e[p] = c | ((id & (kTilePts - 1)) << 16);
+          hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
+        }
+        pos += __popcll(mask);
+      }
+    }
+    if (lane == 0) hoff[wave * (ntiles + 1) + ntiles] = woff + pos;
+  }
+
+  f32x16 z2[2];
+  double db = 0.0, dg = 0.0, s1c = 0.0;
 
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTilePts, a.N - tile * kTilePts);
@@ -73,29 +136,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 
-    // ---- layer 2 forward: keep z2 (pre-BN, minus bias) in registers, h2 -> Y ----
-    f32x16 z2[kZ2Slots][4];
+    // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y ----
+    if (has_item) {
 #pragma unroll
-    for (int s = 0; s < kZ2Slots; ++s) {
-      const int ct = wave + s * kWaves;
-      if (ct < CT2) {
-        mfma_rows<4>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2[s]);
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C2;
-        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-        if (col < ((a.C2 + 7) & ~7)) {
+      for (int r = 0; r < 16; ++r) { z2[0][r] = 0.f; z2[1][r] = 0.f; }
+      mfma_rows2_acc(X + rg * 64 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
+      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      if (col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = acc_row(m, r, lane);
-              Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[s][m][r], sc, sh), 0.f) : 0.f;
-            }
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int row = rg * 64 + acc_row(m, r, lane);
+            Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[m][r], sc, sh), 0.f) : 0.f;
+          }
       }
     }
-    // Gram / column sums of h1 (X) -- needed by the statistics part of layer 2's backward
-    for (int item = kWaves - 1 - wave; item < CT1 * CT1; item += kWaves) {   // waves without a z2 tile go first
+    // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
+    for (int item = wave; item < CT1 * CT1; item += kWaves) {
       const int it = item / CT1, jt = item % CT1;
       const float* pa = X + half * ld0 + it * 32 + (lane & 31);
       const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
@@ -104,106 +162,90 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
       for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
-      const int j = jt * 32 + (lane & 31);
-      if (j < a.C1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = it * 32 + acc_row(0, r, lane);
-          if (i < a.C1) { float* d = my_g1 + (size_t)i * a.C1 + j; *d = first ? g[r] : *d + g[r]; }
-        }
-      }
+      accum_tile_global(my_g1, a.C1, it, jt, a.C1, a.C1, g, first, lane);
     }
     if (tid < a.C1) {
       float sm = 0.f;
       for (int r = 0; r < kTilePts; ++r) sm += X[r * ld0 + tid];
-      double* d = a.s1_part + (size_t)cloud * a.C1 + tid;
-      *d = first ? (double)sm : *d + (double)sm;
+      s1c += (double)sm;
     }
     __syncthreads();
 
-    // ---- sparse rows of dh2: X <- 0, then X[n*-tile0][:] += gs[b,c] * W3[:,c]  (deterministic: wave w owns rows = w mod 8) ----
+    // ---- sparse rows of dh2: X <- 0, then X[row][:] += g * W3[:, c] for this tile's hits ----
     for (int i = tid; i < kTilePts * ldb; i += kWaves * 64) X[i] = 0.f;
     __syncthreads();
-    for (int base = 0; base < a.C3; base += 64) {
-      const int c = base + lane;
-      const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTilePts : -1;
-      const bool hit = rel >= 0 && rel < nvalid && (rel & (kWaves - 1)) == wave;
-      unsigned long long mask = __ballot(hit);
-      while (mask) {
-        const int l = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int row = __shfl(rel, l);
-        const int cc = base + l;
-        const float g = a.gs[(size_t)cloud * a.C3 + cc];
-        for (int k = lane; k < a.C2; k += 64) X[row * ldb + k] += g * a.w3t[(size_t)cc * a.C2 + k];
+    if (a.dbg & 8) {
+      for (int base = 0; base < a.C3; base += 64) {
+        const int c = base + lane;
+        const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTilePts : -1;
+        const bool hit = rel >= 0 && rel < nvalid && (rel & (kWaves - 1)) == wave;
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+          const int l = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const int row = __shfl(rel, l);
+          const int cc = base + l;
+          const float g = a.gs[(size_t)cloud * a.C3 + cc];
+          for (int k = lane; k < a.C2; k += 64) X[row * ldb + k] += g * a.w3t[(size_t)cc * a.C2 + k];
+        }
+      }
+    } else {
+      const int h0 = hoff[wave * (ntiles + 1) + tile], h1 = hoff[wave * (ntiles + 1) + tile + 1];
+      for (int hb = h0; hb < h1; hb += 4) {
+        int e[4]; float g[4], w0[4], w1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = hb + q < h1;
+          e[q] = ok ? hit_e[hb + q] : 0;
+          g[q] = ok ? hit_g[hb + q] : 0.f;
+          const float* wr = a.w3t + (size_t)(e[q] & 0xffff) * a.C2;
+          w0[q] = lane < a.C2 ? wr[lane] : 0.f;
+          w1[q] = lane + 64 < a.C2 ? wr[lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // in list order: two hits may share a row
+          if (hb + q >= h1) break;      // padded slots must not touch LDS: row 0 belongs to another wave
+          const int row = e[q] >> 16;
+          if (lane < a.C2) X[row * ldb + lane] += g[q] * w0[q];
+          if (lane + 64 < a.C2) X[row * ldb + lane + 64] += g[q] * w1[q];
+        }
       }
     }
     __syncthreads();
 
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
+    if (has_item) {
+      const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
+      f32x16 acc[2];
 #pragma unroll
-    for (int s = 0; s < kZ2Slots; ++s) {
-      const int ct = wave + s * kWaves;
-      if (ct < CT2) {
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C2;
-        const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
-        f32x16 acc[4];
-        {
-          // accumulate h2 Q3 on top of the sparse rows
-          const f32x4* Wp = q3img + (size_t)ct * KGq * 64;
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+        for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[(rg * 64 + acc_row(m, r, lane)) * ldb + col] : 0.f) + qb;
+      mfma_rows2_acc(Y + rg * 64 * ldb, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
+      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
+      const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
+      float lb = 0.f, lg = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
-          const float* arow = Y + (lane & 31) * ldb + (lane >> 5) * 4;
-          for (int kg = 0; kg < KGq; ++kg) {
-            const f32x4 bv = Wp[kg * 64 + lane];
-            f32x4 av[4];
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * ldb + kg * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[q], acc[m], 0, 0, 0);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 64 + acc_row(m, r, lane);
+          const bool on = row < nvalid && fmaf(z2[m][r], sc, sh) > 0.f;
+          const float dy = on ? acc[m][r] : 0.f;
+          lb += dy; lg += dy * ((z2[m][r] + bias - mu) * rs);
+          z2[m][r] = dy;   // the registers now hold dy2
         }
-        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-        const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
-        const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
-        float lb = 0.f, lg = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(m, r, lane);
-            const bool on = row < nvalid && fmaf(z2[s][m][r], sc, sh) > 0.f;
-            const float dy = on ? acc[m][r] : 0.f;
-            const float zh = (z2[s][m][r] + bias - mu) * rs;
-            lb += dy; lg += dy * zh;
-            z2[s][m][r] = dy;   // reuse the registers for dy2
-          }
-        if (live) {
-          my_dbg[col * 2] = first ? (double)lb : my_dbg[col * 2] + (double)lb;
-          my_dbg[col * 2 + 1] = first ? (double)lg : my_dbg[col * 2 + 1] + (double)lg;
-        }
-      }
+      db += (double)lb; dg += (double)lg;
     }
     __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
 
     // ---- dy2 -> Y ; h1 -> X again ----
+    if (has_item && col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-    for (int s = 0; s < kZ2Slots; ++s) {
-      const int ct = wave + s * kWaves;
-      if (ct < CT2) {
-        const int col = ct * 32 + (lane & 31);
-        if (col < ((a.C2 + 7) & ~7)) {
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[s][m][r] : 0.f;
-        }
-      }
+        for (int r = 0; r < 16; ++r) Y[(rg * 64 + acc_row(m, r, lane)) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
     }
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
@@ -225,17 +267,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
         for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll 8
         for (int r = 0; r < kTilePts; r += 2) u = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldb], u, 0, 0, 0);
-        const int j = jt * 32 + (lane & 31);
-        if (j < a.C2) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = it * 32 + acc_row(0, r, lane);
-            if (i < a.C1) { float* d = my_u2 + (size_t)i * a.C2 + j; *d = first ? u[r] : *d + u[r]; }
-          }
-        }
+        accum_tile_global(my_u2, a.C2, it, jt, a.C1, a.C2, u, first, lane);
       }
     }
   }
+  if (live) { my_dbg[col * 2] = db; my_dbg[col * 2 + 1] = dg; }
+  if (tid < a.C1) a.s1_part[(size_t)cloud * a.C1 + tid] = s1c;
 }
 
 // ---------------------------------------------------------------------------------
@@ -334,8 +371,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b1(const BwdB1Args a
         }
         if (live) {   // slice (rg, half) of this cloud
           double* d = a.dbg1_part + (((size_t)cloud * 8 + rg * 2 + (lane >> 5)) * a.C1 + col) * 2;
-          d[0] = first ? (double)lb : d[0] + (double)lb;
-          d[1] = first ? (double)lg : d[1] + (double)lg;
+          const double o0 = first ? 0.0 : d[0], o1 = first ? 0.0 : d[1];
+          d[0] = o0 + (double)lb;
+          d[1] = o1 + (double)lg;
         }
       }
     }
@@ -428,16 +466,27 @@ __global__ __launch_bounds__(256) void train_bwd_b0(const BwdB0Args a)
 // ---------------------------------------------------------------------------------
 // small "prep" kernels between the passes
 // ---------------------------------------------------------------------------------
-// sum of per-cloud partials over one tower's clouds: out[t][i] = sum_b part[(t*B+b)*n + i]   (fp64 accumulate)
+// out[t][i] (+)= alpha * sum_{s < S} part[(t*S + s)*n + i]      (fp64 accumulate, deterministic order)
+// grid (ceil(n/32), towers), block 256 = 32 columns x 8 slice groups
 template <typename T>
-__global__ void reduce_clouds_kernel(const T* __restrict__ part, int B, long n, float* __restrict__ out)
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const T* __restrict__ part, int S, long n, float* __restrict__ out,
+                                                            float alpha, int accumulate)
 {
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
-  if (i >= n) return;
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, t = blockIdx.y;
+  const long i = blockIdx.x * 32L + cl;
   double s = 0.0;
-  for (int b = 0; b < B; ++b) s += (double)part[(size_t)(t * B + b) * n + i];
-  out[(size_t)t * n + i] = (float)s;
+  if (i < n)
+    for (int k = g; k < S; k += 8) s += (double)part[((size_t)t * S + k) * n + i];
+  red[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][cl];
+    const float v = (float)tot * alpha;
+    out[(size_t)t * n + i] = accumulate ? out[(size_t)t * n + i] + v : v;
+  }
 }
 
 // centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
@@ -462,19 +511,27 @@ struct Prep3Args {
   float* E; float* kdb; float* gs;                  // [2][C], [2][C], [2B][C]
 };
 
-__global__ void prep3_kernel(const Prep3Args a)
+__global__ __launch_bounds__(256) void prep3_kernel(const Prep3Args a)   // grid (ceil(C/32), 2), block 32 channels x 8 cloud groups
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-  if (c >= a.C) return;
-  const float rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps), k = a.gamma[t][c] * rs;
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  float rs = 0.f, k = 0.f;
   double sb = 0.0, sg = 0.0;
-  for (int b = 0; b < a.B; ++b) {
-    const size_t pi = t * a.tower_stride + b * a.row_stride + c;
-    const float g0 = a.pooled[pi] > 0.f ? a.dP[pi] : 0.f;
-    const size_t ci = (size_t)(t * a.B + b) * a.C + c;
-    sb += g0; sg += (double)g0 * a.zhat_star[ci];
-    a.gs[ci] = k * g0;
+  if (c < a.C) {
+    rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps); k = a.gamma[t][c] * rs;
+    for (int b = g; b < a.B; b += 8) {
+      const size_t pi = t * a.tower_stride + b * a.row_stride + c;
+      const float g0 = a.pooled[pi] > 0.f ? a.dP[pi] : 0.f;
+      const size_t ci = (size_t)(t * a.B + b) * a.C + c;
+      sb += g0; sg += (double)g0 * a.zhat_star[ci];
+      a.gs[ci] = k * g0;
+    }
   }
+  red[g][cl][0] = sb; red[g][cl][1] = sg;
+  __syncthreads();
+  if (g != 0 || c >= a.C) return;
+  sb = 0.0; sg = 0.0;
+  for (int q = 0; q < 8; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   a.dbeta[t][c] = (float)sb;
   a.dgamma[t][c] = (float)sg;
   a.E[t * a.C + c] = (float)(-(double)k * rs * sg / a.M);
@@ -500,19 +557,22 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
   if (rstd) rstd[t * C + c] = rs;
 }
 
-// Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block C2 (<= 256)
-__global__ void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                 int B, int N, int C2, int C3, float* __restrict__ Sp)
+// Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
+__global__ __launch_bounds__(512) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                                        int B, int N, int C2, int C3, float* __restrict__ Sp)
 {
-  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
-  if (k >= C2) return;
+  __shared__ double red[4][128];
+  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x % C2, g = threadIdx.x / C2;
   double s = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const size_t cloud = (size_t)t * B + b;
-    const float g = gs[cloud * C3 + c];
-    if (g != 0.f) s += (double)g * h2[(cloud * N + idx[cloud * C3 + c]) * C2 + k];
-  }
-  Sp[((size_t)t * C2 + k) * C3 + c] = (float)s;
+  if (g < 4)
+    for (int b = g; b < B; b += 4) {
+      const size_t cloud = (size_t)t * B + b;
+      const float gv = gs[cloud * C3 + c];
+      if (gv != 0.f) s += (double)gv * h2[(cloud * N + idx[cloud * C3 + c]) * C2 + k];
+    }
+  if (g < 4) red[g][k] = s;
+  __syncthreads();
+  if (g == 0) Sp[((size_t)t * C2 + k) * C3 + c] = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
 }
 
 // out[t][i][j] = W[i][j] * col[t][j]   (scale columns)  /  transposed variants via strides
@@ -555,16 +615,6 @@ __global__ void qbias_kernel(const float* __restrict__ Q, const float* __restric
   double w = 0.0;
   for (int c = 0; c < Cout; ++c) w += (double)W[(size_t)j * Cout + c] * kdb[t * Cout + c];
   qb[t * Cin + j] = (float)(s - w / M);
-}
-
-// dW1[d][c] = sum over all clouds of P ; grid covers 3*C1
-__global__ void sum_p_kernel(const float* __restrict__ p_part, int nclouds, int n, float* __restrict__ out)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int b = 0; b < nclouds; ++b) s += (double)p_part[(size_t)b * n + i];
-  out[i] = (float)s;
 }
 
 }  // namespace alignnet

@@ -39,7 +39,28 @@ struct TrainFwdArgs {
   float* gram_part;        // [2B][C2*C2]
   double* colsum_part;     // [2B][2 halves][C2]
   float* h2_store;         // [2B*N][C2]
+  int dbg;                 // debug/ablation flags (0 in production)
 };
+
+// Accumulate one 32x32 MFMA result tile into a lane-owned global matrix: all loads first, then all stores
+// (an unrolled  *d = *d + v  chain serialises on possible aliasing: one memory round trip per element).
+__device__ __forceinline__ void accum_tile_global(float* __restrict__ base, long ld, int it, int jt, int rows, int cols, const f32x16& v,
+                                                  bool first, int lane)
+{
+  const int j = jt * 32 + (lane & 31);
+  if (j >= cols) return;
+  float old[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    old[r] = (first || i >= rows) ? 0.f : base[(size_t)i * ld + j];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (i < rows) base[(size_t)i * ld + j] = old[r] + v[r];
+  }
+}
 
 // x' = (p - c) @ R for the tile's 128 points -> xs[128][4]; rows past N repeat the last point (masked later)
 __device__ __forceinline__ void load_tile_xform(const float* __restrict__ pc, const float* __restrict__ xf, int N,
@@ -178,20 +199,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
       const bool live = col < a.C2;
       if (PHASE == 2) {
         const float bias = live ? a.b2[col] : 0.f;
-        double ls = 0.0, lss = 0.0;
+        // shifted sums in fp32 (shift = this lane's first value), folded into fp64 once per tile:
+        //   sum z = S1 + n z0,  sum z^2 = S2 + 2 z0 S1 + n z0^2   -- no E[z^2]-E[z]^2 cancellation in fp32
+        const float z0 = acc[0][0] + bias;
+        float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (acc_row(m, r, lane) < nvalid) {
-              const double z = (double)(acc[m][r] + bias);
-              ls += z; lss += z * z;
+              const float dlt = (acc[m][r] + bias) - z0;
+              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
             }
-        }
         if (live) {
-          my_stat[col * 2] = first ? ls : my_stat[col * 2] + ls;
-          my_stat[col * 2 + 1] = first ? lss : my_stat[col * 2 + 1] + lss;
+          const double zd = (double)z0, n = (double)cnt;
+          const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
+          const double o0 = first ? 0.0 : my_stat[col * 2], o1 = first ? 0.0 : my_stat[col * 2 + 1];
+          my_stat[col * 2] = o0 + ls;
+          my_stat[col * 2 + 1] = o1 + lss;
         }
       } else {
         const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
     __syncthreads();
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-    {
+    if (!(a.dbg & 2)) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
       const int c4 = a.C2 >> 2;
       for (int i = tid; i < nvalid * c4; i += kWaves * 64) {
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
     }
 
     // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's 128 rows ----
-    for (int item = wave; item < CT2 * CT2; item += kWaves) {
+    for (int item = wave; item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kWaves) {
       const int it = item / CT2, jt = item % CT2;
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
@@ -232,17 +257,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
       for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld1], pb[r * ld1], g, 0, 0, 0);
-      const int j = jt * 32 + (lane & 31);
-      if (j < a.C2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = it * 32 + acc_row(0, r, lane);
-          if (i < a.C2) {
-            float* d = my_gram + (size_t)i * a.C2 + j;
-            *d = first ? g[r] : *d + g[r];
-          }
-        }
-      }
+      accum_tile_global(my_gram, a.C2, it, jt, a.C2, a.C2, g, first, lane);
     }
 
     // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
@@ -253,27 +268,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
       const bool live = col < a.C3;
       const float bias = live ? a.b3[col] : 0.f;
       const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
-      double ls = 0.0, lss = 0.0;
       float be = (first || !live) ? -INFINITY : my_ext[col];
       int bi = (first || !live) ? 0 : my_idx[col];
+      const float z0 = acc[0][0] + bias;
+      float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = acc_row(m, r, lane);
           if (row < nvalid) {
-            const float z = acc[m][r] + bias;
-            const double zd = (double)z;
-            ls += zd; lss += zd * zd;
+            const float z = acc[m][r] + bias, dlt = z - z0;
+            s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
             const float v = z * sg;
             if (v > be) { be = v; bi = tile * kTilePts + row; }
           }
         }
-      }
-      if (live) {
-        my_stat[col * 2] = first ? ls : my_stat[col * 2] + ls;
-        my_stat[col * 2 + 1] = first ? lss : my_stat[col * 2 + 1] + lss;
+      if (live && !(a.dbg & 4)) {
+        const double zd = (double)z0, n = (double)cnt;
+        const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
+        const double o0 = first ? 0.0 : my_stat[col * 2], o1 = first ? 0.0 : my_stat[col * 2 + 1];
+        my_stat[col * 2] = o0 + ls;
+        my_stat[col * 2 + 1] = o1 + lss;
         my_ext[col] = be; my_idx[col] = bi;
       }
     }
@@ -298,15 +314,22 @@ struct StatFinishArgs {
   float* sgn;                // [2][C] or null: sign(gamma) for the next phase
 };
 
-__global__ void stat_finish_kernel(const StatFinishArgs a)
+__global__ __launch_bounds__(256) void stat_finish_kernel(const StatFinishArgs a)   // grid (ceil(C/32), 2), block 32 channels x 8 slice groups
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-  if (c >= a.C) return;
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  const int S = a.B * a.slices;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < a.B * a.slices; ++b) {
-    const double* p = a.part + ((size_t)(t * a.B * a.slices + b) * a.C + c) * 2;
-    s += p[0]; ss += p[1];
-  }
+  if (c < a.C)
+    for (int b = g; b < S; b += 8) {
+      const double* p = a.part + ((size_t)(t * S + b) * a.C + c) * 2;
+      s += p[0]; ss += p[1];
+    }
+  red[g][cl][0] = s; red[g][cl][1] = ss;
+  __syncthreads();
+  if (g != 0 || c >= a.C) return;
+  s = 0.0; ss = 0.0;
+  for (int q = 0; q < 8; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
   const double mean = s / a.count;
   const double var = fmax(ss / a.count - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;

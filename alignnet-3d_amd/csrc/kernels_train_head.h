@@ -59,18 +59,6 @@ __global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
   }
 }
 
-// column sums: out[j] (+)= alpha * sum_i in[i][j]
-__global__ void colsum_kernel(const float* __restrict__ in, long ld, int M, int N, float* __restrict__ out, float alpha,
-                              int accumulate)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
-  double s = 0.0;
-  for (int i = 0; i < M; ++i) s += (double)in[(size_t)i * ld + j];
-  const float v = (float)s * alpha;
-  out[j] = accumulate ? out[j] + v : v;
-}
-
 // counter-based uniform in [0,1) for dropout when the host supplies none (tf.nn.dropout draws
 // random_uniform; the stream cannot match TF's, only the distribution does)
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx)

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -134,11 +135,22 @@ def main():
     outs = {k: torch.empty(B, nb2 if "logits" in k else 3, device=dev) for k in alignnet3d.OUTPUT_NAMES}
     ptrs = {k: v.data_ptr() for k, v in outs.items()}
 
-    if args.mode == "train":
-        raise SystemExit("train mode: see bench_train.py once the training path lands")
+    lab = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
+           ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
+    lab_ptrs = {k: v.data_ptr() for k, v in lab.items()}
+    if world > 1:
+        # data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed
+        uid = [alignnet3d.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
 
-    def step():
+    def train_step():
+        eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
+
+    def infer_step():
         eng.forward_device(p1.data_ptr(), p2.data_ptr(), B, ptrs)
+
+    step = train_step if args.mode == "train" else infer_step
 
     def fence():
         eng.synchronize()
@@ -165,6 +177,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA), fp32
+    train_info = None
+    if args.mode == "infer" and not args.no_train_leg:
+        ksteps = max(3, args.steps // 5)
+        for _ in range(2):
+            train_step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(ksteps):
+            train_step()
+        fence()
+        tdt = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        train_info = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
+                      "steps": ksteps, "dtype": "f32",
+                      "what": "train step: batch-stat forward + loss + backward + " +
+                              ("RCCL all-reduce + " if world > 1 else "") + "Adam + EMA, local-BN data parallel"}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -187,6 +220,11 @@ def main():
                          "algorithmic_flops_per_step": bb_flops_per_step},
             "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2) if world == 1 else None,
         }
+        if args.mode == "train":
+            line["metric"] = "point-cloud pairs/sec at N=1024 (training step)"
+            line["roofline"] = None
+        if train_info is not None:
+            line["train"] = train_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
