@@ -377,8 +377,16 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
+static int infer_tile_pts()
+{
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ALIGNNET_TILE"); v = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 64) ? 64 : 128; }
+  return v;
+}
+
 static size_t backbone_lds_bytes(const alignnet_handle* h, const Stack& st, int ld[2])
 {
+  const int kTilePts = infer_tile_pts();
   int w[2] = {8, 8};
   for (int i = 0; i < st.n - 1; ++i) w[i & 1] = std::max(w[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
   ld[0] = w[0] + 4; ld[1] = w[1] + 4;
@@ -404,17 +412,20 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   HIP_TRY(h, hipMemsetAsync(pooled, 0, pooled_floats * sizeof(float), h->stream));
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const dim3 grid((a.N + kTilePts - 1) / kTilePts, 2 * B);
+  const int TP = infer_tile_pts();
+  const dim3 grid((a.N + TP - 1) / TP, 2 * B);
   std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
   if (h->prof) {
     if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
     else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
     hipEventRecord(evp.first, h->stream);
   }
-  hipLaunchKernelGGL(pointnet_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+  if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
+  else hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a);
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
   HIP_TRY(h, hipGetLastError());
   return 0;

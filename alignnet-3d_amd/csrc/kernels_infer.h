@@ -117,27 +117,81 @@ struct BackboneArgs {
   ConvLayerDev L[kMaxConv];
 };
 
+// Weight (B operand) stream: issued by hand two k-groups ahead and retired with a counted wait.
+// hipcc otherwise sinks the load to the top of the consuming iteration behind `s_waitcnt vmcnt(0)`, exposing
+// the L2 latency on every k-group (cdna_hip_programming.md 5.7: an asm load is invisible to the compiler's
+// wait bookkeeping, so the wait below is ours).  Loads return in order, and nothing else is stored inside the
+// loop, so `vmcnt(2)` means: everything except the two newest loads has landed.
+__device__ __forceinline__ f32x4 wload_issue(const f32x4* p)
+{
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wload_wait2(f32x4& v) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(v)::"memory"); }
+__device__ __forceinline__ void wload_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int MR>
+__device__ __forceinline__ void mfma_kgroup(const f32x4 (&av)[MR], const f32x4& bv, f32x16 (&acc)[MR])
+{
+#ifdef ALIGNNET_SETPRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[s], acc[m], 0, 0, 0);
+#ifdef ALIGNNET_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+template <int MR>
+__device__ __forceinline__ void lds_rows(const float* arow, int lda, int kg, f32x4 (&av)[MR])
+{
+#pragma unroll
+  for (int m = 0; m < MR; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * lda + kg * 8);
+}
+
+// acc[m] (+)= A[rows m*32.., :K] * W  for MR row tiles and one 32-channel tile.  Unrolled by three k-groups so the
+// three in-flight weight registers rotate roles WITHOUT register copies (a copy of an asm-load destination that is
+// still in flight reads garbage).
+template <int MR, bool CLEAR = true>
 __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp,
                                           int KG, int lane, f32x16 (&acc)[MR])
 {
+  if (CLEAR) {
 #pragma unroll
-  for (int m = 0; m < MR; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
-  f32x4 bcur = Wp[lane];
-  for (int kg = 0; kg < KG; ++kg) {
-    const f32x4 bnext = Wp[(kg + 1 < KG ? kg + 1 : kg) * 64 + lane];
-    f32x4 av[MR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) av[m] = *reinterpret_cast<const f32x4*>(arow + m * 32 * lda + kg * 8);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bcur[s], acc[m], 0, 0, 0);
-    bcur = bnext;
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   }
+  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
+  const f32x4* wp = Wp + lane;
+  const int last = KG - 1;
+  wload_drain();   // stores / atomics of the previous epilogue must not sit between the counted loads
+  f32x4 b0 = wload_issue(wp);
+  f32x4 b1 = wload_issue(wp + min(1, last) * 64);
+  f32x4 b2;
+  f32x4 a0[MR], a1[MR];
+  lds_rows<MR>(arow, lda, 0, a0);
+  for (int kg = 0; kg < KG; kg += 3) {
+    b2 = wload_issue(wp + min(kg + 2, last) * 64);
+    lds_rows<MR>(arow, lda, min(kg + 1, last), a1);
+    wload_wait2(b0);
+    mfma_kgroup<MR>(a0, b0, acc);
+    b0 = wload_issue(wp + min(kg + 3, last) * 64);
+    lds_rows<MR>(arow, lda, min(kg + 2, last), a0);
+    wload_wait2(b1);
+    if (kg + 1 < KG) mfma_kgroup<MR>(a1, b1, acc);
+    b1 = wload_issue(wp + min(kg + 4, last) * 64);
+    lds_rows<MR>(arow, lda, min(kg + 3, last), a1);
+    wload_wait2(b2);
+    if (kg + 2 < KG) mfma_kgroup<MR>(a0, b2, acc);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) a0[m] = a1[m];
+  }
+  wload_drain();   // look-ahead loads still in flight: retire them before the registers are reused
 }
 
 // hidden layer: out[row][col] = relu(acc*scale+shift) for this item's MR row tiles x one channel tile
@@ -163,28 +217,30 @@ __device__ __forceinline__ void hidden_item(const float* __restrict__ in, int ld
   }
 }
 
-template <int MR>
+template <int MR, int TP>
 __device__ __forceinline__ void hidden_layer(const float* in, int ldi, float* out, int ldo, const ConvLayerDev& L,
                                              int tower, int wave, int lane)
 {
-  constexpr int RG = (kTilePts / 32) / MR;
+  constexpr int RG = (TP / 32) / MR;
   const int CT = (L.cout + 31) >> 5;
   for (int item = wave; item < CT * RG; item += kWaves) hidden_item<MR>(in, ldi, out, ldo, L, tower, item / RG, item % RG, lane);
 }
 
-static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
+template <int TP>
+__global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cloud = blockIdx.y, tile = blockIdx.x;
   const int tower = cloud >= a.B, b = cloud - tower * a.B;
-  float* xs = smem;                       // [kTilePts][4]
-  float* buf[2] = {smem + kTilePts * 4, smem + kTilePts * 4 + kTilePts * a.ld[0]};
+  float* xs = smem;                       // [TP][4]
+  // integer offsets (not a runtime-selected pointer) keep the LDS address space visible -> ds_read_b128, not flat loads
+  const int boff[2] = {TP * 4, TP * 4 + TP * a.ld[0]};
 
   // ---- prologue: p' = (p - c) @ R   (models/tp8.py:106,113,122,127) ----
-  if (tid < kTilePts) {
-    const int n = min(tile * kTilePts + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
+  if (tid < TP) {
+    const int n = min(tile * TP + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
     const float* p = a.pcs[tower] + ((size_t)b * a.N + n) * 3;
     const float* xf = a.xform + (size_t)cloud * 12;
     const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
@@ -197,14 +253,14 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const Ba
   // ---- layer 0: K = 3 lift on the VALU (not a dense GEMM) ----
   {
     const ConvLayerDev& L = a.L[0];
-    float* out = buf[0];
+    float* out = smem + boff[0];
     const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;   // a 32-lane group writes one row, 32 consecutive channels
     for (int c = c0; c < ldo - 4; c += 32) {
       const bool live = c < L.cout;
       const float w0 = live ? L.w[c] : 0.f, w1 = live ? L.w[L.cout + c] : 0.f, w2 = live ? L.w[2 * L.cout + c] : 0.f;
       const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
 #pragma unroll
-      for (int rr = 0; rr < kTilePts / 16; ++rr) {
+      for (int rr = 0; rr < TP / 16; ++rr) {
         const int row = rr * 16 + r0;
         const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
         const float acc = fmaf(p[2], w2, fmaf(p[1], w1, p[0] * w0));
@@ -218,12 +274,13 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const Ba
   for (int l = 1; l < a.nlayers - 1; ++l) {
     const ConvLayerDev& L = a.L[l];
     const int CT = (L.cout + 31) >> 5;
-    const float* in = buf[(l - 1) & 1];
-    float* out = buf[l & 1];
+    const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
+    float* out = smem + ((l & 1) ? boff[1] : boff[0]);
     const int ldi = a.ld[(l - 1) & 1], ldo = a.ld[l & 1];
-    if (CT >= kWaves) hidden_layer<4>(in, ldi, out, ldo, L, tower, wave, lane);
-    else if (CT * 2 >= kWaves) hidden_layer<2>(in, ldi, out, ldo, L, tower, wave, lane);
-    else hidden_layer<1>(in, ldi, out, ldo, L, tower, wave, lane);
+    constexpr int MT = TP / 32;
+    if (CT >= kWaves) hidden_layer<MT, TP>(in, ldi, out, ldo, L, tower, wave, lane);
+    else if (CT * 2 >= kWaves || MT < 4) hidden_layer<(MT >= 2 ? 2 : 1), TP>(in, ldi, out, ldo, L, tower, wave, lane);
+    else hidden_layer<1, TP>(in, ldi, out, ldo, L, tower, wave, lane);
     __syncthreads();
   }
 
@@ -231,20 +288,20 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const Ba
   {
     const int l = a.nlayers - 1;
     const ConvLayerDev& L = a.L[l];
-    const float* in = buf[(l - 1) & 1];
+    const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
     const int ldi = a.ld[(l - 1) & 1];
     const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
-      f32x16 acc[4];
-      mfma_rows<4>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      f32x16 acc[TP / 32];
+      mfma_rows<TP / 32>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < L.cout;
       const float sc = live ? L.scale[tower * L.cout + col] : 0.f;
       const float sh = live ? L.shift[tower * L.cout + col] : 0.f;
       float mx = 0.f;   // relu folded into the max: max_n relu(v_n) = max(0, max_n v_n)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < TP / 32; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
       mx = fmaxf(mx, __shfl_xor(mx, 32));

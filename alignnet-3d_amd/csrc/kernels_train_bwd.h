@@ -43,23 +43,11 @@ struct BwdB2Args {
   int dbg;
 };
 
-// mfma over 64 rows (two 32-row tiles) x one 32-channel tile; acc is accumulated (not cleared)
+// 64 rows (two 32-row tiles) x one 32-channel tile, accumulating on top of acc
 __device__ __forceinline__ void mfma_rows2_acc(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp, int KG, int lane,
                                                f32x16 (&acc)[2])
 {
-  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
-  f32x4 bcur = Wp[lane];
-  for (int kg = 0; kg < KG; ++kg) {
-    const f32x4 bnext = Wp[(kg + 1 < KG ? kg + 1 : kg) * 64 + lane];
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + kg * 8);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 32 * lda + kg * 8);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bcur[q], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bcur[q], acc[1], 0, 0, 0);
-    }
-    bcur = bnext;
-  }
+  mfma_rows<2, false>(A, lda, Wp, KG, lane, acc);
 }
 
 // Work split: item = (channel tile ct, row group rg of 64 rows) = wave  (C2 <= 128 -> CT2*2 <= 8 items), so
