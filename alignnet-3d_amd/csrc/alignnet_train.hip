@@ -180,7 +180,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     }
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(32 * (size_t)B + 64);
-    w->stat_part = D(B2 * 2 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 2 * maxC2);
+    w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 8 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
     w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
@@ -289,14 +289,14 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);
   hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-  finish(1, C2, 2);
+  finish(1, C2, 4);
   // sgn3 from gamma (per tower)
   for (int t = 0; t < 2; ++t)
     hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + t * C3);
   hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(2, C3, 2);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
-  launch_reduce<double>(h, w->colsum_part, 2 * B, (long)(C2), S.s2);
+  launch_reduce<double>(h, w->colsum_part, 4 * B, (long)(C2), S.s2);
   hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
   const size_t tot = (size_t)2 * B * C3;
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),

@@ -37,7 +37,7 @@ struct TrainFwdArgs {
   float* ext;              // [2B][2 halves][C3] extreme of sgn*z3   (phase 3)
   int* idx;                // [2B][2 halves][C3] its point index
   float* gram_part;        // [2B][C2*C2]
-  double* colsum_part;     // [2B][2 halves][C2]
+  double* colsum_part;     // [2B][4 = 2 row halves x 2 lane halves][C2]
   float* h2_store;         // [2B*N][C2]
   int dbg;                 // debug/ablation flags (0 in production)
 };
@@ -176,10 +176,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
   const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kTilePts - 1) / kTilePts;
   const int Cs = PHASE == 2 ? a.C2 : a.C3;
-  double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2]
+  double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2] (phase 3; phase 2 uses 4 slices)
   float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
-  double* my_col = PHASE == 3 ? a.colsum_part + ((size_t)cloud * 2 + half) * a.C2 : nullptr;
   float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * a.C2 * a.C2 : nullptr;
 
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -191,10 +190,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, buf0, ld0, nvalid, tid);
     __syncthreads();
 
-    // ---- layer 2: z2 = h1 W2 + b2 for all 128 rows ----
-    for (int ct = wave; ct < CT2; ct += kWaves) {
-      f32x16 acc[4];
-      mfma_rows<4>(buf0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+    // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 64-row half) so that all 8 waves work (C2 = 128 -> 8 items) ----
+    for (int item = wave; item < CT2 * 2; item += kWaves) {
+      const int ct = item >> 1, rg = item & 1;
+      f32x16 acc[2];
+      mfma_rows<2>(buf0 + rg * 64 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C2;
       if (PHASE == 2) {
@@ -204,34 +204,38 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
         const float z0 = acc[0][0] + bias;
         float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (acc_row(m, r, lane) < nvalid) {
+            if (rg * 64 + acc_row(m, r, lane) < nvalid) {
               const float dlt = (acc[m][r] + bias) - z0;
               s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
             }
         if (live) {
+          double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col) * 2;   // slice (rg, half)
           const double zd = (double)z0, n = (double)cnt;
           const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-          const double o0 = first ? 0.0 : my_stat[col * 2], o1 = first ? 0.0 : my_stat[col * 2 + 1];
-          my_stat[col * 2] = o0 + ls;
-          my_stat[col * 2 + 1] = o1 + lss;
+          const double o0 = first ? 0.0 : st[0], o1 = first ? 0.0 : st[1];
+          st[0] = o0 + ls;
+          st[1] = o1 + lss;
         }
       } else {
         const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
         float lsum = 0.f;
         const bool wr = col < ((a.C2 + 7) & ~7);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(m, r, lane);
+            const int row = rg * 64 + acc_row(m, r, lane);
             const float h = row < nvalid ? fmaxf(fmaf(acc[m][r], sc, sh), 0.f) : 0.f;
             lsum += h;
             if (wr) buf1[row * ld1 + col] = h;
           }
-        if (live) my_col[col] = first ? (double)lsum : my_col[col] + (double)lsum;
+        if (live) {
+          double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col;
+          *cs = first ? (double)lsum : *cs + (double)lsum;
+        }
       }
     }
     if (PHASE == 2) continue;
@@ -260,30 +264,35 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
       accum_tile_global(my_gram, a.C2, it, jt, a.C2, a.C2, g, first, lane);
     }
 
-    // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
+    // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points.
+    //      Two 64-row halves per channel tile (32 accumulator registers instead of 64; the second pass re-reads
+    //      the 16 KiB weight tile from L2). ----
     for (int ct = wave; ct < CT3; ct += kWaves) {
-      f32x16 acc[4];
-      mfma_rows<4>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
       const float bias = live ? a.b3[col] : 0.f;
       const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
       float be = (first || !live) ? -INFINITY : my_ext[col];
       int bi = (first || !live) ? 0 : my_idx[col];
-      const float z0 = acc[0][0] + bias;
-      float s1 = 0.f, s2 = 0.f; int cnt = 0;
+      float z0 = 0.f, s1 = 0.f, s2 = 0.f; int cnt = 0;
+#pragma unroll 1
+      for (int rg = 0; rg < 2; ++rg) {
+        f32x16 acc[2];
+        mfma_rows<2>(buf1 + rg * 64 * ld1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
+        if (rg == 0) z0 = acc[0][0] + bias;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = acc_row(m, r, lane);
-          if (row < nvalid) {
-            const float z = acc[m][r] + bias, dlt = z - z0;
-            s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
-            const float v = z * sg;
-            if (v > be) { be = v; bi = tile * kTilePts + row; }
+          for (int r = 0; r < 16; ++r) {
+            const int row = rg * 64 + acc_row(m, r, lane);
+            if (row < nvalid) {
+              const float z = acc[m][r] + bias, dlt = z - z0;
+              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
+              const float v = z * sg;
+              if (v > be) { be = v; bi = tile * kTilePts + row; }
+            }
           }
-        }
+      }
       if (live && !(a.dbg & 4)) {
         const double zd = (double)z0, n = (double)cnt;
         const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
