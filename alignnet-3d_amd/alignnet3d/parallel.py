@@ -1,0 +1,46 @@
+"""Data-parallel plumbing (not in the reference, which is single-device: train.py:189).  One process per GPU;
+`torch.distributed` is used only for rendezvous (broadcast of the 128-byte RCCL id, barriers, gathering the
+small prediction arrays); the gradient all-reduce itself runs inside libalignnet_hip.so on RCCL over xGMI."""
+import os
+
+
+def world_info():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) slice of n items for `rank`; sizes differ by at most one, union is exact."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_bytes(dist, payload, src=0):
+    """Send a small bytes object from `src` to every rank (works on gloo and nccl process groups)."""
+    box = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def init_comm(engine, dist, make_id=None):
+    """Create the RCCL communicator of `engine` across the ranks of the default process group."""
+    make_id = make_id or type(engine).comm_unique_id
+    uid = broadcast_bytes(dist, make_id() if dist.get_rank() == 0 else None)
+    engine.comm_init(dist.get_rank(), dist.get_world_size(), uid)
+    return uid
+
+
+def gather_rows(dist, local, counts):
+    """All-gather row blocks of unequal length (prediction arrays in eval); returns the concatenation on every rank."""
+    import numpy as np
+    import torch
+    world = dist.get_world_size()
+    width = local.shape[1]
+    cap = max(counts)
+    buf = torch.zeros(cap, width, dtype=torch.float32)
+    buf[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local, np.float32))
+    if dist.get_backend() == "nccl":
+        buf = buf.cuda()
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)], axis=0)

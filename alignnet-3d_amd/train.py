@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Driver of the drop-in: same command line, config handling, epoch loops, checkpoints cadence and output
+files as the reference's train.py, with the TF graph/session replaced by the MI355X engine.
+
+    python train.py {train,eval_only} --config configs/X.json [--eval_epoch E] [--use_old_results]
+                    [--refineICP] [--its K] [--refineICPmethod p2p]
+
+Launch under `python -m torch.distributed.run --nproc-per-node N` for data-parallel training / batch-split
+evaluation (one process per GPU; gradient all-reduce on RCCL inside the engine)."""
+import argparse
+import copy
+import datetime
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import provider  # noqa: E402
+import evaluation  # noqa: E402
+import models.tp8 as MODEL  # noqa: E402
+from config import load_config, save_config, configGlobal as cfg  # noqa: E402
+from alignnet3d import parallel  # noqa: E402
+
+logger = logging.getLogger("tp")
+CKPT_EXT = ".aln3"   # own container format; TF tensor-bundle import is a later row of SURVEY 8(f)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("operation", choices=["train", "eval_only"], help="Operation to run")
+    p.add_argument("--config", required=True, default="", help="Config file")
+    p.add_argument("--refineICP", action="store_true", help="Whether the results should be refined with ICP")
+    p.add_argument("--its", required=False, default=30, help="How many iteration the result should be refined with ICP")
+    p.add_argument("--use_old_results", action="store_true", help="Use stored predictions instead of running the model")
+    p.add_argument("--refineICPmethod", required=False, default="p2p", choices=["p2p"], help="ICP method for refinement")
+    p.add_argument("--eval_epoch", required=False, default="199", help="Epoch to eval in eval_only mode")
+    return p.parse_args(argv)
+
+
+def setup_logging(logdir, rank):
+    logger.setLevel(logging.DEBUG)
+    fmt = logging.Formatter("%(asctime)s %(name)-12s %(levelname)-8s %(message)s", "%Y-%m-%d %H:%M:%S")
+    if rank == 0:
+        sh = logging.StreamHandler()
+        sh.setLevel(logging.INFO)
+        sh.setFormatter(fmt)
+        logger.addHandler(sh)
+        logfile = "%s/out.log" % logdir
+        if os.path.exists(logfile):
+            logfile = "%s_%s.log" % (logfile[:-4], datetime.datetime.today().strftime("%Y-%m-%d_%H-%M-%S"))
+        fh = logging.FileHandler(logfile)
+        fh.setLevel(logging.DEBUG)
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+
+
+class Run:
+    def __init__(self, flags):
+        self.flags = flags
+        self.rank, self.local_rank, self.world = parallel.world_info()
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
+            self.dist = dist
+        import alignnet3d
+        self.engine = alignnet3d.Engine(cfg, device=self.local_rank if self.world > 1 else None)
+        MODEL.bind_engine(self.engine)
+        if self.dist is not None:
+            parallel.init_comm(self.engine, self.dist)
+        self.train_idx = provider.getDataFiles("%s/split/train.txt" % cfg.data.basepath)
+        self.val_idx = provider.getDataFiles("%s/split/val.txt" % cfg.data.basepath)
+        self.batches_per_epoch = len(self.train_idx) // cfg.training.batch_size
+
+    # ---- checkpoints (train.py:245-293, 313-322 of the reference) --------------------------------------------
+    def ckpt(self, stem):
+        return os.path.join(cfg.logging.logdir, stem + CKPT_EXT)
+
+    def restore_for_training(self):
+        if os.path.isfile(self.ckpt("model.ckpt")):
+            self.engine.load(self.ckpt("model.ckpt"))
+            step = self.engine.state()["step"]
+            assert step % self.batches_per_epoch == 0
+            logger.info("Continuing training at epoch %d" % (step // self.batches_per_epoch))
+            return step // self.batches_per_epoch
+        pre = cfg.training.pretraining.model
+        if pre != "":
+            path = pre if pre.endswith(CKPT_EXT) else pre + CKPT_EXT
+            assert os.path.isfile(path), path
+            self.engine.load(path, skip_step=True)   # every variable except `batch` (train.py:278-281)
+            assert self.engine.state()["step"] == 0
+            logger.info("Pre-trained weights loaded from %s, starting initial evaluation" % pre)
+            self.eval_one_epoch("pretr", eval_only=False, do_timings=False)
+            logger.info("Initial evaluation finished")
+        return 0
+
+    # ---- train.py:335-383 -------------------------------------------------------------------------------------
+    def train_one_epoch(self, epoch):
+        B = cfg.training.batch_size
+        idxs = copy.deepcopy(self.train_idx)
+        np.random.shuffle(idxs)
+        loss_sum = 0.0
+        lo, hi = parallel.shard_range(B, self.rank, self.world)
+        for b in range(len(idxs) // B):
+            batch = provider.load_batch(idxs[b * B:(b + 1) * B])
+            pcs1 = provider.jitter_point_cloud(batch[0])
+            pcs2 = provider.jitter_point_cloud(batch[1])
+            labels = dict(zip(("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"),
+                              [a[lo:hi] for a in batch[2:]]))
+            res = self.engine.train_step(pcs1[lo:hi], pcs2[lo:hi], labels)
+            loss_sum += res["loss"]
+        n = max(len(idxs) // B, 1)
+        logger.info("train mean loss: %f" % (loss_sum / float(n)))
+
+    # ---- train.py:386-545 -------------------------------------------------------------------------------------
+    def eval_one_epoch(self, epoch, eval_only, do_timings, override_batch_size=None):
+        flags = self.flags
+        B = cfg.training.batch_size if override_batch_size is None else override_batch_size
+        val = self.val_idx
+        nval = len(val)
+        eval_dir = "%s/val/eval%s" % (cfg.logging.logdir, str(epoch).zfill(6))
+        if flags.refineICP:
+            raise NotImplementedError("--refineICP needs the Open3D fork of the reference (README.md:32); out of scope here")
+        if self.rank == 0:
+            if os.path.isdir(eval_dir):
+                os.rename(eval_dir, "%s_backup_%d" % (eval_dir, int(time.time())))
+            os.makedirs(eval_dir, exist_ok=True)
+        names3 = ("pred_translations", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers")
+        store = {k: np.empty((nval, 3), np.float32) for k in names3}
+        for k in ("pred_angles", "pred_s2_pc1angles", "pred_s2_pc2angles"):
+            store[k] = np.empty((nval, 1), np.float32)
+        gt_t, gt_a, gt_c1 = np.empty((nval, 3), np.float32), np.empty((nval, 1), np.float32), np.empty((nval, 3), np.float32)
+        loss_sum, cumulated, full_batches = 0.0, 0.0, nval // B
+        for b in range(int(np.ceil(nval / B))):
+            s, e = b * B, min((b + 1) * B, nval)
+            n = e - s
+            batch = provider.load_batch(val[s:e], override_batch_size=override_batch_size)
+            lo, hi = parallel.shard_range(n, self.rank, self.world)
+            t0 = time.time()
+            if hi > lo:
+                ep = self.engine.forward(batch[0][lo:hi], batch[1][lo:hi])   # any batch size: no padding rows needed
+            else:
+                ep = {k: np.zeros((0, 3 if "logits" not in k else 2 * cfg.model.angles.num_bins), np.float32) for k in
+                      ("pred_translations", "pred_remaining_angle_logits", "pred_s1_pc1centers", "pred_s1_pc2centers",
+                       "pred_s2_pc1centers", "pred_s2_pc2centers", "pred_pc1angle_logits", "pred_pc2angle_logits")}
+            cumulated += time.time() - t0
+            if self.world == 1 and n == B:   # last (partial) batch is not counted (train.py:458)
+                labels = dict(zip(("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"),
+                                  [a[:n] for a in batch[2:]]))
+                loss_sum += self.engine.eval_loss(labels, n)[0]
+            if self.dist is not None:
+                counts = [parallel.shard_range(n, r, self.world) for r in range(self.world)]
+                counts = [c[1] - c[0] for c in counts]
+                ep = {k: parallel.gather_rows(self.dist, v, counts) for k, v in ep.items()}
+            a1 = MODEL.classLogits2angle(ep["pred_pc1angle_logits"])
+            a2 = MODEL.classLogits2angle(ep["pred_pc2angle_logits"])
+            ar = MODEL.classLogits2angle(ep["pred_remaining_angle_logits"])
+            store["pred_angles"][s:e, 0] = a2 - a1 + ar          # train.py:456
+            store["pred_s2_pc1angles"][s:e, 0], store["pred_s2_pc2angles"][s:e, 0] = a1, a2
+            for k in names3:
+                store[k][s:e] = ep[k]
+            gt_t[s:e], gt_a[s:e], gt_c1[s:e] = batch[2][:n], batch[3][:n], batch[4][:n]
+        mean_loss = loss_sum / full_batches if full_batches > 0 else 0.0
+        mean_time = cumulated / float(nval)
+        if do_timings:
+            print("Timing bs=%s: %s" % (override_batch_size, mean_time))
+        elif self.rank == 0:
+            for inv in (False, True):
+                ev = evaluation.evaluate(cfg, val, store["pred_translations"], store["pred_angles"], gt_t, gt_a,
+                                         store["pred_s2_pc1centers"], gt_c1, eval_dir=eval_dir, accept_inverted_angle=inv,
+                                         mean_time=mean_time)
+                pct = lambda v: " ".join("%.2f%%" % (a * 100.0) for a in v)
+                logger.info("Mean translation distance: %s, Mean angle distance: %s, Levels: %s, Translation levels: %s, "
+                            "Angle levels: %s, Mean ex. time: %.5f" % (ev.mean_dist_translation, ev.mean_dist_angle, pct(ev.corr_levels),
+                                                                       pct(ev.corr_levels_translation), pct(ev.corr_levels_angles), mean_time))
+        if self.rank == 0:
+            for k, v in store.items():
+                np.save("%s/%s.npy" % (eval_dir, k), v)
+            logger.info("val mean loss: %f" % mean_loss)
+        return mean_time
+
+    # ---- train.py:187-332 -------------------------------------------------------------------------------------
+    def train(self, eval_only=False, eval_epoch=None, do_timings=False, override_batch_size=None):
+        start_epoch = 0
+        if eval_only:
+            if not self.flags.use_old_results and not do_timings:
+                path = self.ckpt("model-%s" % eval_epoch)
+                assert os.path.isfile(path), path
+                self.engine.load(path)
+                step = self.engine.state()["step"]
+                assert step % self.batches_per_epoch == 0
+                assert step // self.batches_per_epoch - 1 == int(eval_epoch)
+            start_epoch = int(eval_epoch)
+            logger.info("Evaluating at epoch %d" % start_epoch)
+        else:
+            start_epoch = self.restore_for_training()
+        start = time.time()
+        try:
+            for epoch in range(start_epoch, cfg.training.num_epochs):
+                st = self.engine.state()
+                logger.info("**** EPOCH %03d ****    lr: %.8f, bn_decay: %.8f" % (epoch, st["learning_rate"], st["bn_decay"]))
+                if not eval_only:
+                    self.train_one_epoch(epoch)
+                if do_timings:
+                    for _ in range(10):
+                        self.eval_one_epoch(epoch, eval_only, True, override_batch_size)
+                else:
+                    self.eval_one_epoch(epoch, eval_only, False)
+                if eval_only:
+                    break
+                last = epoch == cfg.training.num_epochs - 1
+                if self.rank == 0 and (epoch % 2 == 0 or last):
+                    self.engine.save(self.ckpt("model.ckpt"))
+                    logger.info("Model saved in file: %s" % self.ckpt("model.ckpt"))
+                if self.rank == 0 and (epoch % 5 == 0 or last or cfg.evaluation.save_every_epoch):
+                    self.engine.save(self.ckpt("model-%d" % epoch))
+                    logger.info("Model saved in file: %s" % self.ckpt("model-%d" % epoch))
+                el = time.time() - start
+                logger.info("Finished epoch %d. Time elapsed: %s, Time remaining: %s" % (
+                    epoch, datetime.timedelta(seconds=el), datetime.timedelta(seconds=el / (epoch + 1) * (cfg.training.num_epochs - epoch - 1))))
+            logger.info("Finished Training")
+        except KeyboardInterrupt:
+            logger.info("Interrupted")
+
+
+def main(argv=None):
+    flags = parse_args(argv)
+    load_config(flags.config)
+    rank = parallel.world_info()[0]
+    os.makedirs(cfg.logging.logdir, exist_ok=True)
+    if rank == 0:
+        copyfile = "%s/config.json" % cfg.logging.logdir
+        if os.path.exists(copyfile):
+            copyfile = "%s_%s.json" % (copyfile[:-5], datetime.datetime.today().strftime("%Y-%m-%d_%H-%M-%S"))
+        save_config(copyfile)
+    assert cfg.model.model == "tp8"
+    setup_logging(cfg.logging.logdir, rank)
+    logger.debug(cfg)
+    if cfg.evaluation.has("special"):
+        mode = cfg.evaluation.special.mode
+        if mode == "timings":        # train.py:555-559: bs = 32, ten repeated eval epochs, no checkpoint needed
+            for bs in [32]:
+                cfg.training.batch_size = bs
+                Run(flags).train(eval_only=True, eval_epoch=flags.eval_epoch, do_timings=True, override_batch_size=bs)
+        elif mode in ("icp", "held"):
+            raise NotImplementedError("evaluation.special.mode=%s relies on the reference's ICP / held-out tooling (out of scope)" % mode)
+        else:
+            assert False
+    elif flags.operation == "train":
+        Run(flags).train()
+    else:
+        Run(flags).train(eval_only=True, eval_epoch=flags.eval_epoch)
+
+
+if __name__ == "__main__":
+    main()

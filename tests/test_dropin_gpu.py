@@ -1,0 +1,106 @@
+"""GPU: the drop-in driver end to end on a tiny synthetic dataset (train 2 epochs, resume, eval_only, timings
+mode), the RCCL communicator at world size 1, and device-resident entry points."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import alignnet3d
+from oracle import alignnet_ref as R
+from tests.helpers import small_cfg, oracle_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "alignnet-3d_amd")
+
+
+def _make_dataset(root, n=24, seed=0):
+    rng = np.random.default_rng(seed)
+    d = R.synth_pairs(n, 80, seed=seed, dtype=np.float32)
+    for sub in ("meta", "pointcloud1", "pointcloud2", "split"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    txt = lambda v: "\n".join("%.18e" % x for x in np.ravel(v)) + "\n"
+    for i in range(n):
+        meta = {"translation": txt(d["translations"][i]), "rel_angle": float(d["rel_angles"][i, 0]),
+                "start_position": txt(d["pc1_centers"][i]), "end_position": txt(d["pc2_centers"][i]),
+                "start_angle": float(d["pc1_angles"][i, 0]), "end_angle": float(d["pc2_angles"][i, 0])}
+        json.dump(meta, open(os.path.join(root, "meta", "%08d.json" % i), "w"))
+        np.save(os.path.join(root, "pointcloud1", "%08d.npy" % i), d["pcs1"][i][: int(rng.integers(40, 80))])
+        np.save(os.path.join(root, "pointcloud2", "%08d.npy" % i), d["pcs2"][i][: int(rng.integers(40, 80))])
+    open(os.path.join(root, "split", "train.txt"), "w").write("\n".join(map(str, range(16))) + "\n")
+    open(os.path.join(root, "split", "val.txt"), "w").write("\n".join(map(str, range(16, n))) + "\n")
+
+
+def _run(args, cwd):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train.py")] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout + r.stderr
+
+
+def test_train_py_end_to_end(gpu_required, tmp_path):
+    root = tmp_path / "SynthTiny"
+    _make_dataset(str(root))
+    user = {"data": {"basepath": str(root)}, "logging": {"basedir": str(tmp_path / "logs")},
+            "model": {"num_points": 64, "angles": {"num_bins": 12, "accept_inverted_angle": True},
+                      "options": {"s1transformer": [[32, 64, 96], [[64, 32], 0.7]], "s2transformer": [[32, 64, 128], [[64, 32], 0.7]],
+                                  "embedding": [32, 64, 160], "remaining_transform_prediction": [[64, 32], 0.7]}},
+            "training": {"batch_size": 8, "num_epochs": 2, "learning_rate": 0.002}}
+    cfgp = tmp_path / "TinyRun.json"
+    json.dump(user, open(cfgp, "w"))
+    out = _run(["train", "--config", str(cfgp)], str(tmp_path))
+    logdir = tmp_path / "logs" / "TinyRun"
+    assert (logdir / "config.json").exists() and (logdir / "out.log").exists()
+    assert (logdir / "model.ckpt.aln3").exists() and (logdir / "model-0.aln3").exists() and (logdir / "model-1.aln3").exists()
+    assert "train mean loss" in out and "Finished Training" in out
+    ev = logdir / "val" / "eval000001"
+    for f in ("pred_translations", "pred_angles", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers",
+              "pred_s2_pc1angles", "pred_s2_pc2angles"):
+        a = np.load(ev / (f + ".npy"))
+        assert a.shape[0] == 8 and a.dtype == np.float32 and np.all(np.isfinite(a)), f
+    assert json.load(open(ev / "eval.json"))["num"] == 8 and (ev / "eval_180.json").exists()
+    # eval_only restores model-1 and checks the step/epoch consistency (reference train.py:261-264)
+    out2 = _run(["eval_only", "--config", str(cfgp), "--eval_epoch", "1"], str(tmp_path))
+    assert "Evaluating at epoch 1" in out2
+    # timings mode (reference train.py:555-559): bs = 32, no checkpoint needed
+    user["evaluation"] = {"special": {"mode": "timings"}}
+    cfgt = tmp_path / "TinyTimings.json"
+    json.dump(user, open(cfgt, "w"))
+    out3 = _run(["eval_only", "--config", str(cfgt), "--eval_epoch", "0"], str(tmp_path))
+    assert out3.count("Timing bs=32:") == 10
+
+
+def test_rccl_world1_and_device_entry_points(gpu_required):
+    import torch
+    cfg = small_cfg(N=128)
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    d = R.synth_pairs(8, 128, dtype=np.float32)
+    ref = alignnet3d.Engine(cfg)
+    ref.set_variables(P32)
+    # RCCL communicator of size 1: all-reduce must be the identity and the step must equal the single-GPU step
+    eng.comm_init(0, 1, alignnet3d.Engine.comm_unique_id())
+    u = [np.full((8, 32), 0.9, np.float32)] * 5
+    a = eng.train_step(d["pcs1"], d["pcs2"], d, u)
+    b = ref.train_step(d["pcs1"], d["pcs2"], d, u)
+    assert a["loss"] == b["loss"] and a["step"] == b["step"] == 1
+    for name in ("siamese/embedding/conv3/weights", "fc3/biases"):
+        np.testing.assert_array_equal(eng.get_variable(name), ref.get_variable(name))
+    # device-resident inputs: same numbers as the host-pointer entry points
+    t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).cuda() for k in d}
+    outs = {k: torch.empty(8, 24 if "logits" in k else 3, device="cuda") for k in alignnet3d.OUTPUT_NAMES}
+    eng.forward_device(t["pcs1"].data_ptr(), t["pcs2"].data_ptr(), 8, {k: v.data_ptr() for k, v in outs.items()})
+    eng.synchronize()
+    host = eng.forward(d["pcs1"], d["pcs2"])
+    for k in host:
+        np.testing.assert_array_equal(outs[k].cpu().numpy(), host[k])
+    labels = {k: t[k].data_ptr() for k in ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
+    r = eng.train_step_device(t["pcs1"].data_ptr(), t["pcs2"].data_ptr(), labels, 8, want_result=True)
+    assert r["step"] == 2 and np.isfinite(r["loss"])
+    ptr, n = eng.grad_buffer()
+    assert ptr and n == sum(s[0] * s[1] for _, s, tr in eng.variables() if tr)
+    eng.close(); ref.close()

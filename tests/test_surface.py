@@ -1,0 +1,125 @@
+"""CPU: the Python surface of the drop-in (config / provider / decode / evaluation helpers) against golden
+vectors produced by the REFERENCE's own functions (tests/golden/make_golden.py, run in the build container)."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+J = json.load(open(os.path.join(HERE, "golden", "reference_vectors.json")))
+PKG = os.path.join(os.path.dirname(HERE), "alignnet-3d_amd")
+
+
+@pytest.fixture()
+def tiny(tmp_path):
+    """Re-materialise the fixture dataset + config, import the drop-in modules fresh."""
+    root = tmp_path / "TinySet"
+    for sub in ("meta", "pointcloud1", "pointcloud2", "split"):
+        (root / sub).mkdir(parents=True)
+    for i, meta in J["ds_meta"].items():
+        json.dump(meta, open(root / "meta" / ("%08d.json" % int(i)), "w"))
+        np.save(root / "pointcloud1" / ("%08d.npy" % int(i)), G["ds_pc1_%s" % i])
+        np.save(root / "pointcloud2" / ("%08d.npy" % int(i)), G["ds_pc2_%s" % i])
+    (root / "split" / "train.txt").write_text("\n".join(map(str, J["ds_train"])) + "\n")
+    (root / "split" / "val.txt").write_text("\n".join(map(str, J["ds_val"])) + "\n")
+    user = json.loads(json.dumps(J["config_user"]).replace(J["config_user"]["data"]["basepath"], str(root)))
+    user["logging"]["basedir"] = str(tmp_path / "logs")
+    cfg_path = tmp_path / "TinyRun.json"
+    json.dump(user, open(cfg_path, "w"))
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    for m in ("config", "provider", "models.tp8", "models", "evaluation"):
+        sys.modules.pop(m, None)
+    config = importlib.import_module("config")
+    config.load_config(str(cfg_path))
+    return dict(tmp=str(tmp_path), config=config, provider=importlib.import_module("provider"),
+                tp8=importlib.import_module("models.tp8"), evaluation=importlib.import_module("evaluation"))
+
+
+def test_config_merge_matches_reference(tiny):
+    merged = json.loads(json.dumps(tiny["config"].configGlobal.to_dict()).replace(tiny["tmp"], J["tmp_token"]))
+    assert merged == J["config_merged"]
+    cfg = tiny["config"].configGlobal
+    assert cfg.has("name") and cfg.evaluation.has("special") and not cfg.has("nope")
+    out = os.path.join(tiny["tmp"], "saved.json")
+    tiny["config"].save_config(out)
+    assert json.load(open(out)) == tiny["config"].configGlobal.to_dict()
+
+
+def test_provider_batches_match_reference(tiny):
+    prov = tiny["provider"]
+    assert prov.getDataFiles(tiny["config"].configGlobal.data.basepath + "/split/train.txt") == J["ds_train"]
+    names = ("pcs1", "pcs2", "translations", "rel_angles", "pc1centers", "pc2centers", "pc1angles", "pc2angles")
+    np.random.seed(1234)
+    b = prov.load_batch([0, 1, 2, 3])
+    for k, v in zip(names, b):
+        assert v.dtype == np.float64
+        np.testing.assert_array_equal(v, G["lb_" + k], err_msg=k)
+    np.random.seed(99)
+    b2 = prov.load_batch([6, 5], override_batch_size=3)
+    for k, v in zip(names, b2):
+        assert v.shape[0] == 3
+        np.testing.assert_array_equal(v[:2], G["lb2_" + k], err_msg=k)
+    b3 = prov.load_batch([4, 0], override_batch_size=2, dont_load_pointclouds=True)
+    np.testing.assert_array_equal(b3[2], G["lb3_translations"])
+    np.testing.assert_array_equal(b3[7], G["lb3_pc2angles"])
+    np.random.seed(7)
+    np.testing.assert_array_equal(prov.jitter_point_cloud(G["jit_in"].copy()), G["jit_out"])
+
+
+def test_host_decode_matches_reference(tiny):
+    tp8 = tiny["tp8"]
+    np.testing.assert_array_equal(tp8.classLogits2angle(G["dec_logits"]), G["dec_angles"])
+    got = np.array([tp8.class2angle(c, r) for c, r in ((0, 0.1), (5, 0.3), (9, 0.9), (7, -0.2))])
+    np.testing.assert_array_equal(got, G["dec_class2angle"])
+    # the oracle's restatement of the same function
+    from oracle import alignnet_ref as R
+    np.testing.assert_array_equal(R.class_logits_to_angle(G["dec_logits"], 10), G["dec_angles"])
+    ph = tp8.placeholder_inputs(4, 32)
+    assert [p.shape for p in ph] == [(4, 32, 3), (4, 32, 3), (4, 3), (4, 1), (4, 3), (4, 3), (4, 1), (4, 1)]
+
+
+def test_evaluation_helpers_match_reference(tiny):
+    ev = tiny["evaluation"]
+    t, gt, a, ga = G["ev_t"], G["ev_gt_t"], G["ev_a"], G["ev_gt_a"]
+    np.testing.assert_allclose([ev.eval_translation(x, y)[0] for x, y in zip(t, gt)], G["ev_transl_dist"], rtol=0, atol=0)
+    np.testing.assert_array_equal([ev.eval_translation(x, y)[1] for x, y in zip(t, gt)], G["ev_transl_lvl"])
+    for inv in (False, True):
+        np.testing.assert_allclose([ev.eval_angle(x, y, inv)[0] for x, y in zip(a, ga)], G["ev_angle_dist_%d" % inv], rtol=1e-15)
+        np.testing.assert_array_equal([ev.eval_angle(x, y, inv)[1] for x, y in zip(a, ga)], G["ev_angle_lvl_%d" % inv])
+        np.testing.assert_array_equal([ev.eval_transform(x, y, p, q, inv) for x, y, p, q in zip(t, gt, a, ga)], G["ev_transform_%d" % inv])
+    np.testing.assert_allclose(ev.translate_transform_to_new_center_of_rotation(G["ttc_in_t"], G["ttc_in_a"], G["ttc_in_c"], G["ttc_in_g"]),
+                               G["ttc_out"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(tiny["provider"].str_to_np(J["np_to_str"]), G["str_to_np"])
+
+
+def test_evaluate_writes_reference_schema(tiny):
+    ev, cfg = tiny["evaluation"], tiny["config"].configGlobal
+    val = J["ds_val"]
+    n = len(val)
+    rng = np.random.default_rng(0)
+    out_dir = os.path.join(tiny["tmp"], "evaldir")
+    res = ev.evaluate(cfg, val, rng.normal(size=(n, 3)).astype(np.float32) * 0.05, rng.normal(size=(n, 1)).astype(np.float32) * 0.05,
+                      np.zeros((n, 3), np.float32), np.zeros((n, 1), np.float32), np.zeros((n, 3), np.float32),
+                      np.ones((n, 3), np.float32), eval_dir=out_dir, accept_inverted_angle=True, mean_time=0.5)
+    j = json.load(open(os.path.join(out_dir, "eval_180.json")))
+    for key in ("corr_levels", "corr_levels_translation", "mean_dist_translation", "mean_sq_dist_translation", "corr_levels_angles",
+                "mean_dist_angle", "mean_sq_dist_angle", "num", "eval_5m", "eval_10m", "eval_15m", "eval_20m", "val", "test", "reg_eval",
+                "mean_time"):
+        assert key in j, key
+    assert j["num"] == n and j["mean_time"] == 0.5 and res.val.num == n and res.test.num == 0
+
+
+def test_cli_surface():
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    src = open(os.path.join(PKG, "train.py")).read()
+    for flag in ("--config", "--refineICP", "--its", "--use_old_results", "--refineICPmethod", "--eval_epoch"):
+        assert flag in src
+    for fname in ("pred_translations", "pred_angles", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers",
+                  "pred_s2_pc2centers", "pred_s2_pc1angles", "pred_s2_pc2angles"):
+        assert fname in src
