@@ -131,7 +131,11 @@ class Run:
             raise NotImplementedError("--refineICP needs the Open3D fork of the reference (README.md:32); out of scope here")
         if self.rank == 0:
             if os.path.isdir(eval_dir):
-                os.rename(eval_dir, "%s_backup_%d" % (eval_dir, int(time.time())))
+                backup, k = "%s_backup_%d" % (eval_dir, int(time.time())), 0
+                while os.path.exists(backup):   # the reference's second-resolution name collides when an eval takes < 1 s
+                    k += 1
+                    backup = "%s_backup_%d_%d" % (eval_dir, int(time.time()), k)
+                os.rename(eval_dir, backup)
             os.makedirs(eval_dir, exist_ok=True)
         names3 = ("pred_translations", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers")
         store = {k: np.empty((nval, 3), np.float32) for k in names3}

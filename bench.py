@@ -16,7 +16,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                cloud-triple * 2 clouds per pair) / its HIP-event time on the engine's stream,
                measured inside the timed region.  peak = 157.3 TFLOP/s fp32 MFMA
                (MI355X_MICROARCH.md).  traffic = HBM bytes per step from rocprofv3 PMC
-               (profiles/*_pmc_traffic.json, collected in separate --pmc passes), else null.
+               (profiles/*_pmc_traffic.json: the dominant kernel's three launches of one step, collected
+               in separate --pmc passes), else null.
   cpu_baseline the oracle ("port": unfused op-by-op NumPy fp32 restatement, eval mode) timed on
                this box's host cores on a bounded sample (batch 32, repeated ~10-20 s).
 """
@@ -85,7 +86,8 @@ def pmc_traffic():
     if not files:
         return None
     try:
-        return json.load(open(files[-1])).get("hbm_bytes_per_step")
+        j = json.load(open(files[-1]))
+        return j.get("backbone_hbm_bytes_per_step") or j.get("hbm_bytes_per_step")
     except Exception:
         return None
 

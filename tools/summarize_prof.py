@@ -23,7 +23,7 @@ for db in glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True):
     # per-launch detail of the dominant kernel (three launch shapes per step)
     det = defaultdict(list)
     try:
-        for name, gx, dur in c.execute("select name, grid_size, (end-start) from kernels"):
+        for name, gx, dur in c.execute("select name, grid_x*grid_y*grid_z, (end-start) from kernels"):
             det[(short(name), gx)].append(dur)
         with open(os.path.join(dst, f"{tag}_kernel_by_grid.csv"), "w") as g:
             g.write("kernel,grid_size,calls,average_us,min_us,max_us\n")
@@ -53,7 +53,10 @@ for line in open(os.path.join(out, "bench_trace.log")):
 if steps:
     fetch = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in pmc.values())
     write = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in pmc.values())
-    bb = pmc.get("pointnet_fused", {})
+    bb = {}
+    for k, v in pmc.items():
+        if "pointnet_fused" in k:
+            bb = v
     bf, bw = bb.get("FETCH_SIZE", {}).get("sum", 0), bb.get("WRITE_SIZE", {}).get("sum", 0)
     nbb = max(bb.get("FETCH_SIZE", {}).get("dispatches", 1), 1)
     json.dump({"tag": tag, "steps_profiled": steps,
