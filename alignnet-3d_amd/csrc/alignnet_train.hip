@@ -182,7 +182,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->loss_out = F(32); w->loss_scratch = F(32 * (size_t)B + 64);
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
-    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 8 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
+    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
     w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
     w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
@@ -240,7 +240,7 @@ static int pack_all_weights(alignnet_handle* h)
   return 0;
 }
 
-static size_t lds_train(int ld0, int ldb_or_ld1) { return ((size_t)kTilePts * 4 + (size_t)kTilePts * (ld0 + ldb_or_ld1)) * sizeof(float); }
+static size_t lds_train(int ld0, int ldb_or_ld1) { return ((size_t)kTT * 4 + (size_t)kTT * (ld0 + ldb_or_ld1)) * sizeof(float); }
 
 static int set_lds_attrs(alignnet_handle* h)
 {
@@ -288,12 +288,12 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   };
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);
-  hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4);
   // sgn3 from gamma (per tower)
   for (int t = 0; t < 2; ++t)
     hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + t * C3);
-  hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kWaves * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(2, C3, 2);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
   launch_reduce<double>(h, w->colsum_part, 4 * B, (long)(C2), S.s2);
@@ -446,9 +446,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
-  const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kWaves * ((N + kTilePts - 1) / kTilePts + 1) + kWaves) * 4;
+  const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
-  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kWaves * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
+  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
 
   // ---- layer 2 parameter gradients + operators for B1 ----
   launch_reduce<double>(h, w->dbg2_part, 4 * B, (long)(C2 * 2), w->dbg2);
@@ -483,8 +483,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = w->rstd1;
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
-  hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kWaves * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
-  launch_reduce<double>(h, w->dbg1_part, 8 * B, (long)(C1 * 2), w->dbg1);
+  hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  launch_reduce<double>(h, w->dbg1_part, 4 * B, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
                      P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),
                      G(h, w, L[0]->p_bn[1][1]), (float*)nullptr, (float*)nullptr, w->k1, w->rstd1);

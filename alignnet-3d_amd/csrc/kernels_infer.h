@@ -161,7 +161,9 @@ __device__ __forceinline__ void lds_rows(const float* arow, int lda, int kg, f32
 // acc[m] (+)= A[rows m*32.., :K] * W  for MR row tiles and one 32-channel tile.  Unrolled by three k-groups so the
 // three in-flight weight registers rotate roles WITHOUT register copies (a copy of an asm-load destination that is
 // still in flight reads garbage).
-template <int MR, bool CLEAR = true>
+// ASMB = true: hand-issued weight stream (only for kernels verified spill-free: a spilled / re-allocated asm-load
+// destination that is still in flight corrupts its new owner).  ASMB = false: compiler-managed loads.
+template <int MR, bool CLEAR = true, bool ASMB = true>
 __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp,
                                           int KG, int lane, f32x16 (&acc)[MR])
 {
@@ -172,6 +174,22 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   }
   const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
+  if (!ASMB) {
+    f32x4 bcur = Wp[lane];
+    f32x4 av[MR];
+    lds_rows<MR>(arow, lda, 0, av);
+    for (int kg = 0; kg < KG; ++kg) {
+      const int kn = kg + 1 < KG ? kg + 1 : kg;
+      const f32x4 bnext = Wp[kn * 64 + lane];
+      f32x4 an[MR];
+      lds_rows<MR>(arow, lda, kn, an);
+      mfma_kgroup<MR>(av, bcur, acc);
+      bcur = bnext;
+#pragma unroll
+      for (int m = 0; m < MR; ++m) av[m] = an[m];
+    }
+    return;
+  }
   const f32x4* wp = Wp + lane;
   const int last = KG - 1;
   wload_drain();   // stores / atomics of the previous epilogue must not sit between the counted loads

@@ -43,17 +43,10 @@ struct BwdB2Args {
   int dbg;
 };
 
-// 64 rows (two 32-row tiles) x one 32-channel tile, accumulating on top of acc
-__device__ __forceinline__ void mfma_rows2_acc(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp, int KG, int lane,
-                                               f32x16 (&acc)[2])
-{
-  mfma_rows<2, false>(A, lda, Wp, KG, lane, acc);
-}
-
-// Work split: item = (channel tile ct, row group rg of 64 rows) = wave  (C2 <= 128 -> CT2*2 <= 8 items), so
-// the wave that produced z2 for (ct, rg) also owns dh2 for (ct, rg) and keeps z2 in registers in between.
-// LDS: xs | X [128][ldb] | Y [128][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
-__global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a)
+// Work split in B2: item = (channel tile ct, 32-row group rg) = wave + 4*slot  (C2 <= 128 -> CT2*2 <= 8 items, two
+// static slots per wave), so the wave that produced z2 for an item also owns its dh2 and keeps z2 in registers.
+// LDS: xs | X [64][ldb] | Y [64][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
+__global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -62,21 +55,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int ld0 = a.ld0, ldb = a.ldb;
-  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const int ntiles = (a.N + kTT - 1) / kTT;
   float* xs = smem;
-  float* X = smem + kTilePts * 4;
-  float* Y = X + kTilePts * ldb;
-  int* hit_e = reinterpret_cast<int*>(Y + kTilePts * ldb);      // [C3] entry = channel | (row-in-tile << 16)
+  float* X = smem + kTT * 4;
+  float* Y = X + kTT * ldb;
+  int* hit_e = reinterpret_cast<int*>(Y + kTT * ldb);            // [C3] entry = channel | (row-in-tile << 16)
   float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
   int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
-  int* wtot = hoff + kWaves * (ntiles + 1);                       // [8] segment sizes
+  int* wtot = hoff + kTW * (ntiles + 1);                       // [8] segment sizes
   const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
-  const int ct = wave >> 1, rg = wave & 1;            // this wave's z2 / dh2 item
-  const bool has_item = ct < CT2;
-  const int col = ct * 32 + (lane & 31);
-  const bool live = has_item && col < a.C2;
-  double* my_dbg = a.dbg2_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2) * 2;   // slices: (rg, half)
+  constexpr int kSlots = 2;
   float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
   float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
 
@@ -87,7 +76,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
     for (int base = 0; base < a.C3; base += 64) {
       const int c = base + lane;
       const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-      cntw += __popcll(__ballot(id >= 0 && (id & (kWaves - 1)) == wave));
+      cntw += __popcll(__ballot(id >= 0 && (id & (kTW - 1)) == wave));
     }
     if (lane == 0) wtot[wave] = cntw;
     __syncthreads();
@@ -99,11 +88,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
       for (int base = 0; base < a.C3; base += 64) {
         const int c = base + lane;
         const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-        const bool m = id >= 0 && (id >> 7) == t && (id & (kWaves - 1)) == wave;
+        const bool m = id >= 0 && (id / kTT) == t && (id & (kTW - 1)) == wave;
         const unsigned long long mask = __ballot(m);
         if (m) {
           const int p = woff + pos + __popcll(mask & ((1ull << lane) - 1ull));
-          hit_e[p] = c | ((id & (kTilePts - 1)) << 16);
+          hit_e[p] = c | ((id % kTT) << 16);
           hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
         }
         pos += __popcll(mask);
@@ -112,11 +101,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
     if (lane == 0) hoff[wave * (ntiles + 1) + ntiles] = woff + pos;
   }
 
-  f32x16 z2[2];
-  double db = 0.0, dg = 0.0, s1c = 0.0;
+  f32x16 z2[kSlots][1];
+  double db[kSlots] = {0.0, 0.0}, dg[kSlots] = {0.0, 0.0}, s1c = 0.0;
 
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
@@ -125,48 +114,52 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
     __syncthreads();
 
     // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y ----
-    if (has_item) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { z2[0][r] = 0.f; z2[1][r] = 0.f; }
-      mfma_rows2_acc(X + rg * 64 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
-      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-      if (col < ((a.C2 + 7) & ~7)) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
+    for (int sl = 0; sl < kSlots; ++sl) {
+      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
+      if (ct < CT2) {
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C2;
+        mfma_rows<1, true, false>(X + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2[sl]);
+        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        if (col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = rg * 64 + acc_row(m, r, lane);
-            Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[m][r], sc, sh), 0.f) : 0.f;
+            const int row = rg * 32 + acc_row(0, r, lane);
+            Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[sl][0][r], sc, sh), 0.f) : 0.f;
           }
+        }
       }
     }
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
-    for (int item = wave; item < CT1 * CT1; item += kWaves) {
+    for (int item = wave; item < CT1 * CT1; item += kTW) {
       const int it = item / CT1, jt = item % CT1;
       const float* pa = X + half * ld0 + it * 32 + (lane & 31);
       const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
+      float old[16];
+      tile_prefetch(my_g1, a.C1, it, jt, a.C1, a.C1, first, lane, old);
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
-      accum_tile_global(my_g1, a.C1, it, jt, a.C1, a.C1, g, first, lane);
+      for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
+      tile_commit(my_g1, a.C1, it, jt, a.C1, a.C1, g, lane, old);
     }
     if (tid < a.C1) {
       float sm = 0.f;
-      for (int r = 0; r < kTilePts; ++r) sm += X[r * ld0 + tid];
+      for (int r = 0; r < kTT; ++r) sm += X[r * ld0 + tid];
       s1c += (double)sm;
     }
     __syncthreads();
 
     // ---- sparse rows of dh2: X <- 0, then X[row][:] += g * W3[:, c] for this tile's hits ----
-    for (int i = tid; i < kTilePts * ldb; i += kWaves * 64) X[i] = 0.f;
+    for (int i = tid; i < kTT * ldb; i += kTW * 64) X[i] = 0.f;
     __syncthreads();
     if (a.dbg & 8) {
       for (int base = 0; base < a.C3; base += 64) {
         const int c = base + lane;
-        const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTilePts : -1;
-        const bool hit = rel >= 0 && rel < nvalid && (rel & (kWaves - 1)) == wave;
+        const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTT : -1;
+        const bool hit = rel >= 0 && rel < nvalid && (rel & (kTW - 1)) == wave;
         unsigned long long mask = __ballot(hit);
         while (mask) {
           const int l = __ffsll((long long)mask) - 1;
@@ -202,64 +195,79 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b2(const BwdB2Args a
     __syncthreads();
 
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
-    if (has_item) {
-      const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
-      f32x16 acc[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+    for (int sl = 0; sl < kSlots; ++sl) {
+      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
+      if (ct < CT2) {
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C2;
+        const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
+        f32x16 acc[1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[(rg * 64 + acc_row(m, r, lane)) * ldb + col] : 0.f) + qb;
-      mfma_rows2_acc(Y + rg * 64 * ldb, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
-      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
-      const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
-      float lb = 0.f, lg = 0.f;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int r = 0; r < 16; ++r) acc[0][r] = (live ? X[(rg * 32 + acc_row(0, r, lane)) * ldb + col] : 0.f) + qb;
+        mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
+        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
+        const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
+        float lb = 0.f, lg = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = rg * 64 + acc_row(m, r, lane);
-          const bool on = row < nvalid && fmaf(z2[m][r], sc, sh) > 0.f;
-          const float dy = on ? acc[m][r] : 0.f;
-          lb += dy; lg += dy * ((z2[m][r] + bias - mu) * rs);
-          z2[m][r] = dy;   // the registers now hold dy2
+          const int row = rg * 32 + acc_row(0, r, lane);
+          const bool on = row < nvalid && fmaf(z2[sl][0][r], sc, sh) > 0.f;
+          const float dy = on ? acc[0][r] : 0.f;
+          lb += dy; lg += dy * ((z2[sl][0][r] + bias - mu) * rs);
+          z2[sl][0][r] = dy;   // the registers now hold dy2
         }
-      db += (double)lb; dg += (double)lg;
+        db[sl] += (double)lb; dg[sl] += (double)lg;
+      }
     }
     __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
 
     // ---- dy2 -> Y ; h1 -> X again ----
-    if (has_item && col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+    for (int sl = 0; sl < kSlots; ++sl) {
+      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
+      const int col = ct * 32 + (lane & 31);
+      if (ct < CT2 && col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[(rg * 64 + acc_row(m, r, lane)) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
+        for (int r = 0; r < 16; ++r) Y[(rg * 32 + acc_row(0, r, lane)) * ldb + col] = col < a.C2 ? z2[sl][0][r] : 0.f;
+      }
     }
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 
     // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
     {
-      float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;   // C2 % 4 == 0 (multiple of 32 enforced on the host)
-      for (int i = tid; i < nvalid * c4; i += kWaves * 64) {
+      for (int i = tid; i < nvalid * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
       }
-      for (int item = wave; item < CT1 * CT2; item += kWaves) {
+      for (int item = wave; item < CT1 * CT2; item += kTW) {
         const int it = item / CT2, jt = item % CT2;
         const float* pa = X + half * ld0 + it * 32 + (lane & 31);
         const float* pb = Y + half * ldb + jt * 32 + (lane & 31);
+        float old[16];
+        tile_prefetch(my_u2, a.C2, it, jt, a.C1, a.C2, first, lane, old);
         f32x16 u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < kTilePts; r += 2) u = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldb], u, 0, 0, 0);
-        accum_tile_global(my_u2, a.C2, it, jt, a.C1, a.C2, u, first, lane);
+        for (int r = 0; r < kTT; r += 2) u = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldb], u, 0, 0, 0);
+        tile_commit(my_u2, a.C2, it, jt, a.C1, a.C2, u, lane, old);
       }
     }
   }
-  if (live) { my_dbg[col * 2] = db; my_dbg[col * 2 + 1] = dg; }
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) {
+    const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
+    const int col = ct * 32 + (lane & 31);
+    if (ct < CT2 && col < a.C2) {
+      double* d = a.dbg2_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col) * 2;   // slice (rg, half)
+      d[0] = db[sl]; d[1] = dg[sl];
+    }
+  }
   if (tid < a.C1) a.s1_part[(size_t)cloud * a.C1 + tid] = s1c;
 }
 
@@ -275,10 +283,10 @@ struct BwdB1Args {
   const float* q2b;                                  // [2][C1]
   const float* dy2_store;
   float* dy1_store;                                  // [2B*N][C1]
-  double* dbg1_part;                                 // [2B][8 = 4 row groups x 2 halves][C1][2]
+  double* dbg1_part;                                 // [2B][4 = 2 row groups x 2 halves][C1][2]
 };
 
-__global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b1(const BwdB1Args a)
+__global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -287,25 +295,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b1(const BwdB1Args a
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
-  float* X = smem + kTilePts * 4;            // h1   [128][ld0]
-  float* Y = X + kTilePts * a.ld0;           // dy2  [128][ldb]
+  float* X = smem + kTT * 4;            // h1   [64][ld0]
+  float* Y = X + kTT * a.ld0;           // dy2  [64][ldb]
   const int ld0 = a.ld0, ldb = a.ldb;
   const int CT1 = (a.C1 + 31) >> 5, KGv = (a.C2 + 7) >> 3, KGq = (a.C1 + 7) >> 3;
-  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const int ntiles = (a.N + kTT - 1) / kTT;
   const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
-  // items: (column tile ct, row group rg of 32 rows); item = wave + s*8 ; at most kStatSlots per wave (C1 <= 256)
-  const int nitems = CT1 * 4;
+  // items: (column tile ct, 32-row group rg)
+  const int nitems = CT1 * 2;
 
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     {
-      const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;
-      for (int i = tid; i < kTilePts * c4; i += kWaves * 64) {
+      for (int i = tid; i < kTT * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
@@ -315,54 +323,37 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_bwd_b1(const BwdB1Args a
     __syncthreads();
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
-    for (int item = wave; item < nitems; item += kWaves) {
-      {
-        const int ct = item >> 2, rg = item & 3;
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C1;
-        f32x16 acc;
-        const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
+    for (int item = wave; item < nitems; item += kTW) {
+      const int ct = item >> 1, rg = item & 1;
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < a.C1;
+      f32x16 acc[1];
+      const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
+      double* dslice = a.dbg1_part + (((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * a.C1 + (live ? col : 0)) * 2;   // slice (rg, half)
+      const double o0 = (first || !live) ? 0.0 : dslice[0], o1 = (first || !live) ? 0.0 : dslice[1];
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = qb;
-        {
-          const float* arow = Y + (rg * 32 + (lane & 31)) * ldb + (lane >> 5) * 4;
-          const f32x4* Wp = v2img + (size_t)ct * KGv * 64;
-          for (int kg = 0; kg < KGv; ++kg) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8), bv = Wp[kg * 64 + lane];
+      for (int r = 0; r < 16; ++r) acc[0][r] = qb;
+      mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, v2img + (size_t)ct * KGv * 64, KGv, lane, acc);
+      mfma_rows<1, false, false>(X + rg * 32 * ld0, ld0, q2img + (size_t)ct * KGq * 64, KGq, lane, acc);
+      const float w0 = live ? a.w1[col] : 0.f, wa = live ? a.w1[a.C1 + col] : 0.f, wb = live ? a.w1[2 * a.C1 + col] : 0.f;
+      const float bias = live ? a.b1[col] : 0.f, mu = live ? a.mean1[tower * a.C1 + col] : 0.f;
+      const float rs = live ? a.rstd1[tower * a.C1 + col] : 0.f;
+      float lb = 0.f, lg = 0.f;
+      float* dst = a.dy1_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-          }
-        }
-        {
-          const float* arow = X + (rg * 32 + (lane & 31)) * ld0 + (lane >> 5) * 4;
-          const f32x4* Wp = q2img + (size_t)ct * KGq * 64;
-          for (int kg = 0; kg < KGq; ++kg) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8), bv = Wp[kg * 64 + lane];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-          }
-        }
-        const float w0 = live ? a.w1[col] : 0.f, wa = live ? a.w1[a.C1 + col] : 0.f, wb = live ? a.w1[2 * a.C1 + col] : 0.f;
-        const float bias = live ? a.b1[col] : 0.f, mu = live ? a.mean1[tower * a.C1 + col] : 0.f;
-        const float rs = live ? a.rstd1[tower * a.C1 + col] : 0.f;
-        float lb = 0.f, lg = 0.f;
-        float* dst = a.dy1_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
-          const float dy = on ? acc[r] : 0.f;
-          const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
-          const float z = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0)) + bias;
-          lb += dy; lg += dy * ((z - mu) * rs);
-          if (live && row < nvalid) dst[(size_t)row * a.C1 + col] = dy;
-        }
-        if (live) {   // slice (rg, half) of this cloud
-          double* d = a.dbg1_part + (((size_t)cloud * 8 + rg * 2 + (lane >> 5)) * a.C1 + col) * 2;
-          const double o0 = first ? 0.0 : d[0], o1 = first ? 0.0 : d[1];
-          d[0] = o0 + (double)lb;
-          d[1] = o1 + (double)lg;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
+        const float dy = on ? acc[0][r] : 0.f;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float z = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0)) + bias;
+        lb += dy; lg += dy * ((z - mu) * rs);
+        if (live && row < nvalid) dst[(size_t)row * a.C1 + col] = dy;
+      }
+      if (live) {
+        dslice[0] = o0 + (double)lb;
+        dslice[1] = o1 + (double)lg;
       }
     }
   }

@@ -19,6 +19,10 @@
 
 namespace alignnet {
 
+// Training kernels walk 64-point tiles: LDS <= 77 KiB per workgroup -> two workgroups (two clouds) per CU overlap
+// each other's barriers, global round trips and epilogues.
+constexpr int kTT = 64;
+constexpr int kTW = 4;     // waves per training workgroup: 2 workgroups/CU = 2 waves/SIMD -> 256 VGPRs each, no spills
 
 struct TrainFwdArgs {
   const float* pcs[2];
@@ -42,19 +46,25 @@ struct TrainFwdArgs {
   int dbg;                 // debug/ablation flags (0 in production)
 };
 
-// Accumulate one 32x32 MFMA result tile into a lane-owned global matrix: all loads first, then all stores
-// (an unrolled  *d = *d + v  chain serialises on possible aliasing: one memory round trip per element).
-__device__ __forceinline__ void accum_tile_global(float* __restrict__ base, long ld, int it, int jt, int rows, int cols, const f32x16& v,
-                                                  bool first, int lane)
+// Accumulate one 32x32 MFMA result tile into a lane-owned global matrix.  The old values are requested BEFORE the
+// MFMA loop that produces the new ones and pinned there (compiler memory barrier: hipcc otherwise sinks the loads
+// next to their use and exposes one L2 round trip per item), then added and stored afterwards.
+__device__ __forceinline__ void tile_prefetch(const float* __restrict__ base, long ld, int it, int jt, int rows, int cols, bool first,
+                                              int lane, float (&old)[16])
 {
   const int j = jt * 32 + (lane & 31);
-  if (j >= cols) return;
-  float old[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    old[r] = (first || i >= rows) ? 0.f : base[(size_t)i * ld + j];
+    old[r] = (first || i >= rows || j >= cols) ? 0.f : base[(size_t)i * ld + j];
   }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void tile_commit(float* __restrict__ base, long ld, int it, int jt, int rows, int cols, const f32x16& v,
+                                            int lane, const float (&old)[16])
+{
+  const int j = jt * 32 + (lane & 31);
+  if (j >= cols) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -66,8 +76,8 @@ __device__ __forceinline__ void accum_tile_global(float* __restrict__ base, long
 __device__ __forceinline__ void load_tile_xform(const float* __restrict__ pc, const float* __restrict__ xf, int N,
                                                 int tile, float* __restrict__ xs, int tid)
 {
-  if (tid < kTilePts) {
-    const int n = min(tile * kTilePts + tid, N - 1);
+  if (tid < kTT) {
+    const int n = min(tile * kTT + tid, N - 1);
     const float* p = pc + (size_t)n * 3;
     const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
     xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
@@ -81,6 +91,7 @@ __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, cons
                                               const float* __restrict__ sc, const float* __restrict__ sh,
                                               float* __restrict__ out, int ldo, int nvalid, int tid)
 {
+  constexpr int kRowsPerPass = kTW * 2;   // 32 lanes cover 32 channels of one row
   const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (C1 + 7) & ~7;
   for (int c = c0; c < cw; c += 32) {
@@ -88,8 +99,8 @@ __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, cons
     const float w0 = live ? w1[c] : 0.f, wa = live ? w1[C1 + c] : 0.f, wb = live ? w1[2 * C1 + c] : 0.f;
     const float s = live ? sc[c] : 0.f, t = live ? sh[c] : 0.f;
 #pragma unroll
-    for (int rr = 0; rr < kTilePts / 16; ++rr) {
-      const int row = rr * 16 + r0;
+    for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+      const int row = rr * kRowsPerPass + r0;
       const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
       const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
       out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
 // Slice layout: part[(cloud * S + slice) * n + i]; the two half-waves of a column are slices 0/1.
 // ---------------------------------------------------------------------------------
 template <int PHASE>
-__global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
+__global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -169,20 +180,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
-  float* buf0 = smem + kTilePts * 4;
-  float* buf1 = buf0 + kTilePts * a.ld[0];
+  float* buf0 = smem + kTT * 4;
+  float* buf1 = buf0 + kTT * a.ld[0];
   const int ld0 = a.ld[0], ld1 = a.ld[1];
   const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
   const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
-  const int ntiles = (a.N + kTilePts - 1) / kTilePts;
+  const int ntiles = (a.N + kTT - 1) / kTT;
   const int Cs = PHASE == 2 ? a.C2 : a.C3;
   double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2] (phase 3; phase 2 uses 4 slices)
   float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * a.C2 * a.C2 : nullptr;
 
+  // Two workgroups share a CU and run identical per-tile timelines; started together they stay in lockstep and
+  // their non-MFMA phases coincide.  Stagger the second resident wave of workgroups by about half a tile.
+  if (PHASE == 3 && (a.dbg & 16) && ((blockIdx.x / 256) & 1)) {
+    const int reps = (a.dbg >> 8) & 0xff;
+    for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int nvalid = min(kTilePts, a.N - tile * kTilePts);
+    const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
@@ -190,11 +208,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, buf0, ld0, nvalid, tid);
     __syncthreads();
 
-    // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 64-row half) so that all 8 waves work (C2 = 128 -> 8 items) ----
-    for (int item = wave; item < CT2 * 2; item += kWaves) {
+    // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 32-row group): C2 = 128 -> 8 items, one per wave ----
+    for (int item = wave; item < CT2 * 2; item += kTW) {
       const int ct = item >> 1, rg = item & 1;
-      f32x16 acc[2];
-      mfma_rows<2>(buf0 + rg * 64 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+      f32x16 acc[1];
+      mfma_rows<1, true, true>(buf0 + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C2;
       if (PHASE == 2) {
@@ -204,13 +222,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
         const float z0 = acc[0][0] + bias;
         float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (rg * 64 + acc_row(m, r, lane) < nvalid) {
-              const float dlt = (acc[m][r] + bias) - z0;
-              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
-            }
+        for (int r = 0; r < 16; ++r)
+          if (rg * 32 + acc_row(0, r, lane) < nvalid) {
+            const float dlt = (acc[0][r] + bias) - z0;
+            s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
+          }
         if (live) {
           double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col) * 2;   // slice (rg, half)
           const double zd = (double)z0, n = (double)cnt;
@@ -224,14 +240,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
         float lsum = 0.f;
         const bool wr = col < ((a.C2 + 7) & ~7);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rg * 64 + acc_row(m, r, lane);
-            const float h = row < nvalid ? fmaxf(fmaf(acc[m][r], sc, sh), 0.f) : 0.f;
-            lsum += h;
-            if (wr) buf1[row * ld1 + col] = h;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 32 + acc_row(0, r, lane);
+          const float h = row < nvalid ? fmaxf(fmaf(acc[0][r], sc, sh), 0.f) : 0.f;
+          lsum += h;
+          if (wr) buf1[row * ld1 + col] = h;
+        }
         if (live) {
           double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col;
           *cs = first ? (double)lsum : *cs + (double)lsum;
@@ -243,60 +257,58 @@ __global__ __launch_bounds__(kWaves * 64, 2) void train_fwd_phase23(const TrainF
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
     if (!(a.dbg & 2)) {
-      float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTilePts) * a.C2;
+      float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;
-      for (int i = tid; i < nvalid * c4; i += kWaves * 64) {
+      for (int i = tid; i < nvalid * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(buf1 + row * ld1 + q * 4);
       }
     }
 
-    // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's 128 rows ----
-    for (int item = wave; item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kWaves) {
+    // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's rows ----
+    for (int item = wave; item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kTW) {
       const int it = item / CT2, jt = item % CT2;
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
+      float old[16];
+      tile_prefetch(my_gram, a.C2, it, jt, a.C2, a.C2, first, lane, old);
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < kTilePts; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld1], pb[r * ld1], g, 0, 0, 0);
-      accum_tile_global(my_gram, a.C2, it, jt, a.C2, a.C2, g, first, lane);
+      for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld1], pb[r * ld1], g, 0, 0, 0);
+      tile_commit(my_gram, a.C2, it, jt, a.C2, a.C2, g, lane, old);
     }
 
-    // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points.
-    //      Two 64-row halves per channel tile (32 accumulator registers instead of 64; the second pass re-reads
-    //      the 16 KiB weight tile from L2). ----
-    for (int ct = wave; ct < CT3; ct += kWaves) {
+    // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
+    for (int ct = wave; ct < CT3; ct += kTW) {
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
       const float bias = live ? a.b3[col] : 0.f;
       const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
       float be = (first || !live) ? -INFINITY : my_ext[col];
       int bi = (first || !live) ? 0 : my_idx[col];
-      float z0 = 0.f, s1 = 0.f, s2 = 0.f; int cnt = 0;
-#pragma unroll 1
-      for (int rg = 0; rg < 2; ++rg) {
-        f32x16 acc[2];
-        mfma_rows<2>(buf1 + rg * 64 * ld1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
-        if (rg == 0) z0 = acc[0][0] + bias;
+      const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
+      asm volatile("" ::: "memory");   // keep the four loads above the MFMA loop (see tile_prefetch)
+      f32x16 acc[2];
+      mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
+      const float z0 = acc[0][0] + bias;
+      float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rg * 64 + acc_row(m, r, lane);
-            if (row < nvalid) {
-              const float z = acc[m][r] + bias, dlt = z - z0;
-              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
-              const float v = z * sg;
-              if (v > be) { be = v; bi = tile * kTilePts + row; }
-            }
+        for (int r = 0; r < 16; ++r) {
+          const int row = acc_row(m, r, lane);
+          if (row < nvalid) {
+            const float z = acc[m][r] + bias, dlt = z - z0;
+            s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
+            const float v = z * sg;
+            if (v > be) { be = v; bi = tile * kTT + row; }
           }
-      }
+        }
       if (live && !(a.dbg & 4)) {
         const double zd = (double)z0, n = (double)cnt;
         const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-        const double o0 = first ? 0.0 : my_stat[col * 2], o1 = first ? 0.0 : my_stat[col * 2 + 1];
         my_stat[col * 2] = o0 + ls;
         my_stat[col * 2 + 1] = o1 + lss;
         my_ext[col] = be; my_idx[col] = bi;
