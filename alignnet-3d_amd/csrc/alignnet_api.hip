@@ -3,6 +3,7 @@
 // point fails with an error when HIP is unavailable.
 #include "engine.h"
 #include "kernels_infer.h"
+#include "kernels_dgcnn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -69,10 +70,11 @@ static Stack conv_stack(alignnet_handle* h, const std::string& prefix, const ali
   const bool dg = h->cfg.backbone == 1;
   int cin = dg ? 2 * h->cfg.num_channels : h->cfg.num_channels;
   for (int i = 0; i < w.n; ++i) {
-    const bool first = (i == 0) && !dg;
-    // utils/tf_util.py:148-152: fan = kh*kw*channels; first PointNet conv has kernel [1, num_channels] on 1 channel
-    const int fi = first ? h->cfg.num_channels : cin, fo = first ? h->cfg.num_channels * w.w[i] : w.w[i];
-    add_layer(h, prefix + "/conv" + std::to_string(i + 1), cin, w.w[i], true, true, true, first, fi, fo);
+    const bool pn_first = (i == 0) && !dg;
+    // utils/tf_util.py:148-152: fan = kh*kw*channels; first PointNet conv has kernel [1, num_channels] on 1 channel;
+    // DGCNN's first conv is a 1x1 conv on the 2*num_channels edge feature (tf_util_dgcnn.py:705)
+    const int fi = pn_first ? h->cfg.num_channels : cin, fo = pn_first ? h->cfg.num_channels * w.w[i] : w.w[i];
+    add_layer(h, prefix + "/conv" + std::to_string(i + 1), cin, w.w[i], true, true, true, i == 0, fi, fo);
     cin = w.w[i];
   }
   return st;
@@ -181,6 +183,7 @@ static void free_ws(alignnet_handle* h)
 {
   for (int t = 0; t < 2; ++t) if (h->ws.d_pcs[t]) { hipFree(h->ws.d_pcs[t]); h->ws.d_pcs[t] = nullptr; }
   if (h->ws.d_all) { hipFree(h->ws.d_all); h->ws.d_all = nullptr; }
+  if (h->ws.d_nn) { hipFree(h->ws.d_nn); h->ws.d_nn = nullptr; }
   h->ws.cap = 0;
 }
 
@@ -368,6 +371,9 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
     for (int i = 0; i < 8; ++i) w.outs[i] = base + o_out[i];
     w.cap = B;
   }
+  if (h->cfg.backbone == 1 && !w.d_nn) {
+    HIP_TRY(h, hipMalloc(&w.d_nn, (size_t)2 * w.cap * N * 20 * sizeof(int)));
+  }
   if (need_inputs && !w.d_pcs[0]) {
     for (int t = 0; t < 2; ++t) HIP_TRY(h, hipMalloc(&w.d_pcs[t], (size_t)w.cap * N * 3 * sizeof(float)));
   }
@@ -431,6 +437,45 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   return 0;
 }
 
+static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* p1, const float* p2, int B, float* pooled,
+                              long tower_stride, long row_stride, size_t pooled_floats)
+{
+  DgcnnArgs a;
+  a.pcs[0] = p1; a.pcs[1] = p2; a.xform = h->ws.xform; a.nn = h->ws.d_nn; a.pooled = pooled;
+  a.tower_stride = tower_stride; a.row_stride = row_stride;
+  a.B = B; a.N = h->cfg.num_points; a.k = 20; a.nlayers = st.n;   // k = 20 is hard-coded in the reference (tp8.py:33)
+  int wmax[2] = {8, 8};
+  for (int i = 0; i < st.n - 1; ++i) wmax[i & 1] = std::max(wmax[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
+  a.ld[0] = wmax[0] + 4; a.ld[1] = wmax[1] + 4;
+  const size_t lds = ((size_t)kDgTile * 8 + (size_t)kDgTile * (a.ld[0] + a.ld[1])) * sizeof(float);
+  if (lds > 160 * 1024) return fail(h, "dgcnn hidden widths need more than 160 KiB of LDS per 64-point tile");
+  if (h->layers[st.first + st.n - 2].cout > 256) return fail(h, "dgcnn: last edge-conv width limited to 256 channels");
+  for (int i = 0; i < st.n; ++i) {
+    const Layer& L = h->layers[st.first + i];
+    a.L[i].w = L.first_conv ? h->d_params + h->params[L.p_w].offset : h->d_wp + L.off_wp;
+    a.L[i].scale = h->d_scale + L.off_ss;
+    a.L[i].shift = h->d_shift + L.off_ss;
+    a.L[i].cin = L.cin; a.L[i].cout = L.cout;
+  }
+  HIP_TRY(h, hipMemsetAsync(pooled, 0, pooled_floats * sizeof(float), h->stream));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
+  std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
+  if (h->prof) {
+    if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
+    else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
+    hipEventRecord(evp.first, h->stream);
+  }
+  hipLaunchKernelGGL(dgcnn_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+  if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 static int run_fc(alignnet_handle* h, const Layer& L, const float* in, long ldin, float* out, long ldout, int M,
                   int rows_per_set, bool relu)
 {
@@ -460,8 +505,13 @@ static int run_head(alignnet_handle* h, const Stack& st, const float* in, long l
 
 static int forward_device(alignnet_handle* h, const float* p1, const float* p2, int B, float* const outs[8])
 {
-  if (h->cfg.backbone != 0) return fail(h, "alignnet_forward: dgcnn backbone is not implemented in this build");
   if (fold_for_eval(h)) return 1;
+  const bool dg = h->cfg.backbone == 1;
+  if (dg && h->cfg.num_points > 64 * kKnnMaxPerLane) return fail(h, "dgcnn: num_points limited to 4096 (register-resident kNN)");
+  if (dg && h->cfg.num_points < 20) return fail(h, "dgcnn: num_points must be >= k = 20");
+  auto backbone = [&](const Stack& st, float* pooled, long ts, long rs, size_t n) {
+    return dg ? run_backbone_dgcnn(h, st, p1, p2, B, pooled, ts, rs, n) : run_backbone(h, st, p1, p2, B, pooled, ts, rs, n);
+  };
   Workspace& w = h->ws;
   const int N = h->cfg.num_points, nb = h->cfg.num_bins, nb2 = 2 * nb;
   const int C1 = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
@@ -470,18 +520,20 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int B2 = 2 * B;
   if (h->prof) hipEventRecord(h->ev[0], h->stream);
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
+  if (dg)   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
+    hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
   // stage 1 (tp8.py:108-109)
-  if (run_backbone(h, h->s1_conv, p1, p2, B, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
+  if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
   if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B)) return 1;
   hipLaunchKernelGGL(stage1_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o1, w.center_mean, B, w.s1c,
                      w.xform, outs[2], outs[3]);
   // stage 2 (tp8.py:113-125)
-  if (run_backbone(h, h->s2_conv, p1, p2, B, w.pool2, (long)B * C2, C2, (size_t)B2 * C2)) return 1;
+  if (backbone(h->s2_conv, w.pool2, (long)B * C2, C2, (size_t)B2 * C2)) return 1;
   if (run_head(h, h->s2_fc, w.pool2, C2, w.o2, 3 + nb2, B2, B)) return 1;
   hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o2, 3 + nb2, w.s1c, B, nb, w.s2c,
                      w.xform, w.theta, w.cls, outs[4], outs[5], outs[6], outs[7]);
   // stage 3: embedding of the normalised clouds, concat (tp8.py:130,144,153) = row b holds [emb1 | emb2]
-  if (run_backbone(h, h->emb_conv, p1, p2, B, w.emb, CE, 2L * CE, (size_t)B2 * CE)) return 1;
+  if (backbone(h->emb_conv, w.emb, CE, 2L * CE, (size_t)B2 * CE)) return 1;
   if (run_head(h, h->rem_fc, w.emb, 2L * CE, w.o3, 3 + nb2, B, B)) return 1;
   hipLaunchKernelGGL(final_finish_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, w.o3, 3 + nb2, w.s2c, B, nb, outs[0], outs[1]);
   if (h->prof) hipEventRecord(h->ev[1], h->stream);

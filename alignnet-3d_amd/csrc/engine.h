@@ -35,6 +35,7 @@ struct Stack { int first, n; };   // range of layers
 struct Workspace {
   int cap = 0;                     // pairs
   float* d_pcs[2] = {nullptr, nullptr};
+  int* d_nn = nullptr;             // DGCNN neighbour indices [2*cap][N][20]
   float* d_all = nullptr;          // everything else, carved below
   float *xform, *center_mean, *s1c, *s2c, *theta;
   int* cls;

@@ -1,0 +1,294 @@
+// DGCNN backbone, eval mode (models/tp8.py:30-46 with utils/tf_util_dgcnn.py:638-706), gfx950 only.
+//
+//   knn_kernel    pairwise_distance + knn: k nearest neighbours (self included) per point.  The reference
+//                 materialises the [B,N,N] distance matrix (64 MB per cloud at N=4096); here one wave owns one query
+//                 point, keeps its N candidate distances in registers and finds the k-th smallest by bisection on
+//                 order-preserving integer keys, so N^2 never leaves the register file.
+//   dgcnn_fused   edge feature [x_i, x_j - x_i] -> 1x1 convs widths[:-1] over the k neighbours -> max over k ->
+//                 conv widths[-1] -> max over points, fused; activations stay in LDS / registers (the reference
+//                 round-trips [B,N,20,C] tensors: 872 MB per pair at N=4096).
+// The kNN graph is computed once per cloud in the mean-centred frame and shared by the three stages: the later
+// frames differ by a rigid motion, which leaves the graph unchanged (SURVEY.md 8.A6 vii; ties at the k-th
+// neighbour aside).
+#pragma once
+#include "kernels_infer.h"
+
+namespace alignnet {
+
+constexpr int kKnnMaxPerLane = 64;   // N <= 64 * 64 = 4096 candidates per query
+constexpr int kKnnList = 256;        // survivors of the first bound that are selected from LDS
+
+// order-preserving map float -> uint32 (handles the slightly negative "distances" the TF formula can produce)
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// grid: (ceil(N / 4), 2B), block 256 = 4 waves, one query point per wave
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                 const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
+{
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cloud = blockIdx.y, tower = cloud >= B, b = cloud - tower * B;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= N) return;
+  const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
+  const float cx = center[cloud * 3], cy = center[cloud * 3 + 1], cz = center[cloud * 3 + 2];
+  const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
+  const float qq = qx * qx + qy * qy + qz * qz;   // reduce_sum(square(x)) (tf_util_dgcnn.py:655)
+  uint32_t key[kKnnMaxPerLane];
+  const int per = (N + 63) >> 6;
+#pragma unroll
+  for (int t = 0; t < kKnnMaxPerLane; ++t) {
+    key[t] = 0xffffffffu;
+    if (t < per) {
+      const int j = t * 64 + lane;
+      if (j < N) {
+        const float x = pc[j * 3] - cx, y = pc[j * 3 + 1] - cy, z = pc[j * 3 + 2] - cz;
+        const float inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
+        key[t] = fkey(qq + inner + (x * x + y * y + z * z));              // square + inner + square^T (:657)
+      }
+    }
+  }
+  // ---- 1. upper bound: the k-th smallest of the 64 per-lane minima (k lanes hold a value <= it) ----
+  uint32_t lmin = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < kKnnMaxPerLane; ++t)
+    if (t < per) lmin = min(lmin, key[t]);
+  uint32_t lo = 0u, hi = 0xffffffffu;
+  if (k <= 64) {
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (__popcll(__ballot(lmin <= mid)) >= k) hi = mid; else lo = mid + 1;
+    }
+  } else lo = 0xffffffffu;
+  const uint32_t T0 = lo;
+  // ---- 2. compact the survivors (key <= T0), in increasing point index, into this wave's LDS list ----
+  __shared__ uint32_t s_key[4][kKnnList];
+  __shared__ int s_idx[4][kKnnList];
+  int M = 0;
+#pragma unroll
+  for (int t = 0; t < kKnnMaxPerLane; ++t)
+    if (t < per) {
+      const bool sel = key[t] <= T0 && t * 64 + lane < N;
+      const unsigned long long m = __ballot(sel);
+      const int pos = M + __popcll(m & ((1ull << lane) - 1ull));
+      if (sel && pos < kKnnList) { s_key[wave][pos] = key[t]; s_idx[wave][pos] = t * 64 + lane; }
+      M += __popcll(m);
+    }
+  int* out = nn + ((size_t)cloud * N + q) * k;
+  if (M <= kKnnList) {
+    // ---- 3a. k-th smallest of the list by bisection (<= 4 entries per lane), emit in list (= index) order ----
+    uint32_t lk[kKnnList / 64];
+#pragma unroll
+    for (int u = 0; u < kKnnList / 64; ++u) lk[u] = u * 64 + lane < M ? s_key[wave][u * 64 + lane] : 0xffffffffu;
+    lo = 0u; hi = T0;
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int u = 0; u < kKnnList / 64; ++u) c += __popcll(__ballot(lk[u] <= mid));
+      if (c >= k) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t T = lo;
+    int written = 0;
+    for (int pass = 0; pass < 2 && written < k; ++pass)
+#pragma unroll
+      for (int u = 0; u < kKnnList / 64; ++u) {
+        const bool sel = (pass == 0 ? lk[u] < T : lk[u] == T) && u * 64 + lane < M;
+        const unsigned long long m = __ballot(sel);
+        const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < k) out[pos] = s_idx[wave][u * 64 + lane];
+        written += __popcll(m);
+      }
+    return;
+  }
+  // ---- 3b. (rare: more than kKnnList survivors) full bisection over all candidates ----
+  lo = 0u; hi = T0;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < kKnnMaxPerLane; ++t)
+      if (t < per) c += key[t] <= mid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (c >= k) hi = mid; else lo = mid + 1;
+  }
+  const uint32_t T = lo;
+  int written = 0;
+  for (int pass = 0; pass < 2 && written < k; ++pass) {
+#pragma unroll
+    for (int t = 0; t < kKnnMaxPerLane; ++t)
+      if (t < per) {
+        const bool sel = (pass == 0 ? key[t] < T : key[t] == T) && t * 64 + lane < N;
+        const unsigned long long m = __ballot(sel);
+        const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < k) out[pos] = t * 64 + lane;
+        written += __popcll(m);
+      }
+  }
+}
+
+struct DgcnnArgs {
+  const float* pcs[2]; const float* xform; const int* nn;   // nn: [2B][N][k]
+  float* pooled; long tower_stride, row_stride;
+  int B, N, k, nlayers;
+  int ld[2];
+  ConvLayerDev L[kMaxConv];   // L[0].w = raw [6][C1]; others packed images
+};
+
+constexpr int kDgTile = 64;   // points per workgroup (two 32-row MFMA tiles)
+
+// LDS: es [64][8] | buf0 [64][ld0] | buf1 [64][ld1]
+__global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.y, tile = blockIdx.x;
+  const int tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* es = smem;                                   // edge features of the current neighbour slot
+  const int boff[2] = {kDgTile * 8, kDgTile * 8 + kDgTile * a.ld[0]};
+  const int nl = a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
+  const int nvalid = min(kDgTile, a.N - tile * kDgTile);
+
+  // running max over the k neighbours of the LAST edge layer's pre-activation (sc*acc+sh); relu folded after the max
+  const ConvLayerDev& LE = a.L[nl - 2];
+  const int CTE = (LE.cout + 31) >> 5;
+  // item = (32-row tile m of the 64 points, channel tile ct): wave handles items wave, wave+8, ... (<= 2 slots: C <= 256)
+  constexpr int kSlots = 2;
+  f32x16 best[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) best[s][r] = -INFINITY;
+
+  for (int slot = 0; slot < a.k; ++slot) {
+    __syncthreads();
+    // ---- edge feature [x_i, x_j - x_i] in the stage frame: x' = (p - c) R ----
+    if (tid < kDgTile) {
+      const int n = min(tile * kDgTile + tid, a.N - 1);
+      const int j = a.nn[((size_t)cloud * a.N + n) * a.k + slot];
+      const float* p = pc + (size_t)n * 3;
+      const float* pj = pc + (size_t)j * 3;
+      const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+      const float dx = pj[0] - p[0], dy = pj[1] - p[1], dz = pj[2] - p[2];
+      float* e = es + tid * 8;
+      e[0] = x * xf[3] + y * xf[6] + z * xf[9];
+      e[1] = x * xf[4] + y * xf[7] + z * xf[10];
+      e[2] = x * xf[5] + y * xf[8] + z * xf[11];
+      e[3] = dx * xf[3] + dy * xf[6] + dz * xf[9];
+      e[4] = dx * xf[4] + dy * xf[7] + dz * xf[10];
+      e[5] = dx * xf[5] + dy * xf[8] + dz * xf[11];
+    }
+    __syncthreads();
+    // ---- edge layer 0: K = 6 lift on the VALU ----
+    {
+      const ConvLayerDev& L = a.L[0];
+      float* out = smem + boff[0];
+      const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;
+      const int cw = (L.cout + 7) & ~7;
+      for (int c = c0; c < cw; c += 32) {
+        const bool live = c < L.cout;
+        float w[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) w[d] = live ? L.w[d * L.cout + c] : 0.f;
+        const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kDgTile / 16; ++rr) {
+          const int row = rr * 16 + r0;
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+          float acc = e0[0] * w[0];
+          acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
+          acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
+          out[row * ldo + c] = fmaxf(fmaf(acc, sc, sh), 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- middle edge layers 1 .. nl-3 (none for 3-layer width lists) ----
+    for (int l = 1; l < nl - 2; ++l) {
+      const ConvLayerDev& L = a.L[l];
+      const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
+      float* out = smem + ((l & 1) ? boff[1] : boff[0]);
+      hidden_layer<2, kDgTile>(in, a.ld[(l - 1) & 1], out, a.ld[l & 1], L, tower, wave, lane);
+      __syncthreads();
+    }
+    // ---- last edge layer on MFMA; running max over neighbour slots stays in registers ----
+    {
+      const int l = nl - 2;
+      const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
+      const int ldi = a.ld[(l - 1) & 1];
+      const int KG = (LE.cin + 7) >> 3;
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s) {
+        const int item = wave + s * kWaves;
+        if (item < CTE * 2) {
+          const int ct = item >> 1, m = item & 1;
+          f32x16 acc[1];
+          mfma_rows<1>(in + m * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(LE.w) + (size_t)ct * KG * 64, KG, lane, acc);
+          const int col = ct * 32 + (lane & 31);
+          const bool live = col < LE.cout;
+          const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[0][r], sc, sh));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- relu(max_k) -> LDS point features [64][C_E] (tp8.py:42) ----
+  const int lh = (nl - 2) & 1;   // buffer that receives the pooled edge features
+  {
+    float* out = smem + (lh ? boff[1] : boff[0]);
+    const int ldo = a.ld[lh];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int item = wave + s * kWaves;
+      if (item < CTE * 2) {
+        const int ct = item >> 1, m = item & 1;
+        const int col = ct * 32 + (lane & 31);
+        if (col < ((LE.cout + 7) & ~7)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[row * ldo + col] = (col < LE.cout && row < nvalid) ? fmaxf(best[s][r], 0.f) : 0.f;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- point conv (widths[-1]) + max over the tile's points (tp8.py:43-45) ----
+  {
+    const ConvLayerDev& L = a.L[nl - 1];
+    const float* in = smem + (lh ? boff[1] : boff[0]);
+    const int ldi = a.ld[lh];
+    const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
+    float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
+    for (int ct = wave; ct < CT; ct += kWaves) {
+      f32x16 acc[2];
+      mfma_rows<2>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < L.cout;
+      const float sc = live ? L.scale[tower * L.cout + col] : 0.f, sh = live ? L.shift[tower * L.cout + col] : 0.f;
+      float mx = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < nvalid) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
+    }
+  }
+}
+
+}  // namespace alignnet

@@ -41,15 +41,24 @@ N_POINTS = 1024
 
 
 def backbone_macs_per_cloud(cfg):
-    """MACs of the three fused backbones for one cloud (the dominant kernel's algorithmic work)."""
+    """MACs of the three fused backbones for one cloud (the dominant kernel's algorithmic work).
+    dgcnn (models/tp8.py:30-46): edge convs widths[:-1] on k = 20 edges per point, then widths[-1] per point."""
     o = cfg["model"]["options"]
     n = cfg["model"]["num_points"]
+    dg = cfg["model"]["backbone"] == "dgcnn"
     tot = 0
     for widths in (o["s1transformer"][0], o["s2transformer"][0], o["embedding"]):
-        cin = 3
-        for c in widths:
-            tot += cin * c
-            cin = c
+        if dg:
+            cin, edge = 6, 0
+            for c in widths[:-1]:
+                edge += cin * c
+                cin = c
+            tot += 20 * edge + cin * widths[-1]
+        else:
+            cin = 3
+            for c in widths:
+                tot += cin * c
+                cin = c
     return tot * n
 
 
@@ -101,6 +110,9 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--workload", choices=["pointnet", "dgcnn"], default="pointnet",
+                    help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (inference only)")
+    ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +134,12 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = alignnet3d.default_model_config()
+    npts = args.points or (4096 if args.workload == "dgcnn" else N_POINTS)
+    cfg["model"]["num_points"] = npts
+    cfg["model"]["backbone"] = args.workload
+    if args.workload == "dgcnn":
+        args.no_train_leg = True
+        args.no_cpu_baseline = True
     cfg["training"]["batch_size"] = args.batch * world
     B = args.batch
     eng = alignnet3d.Engine(cfg, device=local_rank, seed=0)
@@ -130,7 +148,7 @@ def main():
         if name.endswith("moving_var"):
             eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
 
-    d = R.synth_pairs(B, N_POINTS, seed=1234 + rank, dtype=np.float32)
+    d = R.synth_pairs(B, npts, seed=1234 + rank, dtype=np.float32)
     p1 = torch.from_numpy(d["pcs1"]).to(dev)
     p2 = torch.from_numpy(d["pcs2"]).to(dev)
     nb2 = 2 * cfg["model"]["angles"]["num_bins"]
@@ -208,19 +226,23 @@ def main():
         achieved = bb_flops_per_step / (bb_ms_per_step * 1e-3) / 1e12 if bb_ms_per_step > 0 else None
         peak = 157.3
         line = {
-            "metric": "point-cloud pairs/sec at N=1024 (inference, eval-mode forward)",
+            "metric": "point-cloud pairs/sec at N=%d (inference, eval-mode forward)" % npts,
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SynthCars widths inference, batch=256 pairs/GPU, N=1024, fp32 (BASELINE.json configs[1])",
-                       "pairs_per_gpu": B, "num_points": N_POINTS, "parallelism": f"batch-split x{world} (no collective)"},
+            "config": {"workload": ("SynthCars widths inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[1])" % (B, npts))
+                       if args.workload == "pointnet" else
+                       ("SynthCars widths, DGCNN edge-conv branch (k=20), inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[4] shape)" % (B, npts)),
+                       "pairs_per_gpu": B, "num_points": npts, "parallelism": f"batch-split x{world} (no collective)"},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": pmc_traffic(), "kernel": "pointnet_fused",
+                         "traffic": pmc_traffic() if args.workload == "pointnet" and npts == N_POINTS and B == 256 else None,
+                         "kernel": "pointnet_fused" if args.workload == "pointnet" else "dgcnn_fused",
                          "launches_per_step": prof["backbone_launches"] / args.steps,
                          "kernel_ms_per_step": round(bb_ms_per_step, 4),
                          "algorithmic_flops_per_step": bb_flops_per_step},
-            "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2) if world == 1 else None,
+            "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2)
+            if world == 1 and args.workload == "pointnet" and npts == N_POINTS else None,
         }
         if args.mode == "train":
             line["metric"] = "point-cloud pairs/sec at N=1024 (training step)"
