@@ -1,0 +1,88 @@
+"""Packed dataset cache for the batch loader.
+
+The reference loader opens three files per example per load and parses a JSON document plus four
+np.loadtxt strings (provider.py:85-94); at >100 k pairs/s on the GPU that Python loop is the wall-clock
+bottleneck by orders of magnitude.  `pack_dataset` converts a dataset directory once into
+    <cache>/points1.npy, points2.npy   all clouds concatenated ([sum n, 3], original dtype)
+    <cache>/offsets.npy                [n_examples + 1, 2] row offsets into the two blobs
+    <cache>/labels.npy                 [n_examples, 12] float64: translation(3) rel_angle start_position(3)
+                                       end_position(3) start_angle end_angle
+    <cache>/ids.npy                    example ids (the integers of split/*.txt)
+`PackedDataset.load_batch` returns exactly the reference's 8-tuple (float64, np.empty padding rows) and
+consumes np.random in the same order (`choice(n1, N)` then `choice(n2, N)` per example), so a seeded run is
+bit-identical to the file-based loader (tests/test_surface.py checks it against reference-generated batches)."""
+import json
+import os
+
+import numpy as np
+
+
+def _loadtxt(s):
+    return np.array([float(t) for t in s.split()], dtype=np.float64)
+
+
+def pack_dataset(basepath, cache_dir=None):
+    cache_dir = cache_dir or os.path.join(basepath, "packed_cache")
+    os.makedirs(cache_dir, exist_ok=True)
+    ids = sorted(int(f[:-5]) for f in os.listdir(os.path.join(basepath, "meta")) if f.endswith(".json"))
+    labels = np.empty((len(ids), 12), np.float64)
+    offs = np.zeros((len(ids) + 1, 2), np.int64)
+    blobs = ([], [])
+    for row, ex in enumerate(ids):
+        stem = str(ex).zfill(8)
+        with open(os.path.join(basepath, "meta", stem + ".json")) as fh:
+            m = json.load(fh)
+        labels[row, 0:3] = _loadtxt(m["translation"])
+        labels[row, 3] = m["rel_angle"]
+        labels[row, 4:7] = _loadtxt(m["start_position"])
+        labels[row, 7:10] = _loadtxt(m["end_position"])
+        labels[row, 10], labels[row, 11] = m["start_angle"], m["end_angle"]
+        for t, sub in enumerate(("pointcloud1", "pointcloud2")):
+            pc = np.load(os.path.join(basepath, sub, stem + ".npy"))
+            pc = pc[:, :3] if pc.ndim == 2 and pc.shape[0] > 0 else np.zeros((0, 3), np.float32)
+            blobs[t].append(pc)
+            offs[row + 1, t] = offs[row, t] + pc.shape[0]
+    for t, name in enumerate(("points1.npy", "points2.npy")):
+        dt = np.result_type(*[b.dtype for b in blobs[t]]) if blobs[t] else np.float32
+        arr = np.concatenate([b.astype(dt, copy=False) for b in blobs[t]], axis=0) if blobs[t] else np.zeros((0, 3), dt)
+        np.save(os.path.join(cache_dir, name), arr)
+    np.save(os.path.join(cache_dir, "offsets.npy"), offs)
+    np.save(os.path.join(cache_dir, "labels.npy"), labels)
+    np.save(os.path.join(cache_dir, "ids.npy"), np.asarray(ids, np.int64))
+    return cache_dir
+
+
+class PackedDataset:
+    def __init__(self, cache_dir):
+        self.p = [np.load(os.path.join(cache_dir, "points%d.npy" % t), mmap_mode="r") for t in (1, 2)]
+        self.off = np.load(os.path.join(cache_dir, "offsets.npy"))
+        self.labels = np.load(os.path.join(cache_dir, "labels.npy"))
+        ids = np.load(os.path.join(cache_dir, "ids.npy"))
+        self.row = {int(e): i for i, e in enumerate(ids)}
+
+    def __len__(self):
+        return len(self.row)
+
+    def load_batch(self, indices, num_points, batch_size, num_channels=3, dont_load_pointclouds=False, on_empty=None):
+        B, N = batch_size, num_points
+        pcs1, pcs2 = np.empty((B, N, num_channels)), np.empty((B, N, num_channels))
+        translations, rel_angles = np.empty((B, 3)), np.empty((B, 1))
+        pc1centers, pc2centers = np.empty((B, 3)), np.empty((B, 3))
+        pc1angles, pc2angles = np.empty((B, 1)), np.empty((B, 1))
+        for r, ex in enumerate(indices):
+            i = self.row[int(ex)]
+            if not dont_load_pointclouds:
+                for t, dst in ((0, pcs1), (1, pcs2)):
+                    lo, hi = self.off[i, t], self.off[i + 1, t]
+                    n = int(hi - lo)
+                    if n > 0:   # same RNG consumption as provider.py:97-98: one choice() per non-empty cloud, pc1 first
+                        dst[r] = self.p[t][lo + np.random.choice(n, N, replace=True)]
+                    else:
+                        dst[r] = 0.0
+                if on_empty is not None and (self.off[i + 1, 0] == self.off[i, 0] or self.off[i + 1, 1] == self.off[i, 1]):
+                    on_empty(ex)
+            L = self.labels[i]
+            translations[r], rel_angles[r] = L[0:3], L[3]
+            pc1centers[r], pc2centers[r] = L[4:7], L[7:10]
+            pc1angles[r], pc2angles[r] = L[10], L[11]
+        return pcs1, pcs2, translations, rel_angles, pc1centers, pc2centers, pc1angles, pc2angles

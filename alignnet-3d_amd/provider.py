@@ -55,12 +55,30 @@ def load_from_separate_files(idx, dont_load_pointclouds=False):
     return (pc1, pc2) + labels
 
 
+_packed = None
+
+
+def use_packed_cache(cache_dir=None):
+    """Switch load_batch to the packed cache (alignnet3d/packed.py); builds it on first use.  Same tuple, same
+    np.random call order, bit-identical batches."""
+    global _packed
+    import os
+    from alignnet3d.packed import PackedDataset, pack_dataset
+    cache_dir = cache_dir or os.path.join(cfg.data.basepath, "packed_cache")
+    if not os.path.exists(os.path.join(cache_dir, "ids.npy")):
+        pack_dataset(cfg.data.basepath, cache_dir)
+    _packed = PackedDataset(cache_dir)
+    return _packed
+
+
 def load_batch(indices, override_batch_size=None, dont_load_pointclouds=False):
     """Returns (pcs1, pcs2, translations, rel_angles, pc1centers, pc2centers, pc1angles, pc2angles), float64.
     Rows past len(indices) are left uninitialised exactly like the reference's np.empty (quirk A6(iv)); the
     engine itself accepts any batch size, so callers may simply slice them off."""
     B = cfg.training.batch_size if override_batch_size is None else override_batch_size
     N, C = cfg.model.num_points, cfg.data.num_channels
+    if _packed is not None:
+        return _packed.load_batch(indices, N, B, C, dont_load_pointclouds, on_empty=lambda ex: logger.error("Empty pointcloud! %s" % ex))
     pcs1, pcs2 = np.empty((B, N, C)), np.empty((B, N, C))
     translations, rel_angles = np.empty((B, 3)), np.empty((B, 1))
     pc1centers, pc2centers = np.empty((B, 3)), np.empty((B, 3))

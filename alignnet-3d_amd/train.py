@@ -76,6 +76,8 @@ class Run:
         MODEL.bind_engine(self.engine)
         if self.dist is not None:
             parallel.init_comm(self.engine, self.dist)
+        if os.environ.get("ALIGNNET_PACKED_CACHE", "") not in ("", "0"):
+            provider.use_packed_cache()   # bit-identical batches, no per-example file opens (alignnet3d/packed.py)
         self.train_idx = provider.getDataFiles("%s/split/train.txt" % cfg.data.basepath)
         self.val_idx = provider.getDataFiles("%s/split/val.txt" % cfg.data.basepath)
         self.batches_per_epoch = len(self.train_idx) // cfg.training.batch_size

@@ -123,3 +123,24 @@ def test_cli_surface():
     for fname in ("pred_translations", "pred_angles", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers",
                   "pred_s2_pc2centers", "pred_s2_pc1angles", "pred_s2_pc2angles"):
         assert fname in src
+
+
+def test_packed_loader_is_bit_identical_to_reference_batches(tiny):
+    """the packed cache must reproduce the reference loader's seeded batches exactly."""
+    prov = tiny["provider"]
+    ds = prov.use_packed_cache()
+    assert len(ds) == len(J["ds_meta"])
+    names = ("pcs1", "pcs2", "translations", "rel_angles", "pc1centers", "pc2centers", "pc1angles", "pc2angles")
+    np.random.seed(1234)
+    b = prov.load_batch([0, 1, 2, 3])
+    for k, v in zip(names, b):
+        assert v.dtype == np.float64
+        np.testing.assert_array_equal(v, G["lb_" + k], err_msg=k)
+    np.random.seed(99)
+    b2 = prov.load_batch([6, 5], override_batch_size=3)
+    for k, v in zip(names, b2):
+        np.testing.assert_array_equal(v[:2], G["lb2_" + k], err_msg=k)
+    b3 = prov.load_batch([4, 0], override_batch_size=2, dont_load_pointclouds=True)
+    np.testing.assert_array_equal(b3[2], G["lb3_translations"])
+    np.testing.assert_array_equal(b3[7], G["lb3_pc2angles"])
+    prov._packed = None
