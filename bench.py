@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--train-leg", action="store_true", help="also run the training leg when --gpus > 1 (RCCL all-reduce)")
     ap.add_argument("--workload", choices=["pointnet", "dgcnn"], default="pointnet",
                     help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (inference only)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
@@ -158,11 +159,11 @@ def main():
     lab = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
            ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
     lab_ptrs = {k: v.data_ptr() for k, v in lab.items()}
-    if world > 1:
+    want_train = args.mode == "train" or (not args.no_train_leg and (world == 1 or args.train_leg))
+    if world > 1 and want_train:
         # data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed
-        uid = [alignnet3d.Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
+        from alignnet3d import parallel
+        parallel.init_comm(eng, dist)
 
     def train_step():
         eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
@@ -199,7 +200,7 @@ def main():
 
     # secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA), fp32
     train_info = None
-    if args.mode == "infer" and not args.no_train_leg:
+    if args.mode == "infer" and want_train:
         ksteps = max(3, args.steps // 5)
         for _ in range(2):
             train_step()
