@@ -445,10 +445,19 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = w->rstd2;
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+  b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
+  if (b2.stamps) {
+    long long st[11];
+    hipStreamSynchronize(h->stream);
+    hipMemcpy(st, b2.stamps, sizeof(st), hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "B2 stage %d tile-3 phase cycles:", s);
+    for (int i = 1; i < 11; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+    std::fprintf(stderr, "  total %lld\n", st[10] - st[0]);
+  }
 
   // ---- layer 2 parameter gradients + operators for B1 ----
   launch_reduce<double>(h, w->dbg2_part, 4 * B, (long)(C2 * 2), w->dbg2);

@@ -41,11 +41,13 @@ struct BwdB2Args {
   float* g1_part;               // [2B][C1*C1]
   double* s1_part;              // [2B][C1]
   int dbg;
+  long long* stamps;            // debug: s_memtime stamps of wave 0 / block 0 at the phase boundaries of tile 3
 };
 
 // Work split in B2: item = (channel tile ct, 32-row group rg) = wave + 4*slot  (C2 <= 128 -> CT2*2 <= 8 items, two
 // static slots per wave), so the wave that produced z2 for an item also owns its dh2 and keeps z2 in registers.
 // LDS: xs | X [64][ldb] | Y [64][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
+#define B2_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -108,10 +110,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();
+    B2_STAMP(0);
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
+    B2_STAMP(1);
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
+    B2_STAMP(2);
 
     // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y ----
 #pragma unroll
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         }
       }
     }
+    B2_STAMP(3);
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
     for (int item = wave; item < CT1 * CT1; item += kTW) {
       const int it = item / CT1, jt = item % CT1;
@@ -152,9 +158,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     }
     __syncthreads();
 
+    B2_STAMP(4);
     // ---- sparse rows of dh2: X <- 0, then X[row][:] += g * W3[:, c] for this tile's hits ----
     for (int i = tid; i < kTT * ldb; i += kTW * 64) X[i] = 0.f;
     __syncthreads();
+    B2_STAMP(5);
     if (a.dbg & 8) {
       for (int base = 0; base < a.C3; base += 64) {
         const int c = base + lane;
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     }
     __syncthreads();
 
+    B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
 #pragma unroll
     for (int sl = 0; sl < kSlots; ++sl) {
@@ -221,7 +230,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         db[sl] += (double)lb; dg[sl] += (double)lg;
       }
     }
+    B2_STAMP(7);
     __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
+    B2_STAMP(8);
 
     // ---- dy2 -> Y ; h1 -> X again ----
 #pragma unroll
@@ -236,6 +247,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 
+    B2_STAMP(9);
     // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
     {
       float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         tile_commit(my_u2, a.C2, it, jt, a.C1, a.C2, u, lane, old);
       }
     }
+    B2_STAMP(10);
   }
 #pragma unroll
   for (int sl = 0; sl < kSlots; ++sl) {

@@ -1,0 +1,105 @@
+"""GPU: BASELINE.json's full inference size (SynthCars widths, B = 256, N = 1024), where the fp64 oracle is too slow
+to check every pair: size-independent properties of the path plus an oracle spot check on a subset."""
+import numpy as np
+import pytest
+
+import alignnet3d
+from oracle import alignnet_ref as R
+from tests.helpers import oracle_params, compare_forward
+
+pytestmark = pytest.mark.gpu
+B, N = 256, 1024
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg = alignnet3d.default_model_config()
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    d = R.synth_pairs(B, N, seed=4321, dtype=np.float32)
+    base = eng.forward(d["pcs1"], d["pcs2"])
+    yield cfg, spec, P32, eng, d, base
+    eng.close()
+
+
+def _stable(base, nb, eps=1e-3):
+    def margin(lg):
+        s = np.sort(lg[:, :nb], axis=1)
+        return s[:, -1] - s[:, -2]
+    return (margin(base["pred_pc1angle_logits"]) > eps) & (margin(base["pred_pc2angle_logits"]) > eps)
+
+
+def test_finite_and_deterministic(gpu_required, setup):
+    cfg, spec, P32, eng, d, base = setup
+    again = eng.forward(d["pcs1"], d["pcs2"])
+    for k, v in base.items():
+        assert np.all(np.isfinite(v)), k
+        np.testing.assert_array_equal(v, again[k])
+
+
+def test_point_permutation_invariance(gpu_required, setup):
+    """max-pool and mean are order-free (models/tp8.py:58,104); only the fp32 centroid summation order changes."""
+    cfg, spec, P32, eng, d, base = setup
+    perm = np.random.default_rng(0).permutation(N)
+    out = eng.forward(d["pcs1"][:, perm], d["pcs2"][:, perm])
+    ok = _stable(base, spec.num_bins)
+    for k in base:
+        sel = ok if k in ("pred_translations", "pred_remaining_angle_logits") else slice(None)
+        np.testing.assert_allclose(out[k][sel], base[k][sel], rtol=1e-4, atol=1e-4, err_msg=k)
+
+
+def test_translation_equivariance(gpu_required, setup):
+    """Shifting both clouds by t shifts every predicted centre by t and leaves translation / logits unchanged."""
+    cfg, spec, P32, eng, d, base = setup
+    t = np.array([1.5, -2.25, 0.5], np.float32)
+    out = eng.forward(d["pcs1"] + t, d["pcs2"] + t)
+    ok = _stable(base, spec.num_bins)
+    for k in ("pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers"):
+        np.testing.assert_allclose(out[k], base[k] + t, rtol=0, atol=2e-4, err_msg=k)
+    for k in ("pred_pc1angle_logits", "pred_pc2angle_logits"):
+        np.testing.assert_allclose(out[k], base[k], rtol=1e-4, atol=1e-4, err_msg=k)
+    np.testing.assert_allclose(out["pred_translations"][ok], base["pred_translations"][ok], rtol=0, atol=3e-4)
+
+
+def test_pairs_are_independent_and_towers_swap(gpu_required, setup):
+    """Eval-mode pairs do not interact (any split of the batch gives the same rows); feeding (pcs2, pcs1) through
+    towers with swapped BN sets swaps the per-tower outputs."""
+    cfg, spec, P32, eng, d, base = setup
+    part = eng.forward(d["pcs1"][100:137], d["pcs2"][100:137])
+    for k in base:
+        np.testing.assert_array_equal(part[k], base[k][100:137])
+    swapped = {}
+    for k, v in P32.items():
+        k2 = k.replace("siamese_1/", "@@/").replace("siamese/", "siamese_1/").replace("@@/", "siamese/") if "/bn/" in k else k
+        swapped[k2] = v
+    eng2 = alignnet3d.Engine(cfg)
+    eng2.set_variables(swapped)
+    out = eng2.forward(d["pcs2"], d["pcs1"])
+    eng2.close()
+    np.testing.assert_array_equal(out["pred_s2_pc1centers"], base["pred_s2_pc2centers"])
+    np.testing.assert_array_equal(out["pred_pc2angle_logits"], base["pred_pc1angle_logits"])
+
+
+def test_oracle_spot_check(gpu_required, setup):
+    cfg, spec, P32, eng, d, base = setup
+    idx = np.arange(0, B, 32)
+    P64 = {k: v.astype(np.float64) for k, v in P32.items()}
+    ref, _, _ = R.get_model(P64, spec, d["pcs1"][idx].astype(np.float64), d["pcs2"][idx].astype(np.float64))
+    worst, unstable = compare_forward({k: v[idx] for k, v in base.items()}, ref, spec.num_bins)
+    print("full-size spot check: worst abs err", max(worst.values()), "unstable", unstable)
+
+
+def test_training_reduces_loss_at_full_size(gpu_required):
+    """A few Adam steps on one fixed batch of 256 pairs must lower the reference loss (train.py:368 semantics)."""
+    cfg = alignnet3d.default_model_config()
+    cfg["training"]["batch_size"] = B
+    cfg["data"]["ntrain"] = 100 * B
+    eng = alignnet3d.Engine(cfg, seed=3)
+    d = R.synth_pairs(B, N, seed=7, dtype=np.float32)
+    u = [np.full((B, 256), 0.9, np.float32)] * 5   # dropout off (keep + u >= 1) so that the loss is comparable step to step
+    losses = [eng.train_step(d["pcs1"], d["pcs2"], d, u)["loss"] for _ in range(25)]
+    print("losses", [round(x, 4) for x in losses])
+    assert np.all(np.isfinite(losses)) and min(losses[-5:]) < 0.85 * losses[0]
+    assert eng.state()["step"] == 25
+    eng.close()
