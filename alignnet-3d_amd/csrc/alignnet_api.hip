@@ -415,7 +415,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     a.L[i].shift = h->d_shift + L.off_ss;
     a.L[i].cin = L.cin; a.L[i].cout = L.cout;
   }
-  HIP_TRY(h, hipMemsetAsync(pooled, 0, pooled_floats * sizeof(float), h->stream));
+  (void)pooled_floats;   // all pooled buffers are zeroed by one memset at the start of the step (forward_device)
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -457,7 +457,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
     a.L[i].shift = h->d_shift + L.off_ss;
     a.L[i].cin = L.cin; a.L[i].cout = L.cout;
   }
-  HIP_TRY(h, hipMemsetAsync(pooled, 0, pooled_floats * sizeof(float), h->stream));
+  (void)pooled_floats;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -519,6 +519,8 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   const int B2 = 2 * B;
   if (h->prof) hipEventRecord(h->ev[0], h->stream);
+  // pool1 | pool2 | emb are carved back to back: one memset arms all three atomicMax targets
+  HIP_TRY(h, hipMemsetAsync(w.pool1, 0, (size_t)((char*)w.hid_a - (char*)w.pool1), h->stream));
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
   if (dg)   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
     hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
@@ -530,12 +532,12 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   // stage 2 (tp8.py:113-125)
   if (backbone(h->s2_conv, w.pool2, (long)B * C2, C2, (size_t)B2 * C2)) return 1;
   if (run_head(h, h->s2_fc, w.pool2, C2, w.o2, 3 + nb2, B2, B)) return 1;
-  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o2, 3 + nb2, w.s1c, B, nb, w.s2c,
+  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 3) / 4), dim3(256), 0, h->stream, w.o2, 3 + nb2, w.s1c, B, nb, w.s2c,
                      w.xform, w.theta, w.cls, outs[4], outs[5], outs[6], outs[7]);
   // stage 3: embedding of the normalised clouds, concat (tp8.py:130,144,153) = row b holds [emb1 | emb2]
   if (backbone(h->emb_conv, w.emb, CE, 2L * CE, (size_t)B2 * CE)) return 1;
   if (run_head(h, h->rem_fc, w.emb, 2L * CE, w.o3, 3 + nb2, B, B)) return 1;
-  hipLaunchKernelGGL(final_finish_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, w.o3, 3 + nb2, w.s2c, B, nb, outs[0], outs[1]);
+  hipLaunchKernelGGL(final_finish_kernel, dim3((B * (3 + nb2) + 255) / 256), dim3(256), 0, h->stream, w.o3, 3 + nb2, w.s2c, B, nb, outs[0], outs[1]);
   if (h->prof) hipEventRecord(h->ev[1], h->stream);
   HIP_TRY(h, hipGetLastError());
   h->last_B = B;

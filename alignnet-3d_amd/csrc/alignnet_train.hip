@@ -533,12 +533,12 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   // stage 2
   if (backbone_fwd_train(h, 1, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 1, w->st[1].pooled, w->st[1].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
-  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->o[1], 3 + nb2, w->s1c, B, nb, w->s2c,
+  hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 3) / 4), dim3(256), 0, h->stream, w->o[1], 3 + nb2, w->s1c, B, nb, w->s2c,
                      w->st[2].xform, w->theta, w->cls, w->outs[4], w->outs[5], w->outs[6], w->outs[7]);
   // stage 3
   if (backbone_fwd_train(h, 2, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 2, w->st[2].pooled, w->st[2].row_stride, B, B, bn_decay, update_ema, u_dev)) return 1;
-  hipLaunchKernelGGL(final_finish_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, w->o[2], 3 + nb2, w->s2c, B, nb, w->outs[0], w->outs[1]);
+  hipLaunchKernelGGL(final_finish_kernel, dim3((B * (3 + nb2) + 255) / 256), dim3(256), 0, h->stream, w->o[2], 3 + nb2, w->s2c, B, nb, w->outs[0], w->outs[1]);
   // loss (+ gradient wrt the end points)
   LossArgs la;
   la.B = B; la.nb = nb; la.esf = h->cfg.early_stage_factor; la.af = h->cfg.angle_factor; la.accept_inverted = h->cfg.accept_inverted_angle;

@@ -359,12 +359,15 @@ static __global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int per = (KG + 3) >> 2, k0 = wave * per, k1 = min(KG, k0 + per);
-#pragma unroll 2
-  for (int kg = k0; kg < k1; ++kg) {
-    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8);
-    const f32x4 bv = wp[(size_t)kg * 64];
+  if (k0 < k1) {
+    f32x4 av = *reinterpret_cast<const f32x4*>(arow + k0 * 8), bv = wp[(size_t)k0 * 64];
+    for (int kg = k0; kg < k1; ++kg) {
+      const int kn = kg + 1 < k1 ? kg + 1 : kg;
+      const f32x4 an = *reinterpret_cast<const f32x4*>(arow + kn * 8), bn = wp[(size_t)kn * 64];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      av = an; bv = bn;
+    }
   }
   if (wave > 0) {
 #pragma unroll
@@ -417,54 +420,63 @@ static __global__ void stage1_finish_kernel(const float* __restrict__ o1, const 
 }
 
 // models/tp8.py:117-125 + :294-301,202-212: s2 centre, logits, in-graph yaw decode,
-// R = rot_z(-theta) (tp8.py:26-27), next frame = (s2, R)
-static __global__ void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
+// R = rot_z(-theta) (tp8.py:26-27), next frame = (s2, R).  One wave per cloud (block = 256 threads = 4 clouds).
+static __global__ __launch_bounds__(256) void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
                                      float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
                                      int* __restrict__ cls_out,
                                      float* __restrict__ out_c1, float* __restrict__ out_c2,
                                      float* __restrict__ out_l1, float* __restrict__ out_l2)
 {
-  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int cloud = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cloud >= 2 * B) return;
   const int tower = cloud >= B, b = cloud - tower * B;
   const float* o = o2 + (size_t)cloud * ldo;
   float* oc = tower ? out_c2 : out_c1;
   float* ol = tower ? out_l2 : out_l1;
-  for (int d = 0; d < 3; ++d) {
-    const float v = o[d] + s1c[cloud * 3 + d];
-    s2c[cloud * 3 + d] = v;
-    xform[cloud * 12 + d] = v;
-    if (oc) oc[b * 3 + d] = v;
+  if (lane < 3) {
+    const float v = o[lane] + s1c[cloud * 3 + lane];
+    s2c[cloud * 3 + lane] = v;
+    xform[cloud * 12 + lane] = v;
+    if (oc) oc[b * 3 + lane] = v;
   }
   const float* lg = o + 3;
-  int cls = 0;
-  float best = lg[0];
-  for (int i = 1; i < nb; ++i)
-    if (lg[i] > best) { best = lg[i]; cls = i; }   // first maximum wins, as tf.argmax
-  if (ol) for (int i = 0; i < 2 * nb; ++i) ol[(size_t)b * 2 * nb + i] = lg[i];
-  const float pi = 3.14159274101257324f;   // np.float32(np.pi), tf.constant(np.pi)
-  const float res = lg[nb + cls] * (pi / (float)nb);
-  const float apc = 2.0f * pi / (float)nb;
-  const float ang = (float)cls * apc + res;
-  const float th = floor_modf(ang + pi, 2.0f * pi) - pi;
-  if (theta_out) theta_out[cloud] = th;
-  if (cls_out) cls_out[cloud] = cls;
-  const float a = -th, c = cosf(a), s = sinf(a);
-  float* R = xform + cloud * 12 + 3;
-  R[0] = c;  R[1] = -s; R[2] = 0.f;
-  R[3] = s;  R[4] = c;  R[5] = 0.f;
-  R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+  // arg-max over the class logits: first maximum wins, as tf.argmax (value desc, index asc)
+  float best = -INFINITY; int cls = 0x7fffffff;
+  for (int i = lane; i < nb; i += 64) { const float v = lg[i]; if (v > best) { best = v; cls = i; } }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(cls, off);
+    if (ob > best || (ob == best && oi < cls)) { best = ob; cls = oi; }
+  }
+  if (ol) for (int i = lane; i < 2 * nb; i += 64) ol[(size_t)b * 2 * nb + i] = lg[i];
+  if (lane == 0) {
+    const float pi = 3.14159274101257324f;   // np.float32(np.pi), tf.constant(np.pi)
+    const float res = lg[nb + cls] * (pi / (float)nb);
+    const float apc = 2.0f * pi / (float)nb;
+    const float ang = (float)cls * apc + res;
+    const float th = floor_modf(ang + pi, 2.0f * pi) - pi;
+    if (theta_out) theta_out[cloud] = th;
+    if (cls_out) cls_out[cloud] = cls;
+    const float a = -th, c = cosf(a), sn = sinf(a);
+    float* R = xform + cloud * 12 + 3;
+    R[0] = c;  R[1] = -sn; R[2] = 0.f;
+    R[3] = sn; R[4] = c;  R[5] = 0.f;
+    R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+  }
 }
 
-// models/tp8.py:155-156
+// models/tp8.py:155-156 (one thread per output element)
 static __global__ void final_finish_kernel(const float* __restrict__ net, int ldn, const float* __restrict__ s2c, int B, int nb,
                                     float* __restrict__ out_t, float* __restrict__ out_l)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float* o = net + (size_t)b * ldn;
-  if (out_t) for (int d = 0; d < 3; ++d) out_t[b * 3 + d] = o[d] + (s2c[(B + b) * 3 + d] - s2c[b * 3 + d]);
-  if (out_l) for (int i = 0; i < 2 * nb; ++i) out_l[(size_t)b * 2 * nb + i] = o[3 + i];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = 3 + 2 * nb;
+  if (e >= B * w) return;
+  const int b = e / w, i = e % w;
+  const float v = net[(size_t)b * ldn + i];
+  if (i < 3) { if (out_t) out_t[b * 3 + i] = v + (s2c[(B + b) * 3 + i] - s2c[b * 3 + i]); }
+  else if (out_l) out_l[(size_t)b * 2 * nb + (i - 3)] = v;
 }
 
 }  // namespace alignnet
