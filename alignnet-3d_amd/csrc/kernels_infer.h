@@ -192,7 +192,9 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
   }
   const f32x4* wp = Wp + lane;
   const int last = KG - 1;
-  wload_drain();   // stores / atomics of the previous epilogue must not sit between the counted loads
+  // No drain here: stores / atomics of the previous epilogue may still be in flight.  Loads retire in order among
+  // themselves, so after `vmcnt(2)` at most two operations are outstanding and the oldest of our three loads cannot be
+  // one of them -- the wait is merely conservative while an older store is pending.
   f32x4 b0 = wload_issue(wp);
   f32x4 b1 = wload_issue(wp + min(1, last) * 64);
   f32x4 b2;
