@@ -86,18 +86,30 @@ class Run:
     def ckpt(self, stem):
         return os.path.join(cfg.logging.logdir, stem + CKPT_EXT)
 
+    def restore(self, base, skip_step=False):
+        """Load `<base>.aln3` (own format) or, failing that, the TensorFlow tensor bundle `<base>.index` +
+        `<base>.data-00000-of-00001` written by the reference's tf.train.Saver (alignnet3d/tf_bundle.py)."""
+        if os.path.isfile(base + CKPT_EXT):
+            self.engine.load(base + CKPT_EXT, skip_step=skip_step)
+            return True
+        if os.path.isfile(base + ".index"):
+            from alignnet3d import tf_bundle
+            tf_bundle.load_into_engine(self.engine, base, load_step=not skip_step)
+            logger.info("Restored TensorFlow checkpoint %s" % base)
+            return True
+        return False
+
     def restore_for_training(self):
-        if os.path.isfile(self.ckpt("model.ckpt")):
-            self.engine.load(self.ckpt("model.ckpt"))
+        if os.path.isfile(self.ckpt("model.ckpt")) or os.path.isfile(os.path.join(cfg.logging.logdir, "model.ckpt.index")):
+            assert self.restore(os.path.join(cfg.logging.logdir, "model.ckpt"))
             step = self.engine.state()["step"]
             assert step % self.batches_per_epoch == 0
             logger.info("Continuing training at epoch %d" % (step // self.batches_per_epoch))
             return step // self.batches_per_epoch
         pre = cfg.training.pretraining.model
         if pre != "":
-            path = pre if pre.endswith(CKPT_EXT) else pre + CKPT_EXT
-            assert os.path.isfile(path), path
-            self.engine.load(path, skip_step=True)   # every variable except `batch` (train.py:278-281)
+            base = pre[: -len(CKPT_EXT)] if pre.endswith(CKPT_EXT) else pre
+            assert self.restore(base, skip_step=True), base   # every variable except `batch` (train.py:278-281)
             assert self.engine.state()["step"] == 0
             logger.info("Pre-trained weights loaded from %s, starting initial evaluation" % pre)
             self.eval_one_epoch("pretr", eval_only=False, do_timings=False)
@@ -198,9 +210,8 @@ class Run:
         start_epoch = 0
         if eval_only:
             if not self.flags.use_old_results and not do_timings:
-                path = self.ckpt("model-%s" % eval_epoch)
-                assert os.path.isfile(path), path
-                self.engine.load(path)
+                base = os.path.join(cfg.logging.logdir, "model-%s" % eval_epoch)
+                assert self.restore(base), base + "{.aln3,.index}"
                 step = self.engine.state()["step"]
                 assert step % self.batches_per_epoch == 0
                 assert step // self.batches_per_epoch - 1 == int(eval_epoch)
