@@ -141,7 +141,54 @@ struct DgcnnArgs {
 
 constexpr int kDgTile = 64;   // points per workgroup (two 32-row MFMA tiles)
 
-// LDS: es [64][8] | buf0 [64][ld0] | buf1 [64][ld1]
+// LDS: es [64][8] | buf0 [64][ld0] | buf1 [64][ld1] | buf0' [64][ld0] (second lift buffer)
+// Per neighbour slot: the gather of x_j for slot s+1 is issued before the MFMAs of slot s (its global round trip hides
+// behind them), and the lift output is double-buffered so that lifting slot s+1 does not wait for slot s's readers.
+__device__ __forceinline__ void dg_gather(const DgcnnArgs& a, const float* pc, int cloud, int tile, int slot, int tid, float (&v)[6])
+{
+  const int n = min(tile * kDgTile + tid, a.N - 1);
+  const int j = a.nn[((size_t)cloud * a.N + n) * a.k + slot];
+  const float* p = pc + (size_t)n * 3;
+  const float* pj = pc + (size_t)j * 3;
+  v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  v[3] = pj[0] - p[0]; v[4] = pj[1] - p[1]; v[5] = pj[2] - p[2];
+}
+
+__device__ __forceinline__ void dg_edge_to_lds(const float* xf, const float (&v)[6], float* e)
+{
+  const float x = v[0] - xf[0], y = v[1] - xf[1], z = v[2] - xf[2];
+  e[0] = x * xf[3] + y * xf[6] + z * xf[9];
+  e[1] = x * xf[4] + y * xf[7] + z * xf[10];
+  e[2] = x * xf[5] + y * xf[8] + z * xf[11];
+  e[3] = v[3] * xf[3] + v[4] * xf[6] + v[5] * xf[9];
+  e[4] = v[3] * xf[4] + v[4] * xf[7] + v[5] * xf[10];
+  e[5] = v[3] * xf[5] + v[4] * xf[8] + v[5] * xf[11];
+}
+
+// edge layer 0: K = 6 lift on the VALU, es -> out[64][ldo]
+__device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const float* es, float* out, int ldo, int tid)
+{
+  const int c0 = tid & 31, r0 = tid >> 5;
+  const int cw = (L.cout + 7) & ~7;
+  for (int c = c0; c < cw; c += 32) {
+    const bool live = c < L.cout;
+    float w[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = live ? L.w[d * L.cout + c] : 0.f;
+    const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kDgTile / 16; ++rr) {
+      const int row = rr * 16 + r0;
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+      float acc = e0[0] * w[0];
+      acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
+      acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
+      out[row * ldo + c] = fmaxf(fmaf(acc, sc, sh), 0.f);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -151,10 +198,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
   const int tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
-  float* es = smem;                                   // edge features of the current neighbour slot
+  float* es = smem;                                   // edge features of the slot being lifted
   const int boff[2] = {kDgTile * 8, kDgTile * 8 + kDgTile * a.ld[0]};
+  const int boff0b = kDgTile * 8 + kDgTile * (a.ld[0] + a.ld[1]);   // second lift buffer
   const int nl = a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
   const int nvalid = min(kDgTile, a.N - tile * kDgTile);
+  const bool two_edge_layers = nl == 3;               // pipelined path: lift (VALU) + one MFMA edge layer
 
   // running max over the k neighbours of the LAST edge layer's pre-activation (sc*acc+sh); relu folded after the max
   const ConvLayerDev& LE = a.L[nl - 2];
@@ -167,78 +216,103 @@ __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) best[s][r] = -INFINITY;
 
-  for (int slot = 0; slot < a.k; ++slot) {
-    __syncthreads();
-    // ---- edge feature [x_i, x_j - x_i] in the stage frame: x' = (p - c) R ----
-    if (tid < kDgTile) {
-      const int n = min(tile * kDgTile + tid, a.N - 1);
-      const int j = a.nn[((size_t)cloud * a.N + n) * a.k + slot];
-      const float* p = pc + (size_t)n * 3;
-      const float* pj = pc + (size_t)j * 3;
-      const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
-      const float dx = pj[0] - p[0], dy = pj[1] - p[1], dz = pj[2] - p[2];
-      float* e = es + tid * 8;
-      e[0] = x * xf[3] + y * xf[6] + z * xf[9];
-      e[1] = x * xf[4] + y * xf[7] + z * xf[10];
-      e[2] = x * xf[5] + y * xf[8] + z * xf[11];
-      e[3] = dx * xf[3] + dy * xf[6] + dz * xf[9];
-      e[4] = dx * xf[4] + dy * xf[7] + dz * xf[10];
-      e[5] = dx * xf[5] + dy * xf[8] + dz * xf[11];
+  // Register-resident weights for the common case (last edge layer with cin <= 64, e.g. 64 -> 128): the item's
+  // 8 k-groups x float4 are loaded once per workgroup instead of once per neighbour slot.
+  const bool wreg = two_edge_layers && LE.cin <= 64;
+  f32x4 breg[kSlots][8];
+  if (wreg) {
+    const int KG = (LE.cin + 7) >> 3;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int item = wave + s * kWaves;
+      const int ct = min(item >> 1, CTE - 1);
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg)
+        breg[s][kg] = reinterpret_cast<const f32x4*>(LE.w)[((size_t)ct * KG + min(kg, KG - 1)) * 64 + lane];
     }
-    __syncthreads();
-    // ---- edge layer 0: K = 6 lift on the VALU ----
-    {
-      const ConvLayerDev& L = a.L[0];
-      float* out = smem + boff[0];
-      const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;
-      const int cw = (L.cout + 7) & ~7;
-      for (int c = c0; c < cw; c += 32) {
-        const bool live = c < L.cout;
-        float w[6];
+  }
+  auto edge_mfma_reg = [&](const float* in, int ldi) {
+    const int KG = (LE.cin + 7) >> 3;
 #pragma unroll
-        for (int d = 0; d < 6; ++d) w[d] = live ? L.w[d * L.cout + c] : 0.f;
-        const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+    for (int s = 0; s < kSlots; ++s) {
+      const int item = wave + s * kWaves;
+      if (item < CTE * 2) {
+        const int ct = item >> 1, m = item & 1;
+        const float* arow = in + (m * 32 + (lane & 31)) * ldi + (lane >> 5) * 4;
+        f32x4 av[8];
 #pragma unroll
-        for (int rr = 0; rr < kDgTile / 16; ++rr) {
-          const int row = rr * 16 + r0;
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
-          const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
-          float acc = e0[0] * w[0];
-          acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
-          acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
-          out[row * ldo + c] = fmaxf(fmaf(acc, sc, sh), 0.f);
-        }
+        for (int kg = 0; kg < 8; ++kg) av[kg] = *reinterpret_cast<const f32x4*>(arow + min(kg, KG - 1) * 8);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg)
+          if (kg < KG) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg][q], breg[s][kg][q], acc, 0, 0, 0);
+          }
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < LE.cout;
+        const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[r], sc, sh));
       }
     }
+  };
+  auto edge_mfma = [&](const float* in, int ldi) {
+    const int KG = (LE.cin + 7) >> 3;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int item = wave + s * kWaves;
+      if (item < CTE * 2) {
+        const int ct = item >> 1, m = item & 1;
+        f32x16 acc[1];
+        mfma_rows<1>(in + m * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(LE.w) + (size_t)ct * KG * 64, KG, lane, acc);
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < LE.cout;
+        const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[0][r], sc, sh));
+      }
+    }
+  };
+
+  if (two_edge_layers) {
+    // the gather of x_j for slot s+1 is issued before the MFMAs of slot s; the lift output is double-buffered.
+    // (A one-barrier variant that issued the VALU lift behind the wave's own MFMAs measured 13 % slower: a wave
+    //  issues in order, so only OTHER waves' VALU work overlaps its MFMAs.)
+    float v[6];
+    if (tid < kDgTile) { dg_gather(a, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
     __syncthreads();
-    // ---- middle edge layers 1 .. nl-3 (none for 3-layer width lists) ----
-    for (int l = 1; l < nl - 2; ++l) {
-      const ConvLayerDev& L = a.L[l];
-      const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
-      float* out = smem + ((l & 1) ? boff[1] : boff[0]);
-      hidden_layer<2, kDgTile>(in, a.ld[(l - 1) & 1], out, a.ld[l & 1], L, tower, wave, lane);
+    dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid);
+    __syncthreads();
+    for (int slot = 0; slot < a.k; ++slot) {
+      const bool more = slot + 1 < a.k;
+      if (more && tid < kDgTile) dg_gather(a, pc, cloud, tile, slot + 1, tid, v);        // in flight during the MFMAs
+      if (wreg) edge_mfma_reg(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
+      else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
+      if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
+      __syncthreads();
+      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), a.ld[0], tid);
       __syncthreads();
     }
-    // ---- last edge layer on MFMA; running max over neighbour slots stays in registers ----
-    {
-      const int l = nl - 2;
-      const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
-      const int ldi = a.ld[(l - 1) & 1];
-      const int KG = (LE.cin + 7) >> 3;
-#pragma unroll
-      for (int s = 0; s < kSlots; ++s) {
-        const int item = wave + s * kWaves;
-        if (item < CTE * 2) {
-          const int ct = item >> 1, m = item & 1;
-          f32x16 acc[1];
-          mfma_rows<1>(in + m * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(LE.w) + (size_t)ct * KG * 64, KG, lane, acc);
-          const int col = ct * 32 + (lane & 31);
-          const bool live = col < LE.cout;
-          const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[0][r], sc, sh));
-        }
+  } else {
+    for (int slot = 0; slot < a.k; ++slot) {
+      __syncthreads();
+      if (tid < kDgTile) { float v[6]; dg_gather(a, pc, cloud, tile, slot, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
+      __syncthreads();
+      dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid);
+      __syncthreads();
+      // ---- middle edge layers 1 .. nl-3 ----
+      for (int l = 1; l < nl - 2; ++l) {
+        const ConvLayerDev& L = a.L[l];
+        const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
+        float* out = smem + ((l & 1) ? boff[1] : boff[0]);
+        hidden_layer<2, kDgTile>(in, a.ld[(l - 1) & 1], out, a.ld[l & 1], L, tower, wave, lane);
+        __syncthreads();
       }
+      const int l = nl - 2;
+      edge_mfma(smem + (((l - 1) & 1) ? boff[1] : boff[0]), a.ld[(l - 1) & 1]);
     }
   }
   __syncthreads();
