@@ -31,6 +31,7 @@ struct HeadLayerWS { float *z, *y, *mean, *var, *dz; };   // per hidden FC layer
 struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float* xform;                  // [2B][12] input frame of this stage
   float *mean[3], *var[3], *scale[3], *shift[3];   // [2][C_l]
+  float *rstd[3], *kk[3];                          // [2][C_l]: rsqrt(var+eps), gamma*rsqrt(var+eps)
   float* sgn3;                   // [2][C3]
   float* ext; int* idx2;          // [2B][2 halves][C3] per-half extremes
   int* idx; float* zhat_star;     // [2B][C3] final arg-extreme index, zhat at the extreme
@@ -66,9 +67,13 @@ struct TrainWS {
   float* outs[8];
   // optimiser
   float *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  PackJob* pack_table = nullptr; int n_pack = 0;
 };
 
 }  // namespace alignnet
+
+constexpr int kLossGroups = 64;   // workgroups sharing the B x B part of the loss
+static size_t loss_scratch_floats(int B) { return 26 * (size_t)B + 64 + (size_t)kLossGroups * 12 + (size_t)kLossGroups * 6 * B + 64; }
 
 static TrainWS* tws(alignnet_handle* h)
 {
@@ -85,6 +90,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->grad) hipFree(w->grad);
   if (w->adam_m) hipFree(w->adam_m);
   if (w->adam_v) hipFree(w->adam_v);
+  if (w->pack_table) hipFree(w->pack_table);
   delete w;
   h->train_ws = nullptr;
 }
@@ -158,7 +164,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       const int C[3] = {h->layers[st.first].cout, h->layers[st.first + 1].cout, h->layers[st.first + 2].cout};
       StageWS& S = w->st[s];
       S.xform = F(B2 * 12);
-      for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); }
+      for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); S.rstd[l] = F(2 * C[l]); S.kk[l] = F(2 * C[l]); }
       S.sgn3 = F(2 * C[2]);
       S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
       S.h2 = F(MN * C[1]);
@@ -179,7 +185,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       w->head_din[s] = S.dP;
     }
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
-    w->loss_out = F(32); w->loss_scratch = F(32 * (size_t)B + 64);
+    w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
@@ -230,12 +236,27 @@ static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, floa
   hipLaunchKernelGGL((reduce_slices_kernel<T>), dim3((unsigned)((n + 31) / 32), towers), dim3(256), 0, h->stream, part, S, n, out, alpha, acc);
 }
 
+static void launch_loss(alignnet_handle* h, const LossArgs& la)
+{
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(1024), 0, h->stream, la, kLossGroups);
+  hipLaunchKernelGGL(loss_pairs_kernel, dim3(kLossGroups), dim3(256), 0, h->stream, la, kLossGroups);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, h->stream, la, kLossGroups);
+}
+
 static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
 
 static int pack_all_weights(alignnet_handle* h)
 {
-  for (const Layer& L : h->layers)
-    if (!L.first_conv) launch_pack(h, P(h, L.p_w), L.cin, L.cout, h->d_wp + L.off_wp);
+  TrainWS* w = tws(h);
+  if (!w->pack_table) {   // (src, dst, K, C) per MFMA layer, built once
+    std::vector<PackJob> jobs;
+    for (const Layer& L : h->layers)
+      if (!L.first_conv) jobs.push_back(PackJob{P(h, L.p_w), h->d_wp + L.off_wp, L.cin, L.cout});
+    w->n_pack = (int)jobs.size();
+    HIP_TRY(h, hipMalloc(&w->pack_table, jobs.size() * sizeof(PackJob)));
+    HIP_TRY(h, hipMemcpy(w->pack_table, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
 }
@@ -283,16 +304,15 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     f.bn_decay = bn_decay; f.update_ema = update_ema;
     f.mean = S.mean[l]; f.var = S.var[l]; f.scale = S.scale[l]; f.shift = S.shift[l];
-    f.sgn = l == 2 ? S.sgn3 : nullptr;
+    f.sgn = nullptr; f.next_gamma[0] = f.next_gamma[1] = nullptr;
+    if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
+    f.rstd = S.rstd[l]; f.k = S.kk[l];
     hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(256), 0, h->stream, f);
   };
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);
   hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4);
-  // sgn3 from gamma (per tower)
-  for (int t = 0; t < 2; ++t)
-    hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + t * C3);
   hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(2, C3, 2);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
@@ -380,8 +400,8 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       }
       hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + 63) / 64, nsets), dim3(256), 0, h->stream, b);
       dcur = HL.dz;
-      // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here)
-      HIP_TRY(h, hipMemsetAsync(G(h, w, L.p_b), 0, L.cout * sizeof(float), h->stream));
+      // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here); the whole gradient
+      // vector is zeroed once per step, so nothing to do
     } else {
       launch_reduce<float>(h, dcur, M, (long)L.cout, G(h, w, L.p_b), 1);
     }
@@ -423,7 +443,6 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     launch_gemm(h, S.gram2 + (size_t)t * C2 * C2, C2, 1, W3, C3, 1, w->GW + (size_t)t * C2 * C3, C3, 1, C2, C3, C2);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
                      w->E3, C2, C3, G(h, w, L[2]->p_w));
-  HIP_TRY(h, hipMemsetAsync(G(h, w, L[2]->p_b), 0, C3 * sizeof(float), h->stream));
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0);
   hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 1), dim3(256), 0, h->stream, W3, C2, C3,
                      (const float*)nullptr, w->W3T, 1);
@@ -433,16 +452,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     launch_pack(h, w->Q3 + (size_t)t * C2 * C2, C2, C2, w->q3img + t * qimg);
   }
   hipLaunchKernelGGL(qbias_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
-  hipLaunchKernelGGL(rstd_k_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, S.var[1], P(h, L[1]->p_bn[0][1]), P(h, L[1]->p_bn[1][1]),
-                     C2, w->rstd2, w->k2);
-
   // ---- pass B2 ----
   BwdB2Args b2;
   b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
   b2.ld0 = ((C1 + 7) & ~7) + 4; b2.ldb = ((std::max(C1, C2) + 7) & ~7) + 4;
   b2.w1 = P(h, L[0]->p_w); b2.wp2 = h->d_wp + L[1]->off_wp;
   b2.sc1 = S.scale[0]; b2.sh1 = S.shift[0]; b2.sc2 = S.scale[1]; b2.sh2 = S.shift[1];
-  b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = w->rstd2;
+  b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = S.rstd[1];
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
@@ -472,7 +488,6 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     launch_gemm(h, w->g1 + (size_t)t * C1 * C1, C1, 1, W2, C2, 1, w->GW2 + (size_t)t * C1 * C2, C2, 1, C1, C2, C1);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
                      G(h, w, L[1]->p_w));
-  HIP_TRY(h, hipMemsetAsync(G(h, w, L[1]->p_b), 0, C2 * sizeof(float), h->stream));
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
@@ -482,14 +497,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     launch_pack(h, w->V2 + (size_t)t * C1 * C2, C2, C1, w->v2img + t * vimg);
   }
   hipLaunchKernelGGL(qbias_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
-  hipLaunchKernelGGL(rstd_k_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, S.var[0], P(h, L[0]->p_bn[0][1]), P(h, L[0]->p_bn[1][1]),
-                     C1, w->rstd1, w->k1);
-
   // ---- pass B1 ----
   BwdB1Args b1;
   b1.pcs[0] = p1; b1.pcs[1] = p2; b1.xform = S.xform; b1.B = B; b1.N = N; b1.C1 = C1; b1.C2 = C2;
   b1.ld0 = ((C1 + 7) & ~7) + 4; b1.ldb = ((C2 + 7) & ~7) + 4;
-  b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = w->rstd1;
+  b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = S.rstd[0];
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
   hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
@@ -501,12 +513,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // ---- pass B0 ----
   BwdB0Args b0;
   b0.pcs[0] = p1; b0.pcs[1] = p2; b0.xform = S.xform; b0.B = B; b0.N = N; b0.C1 = C1;
-  b0.w1 = P(h, L[0]->p_w); b0.b1 = P(h, L[0]->p_b); b0.mean1 = S.mean[0]; b0.rstd1 = w->rstd1; b0.k1 = w->k1; b0.dbg1 = w->dbg1;
+  b0.w1 = P(h, L[0]->p_w); b0.b1 = P(h, L[0]->p_b); b0.mean1 = S.mean[0]; b0.rstd1 = S.rstd[0]; b0.k1 = S.kk[0]; b0.dbg1 = w->dbg1;
   b0.count = M; b0.dy1_store = w->dy1; b0.p_part = w->p_part; b0.gx = S.gx; b0.grot = S.grot;
   hipLaunchKernelGGL(train_bwd_b0, dim3(2 * B), dim3(256), 1024 * 4 * sizeof(float) + 256 * 4 * sizeof(double) + (size_t)C1 * 4 * sizeof(float),
                      h->stream, b0);
   launch_reduce<float>(h, w->p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1);
-  HIP_TRY(h, hipMemsetAsync(G(h, w, L[0]->p_b), 0, C1 * sizeof(float), h->stream));
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -523,7 +534,8 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   alignnet_get_state(h, &stt);
   const float bn_decay = stt.bn_decay;
   if (set_lds_attrs(h)) return 1;
-  pack_all_weights(h);
+  if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
+  if (pack_all_weights(h)) return 1;
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
@@ -546,7 +558,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   la.tr = lab[0]; la.c1 = lab[2]; la.c2 = lab[3]; la.a1 = lab[4]; la.a2 = lab[5];
   la.out = w->loss_out; la.d_s1c = w->d_s1c; la.d_s2c = w->d_s2c; la.d_o2 = w->d_o[1]; la.d_o3 = w->d_o[2]; la.scratch = w->loss_scratch;
   la.want_grad = do_backward;
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, h->stream, la);
+  launch_loss(h, la);
   HIP_TRY(h, hipGetLastError());
   if (!do_backward) return 0;
 
@@ -737,7 +749,7 @@ extern "C" int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels* lab
   const int nb = h->cfg.num_bins, nb2 = 2 * nb;
   // label + scratch staging
   float* stage = nullptr;
-  const size_t nlab = (size_t)B * 12, nscr = 32 * (size_t)B + 64 + 32;
+  const size_t nlab = ((size_t)B * 12 + 63) & ~(size_t)63, nscr = loss_scratch_floats(B) + 32;
   HIP_TRY(h, hipMalloc(&stage, (nlab + nscr) * sizeof(float)));
   const float* src[6] = {labels->translations, labels->rel_angles, labels->pc1_centers, labels->pc2_centers, labels->pc1_angles, labels->pc2_angles};
   const int lw[6] = {3, 1, 3, 3, 1, 1};
@@ -752,7 +764,7 @@ extern "C" int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels* lab
   la.s1c = ws.s1c; la.s2c = ws.s2c; la.o2 = ws.o2; la.ldo2 = 3 + nb2; la.o3 = ws.o3; la.ldo3 = 3 + nb2; la.theta = ws.theta; la.pcls = ws.cls;
   la.tr = dl[0]; la.c1 = dl[2]; la.c2 = dl[3]; la.a1 = dl[4]; la.a2 = dl[5];
   la.out = stage + nlab; la.scratch = stage + nlab + 32; la.want_grad = 0;
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, h->stream, la);
+  launch_loss(h, la);
   float lo[17];
   hipMemcpyAsync(lo, la.out, sizeof(lo), hipMemcpyDeviceToHost, h->stream);
   hipError_t e = hipStreamSynchronize(h->stream);

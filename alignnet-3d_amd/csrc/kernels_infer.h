@@ -50,6 +50,22 @@ static __global__ void pack_weights_kernel(const float* __restrict__ W, int K, i
   }
 }
 
+// all MFMA layers in one launch (training re-packs every step): grid (blocks, jobs)
+struct PackJob { const float* src; float* dst; int K, C; };
+static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ jobs)
+{
+  const PackJob j = jobs[blockIdx.y];
+  const int KG = (j.K + 7) >> 3, CT = (j.C + 31) >> 5;
+  const size_t total = (size_t)CT * KG * 256;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int s = idx & 3, lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int kg = t % KG, ct = t / KG;
+    const int k = 8 * kg + 4 * (lane >> 5) + s, c = 32 * ct + (lane & 31);
+    j.dst[idx] = (k < j.K && c < j.C) ? j.src[(size_t)k * j.C + c] : 0.f;
+  }
+}
+
 // scale/shift for one layer and one BN set; bn == nullptr -> plain bias.
 static __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
                                const float* __restrict__ gamma, const float* __restrict__ mean,

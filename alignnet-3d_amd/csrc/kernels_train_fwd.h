@@ -332,13 +332,17 @@ struct StatFinishArgs {
   float bn_decay; int update_ema;
   float* mean; float* var;   // [2][C] batch statistics (kept for the backward)
   float* scale; float* shift;   // [2][C]: y = acc*scale + shift  (acc = z - bias)
-  float* sgn;                // [2][C] or null: sign(gamma) for the next phase
+  float* sgn;                // [2][next_C] or null: sign(gamma) of the NEXT layer (needed by phase 3 before its own statistics)
+  const float* next_gamma[2]; int next_C;
+  float* rstd; float* k;     // [2][C]: rsqrt(var+eps) and gamma*rsqrt(var+eps) (backward passes)
 };
 
 __global__ __launch_bounds__(256) void stat_finish_kernel(const StatFinishArgs a)   // grid (ceil(C/32), 2), block 32 channels x 8 slice groups
 {
   __shared__ double red[8][32][2];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.next_C; i += gridDim.x * 256) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
   const int S = a.B * a.slices;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
@@ -359,7 +363,8 @@ __global__ __launch_bounds__(256) void stat_finish_kernel(const StatFinishArgs a
   const float inv = a.gamma[t][c] * (1.0f / sqrtf(vf + kBnEps));
   a.scale[t * a.C + c] = inv;
   a.shift[t * a.C + c] = (a.bias[c] - mf) * inv + a.beta[t][c];
-  if (a.sgn) a.sgn[t * a.C + c] = a.gamma[t][c] >= 0.f ? 1.f : -1.f;
+  a.rstd[t * a.C + c] = 1.0f / sqrtf(vf + kBnEps);
+  a.k[t * a.C + c] = inv;
   if (a.update_ema) {
     // ExponentialMovingAverage.apply: shadow -= (1 - decay) * (shadow - value)
     a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);

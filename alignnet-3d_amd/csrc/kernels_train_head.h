@@ -214,23 +214,48 @@ __device__ __forceinline__ void angle2class(float angle, int nb, int* cls, float
   *res = sh - ((float)c * apc + apc * 0.5f);
 }
 
-// one angle term A(logits, target) for both variants (theta, theta+pi); see LossArgs
-struct AngleOut { float tot, ce, rl; int variant; };
+// The loss runs as three small launches so that the B x B work (tp8.py:279,327 broadcasts) spreads over the chip:
+//   loss_prep_kernel     (1 block)    Huber terms + their gradients, per-row class / residual targets, log-sum-exp
+//   loss_pairs_kernel    (G blocks)   for a slice of rows i: partial sums over (i, j) of the residual Huber loss and of
+//                                     clip(pick_j - label_ij) per column j, for both variants (theta, theta + pi)
+//   loss_final_kernel    (1 block)    reduce the partials, tf.cond variant choice, totals, angle-term gradients
+// Scratch layout (floats unless noted): see LossScratch.
+struct LossScratch {
+  float* lse;      // [3][B]
+  float* pick;     // [3][2][B]
+  float* lab;      // [2][2][B]      stage-2 labels per tower / variant
+  int* cls;        // [3][2][B]
+  float* sjf;      // [3][B]         S_j of the chosen variant (reduced over the G partials)
+  float* hub;      // [8]            the five Huber means
+  double* ce;      // [3][2]         mean cross-entropy per term / variant
+  double* rlp;     // [G][3][2]      partial sums of huber(pick_j - label_ij)
+  float* sjp;      // [G][3][2][B]   partial sums over i of clip(pick_j - label_ij, 1)
+};
 
-__global__ __launch_bounds__(1024) void loss_kernel(const LossArgs a)
+__device__ __forceinline__ LossScratch loss_scratch(float* base, int B, int G)
+{
+  LossScratch s;
+  s.lse = base; s.pick = s.lse + 3 * B; s.lab = s.pick + 6 * B;
+  s.cls = reinterpret_cast<int*>(s.lab + 4 * B);
+  s.sjf = reinterpret_cast<float*>(s.cls + 6 * B);
+  s.hub = s.sjf + 3 * B;
+  s.ce = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s.hub + 8) + 7) & ~(uintptr_t)7);
+  s.rlp = s.ce + 6;
+  s.sjp = reinterpret_cast<float*>(s.rlp + (size_t)G * 6);
+  return s;
+}
+
+__device__ __forceinline__ const float* term_logits(const LossArgs& a, int term, int row)
+{
+  return term == 0 ? a.o2 + (size_t)row * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(a.B + row) * a.ldo2 + 3 : a.o3 + (size_t)row * a.ldo3 + 3;
+}
+
+__global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G)
 {
   __shared__ double red[16];
-  __shared__ float sres[3][2][3];   // [term][variant][tot, ce, rl]
-  __shared__ int schosen[3];
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
-  // scratch carve
-  float* lse = a.scratch;                 // [3][B] log-sum-exp of class logits per term
-  float* pick = lse + 3 * B;              // [3][2][B] picked residual logit per term/variant
-  float* lab = pick + 6 * B;              // [2][2][B] stage-2 labels per tower/variant
-  int* cls = reinterpret_cast<int*>(lab + 4 * B);   // [3][2][B]
-  float* Sj = reinterpret_cast<float*>(cls + 6 * B);   // [3][B] sum_i clip(err_ij) for the chosen variant
-
+  const LossScratch S = loss_scratch(a.scratch, B, G);
   // ---- Huber terms (tp8.py:312-323) ----
   double h[5] = {0, 0, 0, 0, 0};
   for (int e = tid; e < 3 * B; e += nt) {
@@ -252,66 +277,98 @@ __global__ __launch_bounds__(1024) void loss_kernel(const LossArgs a)
       a.d_o2[(size_t)(B + b) * a.ldo2 + d] = 0.f;
     }
   }
-  float hub[5];
-  for (int k = 0; k < 5; ++k) hub[k] = (float)(block_sum(h[k], red) / (3.0 * B));
-
-  // ---- per-row class/residual targets and log-sum-exp for the three angle terms ----
-  // term 0/1: towers (targets pc1_angles / pc2_angles); term 2: remaining angle (target matrix T[i][j])
+  for (int k = 0; k < 5; ++k) {
+    const double t = block_sum(h[k], red) / (3.0 * B);
+    if (tid == 0) S.hub[k] = (float)t;
+  }
+  // ---- per-row class / residual targets and log-sum-exp for the three angle terms ----
   const int nvar = a.accept_inverted ? 2 : 1;
+  double ce[3][2] = {{0, 0}, {0, 0}, {0, 0}};
   for (int i = tid; i < B; i += nt) {
     for (int term = 0; term < 3; ++term) {
-      const float* lg = term == 0 ? a.o2 + (size_t)i * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + i) * a.ldo2 + 3 : a.o3 + (size_t)i * a.ldo3 + 3;
+      const float* lg = term_logits(a, term, i);
       float m = lg[0];
       for (int k = 1; k < nb; ++k) m = fmaxf(m, lg[k]);
-      float s = 0.f;
-      for (int k = 0; k < nb; ++k) s += expf(lg[k] - m);
-      lse[term * B + i] = m + logf(s);
+      float sm = 0.f;
+      for (int k = 0; k < nb; ++k) sm += expf(lg[k] - m);
+      const float l = m + logf(sm);
+      S.lse[term * B + i] = l;
       // target angle of row i (term 2: column 0 of T, tp8.py:199 class_id[:, 0])
-      float tgt;
-      if (term == 0) tgt = a.a1[i];
-      else if (term == 1) tgt = a.a2[i];
-      else tgt = (a.a2[i] - a.a1[i]) - (a.theta[B + 0] - a.theta[0]);
+      const float tgt = term == 0 ? a.a1[i] : term == 1 ? a.a2[i] : (a.a2[i] - a.a1[i]) - (a.theta[B + 0] - a.theta[0]);
       for (int v = 0; v < nvar; ++v) {
         int c; float r;
         angle2class(tgt + (v ? pi : 0.f), nb, &c, &r);
-        cls[(term * 2 + v) * B + i] = c;
-        pick[(term * 2 + v) * B + i] = lg[nb + min(max(c, 0), nb - 1)];
-        if (term < 2) lab[(term * 2 + v) * B + i] = r / pinb;
+        const int cc = min(max(c, 0), nb - 1);
+        S.cls[(term * 2 + v) * B + i] = cc;
+        S.pick[(term * 2 + v) * B + i] = lg[nb + cc];
+        if (term < 2) S.lab[(term * 2 + v) * B + i] = r / pinb;
+        ce[term][v] += (double)(l - lg[cc]);
       }
     }
   }
-  __syncthreads();
-
-  // ---- CE and residual-Huber means per term/variant ----
   for (int term = 0; term < 3; ++term)
     for (int v = 0; v < nvar; ++v) {
-      double ce = 0.0, rl = 0.0;
-      for (int i = tid; i < B; i += nt) {
-        const float* lg = term == 0 ? a.o2 + (size_t)i * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + i) * a.ldo2 + 3 : a.o3 + (size_t)i * a.ldo3 + 3;
-        const int c = min(max(cls[(term * 2 + v) * B + i], 0), nb - 1);
-        ce += (double)(lse[term * B + i] - lg[c]);
-      }
-      for (long e = tid; e < (long)B * B; e += nt) {
-        const int i = e / B, j = e % B;
-        float label;
-        if (term < 2) label = lab[(term * 2 + v) * B + i];
-        else {
-          const float T = (a.a2[i] - a.a1[i]) - (a.theta[B + j] - a.theta[j]);
-          int c; float r;
-          angle2class(T + (v ? pi : 0.f), nb, &c, &r);
-          label = r / pinb;
-        }
-        rl += (double)huberf(pick[(term * 2 + v) * B + j] - label, 1.f);
-      }
-      ce = block_sum(ce, red) / B;
-      rl = block_sum(rl, red) / ((double)B * B);
-      if (tid == 0) { sres[term][v][0] = (float)ce + 20.0f * (float)rl; sres[term][v][1] = (float)ce; sres[term][v][2] = (float)rl; }
+      const double t = block_sum(ce[term][v], red) / B;
+      if (tid == 0) S.ce[term * 2 + v] = t;
     }
+}
+
+// grid G: block g owns rows i in [g*R, (g+1)*R); thread j-strided over columns
+__global__ __launch_bounds__(256) void loss_pairs_kernel(const LossArgs a, int G)
+{
+  __shared__ double red[4];
+  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x, g = blockIdx.x;
+  const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
+  const LossScratch S = loss_scratch(a.scratch, B, G);
+  const int R = (B + G - 1) / G, i0 = g * R, i1 = min(B, i0 + R);
+  const int nvar = a.accept_inverted ? 2 : 1;
+  for (int term = 0; term < 3; ++term)
+    for (int v = 0; v < nvar; ++v) {
+      double rl = 0.0;
+      for (int j = tid; j < B; j += nt) {
+        const float pj = S.pick[(term * 2 + v) * B + j];
+        float sj = 0.f, hl = 0.f;
+        const float dth = term == 2 ? a.theta[B + j] - a.theta[j] : 0.f;
+        for (int i = i0; i < i1; ++i) {
+          float label;
+          if (term < 2) label = S.lab[(term * 2 + v) * B + i];
+          else {
+            int c; float r;
+            angle2class((a.a2[i] - a.a1[i]) - dth + (v ? pi : 0.f), nb, &c, &r);
+            label = r / pinb;
+          }
+          const float e = pj - label;
+          hl += huberf(e, 1.f);
+          sj += clipf(e, 1.f);
+        }
+        rl += (double)hl;
+        S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sj;
+      }
+      const double t = block_sum(rl, red);
+      if (tid == 0) S.rlp[((size_t)g * 3 + term) * 2 + v] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void loss_final_kernel(const LossArgs a, int G)
+{
+  __shared__ float sres[3][2][3];   // [term][variant][tot, ce, rl]
+  __shared__ int schosen[3];
+  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
+  const LossScratch S = loss_scratch(a.scratch, B, G);
+  const int nvar = a.accept_inverted ? 2 : 1;
+  if (tid < 6) {
+    const int term = tid / 2, v = tid % 2;
+    if (v < nvar) {
+      double rl = 0.0;
+      for (int g = 0; g < G; ++g) rl += S.rlp[((size_t)g * 3 + term) * 2 + v];
+      const float r = (float)(rl / ((double)B * B)), c = (float)S.ce[term * 2 + v];
+      sres[term][v][0] = c + 20.0f * r; sres[term][v][1] = c; sres[term][v][2] = r;
+    }
+  }
   __syncthreads();
   if (tid < 3) schosen[tid] = (a.accept_inverted && !(sres[tid][0][0] > sres[tid][1][0])) ? 1 : 0;   // tf.cond picks the LARGER
   __syncthreads();
-
-  // ---- totals ----
+  const float* hub = S.hub;
   const float s1 = (hub[0] + hub[1]) * 0.5f, s2t = (hub[2] + hub[3]) * 0.5f;
   const float A1 = sres[0][schosen[0]][0], A2 = sres[1][schosen[1]][0], A3 = sres[2][schosen[2]][0];
   const float lt = a.esf * (s1 + s2t) + hub[4];
@@ -324,48 +381,35 @@ __global__ __launch_bounds__(1024) void loss_kernel(const LossArgs a)
     for (int t = 0; t < 3; ++t) for (int k = 0; k < 3; ++k) o[8 + t * 3 + k] = sres[t][schosen[t]][k];
   }
   if (!a.want_grad) return;
-
   // ---- gradients of the angle terms (chosen variant only: tf.cond) ----
-  // S_j = sum_i clip(pick_j - label_ij, 1)
-  for (int term = 0; term < 3; ++term) {
-    const int v = schosen[term];
-    for (int j = tid; j < B; j += nt) {
-      const float pj = pick[(term * 2 + v) * B + j];
-      float s = 0.f;
-      for (int i = 0; i < B; ++i) {
-        float label;
-        if (term < 2) label = lab[(term * 2 + v) * B + i];
-        else {
-          const float T = (a.a2[i] - a.a1[i]) - (a.theta[B + j] - a.theta[j]);
-          int c; float r;
-          angle2class(T + (v ? pi : 0.f), nb, &c, &r);
-          label = r / pinb;
-        }
-        s += clipf(pj - label, 1.f);
-      }
-      Sj[term * B + j] = s;
-    }
+  for (int e = tid; e < 3 * B; e += nt) {   // S_j = sum over the G row slices, once per (term, column)
+    const int term = e / B, j = e % B;
+    float sj = 0.f;
+    for (int g = 0; g < G; ++g) sj += S.sjp[(((size_t)g * 3 + term) * 2 + schosen[term]) * B + j];
+    S.sjf[e] = sj;
   }
   __syncthreads();
   const float invB = 1.0f / (float)B;
   for (long e = tid; e < (long)B * 2 * nb; e += nt) {
     const int j = e / (2 * nb), k = e % (2 * nb);
+    const float s3 = S.sjf[2 * B + j];   // S_j of the stage-3 term, needed by the towers' residual logits
     for (int term = 0; term < 3; ++term) {
       const int v = schosen[term];
       const float w = term < 2 ? invB * a.af * a.esf * 0.5f : invB * a.af;
-      const float* lg = term == 0 ? a.o2 + (size_t)j * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(B + j) * a.ldo2 + 3 : a.o3 + (size_t)j * a.ldo3 + 3;
+      const float* lg = term_logits(a, term, j);
       float* dl = term == 0 ? a.d_o2 + (size_t)j * a.ldo2 + 3 : term == 1 ? a.d_o2 + (size_t)(B + j) * a.ldo2 + 3 : a.d_o3 + (size_t)j * a.ldo3 + 3;
-      const int c = min(max(cls[(term * 2 + v) * B + j], 0), nb - 1);
-      float g;
-      if (k < nb) g = w * invB * (expf(lg[k] - lse[term * B + j]) - (k == c ? 1.f : 0.f));
-      else g = (k - nb == c) ? w * 20.0f * invB * invB * Sj[term * B + j] : 0.f;
+      const int c = S.cls[(term * 2 + v) * B + j];
+      float gval;
+      if (k < nb) gval = w * invB * (expf(lg[k] - S.lse[term * B + j]) - (k == c ? 1.f : 0.f));
+      else if (k - nb == c) gval = w * 20.0f * invB * invB * S.sjf[term * B + j];
+      else gval = 0.f;
       if (term < 2 && k >= nb) {
-        // the stage-3 target depends on the towers' decoded yaw (tp8.py:325-327): gradient through the
-        // gathered residual of the PREDICTED class; d(label_ij)/d(p2_j) = -1/(pi/nb), d(p)/d(logit) = pi/nb
+        // the stage-3 target depends on the towers' decoded yaw (tp8.py:325-327): gradient through the gathered residual
+        // of the PREDICTED class; d(label_ij)/d(p2_j) = -1/(pi/nb), d(p)/d(logit) = pi/nb
         const int pc = a.pcls[term * B + j];
-        if (k - nb == pc) g += (term == 1 ? 1.f : -1.f) * invB * a.af * 20.0f * invB * invB * Sj[2 * B + j];
+        if (k - nb == pc) gval += (term == 1 ? 1.f : -1.f) * invB * a.af * 20.0f * invB * invB * s3;
       }
-      dl[k] = g;
+      dl[k] = gval;
     }
   }
 }
