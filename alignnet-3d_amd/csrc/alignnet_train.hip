@@ -218,10 +218,11 @@ static int ensure_train_ws(alignnet_handle* h, int B)
 // helpers
 // ---------------------------------------------------------------------------------
 static void launch_gemm(alignnet_handle* h, const float* A, long sai, long sak, const float* Bm, long sbk, long sbj, float* C,
-                        long sci, long scj, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f, int acc = 0)
+                        long sci, long scj, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f, int acc = 0,
+                        int batch = 1, long ba = 0, long bb = 0, long bc = 0)
 {
-  GemmArgs g{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, bias, alpha, acc};
-  hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, h->stream, g);
+  GemmArgs g{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, bias, alpha, acc, ba, bb, bc};
+  hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(256), 0, h->stream, g);
 }
 
 static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float* img)
@@ -367,7 +368,7 @@ static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       HeadLayerWS& HL = w->hl[s][j];
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
       BnRowsArgs a = bn_args(h, w, s, j, M, rows_per_set, bn_decay, update_ema, u_dev);
-      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + 63) / 64, nsets), dim3(256), 0, h->stream, a);
+      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(256), 0, h->stream, a);
       cur = HL.y; ldc = L.cout;
     } else {
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, w->o[s], L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
@@ -398,7 +399,7 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
         const int src = L.p_bn[t][0] >= 0 ? t : 0;
         b.dbeta[t] = G(h, w, L.p_bn[src][0]); b.dgamma[t] = G(h, w, L.p_bn[src][1]);
       }
-      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + 63) / 64, nsets), dim3(256), 0, h->stream, b);
+      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(256), 0, h->stream, b);
       dcur = HL.dz;
       // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here); the whole gradient
       // vector is zeroed once per step, so nothing to do
@@ -439,19 +440,18 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(256), 0, h->stream, p3);
   hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * 4), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp);
-  for (int t = 0; t < 2; ++t)   // GW[t] = Ghat2[t] W3
-    launch_gemm(h, S.gram2 + (size_t)t * C2 * C2, C2, 1, W3, C3, 1, w->GW + (size_t)t * C2 * C3, C3, 1, C2, C3, C2);
+  // GW[t] = Ghat2[t] W3  (both towers in one launch)
+  launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
                      w->E3, C2, C3, G(h, w, L[2]->p_w));
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0);
   hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 1), dim3(256), 0, h->stream, W3, C2, C3,
                      (const float*)nullptr, w->W3T, 1);
   const size_t qimg = img_floats(C2, C2);
-  for (int t = 0; t < 2; ++t) {   // Q3[t] = W3 (W3E[t])^T
-    launch_gemm(h, W3, C3, 1, w->W3E + (size_t)t * C2 * C3, 1, C3, w->Q3 + (size_t)t * C2 * C2, C2, 1, C2, C2, C3);
-    launch_pack(h, w->Q3 + (size_t)t * C2 * C2, C2, C2, w->q3img + t * qimg);
-  }
-  hipLaunchKernelGGL(qbias_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+  // Q3[t] = W3 (W3E[t])^T
+  launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
+  for (int t = 0; t < 2; ++t) launch_pack(h, w->Q3 + (size_t)t * C2 * C2, C2, C2, w->q3img + t * qimg);
+  hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
   // ---- pass B2 ----
   BwdB2Args b2;
   b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
@@ -484,19 +484,19 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
                      P(h, L[1]->p_bn[1][1]), C2, M, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
                      G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
-  for (int t = 0; t < 2; ++t)   // GW2[t] = Ghat1[t] W2
-    launch_gemm(h, w->g1 + (size_t)t * C1 * C1, C1, 1, W2, C2, 1, w->GW2 + (size_t)t * C1 * C2, C2, 1, C1, C2, C1);
+  // GW2[t] = Ghat1[t] W2
+  launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
                      G(h, w, L[1]->p_w));
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
+  launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
   for (int t = 0; t < 2; ++t) {
-    launch_gemm(h, W2, C2, 1, w->W2E + (size_t)t * C1 * C2, 1, C2, w->Q2 + (size_t)t * C1 * C1, C1, 1, C1, C1, C2);
     launch_pack(h, w->Q2 + (size_t)t * C1 * C1, C1, C1, w->q2img + t * q2img);
     launch_pack(h, w->V2 + (size_t)t * C1 * C2, C2, C1, w->v2img + t * vimg);
   }
-  hipLaunchKernelGGL(qbias_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
+  hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
   // ---- pass B1 ----
   BwdB1Args b1;
   b1.pcs[0] = p1; b1.pcs[1] = p2; b1.xform = S.xform; b1.B = B; b1.N = N; b1.C1 = C1; b1.C2 = C2;

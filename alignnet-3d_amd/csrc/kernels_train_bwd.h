@@ -597,16 +597,20 @@ __global__ void combine_dw_kernel(const float* __restrict__ Sp, const float* __r
 }
 
 // qb[t][j] = -sum_i m[t][i] Q[t][i][j] - sum_c W[j][c] kdb[t][c] / M      (W: [R=Cin][C=Cout])
-__global__ void qbias_kernel(const float* __restrict__ Q, const float* __restrict__ m, const float* __restrict__ W,
-                             const float* __restrict__ kdb, int Cin, int Cout, double M, float* __restrict__ qb)
+// grid (Cin, 2), block 256: the two sums are spread over the block and reduced (fp64)
+__global__ __launch_bounds__(256) void qbias_kernel(const float* __restrict__ Q, const float* __restrict__ m, const float* __restrict__ W,
+                                                    const float* __restrict__ kdb, int Cin, int Cout, double M, float* __restrict__ qb)
 {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-  if (j >= Cin) return;
+  __shared__ double red[4];
+  const int j = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
   double s = 0.0;
-  for (int i = 0; i < Cin; ++i) s -= (double)m[t * Cin + i] * Q[((size_t)t * Cin + i) * Cin + j];
-  double w = 0.0;
-  for (int c = 0; c < Cout; ++c) w += (double)W[(size_t)j * Cout + c] * kdb[t * Cout + c];
-  qb[t * Cin + j] = (float)(s - w / M);
+  for (int i = tid; i < Cin; i += 256) s -= (double)m[t * Cin + i] * Q[((size_t)t * Cin + i) * Cin + j];
+  for (int c = tid; c < Cout; c += 256) s -= (double)W[(size_t)j * Cout + c] * kdb[t * Cout + c] / M;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) qb[t * Cin + j] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 }  // namespace alignnet

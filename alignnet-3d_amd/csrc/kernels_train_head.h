@@ -18,6 +18,7 @@ struct GemmArgs {
   const float* bias;   // [N] or null
   float alpha;
   int accumulate;      // C += ...
+  long batch_a, batch_b, batch_c;   // element strides between batch entries (blockIdx.z)
 };
 
 __global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
@@ -26,8 +27,8 @@ __global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.y * 32 + (lane & 31), j = blockIdx.x * 32 + (lane & 31), half = lane >> 5;
   const bool iv = i < a.M, jv = j < a.N;
-  const float* pa = a.A + (size_t)(iv ? i : 0) * a.sa_i;
-  const float* pb = a.B + (size_t)(jv ? j : 0) * a.sb_j;
+  const float* pa = a.A + blockIdx.z * a.batch_a + (size_t)(iv ? i : 0) * a.sa_i;
+  const float* pb = a.B + blockIdx.z * a.batch_b + (size_t)(jv ? j : 0) * a.sb_j;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
       const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (row < a.M) {
         float v = (acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]) * a.alpha + bias;
-        float* dst = a.C + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
+        float* dst = a.C + blockIdx.z * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
         *dst = a.accumulate ? *dst + v : v;
       }
     }
@@ -93,19 +94,21 @@ __device__ __forceinline__ float dropout_scale(const BnRowsArgs& a, int set, int
   return floorf(a.keep + u) / a.keep;   // tf.nn.dropout: x / keep * floor(keep + u)
 }
 
+constexpr int kBnCols = 32, kBnGroups = 8;   // block = 32 columns x 8 row groups
+
 __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const BnRowsArgs a)
 {
-  __shared__ double red[4][64][2];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, set = blockIdx.y;
+  __shared__ double red[kBnGroups][kBnCols][2];
+  const int cl = threadIdx.x % kBnCols, rg = threadIdx.x / kBnCols, c = blockIdx.x * kBnCols + cl, set = blockIdx.y;
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
-    for (int r = r0 + rg; r < r1; r += 4) { const double v = a.z[(size_t)r * a.C + c]; s += v; ss += v * v; }
+    for (int r = r0 + rg; r < r1; r += kBnGroups) { const double v = a.z[(size_t)r * a.C + c]; s += v; ss += v * v; }
   red[rg][cl][0] = s; red[rg][cl][1] = ss;
   __syncthreads();
   if (c >= a.C) return;
-  s = red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0];
-  ss = red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1];
+  s = 0.0; ss = 0.0;
+  for (int q = 0; q < kBnGroups; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
   const double mean = s / R, var = fmax(ss / R - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;
   if (rg == 0) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const BnRowsArgs a)
     }
   }
   const float inv = a.gamma[set][c] * (1.0f / sqrtf(vf + kBnEps)), sh = a.beta[set][c] - mf * inv;
-  for (int r = r0 + rg; r < r1; r += 4) {
+  for (int r = r0 + rg; r < r1; r += kBnGroups) {
     const float y = fmaxf(fmaf(a.z[(size_t)r * a.C + c], inv, sh), 0.f);
     a.y[(size_t)r * a.C + c] = y * dropout_scale(a, set, r - r0, c);
   }
@@ -133,14 +136,14 @@ struct BnRowsBwdArgs {
 __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
 {
   const BnRowsArgs& a = b.f;
-  __shared__ double red[4][64][2];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, set = blockIdx.y;
+  __shared__ double red[kBnGroups][kBnCols][2];
+  const int cl = threadIdx.x % kBnCols, rg = threadIdx.x / kBnCols, c = blockIdx.x * kBnCols + cl, set = blockIdx.y;
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   float mf = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
   if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
   double sb = 0.0, sg = 0.0;
   if (c < a.C)
-    for (int r = r0 + rg; r < r1; r += 4) {
+    for (int r = r0 + rg; r < r1; r += kBnGroups) {
       const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
       const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
       sb += g; sg += (double)g * zh;
@@ -148,11 +151,11 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
   red[rg][cl][0] = sb; red[rg][cl][1] = sg;
   __syncthreads();
   if (c >= a.C) return;
-  sb = red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0];
-  sg = red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1];
+  sb = 0.0; sg = 0.0;
+  for (int q = 0; q < kBnGroups; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; }
   const float mb = (float)(sb / R), mg = (float)(sg / R), k = gam * rstd;
-  for (int r = r0 + rg; r < r1; r += 4) {
+  for (int r = r0 + rg; r < r1; r += kBnGroups) {
     const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
     const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
     b.dz[(size_t)r * a.C + c] = k * (g - mb - zh * mg);
