@@ -88,6 +88,8 @@ SYMBOLS = {
     "alignnet_save": (C.c_int, [H, C.c_char_p]),
     "alignnet_load": (C.c_int, [H, C.c_char_p, C.c_int32]),
     "alignnet_profile_enable": (C.c_int, [H, C.c_int32]),
+    "alignnet_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
+    "alignnet_get_option": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_int64)]),
     "alignnet_profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }
 

@@ -295,6 +295,15 @@ class Engine:
         self._check(self._lib.alignnet_set_step(self._h, int(step)))
 
     # ---- profiling hook ----------------------------------------------------------
+    def set_option(self, key, value):
+        """Run-time options outside the reference's config surface (include/alignnet_hip.h: alignnet_set_option)."""
+        self._check(self._lib.alignnet_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._check(self._lib.alignnet_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def profile_enable(self, on=True):
         self._check(self._lib.alignnet_profile_enable(self._h, int(on)))
 

@@ -603,6 +603,25 @@ extern "C" int alignnet_synchronize(alignnet_handle* h)
 }
 
 // ---------------------------------------------------------------------------------
+// run-time options (not part of the reference's config surface)
+// ---------------------------------------------------------------------------------
+extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value)
+{
+  if (!h || !key) return 1;
+  const std::string k(key);
+  if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
+  return fail(h, "alignnet_set_option: unknown key '" + k + "'");
+}
+
+extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value)
+{
+  if (!h || !key || !value) return 1;
+  const std::string k(key);
+  if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
+  return fail(h, "alignnet_get_option: unknown key '" + k + "'");
+}
+
+// ---------------------------------------------------------------------------------
 // profiling hook (bench.py roofline leg)
 // ---------------------------------------------------------------------------------
 extern "C" int alignnet_profile_enable(alignnet_handle* h, int32_t on)

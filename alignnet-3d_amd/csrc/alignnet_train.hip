@@ -68,6 +68,7 @@ struct TrainWS {
   // optimiser
   float *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   PackJob* pack_table = nullptr; int n_pack = 0;
+  unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
 };
 
 }  // namespace alignnet
@@ -91,6 +92,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->adam_m) hipFree(w->adam_m);
   if (w->adam_v) hipFree(w->adam_v);
   if (w->pack_table) hipFree(w->pack_table);
+  for (int s = 0; s < 3; ++s) if (w->wp3h[s]) hipFree(w->wp3h[s]);
   delete w;
   h->train_ws = nullptr;
 }
@@ -258,6 +260,14 @@ static int pack_all_weights(alignnet_handle* h)
     HIP_TRY(h, hipMemcpy(w->pack_table, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
+  if (h->train_bf16)
+    for (int s = 0; s < 3; ++s) {
+      const Layer& L = h->layers[conv_of(h, s).first + 2];
+      const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;
+      if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], n * sizeof(unsigned short)));
+      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, h->stream,
+                         P(h, L.p_w), L.cin, L.cout, w->wp3h[s]);
+    }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
 }
@@ -270,6 +280,7 @@ static int set_lds_attrs(alignnet_handle* h)
   if (done) return 0;
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
@@ -293,7 +304,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.b1 = P(h, L[0]->p_b); a.b2 = P(h, L[1]->p_b); a.b3 = P(h, L[2]->p_b);
   a.sc1 = S.scale[0]; a.sh1 = S.shift[0]; a.sc2 = S.scale[1]; a.sh2 = S.shift[1]; a.sgn3 = S.sgn3;
   a.stat_part = w->stat_part; a.ext = S.ext; a.idx = S.idx2; a.gram_part = w->gram_part; a.colsum_part = w->colsum_part;
-  a.h2_store = S.h2;
+  a.h2_store = S.h2; a.wp3h = nullptr;
   a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const double count = (double)B * N;
   auto finish = [&](int l, int C, int slices) {
@@ -314,7 +325,13 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   finish(0, C1, 1);
   hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4);
-  hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  if (h->train_bf16) {
+    a.wp3h = w->wp3h[s];
+    const size_t ldsh = lds_train(a.ld[0], a.ld[1]) + (size_t)kTT * (((C2 + 15) & ~15) + 8) * sizeof(unsigned short);
+    hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  }
   finish(2, C3, 2);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
   launch_reduce<double>(h, w->colsum_part, 4 * B, (long)(C2), S.s2);

@@ -59,6 +59,7 @@ struct alignnet_handle {
   float* d_scale = nullptr;
   float* d_shift = nullptr;
   size_t n_wp = 0, n_ss = 0;
+  bool train_bf16 = false;         // alignnet_set_option("train_matmul_bf16"): bf16 operands for the dominant training GEMMs
   bool folded = false;             // eval-mode scale/shift + packed weights are current
   alignnet::Workspace ws;
   hipStream_t stream = nullptr;

@@ -33,6 +33,7 @@ struct TrainFwdArgs {
   const float* w1;         // [3][C1]
   const float* wp2;        // MFMA image of W2 [C1][C2]
   const float* wp3;        // MFMA image of W3 [C2][C3]
+  const unsigned short* wp3h;   // bf16 MFMA image of W3 (train_bf16 mode; see pack_weights_bf16_kernel)
   const float *b1, *b2, *b3;       // conv biases (added before BN: utils/tf_util.py:161)
   const float *sc1, *sh1;  // [2][C1] batch-stat scale/shift of layer 1 (phase >= 2)
   const float *sc2, *sh2;  // [2][C2] (phase 3)
@@ -110,6 +111,57 @@ __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, cons
 
 __device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- bf16 operands (BASELINE.json configs[2]: "training ... bf16 with grad step"): the 128 -> C3 lift, 90 % of the
+// training FLOPs, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything else stays fp32 -------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short to_bf16_bits(float x)   // round-to-nearest-even (v_cvt_pk_bf16_f32 semantics)
+{
+  const __bf16 v = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, v);
+}
+
+// bf16 weight image: Wh[ct][kg][lane][8] = W[16 kg + 8 (lane>>5) + s][32 ct + (lane&31)]  (one 16-byte fragment per lane per MFMA)
+static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int K, int C, unsigned short* __restrict__ Wh)
+{
+  const int KG = (K + 15) >> 4, CT = (C + 31) >> 5;
+  const size_t total = (size_t)CT * KG * 512;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int s8 = idx & 7, lane = (idx >> 3) & 63;
+    const size_t t = idx >> 9;
+    const int kg = t % KG, ct = t / KG;
+    const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
+    Wh[idx] = (k < K && c < C) ? to_bf16_bits(W[(size_t)k * C + c]) : (unsigned short)0;
+  }
+}
+
+// acc[m] = A[rows 32 m.., :16 KG] * W tile, A a bf16 LDS tile with row stride lda (elements), one bf16x8 read per MFMA
+template <int MR>
+__device__ __forceinline__ void mfma_rows_bf16(const unsigned short* __restrict__ A, int lda, const bf16x8* __restrict__ Wh,
+                                               int KG, int lane, f32x16 (&acc)[MR])
+{
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const unsigned short* arow = A + (lane & 31) * lda + (lane >> 5) * 8;
+  bf16x8 bcur = Wh[lane];
+  for (int kg = 0; kg < KG; ++kg) {
+    const bf16x8 bnext = Wh[min(kg + 1, KG - 1) * 64 + lane];
+    bf16x8 av[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) av[m] = *reinterpret_cast<const bf16x8*>(arow + m * 32 * lda + kg * 16);
+#ifdef ALIGNNET_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bcur, acc[m], 0, 0, 0);
+#ifdef ALIGNNET_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    bcur = bnext;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // phase 1: statistics of z1 (one workgroup per cloud, 256 threads)
 // ---------------------------------------------------------------------------------
@@ -170,7 +222,7 @@ __global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
 // tile, no atomics): every accumulator element has exactly one owner lane, so the result is deterministic.
 // Slice layout: part[(cloud * S + slice) * n + i]; the two half-waves of a column are slices 0/1.
 // ---------------------------------------------------------------------------------
-template <int PHASE>
+template <int PHASE, bool BF16 = false>
 __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -183,6 +235,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   float* buf0 = smem + kTT * 4;
   float* buf1 = buf0 + kTT * a.ld[0];
   const int ld0 = a.ld[0], ld1 = a.ld[1];
+  // bf16 copy of the h2 tile (A operand of the bf16 lift): row stride K16 + 8 elements (= 4 dwords mod 64 at C2 = 128)
+  const int K16 = (a.C2 + 15) & ~15, ldh = K16 + 8;
+  unsigned short* buf1h = reinterpret_cast<unsigned short*>(buf1 + kTT * ld1);
   const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
   const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT;
@@ -245,6 +300,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
           const float h = row < nvalid ? fmaxf(fmaf(acc[0][r], sc, sh), 0.f) : 0.f;
           lsum += h;
           if (wr) buf1[row * ld1 + col] = h;
+          if (BF16 && col < K16) buf1h[row * ldh + col] = to_bf16_bits(h);
         }
         if (live) {
           double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col;
@@ -291,7 +347,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
       asm volatile("" ::: "memory");   // keep the four loads above the MFMA loop (see tile_prefetch)
       f32x16 acc[2];
-      mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
+      if (BF16)
+        mfma_rows_bf16<2>(buf1h, ldh, reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)ct * (K16 >> 4) * 64, K16 >> 4, lane, acc);
+      else
+        mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
       const float z0 = acc[0][0] + bias;
       float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll

@@ -91,7 +91,7 @@ def cpu_baseline(cfg, seconds=12.0):
 
 def pmc_traffic():
     """HBM bytes per step from a committed rocprofv3 PMC summary, if one exists."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "_train_" not in os.path.basename(f))
     if not files:
         return None
     try:

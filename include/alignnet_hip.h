@@ -184,6 +184,14 @@ int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_step);
  *      (the fused shared-MLP backbone) accumulated since the last reset, and the
  *      number of launches, measured on the handle's own stream. */
 int alignnet_profile_enable(alignnet_handle* h, int32_t on);
+
+/* ---- run-time options with no counterpart in the reference's config surface --------
+ * "train_matmul_bf16" (0/1, default 0): training only -- the 128 -> C3 feature lift of every backbone
+ *   (90 % of the step's FLOPs, models/tp8.py:55-57) runs on bf16 MFMA with fp32 accumulation
+ *   (BASELINE.json configs[2]); statistics, pooling, all other layers, gradients' accumulation,
+ *   optimiser state and the eval-mode forward stay fp32.  Unknown keys fail. */
+int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value);
+int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value);
 int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches,
                           double* total_ms, int32_t reset);
 

@@ -37,9 +37,17 @@ def to_torch(P: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False)
 class TorchTp8:
     """Eager re-statement; `P` is a name->tensor dict using the oracle's names."""
 
-    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor]):
+    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False):
         self.spec, self.P = spec, P
         self.ema_updates: Dict[str, torch.Tensor] = {}
+        # Model of the engine's "train_matmul_bf16" option (not a reference feature): the operands of the last
+        # (widest) conv of every PointNet backbone are rounded to bf16 (round-to-nearest-even), products are
+        # accumulated exactly, and the backward treats the rounding as identity (straight-through).
+        self.bf16_lift = bf16_lift
+
+    @staticmethod
+    def _round_bf16_st(x):
+        return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
     # -- layers ---------------------------------------------------------
     def _bn(self, z, base, training, decay):
@@ -58,8 +66,11 @@ class TorchTp8:
             return y
         return F.batch_norm(z, P[base + "/moving_mean"], P[base + "/moving_var"], g, b, False, 0.0, BN_EPS)
 
-    def _layer(self, x, wbase, bnbase, training, decay, act=True):
-        z = F.linear(x, self.P[wbase + "/weights"].t(), self.P[wbase + "/biases"])
+    def _layer(self, x, wbase, bnbase, training, decay, act=True, round_operands=False):
+        w = self.P[wbase + "/weights"]
+        if round_operands:
+            x, w = self._round_bf16_st(x), self._round_bf16_st(w)
+        z = F.linear(x, w.t(), self.P[wbase + "/biases"])
         if bnbase is not None:
             z = self._bn(z, bnbase, training, decay)
         return torch.relu(z) if act else z
@@ -69,7 +80,8 @@ class TorchTp8:
         h = x.reshape(B * N, -1)
         for i in range(len(widths)):
             nm = f"{scope}/conv{i+1}"
-            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
+                            round_operands=self.bf16_lift and training and i == len(widths) - 1)
         return h.reshape(B, N, -1).amax(dim=1)
 
     def _dgcnn(self, x, scope, widths, tower, training, decay):

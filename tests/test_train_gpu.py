@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
 
 
-def _oracle(cfg, P32, d, du, decay):
+def _oracle(cfg, P32, d, du, decay, bf16_lift=False):
     spec = R.NetSpec.from_cfg(cfg)
     tp = T.to_torch({k: v.astype(np.float64) for k, v in P32.items()}, requires_grad=True)
-    tm = T.TorchTp8(spec, tp)
+    tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift)
     td = {k: torch.tensor(v.astype(np.float64)) for k, v in d.items()}
     tu = {k: torch.tensor(v.astype(np.float64)) for k, v in du.items()}
     ep = tm.forward(td["pcs1"], td["pcs2"], True, decay, tu)
@@ -154,4 +154,59 @@ def test_eval_loss_matches_oracle(gpu_required):
     assert abs(loss - lref) <= 1e-4 * max(1.0, abs(lref)), (loss, lref)
     for k, v in sref.items():
         assert abs(summ[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, summ[k], v)
+    eng.close()
+
+
+@pytest.mark.parametrize("N,B", [(256, 64)])
+def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
+    """BASELINE.json configs[2] (bf16 training): option "train_matmul_bf16" runs the widest 1x1 conv of every backbone on
+    bf16 MFMA (operands rounded to nearest even, fp32 accumulation), backward unchanged (straight-through).  The oracle
+    models exactly that (TorchTp8(bf16_lift=True): same rounding, exact accumulation).  What remains between the two is
+    rounding-boundary noise: an fp32-vs-fp64 difference in h2 moves some entries to the neighbouring bf16 value (one
+    ulp = 0.4 % of one product), and a moved entry on an arg-max row shifts one pooled feature of one sample.
+    Tolerances (written here):
+      * batch statistics of the bf16 lift (read back through the EMA shadows, averages over B*N rows): 1e-4 relative to
+        the largest entry, and >= 10x closer to the rounded oracle than the fp32 step is;
+      * stage-1 centres (identical inputs): median per-sample error <= 1e-3, max <= 2e-2; later predictions: max <= 5e-2;
+        every prediction >= 5x closer to the rounded oracle than the fp32 step's;
+      * loss within 5e-3; whole gradient within cosine 0.97 of the oracle's (a moved arg-max row re-routes that
+        channel's gradient to another point) and >= 3x closer (1 - cos) than the fp32 step's gradient.
+    Against the *fp32* step the bf16 step differs by ~1 % in the stage features and flips a few argmax yaw decodes per
+    batch (tools/bf16_check.py), which is why the comparison is against the rounded oracle."""
+    cfg, spec, P32, d, du = _setup(N, B)
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    stats = ["siamese/transformer1/embedding/conv3/bn/moving_mean", "siamese_1/transformer1/embedding/conv3/bn/moving_var"]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    assert eng.get_option("train_matmul_bf16") == 0
+    res32 = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    ema32 = {k: eng.get_variable(k) for k in stats}
+    g32 = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
+    eng.set_variables(P32)
+    eng.set_option("train_matmul_bf16", 1)
+    assert eng.get_option("train_matmul_bf16") == 1
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert res["loss"] != res32["loss"], "bf16 option had no effect"
+    for k in stats:
+        got, ref = eng.get_variable(k), ema_ref[k]
+        e16, e32 = float(np.abs(got - ref).max()), float(np.abs(ema32[k] - ref).max())
+        print(k, "err vs rounded oracle %.2e (fp32 step: %.2e), scale %.2e" % (e16, e32, np.abs(ref).max()))
+        assert e16 <= 1e-4 * np.abs(ref).max() and e16 < 0.1 * e32, (k, e16, e32)
+    for k in ep_ref:
+        per = np.abs(res[k] - ep_ref[k]).reshape(B, -1).max(1)
+        err32 = float(np.abs(res32[k] - ep_ref[k]).max())
+        print(k, "median %.2e max %.2e (fp32 step max %.2e)" % (np.median(per), per.max(), err32))
+        if "s1_" in k:
+            assert np.median(per) <= 1e-3 and per.max() <= 2e-2, (k, per.max())
+        assert per.max() <= 5e-2 and per.max() < 0.2 * err32, (k, per.max(), err32)
+    assert abs(res["loss"] - loss_ref) <= 5e-3 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    g16 = {n: eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)}
+    a, b = np.concatenate(list(g16.values())), np.concatenate([grads[n].ravel() for n in g16])
+    cos_all = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    cos32 = float(g32 @ b / (np.linalg.norm(g32) * np.linalg.norm(b)))
+    print("loss", res["loss"], loss_ref, "fp32 step", res32["loss"], "gradient cosine", cos_all, "fp32 step's", cos32)
+    assert cos_all > 0.97 and (1 - cos_all) < 0.3 * (1 - cos32)
+    with pytest.raises(RuntimeError):
+        eng.set_option("no_such_option", 1)
     eng.close()
