@@ -327,7 +327,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   finish(1, C2, 4);
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
-    const size_t ldsh = lds_train(a.ld[0], a.ld[1]) + (size_t)kTT * (((C2 + 15) & ~15) + 8) * sizeof(unsigned short);
+    const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
+                        ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
     hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
   } else {
     hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -456,7 +457,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(256), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * 4), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * 4), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,

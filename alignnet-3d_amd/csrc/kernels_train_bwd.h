@@ -550,8 +550,9 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
 }
 
 // Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
+// h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16)
 __global__ __launch_bounds__(512) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                                        int B, int N, int C2, int C3, float* __restrict__ Sp)
+                                                        int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
 {
   __shared__ double red[4][128];
   const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x % C2, g = threadIdx.x / C2;
@@ -560,7 +561,11 @@ __global__ __launch_bounds__(512) void sparse_dw_kernel(const float* __restrict_
     for (int b = g; b < B; b += 4) {
       const size_t cloud = (size_t)t * B + b;
       const float gv = gs[cloud * C3 + c];
-      if (gv != 0.f) s += (double)gv * h2[(cloud * N + idx[cloud * C3 + c]) * C2 + k];
+      if (gv != 0.f) {
+        const size_t e = (cloud * N + idx[cloud * C3 + c]) * C2 + k;
+        const float hv = h2_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h2)[e] << 16) : h2[e];
+        s += (double)gv * hv;
+      }
     }
   if (g < 4) red[g][k] = s;
   __syncthreads();

@@ -235,9 +235,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   float* buf0 = smem + kTT * 4;
   float* buf1 = buf0 + kTT * a.ld[0];
   const int ld0 = a.ld[0], ld1 = a.ld[1];
-  // bf16 copy of the h2 tile (A operand of the bf16 lift): row stride K16 + 8 elements (= 4 dwords mod 64 at C2 = 128)
+  // bf16 mode keeps h2 only as bf16: row-major (A operand of the lift, row stride C2 + 8 elements = 4 dwords mod 64 at
+  // C2 = 128) and transposed [channel][row] (both operands of the Gram, row stride kTT + 8); no fp32 tile
   const int K16 = (a.C2 + 15) & ~15, ldh = K16 + 8;
-  unsigned short* buf1h = reinterpret_cast<unsigned short*>(buf1 + kTT * ld1);
+  constexpr int ldT = kTT + 8;
+  unsigned short* buf1h = reinterpret_cast<unsigned short*>(buf1);
+  unsigned short* bufT = buf1h + kTT * ldh;
   const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
   const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT;
@@ -294,13 +297,33 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
         float lsum = 0.f;
         const bool wr = col < ((a.C2 + 7) & ~7);
+        if (BF16) {
+          // the column sums are those of the ROUNDED values, so that the centred Gram G - s s^T / M (kernels_train_bwd.h)
+          // is the exact covariance of one data matrix
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rg * 32 + acc_row(0, r, lane);
-          const float h = row < nvalid ? fmaxf(fmaf(acc[0][r], sc, sh), 0.f) : 0.f;
-          lsum += h;
-          if (wr) buf1[row * ld1 + col] = h;
-          if (BF16 && col < K16) buf1h[row * ldh + col] = to_bf16_bits(h);
+          for (int q = 0; q < 4; ++q) {
+            unsigned short hb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = q * 4 + e, row = rg * 32 + acc_row(0, r, lane);
+              const float h = row < nvalid ? fmaxf(fmaf(acc[0][r], sc, sh), 0.f) : 0.f;
+              hb[e] = to_bf16_bits(h);
+              lsum += __uint_as_float((unsigned)hb[e] << 16);
+              if (col < K16) buf1h[row * ldh + col] = hb[e];
+            }
+            if (col < K16) {   // rows 8q + 4 half + 0..3 of this column are consecutive in the transposed tile
+              uint2 pk; pk.x = hb[0] | ((unsigned)hb[1] << 16); pk.y = hb[2] | ((unsigned)hb[3] << 16);
+              *reinterpret_cast<uint2*>(bufT + col * ldT + rg * 32 + q * 8 + half * 4) = pk;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rg * 32 + acc_row(0, r, lane);
+            const float h = row < nvalid ? fmaxf(fmaf(acc[0][r], sc, sh), 0.f) : 0.f;
+            lsum += h;
+            if (wr) buf1[row * ld1 + col] = h;
+          }
         }
         if (live) {
           double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col;
@@ -312,7 +335,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     __syncthreads();
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-    if (!(a.dbg & 2)) {
+    if (BF16) {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+      const int c8 = a.C2 >> 3;
+      for (int i = tid; i < nvalid * c8; i += kTW * 64) {
+        const int row = i / c8, q = i % c8;
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 8) = *reinterpret_cast<const f32x4*>(buf1h + row * ldh + q * 8);
+      }
+    } else if (!(a.dbg & 2)) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
@@ -322,7 +352,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     }
 
     // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's rows ----
-    for (int item = wave; item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kTW) {
+    for (int item = wave; BF16 && item < CT2 * CT2; item += kTW) {   // K = the tile's 64 rows = 4 bf16 MFMAs per block
+      const int it = item / CT2, jt = item % CT2;
+      const unsigned short* pa = bufT + (it * 32 + (lane & 31)) * ldT + half * 8;
+      const unsigned short* pb = bufT + (jt * 32 + (lane & 31)) * ldT + half * 8;
+      float old[16];
+      tile_prefetch(my_gram, a.C2, it, jt, a.C2, a.C2, first, lane, old);
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < kTT / 16; ++kg)
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kg * 16), *reinterpret_cast<const bf16x8*>(pb + kg * 16), g, 0, 0, 0);
+      tile_commit(my_gram, a.C2, it, jt, a.C2, a.C2, g, lane, old);
+    }
+    for (int item = wave; !BF16 && item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kTW) {
       const int it = item / CT2, jt = item % CT2;
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
