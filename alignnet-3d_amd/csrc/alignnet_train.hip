@@ -263,10 +263,10 @@ static int pack_all_weights(alignnet_handle* h)
   if (h->train_bf16)
     for (int s = 0; s < 3; ++s) {
       const Layer& L = h->layers[conv_of(h, s).first + 2];
-      const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;
-      if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], n * sizeof(unsigned short)));
-      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, h->stream,
-                         P(h, L.p_w), L.cin, L.cout, w->wp3h[s]);
+      const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;   // per tower (sign of its gamma folded in)
+      if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], 2 * n * sizeof(unsigned short)));
+      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024), 2), dim3(256), 0, h->stream,
+                         P(h, L.p_w), L.cin, L.cout, P(h, L.p_bn[0][1]), P(h, L.p_bn[1][1]), w->wp3h[s]);
     }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
@@ -339,7 +339,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
   const size_t tot = (size_t)2 * B * C3;
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),
-                     S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled, S.tower_stride, S.row_stride, S.zhat_star, S.idx);
+                     S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled, S.tower_stride, S.row_stride, S.zhat_star, S.idx,
+                     h->train_bf16 ? 1 : 0);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }

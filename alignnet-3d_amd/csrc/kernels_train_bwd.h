@@ -484,12 +484,18 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const T* __restrict_
 // centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
 __global__ void centre_gram_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m)
 {
+  // Only the 32 x 32 blocks on or above the block diagonal are read (the bf16 forward accumulates just those); each of
+  // their elements is centred and mirrored into the block below the diagonal by the same thread.
   const int t = blockIdx.y;
   const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (e >= (long)C * C) return;
   const int i = e / C, j = e % C;
-  G[(size_t)t * C * C + e] = (float)((double)G[(size_t)t * C * C + e] - (double)s[t * C + i] * (double)s[t * C + j] / M);
   if (j == 0) m[t * C + i] = (float)((double)s[t * C + i] / M);
+  if ((i >> 5) > (j >> 5)) return;
+  float* Gt = G + (size_t)t * C * C;
+  const float v = (float)((double)Gt[e] - (double)s[t * C + i] * (double)s[t * C + j] / M);
+  Gt[e] = v;
+  if ((i >> 5) < (j >> 5)) Gt[(size_t)j * C + i] = v;
 }
 
 // last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0

@@ -120,17 +120,23 @@ __device__ __forceinline__ unsigned short to_bf16_bits(float x)   // round-to-ne
   return __builtin_bit_cast(unsigned short, v);
 }
 
-// bf16 weight image: Wh[ct][kg][lane][8] = W[16 kg + 8 (lane>>5) + s][32 ct + (lane&31)]  (one 16-byte fragment per lane per MFMA)
-static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int K, int C, unsigned short* __restrict__ Wh)
+// bf16 weight image: Wh[t][ct][kg][lane][8] = sign(gamma_t[c]) * W[16 kg + 8 (lane>>5) + s][c],  c = 32 ct + (lane&31)
+// (one 16-byte fragment per lane per MFMA).  The sign of the following BatchNorm's gamma is folded into the column
+// (exact), so that the kernel's accumulator is already sgn * (z - bias): the pooled extreme is a plain max.
+static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int K, int C, const float* __restrict__ gamma0,
+                                                const float* __restrict__ gamma1, unsigned short* __restrict__ Wh)
 {
-  const int KG = (K + 15) >> 4, CT = (C + 31) >> 5;
+  const int KG = (K + 15) >> 4, CT = (C + 31) >> 5, t = blockIdx.y;
+  const float* gamma = t ? gamma1 : gamma0;
   const size_t total = (size_t)CT * KG * 512;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int s8 = idx & 7, lane = (idx >> 3) & 63;
-    const size_t t = idx >> 9;
-    const int kg = t % KG, ct = t / KG;
+    const size_t q = idx >> 9;
+    const int kg = q % KG, ct = q / KG;
     const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
-    Wh[idx] = (k < K && c < C) ? to_bf16_bits(W[(size_t)k * C + c]) : (unsigned short)0;
+    float v = 0.f;
+    if (k < K && c < C) v = gamma[c] >= 0.f ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
+    Wh[(size_t)t * total + idx] = to_bf16_bits(v);
   }
 }
 
@@ -257,6 +263,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
+  constexpr int kGramSlots = 3;               // ceil(10 upper blocks of a 128 x 128 Gram / 4 waves)
+  const int nblk = CT2 * (CT2 + 1) / 2;
+  f32x16 gacc[BF16 ? kGramSlots : 1];
+  if (BF16) {
+#pragma unroll
+    for (int q = 0; q < kGramSlots; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+  }
+
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
@@ -335,14 +351,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     __syncthreads();
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-    if (BF16) {
+    if (BF16 && !(a.dbg & 2)) {
       unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c8 = a.C2 >> 3;
       for (int i = tid; i < nvalid * c8; i += kTW * 64) {
         const int row = i / c8, q = i % c8;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 8) = *reinterpret_cast<const f32x4*>(buf1h + row * ldh + q * 8);
       }
-    } else if (!(a.dbg & 2)) {
+    } else if (!BF16 && !(a.dbg & 2)) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
@@ -352,19 +368,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     }
 
     // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's rows ----
-    for (int item = wave; BF16 && item < CT2 * CT2; item += kTW) {   // K = the tile's 64 rows = 4 bf16 MFMAs per block
-      const int it = item / CT2, jt = item % CT2;
-      const unsigned short* pa = bufT + (it * 32 + (lane & 31)) * ldT + half * 8;
-      const unsigned short* pb = bufT + (jt * 32 + (lane & 31)) * ldT + half * 8;
-      float old[16];
-      tile_prefetch(my_gram, a.C2, it, jt, a.C2, a.C2, first, lane, old);
-      f32x16 g;
+    if (BF16 && !(a.dbg & 1)) {
+      // upper-triangle blocks only (the Gram is symmetric; centre_gram_kernel mirrors them), register-resident for the
+      // whole cloud: a per-tile read-modify-write of the 64 KiB per-cloud matrix does not stay in L2 (512 clouds in flight)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+      for (int q = 0; q < kGramSlots; ++q) {
+        const int item = wave + q * kTW;
+        if (item < nblk) {
+          int it = 0, rem = item;
+          while (rem >= CT2 - it) { rem -= CT2 - it; ++it; }
+          const int jt = it + rem;
+          const unsigned short* pa = bufT + (it * 32 + (lane & 31)) * ldT + half * 8;
+          const unsigned short* pb = bufT + (jt * 32 + (lane & 31)) * ldT + half * 8;
 #pragma unroll
-      for (int kg = 0; kg < kTT / 16; ++kg)
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kg * 16), *reinterpret_cast<const bf16x8*>(pb + kg * 16), g, 0, 0, 0);
-      tile_commit(my_gram, a.C2, it, jt, a.C2, a.C2, g, lane, old);
+          for (int kg = 0; kg < kTT / 16; ++kg)
+            gacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kg * 16),
+                                                              *reinterpret_cast<const bf16x8*>(pb + kg * 16), gacc[q], 0, 0, 0);
+        }
+      }
     }
     for (int item = wave; !BF16 && item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kTW) {
       const int it = item / CT2, jt = item % CT2;
@@ -381,6 +402,63 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     }
 
     // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
+    if (BF16) {
+      // acc = sgn * (z3 - bias) (sign folded into the bf16 image).  VALU-bound epilogue, 4 ops per element: sum, sum of
+      // squares, and a max over keys = the value with its low 4 mantissa bits replaced by the accumulator register
+      // number (2^-19 relative, far below the bf16 operand rounding), so value and row come out of one v_max3_f32 chain.
+      const int KG16 = K16 >> 4;
+      const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)tower * CT3 * KG16 * 64;
+      for (int ct = wave; ct < ((a.dbg & 8) ? 0 : CT3); ct += kTW) {
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C3;
+        const float bias = live ? a.b3[col] : 0.f;
+        const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
+        float be = (first || !live) ? -INFINITY : my_ext[col];
+        int bi = (first || !live) ? 0 : my_idx[col];
+        const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
+        asm volatile("" ::: "memory");
+        f32x16 acc[2];
+        mfma_rows_bf16<2>(buf1h, ldh, wimg + (size_t)ct * KG16 * 64, KG16, lane, acc);
+        float s1 = 0.f, s2 = 0.f, mx[2] = {-INFINITY, -INFINITY};
+        int cnt = 2 * 16;
+        if (nvalid == kTT) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const float v0 = acc[m][r], v1 = acc[m][r + 1];
+              s1 += v0; s2 = fmaf(v0, v0, s2);
+              s1 += v1; s2 = fmaf(v1, v1, s2);
+              const float k0 = __uint_as_float((__float_as_uint(v0) & ~15u) | (unsigned)r);
+              const float k1 = __uint_as_float((__float_as_uint(v1) & ~15u) | (unsigned)(r + 1));
+              asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[m]) : "v"(mx[m]), "v"(k0), "v"(k1));
+            }
+        } else {
+          cnt = 0;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool ok = acc_row(m, r, lane) < nvalid;
+              const float v = ok ? acc[m][r] : 0.f;
+              s1 += v; s2 = fmaf(v, v, s2); cnt += ok;
+              const float k = ok ? __uint_as_float((__float_as_uint(v) & ~15u) | (unsigned)r) : -INFINITY;
+              asm("v_max_f32 %0, %1, %2" : "=v"(mx[m]) : "v"(mx[m]), "v"(k));
+            }
+        }
+        const int msel = mx[1] > mx[0];   // near-ties resolve to the lower row block
+        const float cand = msel ? mx[1] : mx[0];
+        if (cand > be) { be = cand; bi = tile * kTT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane); }
+        if (live && !(a.dbg & 4)) {
+          // sum z = sg * S1 + n b,  sum z^2 = S2 + 2 b sg S1 + n b^2   (z = sg * acc + b)
+          const double n = (double)cnt, bd = (double)bias, t1 = (double)sg * (double)s1;
+          my_stat[col * 2] = o0 + t1 + n * bd;
+          my_stat[col * 2 + 1] = o1 + (double)s2 + 2.0 * bd * t1 + n * bd * bd;
+          my_ext[col] = be; my_idx[col] = bi;
+        }
+      }
+      continue;
+    }
     for (int ct = wave; ct < CT3; ct += kTW) {
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
@@ -391,10 +469,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
       asm volatile("" ::: "memory");   // keep the four loads above the MFMA loop (see tile_prefetch)
       f32x16 acc[2];
-      if (BF16)
-        mfma_rows_bf16<2>(buf1h, ldh, reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)ct * (K16 >> 4) * 64, K16 >> 4, lane, acc);
-      else
-        mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
+      mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
       const float z0 = acc[0][0] + bias;
       float s1 = 0.f, s2 = 0.f; int cnt = 0;
 #pragma unroll
@@ -415,6 +490,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         my_stat[col * 2] = o0 + ls;
         my_stat[col * 2 + 1] = o1 + lss;
         my_ext[col] = be; my_idx[col] = bi;
+      }
+    }
+  }
+  if (PHASE == 3 && BF16) {
+#pragma unroll
+    for (int q = 0; q < kGramSlots; ++q) {
+      const int item = wave + q * kTW;
+      if (item < nblk) {
+        int it = 0, rem = item;
+        while (rem >= CT2 - it) { rem -= CT2 - it; ++it; }
+        const float zero[16] = {};
+        tile_commit(my_gram, a.C2, it, it + rem, a.C2, a.C2, gacc[q], lane, zero);
       }
     }
   }
@@ -498,7 +585,8 @@ __global__ void pool_finish_kernel(const float* __restrict__ ext, const int* __r
                                    const float* __restrict__ bias, const float* __restrict__ scale,
                                    const float* __restrict__ shift, const float* __restrict__ mean,
                                    const float* __restrict__ var, int B, int C, float* __restrict__ pooled,
-                                   long tower_stride, long row_stride, float* __restrict__ zhat_star, int* __restrict__ idx)
+                                   long tower_stride, long row_stride, float* __restrict__ zhat_star, int* __restrict__ idx,
+                                   int ext_excludes_bias)   // bf16 mode: ext = extreme of sgn*(z - bias)
 {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= (size_t)2 * B * C) return;
@@ -507,8 +595,8 @@ __global__ void pool_finish_kernel(const float* __restrict__ ext, const int* __r
   float e = ext[h0]; int bi = idx2[h0];
   if (ext[h1] > e || (ext[h1] == e && idx2[h1] < bi)) { e = ext[h1]; bi = idx2[h1]; }
   idx[i] = bi;
-  const float z = e * sgn[t * C + c];
-  const float y = fmaf(z - bias[c], scale[t * C + c], shift[t * C + c]);
+  const float z = e * sgn[t * C + c] + (ext_excludes_bias ? bias[c] : 0.f);
+  const float y = fmaf(ext_excludes_bias ? e * sgn[t * C + c] : z - bias[c], scale[t * C + c], shift[t * C + c]);
   pooled[t * tower_stride + b * row_stride + c] = fmaxf(y, 0.f);
   zhat_star[i] = (z - mean[t * C + c]) * (1.0f / sqrtf(var[t * C + c] + kBnEps));
 }

@@ -157,7 +157,7 @@ def test_eval_loss_matches_oracle(gpu_required):
     eng.close()
 
 
-@pytest.mark.parametrize("N,B", [(256, 64)])
+@pytest.mark.parametrize("N,B", [(256, 64), (200, 48)])
 def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
     """BASELINE.json configs[2] (bf16 training): option "train_matmul_bf16" runs the widest 1x1 conv of every backbone on
     bf16 MFMA (operands rounded to nearest even, fp32 accumulation), backward unchanged (straight-through).  The oracle
