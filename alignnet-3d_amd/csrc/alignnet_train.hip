@@ -190,7 +190,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
-    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * maxC1);
+    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 256);   // [2B][256 / C1 row groups][C1]
     w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
     w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
@@ -281,7 +281,8 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
@@ -480,11 +481,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = S.rstd[1];
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+  const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
-  hipLaunchKernelGGL(train_bwd_b2, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
+  if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
+  else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
   if (b2.stamps) {
     long long st[11];
     hipStreamSynchronize(h->stream);
@@ -494,19 +497,26 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     std::fprintf(stderr, "  total %lld\n", st[10] - st[0]);
   }
 
-  // ---- layer 2 parameter gradients + operators for B1 ----
-  launch_reduce<double>(h, w->dbg2_part, 4 * B, (long)(C2 * 2), w->dbg2);
-  launch_reduce<float>(h, w->u2_part, B, (long)(C1 * C2), w->u2);
-  launch_reduce<float>(h, w->g1_part, B, (long)(C1 * C1), w->g1);
-  launch_reduce<double>(h, w->s1_part, B, (long)(C1), w->s1);
-  hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, M, w->m1);
+  // ---- operators for B1 (the layer-2 weight gradient follows B1 when B1 accumulates U2 / Gram(h1)) ----
+  const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
+  const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
+  auto layer2_weight_grad = [&]() {
+    launch_reduce<float>(h, w->u2_part, B, (long)(C1 * C2), w->u2);
+    launch_reduce<float>(h, w->g1_part, B, (long)(C1 * C1), w->g1);
+    hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, M, w->m1);
+    // GW2[t] = Ghat1[t] W2
+    launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
+    hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
+                       G(h, w, L[1]->p_w));
+  };
+  launch_reduce<double>(h, w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2);
+  const int sG = std::max(1, 256 / C1);
+  launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->s1);
+  launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->m1, 2, (float)(1.0 / M));   // m1 = s1 / M (qbias needs it before B1)
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
                      P(h, L[1]->p_bn[1][1]), C2, M, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
                      G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
-  // GW2[t] = Ghat1[t] W2
-  launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
-  hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
-                     G(h, w, L[1]->p_w));
+  if (!acc_in_b1) layer2_weight_grad();
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
@@ -523,7 +533,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = S.rstd[0];
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
+  b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = acc_in_b1 ? w->g1_part : nullptr;
   hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  if (acc_in_b1) layer2_weight_grad();
   launch_reduce<double>(h, w->dbg1_part, 4 * B, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
                      P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),

@@ -36,10 +36,10 @@ struct BwdB2Args {
   const int* idx;               // [2B][C3]
   const float* w3t;             // [C3][C2]
   float* dy2_store;             // [2B*N][C2]
-  double* dbg2_part;            // [2B][4 = 2 row groups x 2 halves][C2][2]  (dbeta2, dgamma2)
+  double* dbg2_part;            // [2B][2 halves][C2][2]  (dbeta2, dgamma2)
   float* u2_part;               // [2B][C1*C2]
   float* g1_part;               // [2B][C1*C1]
-  double* s1_part;              // [2B][C1]
+  double* s1_part;              // [2B][G = 256 / C1 row groups][C1]
   int dbg;
   long long* stamps;            // debug: s_memtime stamps of wave 0 / block 0 at the phase boundaries of tile 3
 };
@@ -48,6 +48,7 @@ struct BwdB2Args {
 // static slots per wave), so the wave that produced z2 for an item also owns its dh2 and keeps z2 in registers.
 // LDS: xs | X [64][ldb] | Y [64][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
 #define B2_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+template <bool ACCUM>
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   int* wtot = hoff + kTW * (ntiles + 1);                       // [8] segment sizes
   const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
-  constexpr int kSlots = 2;
+  const int sG = max(1, (kTW * 64) / a.C1);
   float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
   float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
 
@@ -103,8 +104,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     if (lane == 0) hoff[wave * (ntiles + 1) + ntiles] = woff + pos;
   }
 
-  f32x16 z2[kSlots][1];
-  double db[kSlots] = {0.0, 0.0}, dg[kSlots] = {0.0, 0.0}, s1c = 0.0;
+  f32x16 z2[2];   // [row group]
+  const int ct = wave, col = ct * 32 + (lane & 31);
+  const bool live = col < a.C2;
+  double db = 0.0, dg = 0.0, s1c = 0.0;
 
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
@@ -118,27 +121,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
     B2_STAMP(2);
 
-    // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y ----
+    // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y.  Wave w owns channel tile w and both
+    //      32-row groups (one weight fragment feeds two MFMAs; C2 <= 128 -> CT2 <= 4 waves) ----
+    if (ct < CT2) {
+      mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
+      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      if (col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-    for (int sl = 0; sl < kSlots; ++sl) {
-      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
-      if (ct < CT2) {
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C2;
-        mfma_rows<1, true, false>(X + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2[sl]);
-        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-        if (col < ((a.C2 + 7) & ~7)) {
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = rg * 32 + acc_row(0, r, lane);
-            Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[sl][0][r], sc, sh), 0.f) : 0.f;
+            const int row = acc_row(m, r, lane);
+            Y[row * ldb + col] = row < nvalid ? fmaxf(fmaf(z2[m][r], sc, sh), 0.f) : 0.f;
           }
-        }
       }
     }
     B2_STAMP(3);
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
-    for (int item = wave; item < CT1 * CT1; item += kTW) {
+    for (int item = wave; ACCUM && item < ((a.dbg & 32) ? 0 : CT1 * CT1); item += kTW) {
       const int it = item / CT1, jt = item % CT1;
       const float* pa = X + half * ld0 + it * 32 + (lane & 31);
       const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
@@ -151,16 +151,17 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
       tile_commit(my_g1, a.C1, it, jt, a.C1, a.C1, g, lane, old);
     }
-    if (tid < a.C1) {
+    if (tid < sG * a.C1) {   // column sums of h1: sG row groups x C1 columns
+      const int c = tid % a.C1, g = tid / a.C1;
       float sm = 0.f;
-      for (int r = 0; r < kTT; ++r) sm += X[r * ld0 + tid];
+      for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
       s1c += (double)sm;
     }
     __syncthreads();
 
     B2_STAMP(4);
     // ---- sparse rows of dh2: X <- 0, then X[row][:] += g * W3[:, c] for this tile's hits ----
-    for (int i = tid; i < kTT * ldb; i += kTW * 64) X[i] = 0.f;
+    for (int i = tid; i < kTT * ldb / 4; i += kTW * 64) reinterpret_cast<f32x4*>(X)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // ldb % 4 == 0
     __syncthreads();
     B2_STAMP(5);
     if (a.dbg & 8) {
@@ -179,24 +180,32 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         }
       }
     } else {
+      // one hit per half-wave (32 lanes x 4 columns), 4 hits per half per chunk: 8 W3 rows in flight per wave.
+      // Hits of one wave may share a row, so the two halves apply their updates one after the other, in list order.
       const int h0 = hoff[wave * (ntiles + 1) + tile], h1 = hoff[wave * (ntiles + 1) + tile + 1];
-      for (int hb = h0; hb < h1; hb += 4) {
-        int e[4]; float g[4], w0[4], w1[4];
+      const int l4 = (lane & 31) * 4;
+      for (int hb = h0; hb < h1; hb += 8) {
+        int e[4]; float g[4]; f32x4 wv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const bool ok = hb + q < h1;
-          e[q] = ok ? hit_e[hb + q] : 0;
-          g[q] = ok ? hit_g[hb + q] : 0.f;
-          const float* wr = a.w3t + (size_t)(e[q] & 0xffff) * a.C2;
-          w0[q] = lane < a.C2 ? wr[lane] : 0.f;
-          w1[q] = lane + 64 < a.C2 ? wr[lane + 64] : 0.f;
+          const int hi = hb + 2 * q + half;
+          const bool ok = hi < h1;
+          e[q] = ok ? hit_e[hi] : -1;
+          g[q] = ok ? hit_g[hi] : 0.f;
+          wv[q] = (ok && l4 < a.C2) ? *reinterpret_cast<const f32x4*>(a.w3t + (size_t)(e[q] & 0xffff) * a.C2 + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {   // in list order: two hits may share a row
-          if (hb + q >= h1) break;      // padded slots must not touch LDS: row 0 belongs to another wave
-          const int row = e[q] >> 16;
-          if (lane < a.C2) X[row * ldb + lane] += g[q] * w0[q];
-          if (lane + 64 < a.C2) X[row * ldb + lane + 64] += g[q] * w1[q];
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            if (half == hh && e[q] >= 0 && l4 < a.C2) {
+              f32x4* px = reinterpret_cast<f32x4*>(X + (e[q] >> 16) * ldb + l4);
+              f32x4 v = *px;
+              v[0] = fmaf(g[q], wv[q][0], v[0]); v[1] = fmaf(g[q], wv[q][1], v[1]);
+              v[2] = fmaf(g[q], wv[q][2], v[2]); v[3] = fmaf(g[q], wv[q][3], v[3]);
+              *px = v;
+            }
+          }
         }
       }
     }
@@ -204,45 +213,39 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 
     B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
+    if (ct < CT2) {
+      const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
+      f32x16 acc[2];
 #pragma unroll
-    for (int sl = 0; sl < kSlots; ++sl) {
-      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
-      if (ct < CT2) {
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C2;
-        const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
-        f32x16 acc[1];
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = (live ? X[(rg * 32 + acc_row(0, r, lane)) * ldb + col] : 0.f) + qb;
-        mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
-        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-        const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
-        const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
-        float lb = 0.f, lg = 0.f;
+        for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
+      mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
+      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
+      const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
+      float lb = 0.f, lg = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = rg * 32 + acc_row(0, r, lane);
-          const bool on = row < nvalid && fmaf(z2[sl][0][r], sc, sh) > 0.f;
-          const float dy = on ? acc[0][r] : 0.f;
-          lb += dy; lg += dy * ((z2[sl][0][r] + bias - mu) * rs);
-          z2[sl][0][r] = dy;   // the registers now hold dy2
+          const bool on = acc_row(m, r, lane) < nvalid && fmaf(z2[m][r], sc, sh) > 0.f;
+          const float dy = on ? acc[m][r] : 0.f;
+          lb += dy; lg += dy * ((z2[m][r] + bias - mu) * rs);
+          z2[m][r] = dy;   // the registers now hold dy2
         }
-        db[sl] += (double)lb; dg[sl] += (double)lg;
-      }
+      db += (double)lb; dg += (double)lg;
     }
     B2_STAMP(7);
     __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
     B2_STAMP(8);
 
     // ---- dy2 -> Y ; h1 -> X again ----
+    if (ct < CT2 && col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
-    for (int sl = 0; sl < kSlots; ++sl) {
-      const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
-      const int col = ct * 32 + (lane & 31);
-      if (ct < CT2 && col < ((a.C2 + 7) & ~7)) {
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[(rg * 32 + acc_row(0, r, lane)) * ldb + col] = col < a.C2 ? z2[sl][0][r] : 0.f;
-      }
+        for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
     }
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         const int row = i / c4, q = i % c4;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
       }
-      for (int item = wave; item < CT1 * CT2; item += kTW) {
+      for (int item = wave; ACCUM && item < ((a.dbg & 64) ? 0 : CT1 * CT2); item += kTW) {
         const int it = item / CT2, jt = item % CT2;
         const float* pa = X + half * ld0 + it * 32 + (lane & 31);
         const float* pb = Y + half * ldb + jt * 32 + (lane & 31);
@@ -272,16 +275,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     }
     B2_STAMP(10);
   }
-#pragma unroll
-  for (int sl = 0; sl < kSlots; ++sl) {
-    const int item = wave + sl * kTW, ct = item >> 1, rg = item & 1;
-    const int col = ct * 32 + (lane & 31);
-    if (ct < CT2 && col < a.C2) {
-      double* d = a.dbg2_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col) * 2;   // slice (rg, half)
-      d[0] = db[sl]; d[1] = dg[sl];
-    }
+  if (ct < CT2 && live) {
+    double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;   // slice (half)
+    d[0] = db; d[1] = dg;
   }
-  if (tid < a.C1) a.s1_part[(size_t)cloud * a.C1 + tid] = s1c;
+  if (tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------
@@ -297,6 +295,7 @@ struct BwdB1Args {
   const float* dy2_store;
   float* dy1_store;                                  // [2B*N][C1]
   double* dbg1_part;                                 // [2B][4 = 2 row groups x 2 halves][C1][2]
+  float* u2_part; float* g1_part;                    // [2B][C1*C2], [2B][C1*C1] (upper blocks) or null: accumulated in B2
 };
 
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
@@ -317,6 +316,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   // items: (column tile ct, 32-row group rg)
   const int nitems = CT1 * 2;
+  // U2 = h1^T dy2 (CT1 x CT2 blocks) and the upper blocks of Gram(h1) stay in registers for the whole cloud (a per-tile
+  // read-modify-write of these 48 KiB per cloud falls out of L2 with 512 clouds in flight); <= 3 blocks per wave
+  constexpr int kAccSlots = 3;
+  const int CT2 = (a.C2 + 31) >> 5, half = lane >> 5;
+  const int nblk_u = a.u2_part ? CT1 * CT2 : 0, nblk = a.u2_part ? nblk_u + CT1 * (CT1 + 1) / 2 : 0;
+  f32x16 gacc[kAccSlots];
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
 
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
@@ -336,6 +345,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     __syncthreads();
     layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kAccSlots; ++q) {
+      const int item = wave + q * kTW;
+      if (item < nblk) {
+        int it, jt, ldr;
+        const float* pb;
+        if (item < nblk_u) { it = item / CT2; jt = item % CT2; pb = Y + half * ldb; ldr = ldb; }
+        else {
+          int rem = item - nblk_u; it = 0;
+          while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
+          jt = it + rem; pb = X + half * ld0; ldr = ld0;
+        }
+        const float* pa = X + half * ld0 + it * 32 + (lane & 31);
+        pb += jt * 32 + (lane & 31);
+#pragma unroll 8
+        for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldr], gacc[q], 0, 0, 0);
+      }
+    }
     for (int item = wave; item < nitems; item += kTW) {
       const int ct = item >> 1, rg = item & 1;
       const int col = ct * 32 + (lane & 31);
@@ -367,6 +394,20 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
       if (live) {
         dslice[0] = o0 + (double)lb;
         dslice[1] = o1 + (double)lg;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q) {
+    const int item = wave + q * kTW;
+    if (item < nblk) {
+      const float zero[16] = {};
+      if (item < nblk_u) {
+        tile_commit(a.u2_part + (size_t)cloud * a.C1 * a.C2, a.C2, item / CT2, item % CT2, a.C1, a.C2, gacc[q], lane, zero);
+      } else {
+        int rem = item - nblk_u, it = 0;
+        while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
+        tile_commit(a.g1_part + (size_t)cloud * a.C1 * a.C1, a.C1, it, it + rem, a.C1, a.C1, gacc[q], lane, zero);
       }
     }
   }

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--train-dtype", choices=["f32", "bf16"], default="f32",
+                    help="--mode train: operand type of the dominant training GEMMs (bf16 = BASELINE.json configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--train-leg", action="store_true", help="also run the training leg when --gpus > 1 (RCCL all-reduce)")
@@ -172,6 +174,8 @@ def main():
         eng.forward_device(p1.data_ptr(), p2.data_ptr(), B, ptrs)
 
     step = train_step if args.mode == "train" else infer_step
+    if args.mode == "train" and args.train_dtype == "bf16":
+        eng.set_option("train_matmul_bf16", 1)
 
     def fence():
         eng.synchronize()
@@ -201,23 +205,32 @@ def main():
     # secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA), fp32
     train_info = None
     if args.mode == "infer" and want_train:
-        ksteps = max(3, args.steps // 5)
-        for _ in range(2):
-            train_step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(ksteps):
-            train_step()
-        fence()
-        tdt = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tdt = float(t.item())
-        train_info = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
-                      "steps": ksteps, "dtype": "f32",
-                      "what": "train step: batch-stat forward + loss + backward + " +
-                              ("RCCL all-reduce + " if world > 1 else "") + "Adam + EMA, local-BN data parallel"}
+        train_info = {}
+        for tdtype in ("f32", "bf16"):
+            eng.set_option("train_matmul_bf16", int(tdtype == "bf16"))
+            ksteps = max(3, args.steps // 5)
+            for _ in range(2):
+                train_step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(ksteps):
+                train_step()
+            fence()
+            tdt = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tdt = float(t.item())
+            leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
+                   "steps": ksteps, "dtype": tdtype,
+                   "what": "train step: batch-stat forward + loss + backward + " +
+                           ("RCCL all-reduce + " if world > 1 else "") + "Adam + EMA, local-BN data parallel" +
+                           ("; 128->C3 lift and its Gram on bf16 MFMA, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
+            if tdtype == "f32":
+                train_info = leg
+            else:
+                train_info["bf16"] = leg
+        eng.set_option("train_matmul_bf16", 0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -248,6 +261,11 @@ def main():
         if args.mode == "train":
             line["metric"] = "point-cloud pairs/sec at N=1024 (training step)"
             line["roofline"] = None
+            line["dtype"] = args.train_dtype
+            line["config"]["workload"] = ("KITTITrackletsCars-style training step (SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
+                                          "(BASELINE.json configs[2])" % (B, npts, args.train_dtype))
+            line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients)" if world > 1 else "")
+            line["whole_path_tflops"] = None
         if train_info is not None:
             line["train"] = train_info
         if world == 1 and not args.no_cpu_baseline:
