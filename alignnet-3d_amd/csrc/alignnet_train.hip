@@ -306,6 +306,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.sc1 = S.scale[0]; a.sh1 = S.shift[0]; a.sc2 = S.scale[1]; a.sh2 = S.shift[1]; a.sgn3 = S.sgn3;
   a.stat_part = w->stat_part; a.ext = S.ext; a.idx = S.idx2; a.gram_part = w->gram_part; a.colsum_part = w->colsum_part;
   a.h2_store = S.h2; a.wp3h = nullptr;
+  a.gram_inline = ((C2 + 31) / 32) * ((C2 + 31) / 32 + 1) / 2 > 3 * kTW;   // never for C2 <= 128
   a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const double count = (double)B * N;
   auto finish = [&](int l, int C, int slices) {
@@ -333,6 +334,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
   } else {
     hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    if (!a.gram_inline)
+      hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
+                         w->gram_part);
   }
   finish(2, C3, 2);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);

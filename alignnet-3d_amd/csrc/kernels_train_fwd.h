@@ -44,6 +44,7 @@ struct TrainFwdArgs {
   float* gram_part;        // [2B][C2*C2]
   double* colsum_part;     // [2B][4 = 2 row halves x 2 lane halves][C2]
   float* h2_store;         // [2B*N][C2]
+  int gram_inline;         // fp32 phase 3: 1 = accumulate the Gram per tile in this kernel (fallback), 0 = gram_h2_kernel does it
   int dbg;                 // debug/ablation flags (0 in production)
 };
 
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         }
       }
     }
-    for (int item = wave; !BF16 && item < ((a.dbg & 1) ? 0 : CT2 * CT2); item += kTW) {
+    for (int item = wave; !BF16 && item < (((a.dbg & 1) || !a.gram_inline) ? 0 : CT2 * CT2); item += kTW) {
       const int it = item / CT2, jt = item % CT2;
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
@@ -505,6 +506,64 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Gram of the stored fp32 h2 (fp32 training): G[cloud] = sum over the cloud's rows of h2^T h2, upper 32 x 32 blocks only
+// (centre_gram_kernel mirrors them).  The blocks stay in registers for the whole cloud -- accumulating them per tile
+// inside phase 3 was a read-modify-write of 64 KiB per cloud that does not stay in L2 with 512 clouds in flight.
+// One workgroup (4 waves) per cloud, <= 3 blocks per wave (C2 <= 128), tiles double-buffered through LDS.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTW * 64) void gram_h2_kernel(const float* __restrict__ h2, int N, int C2, float* __restrict__ gram_part)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x;
+  const int ld = C2 + 4, CT2 = (C2 + 31) >> 5, nblk = CT2 * (CT2 + 1) / 2, c4 = C2 >> 2;
+  const int ntiles = (N + kTT - 1) / kTT;
+  const float* src = h2 + (size_t)cloud * N * C2;
+  constexpr int kSlots = 3;
+  f32x16 gacc[kSlots];
+  int bit[kSlots], bjt[kSlots];
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+    int it = 0, rem = wave + q * kTW;
+    while (it < CT2 && rem >= CT2 - it) { rem -= CT2 - it; ++it; }
+    bit[q] = it; bjt[q] = it + rem;
+  }
+  auto load_tile = [&](int tile, float* buf) {
+    const int nvalid = min(kTT, N - tile * kTT);
+    for (int i = tid; i < kTT * c4; i += kTW * 64) {
+      const int row = i / c4, q = i % c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + ((size_t)tile * kTT + row) * C2 + q * 4);
+      *reinterpret_cast<f32x4*>(buf + row * ld + q * 4) = v;
+    }
+  };
+  load_tile(0, smem);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    float* cur = smem + (tile & 1) * kTT * ld;
+    __syncthreads();   // cur is complete; the other buffer's readers (tile - 1) are done
+    if (tile + 1 < ntiles) load_tile(tile + 1, smem + ((tile + 1) & 1) * kTT * ld);
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      if (wave + q * kTW < nblk) {
+        const float* pa = cur + half * ld + bit[q] * 32 + (lane & 31);
+        const float* pb = cur + half * ld + bjt[q] * 32 + (lane & 31);
+#pragma unroll 8
+        for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld], pb[r * ld], gacc[q], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q)
+    if (wave + q * kTW < nblk) {
+      const float zero[16] = {};
+      tile_commit(gram_part + (size_t)cloud * C2 * C2, C2, bit[q], bjt[q], C2, C2, gacc[q], lane, zero);
+    }
 }
 
 // ---------------------------------------------------------------------------------
