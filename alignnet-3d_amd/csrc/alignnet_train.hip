@@ -224,7 +224,7 @@ static void launch_gemm(alignnet_handle* h, const float* A, long sai, long sak, 
                         int batch = 1, long ba = 0, long bb = 0, long bc = 0)
 {
   GemmArgs g{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, bias, alpha, acc, ba, bb, bc};
-  hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(256), 0, h->stream, g);
+  hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(kGemmWaves * 64), 0, h->stream, g);
 }
 
 static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float* img)
@@ -236,7 +236,7 @@ static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float*
 template <typename T>
 static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, float* out, int towers = 2, float alpha = 1.f, int acc = 0)
 {
-  hipLaunchKernelGGL((reduce_slices_kernel<T>), dim3((unsigned)((n + 31) / 32), towers), dim3(256), 0, h->stream, part, S, n, out, alpha, acc);
+  hipLaunchKernelGGL((reduce_slices_kernel<T>), dim3((unsigned)((n + 31) / 32), towers), dim3(1024), 0, h->stream, part, S, n, out, alpha, acc);
 }
 
 static void launch_loss(alignnet_handle* h, const LossArgs& la)
@@ -321,7 +321,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.sgn = nullptr; f.next_gamma[0] = f.next_gamma[1] = nullptr;
     if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
     f.rstd = S.rstd[l]; f.k = S.kk[l];
-    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, h->stream, f);
   };
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);

@@ -502,21 +502,23 @@ __global__ __launch_bounds__(256) void train_bwd_b0(const BwdB0Args a)
 // out[t][i] (+)= alpha * sum_{s < S} part[(t*S + s)*n + i]      (fp64 accumulate, deterministic order)
 // grid (ceil(n/32), towers), block 256 = 32 columns x 8 slice groups
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const T* __restrict__ part, int S, long n, float* __restrict__ out,
-                                                            float alpha, int accumulate)
+__global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict__ part, int S, long n, float* __restrict__ out,
+                                                             float alpha, int accumulate)
 {
-  __shared__ double red[8][32];
+  // 32 columns x 32 slice groups per block: the reduction is a chain of dependent L2 round trips per thread, so the
+  // slice loop is spread as wide as a block allows
+  __shared__ double red[32][33];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, t = blockIdx.y;
   const long i = blockIdx.x * 32L + cl;
   double s = 0.0;
   if (i < n)
-    for (int k = g; k < S; k += 8) s += (double)part[((size_t)t * S + k) * n + i];
+    for (int k = g; k < S; k += 32) s += (double)part[((size_t)t * S + k) * n + i];
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && i < n) {
     double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k][cl];
+    for (int k = 0; k < 32; ++k) tot += red[k][cl];
     const float v = (float)tot * alpha;
     out[(size_t)t * n + i] = accumulate ? out[(size_t)t * n + i] + v : v;
   }

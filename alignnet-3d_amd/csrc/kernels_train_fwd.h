@@ -586,16 +586,16 @@ struct StatFinishArgs {
   float* rstd; float* k;     // [2][C]: rsqrt(var+eps) and gamma*rsqrt(var+eps) (backward passes)
 };
 
-__global__ __launch_bounds__(256) void stat_finish_kernel(const StatFinishArgs a)   // grid (ceil(C/32), 2), block 32 channels x 8 slice groups
+__global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs a)   // grid (ceil(C/32), 2), block 32 channels x 32 slice groups
 {
-  __shared__ double red[8][32][2];
+  __shared__ double red[32][32][2];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
   if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.next_C; i += gridDim.x * 256) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < a.next_C; i += gridDim.x * 1024) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
   const int S = a.B * a.slices;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
-    for (int b = g; b < S; b += 8) {
+    for (int b = g; b < S; b += 32) {
       const double* p = a.part + ((size_t)(t * S + b) * a.C + c) * 2;
       s += p[0]; ss += p[1];
     }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void stat_finish_kernel(const StatFinishArgs a
   __syncthreads();
   if (g != 0 || c >= a.C) return;
   s = 0.0; ss = 0.0;
-  for (int q = 0; q < 8; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
+  for (int q = 0; q < 32; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
   const double mean = s / a.count;
   const double var = fmax(ss / a.count - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;

@@ -8,7 +8,7 @@ namespace alignnet {
 
 // ---------------------------------------------------------------------------------
 // gemm_small: C[i][j] (+)= alpha * sum_k A(i,k) * B(k,j) (+ bias[j]) with arbitrary strides, so
-// NN / TN / NT all map onto it.  One 32x32 tile per workgroup, 4 waves split K (fp32 MFMA).
+// NN / TN / NT all map onto it.  One 32x32 tile per workgroup, 8 waves split K (fp32 MFMA).
 // ---------------------------------------------------------------------------------
 struct GemmArgs {
   const float* A; long sa_i, sa_k;
@@ -21,38 +21,77 @@ struct GemmArgs {
   long batch_a, batch_b, batch_c;   // element strides between batch entries (blockIdx.z)
 };
 
-__global__ __launch_bounds__(256) void gemm_small(const GemmArgs a)
+constexpr int kGemmWaves = 8, kGemmKC = 32, kGemmLd = 33;
+
+// One 32 x 32 output tile per workgroup; K is split over 8 waves.  Each wave stages its own 32-wide K chunks of A and B
+// in a private LDS region (no workgroup barrier in the loop): lanes run along whichever dimension has the smaller
+// stride, so row-major, transposed and column-scaled views all load coalesced; the next chunk's 32 loads are in
+// flight while the current chunk's 16 MFMAs run.
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a)
 {
-  __shared__ float red[3][16][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = blockIdx.y * 32 + (lane & 31), j = blockIdx.x * 32 + (lane & 31), half = lane >> 5;
-  const bool iv = i < a.M, jv = j < a.N;
-  const float* pa = a.A + blockIdx.z * a.batch_a + (size_t)(iv ? i : 0) * a.sa_i;
-  const float* pb = a.B + blockIdx.z * a.batch_b + (size_t)(jv ? j : 0) * a.sb_j;
+  __shared__ float stage[kGemmWaves][2][kGemmKC * kGemmLd];   // [wave][A|B][k][i or j]; reused for the final reduction
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const float* A = a.A + blockIdx.z * a.batch_a;
+  const float* Bm = a.B + blockIdx.z * a.batch_b;
+  float* As = stage[wave][0];
+  float* Bs = stage[wave][1];
+  // K range of this wave: whole chunks
+  const int nchunks = (a.K + kGemmKC - 1) / kGemmKC, per = (nchunks + kGemmWaves - 1) / kGemmWaves;
+  const int c0 = wave * per, c1 = min(nchunks, c0 + per);
+  const bool a_kfast = a.sa_k <= a.sa_i, b_jfast = a.sb_j <= a.sb_k;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int steps = (a.K + 1) >> 1, per = (steps + 3) >> 2, s0 = wave * per, s1 = min(steps, s0 + per);
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) {
-    const int k = 2 * s + half;
-    const bool kv = k < a.K;
-    const float av = (iv && kv) ? pa[(size_t)k * a.sa_k] : 0.f;
-    const float bv = (jv && kv) ? pb[(size_t)k * a.sb_k] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-  }
-  if (wave > 0) {
+  float ra[16], rb[16];
+  auto fetch = [&](int c) {
+    const int kc = c * kGemmKC;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    for (int t = 0; t < 16; ++t) {
+      const int e = lane + 64 * t;
+      const int ai = a_kfast ? e >> 5 : e & 31, ak = a_kfast ? e & 31 : e >> 5;
+      const int bj = b_jfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
+      ra[t] = (i0 + ai < a.M && kc + ak < a.K) ? A[(size_t)(i0 + ai) * a.sa_i + (size_t)(kc + ak) * a.sa_k] : 0.f;
+      rb[t] = (j0 + bj < a.N && kc + bk < a.K) ? Bm[(size_t)(kc + bk) * a.sb_k + (size_t)(j0 + bj) * a.sb_j] : 0.f;
+    }
+  };
+  if (c0 < c1) fetch(c0);
+  for (int c = c0; c < c1; ++c) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = lane + 64 * t;
+      const int ai = a_kfast ? e >> 5 : e & 31, ak = a_kfast ? e & 31 : e >> 5;
+      const int bj = b_jfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
+      As[ak * kGemmLd + ai] = ra[t];
+      Bs[bk * kGemmLd + bj] = rb[t];
+    }
+    if (c + 1 < c1) fetch(c + 1);
+    __builtin_amdgcn_wave_barrier();   // same-wave LDS operations complete in order; keep the compiler from reordering them
+#pragma unroll
+    for (int s2 = 0; s2 < kGemmKC / 2; ++s2) {
+      const int k = 2 * s2 + half;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * kGemmLd + (lane & 31)], Bs[k * kGemmLd + (lane & 31)], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();   // all staging regions are dead: reuse them for the cross-wave reduction
+  float* red = &stage[0][0][0];   // [wave][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
-  if (wave == 0 && jv) {
+  // 8 waves x 2 accumulator registers each finish the tile
+  const int j = j0 + (lane & 31);
+  if (j < a.N) {
     const float bias = a.bias ? a.bias[j] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int rr = 0; rr < 16 / kGemmWaves; ++rr) {
+      const int r = wave * (16 / kGemmWaves) + rr;
+      const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (row < a.M) {
-        float v = (acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane]) * a.alpha + bias;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGemmWaves; ++w) v += red[(w * 16 + r) * 64 + lane];
+        v = v * a.alpha + bias;
         float* dst = a.C + blockIdx.z * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
         *dst = a.accumulate ? *dst + v : v;
       }
