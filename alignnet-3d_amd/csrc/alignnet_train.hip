@@ -392,7 +392,7 @@ static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       HeadLayerWS& HL = w->hl[s][j];
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
       BnRowsArgs a = bn_args(h, w, s, j, M, rows_per_set, bn_decay, update_ema, u_dev);
-      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(256), 0, h->stream, a);
+      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(kBnCols * kBnGroups), 0, h->stream, a);
       cur = HL.y; ldc = L.cout;
     } else {
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, w->o[s], L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
@@ -423,7 +423,7 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
         const int src = L.p_bn[t][0] >= 0 ? t : 0;
         b.dbeta[t] = G(h, w, L.p_bn[src][0]); b.dgamma[t] = G(h, w, L.p_bn[src][1]);
       }
-      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(256), 0, h->stream, b);
+      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(kBnCols * kBnGroups), 0, h->stream, b);
       dcur = HL.dz;
       // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here); the whole gradient
       // vector is zeroed once per step, so nothing to do
@@ -463,7 +463,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(256), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * 4), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,

@@ -460,12 +460,26 @@ __global__ __launch_bounds__(256) void train_bwd_b0(const BwdB0Args a)
       }
       __syncthreads();
       if (active)
-        for (int i = rg; i < cnt; i += per) {
-          const float x0 = xs[i * 4], x1 = xs[i * 4 + 1], x2 = xs[i * 4 + 2];
-          const float zz = fmaf(x2, wb, fmaf(x1, wa, x0 * w0)) + bias;
-          const float zh = (zz - mu) * rs;
-          const float dz = k * (a.dy1_store[((size_t)cloud * a.N + base + i) * C1 + c] - mb - zh * mg);
-          p0 += (double)(x0 * dz); p1 += (double)(x1 * dz); p2 += (double)(x2 * dz); sz += (double)dz;
+        for (int i = rg; i < cnt; i += per * 8) {   // 8 independent loads in flight, fp32 partial sums folded into fp64
+          float dy[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int iu = i + u * per;
+            dy[u] = iu < cnt ? a.dy1_store[((size_t)cloud * a.N + base + iu) * C1 + c] : 0.f;
+          }
+          float q0 = 0.f, q1 = 0.f, q2 = 0.f, qs = 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int iu = i + u * per;
+            if (iu < cnt) {
+              const f32x4 x = *reinterpret_cast<const f32x4*>(xs + iu * 4);
+              const float zz = fmaf(x[2], wb, fmaf(x[1], wa, x[0] * w0)) + bias;
+              const float zh = (zz - mu) * rs;
+              const float dz = k * (dy[u] - mb - zh * mg);
+              q0 = fmaf(x[0], dz, q0); q1 = fmaf(x[1], dz, q1); q2 = fmaf(x[2], dz, q2); qs += dz;
+            }
+          }
+          p0 += (double)q0; p1 += (double)q1; p2 += (double)q2; sz += (double)qs;
         }
     }
     red[tid * 4 + 0] = active ? p0 : 0.0; red[tid * 4 + 1] = active ? p1 : 0.0;
@@ -599,26 +613,49 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
 }
 
 // Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
-// h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16)
-__global__ __launch_bounds__(512) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                                        int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
+// h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16).  The (index, weight) pairs of the channel are staged in
+// LDS first so that the row gathers are independent loads (4 in flight per thread).
+__global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                                         int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
 {
-  __shared__ double red[4][128];
-  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x % C2, g = threadIdx.x / C2;
+  constexpr int kStage = 1024;
+  __shared__ double red[8][128];
+  __shared__ int sidx[kStage];
+  __shared__ float sgv[kStage];
+  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x % C2, g = threadIdx.x / C2, G = blockDim.x / C2;   // G <= 8
   double s = 0.0;
-  if (g < 4)
-    for (int b = g; b < B; b += 4) {
-      const size_t cloud = (size_t)t * B + b;
-      const float gv = gs[cloud * C3 + c];
-      if (gv != 0.f) {
-        const size_t e = (cloud * N + idx[cloud * C3 + c]) * C2 + k;
-        const float hv = h2_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h2)[e] << 16) : h2[e];
-        s += (double)gv * hv;
-      }
+  for (int b0 = 0; b0 < B; b0 += kStage) {
+    const int nb = min(kStage, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+      const size_t cloud = (size_t)t * B + b0 + i;
+      sidx[i] = idx[cloud * C3 + c];
+      sgv[i] = gs[cloud * C3 + c];
     }
-  if (g < 4) red[g][k] = s;
+    __syncthreads();
+    for (int i = g; i < nb; i += G * 4) {
+      float hv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int iu = i + u * G;
+        gv[u] = iu < nb ? sgv[iu] : 0.f;
+        hv[u] = 0.f;
+        if (gv[u] != 0.f) {
+          const size_t e = (((size_t)t * B + b0 + iu) * N + sidx[iu]) * C2 + k;
+          hv[u] = h2_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h2)[e] << 16) : h2[e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)gv[u] * hv[u];
+    }
+  }
+  red[g][k] = s;
   __syncthreads();
-  if (g == 0) Sp[((size_t)t * C2 + k) * C3 + c] = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  if (g == 0) {
+    double tot = 0.0;
+    for (int q = 0; q < G; ++q) tot += red[q][k];
+    Sp[((size_t)t * C2 + k) * C3 + c] = (float)tot;
+  }
 }
 
 // out[t][i][j] = W[i][j] * col[t][j]   (scale columns)  /  transposed variants via strides

@@ -133,16 +133,22 @@ __device__ __forceinline__ float dropout_scale(const BnRowsArgs& a, int set, int
   return floorf(a.keep + u) / a.keep;   // tf.nn.dropout: x / keep * floor(keep + u)
 }
 
-constexpr int kBnCols = 32, kBnGroups = 8;   // block = 32 columns x 8 row groups
+constexpr int kBnCols = 32, kBnGroups = 32, kBnU = 8;   // block = 32 columns x 32 row groups; 8 independent loads per batch
 
-__global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const BnRowsArgs a)
+__global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const BnRowsArgs a)
 {
   __shared__ double red[kBnGroups][kBnCols][2];
   const int cl = threadIdx.x % kBnCols, rg = threadIdx.x / kBnCols, c = blockIdx.x * kBnCols + cl, set = blockIdx.y;
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
-    for (int r = r0 + rg; r < r1; r += kBnGroups) { const double v = a.z[(size_t)r * a.C + c]; s += v; ss += v * v; }
+    for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
+      float v[kBnU];
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) { s += (double)v[u]; ss += (double)v[u] * (double)v[u]; }
+    }
   red[rg][cl][0] = s; red[rg][cl][1] = ss;
   __syncthreads();
   if (c >= a.C) return;
@@ -158,9 +164,15 @@ __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const BnRowsArgs a)
     }
   }
   const float inv = a.gamma[set][c] * (1.0f / sqrtf(vf + kBnEps)), sh = a.beta[set][c] - mf * inv;
-  for (int r = r0 + rg; r < r1; r += kBnGroups) {
-    const float y = fmaxf(fmaf(a.z[(size_t)r * a.C + c], inv, sh), 0.f);
-    a.y[(size_t)r * a.C + c] = y * dropout_scale(a, set, r - r0, c);
+  for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
+    float v[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int ru = r + u * kBnGroups;
+      if (ru < r1) a.y[(size_t)ru * a.C + c] = fmaxf(fmaf(v[u], inv, sh), 0.f) * dropout_scale(a, set, ru - r0, c);
+    }
   }
 }
 
@@ -172,7 +184,7 @@ struct BnRowsBwdArgs {
   float* dbeta[2]; float* dgamma[2];
 };
 
-__global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
+__global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
 {
   const BnRowsArgs& a = b.f;
   __shared__ double red[kBnGroups][kBnCols][2];
@@ -182,10 +194,23 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
   if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
   double sb = 0.0, sg = 0.0;
   if (c < a.C)
-    for (int r = r0 + rg; r < r1; r += kBnGroups) {
-      const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
-      const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
-      sb += g; sg += (double)g * zh;
+    for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
+      float zv[kBnU], dv[kBnU];
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) {
+        const int ru = r + u * kBnGroups;
+        zv[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f;
+        dv[u] = ru < r1 ? b.dy[(size_t)ru * a.C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) {
+        const int ru = r + u * kBnGroups;
+        if (ru < r1) {
+          const float zh = (zv[u] - mf) * rstd;
+          const float g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
+          sb += g; sg += (double)g * zh;
+        }
+      }
     }
   red[rg][cl][0] = sb; red[rg][cl][1] = sg;
   __syncthreads();
@@ -194,10 +219,23 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const BnRowsBwdArgs b)
   for (int q = 0; q < kBnGroups; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; }
   const float mb = (float)(sb / R), mg = (float)(sg / R), k = gam * rstd;
-  for (int r = r0 + rg; r < r1; r += kBnGroups) {
-    const float zh = (a.z[(size_t)r * a.C + c] - mf) * rstd;
-    const float g = fmaf(zh, gam, bet) > 0.f ? b.dy[(size_t)r * a.C + c] * dropout_scale(a, set, r - r0, c) : 0.f;
-    b.dz[(size_t)r * a.C + c] = k * (g - mb - zh * mg);
+  for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
+    float zv[kBnU], dv[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int ru = r + u * kBnGroups;
+      zv[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f;
+      dv[u] = ru < r1 ? b.dy[(size_t)ru * a.C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int ru = r + u * kBnGroups;
+      if (ru < r1) {
+        const float zh = (zv[u] - mf) * rstd;
+        const float g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
+        b.dz[(size_t)ru * a.C + c] = k * (g - mb - zh * mg);
+      }
+    }
   }
 }
 
