@@ -74,7 +74,10 @@ struct TrainWS {
 }  // namespace alignnet
 
 constexpr int kLossGroups = 64;   // workgroups sharing the B x B part of the loss
-static size_t loss_scratch_floats(int B) { return 26 * (size_t)B + 64 + (size_t)kLossGroups * 12 + (size_t)kLossGroups * 6 * B + 64; }
+static size_t loss_scratch_floats(int B)
+{
+  return 26 * (size_t)B + 64 + (size_t)kLossGroups * 12 + (size_t)kLossGroups * 6 * B + 64 + ((size_t)(3 * B + 63) / 64) * 12 + 16;
+}
 
 static TrainWS* tws(alignnet_handle* h)
 {
@@ -241,9 +244,10 @@ static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, floa
 
 static void launch_loss(alignnet_handle* h, const LossArgs& la)
 {
-  hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(1024), 0, h->stream, la, kLossGroups);
+  const int nprep = (3 * la.B + 63) / 64;   // softmax-row workgroups of loss_prep_kernel (+1 for the Huber terms)
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(nprep + 1), dim3(1024), 0, h->stream, la, kLossGroups);
   hipLaunchKernelGGL(loss_pairs_kernel, dim3(kLossGroups), dim3(256), 0, h->stream, la, kLossGroups);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, h->stream, la, kLossGroups);
+  hipLaunchKernelGGL(loss_final_kernel, dim3((la.B + kLossCols - 1) / kLossCols), dim3(256), 0, h->stream, la, kLossGroups, nprep);
 }
 
 static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }

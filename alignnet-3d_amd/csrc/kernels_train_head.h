@@ -310,6 +310,7 @@ struct LossScratch {
   double* ce;      // [3][2]         mean cross-entropy per term / variant
   double* rlp;     // [G][3][2]      partial sums of huber(pick_j - label_ij)
   float* sjp;      // [G][3][2][B]   partial sums over i of clip(pick_j - label_ij, 1)
+  double* cep;     // [ceil(3B/64)][3][2]  per-workgroup partial cross-entropy sums of loss_prep_kernel
 };
 
 __device__ __forceinline__ LossScratch loss_scratch(float* base, int B, int G)
@@ -322,6 +323,7 @@ __device__ __forceinline__ LossScratch loss_scratch(float* base, int B, int G)
   s.ce = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s.hub + 8) + 7) & ~(uintptr_t)7);
   s.rlp = s.ce + 6;
   s.sjp = reinterpret_cast<float*>(s.rlp + (size_t)G * 6);
+  s.cep = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s.sjp + (size_t)G * 6 * B) + 7) & ~(uintptr_t)7);
   return s;
 }
 
@@ -330,47 +332,57 @@ __device__ __forceinline__ const float* term_logits(const LossArgs& a, int term,
   return term == 0 ? a.o2 + (size_t)row * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(a.B + row) * a.ldo2 + 3 : a.o3 + (size_t)row * a.ldo3 + 3;
 }
 
+// grid: ceil(3B/64) workgroups for the softmax rows (16 lanes per (term, row)) + one last workgroup for the Huber terms
 __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G)
 {
   __shared__ double red[16];
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
-  // ---- Huber terms (tp8.py:312-323) ----
-  double h[5] = {0, 0, 0, 0, 0};
-  for (int e = tid; e < 3 * B; e += nt) {
-    const int b = e / 3, d = e % 3;
-    const float e1a = a.s1c[b * 3 + d] - a.c1[e], e1b = a.s1c[(B + b) * 3 + d] - a.c2[e];
-    const float e2a = a.s2c[b * 3 + d] - a.c1[e], e2b = a.s2c[(B + b) * 3 + d] - a.c2[e];
-    const float pt = a.o3[(size_t)b * a.ldo3 + d] + (a.s2c[(B + b) * 3 + d] - a.s2c[b * 3 + d]);
-    const float e3 = pt - a.tr[e];
-    h[0] += huberf(e1a, 1.f); h[1] += huberf(e1b, 1.f); h[2] += huberf(e2a, 1.f); h[3] += huberf(e2b, 1.f); h[4] += huberf(e3, 2.f);
-    if (a.want_grad) {
-      const float w = 1.0f / ((float)B * 3.0f * (float)B);   // (1/B) * mean over 3B elements
-      const float g3 = w * clipf(e3, 2.f);
-      a.d_s1c[b * 3 + d] = w * a.esf * 0.5f * clipf(e1a, 1.f);
-      a.d_s1c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e1b, 1.f);
-      a.d_s2c[b * 3 + d] = w * a.esf * 0.5f * clipf(e2a, 1.f) - g3;      // pred_translations = head + (s2c2 - s2c1)
-      a.d_s2c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e2b, 1.f) + g3;
-      a.d_o3[(size_t)b * a.ldo3 + d] = g3;
-      a.d_o2[(size_t)b * a.ldo2 + d] = 0.f;
-      a.d_o2[(size_t)(B + b) * a.ldo2 + d] = 0.f;
+  if (blockIdx.x == gridDim.x - 1) {
+    // ---- Huber terms (tp8.py:312-323) ----
+    double h[5] = {0, 0, 0, 0, 0};
+    for (int e = tid; e < 3 * B; e += nt) {
+      const int b = e / 3, d = e % 3;
+      const float e1a = a.s1c[b * 3 + d] - a.c1[e], e1b = a.s1c[(B + b) * 3 + d] - a.c2[e];
+      const float e2a = a.s2c[b * 3 + d] - a.c1[e], e2b = a.s2c[(B + b) * 3 + d] - a.c2[e];
+      const float pt = a.o3[(size_t)b * a.ldo3 + d] + (a.s2c[(B + b) * 3 + d] - a.s2c[b * 3 + d]);
+      const float e3 = pt - a.tr[e];
+      h[0] += huberf(e1a, 1.f); h[1] += huberf(e1b, 1.f); h[2] += huberf(e2a, 1.f); h[3] += huberf(e2b, 1.f); h[4] += huberf(e3, 2.f);
+      if (a.want_grad) {
+        const float w = 1.0f / ((float)B * 3.0f * (float)B);   // (1/B) * mean over 3B elements
+        const float g3 = w * clipf(e3, 2.f);
+        a.d_s1c[b * 3 + d] = w * a.esf * 0.5f * clipf(e1a, 1.f);
+        a.d_s1c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e1b, 1.f);
+        a.d_s2c[b * 3 + d] = w * a.esf * 0.5f * clipf(e2a, 1.f) - g3;      // pred_translations = head + (s2c2 - s2c1)
+        a.d_s2c[(B + b) * 3 + d] = w * a.esf * 0.5f * clipf(e2b, 1.f) + g3;
+        a.d_o3[(size_t)b * a.ldo3 + d] = g3;
+        a.d_o2[(size_t)b * a.ldo2 + d] = 0.f;
+        a.d_o2[(size_t)(B + b) * a.ldo2 + d] = 0.f;
+      }
     }
+    for (int k = 0; k < 5; ++k) {
+      const double t = block_sum(h[k], red) / (3.0 * B);
+      if (tid == 0) S.hub[k] = (float)t;
+    }
+    return;
   }
-  for (int k = 0; k < 5; ++k) {
-    const double t = block_sum(h[k], red) / (3.0 * B);
-    if (tid == 0) S.hub[k] = (float)t;
-  }
-  // ---- per-row class / residual targets and log-sum-exp for the three angle terms ----
+  // ---- per-row class / residual targets and log-sum-exp for the three angle terms: 16 lanes per (term, row) ----
   const int nvar = a.accept_inverted ? 2 : 1;
   double ce[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  for (int i = tid; i < B; i += nt) {
-    for (int term = 0; term < 3; ++term) {
-      const float* lg = term_logits(a, term, i);
-      float m = lg[0];
-      for (int k = 1; k < nb; ++k) m = fmaxf(m, lg[k]);
-      float sm = 0.f;
-      for (int k = 0; k < nb; ++k) sm += expf(lg[k] - m);
+  const int p = blockIdx.x * (nt >> 4) + (tid >> 4), sub = tid & 15;
+  if (p < 3 * B) {
+    const int term = p / B, i = p - term * B;
+    const float* lg = term_logits(a, term, i);
+    float m = -INFINITY;
+    for (int k = sub; k < nb; k += 16) m = fmaxf(m, lg[k]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sm = 0.f;
+    for (int k = sub; k < nb; k += 16) sm += expf(lg[k] - m);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    if (sub == 0) {
       const float l = m + logf(sm);
       S.lse[term * B + i] = l;
       // target angle of row i (term 2: column 0 of T, tp8.py:199 class_id[:, 0])
@@ -382,14 +394,15 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
         S.cls[(term * 2 + v) * B + i] = cc;
         S.pick[(term * 2 + v) * B + i] = lg[nb + cc];
         if (term < 2) S.lab[(term * 2 + v) * B + i] = r / pinb;
-        ce[term][v] += (double)(l - lg[cc]);
+        const double d = (double)(l - lg[cc]);
+        if (term == 0) ce[0][v] += d; else if (term == 1) ce[1][v] += d; else ce[2][v] += d;
       }
     }
   }
   for (int term = 0; term < 3; ++term)
-    for (int v = 0; v < nvar; ++v) {
-      const double t = block_sum(ce[term][v], red) / B;
-      if (tid == 0) S.ce[term * 2 + v] = t;
+    for (int v = 0; v < 2; ++v) {
+      const double t = block_sum(ce[term][v], red);
+      if (tid == 0) S.cep[(size_t)blockIdx.x * 6 + term * 2 + v] = t;
     }
 }
 
@@ -429,31 +442,41 @@ __global__ __launch_bounds__(256) void loss_pairs_kernel(const LossArgs a, int G
     }
 }
 
-__global__ __launch_bounds__(1024) void loss_final_kernel(const LossArgs a, int G)
+constexpr int kLossCols = 8;   // columns j per workgroup of loss_final_kernel
+
+// grid: ceil(B / kLossCols) workgroups of 256 threads.  Every workgroup repeats the (tiny) reduction of the partials and
+// the tf.cond choice, then writes the angle-term gradients of its own columns; workgroup 0 writes the scalars.
+__global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, int G, int nprep)
 {
   __shared__ float sres[3][2][3];   // [term][variant][tot, ce, rl]
   __shared__ int schosen[3];
-  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
+  __shared__ float ssj[3][kLossCols];
+  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x, ln = tid & 63, wave = tid >> 6;
   const LossScratch S = loss_scratch(a.scratch, B, G);
   const int nvar = a.accept_inverted ? 2 : 1;
-  if (tid < 6) {
-    const int term = tid / 2, v = tid % 2;
+  for (int q = wave; q < 6; q += nt >> 6) {   // one wave per (term, variant): partials summed across the lanes
+    const int term = q / 2, v = q % 2;
+    double rl = 0.0, ce = 0.0;
     if (v < nvar) {
-      double rl = 0.0;
-      for (int g = 0; g < G; ++g) rl += S.rlp[((size_t)g * 3 + term) * 2 + v];
-      const float r = (float)(rl / ((double)B * B)), c = (float)S.ce[term * 2 + v];
+      for (int g = ln; g < G; g += 64) rl += S.rlp[((size_t)g * 3 + term) * 2 + v];
+      for (int g = ln; g < nprep; g += 64) ce += S.cep[(size_t)g * 6 + q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { rl += __shfl_xor(rl, o); ce += __shfl_xor(ce, o); }
+    if (ln == 0 && v < nvar) {
+      const float r = (float)(rl / ((double)B * B)), c = (float)(ce / B);
       sres[term][v][0] = c + 20.0f * r; sres[term][v][1] = c; sres[term][v][2] = r;
     }
   }
   __syncthreads();
   if (tid < 3) schosen[tid] = (a.accept_inverted && !(sres[tid][0][0] > sres[tid][1][0])) ? 1 : 0;   // tf.cond picks the LARGER
   __syncthreads();
-  const float* hub = S.hub;
-  const float s1 = (hub[0] + hub[1]) * 0.5f, s2t = (hub[2] + hub[3]) * 0.5f;
-  const float A1 = sres[0][schosen[0]][0], A2 = sres[1][schosen[1]][0], A3 = sres[2][schosen[2]][0];
-  const float lt = a.esf * (s1 + s2t) + hub[4];
-  const float la = a.esf * ((A1 + A2) * 0.5f) + A3;
-  if (tid == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
+    const float* hub = S.hub;
+    const float s1 = (hub[0] + hub[1]) * 0.5f, s2t = (hub[2] + hub[3]) * 0.5f;
+    const float A1 = sres[0][schosen[0]][0], A2 = sres[1][schosen[1]][0], A3 = sres[2][schosen[2]][0];
+    const float lt = a.esf * (s1 + s2t) + hub[4];
+    const float la = a.esf * ((A1 + A2) * 0.5f) + A3;
     float* o = a.out;
     o[0] = (lt + a.af * la) / (float)B;
     o[1] = lt; o[2] = la;
@@ -461,18 +484,23 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const LossArgs a, int 
     for (int t = 0; t < 3; ++t) for (int k = 0; k < 3; ++k) o[8 + t * 3 + k] = sres[t][schosen[t]][k];
   }
   if (!a.want_grad) return;
-  // ---- gradients of the angle terms (chosen variant only: tf.cond) ----
-  for (int e = tid; e < 3 * B; e += nt) {   // S_j = sum over the G row slices, once per (term, column)
-    const int term = e / B, j = e % B;
+  // ---- gradients of the angle terms (chosen variant only: tf.cond), columns j0 .. j0 + kLossCols ----
+  const int j0 = blockIdx.x * kLossCols;
+  if (tid < 3 * kLossCols * 4) {   // S_j = sum over the G row slices; 4 lanes share one sum
+    const int e = tid >> 2, gq = tid & 3, term = e / kLossCols, j = j0 + e % kLossCols;
     float sj = 0.f;
-    for (int g = 0; g < G; ++g) sj += S.sjp[(((size_t)g * 3 + term) * 2 + schosen[term]) * B + j];
-    S.sjf[e] = sj;
+    if (j < B)
+      for (int g = gq; g < G; g += 4) sj += S.sjp[(((size_t)g * 3 + term) * 2 + schosen[term]) * B + j];
+    sj += __shfl_xor(sj, 1);
+    sj += __shfl_xor(sj, 2);
+    if (gq == 0) ssj[term][e % kLossCols] = sj;
   }
   __syncthreads();
   const float invB = 1.0f / (float)B;
-  for (long e = tid; e < (long)B * 2 * nb; e += nt) {
-    const int j = e / (2 * nb), k = e % (2 * nb);
-    const float s3 = S.sjf[2 * B + j];   // S_j of the stage-3 term, needed by the towers' residual logits
+  for (int e = tid; e < kLossCols * 2 * nb; e += nt) {
+    const int jl = e / (2 * nb), j = j0 + jl, k = e % (2 * nb);
+    if (j >= B) break;
+    const float s3 = ssj[2][jl];   // S_j of the stage-3 term, needed by the towers' residual logits
     for (int term = 0; term < 3; ++term) {
       const int v = schosen[term];
       const float w = term < 2 ? invB * a.af * a.esf * 0.5f : invB * a.af;
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const LossArgs a, int 
       const int c = S.cls[(term * 2 + v) * B + j];
       float gval;
       if (k < nb) gval = w * invB * (expf(lg[k] - S.lse[term * B + j]) - (k == c ? 1.f : 0.f));
-      else if (k - nb == c) gval = w * 20.0f * invB * invB * S.sjf[term * B + j];
+      else if (k - nb == c) gval = w * 20.0f * invB * invB * ssj[term][jl];
       else gval = 0.f;
       if (term < 2 && k >= nb) {
         // the stage-3 target depends on the towers' decoded yaw (tp8.py:325-327): gradient through the gathered residual
