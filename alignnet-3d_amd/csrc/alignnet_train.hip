@@ -68,6 +68,7 @@ struct TrainWS {
   // optimiser
   float *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   PackJob* pack_table = nullptr; int n_pack = 0;
+  PackJob* stage_pack = nullptr;   // [3 stages][6]: Q3 t0,t1 | Q2 t0,t1, V2 t0,t1 (images rebuilt inside the backward)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
 };
 
@@ -95,6 +96,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->adam_m) hipFree(w->adam_m);
   if (w->adam_v) hipFree(w->adam_v);
   if (w->pack_table) hipFree(w->pack_table);
+  if (w->stage_pack) hipFree(w->stage_pack);
   for (int s = 0; s < 3; ++s) if (w->wp3h[s]) hipFree(w->wp3h[s]);
   delete w;
   h->train_ws = nullptr;
@@ -105,6 +107,8 @@ static const Stack& fc_of(const alignnet_handle* h, int s) { return s == 0 ? h->
 static float keep_of(const alignnet_handle* h, int s) { return s == 0 ? h->cfg.s1_keep : s == 1 ? h->cfg.s2_keep : h->cfg.rem_keep; }
 static float* P(alignnet_handle* h, int pidx) { return h->d_params + h->params[pidx].offset; }
 static float* G(alignnet_handle* h, TrainWS* w, int pidx) { return w->grad + h->params[pidx].offset; }
+
+static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
 
 static int check_trainable_shape(alignnet_handle* h)
 {
@@ -215,6 +219,19 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     }
   }
   for (int t = 0; t < 2; ++t) HIP_TRY(h, hipMalloc(&w->d_pcs[t], (size_t)B * N * 3 * sizeof(float)));
+  {   // pack jobs of the backward (pointers into the carve above)
+    std::vector<PackJob> jobs;
+    for (int s = 0; s < 3; ++s) {
+      const Stack& st = conv_of(h, s);
+      const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout;
+      const size_t qimg = img_floats(C2, C2), vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
+      for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q3 + (size_t)t * C2 * C2, w->q3img + t * qimg, C2, C2});
+      for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q2 + (size_t)t * C1 * C1, w->q2img + t * q2img, C1, C1});
+      for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->V2 + (size_t)t * C1 * C2, w->v2img + t * vimg, C2, C1});
+    }
+    if (!w->stage_pack) HIP_TRY(h, hipMalloc(&w->stage_pack, jobs.size() * sizeof(PackJob)));
+    HIP_TRY(h, hipMemcpy(w->stage_pack, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  }
   w->cap = B;
   return 0;
 }
@@ -228,12 +245,6 @@ static void launch_gemm(alignnet_handle* h, const float* A, long sai, long sak, 
 {
   GemmArgs g{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, bias, alpha, acc, ba, bb, bc};
   hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(kGemmWaves * 64), 0, h->stream, g);
-}
-
-static void launch_pack(alignnet_handle* h, const float* W, int K, int C, float* img)
-{
-  const size_t total = (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, h->stream, W, K, C, img);
 }
 
 template <typename T>
@@ -250,7 +261,6 @@ static void launch_loss(alignnet_handle* h, const LossArgs& la)
   hipLaunchKernelGGL(loss_final_kernel, dim3((la.B + kLossCols - 1) / kLossCols), dim3(256), 0, h->stream, la, kLossGroups, nprep);
 }
 
-static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
 
 static int pack_all_weights(alignnet_handle* h)
 {
@@ -478,7 +488,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const size_t qimg = img_floats(C2, C2);
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
-  for (int t = 0; t < 2; ++t) launch_pack(h, w->Q3 + (size_t)t * C2 * C2, C2, C2, w->q3img + t * qimg);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
   hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
   // ---- pass B2 ----
   BwdB2Args b2;
@@ -529,10 +539,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
-  for (int t = 0; t < 2; ++t) {
-    launch_pack(h, w->Q2 + (size_t)t * C1 * C1, C1, C1, w->q2img + t * q2img);
-    launch_pack(h, w->V2 + (size_t)t * C1 * C2, C2, C1, w->v2img + t * vimg);
-  }
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
   hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
   // ---- pass B1 ----
   BwdB1Args b1;
