@@ -249,6 +249,57 @@ class Engine:
                                                          C.byref(res) if want_result else None))
         return dict(step=res.step, loss=res.loss) if want_result else None
 
+    # ---- HBM-resident dataset + device sampler (include/alignnet_hip.h; replaces provider.load_batch + jitter) ----
+    def upload_dataset(self, points1, points2, offsets, labels):
+        """points*: [sum n, 3]; offsets: [n_examples + 1, 2] int64 row offsets; labels: [n_examples, 12]
+        (alignnet3d/packed.py layout).  Copied to HBM once."""
+        p1 = np.ascontiguousarray(points1, np.float32).reshape(-1, 3)
+        p2 = np.ascontiguousarray(points2, np.float32).reshape(-1, 3)
+        off = np.ascontiguousarray(offsets, np.int64).reshape(-1, 2)
+        lab = np.ascontiguousarray(labels, np.float32).reshape(off.shape[0] - 1, 12)
+        assert off[-1, 0] == p1.shape[0] and off[-1, 1] == p2.shape[0], "offsets do not cover the point blobs"
+        self._check(self._lib.alignnet_dataset_upload(self._h, _fp(p1), _fp(p2), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                      _fp(lab), off.shape[0] - 1))
+
+    @staticmethod
+    def _rows(rows):
+        r = np.ascontiguousarray(rows, np.int32).ravel()
+        return r, r.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def sample_batch(self, rows, seed, jitter_sigma=0.0, jitter_clip=0.05):
+        """Draw the batch on the device; returns (d_pcs1, d_pcs2, {label name: device pointer})."""
+        r, rp = self._rows(rows)
+        self._check(self._lib.alignnet_dataset_sample(self._h, rp, r.size, int(seed), float(jitter_sigma), float(jitter_clip)))
+        p1, p2, L = C.c_void_p(), C.c_void_p(), _capi.Labels()
+        self._check(self._lib.alignnet_dataset_batch(self._h, C.byref(p1), C.byref(p2), C.byref(L)))
+        names = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
+        return p1.value, p2.value, {k: C.cast(getattr(L, k), C.c_void_p).value for k in names}
+
+    def train_step_rows(self, rows, seed, jitter_sigma=0.01, jitter_clip=0.05):
+        """sample (with the reference's jitter defaults, provider.py:60) + full training step, no host batch."""
+        r, rp = self._rows(rows)
+        res = _capi.StepResult()
+        self._check(self._lib.alignnet_train_step_dataset(self._h, rp, r.size, int(seed), float(jitter_sigma), float(jitter_clip),
+                                                          C.byref(res)))
+        return dict(step=res.step, loss=res.loss, learning_rate=res.learning_rate, bn_decay=res.bn_decay,
+                    summaries=dict(zip(SUMMARY_NAMES, list(res.summaries))))
+
+    def forward_rows(self, rows, seed):
+        r, rp = self._rows(rows)
+        arrs, o = self._alloc_outputs(r.size)
+        self._check(self._lib.alignnet_forward_dataset(self._h, rp, r.size, int(seed), C.byref(o)))
+        return arrs
+
+    @staticmethod
+    def read_device(ptr, count, dtype=np.float32):
+        """Debug / test helper: copy `count` elements from a device pointer (synchronous hipMemcpy)."""
+        hip = C.CDLL("libamdhip64.so")
+        out = np.empty(count, dtype)
+        rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), C.c_int(2))
+        if rc != 0:
+            raise EngineError("hipMemcpy device->host failed (%d)" % rc)
+        return out
+
     def apply_gradients(self, grad_scale=1.0):
         self._check(self._lib.alignnet_apply_gradients(self._h, float(grad_scale)))
 

@@ -63,6 +63,14 @@ class PackedDataset:
     def __len__(self):
         return len(self.row)
 
+    def rows_of(self, indices):
+        """Example ids (split/*.txt integers) -> rows of the packed tables."""
+        return np.asarray([self.row[int(e)] for e in indices], np.int32)
+
+    def upload(self, engine):
+        """Copy the whole dataset into HBM once (Engine.upload_dataset); batches are then drawn on the device."""
+        engine.upload_dataset(np.asarray(self.p[0])[:, :3], np.asarray(self.p[1])[:, :3], self.off, self.labels)
+
     def load_batch(self, indices, num_points, batch_size, num_channels=3, dont_load_pointclouds=False, on_empty=None):
         B, N = batch_size, num_points
         pcs1, pcs2 = np.empty((B, N, num_channels)), np.empty((B, N, num_channels))

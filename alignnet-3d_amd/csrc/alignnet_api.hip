@@ -188,6 +188,7 @@ static void free_ws(alignnet_handle* h)
 }
 
 extern "C" void alignnet_train_ws_free(alignnet_handle* h);
+extern "C" int alignnet_dataset_free(alignnet_handle* h);
 extern "C" void alignnet_comm_free(alignnet_handle* h);
 
 extern "C" void alignnet_destroy(alignnet_handle* h)
@@ -197,6 +198,7 @@ extern "C" void alignnet_destroy(alignnet_handle* h)
   if (h->stream) hipStreamSynchronize(h->stream);
   alignnet_comm_free(h);
   alignnet_train_ws_free(h);
+  alignnet_dataset_free(h);
   free_ws(h);
   for (auto& pr : h->prof_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (auto& pr : h->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

@@ -1,0 +1,226 @@
+// HBM-resident dataset + device-side batch sampler, gfx950 only.
+//
+// Replaces, for runs that do not need np.random bit-compatibility, the reference's per-step host work
+//   provider.load_batch (provider.py:85-136): 3 file opens + JSON / loadtxt parsing per example,
+//   np.random.choice(n, N, replace=True) resampling (provider.py:97-98),
+//   provider.jitter_point_cloud (provider.py:60-71, train.py:354-356): clip(sigma * randn, +-clip),
+// and the 6.3 MB host-to-device copy per step.  The whole packed dataset (alignnet3d/packed.py layout: two point
+// blobs, an offsets table, a 12-column label table) is uploaded once -- 288 GB of HBM holds every shipped dataset many
+// times over -- and a batch is drawn by one kernel: uniform resampling with replacement + jitter + label gather,
+// straight into the buffers the forward / training step reads.  The random stream is a counter hash of
+// (seed, example row, tower, point): reproducible, independent of the batch composition, NOT np.random's.
+#include "engine.h"
+#include <cstdio>
+
+namespace {
+
+struct DatasetWS {
+  float* pts[2] = {nullptr, nullptr};
+  long long* off = nullptr;      // [n + 1][2]
+  float* labels = nullptr;       // [n][12]
+  long long n = 0;
+  int cap = 0;                   // pairs the batch buffers hold
+  float* d_p[2] = {nullptr, nullptr};
+  float* d_lab = nullptr;        // [12][cap] laid out as the six label tensors, see lab_ptr()
+  int* d_rows = nullptr;
+  float* d_out[8] = {};
+};
+
+int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1; }
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(h, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+DatasetWS* dws(alignnet_handle* h) { return static_cast<DatasetWS*>(h->dataset_ws); }
+
+// label tensor t of the batch (placeholder order, models/tp8.py:16-22): widths 3,1,3,3,1,1; table columns
+// translation(0:3) rel_angle(3) start_position(4:7) end_position(7:10) start_angle(10) end_angle(11)
+__host__ __device__ inline int lab_width(int t) { return (t == 0 || t == 2 || t == 3) ? 3 : 1; }
+__host__ __device__ inline int lab_col(int t) { return t == 0 ? 0 : t == 1 ? 3 : t == 2 ? 4 : t == 3 ? 7 : t == 4 ? 10 : 11; }
+__host__ __device__ inline size_t lab_off(int t, int cap)
+{
+  size_t o = 0;
+  for (int i = 0; i < t; ++i) o += (size_t)lab_width(i) * cap;
+  return o;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// grid (ceil(N / 256), B, 2 towers)
+__global__ __launch_bounds__(256) void dataset_sample_kernel(const float* __restrict__ pts0, const float* __restrict__ pts1,
+                                                             const long long* __restrict__ off, const float* __restrict__ labels,
+                                                             const int* __restrict__ rows, int B, int N, int cap, uint64_t seed,
+                                                             float sigma, float clip, float* __restrict__ out0,
+                                                             float* __restrict__ out1, float* __restrict__ lab)
+{
+  const int b = blockIdx.y, t = blockIdx.z, n = blockIdx.x * 256 + threadIdx.x;
+  const long long row = rows[b];
+  if (t == 0 && blockIdx.x == 0 && threadIdx.x < 12) {   // the six label tensors of this pair
+    const int c = threadIdx.x;
+    int tt = 0;
+    while (tt < 5 && c >= lab_col(tt + 1)) ++tt;
+    lab[lab_off(tt, cap) + (size_t)b * lab_width(tt) + (c - lab_col(tt))] = labels[row * 12 + c];
+  }
+  if (n >= N) return;
+  const long long lo = off[row * 2 + t], cnt = off[(row + 1) * 2 + t] - lo;
+  float* dst = (t ? out1 : out0) + ((size_t)b * N + n) * 3;
+  if (cnt <= 0) { dst[0] = dst[1] = dst[2] = 0.f; return; }   // provider.py:97-98: empty cloud -> zeros
+  const uint64_t key = mix64(seed ^ ((uint64_t)row * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(2 * n + t) * 0xD1B54A32D192ED03ull));
+  // uniform index in [0, cnt): high 64 bits of key32 * cnt
+  const long long pick = (long long)(((key >> 32) * (uint64_t)cnt) >> 32);
+  const float* src = (t ? pts1 : pts0) + (lo + pick) * 3;
+  float v[3] = {src[0], src[1], src[2]};
+  if (sigma > 0.f) {
+    // three standard normals from two Box-Muller pairs; clip(sigma * z, +-clip)
+    uint64_t k2 = mix64(key + 0x632BE59BD9B4E019ull), k3 = mix64(key + 0xC6BC279692B5C323ull);
+    const float u0 = ((float)(k2 >> 40) + 0.5f) * (1.0f / 16777216.0f), u1 = (float)((k2 >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(k3 >> 40) + 0.5f) * (1.0f / 16777216.0f), u3 = (float)((k3 >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    const float z[3] = {r0 * cosf(6.28318530718f * u1), r0 * sinf(6.28318530718f * u1), r1 * cosf(6.28318530718f * u3)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v[d] += fminf(fmaxf(sigma * z[d], -clip), clip);
+  }
+  dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+}
+
+int ensure_batch(alignnet_handle* h, int B)
+{
+  DatasetWS* w = dws(h);
+  if (B <= w->cap) return 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int t = 0; t < 2; ++t) if (w->d_p[t]) hipFree(w->d_p[t]);
+  if (w->d_lab) hipFree(w->d_lab);
+  if (w->d_rows) hipFree(w->d_rows);
+  if (w->d_out[0]) hipFree(w->d_out[0]);
+  const int N = h->cfg.num_points, nb2 = 2 * h->cfg.num_bins;
+  for (int t = 0; t < 2; ++t) HIP_TRY(h, hipMalloc(&w->d_p[t], (size_t)B * N * 3 * sizeof(float)));
+  HIP_TRY(h, hipMalloc(&w->d_lab, (size_t)B * 12 * sizeof(float)));
+  HIP_TRY(h, hipMalloc(&w->d_rows, (size_t)B * sizeof(int)));
+  const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+  size_t tot = 0;
+  for (int i = 0; i < 8; ++i) tot += (size_t)B * widths[i];
+  float* base = nullptr;
+  HIP_TRY(h, hipMalloc(&base, tot * sizeof(float)));
+  for (int i = 0; i < 8; ++i) { w->d_out[i] = base; base += (size_t)B * widths[i]; }
+  w->cap = B;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int alignnet_dataset_free(alignnet_handle* h)
+{
+  if (!h || !h->dataset_ws) return 0;
+  DatasetWS* w = dws(h);
+  hipStreamSynchronize(h->stream);
+  for (int t = 0; t < 2; ++t) { if (w->pts[t]) hipFree(w->pts[t]); if (w->d_p[t]) hipFree(w->d_p[t]); }
+  if (w->off) hipFree(w->off);
+  if (w->labels) hipFree(w->labels);
+  if (w->d_lab) hipFree(w->d_lab);
+  if (w->d_rows) hipFree(w->d_rows);
+  if (w->d_out[0]) hipFree(w->d_out[0]);
+  delete w;
+  h->dataset_ws = nullptr;
+  return 0;
+}
+
+extern "C" int alignnet_dataset_upload(alignnet_handle* h, const float* points1, const float* points2, const int64_t* offsets,
+                                       const float* labels, int64_t n_examples)
+{
+  if (!h) return 1;
+  if (!offsets || !labels || n_examples < 1) return fail(h, "alignnet_dataset_upload: null table or no examples");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int64_t i = 0; i < n_examples; ++i)
+    for (int t = 0; t < 2; ++t)
+      if (offsets[(i + 1) * 2 + t] < offsets[i * 2 + t]) return fail(h, "alignnet_dataset_upload: offsets must be non-decreasing");
+  if (offsets[0] != 0 || offsets[1] != 0) return fail(h, "alignnet_dataset_upload: offsets must start at 0");
+  alignnet_dataset_free(h);
+  DatasetWS* w = new DatasetWS();
+  h->dataset_ws = w;
+  const float* src[2] = {points1, points2};
+  for (int t = 0; t < 2; ++t) {
+    const size_t np = (size_t)offsets[n_examples * 2 + t];
+    if (np && !src[t]) return fail(h, "alignnet_dataset_upload: null point blob");
+    HIP_TRY(h, hipMalloc(&w->pts[t], std::max<size_t>(np, 1) * 3 * sizeof(float)));
+    if (np) HIP_TRY(h, hipMemcpy(w->pts[t], src[t], np * 3 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(h, hipMalloc(&w->off, (size_t)(n_examples + 1) * 2 * sizeof(long long)));
+  HIP_TRY(h, hipMemcpy(w->off, offsets, (size_t)(n_examples + 1) * 2 * sizeof(long long), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMalloc(&w->labels, (size_t)n_examples * 12 * sizeof(float)));
+  HIP_TRY(h, hipMemcpy(w->labels, labels, (size_t)n_examples * 12 * sizeof(float), hipMemcpyHostToDevice));
+  w->n = n_examples;
+  return 0;
+}
+
+extern "C" int alignnet_dataset_sample(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, float jitter_sigma,
+                                       float jitter_clip)
+{
+  if (!h) return 1;
+  if (!h->dataset_ws) return fail(h, "alignnet_dataset_sample: no dataset uploaded");
+  if (!rows || B < 1) return fail(h, "alignnet_dataset_sample: null rows or B < 1");
+  if (jitter_sigma > 0.f && !(jitter_clip > 0.f)) return fail(h, "alignnet_dataset_sample: clip must be > 0 (provider.py:68)");
+  DatasetWS* w = dws(h);
+  for (int i = 0; i < B; ++i)
+    if (rows[i] < 0 || rows[i] >= w->n) return fail(h, "alignnet_dataset_sample: row " + std::to_string(rows[i]) + " out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (ensure_batch(h, B)) return 1;
+  HIP_TRY(h, hipMemcpyAsync(w->d_rows, rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  const int N = h->cfg.num_points;
+  hipLaunchKernelGGL(dataset_sample_kernel, dim3((N + 255) / 256, B, 2), dim3(256), 0, h->stream, w->pts[0], w->pts[1], w->off,
+                     w->labels, w->d_rows, B, N, w->cap, seed, jitter_sigma, jitter_clip, w->d_p[0], w->d_p[1], w->d_lab);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // `rows` is the caller's (pageable) memory
+  return 0;
+}
+
+extern "C" int alignnet_dataset_batch(alignnet_handle* h, const float** d_pcs1, const float** d_pcs2, alignnet_labels* d_labels)
+{
+  if (!h) return 1;
+  if (!h->dataset_ws || !dws(h)->cap) return fail(h, "alignnet_dataset_batch: no batch sampled yet");
+  DatasetWS* w = dws(h);
+  if (d_pcs1) *d_pcs1 = w->d_p[0];
+  if (d_pcs2) *d_pcs2 = w->d_p[1];
+  if (d_labels) {
+    d_labels->translations = w->d_lab + lab_off(0, w->cap); d_labels->rel_angles = w->d_lab + lab_off(1, w->cap);
+    d_labels->pc1_centers = w->d_lab + lab_off(2, w->cap); d_labels->pc2_centers = w->d_lab + lab_off(3, w->cap);
+    d_labels->pc1_angles = w->d_lab + lab_off(4, w->cap); d_labels->pc2_angles = w->d_lab + lab_off(5, w->cap);
+  }
+  return 0;
+}
+
+extern "C" int alignnet_train_step_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, float jitter_sigma,
+                                           float jitter_clip, alignnet_step_result* result)
+{
+  if (alignnet_dataset_sample(h, rows, B, seed, jitter_sigma, jitter_clip)) return 1;
+  const float *p1, *p2;
+  alignnet_labels lab;
+  if (alignnet_dataset_batch(h, &p1, &p2, &lab)) return 1;
+  return alignnet_train_step_device(h, p1, p2, &lab, B, result);
+}
+
+extern "C" int alignnet_forward_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, const alignnet_outputs* out)
+{
+  if (!h) return 1;
+  if (!out) return fail(h, "alignnet_forward_dataset: null outputs");
+  if (alignnet_dataset_sample(h, rows, B, seed, 0.f, 0.f)) return 1;
+  DatasetWS* w = dws(h);
+  alignnet_outputs d{w->d_out[0], w->d_out[1], w->d_out[2], w->d_out[3], w->d_out[4], w->d_out[5], w->d_out[6], w->d_out[7]};
+  if (alignnet_forward_device(h, w->d_p[0], w->d_p[1], B, &d)) return 1;
+  float* host[8] = {out->pred_translations, out->pred_remaining_angle_logits, out->pred_s1_pc1centers, out->pred_s1_pc2centers,
+                    out->pred_s2_pc1centers, out->pred_s2_pc2centers, out->pred_pc1angle_logits, out->pred_pc2angle_logits};
+  const int nb2 = 2 * h->cfg.num_bins;
+  const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+  for (int i = 0; i < 8; ++i)
+    if (host[i]) HIP_TRY(h, hipMemcpyAsync(host[i], w->d_out[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}

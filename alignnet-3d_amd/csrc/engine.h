@@ -74,6 +74,7 @@ struct alignnet_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
   // training / multi-GPU state (alignnet_train.hip)
   void* train_ws = nullptr;
+  void* dataset_ws = nullptr;      // HBM-resident dataset + batch buffers (alignnet_dataset.hip)
   void* comm = nullptr;
   int comm_world = 1, comm_rank = 0;
   mutable std::string err;

@@ -76,7 +76,13 @@ class Run:
         MODEL.bind_engine(self.engine)
         if self.dist is not None:
             parallel.init_comm(self.engine, self.dist)
-        if os.environ.get("ALIGNNET_PACKED_CACHE", "") not in ("", "0"):
+        self.device_data = None
+        if os.environ.get("ALIGNNET_DEVICE_DATASET", "") not in ("", "0"):
+            # whole dataset resident in HBM, batches resampled + jittered on the device (alignnet_dataset_*): same
+            # distribution as provider.load_batch + jitter_point_cloud, but the engine's own random stream, not np.random's
+            self.device_data = provider.use_packed_cache()
+            self.device_data.upload(self.engine)
+        elif os.environ.get("ALIGNNET_PACKED_CACHE", "") not in ("", "0"):
             provider.use_packed_cache()   # bit-identical batches, no per-example file opens (alignnet3d/packed.py)
         self.train_idx = provider.getDataFiles("%s/split/train.txt" % cfg.data.basepath)
         self.val_idx = provider.getDataFiles("%s/split/val.txt" % cfg.data.basepath)
@@ -124,6 +130,11 @@ class Run:
         loss_sum = 0.0
         lo, hi = parallel.shard_range(B, self.rank, self.world)
         for b in range(len(idxs) // B):
+            if self.device_data is not None:
+                rows = self.device_data.rows_of(idxs[b * B:(b + 1) * B])[lo:hi]
+                res = self.engine.train_step_rows(rows, seed=int(np.random.randint(0, 2 ** 62)))   # jitter 0.01 / 0.05 (provider.py:60)
+                loss_sum += res["loss"]
+                continue
             batch = provider.load_batch(idxs[b * B:(b + 1) * B])
             pcs1 = provider.jitter_point_cloud(batch[0])
             pcs2 = provider.jitter_point_cloud(batch[1])
@@ -160,10 +171,12 @@ class Run:
         for b in range(int(np.ceil(nval / B))):
             s, e = b * B, min((b + 1) * B, nval)
             n = e - s
-            batch = provider.load_batch(val[s:e], override_batch_size=override_batch_size)
+            batch = provider.load_batch(val[s:e], override_batch_size=override_batch_size, dont_load_pointclouds=self.device_data is not None)
             lo, hi = parallel.shard_range(n, self.rank, self.world)
             t0 = time.time()
-            if hi > lo:
+            if hi > lo and self.device_data is not None:
+                ep = self.engine.forward_rows(self.device_data.rows_of(val[s:e])[lo:hi], seed=int(np.random.randint(0, 2 ** 62)))
+            elif hi > lo:
                 ep = self.engine.forward(batch[0][lo:hi], batch[1][lo:hi])   # any batch size: no padding rows needed
             else:
                 ep = {k: np.zeros((0, 3 if "logits" not in k else 2 * cfg.model.angles.num_bins), np.float32) for k in

@@ -185,6 +185,28 @@ int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_step);
  *      number of launches, measured on the handle's own stream. */
 int alignnet_profile_enable(alignnet_handle* h, int32_t on);
 
+/* ---- HBM-resident dataset + device-side batch sampler ------------------------------
+ * Replaces provider.load_batch (provider.py:85-136: per-example file opens, np.random.choice(n, N, replace=True)
+ * resampling :97-98) and provider.jitter_point_cloud (provider.py:60-71, called at train.py:354-356) for runs that do
+ * not need np.random's stream: the packed dataset is uploaded once and a batch is drawn on the device.
+ *   points1/points2: all clouds concatenated, [offsets[n][t], 3] float32;  offsets: [n_examples + 1][2] row offsets
+ *   (int64, start at 0, non-decreasing; an empty cloud samples as zeros like provider.py:97-98);
+ *   labels: [n_examples][12] float32 = translation(3) rel_angle start_position(3) end_position(3) start_angle end_angle
+ *   (the meta/*.json fields read at provider.py:86-89).  Host pointers; copied, not retained.
+ * sample(): rows = example rows (not ids) of the batch; point n of cloud t of example r is a function of
+ *   (seed, r, t, n) only.  jitter_sigma <= 0 disables the jitter (evaluation, train.py:434); clip must be > 0 otherwise.
+ * batch(): device pointers of the last sampled batch (valid until the next sample()/upload()/destroy()).
+ * train_step_dataset = sample + alignnet_train_step_device;  forward_dataset = sample (no jitter) + forward to host. */
+int alignnet_dataset_upload(alignnet_handle* h, const float* points1, const float* points2, const int64_t* offsets,
+                            const float* labels, int64_t n_examples);
+int alignnet_dataset_free(alignnet_handle* h);
+int alignnet_dataset_sample(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, float jitter_sigma,
+                            float jitter_clip);
+int alignnet_dataset_batch(alignnet_handle* h, const float** d_pcs1, const float** d_pcs2, alignnet_labels* d_labels);
+int alignnet_train_step_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, float jitter_sigma,
+                                float jitter_clip, alignnet_step_result* result);
+int alignnet_forward_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, const alignnet_outputs* out);
+
 /* ---- run-time options with no counterpart in the reference's config surface --------
  * "train_matmul_bf16" (0/1, default 0): training only -- the 128 -> C3 feature lift of every backbone
  *   (90 % of the step's FLOPs, models/tp8.py:55-57) runs on bf16 MFMA with fp32 accumulation
