@@ -94,6 +94,10 @@ SYMBOLS = {
     "alignnet_dataset_batch": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(Labels)]),
     "alignnet_train_step_dataset": (C.c_int, [H, C.POINTER(C.c_int32), C.c_int32, C.c_uint64, C.c_float, C.c_float, C.POINTER(StepResult)]),
     "alignnet_forward_dataset": (C.c_int, [H, C.POINTER(C.c_int32), C.c_int32, C.c_uint64, C.POINTER(Outputs)]),
+    "alignnet_icp_refine": (C.c_int, [H, FP, FP, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_double), C.c_double, C.c_int32,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "alignnet_icp_refine_dataset": (C.c_int, [H, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_double), C.c_double, C.c_int32,
+                                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "alignnet_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "alignnet_get_option": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_int64)]),
     "alignnet_profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),

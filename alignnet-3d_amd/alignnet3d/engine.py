@@ -290,6 +290,35 @@ class Engine:
         self._check(self._lib.alignnet_forward_dataset(self._h, rp, r.size, int(seed), C.byref(o)))
         return arrs
 
+    # ---- ICP refinement on the full clouds (icp.py:69-78 / train.py:463-484) ------
+    @staticmethod
+    def _icp_bufs(inits, B):
+        init = np.ascontiguousarray(inits, np.float64).reshape(B, 16)
+        out = np.empty((B, 16), np.float64)
+        fit, rmse, its = np.empty(B, np.float64), np.empty(B, np.float64), np.empty(B, np.int32)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        return init, out, fit, rmse, its, dp
+
+    def icp_refine(self, sources, targets, inits, radius=0.1, its=30):
+        """sources / targets: lists of [n, 3] arrays; inits: [B, 4, 4].  Returns dict(transforms, fitness, rmse, iterations)."""
+        B = len(sources)
+        off = np.zeros((B + 1, 2), np.int64)
+        off[1:, 0] = np.cumsum([len(s) for s in sources]); off[1:, 1] = np.cumsum([len(t) for t in targets])
+        cat = lambda L: np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32).reshape(-1, 3) for x in L], 0)) if L else np.zeros((0, 3), np.float32)
+        p1, p2 = cat(sources), cat(targets)
+        init, out, fit, rmse, it, dp = self._icp_bufs(inits, B)
+        self._check(self._lib.alignnet_icp_refine(self._h, _fp(p1), _fp(p2), off.ctypes.data_as(C.POINTER(C.c_int64)), B, dp(init),
+                                                  float(radius), int(its), dp(out), dp(fit), dp(rmse), it.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(transforms=out.reshape(B, 4, 4), fitness=fit, rmse=rmse, iterations=it)
+
+    def icp_refine_rows(self, rows, inits, radius=0.1, its=30):
+        """Same on the clouds of the uploaded dataset (upload_dataset), addressed by example rows."""
+        r, rp = self._rows(rows)
+        init, out, fit, rmse, it, dp = self._icp_bufs(inits, r.size)
+        self._check(self._lib.alignnet_icp_refine_dataset(self._h, rp, r.size, dp(init), float(radius), int(its), dp(out), dp(fit), dp(rmse),
+                                                          it.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(transforms=out.reshape(r.size, 4, 4), fitness=fit, rmse=rmse, iterations=it)
+
     @staticmethod
     def read_device(ptr, count, dtype=np.float32):
         """Debug / test helper: copy `count` elements from a device pointer (synchronous hipMemcpy)."""

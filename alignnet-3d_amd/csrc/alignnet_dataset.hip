@@ -117,6 +117,14 @@ int ensure_batch(alignnet_handle* h, int B)
 
 }  // namespace
 
+bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out)
+{
+  if (!h || !h->dataset_ws) return false;
+  DatasetWS* w = dws(h);
+  out->pts[0] = w->pts[0]; out->pts[1] = w->pts[1]; out->off = w->off; out->n = w->n;
+  return true;
+}
+
 extern "C" int alignnet_dataset_free(alignnet_handle* h)
 {
   if (!h || !h->dataset_ws) return 0;

@@ -1,0 +1,224 @@
+// ICP refinement of the network's prediction on the FULL clouds, gfx950 only.
+//
+// Replaces icp.icp_p2point (reference icp.py:69-78: o3.registration_icp with
+// TransformationEstimationPointToPoint(with_constraint=True, with_scaling=False)) as called from the evaluation loop
+// (train.py:463-484: radius 0.1, `--its` iterations, init = get_mat_angle(prediction)).  Open3D (a private fork,
+// README.md:32) is not part of the reference tree; the loop and the z-constrained point-to-point estimate are
+// restated in oracle/icp_ref.py, which this kernel follows step for step (same order of evaluate / estimate / stop).
+//
+// One workgroup per pair, all arithmetic in fp64 (Open3D computes in double; nearest-neighbour decisions then agree
+// with the oracle).  The target cloud sits in LDS (structure of arrays, every lane reads the same point: broadcast),
+// the source cloud is re-read from HBM/L2 each iteration (a few thousand points).  Brute force n1 x n2 per
+// iteration: at the datasets' cloud sizes that is a few million distance evaluations per pair -- a KD-tree would be
+// slower to build than this is to run.
+#include "engine.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1; }
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(h, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+constexpr int kIcpThreads = 256, kIcpSums = 12;
+
+struct IcpArgs {
+  const float* pts[2];          // point blobs
+  const long long* off;         // [n + 1][2] row offsets into the blobs
+  const int* rows;              // [B] example rows, or null: pair b is row b
+  const double* init;           // [B][16] row-major 4x4
+  double radius; int its;
+  int lds_points;               // target points that fit in LDS
+  double* out;                  // [B][16]
+  double* fitness; double* rmse; int* iters;   // [B] each, may be null
+};
+
+__device__ __forceinline__ void block_reduce(double (&v)[kIcpSums], double* red /*[4][kIcpSums]*/, double* tot /*[kIcpSums]*/)
+{
+#pragma unroll
+  for (int k = 0; k < kIcpSums; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < kIcpSums; ++k) red[(threadIdx.x >> 6) * kIcpSums + k] = v[k];
+  __syncthreads();
+  if (threadIdx.x < kIcpSums) {
+    double s = 0.0;
+    for (int w = 0; w < kIcpThreads / 64; ++w) s += red[w * kIcpSums + threadIdx.x];   // fixed order: deterministic
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float tgt[];   // [3][lds_points]
+  __shared__ double T[12];            // rows 0..2 of the 4x4
+  __shared__ double red[4 * kIcpSums], tot[kIcpSums];
+  __shared__ int stop;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long row = a.rows ? a.rows[b] : b;
+  const long long s_lo = a.off[row * 2], n1 = a.off[(row + 1) * 2] - s_lo;
+  const long long t_lo = a.off[row * 2 + 1], n2 = a.off[(row + 1) * 2 + 1] - t_lo;
+  const float* src = a.pts[0] + s_lo * 3;
+  const float* dst = a.pts[1] + t_lo * 3;
+  if (tid < 12) T[tid] = a.init[(size_t)b * 16 + tid];
+  const int nl = (int)min((long long)a.lds_points, n2);
+  for (int j = tid; j < nl; j += kIcpThreads) { tgt[j] = dst[j * 3]; tgt[a.lds_points + j] = dst[j * 3 + 1]; tgt[2 * a.lds_points + j] = dst[j * 3 + 2]; }
+  if (tid == 0) stop = 0;
+  __syncthreads();
+  const double r2 = a.radius * a.radius;
+  double fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;
+  int k = 0;
+  if (n1 > 0 && n2 > 0)
+    for (k = 0;; ++k) {
+      // ---- evaluate(T): nearest target point of every transformed source point, sums over the inliers ----
+      double v[kIcpSums];
+#pragma unroll
+      for (int q = 0; q < kIcpSums; ++q) v[q] = 0.0;
+      for (long long i = tid; i < n1; i += kIcpThreads) {
+        const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
+        const double px = T[0] * sx + T[1] * sy + T[2] * sz + T[3];
+        const double py = T[4] * sx + T[5] * sy + T[6] * sz + T[7];
+        const double pz = T[8] * sx + T[9] * sy + T[10] * sz + T[11];
+        double best = 1e300; long long bj = 0;
+        for (int j = 0; j < nl; ++j) {
+          const double dx = px - (double)tgt[j], dy = py - (double)tgt[a.lds_points + j], dz = pz - (double)tgt[2 * a.lds_points + j];
+          const double d = dx * dx + dy * dy + dz * dz;
+          if (d < best) { best = d; bj = j; }   // strict: the first index wins ties (oracle: argmin)
+        }
+        for (long long j = nl; j < n2; ++j) {   // clouds larger than the LDS budget: the tail comes from L2
+          const double dx = px - (double)dst[j * 3], dy = py - (double)dst[j * 3 + 1], dz = pz - (double)dst[j * 3 + 2];
+          const double d = dx * dx + dy * dy + dz * dz;
+          if (d < best) { best = d; bj = j; }
+        }
+        if (best <= r2) {
+          const double qx = bj < nl ? (double)tgt[bj] : (double)dst[bj * 3];
+          const double qy = bj < nl ? (double)tgt[a.lds_points + bj] : (double)dst[bj * 3 + 1];
+          const double qz = bj < nl ? (double)tgt[2 * a.lds_points + bj] : (double)dst[bj * 3 + 2];
+          v[0] += 1.0; v[1] += px; v[2] += py; v[3] += pz; v[4] += qx; v[5] += qy; v[6] += qz;
+          v[7] += px * qx + py * qy; v[8] += px * qy - py * qx; v[9] += best;
+        }
+      }
+      block_reduce(v, red, tot);
+      const double cnt = tot[0];
+      fit = cnt / (double)n1;
+      rmse = cnt > 0.0 ? sqrt(tot[9] / cnt) : 0.0;
+      if (k > 0 && fabs(fit - fit_prev) < 1e-6 && fabs(rmse - rmse_prev) < 1e-6) break;
+      if (k == a.its) break;
+      fit_prev = fit; rmse_prev = rmse;
+      // ---- estimate: rotation about z + translation minimising sum |Rz p + t - q|^2 over the correspondences ----
+      if (tid == 0 && cnt > 0.0) {
+        const double mpx = tot[1] / cnt, mpy = tot[2] / cnt, mpz = tot[3] / cnt;
+        const double mqx = tot[4] / cnt, mqy = tot[5] / cnt, mqz = tot[6] / cnt;
+        const double sxx = tot[7] - cnt * (mpx * mqx + mpy * mqy);
+        const double sxy = tot[8] - cnt * (mpx * mqy - mpy * mqx);
+        const double th = atan2(sxy, sxx), c = cos(th), s = sin(th);
+        const double tx = mqx - (c * mpx - s * mpy), ty = mqy - (s * mpx + c * mpy), tz = mqz - mpz;
+        // T <- U T,  U = [[c,-s,0,tx],[s,c,0,ty],[0,0,1,tz]]
+        double n[12];
+        for (int col = 0; col < 4; ++col) {
+          n[col] = c * T[col] - s * T[4 + col];
+          n[4 + col] = s * T[col] + c * T[4 + col];
+          n[8 + col] = T[8 + col];
+        }
+        n[3] += tx; n[7] += ty; n[11] += tz;
+        for (int q = 0; q < 12; ++q) T[q] = n[q];
+      }
+      __syncthreads();
+    }
+  __syncthreads();
+  if (tid < 12) a.out[(size_t)b * 16 + tid] = T[tid];
+  if (tid >= 12 && tid < 16) a.out[(size_t)b * 16 + tid] = tid == 15 ? 1.0 : 0.0;
+  if (tid == 0) {
+    if (a.fitness) a.fitness[b] = fit;
+    if (a.rmse) a.rmse[b] = rmse;
+    if (a.iters) a.iters[b] = k;
+  }
+}
+
+// shared driver: tables already on the device
+int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long long* d_off, const int* d_rows, long long max_n2,
+            int B, const double* init, double radius, int its, double* out, double* fitness, double* rmse, int* iters)
+{
+  if (!init || !out) return fail(h, "icp: null init / out");
+  if (!(radius > 0.0) || its < 0) return fail(h, "icp: radius must be > 0 and its >= 0");
+  double *d_init = nullptr, *d_out = nullptr, *d_fr = nullptr; int* d_it = nullptr;
+  HIP_TRY(h, hipMalloc(&d_init, (size_t)B * 16 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&d_out, (size_t)B * 16 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&d_fr, (size_t)B * 2 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&d_it, (size_t)B * sizeof(int)));
+  HIP_TRY(h, hipMemcpyAsync(d_init, init, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  IcpArgs a;
+  a.pts[0] = d_p0; a.pts[1] = d_p1; a.off = d_off; a.rows = d_rows; a.init = d_init; a.radius = radius; a.its = its;
+  const long long budget = (150 * 1024) / 12;   // floats x 3 per point within one CU's LDS
+  a.lds_points = (int)std::max<long long>(1, std::min(budget, max_n2));
+  a.out = d_out; a.fitness = d_fr; a.rmse = d_fr + B; a.iters = d_it;
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+    attr = true;
+  }
+  hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 12, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, d_out, (size_t)B * 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (fitness) HIP_TRY(h, hipMemcpyAsync(fitness, d_fr, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (rmse) HIP_TRY(h, hipMemcpyAsync(rmse, d_fr + B, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  hipFree(d_init); hipFree(d_out); hipFree(d_fr); hipFree(d_it);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int alignnet_icp_refine(alignnet_handle* h, const float* points1, const float* points2, const int64_t* offsets, int32_t B,
+                                   const double* init, double radius, int32_t its, double* out, double* fitness, double* rmse,
+                                   int32_t* iterations)
+{
+  if (!h) return 1;
+  if (!offsets || B < 1) return fail(h, "alignnet_icp_refine: null offsets or B < 1");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  long long max_n2 = 0;
+  for (int i = 0; i < B; ++i) {
+    if (offsets[(i + 1) * 2] < offsets[i * 2] || offsets[(i + 1) * 2 + 1] < offsets[i * 2 + 1]) return fail(h, "alignnet_icp_refine: offsets must be non-decreasing");
+    max_n2 = std::max<long long>(max_n2, offsets[(i + 1) * 2 + 1] - offsets[i * 2 + 1]);
+  }
+  const size_t n0 = (size_t)offsets[B * 2], n1 = (size_t)offsets[B * 2 + 1];
+  if ((n0 && !points1) || (n1 && !points2)) return fail(h, "alignnet_icp_refine: null point blob");
+  float *d0 = nullptr, *d1 = nullptr; long long* doff = nullptr;
+  HIP_TRY(h, hipMalloc(&d0, std::max<size_t>(n0, 1) * 3 * sizeof(float)));
+  HIP_TRY(h, hipMalloc(&d1, std::max<size_t>(n1, 1) * 3 * sizeof(float)));
+  HIP_TRY(h, hipMalloc(&doff, (size_t)(B + 1) * 2 * sizeof(long long)));
+  if (n0) HIP_TRY(h, hipMemcpyAsync(d0, points1, n0 * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (n1) HIP_TRY(h, hipMemcpyAsync(d1, points2, n1 * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(doff, offsets, (size_t)(B + 1) * 2 * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  const int rc = run_icp(h, d0, d1, doff, nullptr, max_n2, B, init, radius, its, out, fitness, rmse, iterations);
+  hipFree(d0); hipFree(d1); hipFree(doff);
+  return rc;
+}
+
+extern "C" int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, const double* init, double radius,
+                                           int32_t its, double* out, double* fitness, double* rmse, int32_t* iterations)
+{
+  if (!h) return 1;
+  alignnet::DatasetTables t;
+  if (!alignnet_dataset_tables(h, &t)) return fail(h, "alignnet_icp_refine_dataset: no dataset uploaded");
+  if (!rows || B < 1) return fail(h, "alignnet_icp_refine_dataset: null rows or B < 1");
+  for (int i = 0; i < B; ++i)
+    if (rows[i] < 0 || rows[i] >= t.n) return fail(h, "alignnet_icp_refine_dataset: row " + std::to_string(rows[i]) + " out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  int* d_rows = nullptr;
+  HIP_TRY(h, hipMalloc(&d_rows, (size_t)B * sizeof(int)));
+  HIP_TRY(h, hipMemcpyAsync(d_rows, rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  // the largest target cloud is not known on the host: size the LDS stage for the budget, the kernel clamps per pair
+  const int rc = run_icp(h, t.pts[0], t.pts[1], t.off, d_rows, (150 * 1024) / 12, B, init, radius, its, out, fitness, rmse, iterations);
+  hipFree(d_rows);
+  return rc;
+}

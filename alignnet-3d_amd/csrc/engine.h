@@ -47,6 +47,12 @@ struct Workspace {
 
 }  // namespace alignnet
 
+namespace alignnet {
+struct DatasetTables { const float* pts[2]; const long long* off; long long n; };   // device pointers of the uploaded dataset
+}
+struct alignnet_handle;
+bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out);   // alignnet_dataset.hip; false when none uploaded
+
 struct alignnet_handle {
   alignnet_config cfg;
   std::vector<alignnet::Layer> layers;

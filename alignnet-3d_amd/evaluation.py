@@ -43,6 +43,20 @@ def rot_z(angle):
     return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
 
 
+def get_mat_angle(translation=None, rotation=None, rotation_center=(0.0, 0.0, 0.0)):
+    """4x4: rotate about z by `rotation` around `rotation_center`, then translate (tp_utils/pointcloud.py:279-289);
+    the initial guess handed to the ICP refinement (train.py:465-467)."""
+    c = np.asarray(rotation_center, np.float64).reshape(3)
+    m1, m2, m3 = np.eye(4), np.eye(4), np.eye(4)
+    m1[:3, 3] = -c
+    m3[:3, 3] = c
+    if translation is not None:
+        m3[:3, 3] += np.asarray(translation, np.float64).reshape(3)
+    if rotation is not None:
+        m2[:3, :3] = rot_z(float(np.ravel(rotation)[0]))
+    return m3 @ m2 @ m1
+
+
 def translate_transform_to_new_center_of_rotation(pred_translations, pred_angles, pred_centers, gt_pc1centers):
     """Same map as tp_utils/pointcloud.py:309-318: t' = -d + Rz(angle) d + t with d = new_centre - old_centre."""
     out = np.zeros_like(pred_translations)

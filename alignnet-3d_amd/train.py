@@ -84,6 +84,11 @@ class Run:
             self.device_data.upload(self.engine)
         elif os.environ.get("ALIGNNET_PACKED_CACHE", "") not in ("", "0"):
             provider.use_packed_cache()   # bit-identical batches, no per-example file opens (alignnet3d/packed.py)
+        self.icp_data = self.device_data
+        if flags.refineICP and self.icp_data is None:
+            # ICP refines on the FULL clouds (train.py:469), which live in HBM next to the network (alignnet_icp_refine_dataset)
+            self.icp_data = provider.use_packed_cache()
+            self.icp_data.upload(self.engine)
         self.train_idx = provider.getDataFiles("%s/split/train.txt" % cfg.data.basepath)
         self.val_idx = provider.getDataFiles("%s/split/val.txt" % cfg.data.basepath)
         self.batches_per_epoch = len(self.train_idx) // cfg.training.batch_size
@@ -152,8 +157,13 @@ class Run:
         val = self.val_idx
         nval = len(val)
         eval_dir = "%s/val/eval%s" % (cfg.logging.logdir, str(epoch).zfill(6))
-        if flags.refineICP:
-            raise NotImplementedError("--refineICP needs the Open3D fork of the reference (README.md:32); out of scope here")
+        base_eval_dir = eval_dir
+        refine = bool(eval_only and flags.refineICP)
+        if flags.refineICP:   # train.py:401-402 (the suffix compares the raw flag with the int 30, as the reference does)
+            eval_dir = "%s/refined_%s%s" % (eval_dir, flags.refineICPmethod, ("_" + str(flags.its)) if flags.its != 30 else "")
+        old = None
+        if flags.use_old_results:   # train.py:423-426
+            old = {k: np.load("%s/%s.npy" % (base_eval_dir, k)) for k in ("pred_translations", "pred_angles", "pred_s2_pc1centers")}
         if self.rank == 0:
             if os.path.isdir(eval_dir):
                 backup, k = "%s_backup_%d" % (eval_dir, int(time.time())), 0
@@ -194,7 +204,22 @@ class Run:
             a1 = MODEL.classLogits2angle(ep["pred_pc1angle_logits"])
             a2 = MODEL.classLogits2angle(ep["pred_pc2angle_logits"])
             ar = MODEL.classLogits2angle(ep["pred_remaining_angle_logits"])
-            store["pred_angles"][s:e, 0] = a2 - a1 + ar          # train.py:456
+            pred_angles = a2 - a1 + ar                           # train.py:456
+            if refine and self.rank == 0:
+                # train.py:463-481: ICP on the full clouds seeded by the prediction; the refined transform is about the
+                # origin, so the rotation centre becomes 0 and the angle is the z Euler angle of its rotation part
+                src = old if old is not None else None
+                pt = src["pred_translations"][s:e] if src else ep["pred_translations"]
+                pa = src["pred_angles"][s:e, 0] if src else pred_angles
+                pc = src["pred_s2_pc1centers"][s:e] if src else ep["pred_s2_pc1centers"]
+                inits = [evaluation.get_mat_angle(pt[i], pa[i], rotation_center=pc[i]) for i in range(n)]
+                t0 = time.time()
+                T = self.engine.icp_refine_rows(self.icp_data.rows_of(val[s:e]), inits, radius=0.1, its=int(flags.its))["transforms"]
+                cumulated += time.time() - t0
+                ep["pred_translations"] = T[:, :3, 3].astype(np.float32)
+                pred_angles = np.arctan2(T[:, 1, 0], T[:, 0, 0])
+                ep["pred_s2_pc1centers"] = np.zeros((n, 3), np.float32)
+            store["pred_angles"][s:e, 0] = pred_angles
             store["pred_s2_pc1angles"][s:e, 0], store["pred_s2_pc2angles"][s:e, 0] = a1, a2
             for k in names3:
                 store[k][s:e] = ep[k]

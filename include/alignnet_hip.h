@@ -207,6 +207,22 @@ int alignnet_train_step_dataset(alignnet_handle* h, const int32_t* rows, int32_t
                                 float jitter_clip, alignnet_step_result* result);
 int alignnet_forward_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, uint64_t seed, const alignnet_outputs* out);
 
+/* ---- ICP refinement of the prediction on the full clouds -------------------------------
+ * Replaces icp.icp_p2point (icp.py:69-78: o3.registration_icp, point-to-point, with_constraint=True = rotation about z
+ * only, with_scaling=False) as called by the evaluation loop (train.py:463-484: radius 0.1, --its iterations,
+ * init = get_mat_angle(pred_translation, pred_angle, pred_s2_pc1center), tp_utils/pointcloud.py:279-289).
+ * points1 = source clouds, points2 = target clouds, concatenated; offsets [B + 1][2] as in alignnet_dataset_upload;
+ * init / out: [B][16] row-major 4x4 float64 (out maps source onto target: q ~ out * p); fitness / rmse / iterations:
+ * [B] each, may be NULL (Open3D's RegistrationResult fields + the number of estimate steps taken).
+ * Stops like Open3D: after `its` estimates or when fitness and inlier rmse both change by < 1e-6.
+ * _dataset: the clouds of the uploaded dataset (alignnet_dataset_upload) addressed by example rows -- "Careful: Pass
+ * full point cloud, not subsampled one" (train.py:469). */
+int alignnet_icp_refine(alignnet_handle* h, const float* points1, const float* points2, const int64_t* offsets, int32_t B,
+                        const double* init, double radius, int32_t its, double* out, double* fitness, double* rmse,
+                        int32_t* iterations);
+int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t B, const double* init, double radius,
+                                int32_t its, double* out, double* fitness, double* rmse, int32_t* iterations);
+
 /* ---- run-time options with no counterpart in the reference's config surface --------
  * "train_matmul_bf16" (0/1, default 0): training only -- the 128 -> C3 feature lift of every backbone
  *   (90 % of the step's FLOPs, models/tp8.py:55-57) runs on bf16 MFMA with fp32 accumulation

@@ -154,3 +154,13 @@ def test_train_py_device_dataset(gpu_required, tmp_path):
     assert (ev / "pred_translations.npy").exists() and (ev / "eval.json").exists()
     assert np.isfinite(np.load(ev / "pred_translations.npy")).all()
     assert (root / "packed_cache" / "ids.npy").exists()
+    # eval_only --refineICP (train.py:401-402,463-484): refined results next to the plain ones, rotation centre reset to 0
+    env.pop("ALIGNNET_DEVICE_DATASET")
+    for extra, sub in ((["--refineICP"], "refined_p2p"), (["--refineICP", "--its", "5", "--use_old_results"], "refined_p2p_5")):
+        r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "eval_only", "--config", str(cfgp), "--eval_epoch", "1"] + extra,
+                           cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        ref = ev / sub
+        t, a, c = (np.load(ref / ("%s.npy" % k)) for k in ("pred_translations", "pred_angles", "pred_s2_pc1centers"))
+        assert np.isfinite(t).all() and np.isfinite(a).all() and not c.any() and (ref / "eval.json").exists()
+        assert t.shape == np.load(ev / "pred_translations.npy").shape
