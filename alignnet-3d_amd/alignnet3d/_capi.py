@@ -107,7 +107,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libalignnet_hip.so")
+    """In-tree library; ALIGNNET_HIP_LIB names another build of the same sources (A/B kernel comparisons on one box)."""
+    return os.environ.get("ALIGNNET_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libalignnet_hip.so")
 
 
 def load_library():

@@ -418,6 +418,12 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     a.L[i].cin = L.cin; a.L[i].cout = L.cout;
   }
   (void)pooled_floats;   // all pooled buffers are zeroed by one memset at the start of the step (forward_device)
+#ifdef ALIGNNET_KSTAMP
+  static long long* d_stamps = nullptr;
+  if (!d_stamps) { hipMalloc(&d_stamps, 4 * 64 * sizeof(long long)); }
+  hipMemsetAsync(d_stamps, 0, 4 * 64 * sizeof(long long), h->stream);
+  a.stamps = d_stamps;
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -436,6 +442,18 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   else hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a);
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
   HIP_TRY(h, hipGetLastError());
+#ifdef ALIGNNET_KSTAMP
+  if (st.first == h->emb_conv.first && getenv("ALIGNNET_KSTAMP_PRINT")) {
+    long long hs[4 * 64];
+    hipStreamSynchronize(h->stream);
+    hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost);
+    for (int q = 0; q < 4; ++q) {
+      std::fprintf(stderr, "wave %d ct %d:", (q >> 1) * 4, (q & 1) * 8 + (q >> 1) * 4);
+      for (int i = 1; i < 64 && hs[q * 64 + i]; ++i) std::fprintf(stderr, " %lld", hs[q * 64 + i] - hs[q * 64 + i - 1]);
+      std::fprintf(stderr, "  | first %lld\n", hs[q * 64] - hs[0]);
+    }
+  }
+#endif
   return 0;
 }
 

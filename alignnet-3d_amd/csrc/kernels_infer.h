@@ -136,6 +136,9 @@ struct BackboneArgs {
   int B, N, nlayers;
   int ld[2];             // leading dimensions (floats) of the two LDS activation buffers
   ConvLayerDev L[kMaxConv];
+#ifdef ALIGNNET_KSTAMP
+  long long* stamps;     // debug build: s_memtime at every k-group of the last layer, waves 0 and 4 of workgroup (0, 0)
+#endif
 };
 
 // Weight (B operand) stream: issued by hand two k-groups ahead and retired with a counted wait.
@@ -179,10 +182,18 @@ __device__ __forceinline__ void lds_rows(const float* arow, int lda, int kg, f32
 // still in flight reads garbage).
 // ASMB = true: hand-issued weight stream (only for kernels verified spill-free: a spilled / re-allocated asm-load
 // destination that is still in flight corrupts its new owner).  ASMB = false: compiler-managed loads.
+#ifdef ALIGNNET_KSTAMP
+__device__ long long* g_kstamp = nullptr;   // set per lane-0 of the traced waves; null elsewhere
+#define KSTAMP() do { if (kst) { *kst++ = (long long)__builtin_readcyclecounter(); } } while (0)
+#else
+#define KSTAMP() do {} while (0)
+#endif
+
 template <int MR, bool CLEAR = true, bool ASMB = true>
 __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp,
-                                          int KG, int lane, f32x16 (&acc)[MR])
+                                          int KG, int lane, f32x16 (&acc)[MR], long long* kst = nullptr)
 {
+  (void)kst;
   if (CLEAR) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -217,10 +228,13 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
   f32x4 a0[MR], a1[MR];
   lds_rows<MR>(arow, lda, 0, a0);
   for (int kg = 0; kg < KG; kg += 3) {
+    KSTAMP();
     b2 = wload_issue(wp + min(kg + 2, last) * 64);
     lds_rows<MR>(arow, lda, min(kg + 1, last), a1);
     wload_wait2(b0);
+    KSTAMP();
     mfma_kgroup<MR>(a0, b0, acc);
+    KSTAMP();
     b0 = wload_issue(wp + min(kg + 3, last) * 64);
     lds_rows<MR>(arow, lda, min(kg + 2, last), a0);
     wload_wait2(b1);
@@ -232,7 +246,9 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
 #pragma unroll
     for (int m = 0; m < MR; ++m) a0[m] = a1[m];
   }
+  KSTAMP();
   wload_drain();   // look-ahead loads still in flight: retire them before the registers are reused
+  KSTAMP();
 }
 
 // hidden layer: out[row][col] = relu(acc*scale+shift) for this item's MR row tiles x one channel tile
@@ -335,11 +351,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
       f32x16 acc[TP / 32];
-      mfma_rows<TP / 32>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      // scale / shift are requested BEFORE the MFMA loop (they are older than the weight stream, so its first counted
+      // wait covers them): loaded after it, their L2 round trip sat exposed in every channel tile's epilogue
       const int col = ct * 32 + (lane & 31);
       const bool live = col < L.cout;
       const float sc = live ? L.scale[tower * L.cout + col] : 0.f;
       const float sh = live ? L.shift[tower * L.cout + col] : 0.f;
+      asm volatile("" ::: "memory");
+#ifdef ALIGNNET_KSTAMP
+      long long* kst = (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4) && ct < 16)
+                           ? a.stamps + ((wave >> 2) * 2 + (ct >> 3)) * 64 : nullptr;
+      if (kst) *kst++ = (long long)__builtin_readcyclecounter();
+      mfma_rows<TP / 32>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc, kst);
+#else
+      mfma_rows<TP / 32>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+#endif
       float mx = 0.f;   // relu folded into the max: max_n relu(v_n) = max(0, max_n v_n)
 #pragma unroll
       for (int m = 0; m < TP / 32; ++m)
