@@ -274,6 +274,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
   }
 
+  constexpr int kBfSlots = 8;                 // channel tiles wave, wave + 4, ... of the lift: C3 <= 1024
+  float rs1[BF16 ? kBfSlots : 1], rs2[BF16 ? kBfSlots : 1], rbe[BF16 ? kBfSlots : 1];
+  int rbi[BF16 ? kBfSlots : 1];
+  if (BF16) {
+#pragma unroll
+    for (int q = 0; q < kBfSlots; ++q) { rs1[q] = 0.f; rs2[q] = 0.f; rbe[q] = -INFINITY; rbi[q] = 0; }
+  }
+
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
@@ -407,55 +415,46 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       // acc = sgn * (z3 - bias) (sign folded into the bf16 image).  VALU-bound epilogue, 4 ops per element: sum, sum of
       // squares, and a max over keys = the value with its low 4 mantissa bits replaced by the accumulator register
       // number (2^-19 relative, far below the bf16 operand rounding), so value and row come out of one v_max3_f32 chain.
+      // The per-(channel, lane) running sums / extreme / index stay in registers across the cloud's tiles (fp32 sums of
+      // <= N/2 values per lane: 1e-6 relative, below the operand rounding) and are written once: re-reading and
+      // re-writing those 48 KiB per cloud for every tile was the same L2-overflowing traffic as the Gram's.
       const int KG16 = K16 >> 4;
       const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)tower * CT3 * KG16 * 64;
-      for (int ct = wave; ct < ((a.dbg & 8) ? 0 : CT3); ct += kTW) {
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C3;
-        const float bias = live ? a.b3[col] : 0.f;
-        const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
-        float be = (first || !live) ? -INFINITY : my_ext[col];
-        int bi = (first || !live) ? 0 : my_idx[col];
-        const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
-        asm volatile("" ::: "memory");
-        f32x16 acc[2];
-        mfma_rows_bf16<2>(buf1h, ldh, wimg + (size_t)ct * KG16 * 64, KG16, lane, acc);
-        float s1 = 0.f, s2 = 0.f, mx[2] = {-INFINITY, -INFINITY};
-        int cnt = 2 * 16;
-        if (nvalid == kTT) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+      for (int q = 0; q < kBfSlots; ++q) {
+        const int ct = wave + q * kTW;
+        if (ct < CT3 && !(a.dbg & 8)) {
+          f32x16 acc[2];
+          mfma_rows_bf16<2>(buf1h, ldh, wimg + (size_t)ct * KG16 * 64, KG16, lane, acc);
+          float s1 = 0.f, s2 = 0.f, mx[2] = {-INFINITY, -INFINITY};
+          if (nvalid == kTT) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              const float v0 = acc[m][r], v1 = acc[m][r + 1];
-              s1 += v0; s2 = fmaf(v0, v0, s2);
-              s1 += v1; s2 = fmaf(v1, v1, s2);
-              const float k0 = __uint_as_float((__float_as_uint(v0) & ~15u) | (unsigned)r);
-              const float k1 = __uint_as_float((__float_as_uint(v1) & ~15u) | (unsigned)(r + 1));
-              asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[m]) : "v"(mx[m]), "v"(k0), "v"(k1));
-            }
-        } else {
-          cnt = 0;
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+              for (int r = 0; r < 16; r += 2) {
+                const float v0 = acc[m][r], v1 = acc[m][r + 1];
+                s1 += v0; s2 = fmaf(v0, v0, s2);
+                s1 += v1; s2 = fmaf(v1, v1, s2);
+                const float k0 = __uint_as_float((__float_as_uint(v0) & ~15u) | (unsigned)r);
+                const float k1 = __uint_as_float((__float_as_uint(v1) & ~15u) | (unsigned)(r + 1));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[m]) : "v"(mx[m]), "v"(k0), "v"(k1));
+              }
+          } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool ok = acc_row(m, r, lane) < nvalid;
-              const float v = ok ? acc[m][r] : 0.f;
-              s1 += v; s2 = fmaf(v, v, s2); cnt += ok;
-              const float k = ok ? __uint_as_float((__float_as_uint(v) & ~15u) | (unsigned)r) : -INFINITY;
-              asm("v_max_f32 %0, %1, %2" : "=v"(mx[m]) : "v"(mx[m]), "v"(k));
-            }
-        }
-        const int msel = mx[1] > mx[0];   // near-ties resolve to the lower row block
-        const float cand = msel ? mx[1] : mx[0];
-        if (cand > be) { be = cand; bi = tile * kTT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane); }
-        if (live && !(a.dbg & 4)) {
-          // sum z = sg * S1 + n b,  sum z^2 = S2 + 2 b sg S1 + n b^2   (z = sg * acc + b)
-          const double n = (double)cnt, bd = (double)bias, t1 = (double)sg * (double)s1;
-          my_stat[col * 2] = o0 + t1 + n * bd;
-          my_stat[col * 2 + 1] = o1 + (double)s2 + 2.0 * bd * t1 + n * bd * bd;
-          my_ext[col] = be; my_idx[col] = bi;
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const bool ok = acc_row(m, r, lane) < nvalid;
+                const float v = ok ? acc[m][r] : 0.f;
+                s1 += v; s2 = fmaf(v, v, s2);
+                const float k = ok ? __uint_as_float((__float_as_uint(v) & ~15u) | (unsigned)r) : -INFINITY;
+                asm("v_max_f32 %0, %1, %2" : "=v"(mx[m]) : "v"(mx[m]), "v"(k));
+              }
+          }
+          const int msel = mx[1] > mx[0];   // near-ties resolve to the lower row block
+          const float cand = msel ? mx[1] : mx[0];
+          rs1[q] += s1; rs2[q] += s2;
+          if (cand > rbe[q]) { rbe[q] = cand; rbi[q] = tile * kTT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane); }
         }
       }
       continue;
@@ -495,6 +494,19 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     }
   }
   if (PHASE == 3 && BF16) {
+    // sum z = sg * S1 + n b,  sum z^2 = S2 + 2 b sg S1 + n b^2   (z = sg * acc + b; n = the lane's rows = N / 2)
+    int nrows = 0;
+    for (int r = (lane >> 5) * 4; r < a.N; r += 8) nrows += min(4, a.N - r);   // rows (r & 3) + 8 j + 4 half of every 64-row tile
+#pragma unroll
+    for (int q = 0; q < kBfSlots; ++q) {
+      const int col = (wave + q * kTW) * 32 + (lane & 31);
+      if (col < a.C3 && !(a.dbg & 4)) {
+        const double n = (double)nrows, bd = (double)a.b3[col], t1 = (double)a.sgn3[tower * a.C3 + col] * (double)rs1[q];
+        my_stat[col * 2] = t1 + n * bd;
+        my_stat[col * 2 + 1] = (double)rs2[q] + 2.0 * bd * t1 + n * bd * bd;
+        my_ext[col] = rbe[q]; my_idx[col] = rbi[q];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < kGramSlots; ++q) {
       const int item = wave + q * kTW;
