@@ -61,7 +61,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
   extern __shared__ __attribute__((aligned(16))) float tgt[];   // [3][lds_points]
   __shared__ double T[12];            // rows 0..2 of the 4x4
   __shared__ double red[4 * kIcpSums], tot[kIcpSums];
-  __shared__ int stop;
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long row = a.rows ? a.rows[b] : b;
   const long long s_lo = a.off[row * 2], n1 = a.off[(row + 1) * 2] - s_lo;
@@ -71,7 +70,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
   if (tid < 12) T[tid] = a.init[(size_t)b * 16 + tid];
   const int nl = (int)min((long long)a.lds_points, n2);
   for (int j = tid; j < nl; j += kIcpThreads) { tgt[j] = dst[j * 3]; tgt[a.lds_points + j] = dst[j * 3 + 1]; tgt[2 * a.lds_points + j] = dst[j * 3 + 2]; }
-  if (tid == 0) stop = 0;
   __syncthreads();
   const double r2 = a.radius * a.radius;
   double fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;

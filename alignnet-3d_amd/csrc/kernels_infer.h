@@ -37,7 +37,7 @@ constexpr float kBnEps = 1e-3f;   // utils/tf_util.py:491
 //   Wp[((ct * KG + kg) * 64 + lane) * 4 + s] = W[8*kg + 4*(lane>>5) + s][32*ct + (lane&31)]
 // Out-of-range k / channel entries are zero.
 // ---------------------------------------------------------------------------------
-static __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, float* __restrict__ Wp)
+[[maybe_unused]] static __global__ void pack_weights_kernel(const float* __restrict__ W, int K, int C, float* __restrict__ Wp)
 {
   const int KG = (K + 7) >> 3, CT = (C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 256;
@@ -52,7 +52,7 @@ static __global__ void pack_weights_kernel(const float* __restrict__ W, int K, i
 
 // all MFMA layers in one launch (training re-packs every step): grid (blocks, jobs)
 struct PackJob { const float* src; float* dst; int K, C; };
-static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ jobs)
+[[maybe_unused]] static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ jobs)
 {
   const PackJob j = jobs[blockIdx.y];
   const int KG = (j.K + 7) >> 3, CT = (j.C + 31) >> 5;
@@ -67,7 +67,7 @@ static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ job
 }
 
 // scale/shift for one layer and one BN set; bn == nullptr -> plain bias.
-static __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
+[[maybe_unused]] static __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ var, int C, float* __restrict__ scale,
                                float* __restrict__ shift)
@@ -390,7 +390,7 @@ struct FcArgs {
   int M, K, Nout, relu, rows_per_set;
 };
 
-static __global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
+[[maybe_unused]] static __global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
 {
   __shared__ float red[3][16][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -192,7 +192,7 @@ int alignnet_profile_enable(alignnet_handle* h, int32_t on);
  *   points1/points2: all clouds concatenated, [offsets[n][t], 3] float32;  offsets: [n_examples + 1][2] row offsets
  *   (int64, start at 0, non-decreasing; an empty cloud samples as zeros like provider.py:97-98);
  *   labels: [n_examples][12] float32 = translation(3) rel_angle start_position(3) end_position(3) start_angle end_angle
- *   (the meta/*.json fields read at provider.py:86-89).  Host pointers; copied, not retained.
+ *   (the meta/<id>.json fields read at provider.py:86-89).  Host pointers; copied, not retained.
  * sample(): rows = example rows (not ids) of the batch; point n of cloud t of example r is a function of
  *   (seed, r, t, n) only.  jitter_sigma <= 0 disables the jitter (evaluation, train.py:434); clip must be > 0 otherwise.
  * batch(): device pointers of the last sampled batch (valid until the next sample()/upload()/destroy()).
