@@ -74,6 +74,11 @@ class Run:
         import alignnet3d
         self.engine = alignnet3d.Engine(cfg, device=self.local_rank if self.world > 1 else None)
         MODEL.bind_engine(self.engine)
+        # optional, not a reference key: "training": {"matmul_dtype": "bf16"} (or ALIGNNET_TRAIN_BF16=1) runs the widest conv of
+        # every backbone on bf16 MFMA during training (engine option train_matmul_bf16; evaluation stays fp32)
+        if str(getattr(cfg.training, "matmul_dtype", "f32")).lower() == "bf16" or os.environ.get("ALIGNNET_TRAIN_BF16", "") not in ("", "0"):
+            self.engine.set_option("train_matmul_bf16", 1)
+            logger.info("training with bf16 operands in the 128->C3 lifts")
         if self.dist is not None:
             parallel.init_comm(self.engine, self.dist)
         self.device_data = None

@@ -133,7 +133,7 @@ def test_rows_entry_points_match_host_path(gpu_required):
 
 
 def test_train_py_device_dataset(gpu_required, tmp_path):
-    """train.py with ALIGNNET_DEVICE_DATASET=1: same files written, finite losses, no per-step host batches."""
+    """train.py with ALIGNNET_DEVICE_DATASET=1 (+ the bf16 lift option): same files written, finite losses, no per-step host batches."""
     root = tmp_path / "SynthTiny"
     _make_dataset(str(root))
     user = {"data": {"basepath": str(root)}, "logging": {"basedir": str(tmp_path / "logs")},
@@ -143,13 +143,14 @@ def test_train_py_device_dataset(gpu_required, tmp_path):
             "training": {"batch_size": 8, "num_epochs": 2, "learning_rate": 0.002}}
     cfgp = tmp_path / "DevRun.json"
     json.dump(user, open(cfgp, "w"))
-    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, ALIGNNET_DEVICE_DATASET="1")
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, ALIGNNET_DEVICE_DATASET="1", ALIGNNET_TRAIN_BF16="1")
     r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "train", "--config", str(cfgp)], cwd=str(tmp_path), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = r.stdout + r.stderr
     logdir = tmp_path / "logs" / "DevRun"
     assert "train mean loss" in out and "Finished Training" in out and "nan" not in out.lower()
+    assert "bf16 operands" in out
     ev = logdir / "val" / "eval000001"
     assert (ev / "pred_translations.npy").exists() and (ev / "eval.json").exists()
     assert np.isfinite(np.load(ev / "pred_translations.npy")).all()
