@@ -103,3 +103,35 @@ def test_training_reduces_loss_at_full_size(gpu_required):
     assert np.all(np.isfinite(losses)) and min(losses[-5:]) < 0.85 * losses[0]
     assert eng.state()["step"] == 25
     eng.close()
+
+
+def test_bf16_training_learns_like_fp32(gpu_required):
+    """BASELINE.json configs[2]: with the 128 -> C3 lifts on bf16 MFMA the network must still learn.  120 Adam steps on fresh
+    synthetic batches (64 pairs x 512 points, SynthCars widths) from the same initialisation and the same batch sequence:
+    both runs must cut the training loss by >= 30 % (mean of the first vs the last 10 steps), end within 15 % of each other,
+    and give finite eval-mode predictions whose held-out translation error is within 25 % of each other (the two
+    trajectories diverge step by step, so only the trend is comparable)."""
+    Bs, Ns, steps = 64, 512, 120
+    cfg = alignnet3d.default_model_config()
+    cfg["model"]["num_points"] = Ns
+    cfg["training"]["batch_size"] = Bs
+    cfg["data"]["ntrain"] = 50 * Bs
+    held = R.synth_pairs(Bs, Ns, seed=999, dtype=np.float32)
+    final = {}
+    for mode in (0, 1):
+        eng = alignnet3d.Engine(cfg, seed=3)
+        eng.set_option("train_matmul_bf16", mode)
+        losses = []
+        for k in range(steps):
+            d = R.synth_pairs(Bs, Ns, seed=1000 + k, dtype=np.float32)
+            losses.append(eng.train_step(d["pcs1"], d["pcs2"], d)["loss"])
+        pred = eng.forward(held["pcs1"], held["pcs2"])["pred_translations"]
+        err = float(np.linalg.norm(pred - held["translations"], axis=1).mean())
+        final[mode] = (float(np.mean(losses[:10])), float(np.mean(losses[-10:])), err)
+        eng.close()
+        assert np.all(np.isfinite(losses)) and np.isfinite(pred).all()
+    print("mean loss first / last 10 steps, held-out translation error: fp32", final[0], "bf16", final[1])
+    for mode in (0, 1):
+        assert final[mode][1] < 0.7 * final[mode][0], final
+    assert abs(final[1][1] - final[0][1]) < 0.15 * final[0][1], final
+    assert final[1][2] < 1.25 * final[0][2] + 0.02, final
