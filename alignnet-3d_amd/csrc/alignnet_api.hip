@@ -4,6 +4,7 @@
 #include "engine.h"
 #include "kernels_infer.h"
 #include "kernels_dgcnn.h"
+#include "kernels_infer_split.h"
 
 #include <algorithm>
 #include <cmath>
@@ -206,6 +207,7 @@ extern "C" void alignnet_destroy(alignnet_handle* h)
   if (h->ev[1]) hipEventDestroy(h->ev[1]);
   if (h->d_params) hipFree(h->d_params);
   if (h->d_wp) hipFree(h->d_wp);
+  if (h->d_wps) hipFree(h->d_wps);
   if (h->d_scale) hipFree(h->d_scale);
   if (h->d_shift) hipFree(h->d_shift);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -314,6 +316,26 @@ static int fold_for_eval(alignnet_handle* h)
       const size_t total = (size_t)((L.cout + 31) / 32) * ((L.cin + 7) / 8) * 256;
       hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
                          h->stream, h->d_params + h->params[L.p_w].offset, L.cin, L.cout, h->d_wp + L.off_wp);
+    }
+  }
+  if (h->infer_split) {
+    if (!h->d_wps) {
+      size_t n = 0;
+      h->off_wps.assign(h->layers.size(), 0);
+      for (size_t i = 0; i < h->layers.size(); ++i) {
+        const Layer& L = h->layers[i];
+        if (!L.conv || L.first_conv) continue;
+        h->off_wps[i] = n;
+        n += (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 1024;
+      }
+      HIP_TRY(h, hipMalloc(&h->d_wps, std::max<size_t>(n, 1) * sizeof(unsigned short)));
+    }
+    for (size_t i = 0; i < h->layers.size(); ++i) {
+      const Layer& L = h->layers[i];
+      if (!L.conv || L.first_conv) continue;
+      const size_t total = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;
+      hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                         h->d_params + h->params[L.p_w].offset, L.cin, L.cout, h->d_wps + h->off_wps[i]);
     }
   }
   HIP_TRY(h, hipGetLastError());
@@ -438,7 +460,20 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
     hipEventRecord(evp.first, h->stream);
   }
-  if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
+  const int sc1 = h->layers[st.first].cout, sc2 = st.n == 3 ? h->layers[st.first + 1].cout : 0;
+  if (h->infer_split && st.n == 3 && sc1 <= 16 * kSplitKB1 && sc2 <= 16 * kSplitKB2) {
+    // split-bf16 backbone (opt-in): same tiling, three bf16 MFMAs per fp32 product
+    SplitArgs sa;
+    sa.pcs[0] = p1; sa.pcs[1] = p2; sa.xform = a.xform; sa.pooled = pooled; sa.tower_stride = tower_stride; sa.row_stride = row_stride;
+    sa.B = B; sa.N = a.N; sa.C1 = sc1; sa.C2 = sc2; sa.C3 = h->layers[st.first + 2].cout;
+    sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
+    sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
+    const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
+    const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
+    static bool sattr = false;
+    if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+    hipLaunchKernelGGL(pointnet_split, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+  } else if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
   else hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a);
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
   HIP_TRY(h, hipGetLastError());
@@ -630,6 +665,11 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   if (!h || !key) return 1;
   const std::string k(key);
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
+  if (k == "infer_matmul_bf16x3") {
+    if (h->infer_split != (value != 0)) h->folded = false;   // the split weight images are packed by the next eval forward
+    h->infer_split = value != 0;
+    return 0;
+  }
   return fail(h, "alignnet_set_option: unknown key '" + k + "'");
 }
 
@@ -638,6 +678,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (!h || !key || !value) return 1;
   const std::string k(key);
   if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
+  if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
   return fail(h, "alignnet_get_option: unknown key '" + k + "'");
 }
 

@@ -65,6 +65,9 @@ struct alignnet_handle {
   float* d_scale = nullptr;
   float* d_shift = nullptr;
   size_t n_wp = 0, n_ss = 0;
+  bool infer_split = false;        // alignnet_set_option("infer_matmul_bf16x3"): split-bf16 backbone (kernels_infer_split.h)
+  unsigned short* d_wps = nullptr; // split (hi, lo) bf16 weight images of the MFMA conv layers, built on demand
+  std::vector<size_t> off_wps;     // per layer, in elements
   bool train_bf16 = false;         // alignnet_set_option("train_matmul_bf16"): bf16 operands for the dominant training GEMMs
   bool folded = false;             // eval-mode scale/shift + packed weights are current
   alignnet::Workspace ws;

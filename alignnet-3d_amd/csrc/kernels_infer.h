@@ -118,6 +118,14 @@ static __global__ __launch_bounds__(256) void centroid_kernel(const float* __res
   if (threadIdx.x < 9) xform[cloud * 12 + 3 + threadIdx.x] = (threadIdx.x % 4 == 0) ? 1.f : 0.f;
 }
 
+// bf16 operands (training option train_matmul_bf16, inference option infer_matmul_bf16x3)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short to_bf16_bits(float x)   // round-to-nearest-even (v_cvt_pk_bf16_f32 semantics)
+{
+  const __bf16 v = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, v);
+}
+
 // ---------------------------------------------------------------------------------
 // pointnet_fused
 // ---------------------------------------------------------------------------------

@@ -114,12 +114,6 @@ __device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 +
 
 // ---- bf16 operands (BASELINE.json configs[2]: "training ... bf16 with grad step"): the 128 -> C3 lift, 90 % of the
 // training FLOPs, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything else stays fp32 -------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned short to_bf16_bits(float x)   // round-to-nearest-even (v_cvt_pk_bf16_f32 semantics)
-{
-  const __bf16 v = (__bf16)x;
-  return __builtin_bit_cast(unsigned short, v);
-}
 
 // bf16 weight image: Wh[t][ct][kg][lane][8] = sign(gamma_t[c]) * W[16 kg + 8 (lane>>5) + s][c],  c = 32 ct + (lane&31)
 // (one 16-byte fragment per lane per MFMA).  The sign of the following BatchNorm's gamma is folded into the column

@@ -10,10 +10,13 @@ from tests.helpers import small_cfg, oracle_params, compare_forward
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, B, seed=1234):
+def _run(cfg, B, seed=1234, split=False):
     spec, P32 = oracle_params(cfg)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
+    if split:
+        eng.set_option("infer_matmul_bf16x3", 1)
+        assert eng.get_option("infer_matmul_bf16x3") == 1
     d = R.synth_pairs(B, spec.num_points, seed=seed, dtype=np.float32)
     ep = eng.forward(d["pcs1"], d["pcs2"])
     P64 = {k: v.astype(np.float64) for k, v in P32.items()}
@@ -37,6 +40,27 @@ def test_forward_synthcars_widths_n1024(gpu_required):
     worst, unstable = compare_forward(ep, ref, spec.num_bins)
     print("worst abs err", worst, "unstable pairs", unstable)
     assert unstable <= 2
+
+
+@pytest.mark.parametrize("N,B", [(128, 5), (100, 3), (256, 33), (37, 1)])
+def test_forward_split_bf16_small_widths(gpu_required, N, B):
+    """Opt-in split-bf16 backbone ("infer_matmul_bf16x3": x = hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate):
+    held to the SAME bar as the exact-fp32 path (1e-4, compare_forward)."""
+    cfg = small_cfg(N=N)
+    ep, ref, spec = _run(cfg, B, split=True)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    print("split-bf16 worst abs err", worst, "unstable pairs", unstable)
+    assert unstable <= max(1, B // 4)
+
+
+def test_forward_split_bf16_synthcars_widths_n1024(gpu_required):
+    cfg = alignnet3d.default_model_config()
+    ep, ref, spec = _run(cfg, 8, split=True)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    ep32, _, _ = _run(cfg, 8)
+    print("split-bf16 worst abs err", worst, "vs exact-fp32 path", {k: float(np.abs(ep32[k] - ref[k]).max()) for k in ref})
+    assert unstable <= 2
+    assert any(not np.array_equal(ep[k], ep32[k]) for k in ep), "option had no effect"
 
 
 def test_forward_default_json_widths(gpu_required):
