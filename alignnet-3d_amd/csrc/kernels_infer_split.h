@@ -88,6 +88,24 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   unsigned short* s16 = reinterpret_cast<unsigned short*>(smem + kSplitTP * 4);
   const int o1h = 0, o1l = kSplitTP * ld1, o2h = 2 * kSplitTP * ld1, o2l = o2h + kSplitTP * ld2;   // element offsets
 
+  // ---- weight fragments first: the hidden layer's (this wave's item) and the first channel tile's of the last layer are
+  //      requested before anything else, so their L2 round trips overlap the xyz load and the VALU lift ----
+  const int CT2 = (a.C2 + 31) >> 5, CT3 = (a.C3 + 31) >> 5;
+  const bf16x8* img2 = reinterpret_cast<const bf16x8*>(a.w2s);
+  const bf16x8* img3 = reinterpret_cast<const bf16x8*>(a.w3s);
+  bf16x8 w2h[kSplitKB1], w2l[kSplitKB1];
+  if (wave < CT2 * 2) {
+#pragma unroll
+    for (int kb = 0; kb < kSplitKB1; ++kb)
+      if (kb < KB1) { w2h[kb] = img2[(((size_t)(wave >> 1) * KB1 + kb) * 2) * 64 + lane]; w2l[kb] = img2[(((size_t)(wave >> 1) * KB1 + kb) * 2 + 1) * 64 + lane]; }
+  }
+  bf16x8 bh[kSplitKB2], bl[kSplitKB2];
+  if (wave < CT3) {
+#pragma unroll
+    for (int kb = 0; kb < kSplitKB2; ++kb)
+      if (kb < KB2) { bh[kb] = img3[(((size_t)wave * KB2 + kb) * 2) * 64 + lane]; bl[kb] = img3[(((size_t)wave * KB2 + kb) * 2 + 1) * 64 + lane]; }
+  }
+
   // ---- prologue: p' = (p - c) @ R ----
   if (tid < kSplitTP) {
     const int n = min(tile * kSplitTP + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
@@ -123,14 +141,13 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
 
   // ---- layer 2: item = (channel tile, 64-row half), one per wave at C2 = 128 ----
   {
-    const int CT2 = (a.C2 + 31) >> 5;
-    const bf16x8* img = reinterpret_cast<const bf16x8*>(a.w2s);
     for (int item = wave; item < CT2 * 2; item += kWaves) {
       const int ct = item >> 1, rg = item & 1;
-      bf16x8 bh[kSplitKB1], bl[kSplitKB1];
+      if (item != wave) {   // wider hidden layers: later items load theirs here (the first item's were requested up front)
 #pragma unroll
-      for (int kb = 0; kb < kSplitKB1; ++kb)
-        if (kb < KB1) { bh[kb] = img[(((size_t)ct * KB1 + kb) * 2) * 64 + lane]; bl[kb] = img[(((size_t)ct * KB1 + kb) * 2 + 1) * 64 + lane]; }
+        for (int kb = 0; kb < kSplitKB1; ++kb)
+          if (kb < KB1) { w2h[kb] = img2[(((size_t)ct * KB1 + kb) * 2) * 64 + lane]; w2l[kb] = img2[(((size_t)ct * KB1 + kb) * 2 + 1) * 64 + lane]; }
+      }
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -146,7 +163,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
             ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o1h + arow + m * 32 * ld1 + kb * 16);
             al[m] = *reinterpret_cast<const bf16x8*>(s16 + o1l + arow + m * 32 * ld1 + kb * 16);
           }
-          split_mfma<2>(ah, al, bh[kb], bl[kb], acc);
+          split_mfma<2>(ah, al, w2h[kb], w2l[kb], acc);
         }
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C2;
@@ -171,15 +188,8 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   //      full tile ahead ----
   {
     constexpr int MR = kSplitTP / 32;
-    const int CT3 = (a.C3 + 31) >> 5;
-    const bf16x8* img = reinterpret_cast<const bf16x8*>(a.w3s);
+    const bf16x8* img = img3;
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
-    bf16x8 bh[kSplitKB2], bl[kSplitKB2];
-    if (wave < CT3) {
-#pragma unroll
-      for (int kb = 0; kb < kSplitKB2; ++kb)
-        if (kb < KB2) { bh[kb] = img[(((size_t)wave * KB2 + kb) * 2) * 64 + lane]; bl[kb] = img[(((size_t)wave * KB2 + kb) * 2 + 1) * 64 + lane]; }
-    }
     const int arow = (lane & 31) * ld2 + half * 8;
     for (int ct = wave; ct < CT3; ct += kWaves) {
       const int col = ct * 32 + (lane & 31);
