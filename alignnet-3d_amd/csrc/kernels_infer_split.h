@@ -216,11 +216,17 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
             bl[kb] = img[(((size_t)nct * KB2 + kb) * 2 + 1) * 64 + lane];
           }
         }
-      float mx = 0.f;   // relu folded into the max: max_n relu(v_n) = max(0, max_n v_n)
+      // max_n relu(sc z_n + sh) = max(0, sc * (max_n z_n or min_n z_n) + sh): one v_max3 + one v_min3 per two accumulators,
+      // scale / shift / relu once per channel tile (fmaf is monotone in z, so the result is bit-identical)
+      float hi = -INFINITY, lo = INFINITY;
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
+        for (int r = 0; r < 16; r += 2) {
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(acc[m][r]), "v"(acc[m][r + 1]));
+          asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(acc[m][r]), "v"(acc[m][r + 1]));
+        }
+      float mx = fmaxf(fmaxf(fmaf(hi, sc, sh), fmaf(lo, sc, sh)), 0.f);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));   // >= 0: monotone bit pattern
     }
