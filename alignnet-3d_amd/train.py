@@ -76,6 +76,9 @@ class Run:
         MODEL.bind_engine(self.engine)
         # optional, not a reference key: "training": {"matmul_dtype": "bf16"} (or ALIGNNET_TRAIN_BF16=1) runs the widest conv of
         # every backbone on bf16 MFMA during training (engine option train_matmul_bf16; evaluation stays fp32)
+        if os.environ.get("ALIGNNET_INFER_BF16X3", "") not in ("", "0"):
+            self.engine.set_option("infer_matmul_bf16x3", 1)   # eval-mode backbone on split-bf16 products (1e-4 parity bar kept)
+            logger.info("evaluation with the split-bf16 backbone")
         if str(getattr(cfg.training, "matmul_dtype", "f32")).lower() == "bf16" or os.environ.get("ALIGNNET_TRAIN_BF16", "") not in ("", "0"):
             self.engine.set_option("train_matmul_bf16", 1)
             logger.info("training with bf16 operands in the 128->C3 lifts")

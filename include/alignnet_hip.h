@@ -227,7 +227,13 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "train_matmul_bf16" (0/1, default 0): training only -- the 128 -> C3 feature lift of every backbone
  *   (90 % of the step's FLOPs, models/tp8.py:55-57) runs on bf16 MFMA with fp32 accumulation
  *   (BASELINE.json configs[2]); statistics, pooling, all other layers, gradients' accumulation,
- *   optimiser state and the eval-mode forward stay fp32.  Unknown keys fail. */
+ *   optimiser state and the eval-mode forward stay fp32.
+ * "infer_matmul_bf16x3" (0/1, default 0): eval-mode forward of 3-layer PointNet backbones (every shipped config) -- every
+ *   fp32 operand of the two MFMA layers is written x = bf16(x) + bf16(x - bf16(x)) and each product is formed as
+ *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
+ *   gfx950).  Outputs stay within the 1e-4 parity bar (measured 3e-6 against the fp64 oracle, like the exact path).
+ *   Other backbone shapes and the DGCNN branch keep the exact-fp32 kernels.
+ * Unknown keys fail. */
 int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value);
 int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value);
 int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches,
