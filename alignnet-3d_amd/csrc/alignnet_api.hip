@@ -453,7 +453,14 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     attr_set = true;
   }
   const int TP = infer_tile_pts();
-  const dim3 grid((a.N + TP - 1) / TP, 2 * B);
+  // tiles per workgroup: as many as still leave every CU several workgroups (the pooled max is published once per workgroup)
+  const int ntiles = (a.N + TP - 1) / TP;
+  int per = ntiles;
+  while (per > 1 && (long)2 * B * ((ntiles + per - 1) / per) < 512) per = (per + 1) / 2;   // >= two workgroups per CU
+  static const int per_env = getenv("ALIGNNET_TILES_PER_WG") ? atoi(getenv("ALIGNNET_TILES_PER_WG")) : 0;
+  if (per_env > 0) per = std::min(ntiles, per_env);
+  a.tiles_per_wg = per;
+  const dim3 grid((ntiles + per - 1) / per, 2 * B);
   std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
   if (h->prof) {
     if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
