@@ -310,19 +310,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
   float pool[kPoolRegs] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles_all = (a.N + TP - 1) / TP;
   const int tile_lo = blockIdx.x * a.tiles_per_wg, tile_hi = min(ntiles_all, tile_lo + a.tiles_per_wg);
+  // xyz of the tile to come (threads 0 .. TP-1): requested one tile ahead, so its HBM round trip overlaps the previous
+  // tile's last layer instead of sitting in front of the first barrier
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  auto request_xyz = [&](int t) {
+    if (tid < TP) {
+      const int n = min(t * TP + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
+      const float* p = a.pcs[tower] + ((size_t)b * a.N + n) * 3;
+      nx = p[0]; ny = p[1]; nz = p[2];
+    }
+  };
+  request_xyz(tile_lo);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
   if (tile != tile_lo) __syncthreads();   // the previous tile's readers are done with the LDS buffers
 
   // ---- prologue: p' = (p - c) @ R   (models/tp8.py:106,113,122,127) ----
   if (tid < TP) {
-    const int n = min(tile * TP + tid, a.N - 1);   // tail rows repeat the last point: max unaffected
-    const float* p = a.pcs[tower] + ((size_t)b * a.N + n) * 3;
     const float* xf = a.xform + (size_t)cloud * 12;
-    const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+    const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
     xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
     xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
     xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
   }
+  if (tile + 1 < tile_hi) request_xyz(tile + 1);
   __syncthreads();
 
   // ---- layer 0: K = 3 lift on the VALU (not a dense GEMM) ----
