@@ -5,6 +5,7 @@
 #include "kernels_infer.h"
 #include "kernels_dgcnn.h"
 #include "kernels_infer_split.h"
+#include "kernels_dgcnn_split.h"
 
 #include <algorithm>
 #include <cmath>
@@ -532,7 +533,24 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
     else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
     hipEventRecord(evp.first, h->stream);
   }
-  hipLaunchKernelGGL(dgcnn_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+  {
+    const int dca = h->layers[st.first].cout, dcb = st.n == 3 ? h->layers[st.first + 1].cout : 0;
+    if (h->infer_split && st.n == 3 && dca <= 16 * kSplitKB1 && dcb <= 128) {
+      // split-bf16 variant (opt-in): three bf16 MFMAs per fp32 product
+      DgcnnSplitArgs sa;
+      sa.pcs[0] = p1; sa.pcs[1] = p2; sa.xform = a.xform; sa.nn = a.nn; sa.pooled = pooled; sa.tower_stride = tower_stride; sa.row_stride = row_stride;
+      sa.B = B; sa.N = a.N; sa.k = a.k; sa.Ca = dca; sa.Cb = dcb; sa.C3 = h->layers[st.first + 2].cout;
+      sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
+      sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
+      const int dlda = ((dca + 15) & ~15) + 8, dldb = ((dcb + 15) & ~15) + 8;
+      const size_t dlds = (size_t)kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);
+      static bool dsattr = false;
+      if (!dsattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr = true; }
+      hipLaunchKernelGGL(dgcnn_split, grid, dim3(kWaves * 64), dlds, h->stream, sa);
+    } else {
+      hipLaunchKernelGGL(dgcnn_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+    }
+  }
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -1,0 +1,193 @@
+// Split-bf16 variant of dgcnn_fused (see kernels_infer_split.h for the arithmetic: x = hi + lo bf16, three bf16 MFMAs per
+// product, fp32 accumulate), eval mode, gfx950 only.  Covers the shape of every DGCNN use of the reference
+// (models/tp8.py:30-46 with widths [C_a <= 64, C_b <= 128, C3]): edge feature -> K = 6 lift (VALU) -> 1x1 conv C_a -> C_b over
+// the k neighbours (MFMA) -> max over k -> point conv C_b -> C3 (MFMA) -> max over points.  Other shapes run dgcnn_fused.
+//
+// Per neighbour slot the edge conv is 12 bf16 MFMAs per wave instead of 32 fp32 MFMAs of twice the length; its split weight
+// fragments (4 k blocks x hi/lo) stay in registers for all 20 slots.  The lift writes its output directly as hi / lo bf16
+// tiles (double-buffered across slots), and the pooled edge features are split once for the point conv, whose weight
+// fragments roll one channel tile ahead as in pointnet_split.
+// LDS: es [64][8] f32 | lift tiles [2 buffers][hi, lo][64][Ka+8] bf16 | point features [hi, lo][64][Kb+8] bf16.
+#pragma once
+#include "kernels_dgcnn.h"
+#include "kernels_infer_split.h"
+
+namespace alignnet {
+
+struct DgcnnSplitArgs {
+  const float* pcs[2]; const float* xform; const int* nn;
+  float* pooled; long tower_stride, row_stride;
+  int B, N, k;
+  int Ca, Cb, C3;
+  const float* w1;                  // [6][Ca] fp32
+  const unsigned short* w2s;        // split image of the edge conv [Ca][Cb]
+  const unsigned short* w3s;        // split image of the point conv [Cb][C3]
+  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // folded BN [2 towers][C]
+};
+
+// edge layer 0: K = 6 lift on the VALU, es -> hi / lo tiles [64][lda]; columns Ca .. Ka are zero padding
+__device__ __forceinline__ void dg_lift_split(const DgcnnSplitArgs& a, int tower, const float* es, unsigned short* th, unsigned short* tl,
+                                              int lda, int Ka, int tid)
+{
+  const int c0 = tid & 31, r0 = tid >> 5;
+  for (int c = c0; c < Ka; c += 32) {
+    const bool live = c < a.Ca;
+    float w[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = live ? a.w1[d * a.Ca + c] : 0.f;
+    const float sc = live ? a.sc1[tower * a.Ca + c] : 0.f, sh = live ? a.sh1[tower * a.Ca + c] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kDgTile / 16; ++rr) {
+      const int row = rr * 16 + r0;
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+      float acc = e0[0] * w[0];
+      acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
+      acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
+      unsigned short hi, lo;
+      split_bf16(fmaxf(fmaf(acc, sc, sh), 0.f), hi, lo);
+      th[row * lda + c] = hi;
+      tl[row * lda + c] = lo;
+    }
+  }
+}
+
+static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const DgcnnSplitArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.y, tile = blockIdx.x;
+  const int tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int nvalid = min(kDgTile, a.N - tile * kDgTile);
+  const int Ka = (a.Ca + 15) & ~15, Kb = (a.Cb + 15) & ~15, lda = Ka + 8, ldb = Kb + 8;
+  const int KBa = Ka >> 4, KBb = Kb >> 4;
+  float* es = smem;                                                       // [64][8]
+  unsigned short* s16 = reinterpret_cast<unsigned short*>(smem + kDgTile * 8);
+  const int tsz = kDgTile * lda;                                          // one lift tile
+  const int oP = 4 * tsz, psz = kDgTile * ldb;                            // point features: hi at oP, lo at oP + psz
+  // DgcnnArgs view for the shared gather helper
+  DgcnnArgs ga;
+  ga.nn = a.nn; ga.N = a.N; ga.k = a.k;
+
+  // ---- this wave's edge-conv item (channel tile wave >> 1, 32-row block wave & 1): weight fragments resident for all slots ----
+  const int CTE = (a.Cb + 31) >> 5;
+  const int ect = wave >> 1, em = wave & 1;
+  const bool eactive = ect < CTE;
+  const bf16x8* img2 = reinterpret_cast<const bf16x8*>(a.w2s);
+  bf16x8 eh[kSplitKB1], el[kSplitKB1];
+  if (eactive) {
+#pragma unroll
+    for (int kb = 0; kb < kSplitKB1; ++kb)
+      if (kb < KBa) { eh[kb] = img2[(((size_t)ect * KBa + kb) * 2) * 64 + lane]; el[kb] = img2[(((size_t)ect * KBa + kb) * 2 + 1) * 64 + lane]; }
+  }
+  const int ecol = ect * 32 + (lane & 31);
+  const bool elive = eactive && ecol < a.Cb;
+  const float esc = elive ? a.sc2[tower * a.Cb + ecol] : 0.f, esh = elive ? a.sh2[tower * a.Cb + ecol] : 0.f;
+  f32x16 best;   // running max over the k neighbours of the edge conv's pre-activation; relu folded after the max
+#pragma unroll
+  for (int r = 0; r < 16; ++r) best[r] = -INFINITY;
+
+  auto edge_conv = [&](int buf) {
+    if (!eactive) return;
+    const int oh = (2 * buf) * tsz, ol = oh + tsz;
+    const int arow = (em * 32 + (lane & 31)) * lda + half * 8;
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < kSplitKB1; ++kb)
+      if (kb < KBa) {
+        bf16x8 ah[1], al[1];
+        ah[0] = *reinterpret_cast<const bf16x8*>(s16 + oh + arow + kb * 16);
+        al[0] = *reinterpret_cast<const bf16x8*>(s16 + ol + arow + kb * 16);
+        split_mfma<1>(ah, al, eh[kb], el[kb], acc);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) best[r] = fmaxf(best[r], fmaf(acc[0][r], esc, esh));
+  };
+
+  // ---- slots: the gather of x_j for slot s+1 is in flight during slot s's MFMAs; the lift output is double-buffered ----
+  float v[6];
+  if (tid < kDgTile) { dg_gather(ga, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
+  __syncthreads();
+  dg_lift_split(a, tower, es, s16, s16 + tsz, lda, Ka, tid);
+  __syncthreads();
+  for (int slot = 0; slot < a.k; ++slot) {
+    const bool more = slot + 1 < a.k;
+    if (more && tid < kDgTile) dg_gather(ga, pc, cloud, tile, slot + 1, tid, v);
+    edge_conv(slot & 1);
+    if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
+    __syncthreads();
+    if (more) dg_lift_split(a, tower, es, s16 + (2 * ((slot + 1) & 1)) * tsz, s16 + (2 * ((slot + 1) & 1) + 1) * tsz, lda, Ka, tid);
+    __syncthreads();
+  }
+
+  // ---- relu(max_k) -> point features as hi / lo tiles [64][ldb] (tp8.py:42); rows past the cloud and padding columns are zero ----
+  if (eactive && ecol < Kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = em * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      unsigned short hi, lo;
+      split_bf16((elive && row < nvalid) ? fmaxf(best[r], 0.f) : 0.f, hi, lo);
+      s16[oP + row * ldb + ecol] = hi;
+      s16[oP + psz + row * ldb + ecol] = lo;
+    }
+  }
+  // the first channel tile's fragments of the point conv are requested before the barrier
+  const int CT3 = (a.C3 + 31) >> 5;
+  const bf16x8* img3 = reinterpret_cast<const bf16x8*>(a.w3s);
+  bf16x8 bh[kSplitKB2], bl[kSplitKB2];
+  if (wave < CT3) {
+#pragma unroll
+    for (int kb = 0; kb < kSplitKB2; ++kb)
+      if (kb < KBb) { bh[kb] = img3[(((size_t)wave * KBb + kb) * 2) * 64 + lane]; bl[kb] = img3[(((size_t)wave * KBb + kb) * 2 + 1) * 64 + lane]; }
+  }
+  __syncthreads();
+
+  // ---- point conv + max over the tile's points (tp8.py:43-45) ----
+  {
+    float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
+    const int arow = (lane & 31) * ldb + half * 8;
+    for (int ct = wave; ct < CT3; ct += kWaves) {
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < a.C3;
+      const float sc = live ? a.sc3[tower * a.C3 + col] : 0.f, sh = live ? a.sh3[tower * a.C3 + col] : 0.f;
+      const int nct = ct + kWaves;
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < kSplitKB2; ++kb)
+        if (kb < KBb) {
+          bf16x8 ah[2], al[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            ah[m] = *reinterpret_cast<const bf16x8*>(s16 + oP + arow + m * 32 * ldb + kb * 16);
+            al[m] = *reinterpret_cast<const bf16x8*>(s16 + oP + psz + arow + m * 32 * ldb + kb * 16);
+          }
+          split_mfma<2>(ah, al, bh[kb], bl[kb], acc);
+          if (nct < CT3) {
+            bh[kb] = img3[(((size_t)nct * KBb + kb) * 2) * 64 + lane];
+            bl[kb] = img3[(((size_t)nct * KBb + kb) * 2 + 1) * 64 + lane];
+          }
+        }
+      float mx = 0.f;   // relu folded into the max
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < nvalid) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));   // >= 0: monotone bit pattern
+    }
+  }
+}
+
+}  // namespace alignnet

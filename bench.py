@@ -177,7 +177,7 @@ def main():
         eng.forward_device(p1.data_ptr(), p2.data_ptr(), B, ptrs)
 
     step = train_step if args.mode == "train" else infer_step
-    if args.mode == "infer" and args.infer_dtype == "bf16x3" and args.workload == "pointnet":
+    if args.mode == "infer" and args.infer_dtype == "bf16x3":
         eng.set_option("infer_matmul_bf16x3", 1)
     if args.mode == "train" and args.train_dtype == "bf16":
         eng.set_option("train_matmul_bf16", 1)
@@ -304,13 +304,13 @@ def main():
                                           "(BASELINE.json configs[2])" % (B, npts, args.train_dtype))
             line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients)" if world > 1 else "")
             line["whole_path_tflops"] = None
-        if args.mode == "infer" and args.infer_dtype == "bf16x3" and args.workload == "pointnet":
+        if args.mode == "infer" and args.infer_dtype == "bf16x3":
             line["dtype"] = "bf16x3"
             line["metric"] += " [split-bf16 backbone]"
             line["config"]["workload"] = line["config"]["workload"].replace("fp32", "split-bf16 products with fp32 accumulate")
             line["roofline"]["peak"] = 2500.0 / 3.0
             line["roofline"]["frac"] = None if achieved is None else round(achieved / (2500.0 / 3.0), 4)
-            line["roofline"]["kernel"] = "pointnet_split"
+            line["roofline"]["kernel"] = "pointnet_split" if args.workload == "pointnet" else "dgcnn_split"
             line["roofline"]["traffic"] = None
             line["roofline"]["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
         if split_info is not None:

@@ -232,7 +232,7 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   fp32 operand of the two MFMA layers is written x = bf16(x) + bf16(x - bf16(x)) and each product is formed as
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
  *   gfx950).  Outputs stay within the 1e-4 parity bar (measured 3e-6 against the fp64 oracle, like the exact path).
- *   Other backbone shapes and the DGCNN branch keep the exact-fp32 kernels.
+ *   Also covers the DGCNN branch with widths [<= 64, <= 128, C3]; other backbone shapes keep the exact-fp32 kernels.
  * Unknown keys fail. */
 int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value);
 int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value);

@@ -110,13 +110,13 @@ def test_batch_independence_and_determinism(gpu_required):
 
 
 @pytest.mark.parametrize("N,B", [(64, 4), (128, 6), (200, 3)])
-def test_forward_dgcnn(gpu_required, N, B):
+def test_forward_dgcnn(gpu_required, N, B, split=False):
     """DGCNN branch (reference models/tp8.py:30-46): static kNN graph (k = 20, self included), edge convs,
     max over neighbours, point conv, max over points.  The oracle rebuilds the graph per stage in fp64; the
     engine builds it once in the mean-centred frame in fp32 (the frames differ by a rigid motion).  A different
     neighbour at a near-tie changes an edge feature, so mismatching pairs are counted rather than tolerated."""
     cfg = small_cfg(N=N, backbone="dgcnn")
-    ep, ref, spec = _run(cfg, B)
+    ep, ref, spec = _run(cfg, B, split=split)
     bad = 0
     for b in range(B):
         ok = all(np.allclose(ep[k][b], ref[k][b], rtol=2e-4, atol=2e-4) for k in
@@ -124,3 +124,9 @@ def test_forward_dgcnn(gpu_required, N, B):
         bad += not ok
     print("dgcnn pairs outside 2e-4:", bad, "of", B)
     assert bad == 0
+
+
+@pytest.mark.parametrize("N,B", [(64, 3), (200, 4)])
+def test_forward_dgcnn_split_bf16(gpu_required, N, B):
+    """The DGCNN branch with the split-bf16 kernels (dgcnn_split): same criterion as the exact-fp32 branch."""
+    test_forward_dgcnn(gpu_required, N, B, split=True)
