@@ -63,8 +63,10 @@ def test_forward_split_bf16_synthcars_widths_n1024(gpu_required):
     assert any(not np.array_equal(ep[k], ep32[k]) for k in ep), "option had no effect"
 
 
-def test_forward_default_json_widths(gpu_required):
-    # reference configs/default.json widths: 5-layer backbones, 36 bins
+@pytest.mark.parametrize("split", [False, True])
+def test_forward_default_json_widths(gpu_required, split):
+    # reference configs/default.json widths: 5-layer backbones, 36 bins (the split-bf16 option does not cover 5-layer
+    # backbones or a 128-wide first layer: every stage must fall back to the exact kernels)
     cfg = alignnet3d.default_model_config()
     o = cfg["model"]["options"]
     o["s1transformer"] = [[128, 128, 256], [[512, 256], 0.7]]
@@ -72,7 +74,7 @@ def test_forward_default_json_widths(gpu_required):
     o["embedding"] = [64, 64, 64, 128, 1024]
     cfg["model"]["angles"]["num_bins"] = 36
     cfg["model"]["num_points"] = 512
-    ep, ref, spec = _run(cfg, 4)
+    ep, ref, spec = _run(cfg, 4, split=split)
     worst, unstable = compare_forward(ep, ref, spec.num_bins)
     print("worst abs err", worst, "unstable pairs", unstable)
 
