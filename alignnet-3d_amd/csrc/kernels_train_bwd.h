@@ -240,14 +240,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();   // everyone finished reading X (sparse) and Y (h2)
     B2_STAMP(8);
 
-    // ---- dy2 -> Y ; h1 -> X again ----
+    // ---- dy2 -> Y ; h1 -> X again (only when U2 / Gram(h1) are accumulated here; pass B1 does it otherwise) ----
     if (ct < CT2 && col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
     }
-    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    if (ACCUM) layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 
     B2_STAMP(9);
