@@ -7,7 +7,7 @@
 // fragments (4 k blocks x hi/lo) stay in registers for all 20 slots.  The lift writes its output directly as hi / lo bf16
 // tiles (double-buffered across slots), and the pooled edge features are split once for the point conv, whose weight
 // fragments roll one channel tile ahead as in pointnet_split.
-// LDS: es [64][8] f32 | lift tiles [2 buffers][hi, lo][64][Ka+8] bf16 | point features [hi, lo][64][Kb+8] bf16.
+// LDS: es [64][8] f32 | lift tiles [2 buffers][hi, lo][64][Ka+8] bf16 | point features [hi, lo][64][Kb+8] bf16 | es' [64][8] f32.
 #pragma once
 #include "kernels_dgcnn.h"
 #include "kernels_infer_split.h"
@@ -25,29 +25,47 @@ struct DgcnnSplitArgs {
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // folded BN [2 towers][C]
 };
 
-// edge layer 0: K = 6 lift on the VALU, es -> hi / lo tiles [64][lda]; columns Ca .. Ka are zero padding
-__device__ __forceinline__ void dg_lift_split(const DgcnnSplitArgs& a, int tower, const float* es, unsigned short* th, unsigned short* tl,
-                                              int lda, int Ka, int tid)
+// edge layer 0: K = 6 lift on the VALU, es -> hi / lo tiles [64][lda]; columns Ca .. Ka are zero padding.  The thread's
+// weights, scale and shift (channels c0 and c0 + 32: Ca <= 64) live in registers for all neighbour slots:
+// reloading them from global memory in every slot put an L2 round trip on each slot's critical path.
+struct DgLiftW { float w[2][6]; float sc[2], sh[2]; };
+
+__device__ __forceinline__ DgLiftW dg_lift_weights(const DgcnnSplitArgs& a, int tower, int tid)
+{
+  DgLiftW L;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = (tid & 31) + 32 * g;
+    const bool live = c < a.Ca;
+    L.sc[g] = live ? a.sc1[tower * a.Ca + c] : 0.f;
+    L.sh[g] = live ? a.sh1[tower * a.Ca + c] : 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) L.w[g][d] = live ? a.w1[d * a.Ca + c] : 0.f;
+  }
+  return L;
+}
+
+__device__ __forceinline__ void dg_lift_split(const DgcnnSplitArgs& a, int tower, const DgLiftW& L, const float* es, unsigned short* th,
+                                              unsigned short* tl, int lda, int Ka, int tid)
 {
   const int c0 = tid & 31, r0 = tid >> 5;
-  for (int c = c0; c < Ka; c += 32) {
-    const bool live = c < a.Ca;
-    float w[6];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) w[d] = live ? a.w1[d * a.Ca + c] : 0.f;
-    const float sc = live ? a.sc1[tower * a.Ca + c] : 0.f, sh = live ? a.sh1[tower * a.Ca + c] : 0.f;
+  for (int g = 0; g < 2; ++g) {
+    const int c = c0 + 32 * g;
+    if (c < Ka) {
 #pragma unroll
-    for (int rr = 0; rr < kDgTile / 16; ++rr) {
-      const int row = rr * 16 + r0;
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
-      float acc = e0[0] * w[0];
-      acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
-      acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
-      unsigned short hi, lo;
-      split_bf16(fmaxf(fmaf(acc, sc, sh), 0.f), hi, lo);
-      th[row * lda + c] = hi;
-      tl[row * lda + c] = lo;
+      for (int rr = 0; rr < kDgTile / 16; ++rr) {
+        const int row = rr * 16 + r0;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+        float acc = e0[0] * L.w[g][0];
+        acc = fmaf(e0[1], L.w[g][1], acc); acc = fmaf(e0[2], L.w[g][2], acc); acc = fmaf(e0[3], L.w[g][3], acc);
+        acc = fmaf(e1[0], L.w[g][4], acc); acc = fmaf(e1[1], L.w[g][5], acc);
+        unsigned short hi, lo;
+        split_bf16(fmaxf(fmaf(acc, L.sc[g], L.sh[g]), 0.f), hi, lo);
+        th[row * lda + c] = hi;
+        tl[row * lda + c] = lo;
+      }
     }
   }
 }
@@ -68,9 +86,6 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
   unsigned short* s16 = reinterpret_cast<unsigned short*>(smem + kDgTile * 8);
   const int tsz = kDgTile * lda;                                          // one lift tile
   const int oP = 4 * tsz, psz = kDgTile * ldb;                            // point features: hi at oP, lo at oP + psz
-  // DgcnnArgs view for the shared gather helper
-  DgcnnArgs ga;
-  ga.nn = a.nn; ga.N = a.N; ga.k = a.k;
 
   // ---- this wave's edge-conv item (channel tile wave >> 1, 32-row block wave & 1): weight fragments resident for all slots ----
   const int CTE = (a.Cb + 31) >> 5;
@@ -109,19 +124,55 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
     for (int r = 0; r < 16; ++r) best[r] = fmaxf(best[r], fmaf(acc[0][r], esc, esh));
   };
 
-  // ---- slots: the gather of x_j for slot s+1 is in flight during slot s's MFMAs; the lift output is double-buffered ----
-  float v[6];
-  if (tid < kDgTile) { dg_gather(ga, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
+  // ---- all (point, neighbour slot) edge features are gathered ONCE, up front: lane = point of the tile, wave w holds slots
+  //      w, w + 8, w + 16.  With the edge conv down to ~400 cycles per slot, a per-slot gather (index load, then the
+  //      dependent point load: two HBM/L2 round trips) was exposed 20 times per tile. ----
+  constexpr int kSlotRegs = 3;   // k <= 24
+  float ev[kSlotRegs][6];
+  {
+    const int n = min(tile * kDgTile + lane, a.N - 1);
+    const float* p = pc + (size_t)n * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    const float cxp = px - xf[0], cyp = py - xf[1], czp = pz - xf[2];
+    const float e0 = cxp * xf[3] + cyp * xf[6] + czp * xf[9], e1 = cxp * xf[4] + cyp * xf[7] + czp * xf[10],
+                e2 = cxp * xf[5] + cyp * xf[8] + czp * xf[11];
+#pragma unroll
+    for (int q = 0; q < kSlotRegs; ++q) {
+      const int slot = wave + q * kWaves;
+      ev[q][0] = e0; ev[q][1] = e1; ev[q][2] = e2; ev[q][3] = 0.f; ev[q][4] = 0.f; ev[q][5] = 0.f;
+      if (slot < a.k) {
+        const int j = a.nn[((size_t)cloud * a.N + n) * a.k + slot];
+        const float* pj = pc + (size_t)j * 3;
+        const float dx = pj[0] - px, dy = pj[1] - py, dz = pj[2] - pz;
+        ev[q][3] = dx * xf[3] + dy * xf[6] + dz * xf[9];
+        ev[q][4] = dx * xf[4] + dy * xf[7] + dz * xf[10];
+        ev[q][5] = dx * xf[5] + dy * xf[8] + dz * xf[11];
+      }
+    }
+  }
+  float* es2 = reinterpret_cast<float*>(s16 + oP + 2 * psz);   // second edge-feature buffer [64][8], behind the point tiles
+  auto write_es = [&](int slot) {   // the wave that holds `slot` publishes its 64 edge features
+    if ((slot % kWaves) != wave) return;
+    float* dstp = ((slot & 1) ? es2 : es) + lane * 8;
+    const int q = slot / kWaves;
+#pragma unroll
+    for (int u = 0; u < kSlotRegs; ++u)
+      if (u == q) {
+        *reinterpret_cast<f32x4*>(dstp) = f32x4{ev[u][0], ev[u][1], ev[u][2], ev[u][3]};
+        dstp[4] = ev[u][4]; dstp[5] = ev[u][5];
+      }
+  };
+  write_es(0);
   __syncthreads();
-  dg_lift_split(a, tower, es, s16, s16 + tsz, lda, Ka, tid);
+  const DgLiftW LW = dg_lift_weights(a, tower, tid);
+  dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
   __syncthreads();
   for (int slot = 0; slot < a.k; ++slot) {
     const bool more = slot + 1 < a.k;
-    if (more && tid < kDgTile) dg_gather(ga, pc, cloud, tile, slot + 1, tid, v);
+    if (more) write_es(slot + 1);
     edge_conv(slot & 1);
-    if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
     __syncthreads();
-    if (more) dg_lift_split(a, tower, es, s16 + (2 * ((slot + 1) & 1)) * tsz, s16 + (2 * ((slot + 1) & 1) + 1) * tsz, lda, Ka, tid);
+    if (more) dg_lift_split(a, tower, LW, ((slot + 1) & 1) ? es2 : es, s16 + (2 * ((slot + 1) & 1)) * tsz, s16 + (2 * ((slot + 1) & 1) + 1) * tsz, lda, Ka, tid);
     __syncthreads();
   }
 
