@@ -542,6 +542,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       sa.B = B; sa.N = a.N; sa.k = a.k; sa.Ca = dca; sa.Cb = dcb; sa.C3 = h->layers[st.first + 2].cout;
       sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
       sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
+      sa.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
       const int dlda = ((dca + 15) & ~15) + 8, dldb = ((dcb + 15) & ~15) + 8;
       if (a.k > 3 * kWaves) return fail(h, "dgcnn split kernel: k limited to 24 neighbours");
       const size_t dlds = (size_t)2 * kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);

@@ -23,6 +23,7 @@ struct DgcnnSplitArgs {
   const unsigned short* w2s;        // split image of the edge conv [Ca][Cb]
   const unsigned short* w3s;        // split image of the point conv [Cb][C3]
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // folded BN [2 towers][C]
+  int dbg;
 };
 
 // edge layer 0: K = 6 lift on the VALU, es -> hi / lo tiles [64][lda]; columns Ca .. Ka are zero padding.  The thread's
@@ -162,18 +163,24 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
         dstp[4] = ev[u][4]; dstp[5] = ev[u][5];
       }
   };
-  write_es(0);
-  __syncthreads();
+  // two neighbour slots per iteration (slot s -> es / tile buffer 0, slot s+1 -> es' / tile buffer 1): publish both edge
+  // features, lift both, run both edge convs -- three barriers per two slots instead of four
   const DgLiftW LW = dg_lift_weights(a, tower, tid);
-  dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
-  __syncthreads();
-  for (int slot = 0; slot < a.k; ++slot) {
-    const bool more = slot + 1 < a.k;
-    if (more) write_es(slot + 1);
-    edge_conv(slot & 1);
+  for (int slot = 0; slot < a.k; slot += 2) {
+    const bool two = slot + 1 < a.k;
+    write_es(slot);
+    if (two) write_es(slot + 1);
     __syncthreads();
-    if (more) dg_lift_split(a, tower, LW, ((slot + 1) & 1) ? es2 : es, s16 + (2 * ((slot + 1) & 1)) * tsz, s16 + (2 * ((slot + 1) & 1) + 1) * tsz, lda, Ka, tid);
+    if (!(a.dbg & 2)) {
+      dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
+      if (two) dg_lift_split(a, tower, LW, es2, s16 + 2 * tsz, s16 + 3 * tsz, lda, Ka, tid);
+    }
     __syncthreads();
+    if (!(a.dbg & 1)) {
+      edge_conv(0);
+      if (two) edge_conv(1);
+    }
+    __syncthreads();   // the next pair overwrites es / es' and the tiles
   }
 
   // ---- relu(max_k) -> point features as hi / lo tiles [64][ldb] (tp8.py:42); rows past the cloud and padding columns are zero ----
@@ -202,7 +209,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
   {
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     const int arow = (lane & 31) * ldb + half * 8;
-    for (int ct = wave; ct < CT3; ct += kWaves) {
+    for (int ct = wave; ct < ((a.dbg & 4) ? 0 : CT3); ct += kWaves) {
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
       const float sc = live ? a.sc3[tower * a.C3 + col] : 0.f, sh = live ? a.sh3[tower * a.C3 + col] : 0.f;
