@@ -165,17 +165,45 @@ __device__ __forceinline__ void dg_edge_to_lds(const float* xf, const float (&v)
   e[5] = v[3] * xf[5] + v[4] * xf[8] + v[5] * xf[11];
 }
 
-// edge layer 0: K = 6 lift on the VALU, es -> out[64][ldo]
-__device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const float* es, float* out, int ldo, int tid)
+// edge layer 0: K = 6 lift on the VALU, es -> out[64][ldo].  The thread's weights / scale / shift (channels c0 and
+// c0 + 32 for widths <= 64) are passed in registers: reloading them from global memory in every neighbour slot put an L2
+// round trip on each slot's critical path.
+struct DgLiftRegs { float w[2][6]; float sc[2], sh[2]; };
+
+__device__ __forceinline__ DgLiftRegs dg_lift_load(const ConvLayerDev& L, int tower, int tid)
+{
+  DgLiftRegs R;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = (tid & 31) + 32 * g;
+    const bool live = c < L.cout;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) R.w[g][d] = live ? L.w[d * L.cout + c] : 0.f;
+    R.sc[g] = live ? L.scale[tower * L.cout + c] : 0.f;
+    R.sh[g] = live ? L.shift[tower * L.cout + c] : 0.f;
+  }
+  return R;
+}
+
+__device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const float* es, float* out, int ldo, int tid,
+                                        const DgLiftRegs* regs = nullptr)
 {
   const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (L.cout + 7) & ~7;
   for (int c = c0; c < cw; c += 32) {
     const bool live = c < L.cout;
+    const int g = (c - c0) >> 5;
     float w[6];
+    float sc, sh;
+    if (regs && g < 2) {
 #pragma unroll
-    for (int d = 0; d < 6; ++d) w[d] = live ? L.w[d * L.cout + c] : 0.f;
-    const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+      for (int d = 0; d < 6; ++d) w[d] = g ? regs->w[1][d] : regs->w[0][d];
+      sc = g ? regs->sc[1] : regs->sc[0]; sh = g ? regs->sh[1] : regs->sh[0];
+    } else {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) w[d] = live ? L.w[d * L.cout + c] : 0.f;
+      sc = live ? L.scale[tower * L.cout + c] : 0.f; sh = live ? L.shift[tower * L.cout + c] : 0.f;
+    }
 #pragma unroll
     for (int rr = 0; rr < kDgTile / 16; ++rr) {
       const int row = rr * 16 + r0;
@@ -284,7 +312,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
     float v[6];
     if (tid < kDgTile) { dg_gather(a, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
     __syncthreads();
-    dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid);
+    const DgLiftRegs lregs = dg_lift_load(a.L[0], tower, tid);
+    dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid, &lregs);
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
@@ -293,7 +322,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
       else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
       if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
       __syncthreads();
-      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), a.ld[0], tid);
+      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), a.ld[0], tid, &lregs);
       __syncthreads();
     }
   } else {
