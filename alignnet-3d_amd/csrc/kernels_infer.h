@@ -321,6 +321,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
     }
   };
   request_xyz(tile_lo);
+  // the K = 3 lift's weights / scale / shift of this thread's first two channel groups (widths <= 64): loaded once per
+  // workgroup instead of once per tile
+  float l0w[2][5];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const ConvLayerDev& L0 = a.L[0];
+    const int c = (tid & 31) + 32 * g;
+    const bool live = c < L0.cout;
+    l0w[g][0] = live ? L0.w[c] : 0.f; l0w[g][1] = live ? L0.w[L0.cout + c] : 0.f; l0w[g][2] = live ? L0.w[2 * L0.cout + c] : 0.f;
+    l0w[g][3] = live ? L0.scale[tower * L0.cout + c] : 0.f; l0w[g][4] = live ? L0.shift[tower * L0.cout + c] : 0.f;
+  }
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
   if (tile != tile_lo) __syncthreads();   // the previous tile's readers are done with the LDS buffers
 
@@ -335,15 +346,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
   if (tile + 1 < tile_hi) request_xyz(tile + 1);
   __syncthreads();
 
-  // ---- layer 0: K = 3 lift on the VALU (not a dense GEMM) ----
+  // ---- layer 0: K = 3 lift on the VALU (not a dense GEMM); the first two channel groups' weights come from registers ----
   {
     const ConvLayerDev& L = a.L[0];
     float* out = smem + boff[0];
     const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;   // a 32-lane group writes one row, 32 consecutive channels
     for (int c = c0; c < ldo - 4; c += 32) {
       const bool live = c < L.cout;
-      const float w0 = live ? L.w[c] : 0.f, w1 = live ? L.w[L.cout + c] : 0.f, w2 = live ? L.w[2 * L.cout + c] : 0.f;
-      const float sc = live ? L.scale[tower * L.cout + c] : 0.f, sh = live ? L.shift[tower * L.cout + c] : 0.f;
+      const int g = (c - c0) >> 5;
+      float w0, w1, w2, sc, sh;
+      if (g < 2) { w0 = g ? l0w[1][0] : l0w[0][0]; w1 = g ? l0w[1][1] : l0w[0][1]; w2 = g ? l0w[1][2] : l0w[0][2];
+                   sc = g ? l0w[1][3] : l0w[0][3]; sh = g ? l0w[1][4] : l0w[0][4]; }
+      else { w0 = live ? L.w[c] : 0.f; w1 = live ? L.w[L.cout + c] : 0.f; w2 = live ? L.w[2 * L.cout + c] : 0.f;
+             sc = live ? L.scale[tower * L.cout + c] : 0.f; sh = live ? L.shift[tower * L.cout + c] : 0.f; }
 #pragma unroll
       for (int rr = 0; rr < TP / 16; ++rr) {
         const int row = rr * 16 + r0;
