@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     B2_STAMP(1);
-    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    layer1_to_lds_global(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
     B2_STAMP(2);
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
     }
-    if (ACCUM) layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    if (ACCUM) layer1_to_lds_global(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 
     B2_STAMP(9);
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   // items: (column tile ct, 32-row group rg)
   const int nitems = CT1 * 2;
+  const Layer1W l1w = layer1_load(a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, tid);
   // U2 = h1^T dy2 (CT1 x CT2 blocks) and the upper blocks of Gram(h1) stay in registers for the whole cloud (a per-tile
   // read-modify-write of these 48 KiB per cloud falls out of L2 with 512 clouds in flight); <= 3 blocks per wave
   constexpr int kAccSlots = 3;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
       }
     }
     __syncthreads();
-    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    layer1_to_lds(xs, l1w, a.C1, X, ld0, nvalid, tid);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kAccSlots; ++q) {

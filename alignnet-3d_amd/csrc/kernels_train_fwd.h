@@ -88,12 +88,60 @@ __device__ __forceinline__ void load_tile_xform(const float* __restrict__ pc, co
   }
 }
 
-// layer 1 on the VALU: out[row][c] = relu((x' . w[:,c]) * sc + sh); rows >= nvalid are written as 0
-__device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
-                                              const float* __restrict__ sc, const float* __restrict__ sh,
-                                              float* __restrict__ out, int ldo, int nvalid, int tid)
+// layer 1 on the VALU: out[row][c] = relu((x' . w[:,c]) * sc + sh); rows >= nvalid are written as 0.
+// Layer1W holds the thread's weights / scale / shift for its (<= 4) channel groups c0, c0 + 32, ...: loaded once per
+// workgroup (layer1_load) instead of once per tile -- the reload put an L2 round trip in front of every tile's first barrier.
+struct Layer1W { float w0[2], wa[2], wb[2], s[2], t[2]; const float *w1, *sc, *sh; };   // groups 0, 1 in registers (C1 <= 64)
+
+__device__ __forceinline__ Layer1W layer1_load(const float* __restrict__ w1, int C1, const float* __restrict__ sc,
+                                               const float* __restrict__ sh, int tid)
+{
+  Layer1W L;
+  L.w1 = w1; L.sc = sc; L.sh = sh;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = (tid & 31) + 32 * g;
+    const bool live = c < C1;
+    L.w0[g] = live ? w1[c] : 0.f; L.wa[g] = live ? w1[C1 + c] : 0.f; L.wb[g] = live ? w1[2 * C1 + c] : 0.f;
+    L.s[g] = live ? sc[c] : 0.f; L.t[g] = live ? sh[c] : 0.f;
+  }
+  return L;
+}
+
+__device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, const Layer1W& L, int C1, float* __restrict__ out, int ldo,
+                                              int nvalid, int tid)
 {
   constexpr int kRowsPerPass = kTW * 2;   // 32 lanes cover 32 channels of one row
+  const int c0 = tid & 31, r0 = tid >> 5;
+  const int cw = (C1 + 7) & ~7;           // C1 <= 128: at most four channel groups
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = c0 + 32 * g;
+    if (c < cw) {
+      float w0, wa, wb, s, t;
+      if (g < 2) { w0 = L.w0[g & 1]; wa = L.wa[g & 1]; wb = L.wb[g & 1]; s = L.s[g & 1]; t = L.t[g & 1]; }
+      else {   // wider first layers: loaded per tile
+        const bool live = c < C1;
+        w0 = live ? L.w1[c] : 0.f; wa = live ? L.w1[C1 + c] : 0.f; wb = live ? L.w1[2 * C1 + c] : 0.f;
+        s = live ? L.sc[c] : 0.f; t = live ? L.sh[c] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+        const int row = rr * kRowsPerPass + r0;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+        out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+      }
+    }
+  }
+}
+
+// same lift with the weights loaded from global memory on every call (pass B2 has no registers to spare for Layer1W)
+__device__ __forceinline__ void layer1_to_lds_global(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
+                                                     const float* __restrict__ sc, const float* __restrict__ sh,
+                                                     float* __restrict__ out, int ldo, int nvalid, int tid)
+{
+  constexpr int kRowsPerPass = kTW * 2;
   const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (C1 + 7) & ~7;
   for (int c = c0; c < cw; c += 32) {
@@ -268,6 +316,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
   }
 
+  const Layer1W l1w = layer1_load(a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, tid);
   constexpr int kBfSlots = 8;                 // channel tiles wave, wave + 4, ... of the lift: C3 <= 1024
   float rs1[BF16 ? kBfSlots : 1], rs2[BF16 ? kBfSlots : 1], rbe[BF16 ? kBfSlots : 1];
   int rbi[BF16 ? kBfSlots : 1];
@@ -282,7 +331,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
-    layer1_to_lds(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, buf0, ld0, nvalid, tid);
+    layer1_to_lds(xs, l1w, a.C1, buf0, ld0, nvalid, tid);
     __syncthreads();
 
     // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 32-row group): C2 = 128 -> 8 items, one per wave ----
