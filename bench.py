@@ -91,7 +91,9 @@ def cpu_baseline(cfg, seconds=12.0):
 
 def pmc_traffic():
     """HBM bytes per step from a committed rocprofv3 PMC summary, if one exists."""
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "_train_" not in os.path.basename(f))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
+                   if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))   # the exact-fp32 inference profile of a round
     if not files:
         return None
     try:
