@@ -136,8 +136,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank %= max(torch.cuda.device_count(), 1)   # more ranks than GPUs: share devices rather than fail
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        except Exception as e:   # the inference path has no data-path collective: a barrier and one max are all it needs
+            print(f"[bench] nccl backend unavailable ({e}); using gloo for the barrier / max-over-ranks", file=sys.stderr, flush=True)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -184,6 +189,14 @@ def main():
     if args.mode == "train" and args.train_dtype == "bf16":
         eng.set_option("train_matmul_bf16", 1)
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([x], device=dev if on_gpu else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
@@ -204,10 +217,7 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile_enable(False)
 
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
 
     # secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline value)
     split_info = None
@@ -227,10 +237,7 @@ def main():
         sdt = time.perf_counter() - t1
         sprof = eng.profile_read(reset=True)
         eng.profile_enable(False)
-        if dist is not None:
-            t = torch.tensor([sdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt = float(t.item())
+        sdt = max_over_ranks(sdt)
         diff = max(float((outs[k] - ref_out[k]).abs().max().item()) for k in outs)
         bb_ms = sprof["backbone_ms"] / ksteps
         split_info = {"value": round(world * B * ksteps / sdt, 1), "unit": "pairs/s", "ms_per_step": round(sdt / ksteps * 1e3, 4), "steps": ksteps,
@@ -257,10 +264,7 @@ def main():
                 train_step()
             fence()
             tdt = time.perf_counter() - t1
-            if dist is not None:
-                t = torch.tensor([tdt], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tdt = float(t.item())
+            tdt = max_over_ranks(tdt)
             leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
                    "steps": ksteps, "dtype": tdtype,
                    "what": "train step: batch-stat forward + loss + backward + " +
