@@ -132,3 +132,14 @@ def test_forward_dgcnn(gpu_required, N, B, split=False):
 def test_forward_dgcnn_split_bf16(gpu_required, N, B):
     """The DGCNN branch with the split-bf16 kernels (dgcnn_split): same criterion as the exact-fp32 branch."""
     test_forward_dgcnn(gpu_required, N, B, split=True)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_forward_whole_cloud_workgroups_with_partial_tile(gpu_required, split):
+    """B = 256 makes a workgroup walk all tiles of its cloud (pooled max in registers, published once); N = 200 makes the
+    last of its two tiles partial.  Same bar as every other forward test."""
+    cfg = small_cfg(N=200)
+    ep, ref, spec = _run(cfg, 256, split=split)
+    worst, unstable = compare_forward(ep, ref, spec.num_bins)
+    print("worst abs err", max(worst.values()), "unstable pairs", unstable)
+    assert unstable <= 64
