@@ -589,20 +589,32 @@ __global__ __launch_bounds__(kTW * 64) void gram_h2_kernel(const float* __restri
     while (it < CT2 && rem >= CT2 - it) { rem -= CT2 - it; ++it; }
     bit[q] = it; bjt[q] = it + rem;
   }
-  auto load_tile = [&](int tile, float* buf) {
+  // the next tile is requested into registers (all loads in flight at once) BEFORE this tile's MFMAs and written to the
+  // other LDS buffer after them: a load-then-store loop serialised eight HBM round trips per tile
+  constexpr int kRegs = (kTT * 128 / 4) / (kTW * 64);   // f32x4 per thread at C2 = 128
+  f32x4 nxt[kRegs];
+  auto request_tile = [&](int tile) {
     const int nvalid = min(kTT, N - tile * kTT);
-    for (int i = tid; i < kTT * c4; i += kTW * 64) {
-      const int row = i / c4, q = i % c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + ((size_t)tile * kTT + row) * C2 + q * 4);
-      *reinterpret_cast<f32x4*>(buf + row * ld + q * 4) = v;
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
+      nxt[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < kTT * c4 && row < nvalid) nxt[u] = *reinterpret_cast<const f32x4*>(src + ((size_t)tile * kTT + row) * C2 + q * 4);
     }
   };
-  load_tile(0, smem);
+  auto store_tile = [&](float* buf) {
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
+      if (i < kTT * c4) *reinterpret_cast<f32x4*>(buf + row * ld + q * 4) = nxt[u];
+    }
+  };
+  request_tile(0);
+  store_tile(smem);
   for (int tile = 0; tile < ntiles; ++tile) {
     float* cur = smem + (tile & 1) * kTT * ld;
     __syncthreads();   // cur is complete; the other buffer's readers (tile - 1) are done
-    if (tile + 1 < ntiles) load_tile(tile + 1, smem + ((tile + 1) & 1) * kTT * ld);
+    if (tile + 1 < ntiles) request_tile(tile + 1);
 #pragma unroll
     for (int q = 0; q < kSlots; ++q) {
       if (wave + q * kTW < nblk) {
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(kTW * 64) void gram_h2_kernel(const float* __restri
         for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld], pb[r * ld], gacc[q], 0, 0, 0);
       }
     }
+    if (tile + 1 < ntiles) store_tile(smem + ((tile + 1) & 1) * kTT * ld);
   }
 #pragma unroll
   for (int q = 0; q < kSlots; ++q)
