@@ -69,6 +69,8 @@ struct TrainWS {
   float *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   PackJob* pack_table = nullptr; int n_pack = 0;
   PackJob* stage_pack = nullptr;   // [3 stages][6]: Q3 t0,t1 | Q2 t0,t1, V2 t0,t1 (images rebuilt inside the backward)
+  unsigned short* q3imgh = nullptr;   // bf16 images of Q3, both towers (train_bf16)
+  unsigned short* wp2h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the hidden layers (train_bf16, no sign folding)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
 };
 
@@ -97,7 +99,8 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->adam_v) hipFree(w->adam_v);
   if (w->pack_table) hipFree(w->pack_table);
   if (w->stage_pack) hipFree(w->stage_pack);
-  for (int s = 0; s < 3; ++s) if (w->wp3h[s]) hipFree(w->wp3h[s]);
+  if (w->q3imgh) hipFree(w->q3imgh);
+  for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); }
   delete w;
   h->train_ws = nullptr;
 }
@@ -281,6 +284,11 @@ static int pack_all_weights(alignnet_handle* h)
       if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], 2 * n * sizeof(unsigned short)));
       hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024), 2), dim3(256), 0, h->stream,
                          P(h, L.p_w), L.cin, L.cout, P(h, L.p_bn[0][1]), P(h, L.p_bn[1][1]), w->wp3h[s]);
+      const Layer& L2 = h->layers[conv_of(h, s).first + 1];   // hidden layer: one image, no sign folding
+      const size_t n2 = (size_t)((L2.cout + 31) / 32) * ((L2.cin + 15) / 16) * 512;
+      if (!w->wp2h[s]) HIP_TRY(h, hipMalloc(&w->wp2h[s], n2 * sizeof(unsigned short)));
+      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 1), dim3(256), 0, h->stream,
+                         P(h, L2.p_w), L2.cin, L2.cout, (const float*)nullptr, (const float*)nullptr, w->wp2h[s]);
     }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
@@ -295,8 +303,11 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
@@ -339,7 +350,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   };
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1);
-  hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
+  if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4);
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
@@ -490,6 +503,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
   hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+  const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
+  if (h->train_bf16) {
+    if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
+    for (int t = 0; t < 2; ++t)
+      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((qimgh + 255) / 256), 1), dim3(256), 0, h->stream,
+                         w->Q3 + (size_t)t * C2 * C2, C2, C2, (const float*)nullptr, (const float*)nullptr, w->q3imgh + t * qimgh);
+  }
   // ---- pass B2 ----
   BwdB2Args b2;
   b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
@@ -504,8 +524,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
-  if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
-  else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), lds_train(b2.ldb, b2.ldb) + b2_extra, h->stream, b2);
+  b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
+  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra;
+  if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   if (b2.stamps) {
     long long st[11];
     hipStreamSynchronize(h->stream);

@@ -29,6 +29,9 @@ struct BwdB2Args {
   const float *sc1, *sh1;       // [2][C1]
   const float *sc2, *sh2;       // [2][C2]
   const float* b2; const float *mean2, *rstd2;   // [C2], [2][C2], [2][C2]
+  const unsigned short* wp2h;   // bf16 image of W2 (train_matmul_bf16)
+  const unsigned short* q3imgh; // bf16 images of Q3 per tower (tower stride q3imgh_stride elements)
+  long q3imgh_stride;
   const float* q3img;           // per tower: MFMA image of Q3 [C2][C2]; tower stride q3img_stride floats
   long q3img_stride;
   const float* q3b;             // [2][C2]: -m2 Q3 - W3 (k*dbeta)/M
@@ -48,7 +51,9 @@ struct BwdB2Args {
 // static slots per wave), so the wave that produced z2 for an item also owns its dh2 and keeps z2 in registers.
 // LDS: xs | X [64][ldb] | Y [64][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
 #define B2_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
-template <bool ACCUM>
+// BF16: the hidden layer is recomputed exactly as the bf16 forward did (bf16 h1 tile x bf16 W2 image), and the h2 Q3 product
+// of dh2 takes h2 and Q3 as bf16 operands; accumulation, sparse rows, BN backward and all reductions stay fp32 / fp64.
+template <bool ACCUM, bool BF16 = false>
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
   const int sG = max(1, (kTW * 64) / a.C1);
+  const int K16a = (a.C1 + 15) & ~15, ld0h = K16a + 8, K16b = (a.C2 + 15) & ~15, ldbh = K16b + 8;   // bf16 tiles
   float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
   float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
 
@@ -119,14 +125,39 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(1);
     layer1_to_lds_global(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
     __syncthreads();
+    if (BF16) {   // bf16 copy of h1 behind the fp32 one (X holds [64][ldb] floats; the fp32 h1 uses [64][ld0] of it)
+      unsigned short* Xh = reinterpret_cast<unsigned short*>(X + kTT * ld0);
+      const int half_cols = K16a >> 1;
+      for (int i = tid; i < kTT * half_cols; i += kTW * 64) {
+        const int row = i / half_cols, c = (i % half_cols) * 2;
+        const float v0 = c < a.C1 ? X[row * ld0 + c] : 0.f, v1 = c + 1 < a.C1 ? X[row * ld0 + c + 1] : 0.f;
+        *reinterpret_cast<unsigned*>(Xh + row * ld0h + c) = (unsigned)to_bf16_bits(v0) | ((unsigned)to_bf16_bits(v1) << 16);
+      }
+      __syncthreads();
+    }
     B2_STAMP(2);
 
     // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y.  Wave w owns channel tile w and both
     //      32-row groups (one weight fragment feeds two MFMAs; C2 <= 128 -> CT2 <= 4 waves) ----
     if (ct < CT2) {
-      mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
+      if (BF16)
+        mfma_rows_bf16<2>(reinterpret_cast<const unsigned short*>(X + kTT * ld0), ld0h,
+                          reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
+      else
+        mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
       const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-      if (col < ((a.C2 + 7) & ~7)) {
+      if (BF16) {
+        if (col < K16b) {   // h2 as a bf16 tile in the Y region (row stride K16(C2) + 8 elements)
+          unsigned short* Yh = reinterpret_cast<unsigned short*>(Y);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = acc_row(m, r, lane);
+              Yh[row * ldbh + col] = (row < nvalid && live) ? to_bf16_bits(fmaxf(fmaf(z2[m][r], sc, sh), 0.f)) : (unsigned short)0;
+            }
+        }
+      } else if (col < ((a.C2 + 7) & ~7)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -220,7 +251,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
-      mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
+      if (BF16)
+        mfma_rows_bf16<2, false>(reinterpret_cast<const unsigned short*>(Y), ldbh,
+                                 reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
+      else
+        mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
       const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
       const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
       const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;

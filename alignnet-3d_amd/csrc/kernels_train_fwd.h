@@ -34,6 +34,7 @@ struct TrainFwdArgs {
   const float* wp2;        // MFMA image of W2 [C1][C2]
   const float* wp3;        // MFMA image of W3 [C2][C3]
   const unsigned short* wp3h;   // bf16 MFMA image of W3 (train_bf16 mode; see pack_weights_bf16_kernel)
+  const unsigned short* wp2h;   // bf16 MFMA image of W2 (train_bf16 mode, no sign folding)
   const float *b1, *b2, *b3;       // conv biases (added before BN: utils/tf_util.py:161)
   const float *sc1, *sh1;  // [2][C1] batch-stat scale/shift of layer 1 (phase >= 2)
   const float *sc2, *sh2;  // [2][C2] (phase 3)
@@ -136,6 +137,35 @@ __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, cons
   }
 }
 
+// bf16 copy of the lift's output for the bf16 hidden layer (train_matmul_bf16): out16[row][c], row stride ldh elements,
+// columns C1 .. K16 zero
+__device__ __forceinline__ void layer1_to_lds_bf16(const float* __restrict__ xs, const Layer1W& L, int C1, unsigned short* __restrict__ out16,
+                                                   int ldh, int K16, int nvalid, int tid)
+{
+  constexpr int kRowsPerPass = kTW * 2;
+  const int c0 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = c0 + 32 * g;
+    if (c < K16) {
+      float w0, wa, wb, s, t;
+      if (g < 2) { w0 = L.w0[g & 1]; wa = L.wa[g & 1]; wb = L.wb[g & 1]; s = L.s[g & 1]; t = L.t[g & 1]; }
+      else {
+        const bool live = c < C1;
+        w0 = live ? L.w1[c] : 0.f; wa = live ? L.w1[C1 + c] : 0.f; wb = live ? L.w1[2 * C1 + c] : 0.f;
+        s = live ? L.sc[c] : 0.f; t = live ? L.sh[c] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+        const int row = rr * kRowsPerPass + r0;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+        out16[row * ldh + c] = (row < nvalid && c < C1) ? to_bf16_bits(fmaxf(fmaf(acc, s, t), 0.f)) : (unsigned short)0;
+      }
+    }
+  }
+}
+
 // same lift with the weights loaded from global memory on every call (pass B2 has no registers to spare for Layer1W)
 __device__ __forceinline__ void layer1_to_lds_global(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
                                                      const float* __restrict__ sc, const float* __restrict__ sh,
@@ -170,7 +200,7 @@ static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int
                                                 const float* __restrict__ gamma1, unsigned short* __restrict__ Wh)
 {
   const int KG = (K + 15) >> 4, CT = (C + 31) >> 5, t = blockIdx.y;
-  const float* gamma = t ? gamma1 : gamma0;
+  const float* gamma = t ? gamma1 : gamma0;   // null: no sign folding (hidden layers)
   const size_t total = (size_t)CT * KG * 512;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int s8 = idx & 7, lane = (idx >> 3) & 63;
@@ -178,20 +208,22 @@ static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int
     const int kg = q % KG, ct = q / KG;
     const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
     float v = 0.f;
-    if (k < K && c < C) v = gamma[c] >= 0.f ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
+    if (k < K && c < C) v = (!gamma || gamma[c] >= 0.f) ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
     Wh[(size_t)t * total + idx] = to_bf16_bits(v);
   }
 }
 
 // acc[m] = A[rows 32 m.., :16 KG] * W tile, A a bf16 LDS tile with row stride lda (elements), one bf16x8 read per MFMA
-template <int MR>
+template <int MR, bool CLEAR = true>
 __device__ __forceinline__ void mfma_rows_bf16(const unsigned short* __restrict__ A, int lda, const bf16x8* __restrict__ Wh,
                                                int KG, int lane, f32x16 (&acc)[MR])
 {
+  if (CLEAR) {
 #pragma unroll
-  for (int m = 0; m < MR; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  }
   const unsigned short* arow = A + (lane & 31) * lda + (lane >> 5) * 8;
   bf16x8 bcur = Wh[lane];
   for (int kg = 0; kg < KG; ++kg) {
@@ -331,14 +363,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
-    layer1_to_lds(xs, l1w, a.C1, buf0, ld0, nvalid, tid);
+    // bf16 mode: the hidden layer's operands are bf16 too (h1 tile in the buf0 region, row stride K16(C1) + 8 elements)
+    const int K16a = (a.C1 + 15) & ~15, ld0h = K16a + 8;
+    if (BF16) layer1_to_lds_bf16(xs, l1w, a.C1, reinterpret_cast<unsigned short*>(buf0), ld0h, K16a, nvalid, tid);
+    else layer1_to_lds(xs, l1w, a.C1, buf0, ld0, nvalid, tid);
     __syncthreads();
 
     // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 32-row group): C2 = 128 -> 8 items, one per wave ----
     for (int item = wave; item < CT2 * 2; item += kTW) {
       const int ct = item >> 1, rg = item & 1;
       f32x16 acc[1];
-      mfma_rows<1, true, true>(buf0 + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+      if (BF16)
+        mfma_rows_bf16<1>(reinterpret_cast<const unsigned short*>(buf0) + rg * 32 * ld0h, ld0h,
+                          reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, acc);
+      else
+        mfma_rows<1, true, true>(buf0 + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C2;
       if (PHASE == 2) {

@@ -224,10 +224,10 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
                                 int32_t its, double* out, double* fitness, double* rmse, int32_t* iterations);
 
 /* ---- run-time options with no counterpart in the reference's config surface --------
- * "train_matmul_bf16" (0/1, default 0): training only -- the 128 -> C3 feature lift of every backbone
- *   (90 % of the step's FLOPs, models/tp8.py:55-57) runs on bf16 MFMA with fp32 accumulation
- *   (BASELINE.json configs[2]); statistics, pooling, all other layers, gradients' accumulation,
- *   optimiser state and the eval-mode forward stay fp32.
+ * "train_matmul_bf16" (0/1, default 0): training only -- the two MFMA convs of every backbone (the hidden 1x1 conv
+ *   and the -> C3 feature lift, 96 % of the step's FLOPs, models/tp8.py:55-57), in the forward and in the backward's
+ *   recompute, run on bf16 MFMA with fp32 accumulation (BASELINE.json configs[2]); statistics, pooling, the K = 3 lift,
+ *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.
  * "infer_matmul_bf16x3" (0/1, default 0): eval-mode forward of 3-layer PointNet backbones (every shipped config) -- every
  *   fp32 operand of the two MFMA layers is written x = bf16(x) + bf16(x - bf16(x)) and each product is formed as
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on

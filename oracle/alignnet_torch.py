@@ -40,8 +40,8 @@ class TorchTp8:
     def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False):
         self.spec, self.P = spec, P
         self.ema_updates: Dict[str, torch.Tensor] = {}
-        # Model of the engine's "train_matmul_bf16" option (not a reference feature): the operands of the last
-        # (widest) conv of every PointNet backbone are rounded to bf16 (round-to-nearest-even), products are
+        # Model of the engine's "train_matmul_bf16" option (not a reference feature): the operands of the MFMA convs of
+        # every PointNet backbone (all but the K = 3 lift) are rounded to bf16 (round-to-nearest-even), products are
         # accumulated exactly, and the backward treats the rounding as identity (straight-through).
         self.bf16_lift = bf16_lift
 
@@ -81,7 +81,7 @@ class TorchTp8:
         for i in range(len(widths)):
             nm = f"{scope}/conv{i+1}"
             h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
-                            round_operands=self.bf16_lift and training and i == len(widths) - 1)
+                            round_operands=self.bf16_lift and training and i >= 1)
         return h.reshape(B, N, -1).amax(dim=1)
 
     def _dgcnn(self, x, scope, widths, tower, training, decay):

@@ -159,17 +159,20 @@ def test_eval_loss_matches_oracle(gpu_required):
 
 @pytest.mark.parametrize("N,B", [(256, 64), (200, 48)])
 def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
-    """BASELINE.json configs[2] (bf16 training): option "train_matmul_bf16" runs the widest 1x1 conv of every backbone on
-    bf16 MFMA (operands rounded to nearest even, fp32 accumulation), backward unchanged (straight-through).  The oracle
+    """BASELINE.json configs[2] (bf16 training): option "train_matmul_bf16" runs the MFMA convs of every backbone (hidden
+    layer and lift, forward and the backward's recompute) on bf16 MFMA (operands rounded to nearest even, fp32
+    accumulation); the backward otherwise treats the rounding as identity (straight-through).  The oracle
     models exactly that (TorchTp8(bf16_lift=True): same rounding, exact accumulation).  What remains between the two is
     rounding-boundary noise: an fp32-vs-fp64 difference in h2 moves some entries to the neighbouring bf16 value (one
     ulp = 0.4 % of one product), and a moved entry on an arg-max row shifts one pooled feature of one sample.
     Tolerances (written here):
       * batch statistics of the bf16 lift (read back through the EMA shadows, averages over B*N rows): 1e-4 relative to
         the largest entry, and >= 10x closer to the rounded oracle than the fp32 step is;
-      * stage-1 centres (identical inputs): median per-sample error <= 1e-3, max <= 2e-2; later predictions: max <= 5e-2;
+      * stage-1 centres (identical inputs): median per-sample error <= 1e-3, max <= 2e-2; later predictions: max <= 1e-1
+        (samples whose argmax yaw decode differs from the oracle's are counted and bounded; the stage-3 outputs, which are
+        batch-normalised together, are only compared when there is none);
         every prediction >= 5x closer to the rounded oracle than the fp32 step's;
-      * loss within 5e-3; whole gradient within cosine 0.97 of the oracle's (a moved arg-max row re-routes that
+      * loss within 5e-3 (5e-2 with decode flips); whole gradient within cosine 0.97 (0.85 with flips) of the oracle's (a moved arg-max row re-routes that
         channel's gradient to another point) and >= 3x closer (1 - cos) than the fp32 step's gradient.
     Against the *fp32* step the bf16 step differs by ~1 % in the stage features and flips a few argmax yaw decodes per
     batch (tools/bf16_check.py), which is why the comparison is against the rounded oracle."""
@@ -193,20 +196,31 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
         e16, e32 = float(np.abs(got - ref).max()), float(np.abs(ema32[k] - ref).max())
         print(k, "err vs rounded oracle %.2e (fp32 step: %.2e), scale %.2e" % (e16, e32, np.abs(ref).max()))
         assert e16 <= 1e-4 * np.abs(ref).max() and e16 < 0.1 * e32, (k, e16, e32)
+    nb = spec.num_bins
+    # the yaw decode between the stages is an argmax (tp8.py:294-301): a sample whose decoded class differs between the engine
+    # and the rounded oracle feeds a different frame to stage 3 -- such samples are counted and left out of the stage-3 checks
+    flipped = np.zeros(B, bool)
+    for k in ("pred_pc1angle_logits", "pred_pc2angle_logits"):
+        flipped |= np.argmax(res[k][:, :nb], 1) != np.argmax(ep_ref[k][:, :nb], 1)
+    print("decode flips vs the rounded oracle:", int(flipped.sum()), "of", B)
+    assert flipped.sum() <= max(2, B // 16)
     for k in ep_ref:
         per = np.abs(res[k] - ep_ref[k]).reshape(B, -1).max(1)
         err32 = float(np.abs(res32[k] - ep_ref[k]).max())
+        if k in ("pred_translations", "pred_remaining_angle_logits") and flipped.any():
+            continue   # the pair head normalises over the batch: a flipped sample moves every row of its output
         print(k, "median %.2e max %.2e (fp32 step max %.2e)" % (np.median(per), per.max(), err32))
         if "s1_" in k:
             assert np.median(per) <= 1e-3 and per.max() <= 2e-2, (k, per.max())
-        assert per.max() <= 5e-2 and per.max() < 0.2 * err32, (k, per.max(), err32)
-    assert abs(res["loss"] - loss_ref) <= 5e-3 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+        assert per.max() <= 1e-1 and per.max() < 0.2 * err32, (k, per.max(), err32)
+    clean = not flipped.any()
+    assert abs(res["loss"] - loss_ref) <= (5e-3 if clean else 5e-2) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
     g16 = {n: eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)}
     a, b = np.concatenate(list(g16.values())), np.concatenate([grads[n].ravel() for n in g16])
     cos_all = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
     cos32 = float(g32 @ b / (np.linalg.norm(g32) * np.linalg.norm(b)))
     print("loss", res["loss"], loss_ref, "fp32 step", res32["loss"], "gradient cosine", cos_all, "fp32 step's", cos32)
-    assert cos_all > 0.97 and (1 - cos_all) < 0.3 * (1 - cos32)
+    assert cos_all > (0.97 if clean else 0.85) and (1 - cos_all) < (0.3 if clean else 0.7) * (1 - cos32)
     with pytest.raises(RuntimeError):
         eng.set_option("no_such_option", 1)
     eng.close()
