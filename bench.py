@@ -125,7 +125,7 @@ def main():
 
     import torch
     import alignnet3d
-    from oracle import alignnet_ref as R  # synthetic input generator only (SURVEY 8d recipe)
+    from alignnet3d.synth import synth_pairs  # synthetic input generator (SURVEY 8d recipe); the oracle is only imported by cpu_baseline()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -161,7 +161,7 @@ def main():
         if name.endswith("moving_var"):
             eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
 
-    d = R.synth_pairs(B, npts, seed=1234 + rank, dtype=np.float32)
+    d = synth_pairs(B, npts, seed=1234 + rank, dtype=np.float32)
     p1 = torch.from_numpy(d["pcs1"]).to(dev)
     p2 = torch.from_numpy(d["pcs2"]).to(dev)
     nb2 = 2 * cfg["model"]["angles"]["num_bins"]
