@@ -36,6 +36,7 @@ def test_icp_matches_oracle(gpu_required):
     eng = alignnet3d.Engine(small_cfg(N=64, nb=12))
     src, dst, inits, truth = _pairs(7, seed=2)
     src.append(np.zeros((0, 3), np.float32)); dst.append(dst[0]); inits.append(np.eye(4)); truth.append(np.eye(4))   # empty source
+    src.append(src[0]); dst.append(np.zeros((0, 3), np.float32)); inits.append(inits[1]); truth.append(np.eye(4))    # empty target
     for radius, its in ((0.1, 30), (0.25, 3), (0.1, 0)):
         res = eng.icp_refine(src, dst, inits, radius=radius, its=its)
         for k in range(len(src)):
