@@ -571,7 +571,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.ld0 = ((C1 + 7) & ~7) + 4; b1.ldb = ((C2 + 7) & ~7) + 4;
   b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = S.rstd[0];
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
-  b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part;
+  b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
   b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = acc_in_b1 ? w->g1_part : nullptr;
   hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   if (acc_in_b1) layer2_weight_grad();

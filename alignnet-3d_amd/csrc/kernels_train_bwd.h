@@ -288,11 +288,26 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(9);
     // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
     {
+      if (BF16) {   // dy2 travels to pass B1 as bf16 in this mode (half the 268 MB per stage)
+        unsigned short* dsth = reinterpret_cast<unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+        const int c8 = a.C2 >> 3;
+        for (int i = tid; i < nvalid * c8; i += kTW * 64) {
+          const int row = i / c8, q = i % c8;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 8), v1 = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 8 + 4);
+          uint4 pk;
+          pk.x = (unsigned)to_bf16_bits(v0[0]) | ((unsigned)to_bf16_bits(v0[1]) << 16);
+          pk.y = (unsigned)to_bf16_bits(v0[2]) | ((unsigned)to_bf16_bits(v0[3]) << 16);
+          pk.z = (unsigned)to_bf16_bits(v1[0]) | ((unsigned)to_bf16_bits(v1[1]) << 16);
+          pk.w = (unsigned)to_bf16_bits(v1[2]) | ((unsigned)to_bf16_bits(v1[3]) << 16);
+          *reinterpret_cast<uint4*>(dsth + (size_t)row * a.C2 + q * 8) = pk;
+        }
+      } else {
       float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;   // C2 % 4 == 0 (multiple of 32 enforced on the host)
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
+      }
       }
       for (int item = wave; ACCUM && item < ((a.dbg & 64) ? 0 : CT1 * CT2); item += kTW) {
         const int it = item / CT2, jt = item % CT2;
@@ -331,6 +346,7 @@ struct BwdB1Args {
   float* dy1_store;                                  // [2B*N][C1]
   double* dbg1_part;                                 // [2B][4 = 2 row groups x 2 halves][C1][2]
   float* u2_part; float* g1_part;                    // [2B][C1*C2], [2B][C1*C1] (upper blocks) or null: accumulated in B2
+  int dy2_bf16;                                      // dy2_store holds bf16 (train_matmul_bf16)
 };
 
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
@@ -369,6 +385,20 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     __syncthreads();
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     {
+      if (a.dy2_bf16) {
+        const unsigned short* srch = reinterpret_cast<const unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+        const int c8 = a.C2 >> 3;
+        for (int i = tid; i < kTT * c8; i += kTW * 64) {
+          const int row = i / c8, q = i % c8;
+          uint4 pk = {0u, 0u, 0u, 0u};
+          if (row < nvalid) pk = *reinterpret_cast<const uint4*>(srch + (size_t)row * a.C2 + q * 8);
+          float* yo = Y + row * ldb + q * 8;
+          *reinterpret_cast<f32x4*>(yo) = f32x4{__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                                                __uint_as_float(pk.y & 0xffff0000u)};
+          *reinterpret_cast<f32x4*>(yo + 4) = f32x4{__uint_as_float(pk.z << 16), __uint_as_float(pk.z & 0xffff0000u), __uint_as_float(pk.w << 16),
+                                                    __uint_as_float(pk.w & 0xffff0000u)};
+        }
+      } else {
       const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c4 = a.C2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
@@ -376,6 +406,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
+      }
       }
     }
     __syncthreads();
