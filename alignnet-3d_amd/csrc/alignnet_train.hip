@@ -4,6 +4,7 @@
 #include "kernels_train_fwd.h"
 #include "kernels_train_head.h"
 #include "kernels_train_bwd.h"
+#include "kernels_train_dgcnn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -40,6 +41,10 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float* pooled; long tower_stride, row_stride;    // forward output (layout of the consumer)
   float* dP;                     // dL/dpooled, same layout
   float *gx, *grot;              // [2B][3], [2B]
+  // DGCNN branch (kernels_train_dgcnn.h); h2 holds the pooled edge features p = max_k h2
+  unsigned char* argk;           // [2B*N][C2] arg-max neighbour slot
+  double* mom;                   // [2B][27] moments of the edge feature
+  float* s1e;                    // [2][C1] column sums of h1 over the B*N*k edge rows
 };
 
 struct TrainWS {
@@ -59,6 +64,8 @@ struct TrainWS {
   // transient backward buffers (shared by the stages)
   double* stat_part; float* gram_part; double* colsum_part;
   float *dy2, *dy1;
+  int* nn;                       // DGCNN: [2B][N][20] neighbour indices
+  double* pdy_part;              // DGCNN: [2B][4][7][C1]
   double *dbg2_part, *dbg1_part, *s1_part; float *u2_part, *g1_part, *p_part;
   float *dbg2, *dbg1, *u2, *g1, *s1, *m1;
   float *E3, *kdb3, *gs, *Sp, *GW, *W3E, *W3T, *Q3, *q3b, *q3img;
@@ -115,13 +122,19 @@ static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 
 
 static int check_trainable_shape(alignnet_handle* h)
 {
-  if (h->cfg.backbone != 0) return fail(h, "training: dgcnn backbone is not implemented in this build");
+  const bool dg = h->cfg.backbone == 1;
+  if (dg && h->train_bf16) return fail(h, "training: the dgcnn backbone trains in fp32 only (unset train_matmul_bf16)");
+  if (dg && (h->cfg.num_points > 64 * kKnnMaxPerLane || h->cfg.num_points < kDgK))
+    return fail(h, "training: dgcnn needs 20 <= num_points <= 4096");
   for (int s = 0; s < 3; ++s) {
     const Stack& st = conv_of(h, s);
     if (st.n != 3) return fail(h, "training supports 3-conv-layer backbones (all shipped dataset configs); got " + std::to_string(st.n));
     const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
     if (C1 % 32 || C2 % 32 || C3 % 32) return fail(h, "training: conv widths must be multiples of 32");
     if (C1 > 128 || C2 > 128 || C3 > 1024) return fail(h, "training: conv widths limited to C1,C2 <= 128, C3 <= 1024");
+    const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
+    if (dg && CT1 * CT2 + CT1 * (CT1 + 1) / 2 > 3 * kTW)
+      return fail(h, "training: dgcnn edge widths too large for the register-resident weight-gradient blocks (e.g. 64,128 fits)");
   }
   return 0;
 }
@@ -185,6 +198,9 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       if (s < 2) { S.tower_stride = (long)B * C[2]; S.row_stride = C[2]; }
       else { S.tower_stride = C[2]; S.row_stride = 2L * C[2]; }
       S.gx = F(B2 * 3); S.grot = F(B2);
+      const bool dgb = h->cfg.backbone == 1;
+      S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
+      S.mom = D(dgb ? B2 * kDgMom : 0); S.s1e = F(2 * C[0]);
       const Stack& fs = fc_of(h, s);
       const size_t M = s < 2 ? B2 : (size_t)B;
       for (int j = 0; j < fs.n - 1; ++j) {
@@ -199,9 +215,10 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
-    w->dy2 = F(MN * maxC2); w->dy1 = F(MN * maxC1);
+    w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
+    w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(h->cfg.backbone == 1 ? B2 * 4 * 7 * maxC1 : 0);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 256);   // [2B][256 / C1 row groups][C1]
-    w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 3 * maxC1);
+    w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 6 * maxC1);
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
     w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
     w->E3 = F(2 * maxC3); w->kdb3 = F(2 * maxC3); w->gs = F(B2 * maxC3);
@@ -309,6 +326,11 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_fwd<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
 }
@@ -334,9 +356,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.gram_inline = ((C2 + 31) / 32) * ((C2 + 31) / 32 + 1) / 2 > 3 * kTW;   // never for C2 <= 128
   a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const double count = (double)B * N;
-  auto finish = [&](int l, int C, int slices) {
+  const bool dg = h->cfg.backbone == 1;
+  auto finish = [&](int l, int C, int slices, double cnt) {
     StatFinishArgs f;
-    f.part = w->stat_part; f.B = B; f.C = C; f.slices = slices; f.count = count; f.bias = P(h, L[l]->p_b);
+    f.part = w->stat_part; f.B = B; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L[l]->p_bn[t][0]); f.gamma[t] = P(h, L[l]->p_bn[t][1]);
       f.mov_mean[t] = P(h, L[l]->p_bn[t][2]); f.mov_var[t] = P(h, L[l]->p_bn[t][3]);
@@ -348,12 +371,34 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.rstd = S.rstd[l]; f.k = S.kk[l];
     hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, h->stream, f);
   };
+  if (dg) {
+    // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
+    const double ecount = count * kDgK;
+    DgTrainArgs d;
+    d.pcs[0] = p1; d.pcs[1] = p2; d.xform = S.xform; d.nn = w->nn; d.B = B; d.N = N; d.k = kDgK; d.C1 = C1; d.C2 = C2; d.ld0 = a.ld[0];
+    d.w1 = a.w1; d.b1 = a.b1; d.wp2 = a.wp2; d.b2 = a.b2; d.sc1 = a.sc1; d.sh1 = a.sh1; d.sc2 = a.sc2; d.sh2 = a.sh2;
+    d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part;
+    const size_t dlds = ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
+    hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
+    finish(0, C1, 1, ecount);
+    hipLaunchKernelGGL(dg_train_fwd<2>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    finish(1, C2, 2, ecount);
+    hipLaunchKernelGGL(dg_train_fwd<3>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    const int sG = std::max(1, 256 / C1);
+    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), S.s1e);
+    // point conv on the stored p
+    hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
+    finish(2, C3, 2, count);
+    launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
+    launch_reduce<double>(h, w->colsum_part, 2 * B, (long)(C2), S.s2);
+  } else {
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
-  finish(0, C1, 1);
+  finish(0, C1, 1, count);
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
   if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-  finish(1, C2, 4);
+  finish(1, C2, 4, count);
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
@@ -365,9 +410,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
                          w->gram_part);
   }
-  finish(2, C3, 2);
+  finish(2, C3, 2, count);
   launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
   launch_reduce<double>(h, w->colsum_part, 4 * B, (long)(C2), S.s2);
+  }
   hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
   const size_t tot = (size_t)2 * B * C3;
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),
@@ -480,6 +526,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + 1], &h->layers[st.first + 2]};
   const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
   const double M = (double)B * N;
+  const bool dg = h->cfg.backbone == 1;
+  const double Me = dg ? M * kDgK : M;   // rows behind the statistics of layers 1 and 2 (DGCNN: the B*N*k edge rows)
   const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
   auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
   auto g256t = [](size_t n) { return dim3((unsigned)((n + 255) / 256), 2); };
@@ -526,7 +574,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra;
-  if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  b2.h2_given = S.h2;
+  if (dg) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
@@ -545,7 +595,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   auto layer2_weight_grad = [&]() {
     launch_reduce<float>(h, w->u2_part, B, (long)(C1 * C2), w->u2);
     launch_reduce<float>(h, w->g1_part, B, (long)(C1 * C1), w->g1);
-    hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, M, w->m1);
+    hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, Me, w->m1);
     // GW2[t] = Ghat1[t] W2
     launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
     hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
@@ -553,10 +603,15 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   };
   launch_reduce<double>(h, w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2);
   const int sG = std::max(1, 256 / C1);
-  launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->s1);
-  launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->m1, 2, (float)(1.0 / M));   // m1 = s1 / M (qbias needs it before B1)
+  if (dg) {   // the forward kept the column sums of h1 (all edge rows)
+    launch_reduce<float>(h, S.s1e, 1, (long)(C1), w->s1);
+    launch_reduce<float>(h, S.s1e, 1, (long)(C1), w->m1, 2, (float)(1.0 / Me));
+  } else {
+    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->s1);
+    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->m1, 2, (float)(1.0 / M));   // m1 = s1 / M (qbias needs it before B1)
+  }
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
-                     P(h, L[1]->p_bn[1][1]), C2, M, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
+                     P(h, L[1]->p_bn[1][1]), C2, Me, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
                      G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
   if (!acc_in_b1) layer2_weight_grad();
   hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
@@ -564,7 +619,29 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
-  hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, M, w->q2b);
+  hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);
+  if (dg) {
+    // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
+    DgBwdArgs e;
+    e.pcs[0] = p1; e.pcs[1] = p2; e.xform = S.xform; e.nn = w->nn; e.B = B; e.N = N; e.k = kDgK; e.C1 = C1; e.C2 = C2;
+    e.ld0 = ((C1 + 7) & ~7) + 4; e.ldb = ((C2 + 7) & ~7) + 4;
+    e.w1 = P(h, L[0]->p_w); e.sc1 = S.scale[0]; e.sh1 = S.shift[0];
+    e.v2img = w->v2img; e.q2img = w->q2img; e.v2img_stride = (long)vimg; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
+    e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = w->g1_part; e.pdy_part = w->pdy_part;
+    const size_t elds = ((size_t)2 * kTT * 8 + (size_t)kTT * (e.ld0 + e.ldb)) * sizeof(float);
+    hipLaunchKernelGGL(dg_train_bwd_edge, dim3(2 * B), dim3(kTW * 64), elds, h->stream, e);
+    layer2_weight_grad();
+    DgB0Args z;
+    z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
+    for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
+    z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
+    hipLaunchKernelGGL(dg_b0_totals, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_cloud, dim3(2 * B), dim3(128), 0, h->stream, z);
+    launch_reduce<float>(h, w->p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
   // ---- pass B1 ----
   BwdB1Args b1;
   b1.pcs[0] = p1; b1.pcs[1] = p2; b1.xform = S.xform; b1.B = B; b1.N = N; b1.C1 = C1; b1.C2 = C2;
@@ -607,6 +684,8 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
+  if (h->cfg.backbone == 1)   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
+    hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn);
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 0, w->st[0].pooled, w->st[0].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;

@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t fkey(float f)
 }
 
 // grid: (ceil(N / 4), 2B), block 256 = 4 waves, one query point per wave
-__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+[[maybe_unused]] static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                  const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
 {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
   }
 }
 
-__global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
+[[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -45,6 +45,7 @@ struct BwdB2Args {
   double* s1_part;              // [2B][G = 256 / C1 row groups][C1]
   int dbg;
   long long* stamps;            // debug: s_memtime stamps of wave 0 / block 0 at the phase boundaries of tile 3
+  const float* h2_given;        // [2B*N][C2] (GIVEN variant)
 };
 
 // Work split in B2: item = (channel tile ct, 32-row group rg) = wave + 4*slot  (C2 <= 128 -> CT2*2 <= 8 items, two
@@ -53,7 +54,9 @@ struct BwdB2Args {
 #define B2_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // BF16: the hidden layer is recomputed exactly as the bf16 forward did (bf16 h1 tile x bf16 W2 image), and the h2 Q3 product
 // of dh2 takes h2 and Q3 as bf16 operands; accumulation, sparse rows, BN backward and all reductions stay fp32 / fp64.
-template <bool ACCUM, bool BF16 = false>
+// GIVEN (fp32, !ACCUM): Y is loaded from h2_given (the DGCNN branch's pooled edge features p = max_k h2) instead of being
+// recomputed; the relu mask is p > 0 and zhat at the arg-max slot follows from p itself: acc = (p - sh) / sc.
+template <bool ACCUM, bool BF16 = false, bool GIVEN = false>
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -120,6 +123,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     const bool first = tile == 0;
     __syncthreads();
     B2_STAMP(0);
+    if (GIVEN) {
+      const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+      const int c4 = a.C2 >> 2;
+      for (int i = tid; i < kTT * c4; i += kTW * 64) {
+        const int row = i / c4, q = i % c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
+      }
+    } else {
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     B2_STAMP(1);
@@ -167,6 +180,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           }
       }
     }
+    }   // !GIVEN
     B2_STAMP(3);
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
     for (int item = wave; ACCUM && item < ((a.dbg & 32) ? 0 : CT1 * CT1); item += kTW) {
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
       tile_commit(my_g1, a.C1, it, jt, a.C1, a.C1, g, lane, old);
     }
-    if (tid < sG * a.C1) {   // column sums of h1: sG row groups x C1 columns
+    if (!GIVEN && tid < sG * a.C1) {   // column sums of h1: sG row groups x C1 columns
       const int c = tid % a.C1, g = tid / a.C1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
@@ -260,13 +274,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
       const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
       float lb = 0.f, lg = 0.f;
+      const float isc = GIVEN ? 1.0f / sc : 0.f;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool on = acc_row(m, r, lane) < nvalid && fmaf(z2[m][r], sc, sh) > 0.f;
+          if (GIVEN) {
+            const float p = live ? Y[acc_row(m, r, lane) * ldb + col] : 0.f;
+            z2[m][r] = p > 0.f ? (p - sh) * isc : -INFINITY;   // the pre-BN accumulator at the arg-max slot (only used where p > 0)
+          }
+          const bool on = acc_row(m, r, lane) < nvalid && (GIVEN ? z2[m][r] != -INFINITY : fmaf(z2[m][r], sc, sh) > 0.f);
           const float dy = on ? acc[m][r] : 0.f;
-          lb += dy; lg += dy * ((z2[m][r] + bias - mu) * rs);
+          lb += dy; lg += (GIVEN && !on) ? 0.f : dy * ((z2[m][r] + bias - mu) * rs);
           z2[m][r] = dy;   // the registers now hold dy2
         }
       db += (double)lb; dg += (double)lg;
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;   // slice (half)
     d[0] = db; d[1] = dg;
   }
-  if (tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;   // [cloud][group][C1]
+  if (!GIVEN && tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,0 +1,589 @@
+// Training-mode forward / backward of the DGCNN backbone (models/tp8.py:30-46 with is_training=True,
+// utils/tf_util_dgcnn.py:638-706; BatchNorm with batch statistics utils/tf_util_dgcnn.py batch_norm_template), gfx950 only.
+//
+// Shape handled: widths [C1, C2, C3] = edge conv 6 -> C1, edge conv C1 -> C2 over the B*N*k edge rows, max over the k
+// neighbours, point conv C2 -> C3 over the B*N rows, max over the points.  The point conv and everything behind it is
+// the shared-MLP machinery (kernels_train_fwd.h / kernels_train_bwd.h) fed with the stored pooled edge features
+// p = max_k h2 instead of a recomputed h2 (their GIVEN variants).  What is new here is the edge part:
+//
+//   forward   phase 1: BN statistics of z1 = e W1 + b1.  z1 is linear in the 6-vector e = [x_i, x_j - x_i], so its
+//                      per-channel sum / sum of squares follow from the cloud's first and second moments of e
+//                      (27 numbers, fp64) -- no [B*N*k, C1] pass at all.
+//             phase 2: h1 = relu(bn1(z1)) recomputed per (tile, slot); statistics of z2 = h1 W2 + b2 (MFMA).
+//             phase 3: h1, h2 recomputed; running max over the k slots in registers with the arg-max slot;
+//                      p and arg-k stored ([B*N, C2] floats + bytes); column sums of p and of h1.
+//   backward  B2 (GIVEN) gives dp; only the arg-k row of each (point, channel) receives it:
+//                      dy2[n,s,c] = dp[n,c] [s == argk[n,c]] [p > 0].
+//             edge pass: per (tile, slot): h1_s recomputed, dy2_s built from the register-resident dp tile,
+//                      dh1 = dy2_s V2 + h1_s Q2 + q2b, dy1 = dh1 [h1 > 0]; U2 += h1_s^T dy2_s and Gram(h1) in registers;
+//                      dy1 is never stored: the first layer is linear in e, so dbeta1, dgamma1, dW1 and the per-cloud
+//                      frame gradients follow from  Pdy = sum e^T dy1 (6 x C1), sum dy1 (C1)  and the moments of e.
+#pragma once
+#include "kernels_train_bwd.h"
+#include "kernels_dgcnn.h"
+
+namespace alignnet {
+
+constexpr int kDgK = 20;          // neighbours per point (models/tp8.py:33)
+constexpr int kDgMom = 27;        // sum e (6) | upper triangle of sum e e^T (21, row-major d <= d2)
+
+struct DgTrainArgs {
+  const float* pcs[2]; const float* xform; const int* nn;   // nn: [2B][N][k]
+  int B, N, k, C1, C2;
+  int ld0;                        // LDS leading dim of the h1 tile
+  const float* w1; const float* b1;   // [6][C1], [C1]
+  const float* wp2; const float* b2;  // MFMA image of W2 [C1][C2], [C2]
+  const float *sc1, *sh1, *sc2, *sh2; // [2][C] batch-stat scale / shift (acc -> y)
+  double* mom;                    // [2B][27]                       (phase 1)
+  double* stat_part;              // phase 1: [2B][C1][2]; phase 2: [2B][2 halves][C2][2]
+  float* p_store;                 // [2B*N][C2]                     (phase 3)
+  unsigned char* argk;            // [2B*N][C2]
+  double* colsum_part;            // [2B][2 halves][C2]   column sums of p
+  double* s1_part;                // [2B][sG][C1]         column sums of h1 over all (point, slot) rows
+};
+
+__device__ __forceinline__ void dgt_gather(const float* __restrict__ pc, const int* __restrict__ nnc, int N, int k, int n, int slot,
+                                           float (&v)[6])
+{
+  const int j = nnc[(size_t)n * k + slot];
+  const float* p = pc + (size_t)n * 3;
+  const float* pj = pc + (size_t)j * 3;
+  v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  v[3] = pj[0] - p[0]; v[4] = pj[1] - p[1]; v[5] = pj[2] - p[2];
+}
+
+// ---------------------------------------------------------------------------------
+// phase 1: moments of e per cloud -> statistics of z1.   grid 2B, block 256
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dg_train_phase1(const DgTrainArgs a)
+{
+  __shared__ double red[4][kDgMom];
+  __shared__ double tot[kDgMom];
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
+  double m[kDgMom];
+#pragma unroll
+  for (int i = 0; i < kDgMom; ++i) m[i] = 0.0;
+  const int rows = a.N * a.k;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int n = r / a.k, slot = r - n * a.k;
+    float v[6], e[6];
+    dgt_gather(pc, nnc, a.N, a.k, n, slot, v);
+    dg_edge_to_lds(xf, v, e);
+    int q = 6;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      m[d] += (double)e[d];
+#pragma unroll
+      for (int d2 = d; d2 < 6; ++d2) m[q++] += (double)e[d] * (double)e[d2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kDgMom; ++i) {
+    double v = m[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kDgMom) {
+    const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    tot[threadIdx.x] = t;
+    a.mom[(size_t)cloud * kDgMom + threadIdx.x] = t;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C1; c += 256) {
+    double w[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
+    double sw = 0.0, qd = 0.0;
+    int q = 6;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      sw += w[d] * tot[d];
+#pragma unroll
+      for (int d2 = d; d2 < 6; ++d2) qd += (d == d2 ? 1.0 : 2.0) * w[d] * w[d2] * tot[q++];
+    }
+    const double bb = (double)a.b1[c], n = (double)rows;
+    a.stat_part[((size_t)cloud * a.C1 + c) * 2] = sw + n * bb;
+    a.stat_part[((size_t)cloud * a.C1 + c) * 2 + 1] = qd + 2.0 * bb * sw + n * bb * bb;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// K = 6 lift on the VALU (256 threads): out[row][c] = relu((e . w[:,c]) * sc + sh), rows >= nvalid are written as 0.
+// Channel groups c0, c0 + 32 keep their weights in registers for the whole cloud; wider first layers reload per call.
+// ---------------------------------------------------------------------------------
+struct DgtLiftW { float w[2][6]; float sc[2], sh[2]; };
+
+__device__ __forceinline__ DgtLiftW dgt_lift_load(const float* __restrict__ w1, int C1, const float* __restrict__ sc,
+                                                  const float* __restrict__ sh, int tid)
+{
+  DgtLiftW R;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = (tid & 31) + 32 * g;
+    const bool live = c < C1;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) R.w[g][d] = live ? w1[d * C1 + c] : 0.f;
+    R.sc[g] = live ? sc[c] : 0.f;
+    R.sh[g] = live ? sh[c] : 0.f;
+  }
+  return R;
+}
+
+__device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restrict__ w1, int C1, const float* __restrict__ sc,
+                                         const float* __restrict__ sh, const float* __restrict__ es, float* __restrict__ out, int ldo,
+                                         int nvalid, int tid)
+{
+  const int c0 = tid & 31, r0 = tid >> 5;   // 8 row groups
+  const int cw = (C1 + 7) & ~7;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = c0 + 32 * g;
+    if (c < cw) {
+      float w[6], s, t;
+      if (g < 2) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) w[d] = R.w[g & 1][d];
+        s = R.sc[g & 1]; t = R.sh[g & 1];
+      } else {
+        const bool live = c < C1;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) w[d] = live ? w1[d * C1 + c] : 0.f;
+        s = live ? sc[c] : 0.f; t = live ? sh[c] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < kTT / 8; ++rr) {
+        const int row = rr * 8 + r0;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+        float acc = e0[0] * w[0];
+        acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
+        acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
+        out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// phases 2 and 3: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
+// edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
+// the gather for the next slot is in flight during this slot's MFMAs).
+// ---------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
+  float* es = smem;
+  const int ld0 = a.ld0;
+  const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
+  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const int ct = wave, col = ct * 32 + (lane & 31);
+  const bool mine = ct < CT2, live = mine && col < a.C2;
+  const float bias = live ? a.b2[col] : 0.f;
+  const float sc = (PHASE == 3 && live) ? a.sc2[tower * a.C2 + col] : 0.f, sh = (PHASE == 3 && live) ? a.sh2[tower * a.C2 + col] : 0.f;
+  const float* sc1 = a.sc1 + tower * a.C1;
+  const float* sh1 = a.sh1 + tower * a.C1;
+  const DgtLiftW lw = dgt_lift_load(a.w1, a.C1, sc1, sh1, tid);
+  // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups)
+  const bool wreg = KG2 <= 8;
+  f32x4 breg[8];
+  if (wreg && mine) {
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + min(kg, KG2 - 1)) * 64 + lane];
+  }
+  const int sG = max(1, (kTW * 64) / a.C1);
+  double ds = 0.0, dss = 0.0, dcs = 0.0, s1c = 0.0;
+  f32x16 best[2];
+  int bk[2][16];
+
+  float v[6];
+  if (tid < kTT) {
+    dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
+    dg_edge_to_lds(xf, v, es + tid * 8);
+  }
+  __syncthreads();
+  dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, smem + kTT * 8, ld0, min(kTT, a.N), tid);
+  __syncthreads();
+  for (int it = 0; it < total; ++it) {
+    const int tile = it / a.k, slot = it - tile * a.k;
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    const bool more = it + 1 < total;
+    const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
+    if (more && tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);   // in flight during the MFMAs
+    const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
+    if (PHASE == 3 && slot == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { best[m][r] = -INFINITY; bk[m][r] = 0; }
+    }
+    if (mine) {
+      f32x16 acc[2];
+      if (wreg) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const float* arow = X + (lane & 31) * ld0 + half * 4;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg)
+          if (kg < KG2) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + kg * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 32 * ld0 + kg * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[kg][s], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[kg][s], acc[1], 0, 0, 0);
+            }
+          }
+      } else {
+        mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+      }
+      if (PHASE == 2) {
+        // shifted fp32 sums of this slot's <= 32 values per lane, folded into the fp64 running sums (kernels_train_fwd.h)
+        const float z0 = acc[0][0] + bias;
+        float s1 = 0.f, s2 = 0.f; int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (acc_row(m, r, lane) < nvalid) {
+              const float dlt = (acc[m][r] + bias) - z0;
+              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
+            }
+        const double zd = (double)z0, n = (double)cnt;
+        ds += (double)s1 + n * zd;
+        dss += (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float y = fmaf(acc[m][r], sc, sh);
+            if (y > best[m][r]) { best[m][r] = y; bk[m][r] = slot; }   // first slot wins ties
+          }
+        if (slot == a.k - 1) {
+          float lsum = 0.f;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = acc_row(m, r, lane);
+              if (row < nvalid && live) {
+                const float p = fmaxf(best[m][r], 0.f);
+                const size_t o = ((size_t)cloud * a.N + (size_t)tile * kTT + row) * a.C2 + col;
+                a.p_store[o] = p;
+                a.argk[o] = (unsigned char)bk[m][r];
+                lsum += p;
+              }
+            }
+          dcs += (double)lsum;
+        }
+      }
+    }
+    if (PHASE == 3 && tid < sG * a.C1) {   // column sums of h1 (rows past nvalid are zero)
+      const int c = tid % a.C1, g = tid / a.C1;
+      float sm = 0.f;
+      for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
+      s1c += (double)sm;
+    }
+    if (more && tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
+    __syncthreads();
+    if (more) dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
+    __syncthreads();
+  }
+  if (PHASE == 2 && live) {
+    double* st = a.stat_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;
+    st[0] = ds; st[1] = dss;
+  }
+  if (PHASE == 3) {
+    if (live) a.colsum_part[((size_t)cloud * 2 + half) * a.C2 + col] = dcs;
+    if (tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// backward edge pass (see the header comment).  LDS: es [2][64][8] | X = h1_s [64][ld0] | Y = dy2_s [64][ldb].
+// The tile's dp values and arg-k bytes sit in registers (8 float4 + 8 packed words per thread at C2 = 128) and are
+// masked into Y once per slot.
+// ---------------------------------------------------------------------------------
+struct DgBwdArgs {
+  const float* pcs[2]; const float* xform; const int* nn; int B, N, k, C1, C2;
+  int ld0, ldb;
+  const float* w1; const float *sc1, *sh1;
+  const float* v2img; const float* q2img; long v2img_stride, q2img_stride;   // per-tower MFMA images: V2 [C2][C1], Q2 [C1][C1]
+  const float* q2b;                    // [2][C1]
+  const float* dyp;                    // [2B*N][C2]  dp * [p > 0]   (pass B2, GIVEN)
+  const unsigned char* argk;           // [2B*N][C2]
+  float* u2_part; float* g1_part;      // [2B][C1*C2], [2B][C1*C1] (upper blocks)
+  double* pdy_part;                    // [2B][4 = 2 row groups x 2 halves][7][C1]: sum e_d dy1 (d < 6), sum dy1
+};
+
+__global__ __launch_bounds__(kTW * 64, 2) void dg_train_bwd_edge(const DgBwdArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
+  const int ld0 = a.ld0, ldb = a.ldb;
+  float* X = smem + 2 * kTT * 8;
+  float* Y = X + kTT * ld0;
+  const int CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGv = (a.C2 + 7) >> 3, KGq = (a.C1 + 7) >> 3;
+  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
+  const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
+  const float* sc1 = a.sc1 + tower * a.C1;
+  const float* sh1 = a.sh1 + tower * a.C1;
+  const DgtLiftW lw = dgt_lift_load(a.w1, a.C1, sc1, sh1, tid);
+  const int nitems = CT1 * 2;
+  constexpr int kAccSlots = 3, kItemSlots = 2, kDP = 8;
+  const int nblk_u = CT1 * CT2, nblk = nblk_u + CT1 * (CT1 + 1) / 2;
+  f32x16 gacc[kAccSlots];
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+  double pd[kItemSlots][7];
+  float pf[kItemSlots][7];
+#pragma unroll
+  for (int q = 0; q < kItemSlots; ++q)
+#pragma unroll
+    for (int d = 0; d < 7; ++d) { pd[q][d] = 0.0; pf[q][d] = 0.f; }
+  const int c4 = a.C2 >> 2;
+  f32x4 dp[kDP];
+  unsigned ak[kDP];
+
+  float v[6];
+  if (tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
+  for (int it = 0; it < total; ++it) {
+    const int tile = it / a.k, slot = it - tile * a.k;
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    const bool more = it + 1 < total;
+    float* es = smem + (it & 1) * kTT * 8;
+    if (slot == 0) {
+      const size_t base = ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+#pragma unroll
+      for (int u = 0; u < kDP; ++u) {
+        const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
+        const bool ok = i < kTT * c4 && row < nvalid;
+        dp[u] = ok ? *reinterpret_cast<const f32x4*>(a.dyp + base + (size_t)row * a.C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ak[u] = ok ? *reinterpret_cast<const unsigned*>(a.argk + base + (size_t)row * a.C2 + q * 4) : 0xffffffffu;
+      }
+    }
+    if (tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
+    __syncthreads();   // es ready; every wave is done with the previous slot's X / Y
+    if (more && tid < kTT) {
+      const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
+      dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);
+    }
+    dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, X, ld0, nvalid, tid);
+#pragma unroll
+    for (int u = 0; u < kDP; ++u) {
+      const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
+      if (i < kTT * c4) {
+        const unsigned m = ak[u], s = (unsigned)slot;
+        const f32x4 y = {(m & 0xffu) == s ? dp[u][0] : 0.f, ((m >> 8) & 0xffu) == s ? dp[u][1] : 0.f,
+                         ((m >> 16) & 0xffu) == s ? dp[u][2] : 0.f, (m >> 24) == s ? dp[u][3] : 0.f};
+        *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = y;
+      }
+    }
+    __syncthreads();
+    // ---- U2 += h1_s^T dy2_s, Gram(h1) += h1_s^T h1_s (upper blocks), register-resident for the whole cloud ----
+#pragma unroll
+    for (int q = 0; q < kAccSlots; ++q) {
+      const int item = wave + q * kTW;
+      if (item < nblk) {
+        int itb, jt, ldr;
+        const float* pb;
+        if (item < nblk_u) { itb = item / CT2; jt = item % CT2; pb = Y + half * ldb; ldr = ldb; }
+        else {
+          int rem = item - nblk_u; itb = 0;
+          while (rem >= CT1 - itb) { rem -= CT1 - itb; ++itb; }
+          jt = itb + rem; pb = X + half * ld0; ldr = ld0;
+        }
+        const float* pa = X + half * ld0 + itb * 32 + (lane & 31);
+        pb += jt * 32 + (lane & 31);
+#pragma unroll 8
+        for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldr], gacc[q], 0, 0, 0);
+      }
+    }
+    // ---- dh1 = dy2_s V2 + h1_s Q2 + q2b ; dy1 = dh1 [h1 > 0] ; Pdy += e^T dy1 ----
+#pragma unroll
+    for (int qi = 0; qi < kItemSlots; ++qi) {
+      const int item = wave + qi * kTW;
+      if (item < nitems) {
+        const int ct = item >> 1, rg = item & 1;
+        const int col = ct * 32 + (lane & 31);
+        const bool live = col < a.C1;
+        const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = qb;
+        mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, v2img + (size_t)ct * KGv * 64, KGv, lane, acc);
+        mfma_rows<1, false, false>(X + rg * 32 * ld0, ld0, q2img + (size_t)ct * KGq * 64, KGq, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
+          const float dy = on ? acc[0][r] : 0.f;
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+          pf[qi][0] = fmaf(e0[0], dy, pf[qi][0]); pf[qi][1] = fmaf(e0[1], dy, pf[qi][1]); pf[qi][2] = fmaf(e0[2], dy, pf[qi][2]);
+          pf[qi][3] = fmaf(e0[3], dy, pf[qi][3]); pf[qi][4] = fmaf(e1[0], dy, pf[qi][4]); pf[qi][5] = fmaf(e1[1], dy, pf[qi][5]);
+          pf[qi][6] += dy;
+        }
+        if (slot == a.k - 1) {   // fp32 partial sums of one tile (k * 16 terms per lane) folded into fp64
+#pragma unroll
+          for (int d = 0; d < 7; ++d) { pd[qi][d] += (double)pf[qi][d]; pf[qi][d] = 0.f; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q) {
+    const int item = wave + q * kTW;
+    if (item < nblk) {
+      const float zero[16] = {};
+      if (item < nblk_u) {
+        tile_commit(a.u2_part + (size_t)cloud * a.C1 * a.C2, a.C2, item / CT2, item % CT2, a.C1, a.C2, gacc[q], lane, zero);
+      } else {
+        int rem = item - nblk_u, itb = 0;
+        while (rem >= CT1 - itb) { rem -= CT1 - itb; ++itb; }
+        tile_commit(a.g1_part + (size_t)cloud * a.C1 * a.C1, a.C1, itb, itb + rem, a.C1, a.C1, gacc[q], lane, zero);
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < kItemSlots; ++qi) {
+    const int item = wave + qi * kTW;
+    if (item < nitems) {
+      const int ct = item >> 1, rg = item & 1, col = ct * 32 + (lane & 31);
+      if (col < a.C1) {
+        double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * a.C1 + col;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) dst[(size_t)d * a.C1] = pd[qi][d];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// first-layer backward from the reduced quantities (no [B*N*k, C1] tensor is read):
+//   dz1_r = k (dy1_r - dbeta/M - zhat_r dgamma/M),  zhat_r = (e_r . w_c + b - mu) rstd
+//   dbeta = sum sdy,  dgamma = rstd (sum_d w_dc Pdy_dc + (b - mu) sdy)                                (dg_b0_totals)
+//   per cloud:  P_dc = sum_r e_rd dz1_rc = k [Pdy_dc - mb Se_d - mg rstd (sum_d' Ge_dd' w_d'c + (b - mu) Se_d)]
+//               S_c  = sum_r dz1_rc      = k [sdy_c - n mb - mg rstd (Se . w_c + n (b - mu))]
+//               gx_d = sum_c w_dc S_c (d < 3),  grot = sum_c (w_0c P_1c - w_1c P_0c + w_3c P_4c - w_4c P_3c)   (dg_b0_cloud)
+//   dW1 = sum over clouds of P.
+// ---------------------------------------------------------------------------------
+struct DgB0Args {
+  const double* pdy_part;   // [2B][4][7][C1]
+  const double* mom;        // [2B][27]
+  const float* w1; const float* b1; const float *mean1, *rstd1, *k1;   // [6][C1], [C1], [2][C1] x 3
+  int B, C1, rows;          // rows per cloud = N * k
+  double count;             // M = B * N * k
+  float* dbeta[2]; float* dgamma[2];
+  float* dbg1;              // [2][C1][2] totals (dbeta1, dgamma1)
+  float* p_part;            // [2B][6][C1]
+  float* gx; float* grot;   // [2B][3], [2B]
+};
+
+__global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid (ceil(C1/32), 2), block 32 channels x 32 cloud groups
+{
+  __shared__ double red[32][32][2];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  double sdy = 0.0, wp = 0.0;
+  if (c < a.C1) {
+    double w[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
+    for (int bs = g; bs < a.B * 4; bs += 32) {
+      const double* p = a.pdy_part + ((size_t)t * a.B * 4 + bs) * 7 * a.C1 + c;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) wp += w[d] * p[(size_t)d * a.C1];
+      sdy += p[(size_t)6 * a.C1];
+    }
+  }
+  red[g][cl][0] = sdy; red[g][cl][1] = wp;
+  __syncthreads();
+  if (g != 0 || c >= a.C1) return;
+  sdy = 0.0; wp = 0.0;
+  for (int q = 0; q < 32; ++q) { sdy += red[q][cl][0]; wp += red[q][cl][1]; }
+  const double dg = (double)a.rstd1[t * a.C1 + c] * (wp + ((double)a.b1[c] - (double)a.mean1[t * a.C1 + c]) * sdy);
+  a.dbeta[t][c] = (float)sdy;
+  a.dgamma[t][c] = (float)dg;
+  a.dbg1[(t * a.C1 + c) * 2] = (float)sdy;
+  a.dbg1[(t * a.C1 + c) * 2 + 1] = (float)dg;
+}
+
+__global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2B, block 128 (C1 <= 128)
+{
+  __shared__ double mo[kDgMom];
+  __shared__ double red[2][4];
+  const int cloud = blockIdx.x, t = cloud >= a.B, c = threadIdx.x;
+  if (threadIdx.x < kDgMom) mo[threadIdx.x] = a.mom[(size_t)cloud * kDgMom + threadIdx.x];
+  __syncthreads();
+  double g[4] = {0.0, 0.0, 0.0, 0.0};   // gx0, gx1, gx2, grot
+  if (c < a.C1) {
+    double w[6], pdy[7];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+      double s = 0.0;
+      for (int sl = 0; sl < 4; ++sl) s += a.pdy_part[(((size_t)cloud * 4 + sl) * 7 + d) * a.C1 + c];
+      pdy[d] = s;
+    }
+    const double k = (double)a.k1[t * a.C1 + c], rs = (double)a.rstd1[t * a.C1 + c];
+    const double bm = (double)a.b1[c] - (double)a.mean1[t * a.C1 + c];
+    const double mb = (double)a.dbg1[(t * a.C1 + c) * 2] / a.count, mg = (double)a.dbg1[(t * a.C1 + c) * 2 + 1] / a.count;
+    const double n = (double)a.rows;
+    // symmetric second moment: index of (d, d2), d <= d2, in the packed upper triangle
+    double P[6];
+    double sew = 0.0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) sew += mo[d] * w[d];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      double gw = 0.0;
+#pragma unroll
+      for (int d2 = 0; d2 < 6; ++d2) {
+        const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
+        const int q = 6 + lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+        gw += mo[q] * w[d2];
+      }
+      P[d] = k * (pdy[d] - mb * mo[d] - mg * rs * (gw + bm * mo[d]));
+      a.p_part[((size_t)cloud * 6 + d) * a.C1 + c] = (float)P[d];
+    }
+    const double S = k * (pdy[6] - n * mb - mg * rs * (sew + n * bm));
+    g[0] = w[0] * S; g[1] = w[1] * S; g[2] = w[2] * S;
+    g[3] = w[0] * P[1] - w[1] * P[0] + w[3] * P[4] - w[4] * P[3];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double v = g[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) a.gx[cloud * 3 + threadIdx.x] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x]);
+  if (threadIdx.x == 3) a.grot[cloud] = (float)(red[0][3] + red[1][3]);
+}
+
+}  // namespace alignnet

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
 // tile, no atomics): every accumulator element has exactly one owner lane, so the result is deterministic.
 // Slice layout: part[(cloud * S + slice) * n + i]; the two half-waves of a column are slices 0/1.
 // ---------------------------------------------------------------------------------
-template <int PHASE, bool BF16 = false>
+// GIVEN (phase 3, fp32): the tile of hidden features is read from h2_store (the DGCNN branch's pooled edge features,
+// kernels_train_dgcnn.h) instead of being recomputed from xyz; column sums and the store belong to the producer.
+template <int PHASE, bool BF16 = false, bool GIVEN = false>
 __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -361,6 +363,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
+    if (GIVEN) {
+      const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
+      const int c4 = a.C2 >> 2;
+      for (int i = tid; i < kTT * c4; i += kTW * 64) {
+        const int row = i / c4, q = i % c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        *reinterpret_cast<f32x4*>(buf1 + row * ld1 + q * 4) = v;
+      }
+    } else {
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     // bf16 mode: the hidden layer's operands are bf16 too (h1 tile in the buf0 region, row stride K16(C1) + 8 elements)
@@ -438,11 +450,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         }
       }
     }
+    }   // !GIVEN
     if (PHASE == 2) continue;
     __syncthreads();
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-    if (BF16 && !(a.dbg & 2)) {
+    if (GIVEN) {
+    } else if (BF16 && !(a.dbg & 2)) {
       unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
       const int c8 = a.C2 >> 3;
       for (int i = tid; i < nvalid * c8; i += kTW * 64) {

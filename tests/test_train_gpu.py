@@ -224,3 +224,64 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
     with pytest.raises(RuntimeError):
         eng.set_option("no_such_option", 1)
     eng.close()
+
+
+def _setup_dgcnn(N, B, seed=7):
+    cfg = small_cfg(N=N, s1=(32, 64, 96), s2=(32, 64, 128), emb=(64, 128, 160), fc=(64, 32), backbone="dgcnn")
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=seed)
+    d = R.synth_pairs(B, N, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    return cfg, spec, P32, d, du
+
+
+@pytest.mark.parametrize("N,B", [(128, 6), (96, 4)])
+def test_dgcnn_train_forward_loss_ema(gpu_required, N, B):
+    """DGCNN branch (tp8.py:30-46) in training mode: batch statistics over the B*N*k edge rows, EMA, loss."""
+    cfg, spec, P32, d, du = _setup_dgcnn(N, B)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    st = eng.state()
+    ep_ref, loss_ref, _, ema_ref = _oracle(cfg, P32, d, du, st["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    worst = 0.0
+    for k, v in ema_ref.items():
+        got = eng.get_variable(k)
+        np.testing.assert_allclose(got, v, rtol=1e-4, atol=1e-5, err_msg=k)
+        worst = max(worst, float(np.abs(got - v).max()))
+    print("dgcnn loss", res["loss"], loss_ref, "worst EMA abs err", worst)
+    eng.close()
+
+
+@pytest.mark.parametrize("N,B,tol", [(128, 8, 2e-3), (96, 4, 1e-2)])
+def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol):
+    """Every trainable tensor of the DGCNN model against torch autograd (fp64), same criterion as the PointNet test."""
+    cfg, spec, P32, d, du = _setup_dgcnn(N, B)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    report, bad = {}, {}
+    bn_bias = set()
+    for L in R.layer_table(spec):
+        if L.bn:
+            bn_bias.add((f"siamese/{L.name}" if L.siamese else L.name) + "/biases")
+    for name in R.trainable_names(spec):
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        if name in bn_bias:
+            assert np.abs(g).max() == 0.0 and np.abs(ref).max() < 1e-9 * gscale, name
+            continue
+        err = float(np.abs(g - ref).max())
+        report[name] = err / (float(np.abs(ref).max()) + 1e-30)
+        if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    real = {k: v for k, v in report.items() if np.abs(grads[k]).max() > 1e-6 * gscale}
+    print("dgcnn worst relative gradient errors:", sorted(real.items(), key=lambda kv: -kv[1])[:8])
+    assert not bad, bad
+    eng.close()
