@@ -133,8 +133,9 @@ static int check_trainable_shape(alignnet_handle* h)
     if (C1 % 32 || C2 % 32 || C3 % 32) return fail(h, "training: conv widths must be multiples of 32");
     if (C1 > 128 || C2 > 128 || C3 > 1024) return fail(h, "training: conv widths limited to C1,C2 <= 128, C3 <= 1024");
     const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
-    if (dg && CT1 * CT2 + CT1 * (CT1 + 1) / 2 > 3 * kTW)
-      return fail(h, "training: dgcnn edge widths too large for the register-resident weight-gradient blocks (e.g. 64,128 fits)");
+    if (dg && ((C1 != 32 && C1 != 64) || (C2 != 64 && C2 != 128) || CT1 * 2 + CT1 * (CT1 + 1) / 2 > kBEW || (size_t)C1 * C2 > 8192 || dg_bwd_edge_lds(C1, C2) > 160 * 1024))
+      return fail(h, "training: dgcnn edge-conv widths limited to C1 in {32, 64}, C2 in {64, 128} (e.g. 64,128)");
+    (void)CT2;
   }
   return 0;
 }
@@ -328,9 +329,10 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_fwd<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
 }
@@ -381,9 +383,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t dlds = ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
     finish(0, C1, 1, ecount);
-    hipLaunchKernelGGL(dg_train_fwd<2>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    if (C1 == 64) hipLaunchKernelGGL((dg_train_fwd<2, 64>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    else hipLaunchKernelGGL((dg_train_fwd<2, 32>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     finish(1, C2, 2, ecount);
-    hipLaunchKernelGGL(dg_train_fwd<3>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    if (C1 == 64) hipLaunchKernelGGL((dg_train_fwd<3, 64>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    else hipLaunchKernelGGL((dg_train_fwd<3, 32>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     const int sG = std::max(1, 256 / C1);
     launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), S.s1e);
     // point conv on the stored p
@@ -624,12 +628,25 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
     DgBwdArgs e;
     e.pcs[0] = p1; e.pcs[1] = p2; e.xform = S.xform; e.nn = w->nn; e.B = B; e.N = N; e.k = kDgK; e.C1 = C1; e.C2 = C2;
-    e.ld0 = ((C1 + 7) & ~7) + 4; e.ldb = ((C2 + 7) & ~7) + 4;
+    e.ld0 = ((C1 + 7) & ~7) + 4;
     e.w1 = P(h, L[0]->p_w); e.sc1 = S.scale[0]; e.sh1 = S.shift[0];
-    e.v2img = w->v2img; e.q2img = w->q2img; e.v2img_stride = (long)vimg; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
+    e.v2 = w->V2; e.v2_stride = (long)C1 * C2; e.q2img = w->q2img; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
     e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = w->g1_part; e.pdy_part = w->pdy_part;
-    const size_t elds = ((size_t)2 * kTT * 8 + (size_t)kTT * (e.ld0 + e.ldb)) * sizeof(float);
-    hipLaunchKernelGGL(dg_train_bwd_edge, dim3(2 * B), dim3(kTW * 64), elds, h->stream, e);
+    e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
+    const dim3 eg(2 * B), eb(kBEW * 64);
+    const size_t el = dg_bwd_edge_lds(C1, C2);
+    if (C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128>), eg, eb, el, h->stream, e);
+    else if (C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64>), eg, eb, el, h->stream, e);
+    else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
+    else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
+    if (e.stamps) {
+      long long st[8];
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(st, e.stamps, sizeof(st), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "BE stage %d it-25 phase cycles:", s);
+      for (int i = 1; i < 8; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n");
+    }
     layer2_weight_grad();
     DgB0Args z;
     z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);

@@ -135,11 +135,13 @@ __device__ __forceinline__ DgtLiftW dgt_lift_load(const float* __restrict__ w1, 
   return R;
 }
 
+template <int NT = kTW * 64>
 __device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restrict__ w1, int C1, const float* __restrict__ sc,
                                          const float* __restrict__ sh, const float* __restrict__ es, float* __restrict__ out, int ldo,
                                          int nvalid, int tid)
 {
-  const int c0 = tid & 31, r0 = tid >> 5;   // 8 row groups
+  constexpr int kRG = NT / 32;                // row groups
+  const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (C1 + 7) & ~7;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -157,8 +159,8 @@ __device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restr
         s = live ? sc[c] : 0.f; t = live ? sh[c] : 0.f;
       }
 #pragma unroll
-      for (int rr = 0; rr < kTT / 8; ++rr) {
-        const int row = rr * 8 + r0;
+      for (int rr = 0; rr < kTT / kRG; ++rr) {
+        const int row = rr * kRG + r0;
         const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
         const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
         float acc = e0[0] * w[0];
@@ -175,7 +177,9 @@ __device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restr
 // edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
 // the gather for the next slot is in flight during this slot's MFMAs).
 // ---------------------------------------------------------------------------------
-template <int PHASE>
+// C1 is a template parameter: with a compile-time LDS row stride the per-row tile addresses are immediate offsets; as
+// run-time values the compiler hoists them out of the slot loop into ~50 registers and spills.
+template <int PHASE, int C1>
 __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -186,16 +190,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
   float* es = smem;
-  const int ld0 = a.ld0;
-  const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
+  constexpr int ld0 = C1 + 4;
+  const int KG2 = (C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool mine = ct < CT2, live = mine && col < a.C2;
   const float bias = live ? a.b2[col] : 0.f;
   const float sc = (PHASE == 3 && live) ? a.sc2[tower * a.C2 + col] : 0.f, sh = (PHASE == 3 && live) ? a.sh2[tower * a.C2 + col] : 0.f;
-  const float* sc1 = a.sc1 + tower * a.C1;
-  const float* sh1 = a.sh1 + tower * a.C1;
-  const DgtLiftW lw = dgt_lift_load(a.w1, a.C1, sc1, sh1, tid);
+  const float* sc1 = a.sc1 + tower * C1;
+  const float* sh1 = a.sh1 + tower * C1;
+  const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
   // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups)
   const bool wreg = KG2 <= 8;
   f32x4 breg[8];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 #pragma unroll
     for (int kg = 0; kg < 8; ++kg) breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + min(kg, KG2 - 1)) * 64 + lane];
   }
-  const int sG = max(1, (kTW * 64) / a.C1);
+  const int sG = max(1, (kTW * 64) / C1);
   double ds = 0.0, dss = 0.0, dcs = 0.0, s1c = 0.0;
   f32x16 best[2];
   int bk[2][16];
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     dg_edge_to_lds(xf, v, es + tid * 8);
   }
   __syncthreads();
-  dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, smem + kTT * 8, ld0, min(kTT, a.N), tid);
+  dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8, ld0, min(kTT, a.N), tid);
   __syncthreads();
   for (int it = 0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
@@ -293,15 +297,15 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
         }
       }
     }
-    if (PHASE == 3 && tid < sG * a.C1) {   // column sums of h1 (rows past nvalid are zero)
-      const int c = tid % a.C1, g = tid / a.C1;
+    if (PHASE == 3 && tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
+      const int c = tid % C1, g = tid / C1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
       s1c += (double)sm;
     }
     if (more && tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
     __syncthreads();
-    if (more) dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
+    if (more) dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
     __syncthreads();
   }
   if (PHASE == 2 && live) {
@@ -310,28 +314,46 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   }
   if (PHASE == 3) {
     if (live) a.colsum_part[((size_t)cloud * 2 + half) * a.C2 + col] = dcs;
-    if (tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;
+    if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
   }
 }
 
 // ---------------------------------------------------------------------------------
-// backward edge pass (see the header comment).  LDS: es [2][64][8] | X = h1_s [64][ld0] | Y = dy2_s [64][ldb].
-// The tile's dp values and arg-k bytes sit in registers (8 float4 + 8 packed words per thread at C2 = 128) and are
-// masked into Y once per slot.
+// backward edge pass (see the header comment).  One workgroup of 8 waves per cloud walks (tile, slot).
+// dy2_s = dp [argk == s] has one non-zero per (point, channel) over the k slots, so its two products are done sparsely
+// on the VALU from per-tile index lists (built once per tile with wave ballots, deterministic order):
+//   dh1_s[row,:] += sum over the row's slot-s columns c of dp[row,c] V2[c,:]          (row lists)
+//   U2[:,c]      += sum over the column's slot-s rows of dp[row,c] h1_s[row,:]        (column lists)
+// -- 1/k of the dense MFMA work each.  What stays on MFMA is h1_s Q2 and Gram(h1).
+// LDS: es [2][64][8] | X = h1_s [64][ld0] | D = sparse part of dh1_s [64][ld0] (arg-k staging at tile start) |
+//      DP [64][C2+4] | V2 [C2][C1+4] | row lists [64][C2] + offsets [64][24] | column lists [C2][64] + offsets [C2][24]  (bytes)
 // ---------------------------------------------------------------------------------
+constexpr int kBEW = 8;
+
 struct DgBwdArgs {
   const float* pcs[2]; const float* xform; const int* nn; int B, N, k, C1, C2;
-  int ld0, ldb;
+  int ld0;
   const float* w1; const float *sc1, *sh1;
-  const float* v2img; const float* q2img; long v2img_stride, q2img_stride;   // per-tower MFMA images: V2 [C2][C1], Q2 [C1][C1]
+  const float* v2; long v2_stride;     // per tower: V2 = (W2 diag(k2))^T  [C2][C1] row-major
+  const float* q2img; long q2img_stride;   // per-tower MFMA image of Q2 [C1][C1]
   const float* q2b;                    // [2][C1]
   const float* dyp;                    // [2B*N][C2]  dp * [p > 0]   (pass B2, GIVEN)
   const unsigned char* argk;           // [2B*N][C2]
   float* u2_part; float* g1_part;      // [2B][C1*C2], [2B][C1*C1] (upper blocks)
   double* pdy_part;                    // [2B][4 = 2 row groups x 2 halves][7][C1]: sum e_d dy1 (d < 6), sum dy1
+  long long* stamps;                   // debug: cycle stamps of thread 0 / block 0 at the phase boundaries of iteration 25
 };
+#define BE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
-__global__ __launch_bounds__(kTW * 64, 2) void dg_train_bwd_edge(const DgBwdArgs a)
+static inline size_t dg_bwd_edge_lds(int C1, int C2)
+{
+  const int ld0 = ((C1 + 7) & ~7) + 4;
+  return ((size_t)2 * kTT * 8 + 2 * (size_t)kTT * ld0 + (size_t)kTT * (C2 + 4) + (size_t)C2 * (C1 + 4)) * sizeof(float) +
+         (size_t)kTT * C2 + kTT * 24 + (size_t)C2 * kTT + (size_t)C2 * 24;
+}
+
+template <int C1, int C2>
+__global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -340,34 +362,64 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_bwd_edge(const DgBwdArgs
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
-  const int ld0 = a.ld0, ldb = a.ldb;
+  constexpr int ld0 = C1 + 4, ldv = C1 + 4;
+  constexpr int ldp = C2 + 4;
   float* X = smem + 2 * kTT * 8;
-  float* Y = X + kTT * ld0;
-  const int CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGv = (a.C2 + 7) >> 3, KGq = (a.C1 + 7) >> 3;
+  float* D = X + kTT * ld0;
+  float* DP = D + kTT * ld0;
+  float* V2 = DP + kTT * ldp;
+  unsigned char* SL = reinterpret_cast<unsigned char*>(V2 + C2 * ldv);   // [64][C2]  columns of the row, grouped by slot
+  unsigned char* SO = SL + kTT * C2;                                     // [64][24]  group offsets
+  unsigned char* SLc = SO + kTT * 24;                                      // [C2][64]  rows of the column, grouped by slot
+  unsigned char* SOc = SLc + C2 * kTT;                                   // [C2][24]
+  unsigned char* AK = reinterpret_cast<unsigned char*>(D);                 // [64][C2] staging (tile start only)
+  constexpr int CT1 = (C1 + 31) >> 5, KGq = (C1 + 7) >> 3;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
-  const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
-  const float* sc1 = a.sc1 + tower * a.C1;
-  const float* sh1 = a.sh1 + tower * a.C1;
-  const DgtLiftW lw = dgt_lift_load(a.w1, a.C1, sc1, sh1, tid);
-  const int nitems = CT1 * 2;
-  constexpr int kAccSlots = 3, kItemSlots = 2, kDP = 8;
-  const int nblk_u = CT1 * CT2, nblk = nblk_u + CT1 * (CT1 + 1) / 2;
-  f32x16 gacc[kAccSlots];
+  const float* sc1 = a.sc1 + tower * C1;
+  const float* sh1 = a.sh1 + tower * C1;
+  const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
+  // roles: waves [0, nitems) own one dh1 item (channel tile, 32-row group); the next nG waves one upper Gram block each
+  constexpr int nitems = CT1 * 2, nG = CT1 * (CT1 + 1) / 2;
+  int git = 0, gjt = 0;
+  if (wave >= nitems && wave < nitems + nG) {
+    int rem = wave - nitems;
+    while (rem >= CT1 - git) { rem -= CT1 - git; ++git; }
+    gjt = git + rem;
+  }
+  f32x16 gacc;
 #pragma unroll
-  for (int q = 0; q < kAccSlots; ++q)
+  for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+  // the dh1 waves keep their Q2 fragments in registers for the whole cloud (C1 <= 64: 8 k-groups); streaming them per slot
+  // put eight dependent L2 round trips in front of every slot's MFMAs
+  f32x4 qreg[8];
+  if (wave < nitems) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
-  double pd[kItemSlots][7];
-  float pf[kItemSlots][7];
+    for (int kg = 0; kg < 8; ++kg) qreg[kg] = q2img[((size_t)(wave >> 1) * KGq + min(kg, KGq - 1)) * 64 + lane];
+  }
+  double pd[7];
+  float pf[7];
 #pragma unroll
-  for (int q = 0; q < kItemSlots; ++q)
+  for (int d = 0; d < 7; ++d) { pd[d] = 0.0; pf[d] = 0.f; }
+  // sparse units: P1 = (row, 8-channel chunk of C1), P2 = (column of C2, 16-channel chunk of C1)
+  constexpr int p1n = C1 >> 3;
+  const int p1row = tid / p1n, p1ch = tid - p1row * p1n;
+  const bool p1on = tid < kTT * p1n;
+  constexpr int p2n = C1 >> 4;
+  const int p2c = tid % C2, p2j = tid / C2;
+  const bool p2on = tid < C2 * p2n;
+  float u2[16];
 #pragma unroll
-    for (int d = 0; d < 7; ++d) { pd[q][d] = 0.0; pf[q][d] = 0.f; }
-  const int c4 = a.C2 >> 2;
-  f32x4 dp[kDP];
-  unsigned ak[kDP];
+  for (int i = 0; i < 16; ++i) u2[i] = 0.f;
 
+  {   // V2 of this tower -> LDS, once per cloud
+    const float* src = a.v2 + tower * a.v2_stride;
+    const int c4 = C1 >> 2;
+    for (int i = tid; i < C2 * c4; i += kBEW * 64) {
+      const int r = i / c4, q = i % c4;
+      *reinterpret_cast<f32x4*>(V2 + r * ldv + q * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)r * C1 + q * 4);
+    }
+  }
   float v[6];
   if (tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
   for (int it = 0; it < total; ++it) {
@@ -376,108 +428,148 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_bwd_edge(const DgBwdArgs
     const bool more = it + 1 < total;
     float* es = smem + (it & 1) * kTT * 8;
     if (slot == 0) {
-      const size_t base = ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-#pragma unroll
-      for (int u = 0; u < kDP; ++u) {
-        const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
-        const bool ok = i < kTT * c4 && row < nvalid;
-        dp[u] = ok ? *reinterpret_cast<const f32x4*>(a.dyp + base + (size_t)row * a.C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        ak[u] = ok ? *reinterpret_cast<const unsigned*>(a.argk + base + (size_t)row * a.C2 + q * 4) : 0xffffffffu;
+      __syncthreads();   // the previous tile's readers of D / DP / the lists are done
+      const size_t base = ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
+      const int c4 = C2 >> 2;
+      for (int i = tid; i < kTT * c4; i += kBEW * 64) {
+        const int row = i / c4, q = i % c4;
+        const bool ok = row < nvalid;
+        *reinterpret_cast<f32x4*>(DP + row * ldp + q * 4) =
+            ok ? *reinterpret_cast<const f32x4*>(a.dyp + base + (size_t)row * C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<unsigned*>(AK + row * C2 + q * 4) =
+            ok ? *reinterpret_cast<const unsigned*>(a.argk + base + (size_t)row * C2 + q * 4) : 0xffffffffu;
+      }
+      __syncthreads();
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      for (int row = wave; row < kTT; row += kBEW) {   // row lists: lane <-> columns lane, lane + 64
+        const int c0 = lane, c1 = lane + 64;
+        int a0 = (c0 < C2 && DP[row * ldp + c0] != 0.f) ? AK[row * C2 + c0] : 255;
+        int a1 = (c1 < C2 && DP[row * ldp + c1] != 0.f) ? AK[row * C2 + c1] : 255;
+        int pos = 0;
+        for (int s = 0; s < a.k; ++s) {
+          if (lane == 0) SO[row * 24 + s] = (unsigned char)pos;
+          const unsigned long long m0 = __ballot(a0 == s), m1 = __ballot(a1 == s);
+          if (a0 == s) SL[row * C2 + pos + __popcll(m0 & lt)] = (unsigned char)c0;
+          if (a1 == s) SL[row * C2 + pos + __popcll(m0) + __popcll(m1 & lt)] = (unsigned char)c1;
+          pos += __popcll(m0) + __popcll(m1);
+        }
+        if (lane == 0) SO[row * 24 + a.k] = (unsigned char)pos;
+      }
+      for (int c = wave; c < C2; c += kBEW) {        // column lists: lane <-> row
+        const int av = DP[lane * ldp + c] != 0.f ? AK[lane * C2 + c] : 255;
+        int pos = 0;
+        for (int s = 0; s < a.k; ++s) {
+          if (lane == 0) SOc[c * 24 + s] = (unsigned char)pos;
+          const unsigned long long m = __ballot(av == s);
+          if (av == s) SLc[c * kTT + pos + __popcll(m & lt)] = (unsigned char)lane;
+          pos += __popcll(m);
+        }
+        if (lane == 0) SOc[c * 24 + a.k] = (unsigned char)pos;
       }
     }
+    BE_STAMP(0);
     if (tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
-    __syncthreads();   // es ready; every wave is done with the previous slot's X / Y
+    BE_STAMP(1);
+    __syncthreads();   // es and the lists are ready; every wave is done with the previous slot's X / D (and the arg-k staging)
     if (more && tid < kTT) {
       const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
       dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);
     }
-    dgt_lift(lw, a.w1, a.C1, sc1, sh1, es, X, ld0, nvalid, tid);
-#pragma unroll
-    for (int u = 0; u < kDP; ++u) {
-      const int i = tid + u * kTW * 64, row = i / c4, q = i % c4;
-      if (i < kTT * c4) {
-        const unsigned m = ak[u], s = (unsigned)slot;
-        const f32x4 y = {(m & 0xffu) == s ? dp[u][0] : 0.f, ((m >> 8) & 0xffu) == s ? dp[u][1] : 0.f,
-                         ((m >> 16) & 0xffu) == s ? dp[u][2] : 0.f, (m >> 24) == s ? dp[u][3] : 0.f};
-        *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = y;
+    BE_STAMP(2);
+    dgt_lift<kBEW * 64>(lw, a.w1, C1, sc1, sh1, es, X, ld0, nvalid, tid);
+    BE_STAMP(3);
+    if (p1on) {   // D[row][8 ch ..] = sum_c dp[row,c] V2[c][8 ch ..] over the row's slot columns
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      const int j0 = SO[p1row * 24 + slot], j1 = SO[p1row * 24 + slot + 1];
+      for (int j = j0; j < j1; ++j) {
+        const int c = SL[p1row * C2 + j];
+        const float g = DP[p1row * ldp + c];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(V2 + c * ldv + p1ch * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(V2 + c * ldv + p1ch * 8 + 4);
+        s0[0] = fmaf(g, w0[0], s0[0]); s0[1] = fmaf(g, w0[1], s0[1]); s0[2] = fmaf(g, w0[2], s0[2]); s0[3] = fmaf(g, w0[3], s0[3]);
+        s1[0] = fmaf(g, w1[0], s1[0]); s1[1] = fmaf(g, w1[1], s1[1]); s1[2] = fmaf(g, w1[2], s1[2]); s1[3] = fmaf(g, w1[3], s1[3]);
       }
+      *reinterpret_cast<f32x4*>(D + p1row * ld0 + p1ch * 8) = s0;
+      *reinterpret_cast<f32x4*>(D + p1row * ld0 + p1ch * 8 + 4) = s1;
     }
+    BE_STAMP(4);
     __syncthreads();
-    // ---- U2 += h1_s^T dy2_s, Gram(h1) += h1_s^T h1_s (upper blocks), register-resident for the whole cloud ----
+    BE_STAMP(5);
+    if (p2on) {   // U2[16 j ..][c] += sum over the column's slot rows of dp[row,c] h1_s[row][16 j ..]
+      const int j0 = SOc[p2c * 24 + slot], j1 = SOc[p2c * 24 + slot + 1];
+      for (int j = j0; j < j1; ++j) {
+        const int row = SLc[p2c * kTT + j];
+        const float g = DP[row * ldp + p2c];
+        const float* hx = X + row * ld0 + p2j * 16;
 #pragma unroll
-    for (int q = 0; q < kAccSlots; ++q) {
-      const int item = wave + q * kTW;
-      if (item < nblk) {
-        int itb, jt, ldr;
-        const float* pb;
-        if (item < nblk_u) { itb = item / CT2; jt = item % CT2; pb = Y + half * ldb; ldr = ldb; }
-        else {
-          int rem = item - nblk_u; itb = 0;
-          while (rem >= CT1 - itb) { rem -= CT1 - itb; ++itb; }
-          jt = itb + rem; pb = X + half * ld0; ldr = ld0;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(hx + q * 4);
+          u2[q * 4 + 0] = fmaf(g, hv[0], u2[q * 4 + 0]); u2[q * 4 + 1] = fmaf(g, hv[1], u2[q * 4 + 1]);
+          u2[q * 4 + 2] = fmaf(g, hv[2], u2[q * 4 + 2]); u2[q * 4 + 3] = fmaf(g, hv[3], u2[q * 4 + 3]);
         }
-        const float* pa = X + half * ld0 + itb * 32 + (lane & 31);
-        pb += jt * 32 + (lane & 31);
+      }
+    }
+    BE_STAMP(6);
+    if (wave < nitems) {
+      // ---- dh1 = (sparse part) + h1_s Q2 + q2b ; dy1 = dh1 [h1 > 0] ; Pdy += e^T dy1 ----
+      const int ct = wave >> 1, rg = wave & 1;
+      const int col = ct * 32 + (lane & 31);
+      const bool live = col < C1;
+      const float qb = live ? a.q2b[tower * C1 + col] : 0.f;
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = (live ? D[(rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld0 + col] : 0.f) + qb;
+      asm volatile("" ::: "memory");
+      {
+        const float* arow = X + (rg * 32 + (lane & 31)) * ld0 + half * 4;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg)
+          if (kg < KGq) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kg * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], qreg[kg][q], acc[0], 0, 0, 0);
+          }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
+        const float dy = on ? acc[0][r] : 0.f;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
+        pf[0] = fmaf(e0[0], dy, pf[0]); pf[1] = fmaf(e0[1], dy, pf[1]); pf[2] = fmaf(e0[2], dy, pf[2]);
+        pf[3] = fmaf(e0[3], dy, pf[3]); pf[4] = fmaf(e1[0], dy, pf[4]); pf[5] = fmaf(e1[1], dy, pf[5]);
+        pf[6] += dy;
+        if (r & 1) asm volatile("" ::: "memory");   // keep the LDS reads of later rows below this point: hoisted above the MFMAs they cost 160 VGPRs (spills)
+      }
+      if (slot == a.k - 1) {   // fp32 partial sums of one tile (k * 16 terms per lane) folded into fp64
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { pd[d] += (double)pf[d]; pf[d] = 0.f; }
+      }
+    } else if (wave < nitems + nG) {
+      // ---- Gram(h1) += h1_s^T h1_s, one upper 32 x 32 block per wave, register-resident for the whole cloud ----
+      const float* pa = X + half * ld0 + git * 32 + (lane & 31);
+      const float* pb = X + half * ld0 + gjt * 32 + (lane & 31);
 #pragma unroll 8
-        for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldr], gacc[q], 0, 0, 0);
-      }
+      for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
     }
-    // ---- dh1 = dy2_s V2 + h1_s Q2 + q2b ; dy1 = dh1 [h1 > 0] ; Pdy += e^T dy1 ----
-#pragma unroll
-    for (int qi = 0; qi < kItemSlots; ++qi) {
-      const int item = wave + qi * kTW;
-      if (item < nitems) {
-        const int ct = item >> 1, rg = item & 1;
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < a.C1;
-        const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
-        f32x16 acc[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = qb;
-        mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, v2img + (size_t)ct * KGv * 64, KGv, lane, acc);
-        mfma_rows<1, false, false>(X + rg * 32 * ld0, ld0, q2img + (size_t)ct * KGq * 64, KGq, lane, acc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
-          const float dy = on ? acc[0][r] : 0.f;
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
-          const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
-          pf[qi][0] = fmaf(e0[0], dy, pf[qi][0]); pf[qi][1] = fmaf(e0[1], dy, pf[qi][1]); pf[qi][2] = fmaf(e0[2], dy, pf[qi][2]);
-          pf[qi][3] = fmaf(e0[3], dy, pf[qi][3]); pf[qi][4] = fmaf(e1[0], dy, pf[qi][4]); pf[qi][5] = fmaf(e1[1], dy, pf[qi][5]);
-          pf[qi][6] += dy;
-        }
-        if (slot == a.k - 1) {   // fp32 partial sums of one tile (k * 16 terms per lane) folded into fp64
-#pragma unroll
-          for (int d = 0; d < 7; ++d) { pd[qi][d] += (double)pf[qi][d]; pf[qi][d] = 0.f; }
-        }
-      }
-    }
+    BE_STAMP(7);
   }
-#pragma unroll
-  for (int q = 0; q < kAccSlots; ++q) {
-    const int item = wave + q * kTW;
-    if (item < nblk) {
-      const float zero[16] = {};
-      if (item < nblk_u) {
-        tile_commit(a.u2_part + (size_t)cloud * a.C1 * a.C2, a.C2, item / CT2, item % CT2, a.C1, a.C2, gacc[q], lane, zero);
-      } else {
-        int rem = item - nblk_u, itb = 0;
-        while (rem >= CT1 - itb) { rem -= CT1 - itb; ++itb; }
-        tile_commit(a.g1_part + (size_t)cloud * a.C1 * a.C1, a.C1, itb, itb + rem, a.C1, a.C1, gacc[q], lane, zero);
-      }
-    }
+  if (wave >= nitems && wave < nitems + nG) {
+    const float zero[16] = {};
+    tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
+  if (p2on) {
 #pragma unroll
-  for (int qi = 0; qi < kItemSlots; ++qi) {
-    const int item = wave + qi * kTW;
-    if (item < nitems) {
-      const int ct = item >> 1, rg = item & 1, col = ct * 32 + (lane & 31);
-      if (col < a.C1) {
-        double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * a.C1 + col;
+    for (int i = 0; i < 16; ++i) a.u2_part[((size_t)cloud * C1 + p2j * 16 + i) * C2 + p2c] = u2[i];
+  }
+  if (wave < nitems) {
+    const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
+    if (col < C1) {
+      double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * C1 + col;
 #pragma unroll
-        for (int d = 0; d < 7; ++d) dst[(size_t)d * a.C1] = pd[qi][d];
-      }
+      for (int d = 0; d < 7; ++d) dst[(size_t)d * C1] = pd[d];
     }
   }
 }

@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--train-leg", action="store_true", help="also run the training leg when --gpus > 1 (RCCL all-reduce)")
     ap.add_argument("--workload", choices=["pointnet", "dgcnn"], default="pointnet",
-                    help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (inference only)")
+                    help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (--mode train: fp32 only)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
     args = ap.parse_args()
 
@@ -303,11 +303,14 @@ def main():
             if world == 1 and args.workload == "pointnet" and npts == N_POINTS else None,
         }
         if args.mode == "train":
-            line["metric"] = "point-cloud pairs/sec at N=1024 (training step)"
+            line["metric"] = "point-cloud pairs/sec at N=%d (training step)" % npts
             line["roofline"] = None
             line["dtype"] = args.train_dtype
             line["config"]["workload"] = ("KITTITrackletsCars-style training step (SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
                                           "(BASELINE.json configs[2])" % (B, npts, args.train_dtype))
+            if args.workload == "dgcnn":
+                line["config"]["workload"] = ("training step, DGCNN edge-conv branch (k=20, SynthCars widths), batch=%d pairs/GPU, N=%d, f32 "
+                                              "(BASELINE.json configs[4] shape)" % (B, npts))
             line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients)" if world > 1 else "")
             line["whole_path_tflops"] = None
         if args.mode == "infer" and args.infer_dtype == "bf16x3":

@@ -3,8 +3,11 @@ import sys, time, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'alignnet-3d_amd')); sys.path.insert(0, ROOT)
 import torch, alignnet3d
 from oracle import alignnet_ref as R
-B, N = 256, 1024
-eng = alignnet3d.Engine()
+B, N = int(os.environ.get('ALIGNNET_B', 256)), int(os.environ.get('ALIGNNET_N', 1024))
+cfg = alignnet3d.default_model_config()
+cfg['model']['num_points'] = N
+if os.environ.get('ALIGNNET_DGCNN'): cfg['model']['backbone'] = 'dgcnn'
+eng = alignnet3d.Engine(cfg)
 if os.environ.get('ALIGNNET_BF16'): eng.set_option('train_matmul_bf16', 1)
 d = R.synth_pairs(B, N, dtype=np.float32)
 p1 = torch.tensor(d['pcs1']).cuda(); p2 = torch.tensor(d['pcs2']).cuda()
