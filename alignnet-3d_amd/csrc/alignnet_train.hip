@@ -383,11 +383,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t dlds = ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
     finish(0, C1, 1, ecount);
-    if (C1 == 64) hipLaunchKernelGGL((dg_train_fwd<2, 64>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
-    else hipLaunchKernelGGL((dg_train_fwd<2, 32>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
+    if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     finish(1, C2, 2, ecount);
-    if (C1 == 64) hipLaunchKernelGGL((dg_train_fwd<3, 64>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
-    else hipLaunchKernelGGL((dg_train_fwd<3, 32>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
     const int sG = std::max(1, 256 / C1);
     launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), S.s1e);
     // point conv on the stored p
@@ -640,11 +640,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
     else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
     if (e.stamps) {
-      long long st[8];
+      long long st[10];
       hipStreamSynchronize(h->stream);
       hipMemcpy(st, e.stamps, sizeof(st), hipMemcpyDeviceToHost);
       std::fprintf(stderr, "BE stage %d it-25 phase cycles:", s);
       for (int i = 1; i < 8; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "  | dh1: init %lld mfma %lld epilogue %lld", st[8] - st[6], st[9] - st[8], st[7] - st[9]);
       std::fprintf(stderr, "\n");
     }
     layer2_weight_grad();

@@ -9,9 +9,11 @@
 //   forward   phase 1: BN statistics of z1 = e W1 + b1.  z1 is linear in the 6-vector e = [x_i, x_j - x_i], so its
 //                      per-channel sum / sum of squares follow from the cloud's first and second moments of e
 //                      (27 numbers, fp64) -- no [B*N*k, C1] pass at all.
-//             phase 2: h1 = relu(bn1(z1)) recomputed per (tile, slot); statistics of z2 = h1 W2 + b2 (MFMA).
-//             phase 3: h1, h2 recomputed; running max over the k slots in registers with the arg-max slot;
-//                      p and arg-k stored ([B*N, C2] floats + bytes); column sums of p and of h1.
+//             phase 2: h1 = relu(bn1(z1)) recomputed per (tile, slot); z2 = h1 W2 + b2 on MFMA: its statistics AND, because
+//                      max_k relu(g zhat_k + b) = relu(g zhat* + b) with zhat* the extreme of sign(g) z over the slots and
+//                      sign(gamma2) known up front, the per-(point, channel) extreme and its slot ([B*N, C2] floats +
+//                      bytes) -- the edge conv runs once; column sums of h1.
+//             finish:  p = relu(bn2(extreme)) in place, column sums of p (elementwise).
 //   backward  B2 (GIVEN) gives dp; only the arg-k row of each (point, channel) receives it:
 //                      dy2[n,s,c] = dp[n,c] [s == argk[n,c]] [p > 0].
 //             edge pass: per (tile, slot): h1_s recomputed, dy2_s built from the register-resident dp tile,
@@ -34,6 +36,7 @@ struct DgTrainArgs {
   const float* w1; const float* b1;   // [6][C1], [C1]
   const float* wp2; const float* b2;  // MFMA image of W2 [C1][C2], [C2]
   const float *sc1, *sh1, *sc2, *sh2; // [2][C] batch-stat scale / shift (acc -> y)
+  const float* gamma2[2];         // BatchNorm gamma of the second edge layer per tower (its sign picks max or min over the slots)
   double* mom;                    // [2B][27]                       (phase 1)
   double* stat_part;              // phase 1: [2B][C1][2]; phase 2: [2B][2 halves][C2][2]
   float* p_store;                 // [2B*N][C2]                     (phase 3)
@@ -173,13 +176,13 @@ __device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------
-// phases 2 and 3: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
+// phase 2: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
 // edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
 // the gather for the next slot is in flight during this slot's MFMAs).
 // ---------------------------------------------------------------------------------
 // C1 is a template parameter: with a compile-time LDS row stride the per-row tile addresses are immediate offsets; as
 // run-time values the compiler hoists them out of the slot loop into ~50 registers and spills.
-template <int PHASE, int C1>
+template <int C1>
 __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,7 +199,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool mine = ct < CT2, live = mine && col < a.C2;
   const float bias = live ? a.b2[col] : 0.f;
-  const float sc = (PHASE == 3 && live) ? a.sc2[tower * a.C2 + col] : 0.f, sh = (PHASE == 3 && live) ? a.sh2[tower * a.C2 + col] : 0.f;
+  // max_k relu(g zhat + b) = relu(g zhat* + b) with zhat* the extreme of sign(g) z over the slots: the sign of gamma2 is known
+  // before the statistics are, so this one pass records the extreme (and its slot) next to the sums -- no second edge-conv pass
+  const float sgn = (live && a.gamma2[tower][col] < 0.f) ? -1.f : 1.f;
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
   const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     for (int kg = 0; kg < 8; ++kg) breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + min(kg, KG2 - 1)) * 64 + lane];
   }
   const int sG = max(1, (kTW * 64) / C1);
-  double ds = 0.0, dss = 0.0, dcs = 0.0, s1c = 0.0;
+  double ds = 0.0, dss = 0.0, s1c = 0.0;
   f32x16 best[2];
   int bk[2][16];
 
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
     if (more && tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);   // in flight during the MFMAs
     const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
-    if (PHASE == 3 && slot == 0) {
+    if (slot == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       } else {
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
       }
-      if (PHASE == 2) {
+      {
         // shifted fp32 sums of this slot's <= 32 values per lane, folded into the fp64 running sums (kernels_train_fwd.h)
         const float z0 = acc[0][0] + bias;
         float s1 = 0.f, s2 = 0.f; int cnt = 0;
@@ -270,34 +275,29 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
         const double zd = (double)z0, n = (double)cnt;
         ds += (double)s1 + n * zd;
         dss += (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-      } else {
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float y = acc[m][r] * sgn;
+          if (y > best[m][r]) { best[m][r] = y; bk[m][r] = slot; }   // first slot wins ties
+        }
+      if (slot == a.k - 1) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float y = fmaf(acc[m][r], sc, sh);
-            if (y > best[m][r]) { best[m][r] = y; bk[m][r] = slot; }   // first slot wins ties
-          }
-        if (slot == a.k - 1) {
-          float lsum = 0.f;
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = acc_row(m, r, lane);
-              if (row < nvalid && live) {
-                const float p = fmaxf(best[m][r], 0.f);
-                const size_t o = ((size_t)cloud * a.N + (size_t)tile * kTT + row) * a.C2 + col;
-                a.p_store[o] = p;
-                a.argk[o] = (unsigned char)bk[m][r];
-                lsum += p;
-              }
+            const int row = acc_row(m, r, lane);
+            if (row < nvalid && live) {
+              const size_t o = ((size_t)cloud * a.N + (size_t)tile * kTT + row) * a.C2 + col;
+              a.p_store[o] = best[m][r] * sgn;   // the accumulator (z2 - bias) at the arg-extreme slot; dg_pool_finish turns it into p
+              a.argk[o] = (unsigned char)bk[m][r];
             }
-          dcs += (double)lsum;
-        }
+          }
       }
     }
-    if (PHASE == 3 && tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
+    if (tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
       const int c = tid % C1, g = tid / C1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
@@ -308,13 +308,57 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     if (more) dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
     __syncthreads();
   }
-  if (PHASE == 2 && live) {
+  if (live) {
     double* st = a.stat_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;
     st[0] = ds; st[1] = dss;
   }
-  if (PHASE == 3) {
-    if (live) a.colsum_part[((size_t)cloud * 2 + half) * a.C2 + col] = dcs;
-    if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
+  if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
+}
+
+// p = relu(scale * acc* + shift) in place over the cloud's [N][C2] rows, and the column sums of p.  grid 2B, block 256
+__global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int B, int N, int C2, const float* __restrict__ sc2,
+                                                      const float* __restrict__ sh2, double* __restrict__ colsum_part)
+{
+  __shared__ double red[256][4];
+  const int cloud = blockIdx.x, tower = cloud >= B, tid = threadIdx.x;
+  const int c4 = C2 >> 2, G = 256 / c4, q = tid % c4, g = tid / c4;
+  float* base = p + (size_t)cloud * N * C2;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (g < G) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(sc2 + tower * C2 + q * 4), sh = *reinterpret_cast<const f32x4*>(sh2 + tower * C2 + q * 4);
+    for (int r0 = g; r0 < N; r0 += G * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * G;
+        v[u] = r < N ? *reinterpret_cast<const f32x4*>(base + (size_t)r * C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * G;
+        if (r < N) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = fmaxf(fmaf(v[u][e], sc[e], sh[e]), 0.f); ps[e] += o[e]; }
+          *reinterpret_cast<f32x4*>(base + (size_t)r * C2 + q * 4) = o;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += (double)ps[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[tid][e] = g < G ? s[e] : 0.0;
+  __syncthreads();
+  if (tid < c4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double t = 0.0;
+      for (int gg = 0; gg < G; ++gg) t += red[gg * c4 + tid][e];
+      colsum_part[((size_t)cloud * 2) * C2 + tid * 4 + e] = t;
+      colsum_part[((size_t)cloud * 2 + 1) * C2 + tid * 4 + e] = 0.0;
+    }
   }
 }
 
@@ -397,10 +441,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
 #pragma unroll
     for (int kg = 0; kg < 8; ++kg) qreg[kg] = q2img[((size_t)(wave >> 1) * KGq + min(kg, KGq - 1)) * 64 + lane];
   }
-  double pd[7];
-  float pf[7];
+  double pd[4];
+  f32x16 pacc;
 #pragma unroll
-  for (int d = 0; d < 7; ++d) { pd[d] = 0.0; pf[d] = 0.f; }
+  for (int d = 0; d < 4; ++d) pd[d] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
   // sparse units: P1 = (row, 8-channel chunk of C1), P2 = (column of C2, 16-channel chunk of C1)
   constexpr int p1n = C1 >> 3;
   const int p1row = tid / p1n, p1ch = tid - p1row * p1n;
@@ -481,13 +527,24 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     if (p1on) {   // D[row][8 ch ..] = sum_c dp[row,c] V2[c][8 ch ..] over the row's slot columns
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       const int j0 = SO[p1row * 24 + slot], j1 = SO[p1row * 24 + slot + 1];
-      for (int j = j0; j < j1; ++j) {
-        const int c = SL[p1row * C2 + j];
-        const float g = DP[p1row * ldp + c];
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(V2 + c * ldv + p1ch * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(V2 + c * ldv + p1ch * 8 + 4);
-        s0[0] = fmaf(g, w0[0], s0[0]); s0[1] = fmaf(g, w0[1], s0[1]); s0[2] = fmaf(g, w0[2], s0[2]); s0[3] = fmaf(g, w0[3], s0[3]);
-        s1[0] = fmaf(g, w1[0], s1[0]); s1[1] = fmaf(g, w1[1], s1[1]); s1[2] = fmaf(g, w1[2], s1[2]); s1[3] = fmaf(g, w1[3], s1[3]);
+      // four list entries per trip: index -> dp -> V2 row is a chain of three dependent LDS reads, the trip count is data
+      // dependent and the slowest lane of the workgroup sets the barrier -- so the chains of four entries run side by side
+      for (int j = j0; j < j1; j += 4) {
+        int cc[4]; float g[4]; f32x4 w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cc[u] = SL[p1row * C2 + min(j + u, j1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = j + u < j1 ? DP[p1row * ldp + cc[u]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          w0[u] = *reinterpret_cast<const f32x4*>(V2 + cc[u] * ldv + p1ch * 8);
+          w1[u] = *reinterpret_cast<const f32x4*>(V2 + cc[u] * ldv + p1ch * 8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s0[0] = fmaf(g[u], w0[u][0], s0[0]); s0[1] = fmaf(g[u], w0[u][1], s0[1]); s0[2] = fmaf(g[u], w0[u][2], s0[2]); s0[3] = fmaf(g[u], w0[u][3], s0[3]);
+          s1[0] = fmaf(g[u], w1[u][0], s1[0]); s1[1] = fmaf(g[u], w1[u][1], s1[1]); s1[2] = fmaf(g[u], w1[u][2], s1[2]); s1[3] = fmaf(g[u], w1[u][3], s1[3]);
+        }
       }
       *reinterpret_cast<f32x4*>(D + p1row * ld0 + p1ch * 8) = s0;
       *reinterpret_cast<f32x4*>(D + p1row * ld0 + p1ch * 8 + 4) = s1;
@@ -497,16 +554,23 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     BE_STAMP(5);
     if (p2on) {   // U2[16 j ..][c] += sum over the column's slot rows of dp[row,c] h1_s[row][16 j ..]
       const int j0 = SOc[p2c * 24 + slot], j1 = SOc[p2c * 24 + slot + 1];
-      for (int j = j0; j < j1; ++j) {
-        const int row = SLc[p2c * kTT + j];
-        const float g = DP[row * ldp + p2c];
-        const float* hx = X + row * ld0 + p2j * 16;
+      for (int j = j0; j < j1; j += 2) {   // two entries per trip (see P1)
+        int rr[2]; float g[2]; f32x4 hv[2][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(hx + q * 4);
-          u2[q * 4 + 0] = fmaf(g, hv[0], u2[q * 4 + 0]); u2[q * 4 + 1] = fmaf(g, hv[1], u2[q * 4 + 1]);
-          u2[q * 4 + 2] = fmaf(g, hv[2], u2[q * 4 + 2]); u2[q * 4 + 3] = fmaf(g, hv[3], u2[q * 4 + 3]);
-        }
+        for (int u = 0; u < 2; ++u) rr[u] = SLc[p2c * kTT + min(j + u, j1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) g[u] = j + u < j1 ? DP[rr[u] * ldp + p2c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hv[u][q] = *reinterpret_cast<const f32x4*>(X + rr[u] * ld0 + p2j * 16 + q * 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u2[q * 4 + 0] = fmaf(g[u], hv[u][q][0], u2[q * 4 + 0]); u2[q * 4 + 1] = fmaf(g[u], hv[u][q][1], u2[q * 4 + 1]);
+            u2[q * 4 + 2] = fmaf(g[u], hv[u][q][2], u2[q * 4 + 2]); u2[q * 4 + 3] = fmaf(g[u], hv[u][q][3], u2[q * 4 + 3]);
+          }
       }
     }
     BE_STAMP(6);
@@ -519,7 +583,18 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       f32x16 acc[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] = (live ? D[(rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld0 + col] : 0.f) + qb;
+      // mask (h1 > 0) and e^T operands of the epilogue: unconditional loads, in flight behind the MFMAs below (written as
+      // short-circuit conditions they became 32 exec-masked LDS reads, each waited for on the spot: 4.4 k cycles per slot)
+      const int ei = lane & 31;
+      float xv[16], ev[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        xv[r] = X[row * ld0 + col];
+        ev[r] = es[row * 8 + (ei & 7)];
+      }
       asm volatile("" ::: "memory");
+      BE_STAMP(8);
       {
         const float* arow = X + (rg * 32 + (lane & 31)) * ld0 + half * 4;
 #pragma unroll
@@ -531,21 +606,22 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
           }
       }
       asm volatile("" ::: "memory");
+      BE_STAMP(9);
+      // Pdy[d][col] += sum_rows e[row][d] dy1[row][col] as one more MFMA chain: the masked accumulator element r IS the B
+      // operand of step r (rows paired as the accumulator layout pairs them), A = e^T with a row of ones for sum dy1.
+      // (A VALU epilogue -- two float4 LDS reads and 7 FMAs per row and lane -- cost 4.4 k cycles per slot.)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
-        const float dy = on ? acc[0][r] : 0.f;
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
-        pf[0] = fmaf(e0[0], dy, pf[0]); pf[1] = fmaf(e0[1], dy, pf[1]); pf[2] = fmaf(e0[2], dy, pf[2]);
-        pf[3] = fmaf(e0[3], dy, pf[3]); pf[4] = fmaf(e1[0], dy, pf[4]); pf[5] = fmaf(e1[1], dy, pf[5]);
-        pf[6] += dy;
-        if (r & 1) asm volatile("" ::: "memory");   // keep the LDS reads of later rows below this point: hoisted above the MFMAs they cost 160 VGPRs (spills)
+        const float dy = (row < nvalid && xv[r] > 0.f) ? acc[0][r] : 0.f;
+        const float ea = ei < 6 ? ev[r] : (ei == 6 ? 1.f : 0.f);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea, dy, pacc, 0, 0, 0);
       }
-      if (slot == a.k - 1) {   // fp32 partial sums of one tile (k * 16 terms per lane) folded into fp64
+      if (slot == a.k - 1) {   // fp32 sums of one tile (k * 64 rows) folded into fp64; lane (col, half) holds d = 4 half + q
 #pragma unroll
-        for (int d = 0; d < 7; ++d) { pd[d] += (double)pf[d]; pf[d] = 0.f; }
+        for (int q = 0; q < 4; ++q) { pd[q] += (double)pacc[q]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
       }
     } else if (wave < nitems + nG) {
       // ---- Gram(h1) += h1_s^T h1_s, one upper 32 x 32 block per wave, register-resident for the whole cloud ----
@@ -569,7 +645,10 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     if (col < C1) {
       double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * C1 + col;
 #pragma unroll
-      for (int d = 0; d < 7; ++d) dst[(size_t)d * C1] = pd[d];
+      for (int d = 0; d < 7; ++d) {
+        const int q = d - 4 * half;   // this half-wave holds d = 4 half .. 4 half + 3 (d = 7 does not exist); the rest of the slice is zero
+        dst[(size_t)d * C1] = (q >= 0 && q < 4) ? pd[q & 3] : 0.0;
+      }
     }
   }
 }
