@@ -285,3 +285,41 @@ def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol):
     print("dgcnn worst relative gradient errors:", sorted(real.items(), key=lambda kv: -kv[1])[:8])
     assert not bad, bad
     eng.close()
+
+
+@pytest.mark.parametrize("backbone", ["pointnet", "dgcnn"])
+def test_negative_gammas(gpu_required, backbone):
+    """BatchNorm gammas of mixed sign: the max-pools are taken as the extreme of sign(gamma)*z before the statistics
+    exist (max for gamma >= 0, min for gamma < 0) -- over the points in both backbones, over the k neighbours in DGCNN.
+    Forward, loss and every gradient against autograd with half of all gammas negated."""
+    N, B = 128, 8
+    cfg, spec, P32, d, du = (_setup_dgcnn if backbone == "dgcnn" else _setup)(N, B)
+    rng = np.random.default_rng(11)
+    for k in sorted(P32):
+        if k.endswith("/gamma"):
+            P32[k] = (P32[k] * rng.choice([-1.0, 1.0], size=P32[k].shape)).astype(np.float32)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    bn_bias = set()
+    for L in R.layer_table(spec):
+        if L.bn:
+            bn_bias.add((f"siamese/{L.name}" if L.siamese else L.name) + "/biases")
+    bad, worst = {}, 0.0
+    for name in R.trainable_names(spec):
+        if name in bn_bias:
+            continue
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        err = float(np.abs(g - ref).max())
+        worst = max(worst, err / (float(np.abs(ref).max()) + 1e-6 * gscale))
+        if err > 3e-3 * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    print(backbone, "negative gammas: worst relative gradient error", worst)
+    assert not bad, bad
+    eng.close()
