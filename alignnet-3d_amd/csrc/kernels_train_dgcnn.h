@@ -194,7 +194,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
   float* es = smem;
   constexpr int ld0 = C1 + 4;
-  const int KG2 = (C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
+  constexpr int KG2 = (C1 + 7) >> 3;   // <= 8 (C1 <= 64)
+  const int CT2 = (a.C2 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool mine = ct < CT2, live = mine && col < a.C2;
@@ -205,12 +206,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
   const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
-  // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups)
-  const bool wreg = KG2 <= 8;
-  f32x4 breg[8];
-  if (wreg && mine) {
+  // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups), with the column's sign(gamma2)
+  // folded in (exact): the accumulator is sgn * (z2 - bias), so the extreme over the slots is a plain max and the sums are
+  // those of sgn * (z2 - bias), put right at the end
+  f32x4 breg[KG2];
+  if (mine) {
 #pragma unroll
-    for (int kg = 0; kg < 8; ++kg) breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + min(kg, KG2 - 1)) * 64 + lane];
+    for (int kg = 0; kg < KG2; ++kg) {
+      breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + kg) * 64 + lane];
+      breg[kg][0] *= sgn; breg[kg][1] *= sgn; breg[kg][2] *= sgn; breg[kg][3] *= sgn;
+    }
   }
   const int sG = max(1, (kTW * 64) / C1);
   double ds = 0.0, dss = 0.0, s1c = 0.0;
@@ -240,38 +245,43 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     }
     if (mine) {
       f32x16 acc[2];
-      if (wreg) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        const float* arow = X + (lane & 31) * ld0 + half * 4;
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      const float* arow = X + (lane & 31) * ld0 + half * 4;
 #pragma unroll
-        for (int kg = 0; kg < 8; ++kg)
-          if (kg < KG2) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + kg * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 32 * ld0 + kg * 8);
+      for (int kg = 0; kg < KG2; ++kg) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + kg * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + 32 * ld0 + kg * 8);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[kg][s], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[kg][s], acc[1], 0, 0, 0);
-            }
-          }
-      } else {
-        mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[kg][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[kg][s], acc[1], 0, 0, 0);
+        }
       }
       {
-        // shifted fp32 sums of this slot's <= 32 values per lane, folded into the fp64 running sums (kernels_train_fwd.h)
-        const float z0 = acc[0][0] + bias;
-        float s1 = 0.f, s2 = 0.f; int cnt = 0;
+        // shifted fp32 sums of this slot's <= 32 accumulator values per lane, folded into the fp64 running sums; rows past
+        // nvalid hold zero accumulators (their h1 rows are zero) and are taken out of the count only
+        const float z0 = acc[0][0];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (acc_row(m, r, lane) < nvalid) {
-              const float dlt = (acc[m][r] + bias) - z0;
-              s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
-            }
+          for (int r = 0; r < 16; ++r) {
+            const float dlt = acc[m][r] - z0;
+            s1 += dlt; s2 = fmaf(dlt, dlt, s2);
+          }
+        int cnt = 32;
+        if (nvalid < kTT) {   // remove the padded rows' contribution (value 0 -> dlt = -z0)
+          cnt = 0;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt += acc_row(m, r, lane) < nvalid;
+          const float npad = (float)(32 - cnt);
+          s1 += npad * z0; s2 -= npad * z0 * z0;
+        }
         const double zd = (double)z0, n = (double)cnt;
         ds += (double)s1 + n * zd;
         dss += (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
@@ -280,8 +290,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float y = acc[m][r] * sgn;
-          if (y > best[m][r]) { best[m][r] = y; bk[m][r] = slot; }   // first slot wins ties
+          const bool up = acc[m][r] > best[m][r];   // first slot wins ties
+          bk[m][r] = up ? slot : bk[m][r];
+          best[m][r] = fmaxf(best[m][r], acc[m][r]);
         }
       if (slot == a.k - 1) {
 #pragma unroll
@@ -308,9 +319,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     if (more) dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
     __syncthreads();
   }
-  if (live) {
+  if (live) {   // sum z = sgn S1 + n b,  sum z^2 = S2 + 2 b sgn S1 + n b^2   (accumulator = sgn (z - b); n = the lane's valid rows)
+    int nrows = 0;
+    for (int r = half * 4; r < a.N; r += 8) nrows += min(4, a.N - r);   // rows (r & 3) + 8 j + 4 half of every 64-row tile
+    const double n = (double)nrows * a.k, bd = (double)bias, t1 = (double)sgn * ds;
     double* st = a.stat_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;
-    st[0] = ds; st[1] = dss;
+    st[0] = t1 + n * bd; st[1] = dss + 2.0 * bd * t1 + n * bd * bd;
   }
   if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
 }
