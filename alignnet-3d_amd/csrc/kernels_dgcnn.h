@@ -25,6 +25,12 @@ __device__ __forceinline__ uint32_t fkey(float f)
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+#ifdef ALIGNNET_KNN_STAMP   // tools/microbench/knn_phases.hip: cycle stamps of one wave at the phase boundaries
+__device__ long long g_knn_stamp[8];
+#define KNN_STAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define KNN_STAMP(i) do {} while (0)
+#endif
 // grid: (ceil(N / 4), 2B), block 256 = 4 waves, one query point per wave
 [[maybe_unused]] static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                  const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
@@ -37,33 +43,54 @@ __device__ __forceinline__ uint32_t fkey(float f)
   const float cx = center[cloud * 3], cy = center[cloud * 3 + 1], cz = center[cloud * 3 + 2];
   const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
   const float qq = qx * qx + qy * qy + qz * qz;   // reduce_sum(square(x)) (tf_util_dgcnn.py:655)
+  KNN_STAMP(0);
   uint32_t key[kKnnMaxPerLane];
   const int per = (N + 63) >> 6;
+  // Candidates are loaded eight slots at a time with clamped (always valid) indices and no branch around the loads: guarded
+  // by `if (j < N)` every slot's three loads were issued and waited for inside their own exec-masked block -- 64 exposed
+  // memory round trips per query (50 k of the 75 k cycles of a query at N = 4096).
 #pragma unroll
-  for (int t = 0; t < kKnnMaxPerLane; ++t) {
-    key[t] = 0xffffffffu;
-    if (t < per) {
-      const int j = t * 64 + lane;
-      if (j < N) {
-        const float x = pc[j * 3] - cx, y = pc[j * 3 + 1] - cy, z = pc[j * 3 + 2] - cz;
-        const float inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
-        key[t] = fkey(qq + inner + (x * x + y * y + z * z));              // square + inner + square^T (:657)
+  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8) {
+    if (t0 < per) {
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min((t0 + u) * 64 + lane, N - 1);
+        px[u] = pc[j * 3]; py[u] = pc[j * 3 + 1]; pz[u] = pc[j * 3 + 2];
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = (t0 + u) * 64 + lane;
+        const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
+        const float inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
+        const uint32_t kk = fkey(qq + inner + (x * x + y * y + z * z));   // square + inner + square^T (:657)
+        key[t0 + u] = j < N ? kk : 0xffffffffu;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) key[t0 + u] = 0xffffffffu;
     }
   }
+  KNN_STAMP(1);
   // ---- 1. upper bound: the k-th smallest of the 64 per-lane minima (k lanes hold a value <= it) ----
   uint32_t lmin = 0xffffffffu;
 #pragma unroll
   for (int t = 0; t < kKnnMaxPerLane; ++t)
     if (t < per) lmin = min(lmin, key[t]);
-  uint32_t lo = 0u, hi = 0xffffffffu;
+  // (bisection over the upper 16 key bits only: the bound may be the top of the k-th minimum's 2^-7-wide bucket, which lets a few
+  //  more candidates through to the list and halves this phase)
+  uint32_t lo = 0u, hi = 0xffffu;
   if (k <= 64) {
+    const uint32_t lmin16 = lmin >> 16;
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (__popcll(__ballot(lmin <= mid)) >= k) hi = mid; else lo = mid + 1;
+      if (__popcll(__ballot(lmin16 <= mid)) >= k) hi = mid; else lo = mid + 1;
     }
+    lo = (lo << 16) | 0xffffu;
+    if (lo == 0xffffffffu) lo = 0xfffffffeu;   // never admit the sentinel keys of slots past N
   } else lo = 0xffffffffu;
   const uint32_t T0 = lo;
+  KNN_STAMP(2);
   // ---- 2. compact the survivors (key <= T0), in increasing point index, into this wave's LDS list ----
   __shared__ uint32_t s_key[4][kKnnList];
   __shared__ int s_idx[4][kKnnList];
@@ -71,6 +98,8 @@ __device__ __forceinline__ uint32_t fkey(float f)
 #pragma unroll
   for (int t = 0; t < kKnnMaxPerLane; ++t)
     if (t < per) {
+      // about k + a few of the N candidates survive, so most 64-candidate slots hold none: skip those on the scalar unit
+      if (__ballot(key[t] <= T0) == 0ull) continue;
       const bool sel = key[t] <= T0 && t * 64 + lane < N;
       const unsigned long long m = __ballot(sel);
       const int pos = M + __popcll(m & ((1ull << lane) - 1ull));
@@ -78,20 +107,24 @@ __device__ __forceinline__ uint32_t fkey(float f)
       M += __popcll(m);
     }
   int* out = nn + ((size_t)cloud * N + q) * k;
+  KNN_STAMP(3);
   if (M <= kKnnList) {
     // ---- 3a. k-th smallest of the list by bisection (<= 4 entries per lane), emit in list (= index) order ----
     uint32_t lk[kKnnList / 64];
 #pragma unroll
     for (int u = 0; u < kKnnList / 64; ++u) lk[u] = u * 64 + lane < M ? s_key[wave][u * 64 + lane] : 0xffffffffu;
     lo = 0u; hi = T0;
+    const int nU = (M + 63) >> 6;   // populated registers of the list (usually one)
     while (lo < hi) {
       const uint32_t mid = lo + ((hi - lo) >> 1);
       int c = 0;
 #pragma unroll
-      for (int u = 0; u < kKnnList / 64; ++u) c += __popcll(__ballot(lk[u] <= mid));
+      for (int u = 0; u < kKnnList / 64; ++u)
+        if (u < nU) c += __popcll(__ballot(lk[u] <= mid));
       if (c >= k) hi = mid; else lo = mid + 1;
     }
     const uint32_t T = lo;
+    KNN_STAMP(4);
     int written = 0;
     for (int pass = 0; pass < 2 && written < k; ++pass)
 #pragma unroll
@@ -102,6 +135,7 @@ __device__ __forceinline__ uint32_t fkey(float f)
         if (sel && pos < k) out[pos] = s_idx[wave][u * 64 + lane];
         written += __popcll(m);
       }
+    KNN_STAMP(5);
     return;
   }
   // ---- 3b. (rare: more than kKnnList survivors) full bisection over all candidates ----
