@@ -326,9 +326,16 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -359,6 +366,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
+  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   auto finish = [&](int l, int C, int slices, double cnt) {
     StatFinishArgs f;
     f.part = w->stat_part; f.B = B; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
@@ -391,7 +399,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const int sG = std::max(1, 256 / C1);
     launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), S.s1e);
     // point conv on the stored p
-    hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     finish(2, C3, 2, count);
     launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
@@ -400,7 +409,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1, count);
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
-  if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  else if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4, count);
   if (h->train_bf16) {
@@ -409,7 +420,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
     hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
   } else {
-    hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     if (!a.gram_inline)
       hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
                          w->gram_part);
@@ -579,7 +591,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra;
   b2.h2_given = S.h2;
-  if (dg) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  if (dg && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (dg) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (std_w && !b2_accum && h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (std_w && !b2_accum) hipLaunchKernelGGL((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
@@ -668,7 +684,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
   b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = acc_in_b1 ? w->g1_part : nullptr;
-  hipLaunchKernelGGL(train_bwd_b1, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  // (train_bwd_b1<64, 128> and the bf16 phase 3 with compile-time widths unroll further and spill: 67 / 39 -- generic ones kept)
+  hipLaunchKernelGGL(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   if (acc_in_b1) layer2_weight_grad();
   launch_reduce<double>(h, w->dbg1_part, 4 * B, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),

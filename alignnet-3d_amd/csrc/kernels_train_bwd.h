@@ -56,7 +56,10 @@ struct BwdB2Args {
 // of dh2 takes h2 and Q3 as bf16 operands; accumulation, sparse rows, BN backward and all reductions stay fp32 / fp64.
 // GIVEN (fp32, !ACCUM): Y is loaded from h2_given (the DGCNN branch's pooled edge features p = max_k h2) instead of being
 // recomputed; the relu mask is p > 0 and zhat at the arg-max slot follows from p itself: acc = (p - sh) / sc.
-template <bool ACCUM, bool BF16 = false, bool GIVEN = false>
+// C1T / C2T: compile-time layer widths (0 = take them from the arguments).  With the widths -- hence the LDS row strides --
+// known, the per-row tile addresses of the unrolled epilogues are immediates; as run-time values hipcc hoists them out of the
+// tile loop into registers and spills (kernels_train_dgcnn.h has the measurements).
+template <bool ACCUM, bool BF16 = false, bool GIVEN = false, int C1T = 0, int C2T = 0>
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
-  const int ld0 = a.ld0, ldb = a.ldb;
+  const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
+  const int ld0 = C1T ? C1T + 4 : a.ld0, ldb = (C1T && C2T) ? (C1T > C2T ? C1T : C2T) + 4 : a.ldb;
   const int ntiles = (a.N + kTT - 1) / kTT;
   float* xs = smem;
   float* X = smem + kTT * 4;
@@ -74,12 +78,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
   int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
   int* wtot = hoff + kTW * (ntiles + 1);                       // [8] segment sizes
-  const int KG2 = (a.C1 + 7) >> 3, CT1 = (a.C1 + 31) >> 5, CT2 = (a.C2 + 31) >> 5, KGq = (a.C2 + 7) >> 3;
+  const int KG2 = (kC1 + 7) >> 3, CT1 = (kC1 + 31) >> 5, CT2 = (kC2 + 31) >> 5, KGq = (kC2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
-  const int sG = max(1, (kTW * 64) / a.C1);
-  const int K16a = (a.C1 + 15) & ~15, ld0h = K16a + 8, K16b = (a.C2 + 15) & ~15, ldbh = K16b + 8;   // bf16 tiles
-  float* my_u2 = a.u2_part + (size_t)cloud * a.C1 * a.C2;
-  float* my_g1 = a.g1_part + (size_t)cloud * a.C1 * a.C1;
+  const int sG = max(1, (kTW * 64) / kC1);
+  const int K16a = (kC1 + 15) & ~15, ld0h = K16a + 8, K16b = (kC2 + 15) & ~15, ldbh = K16b + 8;   // bf16 tiles
+  float* my_u2 = a.u2_part + (size_t)cloud * kC1 * kC2;
+  float* my_g1 = a.g1_part + (size_t)cloud * kC1 * kC1;
 
   // ---- per-cloud hit lists: wave w owns the arg-extreme rows with (row & 7) == w, ordered by tile then channel
   //      (fixed order => deterministic summation); built once, consumed tile by tile ----
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 
   f32x16 z2[2];   // [row group]
   const int ct = wave, col = ct * 32 + (lane & 31);
-  const bool live = col < a.C2;
+  const bool live = col < kC2;
   double db = 0.0, dg = 0.0, s1c = 0.0;
 
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -124,26 +128,26 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
     B2_STAMP(0);
     if (GIVEN) {
-      const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c4 = a.C2 >> 2;
+      const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kC2 + q * 4);
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
       }
     } else {
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     B2_STAMP(1);
-    layer1_to_lds_global(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    layer1_to_lds_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, X, ld0, nvalid, tid);
     __syncthreads();
     if (BF16) {   // bf16 copy of h1 behind the fp32 one (X holds [64][ldb] floats; the fp32 h1 uses [64][ld0] of it)
       unsigned short* Xh = reinterpret_cast<unsigned short*>(X + kTT * ld0);
       const int half_cols = K16a >> 1;
       for (int i = tid; i < kTT * half_cols; i += kTW * 64) {
         const int row = i / half_cols, c = (i % half_cols) * 2;
-        const float v0 = c < a.C1 ? X[row * ld0 + c] : 0.f, v1 = c + 1 < a.C1 ? X[row * ld0 + c + 1] : 0.f;
+        const float v0 = c < kC1 ? X[row * ld0 + c] : 0.f, v1 = c + 1 < kC1 ? X[row * ld0 + c + 1] : 0.f;
         *reinterpret_cast<unsigned*>(Xh + row * ld0h + c) = (unsigned)to_bf16_bits(v0) | ((unsigned)to_bf16_bits(v1) << 16);
       }
       __syncthreads();
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
                           reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
-      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
       if (BF16) {
         if (col < K16b) {   // h2 as a bf16 tile in the Y region (row stride K16(C2) + 8 elements)
           unsigned short* Yh = reinterpret_cast<unsigned short*>(Y);
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
               Yh[row * ldbh + col] = (row < nvalid && live) ? to_bf16_bits(fmaxf(fmaf(z2[m][r], sc, sh), 0.f)) : (unsigned short)0;
             }
         }
-      } else if (col < ((a.C2 + 7) & ~7)) {
+      } else if (col < ((kC2 + 7) & ~7)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -188,16 +192,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       const float* pa = X + half * ld0 + it * 32 + (lane & 31);
       const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
       float old[16];
-      tile_prefetch(my_g1, a.C1, it, jt, a.C1, a.C1, first, lane, old);
+      tile_prefetch(my_g1, kC1, it, jt, kC1, kC1, first, lane, old);
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
-      tile_commit(my_g1, a.C1, it, jt, a.C1, a.C1, g, lane, old);
+      tile_commit(my_g1, kC1, it, jt, kC1, kC1, g, lane, old);
     }
-    if (!GIVEN && tid < sG * a.C1) {   // column sums of h1: sG row groups x C1 columns
-      const int c = tid % a.C1, g = tid / a.C1;
+    if (!GIVEN && tid < sG * kC1) {   // column sums of h1: sG row groups x C1 columns
+      const int c = tid % kC1, g = tid / kC1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
       s1c += (double)sm;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           const int row = __shfl(rel, l);
           const int cc = base + l;
           const float g = a.gs[(size_t)cloud * a.C3 + cc];
-          for (int k = lane; k < a.C2; k += 64) X[row * ldb + k] += g * a.w3t[(size_t)cc * a.C2 + k];
+          for (int k = lane; k < kC2; k += 64) X[row * ldb + k] += g * a.w3t[(size_t)cc * kC2 + k];
         }
       }
     } else {
@@ -237,13 +241,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           const bool ok = hi < h1;
           e[q] = ok ? hit_e[hi] : -1;
           g[q] = ok ? hit_g[hi] : 0.f;
-          wv[q] = (ok && l4 < a.C2) ? *reinterpret_cast<const f32x4*>(a.w3t + (size_t)(e[q] & 0xffff) * a.C2 + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          wv[q] = (ok && l4 < kC2) ? *reinterpret_cast<const f32x4*>(a.w3t + (size_t)(e[q] & 0xffff) * kC2 + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            if (half == hh && e[q] >= 0 && l4 < a.C2) {
+            if (half == hh && e[q] >= 0 && l4 < kC2) {
               f32x4* px = reinterpret_cast<f32x4*>(X + (e[q] >> 16) * ldb + l4);
               f32x4 v = *px;
               v[0] = fmaf(g[q], wv[q][0], v[0]); v[1] = fmaf(g[q], wv[q][1], v[1]);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
     if (ct < CT2) {
-      const float qb = live ? a.q3b[tower * a.C2 + col] : 0.f;
+      const float qb = live ? a.q3b[tower * kC2 + col] : 0.f;
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -270,9 +274,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
                                  reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
       else
         mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
-      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
-      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * a.C2 + col] : 0.f;
-      const float rs = live ? a.rstd2[tower * a.C2 + col] : 0.f;
+      const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
+      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * kC2 + col] : 0.f;
+      const float rs = live ? a.rstd2[tower * kC2 + col] : 0.f;
       float lb = 0.f, lg = 0.f;
       const float isc = GIVEN ? 1.0f / sc : 0.f;
 #pragma unroll
@@ -295,21 +299,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(8);
 
     // ---- dy2 -> Y ; h1 -> X again (only when U2 / Gram(h1) are accumulated here; pass B1 does it otherwise) ----
-    if (ct < CT2 && col < ((a.C2 + 7) & ~7)) {
+    if (ct < CT2 && col < ((kC2 + 7) & ~7)) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < a.C2 ? z2[m][r] : 0.f;
+        for (int r = 0; r < 16; ++r) Y[acc_row(m, r, lane) * ldb + col] = col < kC2 ? z2[m][r] : 0.f;
     }
-    if (ACCUM) layer1_to_lds_global(xs, a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, X, ld0, nvalid, tid);
+    if (ACCUM) layer1_to_lds_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, X, ld0, nvalid, tid);
     __syncthreads();
 
     B2_STAMP(9);
     // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
     {
       if (BF16) {   // dy2 travels to pass B1 as bf16 in this mode (half the 268 MB per stage)
-        unsigned short* dsth = reinterpret_cast<unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-        const int c8 = a.C2 >> 3;
+        unsigned short* dsth = reinterpret_cast<unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+        const int c8 = kC2 >> 3;
         for (int i = tid; i < nvalid * c8; i += kTW * 64) {
           const int row = i / c8, q = i % c8;
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 8), v1 = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 8 + 4);
@@ -318,14 +322,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           pk.y = (unsigned)to_bf16_bits(v0[2]) | ((unsigned)to_bf16_bits(v0[3]) << 16);
           pk.z = (unsigned)to_bf16_bits(v1[0]) | ((unsigned)to_bf16_bits(v1[1]) << 16);
           pk.w = (unsigned)to_bf16_bits(v1[2]) | ((unsigned)to_bf16_bits(v1[3]) << 16);
-          *reinterpret_cast<uint4*>(dsth + (size_t)row * a.C2 + q * 8) = pk;
+          *reinterpret_cast<uint4*>(dsth + (size_t)row * kC2 + q * 8) = pk;
         }
       } else {
-      float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c4 = a.C2 >> 2;   // C2 % 4 == 0 (multiple of 32 enforced on the host)
+      float* dst = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;   // C2 % 4 == 0 (multiple of 32 enforced on the host)
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
-        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * kC2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
       }
       }
       for (int item = wave; ACCUM && item < ((a.dbg & 64) ? 0 : CT1 * CT2); item += kTW) {
@@ -333,22 +337,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         const float* pa = X + half * ld0 + it * 32 + (lane & 31);
         const float* pb = Y + half * ldb + jt * 32 + (lane & 31);
         float old[16];
-        tile_prefetch(my_u2, a.C2, it, jt, a.C1, a.C2, first, lane, old);
+        tile_prefetch(my_u2, kC2, it, jt, kC1, kC2, first, lane, old);
         f32x16 u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll 8
         for (int r = 0; r < kTT; r += 2) u = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ldb], u, 0, 0, 0);
-        tile_commit(my_u2, a.C2, it, jt, a.C1, a.C2, u, lane, old);
+        tile_commit(my_u2, kC2, it, jt, kC1, kC2, u, lane, old);
       }
     }
     B2_STAMP(10);
   }
   if (ct < CT2 && live) {
-    double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;   // slice (half)
+    double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * kC2 + col) * 2;   // slice (half)
     d[0] = db; d[1] = dg;
   }
-  if (!GIVEN && tid < sG * a.C1) a.s1_part[(size_t)cloud * sG * a.C1 + tid] = s1c;   // [cloud][group][C1]
+  if (!GIVEN && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------
@@ -368,6 +372,7 @@ struct BwdB1Args {
   int dy2_bf16;                                      // dy2_store holds bf16 (train_matmul_bf16)
 };
 
+template <int C1T = 0, int C2T = 0>   // compile-time widths (0 = from the arguments), see train_bwd_b2
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -378,19 +383,20 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
   float* X = smem + kTT * 4;            // h1   [64][ld0]
-  float* Y = X + kTT * a.ld0;           // dy2  [64][ldb]
-  const int ld0 = a.ld0, ldb = a.ldb;
-  const int CT1 = (a.C1 + 31) >> 5, KGv = (a.C2 + 7) >> 3, KGq = (a.C1 + 7) >> 3;
+  const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
+  const int ld0 = C1T ? C1T + 4 : a.ld0, ldb = C2T ? C2T + 4 : a.ldb;
+  float* Y = X + kTT * ld0;             // dy2  [64][ldb]
+  const int CT1 = (kC1 + 31) >> 5, KGv = (kC2 + 7) >> 3, KGq = (kC1 + 7) >> 3;
   const int ntiles = (a.N + kTT - 1) / kTT;
   const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   // items: (column tile ct, 32-row group rg)
   const int nitems = CT1 * 2;
-  const Layer1W l1w = layer1_load(a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, tid);
+  const Layer1W l1w = layer1_load(a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, tid);
   // U2 = h1^T dy2 (CT1 x CT2 blocks) and the upper blocks of Gram(h1) stay in registers for the whole cloud (a per-tile
   // read-modify-write of these 48 KiB per cloud falls out of L2 with 512 clouds in flight); <= 3 blocks per wave
   constexpr int kAccSlots = 3;
-  const int CT2 = (a.C2 + 31) >> 5, half = lane >> 5;
+  const int CT2 = (kC2 + 31) >> 5, half = lane >> 5;
   const int nblk_u = a.u2_part ? CT1 * CT2 : 0, nblk = a.u2_part ? nblk_u + CT1 * (CT1 + 1) / 2 : 0;
   f32x16 gacc[kAccSlots];
 #pragma unroll
@@ -405,12 +411,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     {
       if (a.dy2_bf16) {
-        const unsigned short* srch = reinterpret_cast<const unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-        const int c8 = a.C2 >> 3;
+        const unsigned short* srch = reinterpret_cast<const unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+        const int c8 = kC2 >> 3;
         for (int i = tid; i < kTT * c8; i += kTW * 64) {
           const int row = i / c8, q = i % c8;
           uint4 pk = {0u, 0u, 0u, 0u};
-          if (row < nvalid) pk = *reinterpret_cast<const uint4*>(srch + (size_t)row * a.C2 + q * 8);
+          if (row < nvalid) pk = *reinterpret_cast<const uint4*>(srch + (size_t)row * kC2 + q * 8);
           float* yo = Y + row * ldb + q * 8;
           *reinterpret_cast<f32x4*>(yo) = f32x4{__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
                                                 __uint_as_float(pk.y & 0xffff0000u)};
@@ -418,18 +424,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
                                                     __uint_as_float(pk.w & 0xffff0000u)};
         }
       } else {
-      const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c4 = a.C2 >> 2;
+      const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kC2 + q * 4);
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
       }
       }
     }
     __syncthreads();
-    layer1_to_lds(xs, l1w, a.C1, X, ld0, nvalid, tid);
+    layer1_to_lds(xs, l1w, kC1, X, ld0, nvalid, tid);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kAccSlots; ++q) {
@@ -452,21 +458,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     for (int item = wave; item < nitems; item += kTW) {
       const int ct = item >> 1, rg = item & 1;
       const int col = ct * 32 + (lane & 31);
-      const bool live = col < a.C1;
+      const bool live = col < kC1;
       f32x16 acc[1];
-      const float qb = live ? a.q2b[tower * a.C1 + col] : 0.f;
-      double* dslice = a.dbg1_part + (((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * a.C1 + (live ? col : 0)) * 2;   // slice (rg, half)
+      const float qb = live ? a.q2b[tower * kC1 + col] : 0.f;
+      double* dslice = a.dbg1_part + (((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * kC1 + (live ? col : 0)) * 2;   // slice (rg, half)
       const double o0 = (first || !live) ? 0.0 : dslice[0], o1 = (first || !live) ? 0.0 : dslice[1];
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] = qb;
       mfma_rows<1, false, false>(Y + rg * 32 * ldb, ldb, v2img + (size_t)ct * KGv * 64, KGv, lane, acc);
       mfma_rows<1, false, false>(X + rg * 32 * ld0, ld0, q2img + (size_t)ct * KGq * 64, KGq, lane, acc);
-      const float w0 = live ? a.w1[col] : 0.f, wa = live ? a.w1[a.C1 + col] : 0.f, wb = live ? a.w1[2 * a.C1 + col] : 0.f;
-      const float bias = live ? a.b1[col] : 0.f, mu = live ? a.mean1[tower * a.C1 + col] : 0.f;
-      const float rs = live ? a.rstd1[tower * a.C1 + col] : 0.f;
+      const float w0 = live ? a.w1[col] : 0.f, wa = live ? a.w1[kC1 + col] : 0.f, wb = live ? a.w1[2 * kC1 + col] : 0.f;
+      const float bias = live ? a.b1[col] : 0.f, mu = live ? a.mean1[tower * kC1 + col] : 0.f;
+      const float rs = live ? a.rstd1[tower * kC1 + col] : 0.f;
       float lb = 0.f, lg = 0.f;
-      float* dst = a.dy1_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C1;
+      float* dst = a.dy1_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
         const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
         const float z = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0)) + bias;
         lb += dy; lg += dy * ((z - mu) * rs);
-        if (live && row < nvalid) dst[(size_t)row * a.C1 + col] = dy;
+        if (live && row < nvalid) dst[(size_t)row * kC1 + col] = dy;
       }
       if (live) {
         dslice[0] = o0 + (double)lb;
@@ -489,11 +495,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     if (item < nblk) {
       const float zero[16] = {};
       if (item < nblk_u) {
-        tile_commit(a.u2_part + (size_t)cloud * a.C1 * a.C2, a.C2, item / CT2, item % CT2, a.C1, a.C2, gacc[q], lane, zero);
+        tile_commit(a.u2_part + (size_t)cloud * kC1 * kC2, kC2, item / CT2, item % CT2, kC1, kC2, gacc[q], lane, zero);
       } else {
         int rem = item - nblk_u, it = 0;
         while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
-        tile_commit(a.g1_part + (size_t)cloud * a.C1 * a.C1, a.C1, it, it + rem, a.C1, a.C1, gacc[q], lane, zero);
+        tile_commit(a.g1_part + (size_t)cloud * kC1 * kC1, kC1, it, it + rem, kC1, kC1, gacc[q], lane, zero);
       }
     }
   }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
 // ---------------------------------------------------------------------------------
 // GIVEN (phase 3, fp32): the tile of hidden features is read from h2_store (the DGCNN branch's pooled edge features,
 // kernels_train_dgcnn.h) instead of being recomputed from xyz; column sums and the store belong to the producer.
-template <int PHASE, bool BF16 = false, bool GIVEN = false>
+template <int PHASE, bool BF16 = false, bool GIVEN = false, int C1T = 0, int C2T = 0>   // C1T / C2T: compile-time widths, see train_bwd_b2
 __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -316,22 +316,23 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
   float* buf0 = smem + kTT * 4;
-  float* buf1 = buf0 + kTT * a.ld[0];
-  const int ld0 = a.ld[0], ld1 = a.ld[1];
+  const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
+  const int ld0 = C1T ? C1T + 4 : a.ld[0], ld1 = C2T ? C2T + 4 : a.ld[1];
+  float* buf1 = buf0 + kTT * ld0;
   // bf16 mode keeps h2 only as bf16: row-major (A operand of the lift, row stride C2 + 8 elements = 4 dwords mod 64 at
   // C2 = 128) and transposed [channel][row] (both operands of the Gram, row stride kTT + 8); no fp32 tile
-  const int K16 = (a.C2 + 15) & ~15, ldh = K16 + 8;
+  const int K16 = (kC2 + 15) & ~15, ldh = K16 + 8;
   constexpr int ldT = kTT + 8;
   unsigned short* buf1h = reinterpret_cast<unsigned short*>(buf1);
   unsigned short* bufT = buf1h + kTT * ldh;
-  const int KG2 = (a.C1 + 7) >> 3, CT2 = (a.C2 + 31) >> 5;
-  const int KG3 = (a.C2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
+  const int KG2 = (kC1 + 7) >> 3, CT2 = (kC2 + 31) >> 5;
+  const int KG3 = (kC2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT;
-  const int Cs = PHASE == 2 ? a.C2 : a.C3;
+  const int Cs = PHASE == 2 ? kC2 : a.C3;
   double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2] (phase 3; phase 2 uses 4 slices)
   float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
-  float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * a.C2 * a.C2 : nullptr;
+  float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * kC2 * kC2 : nullptr;
 
   // Two workgroups share a CU and run identical per-tile timelines; started together they stay in lockstep and
   // their non-MFMA phases coincide.  Stagger the second resident wave of workgroups by about half a tile.
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
   }
 
-  const Layer1W l1w = layer1_load(a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, tid);
+  const Layer1W l1w = layer1_load(a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, tid);
   constexpr int kBfSlots = 8;                 // channel tiles wave, wave + 4, ... of the lift: C3 <= 1024
   float rs1[BF16 ? kBfSlots : 1], rs2[BF16 ? kBfSlots : 1], rbe[BF16 ? kBfSlots : 1];
   int rbi[BF16 ? kBfSlots : 1];
@@ -364,21 +365,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     const bool first = tile == 0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     if (GIVEN) {
-      const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c4 = a.C2 >> 2;
+      const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * a.C2 + q * 4);
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kC2 + q * 4);
         *reinterpret_cast<f32x4*>(buf1 + row * ld1 + q * 4) = v;
       }
     } else {
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     // bf16 mode: the hidden layer's operands are bf16 too (h1 tile in the buf0 region, row stride K16(C1) + 8 elements)
-    const int K16a = (a.C1 + 15) & ~15, ld0h = K16a + 8;
-    if (BF16) layer1_to_lds_bf16(xs, l1w, a.C1, reinterpret_cast<unsigned short*>(buf0), ld0h, K16a, nvalid, tid);
-    else layer1_to_lds(xs, l1w, a.C1, buf0, ld0, nvalid, tid);
+    const int K16a = (kC1 + 15) & ~15, ld0h = K16a + 8;
+    if (BF16) layer1_to_lds_bf16(xs, l1w, kC1, reinterpret_cast<unsigned short*>(buf0), ld0h, K16a, nvalid, tid);
+    else layer1_to_lds(xs, l1w, kC1, buf0, ld0, nvalid, tid);
     __syncthreads();
 
     // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 32-row group): C2 = 128 -> 8 items, one per wave ----
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       else
         mfma_rows<1, true, true>(buf0 + rg * 32 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, acc);
       const int col = ct * 32 + (lane & 31);
-      const bool live = col < a.C2;
+      const bool live = col < kC2;
       if (PHASE == 2) {
         const float bias = live ? a.b2[col] : 0.f;
         // shifted sums in fp32 (shift = this lane's first value), folded into fp64 once per tile:
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
             s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
           }
         if (live) {
-          double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col) * 2;   // slice (rg, half)
+          double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half)
           const double zd = (double)z0, n = (double)cnt;
           const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
           const double o0 = first ? 0.0 : st[0], o1 = first ? 0.0 : st[1];
@@ -413,9 +414,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
           st[1] = o1 + lss;
         }
       } else {
-        const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+        const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
         float lsum = 0.f;
-        const bool wr = col < ((a.C2 + 7) & ~7);
+        const bool wr = col < ((kC2 + 7) & ~7);
         if (BF16) {
           // the column sums are those of the ROUNDED values, so that the centred Gram G - s s^T / M (kernels_train_bwd.h)
           // is the exact covariance of one data matrix
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
           }
         }
         if (live) {
-          double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * a.C2 + col;
+          double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * kC2 + col;
           *cs = first ? (double)lsum : *cs + (double)lsum;
         }
       }
@@ -457,18 +458,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
     if (GIVEN) {
     } else if (BF16 && !(a.dbg & 2)) {
-      unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c8 = a.C2 >> 3;
+      unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c8 = kC2 >> 3;
       for (int i = tid; i < nvalid * c8; i += kTW * 64) {
         const int row = i / c8, q = i % c8;
-        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 8) = *reinterpret_cast<const f32x4*>(buf1h + row * ldh + q * 8);
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * kC2 + q * 8) = *reinterpret_cast<const f32x4*>(buf1h + row * ldh + q * 8);
       }
     } else if (!BF16 && !(a.dbg & 2)) {
-      float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * a.C2;
-      const int c4 = a.C2 >> 2;
+      float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
         const int row = i / c4, q = i % c4;
-        *reinterpret_cast<f32x4*>(dst + (size_t)row * a.C2 + q * 4) = *reinterpret_cast<const f32x4*>(buf1 + row * ld1 + q * 4);
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * kC2 + q * 4) = *reinterpret_cast<const f32x4*>(buf1 + row * ld1 + q * 4);
       }
     }
 
@@ -497,13 +498,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
       float old[16];
-      tile_prefetch(my_gram, a.C2, it, jt, a.C2, a.C2, first, lane, old);
+      tile_prefetch(my_gram, kC2, it, jt, kC2, kC2, first, lane, old);
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll 8
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld1], pb[r * ld1], g, 0, 0, 0);
-      tile_commit(my_gram, a.C2, it, jt, a.C2, a.C2, g, lane, old);
+      tile_commit(my_gram, kC2, it, jt, kC2, kC2, g, lane, old);
     }
 
     // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         int it = 0, rem = item;
         while (rem >= CT2 - it) { rem -= CT2 - it; ++it; }
         const float zero[16] = {};
-        tile_commit(my_gram, a.C2, it, it + rem, a.C2, a.C2, gacc[q], lane, zero);
+        tile_commit(my_gram, kC2, it, it + rem, kC2, kC2, gacc[q], lane, zero);
       }
     }
   }

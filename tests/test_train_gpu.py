@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
 
 
-def _oracle(cfg, P32, d, du, decay, bf16_lift=False):
+def _oracle(cfg, P32, d, du, decay, bf16_lift=False, dt=np.float64):
     spec = R.NetSpec.from_cfg(cfg)
-    tp = T.to_torch({k: v.astype(np.float64) for k, v in P32.items()}, requires_grad=True)
+    tp = T.to_torch({k: v.astype(dt) for k, v in P32.items()}, dtype=torch.float64 if dt == np.float64 else torch.float32, requires_grad=True)
     tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift)
-    td = {k: torch.tensor(v.astype(np.float64)) for k, v in d.items()}
-    tu = {k: torch.tensor(v.astype(np.float64)) for k, v in du.items()}
+    td = {k: torch.tensor(v.astype(dt)) for k, v in d.items()}
+    tu = {k: torch.tensor(v.astype(dt)) for k, v in du.items()}
     ep = tm.forward(td["pcs1"], td["pcs2"], True, decay, tu)
     loss = tm.loss(ep, *[td[k] for k in LABELS])
     loss.backward()
@@ -28,8 +28,13 @@ def _oracle(cfg, P32, d, du, decay, bf16_lift=False):
             {k: v.numpy() for k, v in tm.ema_updates.items()})
 
 
-def _setup(N, B, nb=12, seed=5):
-    cfg = small_cfg(N=N, nb=nb, s1=(32, 64, 96), s2=(32, 64, 128), emb=(32, 64, 160), fc=(64, 32))
+STD = dict(s1=(64, 128, 96), s2=(64, 128, 128), emb=(64, 128, 160))   # first two widths of every shipped config: the
+# engine runs kernel instantiations with these widths compiled in (alignnet_train.hip: std_w)
+
+
+def _setup(N, B, nb=12, seed=5, std=False):
+    w = STD if std else dict(s1=(32, 64, 96), s2=(32, 64, 128), emb=(32, 64, 160))
+    cfg = small_cfg(N=N, nb=nb, fc=(64, 32), **w)
     cfg["training"]["batch_size"] = B
     spec, P32 = oracle_params(cfg, seed=seed)
     # BN-preceding biases have an identically-zero gradient; keep them non-zero to test that path
@@ -64,13 +69,13 @@ def test_train_forward_loss_ema(gpu_required, N, B):
     eng.close()
 
 
-@pytest.mark.parametrize("N,B,tol", [(256, 16, 5e-4), (128, 6, 1e-2)])
-def test_gradients_match_autograd(gpu_required, N, B, tol):
+@pytest.mark.parametrize("N,B,tol,std", [(256, 16, 5e-4, False), (128, 6, 1e-2, False), (192, 12, 1e-3, True)])
+def test_gradients_match_autograd(gpu_required, N, B, tol, std):
     """Every trainable tensor.  Tolerance: relative to the tensor's largest reference entry, plus an absolute
     floor of 1e-5 x the largest gradient entry of the whole model for tensors whose exact gradient is zero
     (e.g. the beta of a BN whose output feeds another BN through a linear map, biases in front of a BN).
     B = 6 is a conditioning stress case (6-row batch statistics amplify fp32 forward differences)."""
-    cfg, spec, P32, d, du = _setup(N, B)
+    cfg, spec, P32, d, du = _setup(N, B, std=std)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
     _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
@@ -157,8 +162,8 @@ def test_eval_loss_matches_oracle(gpu_required):
     eng.close()
 
 
-@pytest.mark.parametrize("N,B", [(256, 64), (200, 48)])
-def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
+@pytest.mark.parametrize("N,B,std", [(256, 64, False), (200, 48, False), (192, 48, True)])
+def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B, std):
     """BASELINE.json configs[2] (bf16 training): option "train_matmul_bf16" runs the MFMA convs of every backbone (hidden
     layer and lift, forward and the backward's recompute) on bf16 MFMA (operands rounded to nearest even, fp32
     accumulation); the backward otherwise treats the rounding as identity (straight-through).  The oracle
@@ -176,7 +181,7 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
         channel's gradient to another point) and >= 3x closer (1 - cos) than the fp32 step's gradient.
     Against the *fp32* step the bf16 step differs by ~1 % in the stage features and flips a few argmax yaw decodes per
     batch (tools/bf16_check.py), which is why the comparison is against the rounded oracle."""
-    cfg, spec, P32, d, du = _setup(N, B)
+    cfg, spec, P32, d, du = _setup(N, B, std=std)
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     stats = ["siamese/transformer1/embedding/conv3/bn/moving_mean", "siamese_1/transformer1/embedding/conv3/bn/moving_var"]
     eng = alignnet3d.Engine(cfg)
@@ -226,8 +231,9 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B):
     eng.close()
 
 
-def _setup_dgcnn(N, B, seed=7):
-    cfg = small_cfg(N=N, s1=(32, 64, 96), s2=(32, 64, 128), emb=(64, 128, 160), fc=(64, 32), backbone="dgcnn")
+def _setup_dgcnn(N, B, seed=7, std=False):
+    w = STD if std else dict(s1=(32, 64, 96), s2=(32, 64, 128), emb=(64, 128, 160))
+    cfg = small_cfg(N=N, fc=(64, 32), backbone="dgcnn", **w)
     cfg["training"]["batch_size"] = B
     spec, P32 = oracle_params(cfg, seed=seed)
     d = R.synth_pairs(B, N, seed=seed, dtype=np.float32)
@@ -257,13 +263,23 @@ def test_dgcnn_train_forward_loss_ema(gpu_required, N, B):
     eng.close()
 
 
-@pytest.mark.parametrize("N,B,tol", [(128, 8, 2e-3), (96, 4, 1e-2)])
-def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol):
-    """Every trainable tensor of the DGCNN model against torch autograd (fp64), same criterion as the PointNet test."""
-    cfg, spec, P32, d, du = _setup_dgcnn(N, B)
+@pytest.mark.parametrize("N,B,tol,std", [(128, 8, 2e-3, False), (96, 4, 1e-2, False), (128, 16, 3e-3, True)])
+def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol, std):
+    """Every trainable tensor of the DGCNN model against torch autograd (fp64), same criterion as the PointNet test.
+    The model takes 20x more max decisions than PointNet (k-max per point and channel), and in fp32 a near-tie routes a
+    gradient to another edge row: the SAME oracle evaluated in fp32 is 1e-2..3e-2 away from its fp64 evaluation on some
+    tensors (tools/dgcnn_grad_dist.py).  The widest case (std: the 64/128 widths of the shipped configs, kernel
+    instantiations with the widths compiled in) therefore bounds the HIP error by twice the fp32 oracle's own error."""
+    cfg, spec, P32, d, du = _setup_dgcnn(N, B, std=std)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
     _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    rel32 = 0.0
+    if std:
+        _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32)
+        gs = max(float(np.abs(v).max()) for v in grads.values())
+        rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs) for k in grads)
+        tol = max(tol, 2.0 * rel32)
     eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     report, bad = {}, {}
@@ -282,7 +298,7 @@ def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol):
         if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
             bad[name] = (err, float(np.abs(ref).max()))
     real = {k: v for k, v in report.items() if np.abs(grads[k]).max() > 1e-6 * gscale}
-    print("dgcnn worst relative gradient errors:", sorted(real.items(), key=lambda kv: -kv[1])[:8])
+    print("dgcnn worst relative gradient errors:", sorted(real.items(), key=lambda kv: -kv[1])[:4], "fp32 oracle vs fp64 oracle:", rel32)
     assert not bad, bad
     eng.close()
 
