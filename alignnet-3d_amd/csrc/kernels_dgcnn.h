@@ -74,9 +74,14 @@ __device__ long long g_knn_stamp[8];
   KNN_STAMP(1);
   // ---- 1. upper bound: the k-th smallest of the 64 per-lane minima (k lanes hold a value <= it) ----
   uint32_t lmin = 0xffffffffu;
+  // (the slot loops below test `per` once per block of eight slots: slots past N hold the sentinel key, which no bound admits;
+  //  a uniform `t < per` per slot made hipcc keep 64 such predicates in SGPRs across the loops -- 587 scalar spills)
 #pragma unroll
-  for (int t = 0; t < kKnnMaxPerLane; ++t)
-    if (t < per) lmin = min(lmin, key[t]);
+  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+    if (t0 < per) {
+#pragma unroll
+      for (int t = t0; t < t0 + 8; ++t) lmin = min(lmin, key[t]);
+    }
   // (bisection over the upper 16 key bits only: the bound may be the top of the k-th minimum's 2^-7-wide bucket, which lets a few
   //  more candidates through to the list and halves this phase)
   uint32_t lo = 0u, hi = 0xffffu;
@@ -88,7 +93,7 @@ __device__ long long g_knn_stamp[8];
     }
     lo = (lo << 16) | 0xffffu;
     if (lo == 0xffffffffu) lo = 0xfffffffeu;   // never admit the sentinel keys of slots past N
-  } else lo = 0xffffffffu;
+  } else lo = 0xfffffffeu;   // every real candidate; the sentinel keys (0xffffffff) of slots past N stay out without an index test
   const uint32_t T0 = lo;
   KNN_STAMP(2);
   // ---- 2. compact the survivors (key <= T0), in increasing point index, into this wave's LDS list ----
@@ -96,15 +101,18 @@ __device__ long long g_knn_stamp[8];
   __shared__ int s_idx[4][kKnnList];
   int M = 0;
 #pragma unroll
-  for (int t = 0; t < kKnnMaxPerLane; ++t)
-    if (t < per) {
-      // about k + a few of the N candidates survive, so most 64-candidate slots hold none: skip those on the scalar unit
-      if (__ballot(key[t] <= T0) == 0ull) continue;
-      const bool sel = key[t] <= T0 && t * 64 + lane < N;
-      const unsigned long long m = __ballot(sel);
-      const int pos = M + __popcll(m & ((1ull << lane) - 1ull));
-      if (sel && pos < kKnnList) { s_key[wave][pos] = key[t]; s_idx[wave][pos] = t * 64 + lane; }
-      M += __popcll(m);
+  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+    if (t0 < per) {
+#pragma unroll
+      for (int t = t0; t < t0 + 8; ++t) {
+        // about k + a few of the N candidates survive, so most 64-candidate slots hold none: skip those on the scalar unit
+        const bool sel = key[t] <= T0;   // T0 <= 0xfffffffe: no sentinel passes, no `t * 64 + lane < N` needed
+        const unsigned long long m = __ballot(sel);
+        if (m == 0ull) continue;
+        const int pos = M + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < kKnnList) { s_key[wave][pos] = key[t]; s_idx[wave][pos] = t * 64 + lane; }
+        M += __popcll(m);
+      }
     }
   int* out = nn + ((size_t)cloud * N + q) * k;
   KNN_STAMP(3);
@@ -144,8 +152,11 @@ __device__ long long g_knn_stamp[8];
     const uint32_t mid = lo + ((hi - lo) >> 1);
     int c = 0;
 #pragma unroll
-    for (int t = 0; t < kKnnMaxPerLane; ++t)
-      if (t < per) c += key[t] <= mid;
+    for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+      if (t0 < per) {
+#pragma unroll
+        for (int t = t0; t < t0 + 8; ++t) c += key[t] <= mid;
+      }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if (c >= k) hi = mid; else lo = mid + 1;
@@ -155,8 +166,8 @@ __device__ long long g_knn_stamp[8];
   for (int pass = 0; pass < 2 && written < k; ++pass) {
 #pragma unroll
     for (int t = 0; t < kKnnMaxPerLane; ++t)
-      if (t < per) {
-        const bool sel = (pass == 0 ? key[t] < T : key[t] == T) && t * 64 + lane < N;
+      if ((t & ~7) < per) {
+        const bool sel = pass == 0 ? key[t] < T : key[t] == T;   // T <= T0 <= 0xfffffffe
         const unsigned long long m = __ballot(sel);
         const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
         if (sel && pos < k) out[pos] = t * 64 + lane;
