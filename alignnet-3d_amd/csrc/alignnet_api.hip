@@ -504,6 +504,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
                               long tower_stride, long row_stride, size_t pooled_floats)
 {
   DgcnnArgs a;
+  a.stamps = nullptr;
   a.pcs[0] = p1; a.pcs[1] = p2; a.xform = h->ws.xform; a.nn = h->ws.d_nn; a.pooled = pooled;
   a.tower_stride = tower_stride; a.row_stride = row_stride;
   a.B = B; a.N = h->cfg.num_points; a.k = 20; a.nlayers = st.n;   // k = 20 is hard-coded in the reference (tp8.py:33)
@@ -550,7 +551,16 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       if (!dsattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr = true; }
       hipLaunchKernelGGL(dgcnn_split, grid, dim3(kWaves * 64), dlds, h->stream, sa);
     } else {
+      const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+      a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
       hipLaunchKernelGGL(dgcnn_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+      if (a.stamps) {
+        long long sv[9];
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(sv, a.stamps, sizeof(sv), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "dgcnn_fused slot-5 cycles: mfma %lld es %lld barrier %lld lift %lld barrier %lld | k-max store + barrier %lld point conv %lld\n",
+                     sv[1] - sv[0], sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[7] - sv[6], sv[8] - sv[7]);
+      }
     }
   }
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }

@@ -182,7 +182,9 @@ struct DgcnnArgs {
   int B, N, k, nlayers;
   int ld[2];
   ConvLayerDev L[kMaxConv];   // L[0].w = raw [6][C1]; others packed images
+  long long* stamps;          // debug (ALIGNNET_DBG & 64): cycle stamps of thread 0 / workgroup (1, 0) around neighbour slot 5
 };
+#define DG_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 constexpr int kDgTile = 64;   // points per workgroup (two 32-row MFMA tiles)
 
@@ -304,13 +306,23 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
         breg[s][kg] = reinterpret_cast<const f32x4*>(LE.w)[((size_t)ct * KG + min(kg, KG - 1)) * 64 + lane];
     }
   }
+  // scale / shift of the wave's (<= 2) items stay in registers across the neighbour slots (reloaded per slot they were an L2
+  // round trip between every slot's MFMAs and its running max)
+  float esc[kSlots], esh[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int col = (min(wave + s * kWaves, CTE * 2 - 1) >> 1) * 32 + (lane & 31);
+    const bool live = col < LE.cout;
+    esc[s] = live ? LE.scale[tower * LE.cout + col] : 0.f;
+    esh[s] = live ? LE.shift[tower * LE.cout + col] : 0.f;
+  }
   auto edge_mfma_reg = [&](const float* in, int ldi) {
     const int KG = (LE.cin + 7) >> 3;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
       const int item = wave + s * kWaves;
       if (item < CTE * 2) {
-        const int ct = item >> 1, m = item & 1;
+        const int m = item & 1;
         const float* arow = in + (m * 32 + (lane & 31)) * ldi + (lane >> 5) * 4;
         f32x4 av[8];
 #pragma unroll
@@ -324,11 +336,8 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg][q], breg[s][kg][q], acc, 0, 0, 0);
           }
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < LE.cout;
-        const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[r], sc, sh));
+        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[r], esc[s], esh[s]));
       }
     }
   };
@@ -341,11 +350,8 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
         const int ct = item >> 1, m = item & 1;
         f32x16 acc[1];
         mfma_rows<1>(in + m * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(LE.w) + (size_t)ct * KG * 64, KG, lane, acc);
-        const int col = ct * 32 + (lane & 31);
-        const bool live = col < LE.cout;
-        const float sc = live ? LE.scale[tower * LE.cout + col] : 0.f, sh = live ? LE.shift[tower * LE.cout + col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[0][r], sc, sh));
+        for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[0][r], esc[s], esh[s]));
       }
     }
   };
@@ -362,14 +368,21 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
+      if (slot == 5) DG_STAMP(0);
       if (more && tid < kDgTile) dg_gather(a, pc, cloud, tile, slot + 1, tid, v);        // in flight during the MFMAs
       if (wreg) edge_mfma_reg(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
       else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
+      if (slot == 5) DG_STAMP(1);
       if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
+      if (slot == 5) DG_STAMP(2);
       __syncthreads();
+      if (slot == 5) DG_STAMP(3);
       if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), a.ld[0], tid, &lregs);
+      if (slot == 5) DG_STAMP(4);
       __syncthreads();
+      if (slot == 5) DG_STAMP(5);
     }
+    DG_STAMP(6);
   } else {
     for (int slot = 0; slot < a.k; ++slot) {
       __syncthreads();
@@ -412,6 +425,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     }
   }
   __syncthreads();
+  DG_STAMP(7);
   // ---- point conv (widths[-1]) + max over the tile's points (tp8.py:43-45) ----
   {
     const ConvLayerDev& L = a.L[nl - 1];
@@ -437,6 +451,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
       if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
     }
   }
+  DG_STAMP(8);
 }
 
 }  // namespace alignnet
