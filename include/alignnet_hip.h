@@ -142,7 +142,10 @@ int alignnet_synchronize(alignnet_handle* h);
  *      forward with batch statistics, loss, backward, (all-reduce), Adam, EMA, step++ */
 /* dropout_u: optional host array of uniforms [0,1) used for the dropout masks, laid out
  * [s1 tower0 | s2 tower0 | s1 tower1 | s2 tower1 | pair head], each B x last-hidden-width;
- * NULL = draw on the device from cfg.seed and the step counter. */
+ * NULL = draw on the device from cfg.seed and the step counter.
+ * Shapes: three-conv backbones, widths multiples of 32, C1, C2 <= 128, C3 <= 1024 (every shipped config);
+ * backbone "dgcnn" (models/tp8.py:30-46, k = 20): fp32 only, C1 in {32, 64}, C2 in {64, 128}, 20 <= num_points <= 4096.
+ * Anything else fails with a message (alignnet_last_error), it is never run on a fallback. */
 int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
                         const alignnet_labels* labels, int32_t B, const float* dropout_u,
                         alignnet_step_result* result, const alignnet_outputs* out);
