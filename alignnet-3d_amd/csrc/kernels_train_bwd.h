@@ -476,7 +476,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const bool on = live && row < nvalid && X[row * ld0 + col] > 0.f;
+        const float h1v = X[row * ld0 + (live ? col : 0)];   // unconditional: behind `&&` it is an exec-masked read waited for on the spot
+        const bool on = live && row < nvalid && h1v > 0.f;
         const float dy = on ? acc[0][r] : 0.f;
         const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
         const float z = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0)) + bias;
