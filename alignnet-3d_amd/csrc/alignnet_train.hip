@@ -274,6 +274,16 @@ static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, floa
   hipLaunchKernelGGL((reduce_slices_kernel<T>), dim3((unsigned)((n + 31) / 32), towers), dim3(1024), 0, h->stream, part, S, n, out, alpha, acc);
 }
 
+static ReduceJob rjob(const float* part, int S, long n, float* out, float alpha = 1.f, int towers = 2) { return ReduceJob{part, 0, S, n, out, alpha, towers}; }
+static ReduceJob rjob(const double* part, int S, long n, float* out, float alpha = 1.f, int towers = 2) { return ReduceJob{part, 1, S, n, out, alpha, towers}; }
+static void launch_reduce_multi(alignnet_handle* h, int njobs, ReduceJob a, ReduceJob b, ReduceJob c = ReduceJob{nullptr, 0, 0, 0, nullptr, 1.f, 0})
+{
+  ReduceJobs J{{a, b, c}};
+  long nmax = 0;
+  for (int i = 0; i < njobs; ++i) nmax = std::max(nmax, J.j[i].n);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, njobs), dim3(1024), 0, h->stream, J);
+}
+
 static void launch_loss(alignnet_handle* h, const LossArgs& la)
 {
   const int nprep = (3 * la.B + 63) / 64;   // softmax-row workgroups of loss_prep_kernel (+1 for the Huber terms)
@@ -403,8 +413,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     finish(2, C3, 2, count);
-    launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
-    launch_reduce<double>(h, w->colsum_part, 2 * B, (long)(C2), S.s2);
+    launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
   } else {
   hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
   finish(0, C1, 1, count);
@@ -427,8 +436,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                          w->gram_part);
   }
   finish(2, C3, 2, count);
-  launch_reduce<float>(h, w->gram_part, B, (long)(C2 * C2), S.gram2);
-  launch_reduce<double>(h, w->colsum_part, 4 * B, (long)(C2), S.s2);
+  launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
   }
   hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
   const size_t tot = (size_t)2 * B * C3;
@@ -553,15 +561,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
-  hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(256), 0, h->stream, p3);
+  hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
   hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
                      w->E3, C2, C3, G(h, w, L[2]->p_w));
-  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0);
-  hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 1), dim3(256), 0, h->stream, W3, C2, C3,
-                     (const float*)nullptr, w->W3T, 1);
+  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0, 2, (const float*)nullptr, w->W3T, 1, 1);
   const size_t qimg = img_floats(C2, C2);
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
@@ -613,29 +619,25 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   auto layer2_weight_grad = [&]() {
-    launch_reduce<float>(h, w->u2_part, B, (long)(C1 * C2), w->u2);
-    launch_reduce<float>(h, w->g1_part, B, (long)(C1 * C1), w->g1);
+    launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(w->g1_part, B, (long)(C1 * C1), w->g1));
     hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, Me, w->m1);
     // GW2[t] = Ghat1[t] W2
     launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
     hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
                        G(h, w, L[1]->p_w));
   };
-  launch_reduce<double>(h, w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2);
   const int sG = std::max(1, 256 / C1);
-  if (dg) {   // the forward kept the column sums of h1 (all edge rows)
-    launch_reduce<float>(h, S.s1e, 1, (long)(C1), w->s1);
-    launch_reduce<float>(h, S.s1e, 1, (long)(C1), w->m1, 2, (float)(1.0 / Me));
-  } else {
-    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->s1);
-    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), w->m1, 2, (float)(1.0 / M));   // m1 = s1 / M (qbias needs it before B1)
-  }
+  if (dg)   // the forward kept the column sums of h1 (all edge rows)
+    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), w->s1),
+                        rjob(S.s1e, 1, (long)(C1), w->m1, (float)(1.0 / Me)));
+  else      // m1 = s1 / M (qbias needs it before B1)
+    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(w->s1_part, B * sG, (long)(C1), w->s1),
+                        rjob(w->s1_part, B * sG, (long)(C1), w->m1, (float)(1.0 / M)));
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
                      P(h, L[1]->p_bn[1][1]), C2, Me, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
                      G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
   if (!acc_in_b1) layer2_weight_grad();
-  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0);
-  hipLaunchKernelGGL(scale_cols_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->k2, w->V2, 1);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
+  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0, 2, w->k2, w->V2, 1, 2);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);

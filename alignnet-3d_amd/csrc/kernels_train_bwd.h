@@ -631,6 +631,32 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
   }
 }
 
+// Several slice reductions in one launch (every launch costs >= 4.7 us on the one stream of a step, whatever its work):
+// grid (max over jobs of ceil(n/32), 2 towers, jobs).  Same summation order as reduce_slices_kernel.
+struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers; };
+struct ReduceJobs { ReduceJob j[3]; };
+__global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs jobs)
+{
+  __shared__ double red[32][33];
+  const ReduceJob jb = jobs.j[blockIdx.z];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, t = blockIdx.y;
+  const long i = blockIdx.x * 32L + cl;
+  if (t >= jb.towers || blockIdx.x * 32L >= jb.n) return;
+  double s = 0.0;
+  if (i < jb.n) {
+    if (jb.is_double) { const double* p = static_cast<const double*>(jb.part); for (int k = g; k < jb.S; k += 32) s += p[((size_t)t * jb.S + k) * jb.n + i]; }
+    else { const float* p = static_cast<const float*>(jb.part); for (int k = g; k < jb.S; k += 32) s += (double)p[((size_t)t * jb.S + k) * jb.n + i]; }
+  }
+  red[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && i < jb.n) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) tot += red[k][cl];
+    jb.out[(size_t)t * jb.n + i] = (float)tot * jb.alpha;
+  }
+}
+
 // centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
 __global__ void centre_gram_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m)
 {
@@ -659,15 +685,15 @@ struct Prep3Args {
   float* E; float* kdb; float* gs;                  // [2][C], [2][C], [2B][C]
 };
 
-__global__ __launch_bounds__(256) void prep3_kernel(const Prep3Args a)   // grid (ceil(C/32), 2), block 32 channels x 8 cloud groups
+__global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // grid (ceil(C/32), 2), block 32 channels x 32 cloud groups (the cloud loop is a chain of dependent loads)
 {
-  __shared__ double red[8][32][2];
+  __shared__ double red[32][32][2];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
   float rs = 0.f, k = 0.f;
   double sb = 0.0, sg = 0.0;
   if (c < a.C) {
     rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps); k = a.gamma[t][c] * rs;
-    for (int b = g; b < a.B; b += 8) {
+    for (int b = g; b < a.B; b += 32) {
       const size_t pi = t * a.tower_stride + b * a.row_stride + c;
       const float g0 = a.pooled[pi] > 0.f ? a.dP[pi] : 0.f;
       const size_t ci = (size_t)(t * a.B + b) * a.C + c;
@@ -679,7 +705,7 @@ __global__ __launch_bounds__(256) void prep3_kernel(const Prep3Args a)   // grid
   __syncthreads();
   if (g != 0 || c >= a.C) return;
   sb = 0.0; sg = 0.0;
-  for (int q = 0; q < 8; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
+  for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   a.dbeta[t][c] = (float)sb;
   a.dgamma[t][c] = (float)sg;
   a.E[t * a.C + c] = (float)(-(double)k * rs * sg / a.M);
@@ -762,6 +788,25 @@ __global__ void scale_cols_kernel(const float* __restrict__ W, int R, int C, con
   const float v = W[e] * (col ? col[t * C + j] : 1.f);
   if (transpose_out) out[(size_t)t * R * C + (size_t)j * R + i] = v;
   else out[(size_t)t * R * C + e] = v;
+}
+
+// two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)
+__global__ void scale_cols2_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ colA, float* __restrict__ outA, int trA,
+                                   int towersA, const float* __restrict__ colB, float* __restrict__ outB, int trB, int towersB)
+{
+  const int t = blockIdx.y;
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= (long)R * C) return;
+  const int i = e / C, j = e % C;
+  const float wv = W[e];
+  if (t < towersA) {
+    const float v = wv * (colA ? colA[t * C + j] : 1.f);
+    outA[(size_t)t * R * C + (trA ? (size_t)j * R + i : (size_t)e)] = v;
+  }
+  if (t < towersB) {
+    const float v = wv * (colB ? colB[t * C + j] : 1.f);
+    outB[(size_t)t * R * C + (trB ? (size_t)j * R + i : (size_t)e)] = v;
+  }
 }
 
 // dW[i][j] (+)= sum_t ( Sp[t][i][j]*spscale[t][j] - m[t][i]*kdb[t][j] + GW[t][i][j]*E[t][j] )
