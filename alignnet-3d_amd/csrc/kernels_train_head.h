@@ -44,15 +44,40 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float ra[16], rb[16];
+  // Element addresses are fixed per lane up to the chunk offset: computed once (clamped to the matrix, so the loads need no
+  // branch around them) instead of 64-bit multiply-adds and two exec-masked blocks per load in every chunk -- the address
+  // arithmetic was about 500 VALU instructions per chunk and wave, more than the 16 MFMAs it feeds.
+  const float* pa[16];
+  const float* pb[16];
+  unsigned va = 0u, vb = 0u;   // bit t: row (column) of element t is inside the matrix
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int e = lane + 64 * t;
+    const int ai = a_kfast ? e >> 5 : e & 31, ak = a_kfast ? e & 31 : e >> 5;
+    const int bj = b_jfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
+    pa[t] = A + (size_t)min(i0 + ai, a.M - 1) * a.sa_i + (size_t)ak * a.sa_k;
+    pb[t] = Bm + (size_t)bk * a.sb_k + (size_t)min(j0 + bj, a.N - 1) * a.sb_j;
+    va |= (unsigned)(i0 + ai < a.M) << t;
+    vb |= (unsigned)(j0 + bj < a.N) << t;
+  }
   auto fetch = [&](int c) {
     const int kc = c * kGemmKC;
+    if (kc + kGemmKC <= a.K) {   // whole chunk inside K (always, for K % 32 == 0)
+      const size_t oa = (size_t)kc * a.sa_k, ob = (size_t)kc * a.sb_k;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int e = lane + 64 * t;
-      const int ai = a_kfast ? e >> 5 : e & 31, ak = a_kfast ? e & 31 : e >> 5;
-      const int bj = b_jfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
-      ra[t] = (i0 + ai < a.M && kc + ak < a.K) ? A[(size_t)(i0 + ai) * a.sa_i + (size_t)(kc + ak) * a.sa_k] : 0.f;
-      rb[t] = (j0 + bj < a.N && kc + bk < a.K) ? Bm[(size_t)(kc + bk) * a.sb_k + (size_t)(j0 + bj) * a.sb_j] : 0.f;
+      for (int t = 0; t < 16; ++t) { ra[t] = pa[t][oa]; rb[t] = pb[t][ob]; }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { ra[t] = (va >> t) & 1u ? ra[t] : 0.f; rb[t] = (vb >> t) & 1u ? rb[t] : 0.f; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = lane + 64 * t;
+        const int ak = a_kfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
+        const int ka = min(kc + ak, a.K - 1) - ak, kb = min(kc + bk, a.K - 1) - bk;   // clamped chunk offsets
+        const float xa = pa[t][(size_t)ka * a.sa_k], xb = pb[t][(size_t)kb * a.sb_k];
+        ra[t] = (((va >> t) & 1u) && kc + ak < a.K) ? xa : 0.f;
+        rb[t] = (((vb >> t) & 1u) && kc + bk < a.K) ? xb : 0.f;
+      }
     }
   };
   if (c0 < c1) fetch(c0);
