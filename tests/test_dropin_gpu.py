@@ -73,6 +73,25 @@ def test_train_py_end_to_end(gpu_required, tmp_path):
     assert out3.count("Timing bs=32:") == 10
 
 
+def test_train_py_dgcnn_backbone(gpu_required, tmp_path):
+    """cfg.model.backbone = "dgcnn" (reference tp8.py:228-231) through the drop-in driver: trains, checkpoints, evaluates."""
+    root = tmp_path / "SynthTiny"
+    _make_dataset(str(root))
+    user = {"data": {"basepath": str(root)}, "logging": {"basedir": str(tmp_path / "logs")},
+            "model": {"backbone": "dgcnn", "num_points": 64, "angles": {"num_bins": 12, "accept_inverted_angle": True},
+                      "options": {"s1transformer": [[32, 64, 96], [[64, 32], 0.7]], "s2transformer": [[32, 64, 128], [[64, 32], 0.7]],
+                                  "embedding": [32, 64, 160], "remaining_transform_prediction": [[64, 32], 0.7]}},
+            "training": {"batch_size": 8, "num_epochs": 1, "learning_rate": 0.002}}
+    cfgp = tmp_path / "TinyDgcnn.json"
+    json.dump(user, open(cfgp, "w"))
+    out = _run(["train", "--config", str(cfgp)], str(tmp_path))
+    logdir = tmp_path / "logs" / "TinyDgcnn"
+    assert (logdir / "model-0.aln3").exists() and "train mean loss" in out and "Finished Training" in out
+    ev = logdir / "val" / "eval000000"
+    a = np.load(ev / "pred_translations.npy")
+    assert a.shape[0] == 8 and np.all(np.isfinite(a))
+
+
 def test_rccl_world1_and_device_entry_points(gpu_required):
     import torch
     cfg = small_cfg(N=128)
