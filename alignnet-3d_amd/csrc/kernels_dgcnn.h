@@ -58,13 +58,15 @@ __device__ long long g_knn_stamp[8];
         const int j = min((t0 + u) * 64 + lane, N - 1);
         px[u] = pc[j * 3]; py[u] = pc[j * 3 + 1]; pz[u] = pc[j * 3 + 2];
       }
+      // two candidates per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32): same operations per component
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = (t0 + u) * 64 + lane;
-        const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
-        const float inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
-        const uint32_t kk = fkey(qq + inner + (x * x + y * y + z * z));   // square + inner + square^T (:657)
-        key[t0 + u] = j < N ? kk : 0xffffffffu;
+      for (int u = 0; u < 8; u += 2) {
+        const f32x2 x = f32x2{px[u], px[u + 1]} - cx, y = f32x2{py[u], py[u + 1]} - cy, z = f32x2{pz[u], pz[u + 1]} - cz;
+        const f32x2 inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
+        const f32x2 d = qq + inner + (x * x + y * y + z * z);             // square + inner + square^T (:657)
+        key[t0 + u] = (t0 + u) * 64 + lane < N ? fkey(d[0]) : 0xffffffffu;
+        key[t0 + u + 1] = (t0 + u + 1) * 64 + lane < N ? fkey(d[1]) : 0xffffffffu;
       }
     } else {
 #pragma unroll
@@ -116,6 +118,22 @@ __device__ long long g_knn_stamp[8];
     }
   int* out = nn + ((size_t)cloud * N + q) * k;
   KNN_STAMP(3);
+  if (M <= 64) {
+    // ---- 3a'. the usual case, one list entry per lane: rank every entry among the others by its (key, index) pair --
+    //           one 64-bit compare per entry -- and let the entries of rank < k write themselves (nearest first; ties at
+    //           the k-th key go to the lower point indices as tf.nn.top_k).  A 32-step bisection was 5.2 k cycles. ----
+    const bool in = lane < M;
+    const unsigned long long mine = in ? ((unsigned long long)s_key[wave][lane] << 32) | (unsigned)s_idx[wave][lane] : ~0ull;
+    int rank = 0;
+    for (int i = 0; i < M; ++i) {
+      const unsigned long long other = __shfl(mine, i);   // uniform source lane: a v_readlane pair
+      rank += other < mine;
+    }
+    if (in && rank < k) out[rank] = (int)(mine & 0xffffffffu);
+    KNN_STAMP(4);
+    KNN_STAMP(5);
+    return;
+  }
   if (M <= kKnnList) {
     // ---- 3a. k-th smallest of the list by bisection (<= 4 entries per lane), emit in list (= index) order ----
     uint32_t lk[kKnnList / 64];
