@@ -201,7 +201,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.gx = F(B2 * 3); S.grot = F(B2);
       const bool dgb = h->cfg.backbone == 1;
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
-      S.mom = D(dgb ? B2 * kDgMom : 0); S.s1e = F(2 * C[0]);
+      S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]);
       const Stack& fs = fc_of(h, s);
       const size_t M = s < 2 ? B2 : (size_t)B;
       for (int j = 0; j < fs.n - 1; ++j) {
@@ -217,7 +217,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
-    w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(h->cfg.backbone == 1 ? B2 * 4 * 7 * maxC1 : 0);
+    w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(B2 * 4 * 7 * maxC1);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 256);   // [2B][256 / C1 row groups][C1]
     w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 6 * maxC1);
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
@@ -337,6 +337,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -672,8 +673,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
-    hipLaunchKernelGGL(dg_b0_totals, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
-    hipLaunchKernelGGL(dg_b0_cloud, dim3(2 * B), dim3(128), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_cloud<6>, dim3(2 * B), dim3(128), 0, h->stream, z);
     launch_reduce<float>(h, w->p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1);
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -687,8 +688,25 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
   b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = acc_in_b1 ? w->g1_part : nullptr;
   // (train_bwd_b1<64, 128> and the bf16 phase 3 with compile-time widths unroll further and spill: 67 / 39 -- generic ones kept)
-  hipLaunchKernelGGL(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
+  b1.pdy_part = w->pdy_part;
+  if (pdy) hipLaunchKernelGGL((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  else hipLaunchKernelGGL(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   if (acc_in_b1) layer2_weight_grad();
+  if (pdy) {
+    // first layer from the reduced quantities (kernels_train_dgcnn.h, D = 3)
+    hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom);
+    DgB0Args z;
+    z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N; z.count = M;
+    for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
+    z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
+    hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_cloud<3>, dim3(2 * B), dim3(128), 0, h->stream, z);
+    launch_reduce<float>(h, w->p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
   launch_reduce<double>(h, w->dbg1_part, 4 * B, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
                      P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),

@@ -261,6 +261,40 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
 }
 
 // hidden layer: out[row][col] = relu(acc*scale+shift) for this item's MR row tiles x one channel tile
+// Same product with compiler-managed loads (safe under spills) and the weight stream three k-groups deep: each load is
+// pinned in front of the MFMAs of the k-group two ahead of it by a compiler barrier (left alone, hipcc sinks it next to its
+// use and every k-group starts with an exposed L2 round trip -- a one-deep lookahead covers 256 cycles of MFMAs at MR = 1,
+// the round trip is 500-800).
+template <int MR, bool CLEAR = true>
+__device__ __forceinline__ void mfma_rows_deep(const float* __restrict__ A, int lda, const f32x4* __restrict__ Wp, int KG, int lane,
+                                               f32x16 (&acc)[MR])
+{
+  if (CLEAR) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  }
+  const float* arow = A + (lane & 31) * lda + (lane >> 5) * 4;
+  const f32x4* wp = Wp + lane;
+  const int last = KG - 1;
+  f32x4 b0 = wp[0], b1 = wp[min(1, last) * 64], b2 = wp[min(2, last) * 64];
+  asm volatile("" ::: "memory");
+  f32x4 av[MR];
+  for (int kg = 0; kg < KG; kg += 3) {
+    lds_rows<MR>(arow, lda, kg, av);
+    mfma_kgroup<MR>(av, b0, acc);
+    b0 = wp[min(kg + 3, last) * 64];
+    asm volatile("" ::: "memory");
+    if (kg + 1 < KG) { lds_rows<MR>(arow, lda, kg + 1, av); mfma_kgroup<MR>(av, b1, acc); }
+    b1 = wp[min(kg + 4, last) * 64];
+    asm volatile("" ::: "memory");
+    if (kg + 2 < KG) { lds_rows<MR>(arow, lda, kg + 2, av); mfma_kgroup<MR>(av, b2, acc); }
+    b2 = wp[min(kg + 5, last) * 64];
+    asm volatile("" ::: "memory");
+  }
+}
+
 template <int MR>
 __device__ __forceinline__ void hidden_item(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
                                             const ConvLayerDev& L, int tower, int ct, int rg, int lane)

@@ -370,9 +370,15 @@ struct BwdB1Args {
   double* dbg1_part;                                 // [2B][4 = 2 row groups x 2 halves][C1][2]
   float* u2_part; float* g1_part;                    // [2B][C1*C2], [2B][C1*C1] (upper blocks) or null: accumulated in B2
   int dy2_bf16;                                      // dy2_store holds bf16 (train_matmul_bf16)
+  double* pdy_part;                                  // PDY variant: [2B][4 = 2 row groups x 2 halves][4][C1]: sum x'_d dy1 (d < 3), sum dy1
 };
 
-template <int C1T = 0, int C2T = 0>   // compile-time widths (0 = from the arguments), see train_bwd_b2
+// PDY (C1 <= 64, one item per wave): dy1 is not stored and dbeta1 / dgamma1 are not reduced here.  The first layer is linear in
+// x', so everything behind it -- dbeta1, dgamma1, dW1 and the per-cloud frame gradients -- follows from Pdy = sum x'^T dy1 (3 x C1),
+// sum dy1 and the cloud's moments of x' (dg_b0_totals<3> / dg_b0_cloud<3>, kernels_train_dgcnn.h): no pass B0, no [B*N, C1]
+// round trip.  Pdy rides on the accumulator layout as one more MFMA chain (the masked accumulator element r is the B operand of
+// step r, A = x'^T with a row of ones).
+template <int C1T = 0, int C2T = 0, bool PDY = false>   // compile-time widths (0 = from the arguments), see train_bwd_b2
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -404,6 +410,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
 
+  f32x16 pacc;
+  double pd[4] = {0.0, 0.0, 0.0, 0.0};
+  if (PDY) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+  }
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
@@ -461,6 +473,28 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
       const bool live = col < kC1;
       f32x16 acc[1];
       const float qb = live ? a.q2b[tower * kC1 + col] : 0.f;
+      if (PDY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = qb;
+        mfma_rows_deep<1, false>(Y + rg * 32 * ldb, ldb, v2img + (size_t)ct * KGv * 64, KGv, lane, acc);
+        mfma_rows_deep<1, false>(X + rg * 32 * ld0, ld0, q2img + (size_t)ct * KGq * 64, KGq, lane, acc);
+        const int ei = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float h1v = X[row * ld0 + (live ? col : 0)];
+          const float xv = xs[row * 4 + (ei & 3)];
+          const float dy = (live && row < nvalid && h1v > 0.f) ? acc[0][r] : 0.f;
+          const float ea = ei < 3 ? xv : (ei == 3 ? 1.f : 0.f);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea, dy, pacc, 0, 0, 0);
+        }
+        // fp32 sums of one tile folded into fp64: lanes of the lower half hold d = 0..2 and sum dy1 (q = 0..3), the upper half zeros
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pd[q] += (double)pacc[q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+        continue;
+      }
       double* dslice = a.dbg1_part + (((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * kC1 + (live ? col : 0)) * 2;   // slice (rg, half)
       const double o0 = (first || !live) ? 0.0 : dslice[0], o1 = (first || !live) ? 0.0 : dslice[1];
       asm volatile("" ::: "memory");
@@ -488,6 +522,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
         dslice[0] = o0 + (double)lb;
         dslice[1] = o1 + (double)lg;
       }
+    }
+  }
+  if (PDY && wave < nitems) {
+    const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
+    if (col < kC1) {
+      double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * 4 * kC1 + col;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dst[(size_t)d * kC1] = pd[d];   // the upper half-wave's slice is zero
     }
   }
 #pragma unroll

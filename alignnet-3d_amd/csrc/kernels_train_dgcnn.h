@@ -676,32 +676,35 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
 //               gx_d = sum_c w_dc S_c (d < 3),  grot = sum_c (w_0c P_1c - w_1c P_0c + w_3c P_4c - w_4c P_3c)   (dg_b0_cloud)
 //   dW1 = sum over clouds of P.
 // ---------------------------------------------------------------------------------
+// D = 6: DGCNN (e = [x_i, x_j - x_i]);  D = 3: the PointNet first layer (e = x'), where the same identities replace pass B0 and
+// the stored dy1: moments [2B][D + D(D+1)/2] = sum e | upper triangle of sum e e^T (row-major, d <= d2); Pdy [2B][4][D + 1][C1].
 struct DgB0Args {
-  const double* pdy_part;   // [2B][4][7][C1]
-  const double* mom;        // [2B][27]
-  const float* w1; const float* b1; const float *mean1, *rstd1, *k1;   // [6][C1], [C1], [2][C1] x 3
-  int B, C1, rows;          // rows per cloud = N * k
-  double count;             // M = B * N * k
+  const double* pdy_part;   // [2B][4][D + 1][C1]
+  const double* mom;        // [2B][D + D (D + 1) / 2]
+  const float* w1; const float* b1; const float *mean1, *rstd1, *k1;   // [D][C1], [C1], [2][C1] x 3
+  int B, C1, rows;          // rows per cloud (DGCNN: N * k)
+  double count;             // M = B * rows
   float* dbeta[2]; float* dgamma[2];
   float* dbg1;              // [2][C1][2] totals (dbeta1, dgamma1)
-  float* p_part;            // [2B][6][C1]
+  float* p_part;            // [2B][D][C1]
   float* gx; float* grot;   // [2B][3], [2B]
 };
 
+template <int D>
 __global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid (ceil(C1/32), 2), block 32 channels x 32 cloud groups
 {
   __shared__ double red[32][32][2];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
   double sdy = 0.0, wp = 0.0;
   if (c < a.C1) {
-    double w[6];
+    double w[D];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
+    for (int d = 0; d < D; ++d) w[d] = (double)a.w1[d * a.C1 + c];
     for (int bs = g; bs < a.B * 4; bs += 32) {
-      const double* p = a.pdy_part + ((size_t)t * a.B * 4 + bs) * 7 * a.C1 + c;
+      const double* p = a.pdy_part + ((size_t)t * a.B * 4 + bs) * (D + 1) * a.C1 + c;
 #pragma unroll
-      for (int d = 0; d < 6; ++d) wp += w[d] * p[(size_t)d * a.C1];
-      sdy += p[(size_t)6 * a.C1];
+      for (int d = 0; d < D; ++d) wp += w[d] * p[(size_t)d * a.C1];
+      sdy += p[(size_t)D * a.C1];
     }
   }
   red[g][cl][0] = sdy; red[g][cl][1] = wp;
@@ -716,48 +719,50 @@ __global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid
   a.dbg1[(t * a.C1 + c) * 2 + 1] = (float)dg;
 }
 
+template <int D>
 __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2B, block 128 (C1 <= 128)
 {
-  __shared__ double mo[kDgMom];
+  constexpr int kMom = D + D * (D + 1) / 2;
+  __shared__ double mo[kMom];
   __shared__ double red[2][4];
   const int cloud = blockIdx.x, t = cloud >= a.B, c = threadIdx.x;
-  if (threadIdx.x < kDgMom) mo[threadIdx.x] = a.mom[(size_t)cloud * kDgMom + threadIdx.x];
+  if (threadIdx.x < kMom) mo[threadIdx.x] = a.mom[(size_t)cloud * kMom + threadIdx.x];
   __syncthreads();
   double g[4] = {0.0, 0.0, 0.0, 0.0};   // gx0, gx1, gx2, grot
   if (c < a.C1) {
-    double w[6], pdy[7];
+    double w[D], pdy[D + 1];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
+    for (int d = 0; d < D; ++d) w[d] = (double)a.w1[d * a.C1 + c];
 #pragma unroll
-    for (int d = 0; d < 7; ++d) {
+    for (int d = 0; d < D + 1; ++d) {
       double s = 0.0;
-      for (int sl = 0; sl < 4; ++sl) s += a.pdy_part[(((size_t)cloud * 4 + sl) * 7 + d) * a.C1 + c];
+      for (int sl = 0; sl < 4; ++sl) s += a.pdy_part[(((size_t)cloud * 4 + sl) * (D + 1) + d) * a.C1 + c];
       pdy[d] = s;
     }
     const double k = (double)a.k1[t * a.C1 + c], rs = (double)a.rstd1[t * a.C1 + c];
     const double bm = (double)a.b1[c] - (double)a.mean1[t * a.C1 + c];
     const double mb = (double)a.dbg1[(t * a.C1 + c) * 2] / a.count, mg = (double)a.dbg1[(t * a.C1 + c) * 2 + 1] / a.count;
     const double n = (double)a.rows;
-    // symmetric second moment: index of (d, d2), d <= d2, in the packed upper triangle
-    double P[6];
+    double P[D];
     double sew = 0.0;
 #pragma unroll
-    for (int d = 0; d < 6; ++d) sew += mo[d] * w[d];
+    for (int d = 0; d < D; ++d) sew += mo[d] * w[d];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) {
+    for (int d = 0; d < D; ++d) {
       double gw = 0.0;
 #pragma unroll
-      for (int d2 = 0; d2 < 6; ++d2) {
+      for (int d2 = 0; d2 < D; ++d2) {   // symmetric second moment: index of (d, d2) in the packed upper triangle
         const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
-        const int q = 6 + lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+        const int q = D + lo * D - lo * (lo - 1) / 2 + (hi - lo);
         gw += mo[q] * w[d2];
       }
       P[d] = k * (pdy[d] - mb * mo[d] - mg * rs * (gw + bm * mo[d]));
-      a.p_part[((size_t)cloud * 6 + d) * a.C1 + c] = (float)P[d];
+      a.p_part[((size_t)cloud * D + d) * a.C1 + c] = (float)P[d];
     }
-    const double S = k * (pdy[6] - n * mb - mg * rs * (sew + n * bm));
+    const double S = k * (pdy[D] - n * mb - mg * rs * (sew + n * bm));
     g[0] = w[0] * S; g[1] = w[1] * S; g[2] = w[2] * S;
-    g[3] = w[0] * P[1] - w[1] * P[0] + w[3] * P[4] - w[4] * P[3];
+    g[3] = w[0] * P[1] - w[1] * P[0];
+    if (D == 6) g[3] += w[3] * P[4] - w[4] * P[3];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -769,6 +774,38 @@ __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2
   __syncthreads();
   if (threadIdx.x < 3) a.gx[cloud * 3 + threadIdx.x] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x]);
   if (threadIdx.x == 3) a.grot[cloud] = (float)(red[0][3] + red[1][3]);
+}
+
+// first and second moments of the stage-frame points x' of every cloud (the D = 3 input of the two kernels above), fp64.  grid 2B
+__global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                         const float* __restrict__ xform, int B, int N, double* __restrict__ mom)
+{
+  __shared__ double red[4][9];
+  const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
+  const float* xf = xform + (size_t)cloud * 12;
+  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float x = pc[n * 3] - xf[0], y = pc[n * 3 + 1] - xf[1], z = pc[n * 3 + 2] - xf[2];
+    const double e[3] = {(double)(x * xf[3] + y * xf[6] + z * xf[9]), (double)(x * xf[4] + y * xf[7] + z * xf[10]),
+                         (double)(x * xf[5] + y * xf[8] + z * xf[11])};
+    int q = 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      m[d] += e[d];
+#pragma unroll
+      for (int d2 = d; d2 < 3; ++d2) m[q++] += e[d] * e[d2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double v = m[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) mom[(size_t)cloud * 9 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 }  // namespace alignnet
