@@ -417,7 +417,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     finish(2, C3, 2, count);
     launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
   } else {
-  hipLaunchKernelGGL(train_fwd_phase1, dim3(2 * B), dim3(256), (2048 * 4) * sizeof(float) + 256 * 2 * sizeof(double), h->stream, a);
+  // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
+  hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
   finish(0, C1, 1, count);
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
   if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -697,7 +698,6 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (acc_in_b1) layer2_weight_grad();
   if (pdy) {
     // first layer from the reduced quantities (kernels_train_dgcnn.h, D = 3)
-    hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom);
     DgB0Args z;
     z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N; z.count = M;

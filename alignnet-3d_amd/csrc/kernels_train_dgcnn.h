@@ -777,10 +777,15 @@ __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2
 }
 
 // first and second moments of the stage-frame points x' of every cloud (the D = 3 input of the two kernels above), fp64.  grid 2B
+// With w1 / b1 / stat_part given it is also phase 1 of the PointNet forward: z1 = x' W1 + b1 is linear in x', so the per-channel
+// sum and sum of squares of z1 over the cloud follow from the nine moments (as dg_train_phase1 does for the edge layer).
 __global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
-                                                         const float* __restrict__ xform, int B, int N, double* __restrict__ mom)
+                                                         const float* __restrict__ xform, int B, int N, double* __restrict__ mom,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int C1,
+                                                         double* __restrict__ stat_part)
 {
   __shared__ double red[4][9];
+  __shared__ double tot[9];
   const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   const float* xf = xform + (size_t)cloud * 12;
@@ -805,7 +810,27 @@ __global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 9) mom[(size_t)cloud * 9 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 9) {
+    const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    tot[threadIdx.x] = t;
+    mom[(size_t)cloud * 9 + threadIdx.x] = t;
+  }
+  if (!stat_part) return;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C1; c += 256) {
+    const double w[3] = {(double)w1[c], (double)w1[C1 + c], (double)w1[2 * C1 + c]};
+    double sw = 0.0, qd = 0.0;
+    int q = 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      sw += w[d] * tot[d];
+#pragma unroll
+      for (int d2 = d; d2 < 3; ++d2) qd += (d == d2 ? 1.0 : 2.0) * w[d] * w[d2] * tot[q++];
+    }
+    const double bb = (double)b1[c], n = (double)N;
+    stat_part[((size_t)cloud * C1 + c) * 2] = sw + n * bb;
+    stat_part[((size_t)cloud * C1 + c) * 2 + 1] = qd + 2.0 * bb * sw + n * bb * bb;
+  }
 }
 
 }  // namespace alignnet
