@@ -376,6 +376,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.h2_store = S.h2; a.wp3h = nullptr;
   a.gram_inline = ((C2 + 31) / 32) * ((C2 + 31) / 32 + 1) / 2 > 3 * kTW;   // never for C2 <= 128
   a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+  a.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 32 : nullptr;
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
@@ -431,6 +432,13 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
     hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+    if (a.stamps) {
+      long long sv[8];
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(sv, a.stamps, sizeof(sv), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "P3 stage %d tile-3 cycles: xform %lld lift %lld layer2 %lld barrier %lld store %lld gram %lld layer3 %lld\n", s, sv[1] - sv[0],
+                   sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
+    }
   } else {
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);

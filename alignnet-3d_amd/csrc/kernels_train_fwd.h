@@ -47,7 +47,9 @@ struct TrainFwdArgs {
   float* h2_store;         // [2B*N][C2]
   int gram_inline;         // fp32 phase 3: 1 = accumulate the Gram per tile in this kernel (fallback), 0 = gram_h2_kernel does it
   int dbg;                 // debug/ablation flags (0 in production)
+  long long* stamps;       // debug (dbg & 32): cycle stamps of thread 0 / block 0 at the phase boundaries of tile 3
 };
+#define P3_STAMP(i) do { if (PHASE == 3 && a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // Accumulate one 32x32 MFMA result tile into a lane-owned global matrix.  The old values are requested BEFORE the
 // MFMA loop that produces the new ones and pinned there (compiler memory barrier: hipcc otherwise sinks the loads
@@ -360,10 +362,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     for (int q = 0; q < kBfSlots; ++q) { rs1[q] = 0.f; rs2[q] = 0.f; rbe[q] = -INFINITY; rbi[q] = 0; }
   }
 
+  // layer-2 items of this wave (static slots): batch-stat scale / shift and the running sums stay in registers for the whole cloud
+  // (read / read-modify-written per tile they were dependent L2 round trips inside every tile: ~3 k of its 6.3 k layer-2 cycles)
+  // (phase 2 only -- in the fp32 phase 3 the hand-issued weight stream must stay spill-free, and these eight registers tip it over)
+  constexpr bool kRegSums = PHASE == 2;   // (the bf16 phase 3 spills 27 registers with them and its layer-2 part gets slower: 6.3 k -> 9.8 k cycles per tile)
+  float l2sc[2], l2sh[2];
+  double l2s[2] = {0.0, 0.0}, l2ss[2] = {0.0, 0.0};
+#pragma unroll
+  for (int q2 = 0; q2 < 2; ++q2) {
+    const int col = (min(wave + q2 * kTW, CT2 * 2 - 1) >> 1) * 32 + (lane & 31);
+    const bool live = kRegSums && PHASE == 3 && !GIVEN && col < kC2;
+    l2sc[q2] = live ? a.sc2[tower * kC2 + col] : 0.f;
+    l2sh[q2] = live ? a.sh2[tower * kC2 + col] : 0.f;
+  }
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
+    P3_STAMP(0);
     if (GIVEN) {
       const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c4 = kC2 >> 2;
@@ -376,14 +392,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     } else {
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
+    P3_STAMP(1);
     // bf16 mode: the hidden layer's operands are bf16 too (h1 tile in the buf0 region, row stride K16(C1) + 8 elements)
     const int K16a = (kC1 + 15) & ~15, ld0h = K16a + 8;
     if (BF16) layer1_to_lds_bf16(xs, l1w, kC1, reinterpret_cast<unsigned short*>(buf0), ld0h, K16a, nvalid, tid);
     else layer1_to_lds(xs, l1w, kC1, buf0, ld0, nvalid, tid);
     __syncthreads();
+    P3_STAMP(2);
 
     // ---- layer 2: z2 = h1 W2 + b2; item = (channel tile, 32-row group): C2 = 128 -> 8 items, one per wave ----
-    for (int item = wave; item < CT2 * 2; item += kTW) {
+    auto l2_item = [&](const int q2, const int item) {
       const int ct = item >> 1, rg = item & 1;
       f32x16 acc[1];
       if (BF16)
@@ -405,16 +423,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
             const float dlt = (acc[0][r] + bias) - z0;
             s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
           }
-        if (live) {
-          double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half)
+        {
           const double zd = (double)z0, n = (double)cnt;
-          const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-          const double o0 = first ? 0.0 : st[0], o1 = first ? 0.0 : st[1];
-          st[0] = o0 + ls;
-          st[1] = o1 + lss;
+          l2s[q2] += (double)s1 + n * zd;
+          l2ss[q2] += (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
         }
       } else {
-        const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
+        const float sc = kRegSums ? l2sc[q2] : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = kRegSums ? l2sh[q2] : (live ? a.sh2[tower * kC2 + col] : 0.f);
         float lsum = 0.f;
         const bool wr = col < ((kC2 + 7) & ~7);
         if (BF16) {
@@ -445,15 +460,25 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
             if (wr) buf1[row * ld1 + col] = h;
           }
         }
-        if (live) {
+        if (kRegSums) l2s[q2] += (double)lsum;   // phase 3: the column sum of h2
+        else if (live) {
           double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * kC2 + col;
           *cs = first ? (double)lsum : *cs + (double)lsum;
         }
       }
+    };
+    if constexpr (kRegSums) {   // C2 <= 128: at most two items per wave, static slots (their running sums live in registers)
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+        if (wave + q2 * kTW < CT2 * 2) l2_item(q2, wave + q2 * kTW);
+    } else {
+      for (int item = wave; item < CT2 * 2; item += kTW) l2_item(0, item);
     }
     }   // !GIVEN
+    P3_STAMP(3);
     if (PHASE == 2) continue;
     __syncthreads();
+    P3_STAMP(4);
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
     if (GIVEN) {
@@ -473,6 +498,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       }
     }
 
+    P3_STAMP(5);
     // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's rows ----
     if (BF16 && !(a.dbg & 1)) {
       // upper-triangle blocks only (the Gram is symmetric; centre_gram_kernel mirrors them), register-resident for the
@@ -507,6 +533,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       tile_commit(my_gram, kC2, it, jt, kC2, kC2, g, lane, old);
     }
 
+    P3_STAMP(6);
     // ---- layer 3: z3 = h2 W3 + b3: statistics + extreme of sgn*z3 over the cloud's points ----
     if (BF16) {
       // acc = sgn * (z3 - bias) (sign folded into the bf16 image).  VALU-bound epilogue, 4 ops per element: sum, sum of
@@ -554,6 +581,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
           if (cand > rbe[q]) { rbe[q] = cand; rbi[q] = tile * kTT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane); }
         }
       }
+      P3_STAMP(7);
       continue;
     }
     for (int ct = wave; ct < CT3; ct += kTW) {
@@ -587,6 +615,23 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         my_stat[col * 2] = o0 + ls;
         my_stat[col * 2 + 1] = o1 + lss;
         my_ext[col] = be; my_idx[col] = bi;
+      }
+    }
+  }
+  if (!GIVEN && kRegSums) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int item = wave + q2 * kTW;
+      if (item < CT2 * 2) {
+        const int ct = item >> 1, rg = item & 1, col = ct * 32 + (lane & 31);
+        if (col < kC2) {
+          if (PHASE == 2) {
+            double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half)
+            st[0] = l2s[q2]; st[1] = l2ss[q2];
+          } else {
+            a.colsum_part[((size_t)cloud * 4 + rg * 2 + half) * kC2 + col] = l2s[q2];
+          }
+        }
       }
     }
   }
