@@ -544,12 +544,49 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       // re-writing those 48 KiB per cloud for every tile was the same L2-overflowing traffic as the Gram's.
       const int KG16 = K16 >> 4;
       const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)tower * CT3 * KG16 * 64;
+      // One continuous weight stream over the wave's channel tiles, kRing fragments deep (KG16 % kRing == 0): a bf16 k-group is
+      // two MFMAs = 64 cycles, so the one-deep lookahead of mfma_rows_bf16 left most of every L2 round trip exposed (3.1 k
+      // cycles per channel tile against 0.5 k of MFMA); the ring keeps loading through the epilogues.
+      constexpr int kRing = 4;
+      bf16x8 ring[kRing];
+      const bf16x8* wnext = wimg + (size_t)wave * KG16 * 64 + lane;      // next fragment to request
+      int knext = 0, left = wave < CT3 ? ((CT3 - wave + kTW - 1) / kTW) * KG16 : 0;   // fragments of this wave not yet requested
+      auto request = [&](bf16x8& dst) {
+        dst = *wnext;
+        if (left > 1) {
+          --left;
+          wnext += 64;
+          if (++knext == KG16) { knext = 0; wnext += (size_t)(kTW - 1) * KG16 * 64; }
+        }
+      };
+      if (wave < CT3) {
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) request(ring[j]);
+      }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int q = 0; q < kBfSlots; ++q) {
         const int ct = wave + q * kTW;
         if (ct < CT3 && !(a.dbg & 8)) {
           f32x16 acc[2];
-          mfma_rows_bf16<2>(buf1h, ldh, wimg + (size_t)ct * KG16 * 64, KG16, lane, acc);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+          {
+            const unsigned short* arow = buf1h + (lane & 31) * ldh + (lane >> 5) * 8;
+            for (int kg0 = 0; kg0 < KG16; kg0 += kRing) {
+#pragma unroll
+              for (int j = 0; j < kRing; ++j) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(arow + (kg0 + j) * 16);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + 32 * ldh + (kg0 + j) * 16);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ring[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ring[j], acc[1], 0, 0, 0);
+                request(ring[j]);
+                asm volatile("" ::: "memory");
+              }
+            }
+          }
           float s1 = 0.f, s2 = 0.f, mx[2] = {-INFINITY, -INFINITY};
           if (nvalid == kTT) {
 #pragma unroll
