@@ -158,8 +158,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     //      32-row groups (one weight fragment feeds two MFMAs; C2 <= 128 -> CT2 <= 4 waves) ----
     if (ct < CT2) {
       if (BF16)
-        mfma_rows_bf16<2>(reinterpret_cast<const unsigned short*>(X + kTT * ld0), ld0h,
-                          reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
+        mfma_rows_bf16_all<2>(reinterpret_cast<const unsigned short*>(X + kTT * ld0), ld0h,
+                              reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
       const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
       if (BF16)
-        mfma_rows_bf16<2, false>(reinterpret_cast<const unsigned short*>(Y), ldbh,
-                                 reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
+        mfma_rows_bf16_all<2, false>(reinterpret_cast<const unsigned short*>(Y), ldbh,
+                                     reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
       else
         mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
       const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;

@@ -245,6 +245,31 @@ __device__ __forceinline__ void mfma_rows_bf16(const unsigned short* __restrict_
   }
 }
 
+// same product with every weight fragment requested up front (KG <= 8): for the short bf16 products of pass B2 (two MFMAs = 64
+// cycles per k-group) a one-deep lookahead leaves an L2 round trip exposed per k-group
+template <int MR, bool CLEAR = true>
+__device__ __forceinline__ void mfma_rows_bf16_all(const unsigned short* __restrict__ A, int lda, const bf16x8* __restrict__ Wh,
+                                                   int KG, int lane, f32x16 (&acc)[MR])
+{
+  if (CLEAR) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  }
+  bf16x8 b[8];
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) b[kg] = Wh[min(kg, KG - 1) * 64 + lane];
+  const unsigned short* arow = A + (lane & 31) * lda + (lane >> 5) * 8;
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg)
+    if (kg < KG) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + m * 32 * lda + kg * 16), b[kg], acc[m], 0, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // phase 1: statistics of z1 (one workgroup per cloud, 256 threads)
 // ---------------------------------------------------------------------------------
