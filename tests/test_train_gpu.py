@@ -339,3 +339,36 @@ def test_negative_gammas(gpu_required, backbone):
     print(backbone, "negative gammas: worst relative gradient error", worst)
     assert not bad, bad
     eng.close()
+
+
+def test_gradients_wide_first_layers(gpu_required):
+    """C1 = C2 = 128 (the widest the training path accepts): the weight-gradient blocks no longer fit the registers of pass B1, so
+    pass B2 accumulates U2 / Gram(h1) per tile, pass B1 stores dy1 and pass B0 runs (the generic kernel instantiations)."""
+    N, B = 128, 8
+    cfg = small_cfg(N=N, nb=12, s1=(128, 128, 96), s2=(128, 128, 128), emb=(128, 128, 160), fc=(64, 32))
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=5)
+    d = R.synth_pairs(B, N, seed=5, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
+    bad, worst = {}, 0.0
+    for name in R.trainable_names(spec):
+        if name in bn_bias:
+            continue
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        err = float(np.abs(g - ref).max())
+        worst = max(worst, err / (float(np.abs(ref).max()) + 1e-6 * gscale))
+        if err > 3e-3 * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    print("wide first layers: worst relative gradient error", worst)
+    assert not bad, bad
+    eng.close()
