@@ -405,8 +405,16 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
     finish(0, C1, 1, ecount);
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
+    d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
     if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    if (d.stamps) {
+      long long sv[8];
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(sv, d.stamps, sizeof(sv), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "FE stage %d it-25 cycles: gather + mfma %lld epilogue %lld colsum %lld es %lld barrier %lld lift %lld barrier %lld\n", s,
+                   sv[1] - sv[0], sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
+    }
     finish(1, C2, 2, ecount);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
     const int sG = std::max(1, 256 / C1);

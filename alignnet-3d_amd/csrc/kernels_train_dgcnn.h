@@ -43,7 +43,9 @@ struct DgTrainArgs {
   unsigned char* argk;            // [2B*N][C2]
   double* colsum_part;            // [2B][2 halves][C2]   column sums of p
   double* s1_part;                // [2B][sG][C1]         column sums of h1 over all (point, slot) rows
+  long long* stamps;              // debug (ALIGNNET_DBG & 32): cycle stamps of thread 0 / block 0, iteration 25
 };
+#define FE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ void dgt_gather(const float* __restrict__ pc, const int* __restrict__ nnc, int N, int k, int n, int slot,
                                            float (&v)[6])
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool more = it + 1 < total;
     const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
+    FE_STAMP(0);
     if (more && tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);   // in flight during the MFMAs
     const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
     if (slot == 0) {
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[kg][s], acc[1], 0, 0, 0);
         }
       }
+      FE_STAMP(1);
       {
         // shifted fp32 sums of this slot's <= 32 accumulator values per lane, folded into the fp64 running sums; rows past
         // nvalid hold zero accumulators (their h1 rows are zero) and are taken out of the count only
@@ -308,16 +312,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
           }
       }
     }
+    FE_STAMP(2);
     if (tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
       const int c = tid % C1, g = tid / C1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
       s1c += (double)sm;
     }
+    FE_STAMP(3);
     if (more && tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
+    FE_STAMP(4);
     __syncthreads();
+    FE_STAMP(5);
     if (more) dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
+    FE_STAMP(6);
     __syncthreads();
+    FE_STAMP(7);
   }
   if (live) {   // sum z = sgn S1 + n b,  sum z^2 = S2 + 2 b sgn S1 + n b^2   (accumulator = sgn (z - b); n = the lane's valid rows)
     int nrows = 0;
