@@ -44,7 +44,8 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   // DGCNN branch (kernels_train_dgcnn.h); h2 holds the pooled edge features p = max_k h2
   unsigned char* argk;           // [2B*N][C2] arg-max neighbour slot
   double* mom;                   // [2B][27] moments of the edge feature
-  float* s1e;                    // [2][C1] column sums of h1 over the B*N*k edge rows
+  float* s1e;                    // [2][C1] column sums of h1 (DGCNN: over the B*N*k edge rows), kept by the forward
+  float* g1f;                    // [2][C1*C1] Gram(h1) of the forward (upper blocks), PointNet: statistics of z2 and the layer-2 weight gradient
 };
 
 struct TrainWS {
@@ -201,7 +202,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.gx = F(B2 * 3); S.grot = F(B2);
       const bool dgb = h->cfg.backbone == 1;
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
-      S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]);
+      S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]); S.g1f = F(2 * (size_t)C[0] * C[0]);
       const Stack& fs = fc_of(h, s);
       const size_t M = s < 2 ? B2 : (size_t)B;
       for (int j = 0; j < fs.n - 1; ++j) {
@@ -380,9 +381,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
-  auto finish = [&](int l, int C, int slices, double cnt) {
+  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1) {
     StatFinishArgs f;
-    f.part = w->stat_part; f.B = B; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
+    f.part = w->stat_part; f.B = nb < 0 ? B : nb; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L[l]->p_bn[t][0]); f.gamma[t] = P(h, L[l]->p_bn[t][1]);
       f.mov_mean[t] = P(h, L[l]->p_bn[t][2]); f.mov_var[t] = P(h, L[l]->p_bn[t][3]);
@@ -430,11 +431,29 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
   finish(0, C1, 1, count);
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
+  const int CT1f = (C1 + 31) / 32, CT2f = (C2 + 31) / 32;
+  // fp32 only: the bf16 phase 2 is light on the matrix pipe (49 us) and a fp32 Gram there costs more than passes B1 / B2 save
+  const bool fwd_gram = !h->train_bf16 && CT1f * CT2f + CT1f * (CT1f + 1) / 2 <= 3 * kTW && !getenv("ALIGNNET_PHASE2_LEGACY");   // cf. acc_in_b1 below
+  if (fwd_gram) {
+    // phase 2 from s1 = sum h1 and G1 = sum h1^T h1 (kept for the backward)
+    Gram1Args g;
+    g.pcs[0] = p1; g.pcs[1] = p2; g.xform = S.xform; g.B = B; g.N = N; g.C1 = C1; g.ld0 = a.ld[0];
+    g.w1 = a.w1; g.sc1 = a.sc1; g.sh1 = a.sh1; g.g1_part = w->g1_part; g.s1_part = w->s1_part;
+    const size_t glds = ((size_t)kTT * 4 + (size_t)kTT * g.ld0) * sizeof(float);
+    if (h->train_bf16) hipLaunchKernelGGL(train_fwd_gram1<true>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
+    else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
+    const int sG1 = std::max(1, 256 / C1);
+    launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
+    hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count,
+                       h->train_bf16 ? 1 : 0, w->stat_part);
+    finish(1, C2, 1, count, 1);
+  } else {
   if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   finish(1, C2, 4, count);
+  }
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
@@ -610,7 +629,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
   const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
-  b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part; b2.s1_part = w->s1_part;
+  b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part;
+  b2.s1_part = (!dg && !h->train_bf16 && !b2_accum && !getenv("ALIGNNET_PHASE2_LEGACY")) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
@@ -637,8 +657,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // ---- operators for B1 (the layer-2 weight gradient follows B1 when B1 accumulates U2 / Gram(h1)) ----
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
+  const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !getenv("ALIGNNET_PHASE2_LEGACY");   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
   auto layer2_weight_grad = [&]() {
-    launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(w->g1_part, B, (long)(C1 * C1), w->g1));
+    if (fwd_gram) launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(S.g1f, 1, (long)(C1 * C1), w->g1));
+    else launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(w->g1_part, B, (long)(C1 * C1), w->g1));
     hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, Me, w->m1);
     // GW2[t] = Ghat1[t] W2
     launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
@@ -646,7 +668,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
                        G(h, w, L[1]->p_w));
   };
   const int sG = std::max(1, 256 / C1);
-  if (dg)   // the forward kept the column sums of h1 (all edge rows)
+  if (dg || fwd_gram)   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
     launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), w->s1),
                         rjob(S.s1e, 1, (long)(C1), w->m1, (float)(1.0 / Me)));
   else      // m1 = s1 / M (qbias needs it before B1)
@@ -704,7 +726,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = S.rstd[0];
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
-  b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = acc_in_b1 ? w->g1_part : nullptr;
+  b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = (acc_in_b1 && !fwd_gram) ? w->g1_part : nullptr;
   // (the legacy train_bwd_b1<64, 128> and the bf16 phase 3 with compile-time widths unroll further and spill: 67 / 39 -- generic ones kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
       tile_commit(my_g1, kC1, it, jt, kC1, kC1, g, lane, old);
     }
-    if (!GIVEN && tid < sG * kC1) {   // column sums of h1: sG row groups x C1 columns
+    if (!GIVEN && a.s1_part && tid < sG * kC1) {   // column sums of h1 (only when the forward did not keep them): sG row groups x C1 columns
       const int c = tid % kC1, g = tid / kC1;
       float sm = 0.f;
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * kC2 + col) * 2;   // slice (half)
     d[0] = db; d[1] = dg;
   }
-  if (!GIVEN && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
+  if (!GIVEN && a.s1_part && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   // read-modify-write of these 48 KiB per cloud falls out of L2 with 512 clouds in flight); <= 3 blocks per wave
   constexpr int kAccSlots = 3;
   const int CT2 = (kC2 + 31) >> 5, half = lane >> 5;
-  const int nblk_u = a.u2_part ? CT1 * CT2 : 0, nblk = a.u2_part ? nblk_u + CT1 * (CT1 + 1) / 2 : 0;
+  const int nblk_u = a.u2_part ? CT1 * CT2 : 0, nblk = nblk_u + ((a.u2_part && a.g1_part) ? CT1 * (CT1 + 1) / 2 : 0);   // Gram(h1) only if the forward did not keep it
   f32x16 gacc[kAccSlots];
 #pragma unroll
   for (int q = 0; q < kAccSlots; ++q)

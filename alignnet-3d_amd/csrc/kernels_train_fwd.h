@@ -111,6 +111,7 @@ __device__ __forceinline__ Layer1W layer1_load(const float* __restrict__ w1, int
   return L;
 }
 
+template <bool ROUND = false>   // ROUND: the value is rounded to bf16 (and kept as fp32): what the bf16 hidden layer consumes
 __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, const Layer1W& L, int C1, float* __restrict__ out, int ldo,
                                               int nvalid, int tid)
 {
@@ -133,7 +134,9 @@ __device__ __forceinline__ void layer1_to_lds(const float* __restrict__ xs, cons
         const int row = rr * kRowsPerPass + r0;
         const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
         const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
-        out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+        float hv = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+        if (ROUND) hv = __uint_as_float((unsigned)to_bf16_bits(hv) << 16);
+        out[row * ldo + c] = hv;
       }
     }
   }
@@ -721,6 +724,108 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         tile_commit(my_gram, kC2, it, it + rem, kC2, kC2, gacc[q], lane, zero);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Phase 2 without the hidden layer: z2 = h1 W2 + b2 is linear in h1, so its batch statistics follow from the column sums
+// s1 = sum h1 and the Gram G1 = sum h1^T h1 of the tower (sum z2_c = s1 . w_c + M b_c, sum z2_c^2 = w_c^T G1 w_c + 2 b_c s1 . w_c +
+// M b_c^2) -- three 32 x 32 Gram blocks per tile instead of the 64 x 128 product and its statistics epilogue, and the same s1 / G1
+// are what the backward needs for the layer-2 weight gradient (pass B2 no longer sums h1, pass B1 no longer accumulates the Gram).
+// The per-cloud Gram stays in fp32 registers, clouds are added in fp64: the variance comes out to ~1e-7 relative
+// (tools note in DESIGN.md).  BF16: h1 is rounded to bf16 first -- the statistics are those of the bf16 product exactly.
+// grid 2B, block 4 waves; LDS xs | X [64][ld0]
+// ---------------------------------------------------------------------------------
+struct Gram1Args {
+  const float* pcs[2]; const float* xform; int B, N, C1; int ld0;
+  const float* w1; const float *sc1, *sh1;
+  float* g1_part;      // [2B][C1*C1] upper blocks
+  double* s1_part;     // [2B][sG][C1]
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;
+  float* X = smem + kTT * 4;
+  const int ld0 = a.ld0, C1 = a.C1, CT1 = (C1 + 31) >> 5, nblk = CT1 * (CT1 + 1) / 2;
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int sG = max(1, (kTW * 64) / C1);
+  const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
+  constexpr int kSlots = 3;
+  f32x16 gacc[kSlots];
+  int bit[kSlots], bjt[kSlots];
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+    int it = 0, rem = wave + q * kTW;
+    while (it < CT1 && rem >= CT1 - it) { rem -= CT1 - it; ++it; }
+    bit[q] = it; bjt[q] = it + rem;
+  }
+  double s1c = 0.0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    __syncthreads();
+    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    __syncthreads();
+    layer1_to_lds<BF16>(xs, l1w, C1, X, ld0, nvalid, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q)
+      if (wave + q * kTW < nblk) {
+        const float* pa = X + half * ld0 + bit[q] * 32 + (lane & 31);
+        const float* pb = X + half * ld0 + bjt[q] * 32 + (lane & 31);
+#pragma unroll 8
+        for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc[q], 0, 0, 0);
+      }
+    if (tid < sG * C1) {   // column sums of h1: sG row groups x C1 columns (rows past nvalid are zero)
+      const int c = tid % C1, g = tid / C1;
+      float sm = 0.f;
+      for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
+      s1c += (double)sm;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q)
+    if (wave + q * kTW < nblk) {
+      const float zero[16] = {};
+      tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, bit[q], bjt[q], C1, C1, gacc[q], lane, zero);
+    }
+  if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
+}
+
+// (sum z2, sum z2^2) per tower and channel from the reduced s1 [2][C1] and G1 [2][C1*C1] (upper 32 x 32 blocks valid), fp64.
+// round_w: the hidden layer runs on bf16 operands -- W2 as rounded.  grid (C2, 2), block 256.  out: [2][C2][2] doubles.
+__global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+                                                              const float* __restrict__ b2, int C1, int C2, double M, int round_w,
+                                                              double* __restrict__ out)
+{
+  __shared__ double red[4][2];
+  const int c = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  auto wv = [&](int i) { const float w = W2[(size_t)i * C2 + c]; return (double)(round_w ? __uint_as_float((unsigned)to_bf16_bits(w) << 16) : w); };
+  const float* G = G1 + (size_t)t * C1 * C1;
+  double q = 0.0, sw = 0.0;
+  for (int e = tid; e < C1 * C1; e += 256) {
+    const int i = e / C1, j = e % C1;
+    const double g = (i >> 5) <= (j >> 5) ? (double)G[(size_t)i * C1 + j] : (double)G[(size_t)j * C1 + i];
+    q += wv(i) * g * wv(j);
+  }
+  for (int i = tid; i < C1; i += 256) sw += (double)s1[t * C1 + i] * wv(i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); sw += __shfl_xor(sw, o); }
+  if ((tid & 63) == 0) { red[tid >> 6][0] = q; red[tid >> 6][1] = sw; }
+  __syncthreads();
+  if (tid == 0) {
+    const double Q = red[0][0] + red[1][0] + red[2][0] + red[3][0], S = red[0][1] + red[1][1] + red[2][1] + red[3][1], bb = (double)b2[c];
+    out[((size_t)t * C2 + c) * 2] = S + M * bb;
+    out[((size_t)t * C2 + c) * 2 + 1] = Q + 2.0 * bb * S + M * bb * bb;
   }
 }
 
