@@ -401,7 +401,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     DgTrainArgs d;
     d.pcs[0] = p1; d.pcs[1] = p2; d.xform = S.xform; d.nn = w->nn; d.B = B; d.N = N; d.k = kDgK; d.C1 = C1; d.C2 = C2; d.ld0 = a.ld[0];
     d.w1 = a.w1; d.b1 = a.b1; d.wp2 = a.wp2; d.b2 = a.b2; d.sc1 = a.sc1; d.sh1 = a.sh1; d.sc2 = a.sc2; d.sh2 = a.sh2;
-    d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part;
+    d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part; d.g1_part = w->g1_part;
     const size_t dlds = ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
     finish(0, C1, 1, ecount);
@@ -416,10 +416,14 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       std::fprintf(stderr, "FE stage %d it-25 cycles: gather + mfma %lld epilogue %lld colsum %lld es %lld barrier %lld lift %lld barrier %lld\n", s,
                    sv[1] - sv[0], sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
     }
-    finish(1, C2, 2, ecount);
+    {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
+      const int sGe = std::max(1, 256 / C1);
+      launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
+      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount, 0,
+                         w->stat_part);
+    }
+    finish(1, C2, 1, ecount, 1);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
-    const int sG = std::max(1, 256 / C1);
-    launch_reduce<double>(h, w->s1_part, B * sG, (long)(C1), S.s1e);
     // point conv on the stored p
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -659,7 +663,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !getenv("ALIGNNET_PHASE2_LEGACY");   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
   auto layer2_weight_grad = [&]() {
-    if (fwd_gram) launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(S.g1f, 1, (long)(C1 * C1), w->g1));
+    if (fwd_gram || dg) launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(S.g1f, 1, (long)(C1 * C1), w->g1));
     else launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(w->g1_part, B, (long)(C1 * C1), w->g1));
     hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, Me, w->m1);
     // GW2[t] = Ghat1[t] W2
@@ -690,7 +694,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.ld0 = ((C1 + 7) & ~7) + 4;
     e.w1 = P(h, L[0]->p_w); e.sc1 = S.scale[0]; e.sh1 = S.shift[0];
     e.v2 = w->V2; e.v2_stride = (long)C1 * C2; e.q2img = w->q2img; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
-    e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = w->g1_part; e.pdy_part = w->pdy_part;
+    e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = nullptr; e.pdy_part = w->pdy_part;   // Gram(h1): the forward's
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2);

@@ -38,7 +38,8 @@ struct DgTrainArgs {
   const float *sc1, *sh1, *sc2, *sh2; // [2][C] batch-stat scale / shift (acc -> y)
   const float* gamma2[2];         // BatchNorm gamma of the second edge layer per tower (its sign picks max or min over the slots)
   double* mom;                    // [2B][27]                       (phase 1)
-  double* stat_part;              // phase 1: [2B][C1][2]; phase 2: [2B][2 halves][C2][2]
+  double* stat_part;              // phase 1: [2B][C1][2]
+  float* g1_part;                 // phase 2: [2B][C1*C1] Gram(h1) over the cloud's (point, slot) rows, upper blocks
   float* p_store;                 // [2B*N][C2]                     (phase 3)
   unsigned char* argk;            // [2B*N][C2]
   double* colsum_part;            // [2B][2 halves][C2]   column sums of p
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool mine = ct < CT2, live = mine && col < a.C2;
-  const float bias = live ? a.b2[col] : 0.f;
   // max_k relu(g zhat + b) = relu(g zhat* + b) with zhat* the extreme of sign(g) z over the slots: the sign of gamma2 is known
   // before the statistics are, so this one pass records the extreme (and its slot) next to the sums -- no second edge-conv pass
   const float sgn = (live && a.gamma2[tower][col] < 0.f) ? -1.f : 1.f;
@@ -220,7 +220,17 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     }
   }
   const int sG = max(1, (kTW * 64) / C1);
-  double ds = 0.0, dss = 0.0, s1c = 0.0;
+  double s1c = 0.0;
+  constexpr int CT1 = (C1 + 31) >> 5, nG = CT1 * (CT1 + 1) / 2;   // <= 3 blocks (C1 <= 64) <= 4 waves
+  int git = 0, gjt = 0;
+  {
+    int rem = min(wave, nG - 1);
+    while (rem >= CT1 - git) { rem -= CT1 - git; ++git; }
+    gjt = git + rem;
+  }
+  f32x16 gacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
   f32x16 best[2];
   int bk[2][16];
 
@@ -264,32 +274,6 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
         }
       }
       FE_STAMP(1);
-      {
-        // shifted fp32 sums of this slot's <= 32 accumulator values per lane, folded into the fp64 running sums; rows past
-        // nvalid hold zero accumulators (their h1 rows are zero) and are taken out of the count only
-        const float z0 = acc[0][0];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float dlt = acc[m][r] - z0;
-            s1 += dlt; s2 = fmaf(dlt, dlt, s2);
-          }
-        int cnt = 32;
-        if (nvalid < kTT) {   // remove the padded rows' contribution (value 0 -> dlt = -z0)
-          cnt = 0;
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnt += acc_row(m, r, lane) < nvalid;
-          const float npad = (float)(32 - cnt);
-          s1 += npad * z0; s2 -= npad * z0 * z0;
-        }
-        const double zd = (double)z0, n = (double)cnt;
-        ds += (double)s1 + n * zd;
-        dss += (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -312,6 +296,15 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
           }
       }
     }
+    // Gram(h1) += h1_s^T h1_s (upper 32 x 32 blocks, one per wave): with the column sums below it gives the statistics of
+    // z2 = h1 W2 + b2 (linear in h1: stat2_from_gram_kernel) and the layer-2 weight gradient of the backward -- the 32 sums
+    // per lane and slot this replaces were a third of the kernel's VALU work, and the kernel is bound by that, not by the matrix pipe
+    if (wave < nG) {
+      const float* pa = X + half * ld0 + git * 32 + (lane & 31);
+      const float* pb = X + half * ld0 + gjt * 32 + (lane & 31);
+#pragma unroll 8
+      for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
+    }
     FE_STAMP(2);
     if (tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
       const int c = tid % C1, g = tid / C1;
@@ -329,12 +322,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     __syncthreads();
     FE_STAMP(7);
   }
-  if (live) {   // sum z = sgn S1 + n b,  sum z^2 = S2 + 2 b sgn S1 + n b^2   (accumulator = sgn (z - b); n = the lane's valid rows)
-    int nrows = 0;
-    for (int r = half * 4; r < a.N; r += 8) nrows += min(4, a.N - r);   // rows (r & 3) + 8 j + 4 half of every 64-row tile
-    const double n = (double)nrows * a.k, bd = (double)bias, t1 = (double)sgn * ds;
-    double* st = a.stat_part + (((size_t)cloud * 2 + half) * a.C2 + col) * 2;
-    st[0] = t1 + n * bd; st[1] = dss + 2.0 * bd * t1 + n * bd * bd;
+  if (wave < nG) {
+    const float zero[16] = {};
+    tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
   if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
 }
@@ -647,7 +637,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
 #pragma unroll
         for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
       }
-    } else if (wave < nitems + nG) {
+    } else if (a.g1_part && wave < nitems + nG) {   // (null: the forward kept Gram(h1))
       // ---- Gram(h1) += h1_s^T h1_s, one upper 32 x 32 block per wave, register-resident for the whole cloud ----
       const float* pa = X + half * ld0 + git * 32 + (lane & 31);
       const float* pb = X + half * ld0 + gjt * 32 + (lane & 31);
@@ -656,7 +646,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     }
     BE_STAMP(7);
   }
-  if (wave >= nitems && wave < nitems + nG) {
+  if (a.g1_part && wave >= nitems && wave < nitems + nG) {
     const float zero[16] = {};
     tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
