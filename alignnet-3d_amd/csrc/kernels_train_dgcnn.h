@@ -43,7 +43,7 @@ struct DgTrainArgs {
   float* p_store;                 // [2B*N][C2]                     (phase 3)
   unsigned char* argk;            // [2B*N][C2]
   double* colsum_part;            // [2B][2 halves][C2]   column sums of p
-  double* s1_part;                // [2B][sG][C1]         column sums of h1 over all (point, slot) rows
+  double* s1_part;                // [2B][1024 / C1][C1]  column sums of h1 over all (point, slot) rows, per row group
   long long* stamps;              // debug (ALIGNNET_DBG & 32): cycle stamps of thread 0 / block 0, iteration 25
 };
 #define FE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -219,8 +219,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       breg[kg][0] *= sgn; breg[kg][1] *= sgn; breg[kg][2] *= sgn; breg[kg][3] *= sgn;
     }
   }
-  const int sG = max(1, (kTW * 64) / C1);
-  double s1c = 0.0;
+  double s1q[4] = {0.0, 0.0, 0.0, 0.0};
   constexpr int CT1 = (C1 + 31) >> 5, nG = CT1 * (CT1 + 1) / 2;   // <= 3 blocks (C1 <= 64) <= 4 waves
   int git = 0, gjt = 0;
   {
@@ -306,11 +305,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
     }
     FE_STAMP(2);
-    if (tid < sG * C1) {   // column sums of h1 (rows past nvalid are zero)
-      const int c = tid % C1, g = tid / C1;
-      float sm = 0.f;
-      for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
-      s1c += (double)sm;
+    {   // column sums of h1 (rows past nvalid are zero): thread = (4 columns, one of kQG row groups), float4 reads
+      constexpr int kQ = C1 / 4, kQG = (kTW * 64) / kQ;   // C1 = 64: 16 column quads x 16 row groups
+      const int cq = tid % kQ, g = tid / kQ;
+      f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < kTT / kQG; ++r) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(X + (g + r * kQG) * ld0 + cq * 4);
+        sm[0] += hv[0]; sm[1] += hv[1]; sm[2] += hv[2]; sm[3] += hv[3];
+      }
+      s1q[0] += (double)sm[0]; s1q[1] += (double)sm[1]; s1q[2] += (double)sm[2]; s1q[3] += (double)sm[3];
     }
     FE_STAMP(3);
     if (more && tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
@@ -326,7 +330,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const float zero[16] = {};
     tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
-  if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
+  {   // s1_part [cloud][kQG row groups][C1]
+    constexpr int kQ = C1 / 4, kQG = (kTW * 64) / kQ;
+    const int cq = tid % kQ, g = tid / kQ;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.s1_part[((size_t)cloud * kQG + g) * C1 + cq * 4 + e] = s1q[e];
+  }
 }
 
 // p = relu(scale * acc* + shift) in place over the cloud's [N][C2] rows, and the column sums of p.  grid 2B, block 256
