@@ -501,15 +501,22 @@ struct FcArgs {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int per = (KG + 3) >> 2, k0 = wave * per, k1 = min(KG, k0 + per);
-  if (k0 < k1) {
-    f32x4 av = *reinterpret_cast<const f32x4*>(arow + k0 * 8), bv = wp[(size_t)k0 * 64];
-    for (int kg = k0; kg < k1; ++kg) {
-      const int kn = kg + 1 < k1 ? kg + 1 : kg;
-      const f32x4 an = *reinterpret_cast<const f32x4*>(arow + kn * 8), bn = wp[(size_t)kn * 64];
+  // eight k-groups of operands are requested before their MFMAs (a one-deep lookahead exposed one memory round trip per
+  // k-group: 32 of them per wave at K = 1024)
+  for (int kg = k0; kg < k1; kg += 8) {
+    f32x4 av[8], bv[8];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-      av = an; bv = bn;
+    for (int u = 0; u < 8; ++u) {
+      const int kk = min(kg + u, k1 - 1);
+      av[u] = *reinterpret_cast<const f32x4*>(arow + kk * 8);
+      bv[u] = wp[(size_t)kk * 64];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kg + u < k1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][s], bv[u][s], acc, 0, 0, 0);
+      }
   }
   if (wave > 0) {
 #pragma unroll
