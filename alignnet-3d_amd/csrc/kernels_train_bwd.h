@@ -819,19 +819,6 @@ __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict
   }
 }
 
-// out[t][i][j] = W[i][j] * col[t][j]   (scale columns)  /  transposed variants via strides
-__global__ void scale_cols_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ col, float* __restrict__ out,
-                                  int transpose_out)
-{
-  const int t = blockIdx.y;
-  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (e >= (long)R * C) return;
-  const int i = e / C, j = e % C;
-  const float v = W[e] * (col ? col[t * C + j] : 1.f);
-  if (transpose_out) out[(size_t)t * R * C + (size_t)j * R + i] = v;
-  else out[(size_t)t * R * C + e] = v;
-}
-
 // two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)
 __global__ void scale_cols2_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ colA, float* __restrict__ outA, int trA,
                                    int towersA, const float* __restrict__ colB, float* __restrict__ outB, int trB, int towersB)

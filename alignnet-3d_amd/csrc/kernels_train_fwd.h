@@ -4,7 +4,7 @@
 // Training BN couples all B*N points of a tower, so the forward is three grid-wide phases; each phase
 // recomputes the cheap earlier layers from xyz (inputs are 12 B/point) instead of round-tripping
 // [B*N, C] activations through HBM:
-//   phase 1: statistics of z1 = x' W1 + b1                      (VALU, K = 3)
+//   phase 1: statistics of z1 = x' W1 + b1                      (from the moments of x', kernels_train_dgcnn.h)
 //   phase 2: h1 = relu(bn1(z1));  statistics of z2 = h1 W2 + b2 (MFMA)
 //   phase 3: h1, h2;  z3 = h2 W3 + b3: statistics, and -- because
 //              max_n relu(g*z_n + b) = relu(g * max_n z_n + b)   for g >= 0   (min_n for g < 0)
@@ -273,59 +273,7 @@ __device__ __forceinline__ void mfma_rows_bf16_all(const unsigned short* __restr
     }
 }
 
-// ---------------------------------------------------------------------------------
-// phase 1: statistics of z1 (one workgroup per cloud, 256 threads)
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void train_fwd_phase1(const TrainFwdArgs a)
-{
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
-  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
-  const float* xf = a.xform + (size_t)cloud * 12;
-  float* xs = smem;   // [chunk][4]
-  constexpr int kChunk = 2048;
-  const int C1 = a.C1;
-  // thread -> (channel, row group): groups of C1r threads share a row stride
-  const int nthreads = blockDim.x;
-  double* red = reinterpret_cast<double*>(smem + kChunk * 4);   // [nthreads][2]
-  for (int c0 = 0; c0 < C1; c0 += nthreads) {
-    // each thread owns channel c (if < C1) and walks ALL rows when C1 >= nthreads; otherwise rows are split
-    const int per = max(1, nthreads / max(C1, 1));        // row groups
-    const int span = min(C1 - c0, nthreads);
-    const int c = c0 + (threadIdx.x % span), rg = threadIdx.x / span;
-    const bool active = rg < per && (threadIdx.x < span * per);
-    double s = 0.0, ss = 0.0;
-    const float w0 = a.w1[c], wa = a.w1[C1 + c], wb = a.w1[2 * C1 + c], bias = a.b1[c];
-    for (int base = 0; base < a.N; base += kChunk) {
-      const int cnt = min(kChunk, a.N - base);
-      __syncthreads();
-      for (int i = threadIdx.x; i < cnt; i += nthreads) {
-        const float* p = pc + (size_t)(base + i) * 3;
-        const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
-        xs[i * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-        xs[i * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-        xs[i * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
-      }
-      __syncthreads();
-      if (active)
-        for (int i = rg; i < cnt; i += per) {
-          const float zz = fmaf(xs[i * 4 + 2], wb, fmaf(xs[i * 4 + 1], wa, xs[i * 4] * w0)) + bias;
-          s += (double)zz;
-          ss += (double)zz * (double)zz;
-        }
-    }
-    red[threadIdx.x * 2] = active ? s : 0.0;
-    red[threadIdx.x * 2 + 1] = active ? ss : 0.0;
-    __syncthreads();
-    if (threadIdx.x < span) {
-      double ts = 0.0, tss = 0.0;
-      for (int g = 0; g < per; ++g) { ts += red[(g * span + threadIdx.x) * 2]; tss += red[(g * span + threadIdx.x) * 2 + 1]; }
-      a.stat_part[((size_t)cloud * C1 + c0 + threadIdx.x) * 2] = ts;
-      a.stat_part[((size_t)cloud * C1 + c0 + threadIdx.x) * 2 + 1] = tss;
-    }
-    __syncthreads();
-  }
-}
+// (phase 1, the statistics of z1, comes from the cloud's nine moments of x': pn_moments_kernel in kernels_train_dgcnn.h)
 
 // ---------------------------------------------------------------------------------
 // phases 2 and 3 (one workgroup of 8 waves per cloud).
