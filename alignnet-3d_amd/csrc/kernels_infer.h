@@ -326,9 +326,12 @@ __device__ __forceinline__ void hidden_layer(const float* in, int ldi, float* ou
   for (int item = wave; item < CT * RG; item += kWaves) hidden_item<MR>(in, ldi, out, ldo, L, tower, item / RG, item % RG, lane);
 }
 
-template <int TP>
+// LD0 / LD1: compile-time LDS row strides of the two activation buffers (0 = from the arguments): immediates instead of address
+// registers in the unrolled hidden-layer epilogues
+template <int TP, int LD0 = 0, int LD1 = 0>
 __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
 {
+  const int lds_ld[2] = {LD0 ? LD0 : a.ld[0], LD1 ? LD1 : a.ld[1]};
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
   const int tower = cloud >= a.B, b = cloud - tower * a.B;
   float* xs = smem;                       // [TP][4]
   // integer offsets (not a runtime-selected pointer) keep the LDS address space visible -> ds_read_b128, not flat loads
-  const int boff[2] = {TP * 4, TP * 4 + TP * a.ld[0]};
+  const int boff[2] = {TP * 4, TP * 4 + TP * lds_ld[0]};
   // A workgroup walks tiles_per_wg consecutive tiles of its cloud and keeps the pooled maximum of its (<= kPoolRegs per
   // wave) channel tiles in registers: one atomicMax per (workgroup, channel) instead of one per (tile, channel) -- that
   // per-tile stream was 60 % of the kernel's HBM traffic.
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
   {
     const ConvLayerDev& L = a.L[0];
     float* out = smem + boff[0];
-    const int ldo = a.ld[0], c0 = tid & 31, r0 = tid >> 5;   // a 32-lane group writes one row, 32 consecutive channels
+    const int ldo = lds_ld[0], c0 = tid & 31, r0 = tid >> 5;   // a 32-lane group writes one row, 32 consecutive channels
     for (int c = c0; c < ldo - 4; c += 32) {
       const bool live = c < L.cout;
       const int g = (c - c0) >> 5;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
     const int CT = (L.cout + 31) >> 5;
     const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
     float* out = smem + ((l & 1) ? boff[1] : boff[0]);
-    const int ldi = a.ld[(l - 1) & 1], ldo = a.ld[l & 1];
+    const int ldi = lds_ld[(l - 1) & 1], ldo = lds_ld[l & 1];
     constexpr int MT = TP / 32;
     if (CT >= kWaves) hidden_layer<MT, TP>(in, ldi, out, ldo, L, tower, wave, lane);
     else if (CT * 2 >= kWaves || MT < 4) hidden_layer<(MT >= 2 ? 2 : 1), TP>(in, ldi, out, ldo, L, tower, wave, lane);
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
     const int l = a.nlayers - 1;
     const ConvLayerDev& L = a.L[l];
     const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
-    const int ldi = a.ld[(l - 1) & 1];
+    const int ldi = lds_ld[(l - 1) & 1];
     const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
