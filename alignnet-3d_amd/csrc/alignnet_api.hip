@@ -451,6 +451,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   if (!attr_set) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -483,6 +484,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
     hipLaunchKernelGGL(pointnet_split, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
   } else if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
+  else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
   else if (a.ld[0] == 68 && a.ld[1] == 132 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);   // the shipped widths 64, 128
   else hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a);
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }

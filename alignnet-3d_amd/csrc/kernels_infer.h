@@ -328,7 +328,7 @@ __device__ __forceinline__ void hidden_layer(const float* in, int ldi, float* ou
 
 // LD0 / LD1: compile-time LDS row strides of the two activation buffers (0 = from the arguments): immediates instead of address
 // registers in the unrolled hidden-layer epilogues
-template <int TP, int LD0 = 0, int LD1 = 0>
+template <int TP, int LD0 = 0, int LD1 = 0, int KGL = 0>   // KGL: k-groups of the last layer (0 = from the arguments)
 __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneArgs a)
 {
   const int lds_ld[2] = {LD0 ? LD0 : a.ld[0], LD1 ? LD1 : a.ld[1]};
@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
     const ConvLayerDev& L = a.L[l];
     const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
     const int ldi = lds_ld[(l - 1) & 1];
-    const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
+    // (with the strides compiled in the last layer's depth is too: three conv layers, input = buffer 1 of width LD1 - 4)
+    const int KG = (LD1 && KGL) ? KGL : (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
       f32x16 acc[TP / 32];
