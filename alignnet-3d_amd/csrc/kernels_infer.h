@@ -295,11 +295,11 @@ __device__ __forceinline__ void mfma_rows_deep(const float* __restrict__ A, int 
   }
 }
 
-template <int MR>
+template <int MR, int KGC = 0>   // KGC: compile-time k-depth (0 = from the layer)
 __device__ __forceinline__ void hidden_item(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
                                             const ConvLayerDev& L, int tower, int ct, int rg, int lane)
 {
-  const int KG = (L.cin + 7) >> 3;
+  const int KG = KGC ? KGC : (L.cin + 7) >> 3;
   f32x16 acc[MR];
   mfma_rows<MR>(in + rg * MR * 32 * ldi, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
   const int col = ct * 32 + (lane & 31);
@@ -408,6 +408,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
   __syncthreads();
 
   // ---- hidden MFMA layers 1 .. nlayers-2 ----
+  if constexpr (KGL != 0 && LD0 != 0 && LD1 != 0) {
+    // shipped shape (three conv layers, widths LD0 - 4 -> LD1 - 4): one (channel tile, 64-row group) item per wave, everything constant
+    constexpr int CTH = (LD1 - 4) / 32, RGH = (TP / 32) / 2;
+    for (int item = wave; item < CTH * RGH; item += kWaves)
+      hidden_item<2, (LD0 - 4) / 8>(smem + boff[0], LD0, smem + boff[1], LD1, a.L[1], tower, item / RGH, item % RGH, lane);
+    __syncthreads();
+  } else
   for (int l = 1; l < a.nlayers - 1; ++l) {
     const ConvLayerDev& L = a.L[l];
     const int CT = (L.cout + 31) >> 5;
