@@ -528,7 +528,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
   (void)pooled_floats;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
@@ -557,7 +557,12 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
     } else {
       const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
-      hipLaunchKernelGGL(dgcnn_fused, grid, dim3(kWaves * 64), lds, h->stream, a);
+      if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
+        static bool sattr = false;
+        if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+        hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
+      } else
+      hipLaunchKernelGGL(dgcnn_fused<>, grid, dim3(kWaves * 64), lds, h->stream, a);
       if (a.stamps) {
         long long sv[9];
         hipStreamSynchronize(h->stream);

@@ -282,8 +282,12 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
   }
 }
 
+// LD0 / LD1 != 0: the shipped shape compiled in -- widths [LD0 - 4, LD1 - 4, C3], three layers -- so that LDS strides, k-depths
+// and tile counts are constants (as for pointnet_fused: fewer address registers, no generic layer dispatch)
+template <int LD0 = 0, int LD1 = 0>
 [[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
 {
+  const int ld0 = LD0 ? LD0 : a.ld[0], ld1 = LD1 ? LD1 : a.ld[1];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,15 +296,16 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* es = smem;                                   // edge features of the slot being lifted
-  const int boff[2] = {kDgTile * 8, kDgTile * 8 + kDgTile * a.ld[0]};
-  const int boff0b = kDgTile * 8 + kDgTile * (a.ld[0] + a.ld[1]);   // second lift buffer
-  const int nl = a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
+  const int boff[2] = {kDgTile * 8, kDgTile * 8 + kDgTile * ld0};
+  const int boff0b = kDgTile * 8 + kDgTile * (ld0 + ld1);   // second lift buffer
+  const int nl = LD0 ? 3 : a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
   const int nvalid = min(kDgTile, a.N - tile * kDgTile);
   const bool two_edge_layers = nl == 3;               // pipelined path: lift (VALU) + one MFMA edge layer
 
   // running max over the k neighbours of the LAST edge layer's pre-activation (sc*acc+sh); relu folded after the max
   const ConvLayerDev& LE = a.L[nl - 2];
-  const int CTE = (LE.cout + 31) >> 5;
+  const int le_cin = LD0 ? LD0 - 4 : LE.cin, le_cout = LD1 ? LD1 - 4 : LE.cout;
+  const int CTE = (le_cout + 31) >> 5;
   // item = (32-row tile m of the 64 points, channel tile ct): wave handles items wave, wave+8, ... (<= 2 slots: C <= 256)
   constexpr int kSlots = 2;
   f32x16 best[kSlots];
@@ -311,10 +316,10 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 
   // Register-resident weights for the common case (last edge layer with cin <= 64, e.g. 64 -> 128): the item's
   // 8 k-groups x float4 are loaded once per workgroup instead of once per neighbour slot.
-  const bool wreg = two_edge_layers && LE.cin <= 64;
+  const bool wreg = two_edge_layers && le_cin <= 64;
   f32x4 breg[kSlots][8];
   if (wreg) {
-    const int KG = (LE.cin + 7) >> 3;
+    const int KG = (le_cin + 7) >> 3;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
       const int item = wave + s * kWaves;
@@ -330,12 +335,12 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) {
     const int col = (min(wave + s * kWaves, CTE * 2 - 1) >> 1) * 32 + (lane & 31);
-    const bool live = col < LE.cout;
-    esc[s] = live ? LE.scale[tower * LE.cout + col] : 0.f;
-    esh[s] = live ? LE.shift[tower * LE.cout + col] : 0.f;
+    const bool live = col < le_cout;
+    esc[s] = live ? LE.scale[tower * le_cout + col] : 0.f;
+    esh[s] = live ? LE.shift[tower * le_cout + col] : 0.f;
   }
   auto edge_mfma_reg = [&](const float* in, int ldi) {
-    const int KG = (LE.cin + 7) >> 3;
+    const int KG = (le_cin + 7) >> 3;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
       const int item = wave + s * kWaves;
@@ -360,7 +365,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     }
   };
   auto edge_mfma = [&](const float* in, int ldi) {
-    const int KG = (LE.cin + 7) >> 3;
+    const int KG = (le_cin + 7) >> 3;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
       const int item = wave + s * kWaves;
@@ -382,20 +387,20 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     if (tid < kDgTile) { dg_gather(a, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
     __syncthreads();
     const DgLiftRegs lregs = dg_lift_load(a.L[0], tower, tid);
-    dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid, &lregs);
+    dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, &lregs);
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
       if (slot == 5) DG_STAMP(0);
       if (more && tid < kDgTile) dg_gather(a, pc, cloud, tile, slot + 1, tid, v);        // in flight during the MFMAs
-      if (wreg) edge_mfma_reg(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
-      else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), a.ld[0]);
+      if (wreg) edge_mfma_reg(smem + ((slot & 1) ? boff0b : boff[0]), ld0);
+      else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), ld0);
       if (slot == 5) DG_STAMP(1);
       if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
       if (slot == 5) DG_STAMP(2);
       __syncthreads();
       if (slot == 5) DG_STAMP(3);
-      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), a.ld[0], tid, &lregs);
+      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, &lregs);
       if (slot == 5) DG_STAMP(4);
       __syncthreads();
       if (slot == 5) DG_STAMP(5);
@@ -406,18 +411,18 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
       __syncthreads();
       if (tid < kDgTile) { float v[6]; dg_gather(a, pc, cloud, tile, slot, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
       __syncthreads();
-      dg_lift(a.L[0], tower, es, smem + boff[0], a.ld[0], tid);
+      dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid);
       __syncthreads();
       // ---- middle edge layers 1 .. nl-3 ----
       for (int l = 1; l < nl - 2; ++l) {
         const ConvLayerDev& L = a.L[l];
         const float* in = smem + (((l - 1) & 1) ? boff[1] : boff[0]);
         float* out = smem + ((l & 1) ? boff[1] : boff[0]);
-        hidden_layer<2, kDgTile>(in, a.ld[(l - 1) & 1], out, a.ld[l & 1], L, tower, wave, lane);
+        hidden_layer<2, kDgTile>(in, (((l - 1) & 1) ? ld1 : ld0), out, ((l & 1) ? ld1 : ld0), L, tower, wave, lane);
         __syncthreads();
       }
       const int l = nl - 2;
-      edge_mfma(smem + (((l - 1) & 1) ? boff[1] : boff[0]), a.ld[(l - 1) & 1]);
+      edge_mfma(smem + (((l - 1) & 1) ? boff[1] : boff[0]), (((l - 1) & 1) ? ld1 : ld0));
     }
   }
   __syncthreads();
@@ -425,18 +430,18 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
   const int lh = (nl - 2) & 1;   // buffer that receives the pooled edge features
   {
     float* out = smem + (lh ? boff[1] : boff[0]);
-    const int ldo = a.ld[lh];
+    const int ldo = (lh ? ld1 : ld0);
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
       const int item = wave + s * kWaves;
       if (item < CTE * 2) {
         const int ct = item >> 1, m = item & 1;
         const int col = ct * 32 + (lane & 31);
-        if (col < ((LE.cout + 7) & ~7)) {
+        if (col < ((le_cout + 7) & ~7)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            out[row * ldo + col] = (col < LE.cout && row < nvalid) ? fmaxf(best[s][r], 0.f) : 0.f;
+            out[row * ldo + col] = (col < le_cout && row < nvalid) ? fmaxf(best[s][r], 0.f) : 0.f;
           }
         }
       }
@@ -448,8 +453,8 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
   {
     const ConvLayerDev& L = a.L[nl - 1];
     const float* in = smem + (lh ? boff[1] : boff[0]);
-    const int ldi = a.ld[lh];
-    const int KG = (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
+    const int ldi = (lh ? ld1 : ld0);
+    const int KG = LD1 ? (LD1 - 4) / 8 : (L.cin + 7) >> 3, CT = (L.cout + 31) >> 5;
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
       f32x16 acc[2];
