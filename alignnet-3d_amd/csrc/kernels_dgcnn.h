@@ -285,7 +285,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 // LD0 / LD1 != 0: the shipped shape compiled in -- widths [LD0 - 4, LD1 - 4, C3], three layers -- so that LDS strides, k-depths
 // and tile counts are constants (as for pointnet_fused: fewer address registers, no generic layer dispatch)
 template <int LD0 = 0, int LD1 = 0>
-[[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_fused(const DgcnnArgs a)
+[[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, LD0 ? 4 : 2) void dgcnn_fused(const DgcnnArgs a)
 {
   const int ld0 = LD0 ? LD0 : a.ld[0], ld1 = LD1 ? LD1 : a.ld[1];
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -458,7 +458,10 @@ template <int LD0 = 0, int LD1 = 0>
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
       f32x16 acc[2];
-      mfma_rows<2>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      // (the 128-VGPR instantiation spills a few registers: compiler-managed weight loads there, the hand-issued stream
+      //  is only safe in spill-free kernels)
+      if (LD0) mfma_rows<2, true, false>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      else mfma_rows<2>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < L.cout;
       const float sc = live ? L.scale[tower * L.cout + col] : 0.f, sh = live ? L.shift[tower * L.cout + col] : 0.f;
