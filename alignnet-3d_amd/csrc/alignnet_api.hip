@@ -481,8 +481,13 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
     static bool sattr = false;
-    if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
-    hipLaunchKernelGGL(pointnet_split, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+    if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+    if (sc1 == 64 && sc2 == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+      static bool sattr = false;
+      if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+      hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+    } else
+    hipLaunchKernelGGL(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
   } else if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
   else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
   else if (a.ld[0] == 68 && a.ld[1] == 132 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);   // the shipped widths 64, 128

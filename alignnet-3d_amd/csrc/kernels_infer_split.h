@@ -75,14 +75,17 @@ __device__ __forceinline__ void split_mfma(const bf16x8 (&ah)[MR], const bf16x8 
 #endif
 }
 
+// C1T / C2T != 0: the shipped widths compiled in (strides, k-depths and tile counts become constants)
+template <int C1T = 0, int C2T = 0>
 static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const SplitArgs a)
 {
+  const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cloud = blockIdx.y, tile = blockIdx.x;
   const int tower = cloud >= a.B, b = cloud - tower * a.B;
-  const int K1 = (a.C1 + 15) & ~15, K2 = (a.C2 + 15) & ~15, ld1 = K1 + 8, ld2 = K2 + 8;
+  const int K1 = (kC1 + 15) & ~15, K2 = (kC2 + 15) & ~15, ld1 = K1 + 8, ld2 = K2 + 8;
   const int KB1 = K1 >> 4, KB2 = K2 >> 4;
   float* xs = smem;                                                         // [128][4]
   unsigned short* s16 = reinterpret_cast<unsigned short*>(smem + kSplitTP * 4);
@@ -90,7 +93,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
 
   // ---- weight fragments first: the hidden layer's (this wave's item) and the first channel tile's of the last layer are
   //      requested before anything else, so their L2 round trips overlap the xyz load and the VALU lift ----
-  const int CT2 = (a.C2 + 31) >> 5, CT3 = (a.C3 + 31) >> 5;
+  const int CT2 = (kC2 + 31) >> 5, CT3 = (a.C3 + 31) >> 5;
   const bf16x8* img2 = reinterpret_cast<const bf16x8*>(a.w2s);
   const bf16x8* img3 = reinterpret_cast<const bf16x8*>(a.w3s);
   bf16x8 w2h[kSplitKB1], w2l[kSplitKB1];
@@ -122,9 +125,9 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   {
     const int c0 = tid & 31, r0 = tid >> 5;
     for (int c = c0; c < K1; c += 32) {
-      const bool live = c < a.C1;
-      const float w0 = live ? a.w1[c] : 0.f, w1 = live ? a.w1[a.C1 + c] : 0.f, w2 = live ? a.w1[2 * a.C1 + c] : 0.f;
-      const float sc = live ? a.sc1[tower * a.C1 + c] : 0.f, sh = live ? a.sh1[tower * a.C1 + c] : 0.f;
+      const bool live = c < kC1;
+      const float w0 = live ? a.w1[c] : 0.f, w1 = live ? a.w1[kC1 + c] : 0.f, w2 = live ? a.w1[2 * kC1 + c] : 0.f;
+      const float sc = live ? a.sc1[tower * kC1 + c] : 0.f, sh = live ? a.sh1[tower * kC1 + c] : 0.f;
 #pragma unroll
       for (int rr = 0; rr < kSplitTP / 16; ++rr) {
         const int row = rr * 16 + r0;
@@ -166,8 +169,8 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
           split_mfma<2>(ah, al, w2h[kb], w2l[kb], acc);
         }
       const int col = ct * 32 + (lane & 31);
-      const bool live = col < a.C2;
-      const float sc = live ? a.sc2[tower * a.C2 + col] : 0.f, sh = live ? a.sh2[tower * a.C2 + col] : 0.f;
+      const bool live = col < kC2;
+      const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
       if (col < K2) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
