@@ -557,8 +557,13 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       if (a.k > 3 * kWaves) return fail(h, "dgcnn split kernel: k limited to 24 neighbours");
       const size_t dlds = (size_t)2 * kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);
       static bool dsattr = false;
-      if (!dsattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr = true; }
-      hipLaunchKernelGGL(dgcnn_split, grid, dim3(kWaves * 64), dlds, h->stream, sa);
+      if (!dsattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr = true; }
+      if (dca == 64 && dcb == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+        static bool dsattr2 = false;
+        if (!dsattr2) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2 = true; }
+        hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
+      } else
+      hipLaunchKernelGGL(dgcnn_split<>, grid, dim3(kWaves * 64), dlds, h->stream, sa);
     } else {
       const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone

@@ -71,8 +71,13 @@ __device__ __forceinline__ void dg_lift_split(const DgcnnSplitArgs& a, int tower
   }
 }
 
-static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const DgcnnSplitArgs a)
+// CaT / CbT != 0: the shipped edge widths compiled in (strides, k-depths and tile counts become constants)
+template <int CaT = 0, int CbT = 0>
+static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const DgcnnSplitArgs a0)
 {
+  DgcnnSplitArgs a = a0;
+  if (CaT) a.Ca = CaT;
+  if (CbT) a.Cb = CbT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
