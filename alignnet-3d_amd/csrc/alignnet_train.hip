@@ -427,7 +427,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     // point conv on the stored p
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-    hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
+    hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     finish(2, C3, 2, count);
     launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
   } else {
@@ -474,7 +474,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     if (!a.gram_inline)
-      hipLaunchKernelGGL(gram_h2_kernel, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
+      hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
                          w->gram_part);
   }
   finish(2, C3, 2, count);

@@ -783,8 +783,10 @@ __global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __res
 // inside phase 3 was a read-modify-write of 64 KiB per cloud that does not stay in L2 with 512 clouds in flight.
 // One workgroup (4 waves) per cloud, <= 3 blocks per wave (C2 <= 128), tiles double-buffered through LDS.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTW * 64) void gram_h2_kernel(const float* __restrict__ h2, int N, int C2, float* __restrict__ gram_part)
+template <int C2T = 0>   // C2T: compile-time width (0 = from the argument)
+__global__ __launch_bounds__(kTW * 64) void gram_h2_kernel(const float* __restrict__ h2, int N, int C2rt, float* __restrict__ gram_part)
 {
+  const int C2 = C2T ? C2T : C2rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
