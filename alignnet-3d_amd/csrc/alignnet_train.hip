@@ -446,6 +446,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     g.w1 = a.w1; g.sc1 = a.sc1; g.sh1 = a.sh1; g.g1_part = w->g1_part; g.s1_part = w->s1_part;
     const size_t glds = ((size_t)kTT * 4 + (size_t)kTT * g.ld0) * sizeof(float);
     if (h->train_bf16) hipLaunchKernelGGL(train_fwd_gram1<true>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
+    else if (C1 == 64) hipLaunchKernelGGL((train_fwd_gram1<false, 64>), dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
     launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));

@@ -691,7 +691,7 @@ struct Gram1Args {
   double* s1_part;     // [2B][sG][C1]
 };
 
-template <bool BF16>
+template <bool BF16, int C1T = 0>   // C1T: compile-time width (0 = from the arguments)
 __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
   float* X = smem + kTT * 4;
-  const int ld0 = a.ld0, C1 = a.C1, CT1 = (C1 + 31) >> 5, nblk = CT1 * (CT1 + 1) / 2;
+  const int ld0 = C1T ? C1T + 4 : a.ld0, C1 = C1T ? C1T : a.C1, CT1 = (C1 + 31) >> 5, nblk = CT1 * (CT1 + 1) / 2;
   const int ntiles = (a.N + kTT - 1) / kTT;
   const int sG = max(1, (kTW * 64) / C1);
   const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
