@@ -634,7 +634,7 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   HIP_TRY(h, hipMemsetAsync(w.pool1, 0, (size_t)((char*)w.hid_a - (char*)w.pool1), h->stream));
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
   if (dg)   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
-    hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
+    hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
   // stage 1 (tp8.py:108-109)
   if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
   if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B)) return 1;

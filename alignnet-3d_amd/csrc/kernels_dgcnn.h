@@ -32,6 +32,9 @@ __device__ long long g_knn_stamp[8];
 #define KNN_STAMP(i) do {} while (0)
 #endif
 // grid: (ceil(N / 4), 2B), block 256 = 4 waves, one query point per wave
+// PER: candidate slots per lane compiled in (N <= 64 PER): 64 for the full 4096-point range, 16 for N <= 1024 (a quarter of the
+// key registers, twice the waves per SIMD)
+template <int PER = kKnnMaxPerLane>
 [[maybe_unused]] static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                  const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
 {
@@ -44,13 +47,13 @@ __device__ long long g_knn_stamp[8];
   const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
   const float qq = qx * qx + qy * qy + qz * qz;   // reduce_sum(square(x)) (tf_util_dgcnn.py:655)
   KNN_STAMP(0);
-  uint32_t key[kKnnMaxPerLane];
+  uint32_t key[PER];
   const int per = (N + 63) >> 6;
   // Candidates are loaded eight slots at a time with clamped (always valid) indices and no branch around the loads: guarded
   // by `if (j < N)` every slot's three loads were issued and waited for inside their own exec-masked block -- 64 exposed
   // memory round trips per query (50 k of the 75 k cycles of a query at N = 4096).
 #pragma unroll
-  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8) {
+  for (int t0 = 0; t0 < PER; t0 += 8) {
     if (t0 < per) {
       float px[8], py[8], pz[8];
 #pragma unroll
@@ -79,7 +82,7 @@ __device__ long long g_knn_stamp[8];
   // (the slot loops below test `per` once per block of eight slots: slots past N hold the sentinel key, which no bound admits;
   //  a uniform `t < per` per slot made hipcc keep 64 such predicates in SGPRs across the loops -- 587 scalar spills)
 #pragma unroll
-  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+  for (int t0 = 0; t0 < PER; t0 += 8)
     if (t0 < per) {
 #pragma unroll
       for (int t = t0; t < t0 + 8; ++t) lmin = min(lmin, key[t]);
@@ -103,7 +106,7 @@ __device__ long long g_knn_stamp[8];
   __shared__ int s_idx[4][kKnnList];
   int M = 0;
 #pragma unroll
-  for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+  for (int t0 = 0; t0 < PER; t0 += 8)
     if (t0 < per) {
 #pragma unroll
       for (int t = t0; t < t0 + 8; ++t) {
@@ -170,7 +173,7 @@ __device__ long long g_knn_stamp[8];
     const uint32_t mid = lo + ((hi - lo) >> 1);
     int c = 0;
 #pragma unroll
-    for (int t0 = 0; t0 < kKnnMaxPerLane; t0 += 8)
+    for (int t0 = 0; t0 < PER; t0 += 8)
       if (t0 < per) {
 #pragma unroll
         for (int t = t0; t < t0 + 8; ++t) c += key[t] <= mid;
@@ -183,7 +186,7 @@ __device__ long long g_knn_stamp[8];
   int written = 0;
   for (int pass = 0; pass < 2 && written < k; ++pass) {
 #pragma unroll
-    for (int t = 0; t < kKnnMaxPerLane; ++t)
+    for (int t = 0; t < PER; ++t)
       if ((t & ~7) < per) {
         const bool sel = pass == 0 ? key[t] < T : key[t] == T;   // T <= T0 <= 0xfffffffe
         const unsigned long long m = __ballot(sel);

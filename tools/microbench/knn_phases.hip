@@ -61,7 +61,7 @@ int main(int argc, char** argv)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4, 2 * B), dim3(256), 0, 0, d1, d2, dc, B, N, k, nn);
+    hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, 2 * B), dim3(256), 0, 0, d1, d2, dc, B, N, k, nn);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long st[8];
