@@ -397,6 +397,12 @@ __global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int
 // ---------------------------------------------------------------------------------
 constexpr int kBEW = 8;
 
+template <int I, int N, class F>
+__device__ __forceinline__ void dg_static_for(F&& f)   // f(integral_constant<int, I>) for I in [I, N): loop indices usable as asm immediates
+{
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); dg_static_for<I + 1, N>(f); }
+}
+
 struct DgBwdArgs {
   const float* pcs[2]; const float* xform; const int* nn; int B, N, k, C1, C2;
   int ld0;
@@ -411,6 +417,8 @@ struct DgBwdArgs {
   long long* stamps;                   // debug: cycle stamps of thread 0 / block 0 at the phase boundaries of iteration 25
 };
 #define BE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// stamps 10..15: the tile-start block of iteration 40; stamp 16: iteration 45 (20 iterations = one tile after stamp 0)
+#define BE_TSTAMP(i, at) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == at) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 static inline size_t dg_bwd_edge_lds(int C1, int C2)
 {
@@ -497,7 +505,9 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     const bool more = it + 1 < total;
     float* es = smem + (it & 1) * kTT * 8;
     if (slot == 0) {
+      BE_TSTAMP(10, 40);
       __syncthreads();   // the previous tile's readers of D / DP / the lists are done
+      BE_TSTAMP(11, 40);
       const size_t base = ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
       const int c4 = C2 >> 2;
       for (int i = tid; i < kTT * c4; i += kBEW * 64) {
@@ -508,35 +518,81 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         *reinterpret_cast<unsigned*>(AK + row * C2 + q * 4) =
             ok ? *reinterpret_cast<const unsigned*>(a.argk + base + (size_t)row * C2 + q * 4) : 0xffffffffu;
       }
+      BE_TSTAMP(12, 40);
       __syncthreads();
-      const unsigned long long lt = (1ull << lane) - 1ull;
+      BE_TSTAMP(13, 40);
+      // stable counting sort by slot without a per-lane select per slot: one compare per slot gives the wave mask of the slot's
+      // entries; the mask and the running offset are parked in lane `slot` of a register (v_writelane), and after the loop every
+      // lane fetches the mask / offset of ITS slot with ds_bpermute and ranks itself in it (mbcnt).  One byte store per entry.
+      // (As a run-time loop with a guarded store per slot this took 162 k cycles per tile -- 45 % of the kernel; with per-slot
+      // selects, which hipcc turns into three exec-masked regions per slot, 76 k.)
+      // (No writelane builtin in this hipcc, hence asm: one scalar data operand per instruction, the lane select an immediate --
+      // hence the compile-time slot loop.  gfx950 needs two wait states between a VALU write of an SGPR (the compare) and a VALU
+      // read of it; hipcc inserts them for its own instructions but does not look inside an asm block: without the s_nop the
+      // writelane reads the previous compare's mask.)
+#define DG_PARK3(o, l, h, so, sl, sh, ln) \
+  asm("s_nop 1\n\tv_writelane_b32 %0, %3, %6\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6" \
+      : "+v"(o), "+v"(l), "+v"(h) : "s"(so), "s"(sl), "s"(sh), "n"(ln))
+#define DG_PARK2(l, h, sl, sh, ln) \
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(l), "+v"(h) : "s"(sl), "s"(sh), "n"(ln))
+#define DG_PARK1(o, so, ln) asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(o) : "s"(so), "n"(ln))
+      auto rank_in = [](int lo, int hi) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)hi, __builtin_amdgcn_mbcnt_lo((unsigned)lo, 0u)); };
+      auto from_lane = [](int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); };
       for (int row = wave; row < kTT; row += kBEW) {   // row lists: lane <-> columns lane, lane + 64
         const int c0 = lane, c1 = lane + 64;
-        int a0 = (c0 < C2 && DP[row * ldp + c0] != 0.f) ? AK[row * C2 + c0] : 255;
-        int a1 = (c1 < C2 && DP[row * ldp + c1] != 0.f) ? AK[row * C2 + c1] : 255;
-        int pos = 0;
-        for (int s = 0; s < a.k; ++s) {
-          if (lane == 0) SO[row * 24 + s] = (unsigned char)pos;
+        const float d0 = DP[row * ldp + c0];
+        const int k0 = AK[row * C2 + c0];
+        const int a0 = d0 != 0.f ? k0 : 255;
+        int a1 = 255;
+        if constexpr (C2 > 64) {
+          const float d1 = DP[row * ldp + c1];
+          const int k1 = AK[row * C2 + c1];
+          a1 = d1 != 0.f ? k1 : 255;
+        }
+        int pos = 0, offv = 0, l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+        dg_static_for<0, kDgK>([&](auto S) {
+          constexpr int s = decltype(S)::value;
           const unsigned long long m0 = __ballot(a0 == s), m1 = __ballot(a1 == s);
-          if (a0 == s) SL[row * C2 + pos + __popcll(m0 & lt)] = (unsigned char)c0;
-          if (a1 == s) SL[row * C2 + pos + __popcll(m0) + __popcll(m1 & lt)] = (unsigned char)c1;
+          DG_PARK3(offv, l0, h0, pos, (int)(unsigned)m0, (int)(unsigned)(m0 >> 32), s);
+          if constexpr (C2 > 64) DG_PARK2(l1, h1, (int)(unsigned)m1, (int)(unsigned)(m1 >> 32), s);
           pos += __popcll(m0) + __popcll(m1);
+        });
+        DG_PARK1(offv, pos, kDgK);
+        if (lane <= kDgK) SO[row * 24 + lane] = (unsigned char)offv;
+        const int s0 = a0 & 31, s1 = a1 & 31;   // (255 -> lane 31: fetched, not used)
+        const int p0 = from_lane(s0, offv) + rank_in(from_lane(s0, l0), from_lane(s0, h0));
+        if (a0 < kDgK) SL[row * C2 + p0] = (unsigned char)c0;
+        if constexpr (C2 > 64) {
+          const int n0 = __popc(l0) + __popc(h0);   // lane s: the slot's entries among the first 64 columns
+          const int p1 = from_lane(s1, offv) + from_lane(s1, n0) + rank_in(from_lane(s1, l1), from_lane(s1, h1));
+          if (a1 < kDgK) SL[row * C2 + p1] = (unsigned char)c1;
         }
-        if (lane == 0) SO[row * 24 + a.k] = (unsigned char)pos;
       }
+      BE_TSTAMP(14, 40);
       for (int c = wave; c < C2; c += kBEW) {        // column lists: lane <-> row
-        const int av = DP[lane * ldp + c] != 0.f ? AK[lane * C2 + c] : 255;
-        int pos = 0;
-        for (int s = 0; s < a.k; ++s) {
-          if (lane == 0) SOc[c * 24 + s] = (unsigned char)pos;
+        const float dv = DP[lane * ldp + c];
+        const int kv = AK[lane * C2 + c];
+        const int av = dv != 0.f ? kv : 255;
+        int pos = 0, offv = 0, l0 = 0, h0 = 0;
+        dg_static_for<0, kDgK>([&](auto S) {
+          constexpr int s = decltype(S)::value;
           const unsigned long long m = __ballot(av == s);
-          if (av == s) SLc[c * kTT + pos + __popcll(m & lt)] = (unsigned char)lane;
+          DG_PARK3(offv, l0, h0, pos, (int)(unsigned)m, (int)(unsigned)(m >> 32), s);
           pos += __popcll(m);
-        }
-        if (lane == 0) SOc[c * 24 + a.k] = (unsigned char)pos;
+        });
+        DG_PARK1(offv, pos, kDgK);
+        if (lane <= kDgK) SOc[c * 24 + lane] = (unsigned char)offv;
+        const int sv = av & 31;
+        const int pp = from_lane(sv, offv) + rank_in(from_lane(sv, l0), from_lane(sv, h0));
+        if (av < kDgK) SLc[c * kTT + pp] = (unsigned char)lane;
       }
+#undef DG_PARK3
+#undef DG_PARK2
+#undef DG_PARK1
+      BE_TSTAMP(15, 40);
     }
     BE_STAMP(0);
+    BE_TSTAMP(16, 45);
     if (tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
     BE_STAMP(1);
     __syncthreads();   // es and the lists are ready; every wave is done with the previous slot's X / D (and the arg-k staging)
