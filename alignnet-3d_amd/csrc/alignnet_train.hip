@@ -706,12 +706,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
     else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
     if (e.stamps) {
-      long long st[17];
+      long long st[19];
       hipStreamSynchronize(h->stream);
       hipMemcpy(st, e.stamps, sizeof(st), hipMemcpyDeviceToHost);
       std::fprintf(stderr, "BE stage %d it-25 phase cycles:", s);
       for (int i = 1; i < 8; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "  | dh1: init %lld mfma %lld epilogue %lld", st[8] - st[6], st[9] - st[8], st[7] - st[9]);
+      std::fprintf(stderr, "  | dh1: init %lld mfma %lld epilogue %lld | P2 (waves 4-7, from the dh1 start) %lld .. %lld", st[8] - st[6], st[9] - st[8], st[7] - st[9],
+                   st[17] - st[6], st[18] - st[6]);
       std::fprintf(stderr, "  | tile start (it 40): barrier %lld staging %lld barrier %lld row lists %lld column lists %lld | 20 slots + 1 tile start %lld\n",
                    st[11] - st[10], st[12] - st[11], st[13] - st[12], st[14] - st[13], st[15] - st[14], st[16] - st[0]);
     }

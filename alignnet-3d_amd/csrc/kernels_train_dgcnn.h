@@ -454,17 +454,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
   const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
-  // roles: waves [0, nitems) own one dh1 item (channel tile, 32-row group); the next nG waves one upper Gram block each
-  constexpr int nitems = CT1 * 2, nG = CT1 * (CT1 + 1) / 2;
-  int git = 0, gjt = 0;
-  if (wave >= nitems && wave < nitems + nG) {
-    int rem = wave - nitems;
-    while (rem >= CT1 - git) { rem -= CT1 - git; ++git; }
-    gjt = git + rem;
-  }
-  f32x16 gacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+  // roles: waves [0, nitems) own one dh1 item (channel tile, 32-row group), nitems <= 4; waves 4..7 the sparse U2 units (P2)
+  constexpr int nitems = CT1 * 2;
   // the dh1 waves keep their Q2 fragments in registers for the whole cloud (C1 <= 64: 8 k-groups); streaming them per slot
   // put eight dependent L2 round trips in front of every slot's MFMAs
   f32x4 qreg[8];
@@ -482,12 +473,16 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   constexpr int p1n = C1 >> 3;
   const int p1row = tid / p1n, p1ch = tid - p1row * p1n;
   const bool p1on = tid < kTT * p1n;
-  constexpr int p2n = C1 >> 4;
-  const int p2c = tid % C2, p2j = tid / C2;
-  const bool p2on = tid < C2 * p2n;
-  float u2[16];
+  // P2 is the job of waves 4..7 alone, next to the dh1 items of waves 0..3 (the Gram blocks those waves once held are the
+  // forward's now): 256 threads, so the shipped shape walks a column's list once for a 32-channel chunk
+  constexpr int kP2W = (C1 * C2 >= 256 * 32) ? 32 : 16, kP2Q = kP2W / 4;
+  constexpr int p2n = C1 / kP2W;
+  const int p2t = tid - 4 * 64;
+  const int p2c = (p2t & 0x7fffffff) % C2, p2j = (p2t & 0x7fffffff) / C2;
+  const bool p2on = p2t >= 0 && p2t < C2 * p2n;
+  float u2[kP2W];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) u2[i] = 0.f;
+  for (int i = 0; i < kP2W; ++i) u2[i] = 0.f;
 
   {   // V2 of this tower -> LDS, once per cloud
     const float* src = a.v2 + tower * a.v2_stride;
@@ -631,26 +626,30 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     BE_STAMP(4);
     __syncthreads();
     BE_STAMP(5);
-    if (p2on) {   // U2[16 j ..][c] += sum over the column's slot rows of dp[row,c] h1_s[row][16 j ..]
-      const int j0 = SOc[p2c * 24 + slot], j1 = SOc[p2c * 24 + slot + 1];
-      for (int j = j0; j < j1; j += 2) {   // two entries per trip (see P1)
-        int rr[2]; float g[2]; f32x4 hv[2][4];
+    if (wave >= 4) {
+      if (a.stamps && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[17] = (long long)__builtin_readcyclecounter();
+      if (p2on) {   // U2[kP2W j ..][c] += sum over the column's slot rows of dp[row,c] h1_s[row][kP2W j ..]
+        const int j0 = SOc[p2c * 24 + slot], j1 = SOc[p2c * 24 + slot + 1];
+        for (int j = j0; j < j1; j += 2) {   // two entries per trip (see P1)
+          int rr[2]; float g[2]; f32x4 hv[2][kP2Q];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) rr[u] = SLc[p2c * kTT + min(j + u, j1 - 1)];
+          for (int u = 0; u < 2; ++u) rr[u] = SLc[p2c * kTT + min(j + u, j1 - 1)];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) g[u] = j + u < j1 ? DP[rr[u] * ldp + p2c] : 0.f;
+          for (int u = 0; u < 2; ++u) g[u] = j + u < j1 ? DP[rr[u] * ldp + p2c] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hv[u][q] = *reinterpret_cast<const f32x4*>(X + rr[u] * ld0 + p2j * 16 + q * 4);
+            for (int q = 0; q < kP2Q; ++q) hv[u][q] = *reinterpret_cast<const f32x4*>(X + rr[u] * ld0 + p2j * kP2W + q * 4);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            u2[q * 4 + 0] = fmaf(g[u], hv[u][q][0], u2[q * 4 + 0]); u2[q * 4 + 1] = fmaf(g[u], hv[u][q][1], u2[q * 4 + 1]);
-            u2[q * 4 + 2] = fmaf(g[u], hv[u][q][2], u2[q * 4 + 2]); u2[q * 4 + 3] = fmaf(g[u], hv[u][q][3], u2[q * 4 + 3]);
-          }
+            for (int q = 0; q < kP2Q; ++q) {
+              u2[q * 4 + 0] = fmaf(g[u], hv[u][q][0], u2[q * 4 + 0]); u2[q * 4 + 1] = fmaf(g[u], hv[u][q][1], u2[q * 4 + 1]);
+              u2[q * 4 + 2] = fmaf(g[u], hv[u][q][2], u2[q * 4 + 2]); u2[q * 4 + 3] = fmaf(g[u], hv[u][q][3], u2[q * 4 + 3]);
+            }
+        }
       }
+      if (a.stamps && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[18] = (long long)__builtin_readcyclecounter();
     }
     BE_STAMP(6);
     if (wave < nitems) {
@@ -702,22 +701,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
 #pragma unroll
         for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
       }
-    } else if (a.g1_part && wave < nitems + nG) {   // (null: the forward kept Gram(h1))
-      // ---- Gram(h1) += h1_s^T h1_s, one upper 32 x 32 block per wave, register-resident for the whole cloud ----
-      const float* pa = X + half * ld0 + git * 32 + (lane & 31);
-      const float* pb = X + half * ld0 + gjt * 32 + (lane & 31);
-#pragma unroll 8
-      for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
     }
     BE_STAMP(7);
   }
-  if (a.g1_part && wave >= nitems && wave < nitems + nG) {
-    const float zero[16] = {};
-    tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
-  }
   if (p2on) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a.u2_part[((size_t)cloud * C1 + p2j * 16 + i) * C2 + p2c] = u2[i];
+    for (int i = 0; i < kP2W; ++i) a.u2_part[((size_t)cloud * C1 + p2j * kP2W + i) * C2 + p2c] = u2[i];
   }
   if (wave < nitems) {
     const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
