@@ -128,6 +128,14 @@ def test_forward_dgcnn(gpu_required, N, B, split=False):
     assert bad == 0
 
 
+@pytest.mark.parametrize("N", [1500, 4096])
+def test_forward_dgcnn_large_clouds(gpu_required, N):
+    """The kNN kernel is compiled for 16 / 32 / 64 candidate slots per lane (N <= 1024 / 2048 / 4096): the small-N cases above
+    only reach the first.  Same criterion; a neighbour swapped at a near-tie of the fp32 distances (the oracle's are fp64)
+    would show up as a mismatching pair."""
+    test_forward_dgcnn(gpu_required, N, 2)
+
+
 @pytest.mark.parametrize("N,B", [(64, 3), (200, 4)])
 def test_forward_dgcnn_split_bf16(gpu_required, N, B):
     """The DGCNN branch with the split-bf16 kernels (dgcnn_split): same criterion as the exact-fp32 branch."""
