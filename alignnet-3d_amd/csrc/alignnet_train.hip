@@ -408,12 +408,15 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     finish(0, C1, 1, ecount);
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
+    if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
     if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     if (d.stamps) {
-      long long sv[8];
+      long long sv[11];
       hipStreamSynchronize(h->stream);
       hipMemcpy(sv, d.stamps, sizeof(sv), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "FE stage %d whole-kernel cycles per workgroup: longest %lld shortest %lld workgroup 0 %lld (%d slots)\n", s, sv[8], (1ll << 40) - sv[9], sv[10],
+                   ((N + kTT - 1) / kTT) * kDgK);
       std::fprintf(stderr, "FE stage %d it-25 cycles: gather + mfma %lld epilogue %lld colsum %lld es %lld barrier %lld lift %lld barrier %lld\n", s,
                    sv[1] - sv[0], sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
     }

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const long long t_begin = a.stamps ? (long long)__builtin_readcyclecounter() : 0;   // (debug: whole-kernel cycles per workgroup)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
@@ -329,6 +330,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   if (wave < nG) {
     const float zero[16] = {};
     tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
+  }
+  if (a.stamps && tid == 0) {   // stamps 8 / 9 / 10: longest and (2^40 - shortest) workgroup, workgroup 0 -- zeroed by the host
+    const long long d = (long long)__builtin_readcyclecounter() - t_begin;
+    atomicMax(reinterpret_cast<unsigned long long*>(a.stamps + 8), (unsigned long long)d);
+    atomicMax(reinterpret_cast<unsigned long long*>(a.stamps + 9), (unsigned long long)((1ll << 40) - d));
+    if (blockIdx.x == 0) a.stamps[10] = d;
   }
   {   // s1_part [cloud][kQG row groups][C1]
     constexpr int kQ = C1 / 4, kQG = (kTW * 64) / kQ;
