@@ -26,6 +26,13 @@ SUMMARY_NAMES = (
     "losses_stages/stage3_angle_residual_loss")  # models/tp8.py:336-353 order
 
 
+# include/alignnet_hip.h ALIGNNET_KERNEL_*: which backbone instantiation an eval forward launched (get_option("last_backbone_kernel"))
+KERNEL_IDS = {"pointnet_fused": 1, "pointnet_fused<64,128>": 2, "pointnet_fused<64,128,k16>": 3, "pointnet_fused<tp64>": 4,
+              "pointnet_split": 5, "pointnet_split<64,128>": 6, "dgcnn_fused": 10, "dgcnn_fused<64,128>": 11,
+              "dgcnn_split": 12, "dgcnn_split<64,128>": 13}
+KERNEL_NAMES = {v: k for k, v in KERNEL_IDS.items()}
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -338,6 +345,15 @@ class Engine:
         self._check(self._lib.alignnet_get_grad(self._h, name.encode(), _fp(a), a.size))
         return a.reshape(shp) if shp[0] > 1 else a
 
+    def debug_dropout_uniforms(self, B):
+        """The uniforms the device-side dropout stream draws at the current step (layout of `dropout_u`): list of five
+        [B, width] arrays [s1 tower0, s2 tower0, s1 tower1, s2 tower1, pair head]."""
+        o = self.cfg["model"]["options"]
+        w12, w3 = int(o["s1transformer"][1][0][-1]), int(o["remaining_transform_prediction"][0][-1])
+        a = np.empty(B * (4 * w12 + w3), np.float32)
+        self._check(self._lib.alignnet_debug_dropout_uniforms(self._h, B, _fp(a), a.size))
+        return [a[i * B * w12:(i + 1) * B * w12].reshape(B, w12) for i in range(4)] + [a[4 * B * w12:].reshape(B, w3)]
+
     def grad_buffer(self):
         ptr, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.alignnet_grad_buffer(self._h, C.byref(ptr), C.byref(n)))
@@ -383,6 +399,10 @@ class Engine:
         v = C.c_int64(0)
         self._check(self._lib.alignnet_get_option(self._h, key.encode(), C.byref(v)))
         return int(v.value)
+
+    def last_backbone_kernel(self):
+        """Name of the backbone kernel instantiation the most recent eval forward launched."""
+        return KERNEL_NAMES.get(self.get_option("last_backbone_kernel"), "none")
 
     def profile_enable(self, on=True):
         self._check(self._lib.alignnet_profile_enable(self._h, int(on)))

@@ -486,12 +486,19 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
       static bool sattr = false;
       if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
       hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
-    } else
-    hipLaunchKernelGGL(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
-  } else if (TP == 64) hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a);
-  else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
-  else if (a.ld[0] == 68 && a.ld[1] == 132 && !getenv("ALIGNNET_NO_LD_CONST")) hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);   // the shipped widths 64, 128
-  else hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a);
+      h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_64_128;
+    } else {
+      hipLaunchKernelGGL(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+      h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT;
+    }
+  } else if (TP == 64) { hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_TP64; }
+  else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+    hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
+    h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16;
+  } else if (a.ld[0] == 68 && a.ld[1] == 132 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
+    hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
+    h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128;
+  } else { hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED; }
   if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
   HIP_TRY(h, hipGetLastError());
 #ifdef ALIGNNET_KSTAMP
@@ -562,8 +569,11 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
         static bool dsattr2 = false;
         if (!dsattr2) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2 = true; }
         hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
-      } else
-      hipLaunchKernelGGL(dgcnn_split<>, grid, dim3(kWaves * 64), dlds, h->stream, sa);
+        h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT_64_128;
+      } else {
+        hipLaunchKernelGGL(dgcnn_split<>, grid, dim3(kWaves * 64), dlds, h->stream, sa);
+        h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT;
+      }
     } else {
       const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
@@ -571,8 +581,11 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
         static bool sattr = false;
         if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
         hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
-      } else
-      hipLaunchKernelGGL(dgcnn_fused<>, grid, dim3(kWaves * 64), lds, h->stream, a);
+        h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED_64_128;
+      } else {
+        hipLaunchKernelGGL(dgcnn_fused<>, grid, dim3(kWaves * 64), lds, h->stream, a);
+        h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED;
+      }
       if (a.stamps) {
         long long sv[9];
         hipStreamSynchronize(h->stream);
@@ -735,6 +748,8 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   const std::string k(key);
   if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
   if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
+  if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
+  if (k == "last_train_kernel") { *value = h->last_train_kernel; return 0; }
   return fail(h, "alignnet_get_option: unknown key '" + k + "'");
 }
 

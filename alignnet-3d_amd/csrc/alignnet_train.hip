@@ -524,6 +524,39 @@ static BnRowsArgs bn_args(alignnet_handle* h, TrainWS* w, int s, int j, int M, i
   return a;
 }
 
+// The uniforms of the device-side dropout stream for the current step counter, in the host layout of `dropout_u`
+// (include/alignnet_hip.h).  Evaluates the very expression dropout_scale() evaluates (seed of bn_args + set, element index).
+__global__ void dropout_uniforms_kernel(float* __restrict__ out, int B, int w12, int w3, uint64_t seed_base)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t blk = (size_t)B * w12, n = 4 * blk + (size_t)B * w3;
+  if (i >= n) return;
+  int s, set; size_t e;
+  if (i < 4 * blk) { const int q = (int)(i / blk); s = q & 1; set = q >> 1; e = i - (size_t)q * blk; }   // [s1 t0 | s2 t0 | s1 t1 | s2 t1]
+  else { s = 2; set = 0; e = i - 4 * blk; }
+  out[i] = hash_uniform(seed_base + (uint64_t)s * 4 + set, (uint64_t)e);
+}
+
+extern "C" int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, float* dst, size_t count)
+{
+  if (!h || !dst) return 1;
+  const int w1 = h->layers[h->s1_fc.first + h->s1_fc.n - 2].cout, w2 = h->layers[h->s2_fc.first + h->s2_fc.n - 2].cout;
+  const int w3 = h->layers[h->rem_fc.first + h->rem_fc.n - 2].cout;
+  if (w1 != w2) return fail(h, "alignnet_debug_dropout_uniforms: needs equal last-hidden widths in the s1/s2 heads");
+  const size_t n = (size_t)B * (4 * (size_t)w1 + w3);
+  if (B < 1 || count != n) return fail(h, "alignnet_debug_dropout_uniforms: count must be B * (4 * w_hidden + w_pair_hidden)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  float* d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, n * sizeof(float)));
+  hipLaunchKernelGGL(dropout_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, B, w1, w3,
+                     h->cfg.seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->step * 16);
+  hipError_t e = hipMemcpyAsync(dst, d, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d);
+  HIP_TRY(h, e);
+  return 0;
+}
+
 static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin, int M, int rows_per_set, float bn_decay,
                           int update_ema, const float* u_dev)
 {
@@ -788,6 +821,11 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   alignnet_get_state(h, &stt);
   const float bn_decay = stt.bn_decay;
   if (set_lds_attrs(h)) return 1;
+  {
+    bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
+    for (int s = 0; s < 3; ++s) std_all = std_all && h->layers[conv_of(h, s).first].cout == 64 && h->layers[conv_of(h, s).first + 1].cout == 128;
+    h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0);
+  }
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);

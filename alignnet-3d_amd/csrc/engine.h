@@ -74,6 +74,8 @@ struct alignnet_handle {
   hipStream_t stream = nullptr;
   int64_t step = 0;
   int last_B = 0;
+  int last_kernel = 0;             // which backbone instantiation the last eval forward launched (alignnet_get_option "last_backbone_kernel")
+  int last_train_kernel = 0;       // same for the training step: bit 0 = compile-time widths (64, 128), bit 1 = bf16 operands, bit 2 = dgcnn
   // profiling
   bool prof = false;
   hipEvent_t ev[2] = {nullptr, nullptr};

@@ -165,6 +165,10 @@ int alignnet_grad_buffer(alignnet_handle* h, float** d_grad, size_t* count);
 int alignnet_apply_gradients(alignnet_handle* h, float grad_scale);
 /* Debug/parity: copy the flat gradient of one variable to the host. */
 int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t count);
+/* Debug/parity: the uniforms the device-side dropout stream (tf.nn.dropout's random_uniform, utils/tf_util.py:554-575) draws at
+ * the current step counter when dropout_u is NULL, in the layout of dropout_u; count = B * (4 * w_hidden + w_pair_hidden).
+ * A step run with these uniforms passed explicitly is bit-identical to the step that draws them itself. */
+int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, float* dst, size_t count);
 
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
  *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */
@@ -236,7 +240,22 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
  *   gfx950).  Outputs stay within the 1e-4 parity bar (measured 3e-6 against the fp64 oracle, like the exact path).
  *   Also covers the DGCNN branch with widths [<= 64, <= 128, C3]; other backbone shapes keep the exact-fp32 kernels.
+ * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped
+ * widths 64 / 128 dispatch to kernels with the widths compiled in):
+ * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
+ * "last_train_kernel": bit mask of the most recent training step -- 1 = compile-time widths (64, 128), 2 = bf16 operands,
+ *   4 = dgcnn backbone.
  * Unknown keys fail. */
+#define ALIGNNET_KERNEL_POINTNET_FUSED 1            /* pointnet_fused<128>: run-time widths */
+#define ALIGNNET_KERNEL_POINTNET_FUSED_64_128 2     /* pointnet_fused<128, 68, 132> */
+#define ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16 3 /* pointnet_fused<128, 68, 132, 16>: the shipped 3-layer shape */
+#define ALIGNNET_KERNEL_POINTNET_FUSED_TP64 4       /* pointnet_fused<64> (ALIGNNET_TILE=64) */
+#define ALIGNNET_KERNEL_POINTNET_SPLIT 5            /* pointnet_split<> */
+#define ALIGNNET_KERNEL_POINTNET_SPLIT_64_128 6     /* pointnet_split<64, 128> */
+#define ALIGNNET_KERNEL_DGCNN_FUSED 10              /* dgcnn_fused<> */
+#define ALIGNNET_KERNEL_DGCNN_FUSED_64_128 11       /* dgcnn_fused<68, 132> */
+#define ALIGNNET_KERNEL_DGCNN_SPLIT 12              /* dgcnn_split<> */
+#define ALIGNNET_KERNEL_DGCNN_SPLIT_64_128 13       /* dgcnn_split<64, 128> */
 int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value);
 int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value);
 int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches,

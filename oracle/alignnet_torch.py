@@ -37,8 +37,11 @@ def to_torch(P: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False)
 class TorchTp8:
     """Eager re-statement; `P` is a name->tensor dict using the oracle's names."""
 
-    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False):
+    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False, checkpoint: bool = False):
         self.spec, self.P = spec, P
+        # checkpoint: recompute each backbone in the backward instead of keeping its [B*N, C] activations (full-size batches:
+        # 256 x 1024 points x 1024 channels in fp64 is 2 GB per tensor).  Same arithmetic, same gradients.
+        self.checkpoint = checkpoint
         self.ema_updates: Dict[str, torch.Tensor] = {}
         # Model of the engine's "train_matmul_bf16" option (not a reference feature): the operands of the MFMA convs of
         # every PointNet backbone (all but the K = 3 lift) are rounded to bf16 (round-to-nearest-even), products are
@@ -103,7 +106,11 @@ class TorchTp8:
         return h.reshape(B, N, -1).amax(dim=1)
 
     def _backbone(self, *a):
-        return (self._pointnet if self.spec.backbone == "pointnet" else self._dgcnn)(*a)
+        fn = self._pointnet if self.spec.backbone == "pointnet" else self._dgcnn
+        if self.checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(fn, *a, use_reentrant=False)
+        return fn(*a)
 
     def _mlp(self, x, scope, widths, tower, keep, training, decay, u):
         h = x

@@ -19,10 +19,15 @@ def _run(cfg, B, seed=1234, split=False):
         assert eng.get_option("infer_matmul_bf16x3") == 1
     d = R.synth_pairs(B, spec.num_points, seed=seed, dtype=np.float32)
     ep = eng.forward(d["pcs1"], d["pcs2"])
+    global LAST_KERNEL
+    LAST_KERNEL = eng.last_backbone_kernel()   # which instantiation the embedding backbone (the last launch) ran
     P64 = {k: v.astype(np.float64) for k, v in P32.items()}
     ref, _, _ = R.get_model(P64, spec, d["pcs1"].astype(np.float64), d["pcs2"].astype(np.float64))
     eng.close()
     return ep, ref, spec
+
+
+LAST_KERNEL = "none"
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (100, 3), (256, 33), (37, 1)])
@@ -40,6 +45,7 @@ def test_forward_synthcars_widths_n1024(gpu_required):
     worst, unstable = compare_forward(ep, ref, spec.num_bins)
     print("worst abs err", worst, "unstable pairs", unstable)
     assert unstable <= 2
+    assert LAST_KERNEL == "pointnet_fused<64,128,k16>", LAST_KERNEL   # the instantiation bench.py times
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (100, 3), (256, 33), (37, 1)])
@@ -61,6 +67,8 @@ def test_forward_split_bf16_synthcars_widths_n1024(gpu_required):
     print("split-bf16 worst abs err", worst, "vs exact-fp32 path", {k: float(np.abs(ep32[k] - ref[k]).max()) for k in ref})
     assert unstable <= 2
     assert any(not np.array_equal(ep[k], ep32[k]) for k in ep), "option had no effect"
+    ep, ref, spec = _run(cfg, 8, split=True)
+    assert LAST_KERNEL == "pointnet_split<64,128>", LAST_KERNEL
 
 
 @pytest.mark.parametrize("split", [False, True])
@@ -140,6 +148,32 @@ def test_forward_dgcnn_large_clouds(gpu_required, N):
 def test_forward_dgcnn_split_bf16(gpu_required, N, B):
     """The DGCNN branch with the split-bf16 kernels (dgcnn_split): same criterion as the exact-fp32 branch."""
     test_forward_dgcnn(gpu_required, N, B, split=True)
+
+
+DG_KEYS = ("pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers", "pred_pc1angle_logits", "pred_pc2angle_logits")
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("N,B,full", [(1024, 4, True), (4096, 2, True), (4096, 2, False), (200, 5, False), (1500, 2, False)])
+def test_forward_dgcnn_shipped_widths(gpu_required, N, B, full, split):
+    """The DGCNN kernels bench.py times (BASELINE.json configs[4]): edge widths 64 / 128 dispatch to instantiations with the widths
+    compiled in -- dgcnn_fused<68, 132> (two workgroups per CU, bounded to 128 VGPRs) and dgcnn_split<64, 128> -- which are different
+    code from the generic kernels the small-width tests reach.  full = the SynthCars widths (C3 = 256 / 512 / 1024) at the bench's
+    cloud sizes; otherwise narrow last layers so that ragged N (partial tiles, all three kNN slot counts) stays cheap for the
+    oracle.  Same criterion as test_forward_dgcnn, plus the stage-3 outputs on decode-stable pairs, plus the read-back of which
+    instantiation ran."""
+    if full:
+        cfg = alignnet3d.default_model_config()
+        cfg["model"]["num_points"] = N
+        cfg["model"]["backbone"] = "dgcnn"
+    else:
+        cfg = small_cfg(N=N, backbone="dgcnn", s1=(64, 128, 96), s2=(64, 128, 128), emb=(64, 128, 160))
+    ep, ref, spec = _run(cfg, B, split=split)
+    assert LAST_KERNEL == ("dgcnn_split<64,128>" if split else "dgcnn_fused<64,128>"), LAST_KERNEL
+    bad = sum(not all(np.allclose(ep[k][b], ref[k][b], rtol=2e-4, atol=2e-4) for k in DG_KEYS) for b in range(B))
+    worst, unstable = compare_forward(ep, ref, spec.num_bins, atol=2e-4, rtol=2e-4)
+    print("dgcnn shipped widths N=%d B=%d split=%s: pairs outside 2e-4: %d, worst abs err %.2e, unstable %d" % (N, B, split, bad, max(worst.values()), unstable))
+    assert bad == 0 and unstable <= 1
 
 
 @pytest.mark.parametrize("split", [False, True])

@@ -159,3 +159,76 @@ def test_dgcnn_training_learns(gpu_required):
     print("dgcnn mean loss first / last 10 steps:", first, last)
     assert np.all(np.isfinite(losses)) and np.isfinite(pred).all()
     assert last < 0.75 * first, (first, last)
+
+
+def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
+    cfg = alignnet3d.default_model_config()
+    cfg["model"]["num_points"] = Nt
+    cfg["model"]["backbone"] = backbone
+    cfg["training"]["batch_size"] = Bt
+    spec, P32 = oracle_params(cfg, seed=seed)
+    d = R.synth_pairs(Bt, Nt, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    du = {k: rng.uniform(size=(Bt, 256)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    return cfg, spec, P32, d, du
+
+
+def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4):
+    """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
+    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`)."""
+    from tests import test_train_gpu as TT
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert eng.get_option("last_train_kernel") == expect_kernel
+    worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=pred_tol, atol=pred_tol, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    worst_ema = 0.0
+    for k, v in ema_ref.items():
+        got = eng.get_variable(k)
+        np.testing.assert_allclose(got, v, rtol=1e-4, atol=1e-5, err_msg=k)
+        worst_ema = max(worst_ema, float(np.abs(got - v).max()))
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
+    bad, rel = {}, {}
+    for name in R.trainable_names(spec):
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        if name in bn_bias:
+            assert np.abs(g).max() == 0.0 and np.abs(ref).max() < 1e-9 * gscale, name
+            continue
+        err = float(np.abs(g - ref).max())
+        if np.abs(ref).max() > 1e-6 * gscale:
+            rel[name] = err / float(np.abs(ref).max())
+        if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    eng.close()
+    print("full size: loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, worst relative gradient errors %s"
+          % (res["loss"], loss_ref, worst_pred, worst_ema, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
+    assert not bad, bad
+
+
+def test_train_fp32_full_size_matches_autograd(gpu_required):
+    """BASELINE.json configs[2]'s shape in fp32: SynthCars widths, 256 pairs x 1024 points -- the kernel instantiations with the
+    widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256."""
+    cfg, spec, P32, d, du = _train_setup()
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1)
+
+
+def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):
+    """BASELINE.json configs[2] at its own size: bf16 MFMA convs, 256 pairs x 1024 points, against the oracle that models the
+    operand rounding (same criteria as tests/test_train_gpu.py::test_bf16_lift_matches_rounded_oracle)."""
+    from tests import test_train_gpu as TT
+    cfg, spec, P32, d, du = _train_setup()
+    TT.bf16_check(cfg, spec, P32, d, du, B, expect_kernel=3, checkpoint=True)
+
+
+def test_train_dgcnn_n1024_matches_autograd(gpu_required):
+    """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
+    SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 4 keeps the [B*N*k, C] autograd oracle in memory."""
+    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=1024, seed=7)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5)

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
 
 
-def _oracle(cfg, P32, d, du, decay, bf16_lift=False, dt=np.float64):
+def _oracle(cfg, P32, d, du, decay, bf16_lift=False, dt=np.float64, checkpoint=False):
     spec = R.NetSpec.from_cfg(cfg)
     tp = T.to_torch({k: v.astype(dt) for k, v in P32.items()}, dtype=torch.float64 if dt == np.float64 else torch.float32, requires_grad=True)
-    tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift)
+    tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift, checkpoint=checkpoint)
     td = {k: torch.tensor(v.astype(dt)) for k, v in d.items()}
     tu = {k: torch.tensor(v.astype(dt)) for k, v in du.items()}
     ep = tm.forward(td["pcs1"], td["pcs2"], True, decay, tu)
@@ -182,6 +182,11 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B, std):
     Against the *fp32* step the bf16 step differs by ~1 % in the stage features and flips a few argmax yaw decodes per
     batch (tools/bf16_check.py), which is why the comparison is against the rounded oracle."""
     cfg, spec, P32, d, du = _setup(N, B, std=std)
+    bf16_check(cfg, spec, P32, d, du, B, expect_kernel=3 if std else 2)
+
+
+def bf16_check(cfg, spec, P32, d, du, B, expect_kernel, checkpoint=False):
+    """Body of test_bf16_lift_matches_rounded_oracle (also run at BASELINE.json's full size by tests/test_fullsize_gpu.py)."""
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     stats = ["siamese/transformer1/embedding/conv3/bn/moving_mean", "siamese_1/transformer1/embedding/conv3/bn/moving_var"]
     eng = alignnet3d.Engine(cfg)
@@ -193,9 +198,10 @@ def test_bf16_lift_matches_rounded_oracle(gpu_required, N, B, std):
     eng.set_variables(P32)
     eng.set_option("train_matmul_bf16", 1)
     assert eng.get_option("train_matmul_bf16") == 1
-    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True)
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True, checkpoint=checkpoint)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     assert res["loss"] != res32["loss"], "bf16 option had no effect"
+    assert eng.get_option("last_train_kernel") == expect_kernel   # bit 0: widths (64, 128) compiled in, bit 1: bf16 operands
     for k in stats:
         got, ref = eng.get_variable(k), ema_ref[k]
         e16, e32 = float(np.abs(got - ref).max()), float(np.abs(ema32[k] - ref).max())
