@@ -101,6 +101,7 @@ SYMBOLS = {
                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "alignnet_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "alignnet_get_option": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_int64)]),
+    "alignnet_profile_read_kernel": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "alignnet_profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }
 

@@ -108,6 +108,14 @@ def make_c_config(cfg, device=None, seed=0):
         raise AssertionError("Invalid optimizer")  # train.py:216
     c.optimizer = 0 if opt == "adam" else 1
     c.momentum = float(t.get("optimizer", {}).get("momentum", 0.9))
+    # the engine implements loss "separate" with hard angle classes (every shipped config); anything else must not train silently
+    loss = t.get("loss", {})
+    if isinstance(loss, dict):
+        if loss.get("loss", "separate") != "separate":
+            raise AssertionError("training.loss.loss=%r: only the 'separate' loss is built (models/tp8.py:401-407; 'p2p' is never "
+                                 "enabled by a shipped config, SURVEY 8.A4)" % loss.get("loss"))
+        if (loss.get("options", {}) or {}).get("soft_angle_classes", False):
+            raise AssertionError("training.loss.options.soft_angle_classes is not built (models/tp8.py:253-274; no shipped config enables it)")
     c.seed = int(seed)
     return c
 
@@ -406,6 +414,19 @@ class Engine:
 
     def profile_enable(self, on=True):
         self._check(self._lib.alignnet_profile_enable(self._h, int(on)))
+
+    PROFILED_KERNELS = ("backbone", "knn", "train_fwd_phase2", "train_fwd_phase3", "train_gram_h2", "train_bwd_b2", "train_bwd_b1",
+                        "dg_train_fwd", "dg_train_bwd_edge", "allreduce", "optimizer")
+
+    def profile_kernels(self):
+        """{kernel: (ms, launches)} accumulated since the last profile_read(reset=True); call BEFORE that reset."""
+        out = {}
+        for k in self.PROFILED_KERNELS:
+            ms, n = C.c_double(), C.c_int64()
+            self._check(self._lib.alignnet_profile_read_kernel(self._h, k.encode(), C.byref(ms), C.byref(n)))
+            if n.value:
+                out[k] = (ms.value, n.value)
+        return out
 
     def profile_read(self, reset=True):
         ms, n, tot = C.c_double(), C.c_int64(), C.c_double()

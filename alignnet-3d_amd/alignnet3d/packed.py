@@ -21,9 +21,38 @@ def _loadtxt(s):
     return np.array([float(t) for t in s.split()], dtype=np.float64)
 
 
+def dataset_fingerprint(basepath):
+    """What a cache is valid for: the example ids present and the newest modification time of the three per-example
+    directories (a re-generated or extended dataset changes one of them)."""
+    names = sorted(f for f in os.listdir(os.path.join(basepath, "meta")) if f.endswith(".json"))
+    mtime = max([os.stat(os.path.join(basepath, d)).st_mtime_ns for d in ("meta", "pointcloud1", "pointcloud2")] +
+                [os.stat(os.path.join(basepath, "meta", f)).st_mtime_ns for f in names[:1] + names[-1:]])
+    return {"n_examples": len(names), "first": names[0] if names else "", "last": names[-1] if names else "", "mtime_ns": int(mtime)}
+
+
+def cache_is_current(basepath, cache_dir):
+    try:
+        with open(os.path.join(cache_dir, "manifest.json")) as fh:
+            return json.load(fh) == dataset_fingerprint(basepath)
+    except (OSError, ValueError):
+        return False
+
+
 def pack_dataset(basepath, cache_dir=None):
+    """Build the cache.  Every table is written to a temporary name and renamed into place, the manifest last, so a reader
+    never maps a half-written file and an interrupted build is not mistaken for a cache."""
     cache_dir = cache_dir or os.path.join(basepath, "packed_cache")
     os.makedirs(cache_dir, exist_ok=True)
+    fingerprint = dataset_fingerprint(basepath)
+    try:
+        os.remove(os.path.join(cache_dir, "manifest.json"))
+    except OSError:
+        pass
+
+    def save(name, arr):
+        tmp = os.path.join(cache_dir, ".%s.%d.tmp.npy" % (name, os.getpid()))
+        np.save(tmp, arr)
+        os.replace(tmp, os.path.join(cache_dir, name))
     ids = sorted(int(f[:-5]) for f in os.listdir(os.path.join(basepath, "meta")) if f.endswith(".json"))
     labels = np.empty((len(ids), 12), np.float64)
     offs = np.zeros((len(ids) + 1, 2), np.int64)
@@ -45,10 +74,14 @@ def pack_dataset(basepath, cache_dir=None):
     for t, name in enumerate(("points1.npy", "points2.npy")):
         dt = np.result_type(*[b.dtype for b in blobs[t]]) if blobs[t] else np.float32
         arr = np.concatenate([b.astype(dt, copy=False) for b in blobs[t]], axis=0) if blobs[t] else np.zeros((0, 3), dt)
-        np.save(os.path.join(cache_dir, name), arr)
-    np.save(os.path.join(cache_dir, "offsets.npy"), offs)
-    np.save(os.path.join(cache_dir, "labels.npy"), labels)
-    np.save(os.path.join(cache_dir, "ids.npy"), np.asarray(ids, np.int64))
+        save(name, arr)
+    save("offsets.npy", offs)
+    save("labels.npy", labels)
+    save("ids.npy", np.asarray(ids, np.int64))
+    tmp = os.path.join(cache_dir, ".manifest.%d.tmp" % os.getpid())
+    with open(tmp, "w") as fh:
+        json.dump(fingerprint, fh)
+    os.replace(tmp, os.path.join(cache_dir, "manifest.json"))
     return cache_dir
 
 

@@ -22,6 +22,44 @@ def broadcast_bytes(dist, payload, src=0):
     return box[0]
 
 
+def broadcast_object(dist, obj, src=0):
+    """Any picklable object from `src` to every rank (the epoch's permutation of the training ids)."""
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def mean_scalar(dist, x):
+    import torch
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
+def average_ema_shadows(engine, dist):
+    """All-reduce-average the non-trainable variables (the BatchNorm EMA shadows) across ranks.  Local-BN data parallelism
+    updates each rank's shadows from its own shard's batch statistics; averaging them (the mean of the per-rank EMAs is the EMA
+    of the per-rank means) keeps every rank's eval-mode model -- and the checkpoint rank 0 writes -- identical."""
+    import numpy as np
+    import torch
+    names = [(n, s) for n, s, trainable in engine.variables() if not trainable]
+    if not names:
+        return 0
+    flat = np.concatenate([np.asarray(engine.get_variable(n), np.float32).ravel() for n, _ in names])
+    t = torch.from_numpy(flat)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    flat = (t.cpu().numpy() / dist.get_world_size()).astype(np.float32)
+    off = 0
+    for n, (r, c) in names:
+        engine.set_variable(n, flat[off:off + r * c])
+        off += r * c
+    return len(names)
+
+
 def init_comm(engine, dist, make_id=None):
     """Create the RCCL communicator of `engine` across the ranks of the default process group."""
     make_id = make_id or type(engine).comm_unique_id

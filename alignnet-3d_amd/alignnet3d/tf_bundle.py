@@ -301,21 +301,44 @@ def write_bundle(prefix, tensors, block_entries=64):
 
 
 # ---- variable-name mapping -----------------------------------------------------------------------------
+def tf_shadow_name(name):
+    """TF 1.x checkpoint name of a BatchNorm EMA shadow, given the engine's `<tower>/<layer>/bn/moving_{mean,var}`.
+
+    batch_norm_template (utils/tf_util.py:455-492) calls `ema.apply([batch_mean, batch_var])` on the two output TENSORS of
+    `tf.nn.moments(..., name='moments')`, whose op names live in the NAME scope: `<tower>/<layer>/bn/moments/Squeeze` (mean)
+    and `.../Squeeze_1` (variance), tower = `siamese` or `siamese_1` (the second `tf.variable_scope("siamese", reuse=AUTO_REUSE)`
+    of models/tp8.py:140-143 re-enters the same VARIABLE scope under a uniquified name scope).  ExponentialMovingAverage.apply
+    creates the shadow with slot_creator.create_zeros_slot -> `variable_scope(None, primary.op.name + "/ExponentialMovingAverage")`
+    + `get_variable("")`, i.e. the slot is named by the current VARIABLE scope -- `siamese/<layer>/bn` for BOTH towers -- followed
+    by the primary's full op name:
+        siamese/<layer>/bn/ + <tower>/<layer>/bn/moments/Squeeze[_1]/ExponentialMovingAverage
+    The pair head sits at the top level (scope '' at models/tp8.py:154): `fc1/bn/fc1/bn/moments/Squeeze/ExponentialMovingAverage`."""
+    for leaf, op in (("/bn/moving_mean", "Squeeze"), ("/bn/moving_var", "Squeeze_1")):
+        if name.endswith(leaf):
+            inner = name[: -len(leaf)] + "/bn"                 # name scope of the moments op
+            parts = inner.split("/", 1)
+            var_scope = ("siamese/" + parts[1]) if parts[0] in ("siamese", "siamese_1") else inner
+            return "%s/%s/moments/%s/ExponentialMovingAverage" % (var_scope, inner, op)
+    return None
+
+
 def map_variables(engine_vars, ckpt_names):
-    """engine variable name -> checkpoint tensor name.  weights/biases/beta/gamma keep their graph names; the EMA
-    shadows of batch_norm_template are `<bn scope>/<bn scope>/moments/Squeeze[_1]/ExponentialMovingAverage`-style names
-    whose exact spelling depends on the TF version, so they are matched structurally.  Returns (mapping, missing)."""
+    """engine variable name -> checkpoint tensor name.  weights / biases / beta / gamma keep their graph names; the EMA shadows
+    follow tf_shadow_name().  Should another TF version spell the slot's outer scope differently, a shadow is also accepted by
+    its unambiguous tail `/<tower>/<layer>/bn/moments/Squeeze[_1]/ExponentialMovingAverage`.  Returns (mapping, missing)."""
     ck = set(ckpt_names)
     mapping, missing = {}, []
     for name, _shape, _tr in engine_vars:
         if name in ck:
             mapping[name] = name
             continue
-        if name.endswith("/bn/moving_mean") or name.endswith("/bn/moving_var"):
-            scope = name.rsplit("/", 1)[0] + "/"
-            want_var = name.endswith("moving_var")
-            cands = [c for c in ck if c.startswith(scope) and c.endswith("ExponentialMovingAverage") and "moments" in c]
-            pick = [c for c in cands if ("Squeeze_1" in c) == want_var]
+        want = tf_shadow_name(name)
+        if want is not None:
+            if want in ck:
+                mapping[name] = want
+                continue
+            tail = want[want.index("/bn/") + len("/bn/"):]    # <tower>/<layer>/bn/moments/...
+            pick = [c for c in ck if c == tail or c.endswith("/" + tail)]
             if len(pick) == 1:
                 mapping[name] = pick[0]
                 continue
@@ -346,10 +369,12 @@ def load_into_engine(engine, prefix, load_step=True, strict=True):
 
 
 def export_from_engine(engine, prefix):
-    """Write the engine's variables under their graph names (conv kernels back in HWIO) plus the global step."""
+    """Write the engine's variables under the names the reference's tf.train.Saver uses (conv kernels back in HWIO, EMA
+    shadows under tf_shadow_name()) plus the global step `Variable` (train.py:195)."""
     out = {}
     for name, (r, c), _ in engine.variables():
         a = engine.get_variable(name).reshape(r, c)
+        name = tf_shadow_name(name) or name
         if name.endswith("/weights") and "/conv" in name:
             a = a.reshape(1, 3, 1, c) if (r == 3 and name.endswith("conv1/weights")) else a.reshape(1, 1, r, c)
         elif r == 1:

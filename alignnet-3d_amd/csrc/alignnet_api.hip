@@ -202,7 +202,7 @@ extern "C" void alignnet_destroy(alignnet_handle* h)
   alignnet_train_ws_free(h);
   alignnet_dataset_free(h);
   free_ws(h);
-  for (auto& pr : h->prof_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (auto& pr : h->prof_pending) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
   for (auto& pr : h->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   if (h->ev[0]) hipEventDestroy(h->ev[0]);
   if (h->ev[1]) hipEventDestroy(h->ev[1]);
@@ -464,12 +464,8 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   if (per_env > 0) per = std::min(ntiles, per_env);
   a.tiles_per_wg = per;
   const dim3 grid((ntiles + per - 1) / per, 2 * B);
-  std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
-  if (h->prof) {
-    if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
-    else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
-    hipEventRecord(evp.first, h->stream);
-  }
+  {
+  ProfScope prof_scope(h, PK_BACKBONE);
   const int sc1 = h->layers[st.first].cout, sc2 = st.n == 3 ? h->layers[st.first + 1].cout : 0;
   if (h->infer_split && st.n == 3 && sc1 <= 16 * kSplitKB1 && sc2 <= 16 * kSplitKB2) {
     // split-bf16 backbone (opt-in): same tiling, three bf16 MFMAs per fp32 product
@@ -499,7 +495,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
     h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128;
   } else { hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED; }
-  if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
+  }
   HIP_TRY(h, hipGetLastError());
 #ifdef ALIGNNET_KSTAMP
   if (st.first == h->emb_conv.first && getenv("ALIGNNET_KSTAMP_PRINT")) {
@@ -544,12 +540,8 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
     attr_set = true;
   }
   const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
-  std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
-  if (h->prof) {
-    if (!h->prof_pool.empty()) { evp = h->prof_pool.back(); h->prof_pool.pop_back(); }
-    else { hipEventCreate(&evp.first); hipEventCreate(&evp.second); }
-    hipEventRecord(evp.first, h->stream);
-  }
+  {
+  ProfScope prof_scope(h, PK_BACKBONE);
   {
     const int dca = h->layers[st.first].cout, dcb = st.n == 3 ? h->layers[st.first + 1].cout : 0;
     if (h->infer_split && st.n == 3 && dca <= 16 * kSplitKB1 && dcb <= 128) {
@@ -595,7 +587,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       }
     }
   }
-  if (h->prof) { hipEventRecord(evp.second, h->stream); h->prof_pending.push_back(evp); }
+  }
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -646,8 +638,10 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   // pool1 | pool2 | emb are carved back to back: one memset arms all three atomicMax targets
   HIP_TRY(h, hipMemsetAsync(w.pool1, 0, (size_t)((char*)w.hid_a - (char*)w.pool1), h->stream));
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
-  if (dg)   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
+  if (dg) {   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
+    ProfScope prof_scope(h, PK_KNN);
     hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
+  }
   // stage 1 (tp8.py:108-109)
   if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
   if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B)) return 1;
@@ -674,8 +668,11 @@ static int drain_profile(alignnet_handle* h)
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (auto& pr : h->prof_pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { h->prof_backbone_ms += ms; h->prof_backbone_launches++; }
-    h->prof_pool.push_back(pr);
+    if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+      h->prof_ms[pr.id] += ms; h->prof_launches[pr.id]++;
+      if (pr.id == PK_BACKBONE) { h->prof_backbone_ms += ms; h->prof_backbone_launches++; }
+    }
+    h->prof_pool.push_back({pr.a, pr.b});
   }
   h->prof_pending.clear();
   return 0;
@@ -734,6 +731,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   if (!h || !key) return 1;
   const std::string k(key);
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
+  if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
   if (k == "infer_matmul_bf16x3") {
     if (h->infer_split != (value != 0)) h->folded = false;   // the split weight images are packed by the next eval forward
     h->infer_split = value != 0;
@@ -748,6 +746,9 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   const std::string k(key);
   if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
   if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
+  if (k == "allreduce_overlap") { *value = h->comm_overlap ? 1 : 0; return 0; }
+  if (k == "comm_world") { *value = h->comm ? h->comm_world : 0; return 0; }
+  if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }
   if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
   if (k == "last_train_kernel") { *value = h->last_train_kernel; return 0; }
   return fail(h, "alignnet_get_option: unknown key '" + k + "'");
@@ -772,8 +773,24 @@ extern "C" int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, in
   if (backbone_ms) *backbone_ms = h->prof_backbone_ms;
   if (backbone_launches) *backbone_launches = h->prof_backbone_launches;
   if (total_ms) *total_ms = h->prof_total_ms;
-  if (reset) { h->prof_backbone_ms = 0; h->prof_total_ms = 0; h->prof_backbone_launches = 0; }
+  if (reset) {
+    h->prof_backbone_ms = 0; h->prof_total_ms = 0; h->prof_backbone_launches = 0;
+    for (int i = 0; i < PK_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_launches[i] = 0; }
+  }
   return 0;
+}
+
+extern "C" int alignnet_profile_read_kernel(alignnet_handle* h, const char* name, double* ms, int64_t* launches)
+{
+  if (!h || !name) return 1;
+  if (drain_profile(h)) return 1;
+  for (int i = 0; i < PK_COUNT; ++i)
+    if (std::strcmp(name, kProfKernelNames[i]) == 0) {
+      if (ms) *ms = h->prof_ms[i];
+      if (launches) *launches = h->prof_launches[i];
+      return 0;
+    }
+  return fail(h, std::string("alignnet_profile_read_kernel: unknown kernel '") + name + "'");
 }
 
 // ---------------------------------------------------------------------------------

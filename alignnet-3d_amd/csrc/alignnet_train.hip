@@ -409,8 +409,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
+  { ProfScope prof_scope(h, PK_DG_FWD);
     if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+  }
     if (d.stamps) {
       long long sv[11];
       hipStreamSynchronize(h->stream);
@@ -429,9 +431,13 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     finish(1, C2, 1, ecount, 1);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
     // point conv on the stored p
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  }
+    { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
+    }
     finish(2, C3, 2, count);
     launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
   } else {
@@ -457,18 +463,22 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                        h->train_bf16 ? 1 : 0, w->stat_part);
     finish(1, C2, 1, count, 1);
   } else {
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE2);
   if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  }
   finish(1, C2, 4, count);
   }
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     if (std_w && !getenv("ALIGNNET_P3BF16_GENERIC")) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+  }
     if (a.stamps) {
       long long sv[8];
       hipStreamSynchronize(h->stream);
@@ -477,11 +487,15 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                    sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
     }
   } else {
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  }
+    { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     if (!a.gram_inline)
       hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
                          w->gram_part);
+    }
   }
   finish(2, C3, 2, count);
   launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
@@ -680,6 +694,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra;
   b2.h2_given = S.h2;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  { ProfScope prof_scope(h, PK_TRAIN_B2);
   if (dg && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (dg) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (std_w && !b2_accum && h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
@@ -688,6 +703,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   else if (h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  }
   if (b2.stamps) {
     long long st[11];
     hipStreamSynchronize(h->stream);
@@ -737,10 +753,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2);
+  { ProfScope prof_scope(h, PK_DG_BWD_EDGE);
     if (C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128>), eg, eb, el, h->stream, e);
     else if (C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64>), eg, eb, el, h->stream, e);
     else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
     else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
+  }
     if (e.stamps) {
       long long st[19];
       hipStreamSynchronize(h->stream);
@@ -775,9 +793,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;
+  { ProfScope prof_scope(h, PK_TRAIN_B1);
   if (pdy && std_w) hipLaunchKernelGGL((train_bwd_b1<64, 128, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   else if (pdy) hipLaunchKernelGGL((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   else hipLaunchKernelGGL(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  }
   if (acc_in_b1) layer2_weight_grad();
   if (pdy) {
     // first layer from the reduced quantities (kernels_train_dgcnn.h, D = 3)
@@ -812,8 +832,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
 // ---------------------------------------------------------------------------------
 // full forward + backward on device buffers
 // ---------------------------------------------------------------------------------
+static int comm_bucket(alignnet_handle* h, int stage);   // defined with the RCCL section below
+static int comm_join(alignnet_handle* h);
+
 static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, const float* const lab[6], int B, const float* u_dev,
-                          int do_backward, int update_ema)
+                          int do_backward, int update_ema, int comm_overlap = 0)
 {
   TrainWS* w = tws(h);
   const int N = h->cfg.num_points, nb = h->cfg.num_bins, nb2 = 2 * nb, B2 = 2 * B;
@@ -829,8 +852,10 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
-  if (h->cfg.backbone == 1)   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
+  if (h->cfg.backbone == 1) {   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
+    ProfScope prof_scope(h, PK_KNN);
     hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn);
+  }
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 0, w->st[0].pooled, w->st[0].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
@@ -858,19 +883,23 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
 
   // ---- backward ----
   const int CE = h->layers[h->emb_conv.first + 2].cout;
+  h->comm_buckets = 0;
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
+  if (comm_overlap && comm_bucket(h, 2)) return 1;   // the stage-3 segment (embedding convs + pair head: 64 % of the vector) is final
   hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
                      B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
   hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
   const int C2l = h->layers[h->s2_conv.first + 2].cout, C1l = h->layers[h->s1_conv.first + 2].cout;
   if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
+  if (comm_overlap && comm_bucket(h, 1)) return 1;
   hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
   // s1c = o1 + center_mean  ->  d_o1 = d_s1c
   HIP_TRY(h, hipMemcpyAsync(w->d_o[0], w->d_s1c, (size_t)B2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
+  if (comm_overlap && comm_bucket(h, 0)) return 1;
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -910,6 +939,7 @@ extern "C" int alignnet_apply_gradients(alignnet_handle* h, float grad_scale)
   alignnet_get_state(h, &st);   // schedules use the pre-increment step (train.py:145-150,172)
   const size_t n = h->n_trainable;
   const dim3 grid((unsigned)((n + 255) / 256));
+  ProfScope prof_scope(h, PK_OPTIMIZER);
   if (h->cfg.optimizer == 0) {
     const double t = (double)(h->step + 1);
     const float lr_t = (float)((double)st.learning_rate * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
@@ -975,10 +1005,9 @@ static int fetch_result(alignnet_handle* h, alignnet_step_result* result, const 
   return 0;
 }
 
-extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
-                                               int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+static int train_fb_host(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
+                         const float* dropout_u, int comm_overlap)
 {
-  if (!h) return 1;
   if (!pcs1 || !pcs2 || !labels) return fail(h, "alignnet_train_forward_backward: null argument");
   if (B < 2) return fail(h, "training needs B >= 2 (batch statistics)");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -987,25 +1016,40 @@ extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float* 
   TrainWS* w = tws(h);
   const float* u_dev = nullptr;
   if (stage_inputs(h, pcs1, pcs2, labels, B, dropout_u, &u_dev)) return 1;
+  return fwd_bwd_device(h, w->d_pcs[0], w->d_pcs[1], w->labels, B, u_dev, 1, 1, comm_overlap);
+}
+
+extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
+                                               int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+{
+  if (!h) return 1;
   alignnet_state pre;
   alignnet_get_state(h, &pre);
-  if (fwd_bwd_device(h, w->d_pcs[0], w->d_pcs[1], w->labels, B, u_dev, 1, 1)) return 1;
+  if (train_fb_host(h, pcs1, pcs2, labels, B, dropout_u, 0)) return 1;
   return fetch_result(h, result, out, B, pre);
+}
+
+// all-reduce (bucketed next to the backward, or one call after it) + optimiser: the tail of both train_step entry points
+static int reduce_and_apply(alignnet_handle* h, int overlapped)
+{
+  float scale = 1.f;
+  if (h->comm) {
+    ProfScope prof_scope(h, PK_ALLREDUCE);   // what the compute stream waits for: the part of the all-reduce the backward did not hide
+    if (overlapped ? comm_join(h) : alignnet_comm_allreduce_grads(h)) return 1;
+    scale = 1.f / (float)h->comm_world;
+  }
+  return alignnet_apply_gradients(h, scale);
 }
 
 extern "C" int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
                                    const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
 {
   if (!h) return 1;
-  if (alignnet_train_forward_backward(h, pcs1, pcs2, labels, B, dropout_u, nullptr, nullptr)) return 1;
   alignnet_state pre;
   alignnet_get_state(h, &pre);
-  float scale = 1.f;
-  if (h->comm) {
-    if (alignnet_comm_allreduce_grads(h)) return 1;
-    scale = 1.f / (float)h->comm_world;
-  }
-  if (alignnet_apply_gradients(h, scale)) return 1;
+  const int overlap = h->comm && h->comm_overlap;
+  if (train_fb_host(h, pcs1, pcs2, labels, B, dropout_u, overlap)) return 1;
+  if (reduce_and_apply(h, overlap)) return 1;
   return fetch_result(h, result, out, B, pre);
 }
 
@@ -1022,13 +1066,9 @@ extern "C" int alignnet_train_step_device(alignnet_handle* h, const float* d_pcs
                          d_labels->pc2_angles};
   alignnet_state pre;
   alignnet_get_state(h, &pre);
-  if (fwd_bwd_device(h, d_pcs1, d_pcs2, lab, B, nullptr, 1, 1)) return 1;
-  float scale = 1.f;
-  if (h->comm) {
-    if (alignnet_comm_allreduce_grads(h)) return 1;
-    scale = 1.f / (float)h->comm_world;
-  }
-  if (alignnet_apply_gradients(h, scale)) return 1;
+  const int overlap = h->comm && h->comm_overlap;
+  if (fwd_bwd_device(h, d_pcs1, d_pcs2, lab, B, nullptr, 1, 1, overlap)) return 1;
+  if (reduce_and_apply(h, overlap)) return 1;
   if (result) return fetch_result(h, result, nullptr, B, pre);
   return 0;
 }
@@ -1160,7 +1200,42 @@ extern "C" int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t worl
 
 extern "C" void alignnet_comm_free(alignnet_handle* h)
 {
-  if (h && h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  if (!h) return;
+  if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
+  if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  for (auto& e : h->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
+  if (h->comm_stream) { hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+}
+
+// Bucket `stage` of the gradient all-reduce: the flat gradient is laid out [stage 1 | stage 2 | stage 3] (graph-construction order,
+// alignnet_api.hip), and the backward runs stage 3 -> 2 -> 1, writing only that stage's segment.  As soon as a segment is final
+// the side stream waits for it and all-reduces it over xGMI while the compute stream goes on with the next stage's backward.
+static int comm_bucket(alignnet_handle* h, int stage)
+{
+  if (!h->comm) return 0;
+  TrainWS* w = tws(h);
+  if (!h->comm_stream) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    for (auto& e : h->comm_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const size_t lo = h->params[h->layers[conv_of(h, stage).first].p_w].offset;
+  const size_t hi = stage == 2 ? h->n_trainable : h->params[h->layers[conv_of(h, stage + 1).first].p_w].offset;
+  if (hi <= lo || hi > h->n_trainable) return fail(h, "comm_bucket: gradient segments are not in stage order");
+  HIP_TRY(h, hipEventRecord(h->comm_ev[stage], h->stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ev[stage], 0));
+  const int rc = g_rccl.AllReduce(w->grad + lo, w->grad + lo, hi - lo, 7, 0, h->comm, h->comm_stream);   // ncclFloat = 7, ncclSum = 0
+  if (rc != 0) return fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  h->comm_buckets++;
+  return 0;
+}
+
+// The optimiser (compute stream) must not start before the last bucket has landed.
+static int comm_join(alignnet_handle* h)
+{
+  if (!h->comm || !h->comm_stream || h->comm_buckets != 3) return fail(h, "comm_join: the three gradient buckets were not issued");
+  HIP_TRY(h, hipEventRecord(h->comm_ev[3], h->comm_stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_ev[3], 0));
+  return 0;
 }
 
 extern "C" int alignnet_comm_allreduce_grads(alignnet_handle* h)
@@ -1223,7 +1298,7 @@ extern "C" int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_
   char magic[8]; int64_t step = 0; int32_t nvars = 0;
   bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "ALN3CKP1", 8) == 0 && std::fread(&step, 8, 1, f) == 1 &&
             std::fread(&nvars, 4, 1, f) == 1;
-  if (!ok) { std::fclose(f); return fail(h, "alignnet_load: not an ALN3CKP1 checkpoint"); }
+  if (!ok || nvars < 0 || nvars > 1 << 20) { std::fclose(f); return fail(h, "alignnet_load: not an ALN3CKP1 checkpoint"); }
   if (ensure_train_ws(h, 0)) { std::fclose(f); return 1; }
   TrainWS* w = tws(h);
   std::vector<float> host(h->n_total), m(h->n_trainable, 0.f), v(h->n_trainable, 0.f);
@@ -1236,6 +1311,11 @@ extern "C" int alignnet_load(alignnet_handle* h, const char* path, int32_t skip_
     std::string name(ok ? len : 0, '\0');
     ok = ok && std::fread(&name[0], 1, len, f) == (size_t)len && std::fread(dims, 4, 3, f) == 3;
     if (!ok) break;
+    // a corrupt header must not become a bad_alloc / abort across the C ABI: dims are checked against the graph before allocating
+    if (dims[0] <= 0 || dims[1] <= 0 || (int64_t)dims[0] * dims[1] > (int64_t)h->n_total || (dims[2] != 0 && dims[2] != 1)) {
+      std::fclose(f);
+      return fail(h, "alignnet_load: corrupt header for variable '" + name + "' (dims " + std::to_string(dims[0]) + " x " + std::to_string(dims[1]) + ")");
+    }
     const size_t cnt = (size_t)dims[0] * dims[1];
     std::vector<float> buf(cnt), bm, bv;
     ok = std::fread(buf.data(), 4, cnt, f) == cnt;

@@ -32,6 +32,13 @@ struct Layer {
 
 struct Stack { int first, n; };   // range of layers
 
+// Kernels whose launches are bracketed with HIP events on the handle's stream while profiling is enabled
+// (alignnet_profile_enable; read back by name through alignnet_profile_read_kernel -- bench.py's roofline legs).
+enum ProfKernel { PK_BACKBONE = 0, PK_KNN, PK_TRAIN_PHASE2, PK_TRAIN_PHASE3, PK_TRAIN_GRAM, PK_TRAIN_B2, PK_TRAIN_B1, PK_DG_FWD, PK_DG_BWD_EDGE,
+                  PK_ALLREDUCE, PK_OPTIMIZER, PK_COUNT };
+static const char* const kProfKernelNames[PK_COUNT] = {"backbone", "knn", "train_fwd_phase2", "train_fwd_phase3", "train_gram_h2", "train_bwd_b2",
+                                                       "train_bwd_b1", "dg_train_fwd", "dg_train_bwd_edge", "allreduce", "optimizer"};
+
 struct Workspace {
   int cap = 0;                     // pairs
   float* d_pcs[2] = {nullptr, nullptr};
@@ -81,12 +88,43 @@ struct alignnet_handle {
   hipEvent_t ev[2] = {nullptr, nullptr};
   double prof_backbone_ms = 0, prof_total_ms = 0;
   int64_t prof_backbone_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  struct ProfEv { int id; hipEvent_t a, b; };
+  std::vector<ProfEv> prof_pending;                                  // recorded, not yet read back
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;          // event pairs ready for reuse
+  double prof_ms[alignnet::PK_COUNT] = {0};                          // accumulated HIP-event time per timed kernel (PK_*)
+  int64_t prof_launches[alignnet::PK_COUNT] = {0};
   // training / multi-GPU state (alignnet_train.hip)
   void* train_ws = nullptr;
   void* dataset_ws = nullptr;      // HBM-resident dataset + batch buffers (alignnet_dataset.hip)
   void* comm = nullptr;
   int comm_world = 1, comm_rank = 0;
+  // gradient all-reduce in three buckets (stage 3 | stage 2 | stage 1 segment of the flat gradient) on a side stream, each issued as
+  // soon as that stage's backward has produced its segment; the optimiser waits for the last one (alignnet_train.hip: comm_bucket)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [stage] = segment ready on the compute stream; [3] = buckets done
+  bool comm_overlap = true;        // alignnet_set_option("allreduce_overlap")
+  int comm_buckets = 0;            // bucket all-reduces issued by the last training step (0: one all-reduce after the backward)
   mutable std::string err;
 };
+
+namespace alignnet {
+// Brackets everything launched on h->stream during its lifetime with one event pair (only while h->prof is set).
+struct ProfScope {
+  alignnet_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(alignnet_handle* h_, int id_) : h(h_), id(id_)
+  {
+    if (!h->prof) return;
+    if (!h->prof_pool.empty()) { a = h->prof_pool.back().first; b = h->prof_pool.back().second; h->prof_pool.pop_back(); }
+    else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    hipEventRecord(a, h->stream);
+  }
+  ~ProfScope()
+  {
+    if (!a) return;
+    hipEventRecord(b, h->stream);
+    h->prof_pending.push_back(alignnet_handle::ProfEv{id, a, b});
+  }
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+};
+}  // namespace alignnet

@@ -609,6 +609,7 @@ static __global__ __launch_bounds__(256) void stage2_finish_kernel(const float* 
     const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(cls, off);
     if (ob > best || (ob == best && oi < cls)) { best = ob; cls = oi; }
   }
+  if (cls >= nb) cls = 0;   // every class logit NaN (or -inf): tf.argmax returns 0 and the run continues with NaNs, it does not fault
   if (ol) for (int i = lane; i < 2 * nb; i += 64) ol[(size_t)b * 2 * nb + i] = lg[i];
   if (lane == 0) {
     const float pi = 3.14159274101257324f;   // np.float32(np.pi), tf.constant(np.pi)

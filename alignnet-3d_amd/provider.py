@@ -58,15 +58,25 @@ def load_from_separate_files(idx, dont_load_pointclouds=False):
 _packed = None
 
 
-def use_packed_cache(cache_dir=None):
-    """Switch load_batch to the packed cache (alignnet3d/packed.py); builds it on first use.  Same tuple, same
-    np.random call order, bit-identical batches."""
+def use_packed_cache(cache_dir=None, dist=None):
+    """Switch load_batch to the packed cache (alignnet3d/packed.py).  Same tuple, same np.random call order, bit-identical
+    batches.  The cache is (re)built when it is missing or its manifest no longer matches the dataset (example count, newest
+    modification time) -- by rank 0 only in a multi-process run (RANK / `dist`), the other ranks wait at a barrier."""
     global _packed
     import os
-    from alignnet3d.packed import PackedDataset, pack_dataset
+    from alignnet3d.packed import PackedDataset, pack_dataset, cache_is_current
     cache_dir = cache_dir or os.path.join(cfg.data.basepath, "packed_cache")
-    if not os.path.exists(os.path.join(cache_dir, "ids.npy")):
+    rank = int(os.environ.get("RANK", "0"))
+    if dist is None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as td
+        dist = td if td.is_initialized() else None
+    if rank == 0 and not cache_is_current(cfg.data.basepath, cache_dir):
         pack_dataset(cfg.data.basepath, cache_dir)
+    if dist is not None:
+        dist.barrier()
+    elif rank != 0:
+        raise RuntimeError("use_packed_cache: a multi-process run needs an initialised process group (rank 0 builds the cache, "
+                           "the others wait for it)")
     _packed = PackedDataset(cache_dir)
     return _packed
 

@@ -139,23 +139,32 @@ class Run:
     def train_one_epoch(self, epoch):
         B = cfg.training.batch_size
         idxs = copy.deepcopy(self.train_idx)
-        np.random.shuffle(idxs)
+        np.random.shuffle(idxs)                      # train.py:338 (np.random's stream, single process: as the reference)
+        if self.dist is not None:
+            # one permutation for all ranks (rank 0's): each global batch is then a partition of B distinct examples and an
+            # epoch is one pass over the training set, as in the reference; every rank loads only its own slice
+            idxs = parallel.broadcast_object(self.dist, idxs)
         loss_sum = 0.0
         lo, hi = parallel.shard_range(B, self.rank, self.world)
         for b in range(len(idxs) // B):
+            mine = idxs[b * B + lo:b * B + hi]
             if self.device_data is not None:
-                rows = self.device_data.rows_of(idxs[b * B:(b + 1) * B])[lo:hi]
+                rows = self.device_data.rows_of(mine)
                 res = self.engine.train_step_rows(rows, seed=int(np.random.randint(0, 2 ** 62)))   # jitter 0.01 / 0.05 (provider.py:60)
                 loss_sum += res["loss"]
                 continue
-            batch = provider.load_batch(idxs[b * B:(b + 1) * B])
+            batch = provider.load_batch(mine, override_batch_size=hi - lo)
             pcs1 = provider.jitter_point_cloud(batch[0])
             pcs2 = provider.jitter_point_cloud(batch[1])
-            labels = dict(zip(("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"),
-                              [a[lo:hi] for a in batch[2:]]))
-            res = self.engine.train_step(pcs1[lo:hi], pcs2[lo:hi], labels)
+            labels = dict(zip(("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"), batch[2:]))
+            res = self.engine.train_step(pcs1, pcs2, labels)
             loss_sum += res["loss"]
         n = max(len(idxs) // B, 1)
+        if self.dist is not None:
+            # local-BN data parallelism: every rank's EMA shadows saw only its shard's statistics; average them so
+            # that all ranks evaluate (and rank 0 checkpoints) the same model, and report the mean of the ranks' shard losses
+            parallel.average_ema_shadows(self.engine, self.dist)
+            loss_sum = parallel.mean_scalar(self.dist, loss_sum)
         logger.info("train mean loss: %f" % (loss_sum / float(n)))
 
     # ---- train.py:386-545 -------------------------------------------------------------------------------------
@@ -205,6 +214,8 @@ class Run:
                 labels = dict(zip(("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles"),
                                   [a[:n] for a in batch[2:]]))
                 loss_sum += self.engine.eval_loss(labels, n)[0]
+            # world > 1: the loss couples the rows of a batch ([B,B] terms, tp8.py:279,327), so a shard's loss is not the batch's;
+            # it is not computed and is logged as n/a below rather than as a number that looks real
             if self.dist is not None:
                 counts = [parallel.shard_range(n, r, self.world) for r in range(self.world)]
                 counts = [c[1] - c[0] for c in counts]
@@ -248,19 +259,21 @@ class Run:
         if self.rank == 0:
             for k, v in store.items():
                 np.save("%s/%s.npy" % (eval_dir, k), v)
-            logger.info("val mean loss: %f" % mean_loss)
+            logger.info("val mean loss: %f" % mean_loss if self.world == 1 else "val mean loss: n/a (batch split over %d ranks)" % self.world)
         return mean_time
 
     # ---- train.py:187-332 -------------------------------------------------------------------------------------
-    def train(self, eval_only=False, eval_epoch=None, do_timings=False, override_batch_size=None):
+    def train(self, eval_only=False, eval_epoch=None, eval_only_model_to_load=None, do_timings=False, override_batch_size=None):
         start_epoch = 0
         if eval_only:
+            model_to_load = cfg.logging.logdir if eval_only_model_to_load is None else eval_only_model_to_load   # train.py:247-249
             if not self.flags.use_old_results and not do_timings:
-                base = os.path.join(cfg.logging.logdir, "model-%s" % eval_epoch)
+                base = os.path.join(model_to_load, "model-%s" % eval_epoch)
                 assert self.restore(base), base + "{.aln3,.index}"
-                step = self.engine.state()["step"]
-                assert step % self.batches_per_epoch == 0
-                assert step // self.batches_per_epoch - 1 == int(eval_epoch)
+                if eval_only_model_to_load is None:   # a held-out model was trained on another split: no epoch check (train.py:255)
+                    step = self.engine.state()["step"]
+                    assert step % self.batches_per_epoch == 0
+                    assert step // self.batches_per_epoch - 1 == int(eval_epoch)
             start_epoch = int(eval_epoch)
             logger.info("Evaluating at epoch %d" % start_epoch)
         else:
@@ -313,8 +326,11 @@ def main(argv=None):
             for bs in [32]:
                 cfg.training.batch_size = bs
                 Run(flags).train(eval_only=True, eval_epoch=flags.eval_epoch, do_timings=True, override_batch_size=bs)
-        elif mode in ("icp", "held"):
-            raise NotImplementedError("evaluation.special.mode=%s relies on the reference's ICP / held-out tooling (out of scope)" % mode)
+        elif mode == "held":         # train.py:553-554: eval_only with the checkpoint of another run's logdir
+            Run(flags).train(eval_only=True, eval_epoch=flags.eval_epoch, eval_only_model_to_load=cfg.evaluation.special.held.model)
+        elif mode == "icp":
+            raise NotImplementedError("evaluation.special.mode=icp runs the reference's CPU ICP baselines (icp.py:80-330: global registration, "
+                                      "Go-ICP): out of scope (SURVEY 2); --refineICP is the supported ICP path")
         else:
             assert False
     elif flags.operation == "train":

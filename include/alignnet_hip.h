@@ -240,9 +240,14 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
  *   gfx950).  Outputs stay within the 1e-4 parity bar (measured 3e-6 against the fp64 oracle, like the exact path).
  *   Also covers the DGCNN branch with widths [<= 64, <= 128, C3]; other backbone shapes keep the exact-fp32 kernels.
+ * "allreduce_overlap" (0/1, default 1): data-parallel training steps (alignnet_train_step*, communicator initialised) all-reduce the
+ *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient, each issued as soon
+ *   as that stage's backward has written it -- so that only the last (smallest) bucket is exposed; 0 = one all-reduce of the whole
+ *   vector after the backward.  Same sums either way.
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped
  * widths 64 / 128 dispatch to kernels with the widths compiled in):
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
+ * "comm_world": number of ranks of the RCCL communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
  * "last_train_kernel": bit mask of the most recent training step -- 1 = compile-time widths (64, 128), 2 = bf16 operands,
  *   4 = dgcnn backbone.
  * Unknown keys fail. */
@@ -260,6 +265,11 @@ int alignnet_set_option(alignnet_handle* h, const char* key, int64_t value);
 int alignnet_get_option(alignnet_handle* h, const char* key, int64_t* value);
 int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, int64_t* backbone_launches,
                           double* total_ms, int32_t reset);
+/* HIP-event time (ms, summed) and launch count of one timed kernel since the last reset (alignnet_profile_read(..., reset = 1)), measured
+ * on the stream it is launched on while profiling is enabled.  name: "backbone" (eval-mode fused backbone), "knn",
+ * "train_fwd_phase2", "train_fwd_phase3", "train_gram_h2", "train_bwd_b2", "train_bwd_b1", "dg_train_fwd", "dg_train_bwd_edge",
+ * "allreduce" (what the compute stream waits for), "optimizer". */
+int alignnet_profile_read_kernel(alignnet_handle* h, const char* name, double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

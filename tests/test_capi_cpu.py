@@ -55,3 +55,18 @@ def test_config_marshalling():
     bad["model"]["backbone"] = "voxel"
     with pytest.raises(AssertionError):
         make_c_config(bad)
+
+
+def test_unbuilt_loss_variants_are_rejected():
+    """config.py accepts training.loss.loss = 'p2p' and loss.options.soft_angle_classes (models/tp8.py:253-274,357-407); the engine
+    only builds the 'separate' hard-class loss, so marshalling such a config must fail instead of training another loss silently."""
+    from alignnet3d.engine import make_c_config, default_model_config
+    cfg = default_model_config()
+    cfg["training"]["loss"] = {"loss": "separate", "options": {"soft_angle_classes": False}}
+    make_c_config(cfg)
+    cfg["training"]["loss"]["loss"] = "p2p"
+    with pytest.raises(AssertionError, match="separate"):
+        make_c_config(cfg)
+    cfg["training"]["loss"] = {"loss": "separate", "options": {"soft_angle_classes": True}}
+    with pytest.raises(AssertionError, match="soft_angle_classes"):
+        make_c_config(cfg)

@@ -71,6 +71,17 @@ def test_train_py_end_to_end(gpu_required, tmp_path):
     json.dump(user, open(cfgt, "w"))
     out3 = _run(["eval_only", "--config", str(cfgt), "--eval_epoch", "0"], str(tmp_path))
     assert out3.count("Timing bs=32:") == 10
+    # held mode (reference train.py:553-554, 247-255): eval_only with the checkpoint of ANOTHER run's logdir, no step/epoch check
+    # (a different batch size makes batches_per_epoch differ, which the plain eval_only assertion would reject)
+    user["evaluation"] = {"special": {"mode": "held", "held": {"model": str(logdir)}}}
+    user["training"]["batch_size"] = 4
+    cfgh = tmp_path / "TinyHeld.json"
+    json.dump(user, open(cfgh, "w"))
+    out4 = _run(["eval_only", "--config", str(cfgh), "--eval_epoch", "1"], str(tmp_path))
+    assert "Evaluating at epoch 1" in out4
+    held = np.load(tmp_path / "logs" / "TinyHeld" / "val" / "eval000001" / "pred_translations.npy")
+    np.testing.assert_allclose(held, np.load(ev / "pred_translations.npy"), rtol=0, atol=0.5)   # same model (clouds are re-sampled per load)
+    assert np.all(np.isfinite(held)) and held.shape == (8, 3)
 
 
 def test_train_py_dgcnn_backbone(gpu_required, tmp_path):
@@ -109,6 +120,17 @@ def test_rccl_world1_and_device_entry_points(gpu_required):
     assert a["loss"] == b["loss"] and a["step"] == b["step"] == 1
     for name in ("siamese/embedding/conv3/weights", "fc3/biases"):
         np.testing.assert_array_equal(eng.get_variable(name), ref.get_variable(name))
+    # default: three bucket all-reduces on the side stream (stage 3 / 2 / 1 segments) issued next to the backward
+    assert eng.get_option("comm_world") == 1 and eng.get_option("allreduce_overlap") == 1 and eng.get_option("comm_buckets") == 3
+    assert ref.get_option("comm_world") == 0 and ref.get_option("comm_buckets") == 0
+    # one all-reduce after the backward: same numbers
+    eng.set_option("allreduce_overlap", 0)
+    a = eng.train_step(d["pcs1"], d["pcs2"], d, u)
+    b = ref.train_step(d["pcs1"], d["pcs2"], d, u)
+    assert eng.get_option("comm_buckets") == 0 and a["loss"] == b["loss"] and a["step"] == 2
+    for name, _, _ in eng.variables():
+        np.testing.assert_array_equal(eng.get_variable(name), ref.get_variable(name), err_msg=name)
+    eng.set_option("allreduce_overlap", 1)
     # device-resident inputs: same numbers as the host-pointer entry points
     t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).cuda() for k in d}
     outs = {k: torch.empty(8, 24 if "logits" in k else 3, device="cuda") for k in alignnet3d.OUTPUT_NAMES}
@@ -119,7 +141,76 @@ def test_rccl_world1_and_device_entry_points(gpu_required):
         np.testing.assert_array_equal(outs[k].cpu().numpy(), host[k])
     labels = {k: t[k].data_ptr() for k in ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
     r = eng.train_step_device(t["pcs1"].data_ptr(), t["pcs2"].data_ptr(), labels, 8, want_result=True)
-    assert r["step"] == 2 and np.isfinite(r["loss"])
+    assert r["step"] == 3 and np.isfinite(r["loss"]) and eng.get_option("comm_buckets") == 3
     ptr, n = eng.grad_buffer()
     assert ptr and n == sum(s[0] * s[1] for _, s, tr in eng.variables() if tr)
     eng.close(); ref.close()
+
+
+RCCL2_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path[:0] = [%(root)r, %(pkg)r]
+import torch, torch.distributed as dist
+import alignnet3d
+from alignnet3d import parallel
+from oracle import alignnet_ref as R
+from tests.helpers import small_cfg, oracle_params
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+cfg = small_cfg(N=128)
+cfg["training"]["batch_size"] = 16
+spec, P32 = oracle_params(cfg)
+d = R.synth_pairs(16, 128, dtype=np.float32)
+lo, hi = parallel.shard_range(16, rank, world)
+shard = {k: v[lo:hi] for k, v in d.items()}
+u = [np.full((hi - lo, 32), 0.9, np.float32)] * 5
+out = {}
+for overlap in (1, 0):
+    eng = alignnet3d.Engine(cfg, device=rank)
+    eng.set_variables(P32)
+    parallel.init_comm(eng, dist)
+    eng.set_option("allreduce_overlap", overlap)
+    assert eng.get_option("comm_world") == world
+    # reference for this rank: local gradient of every rank, summed on the host through torch.distributed, scaled by 1/world
+    eng.train_forward_backward(shard["pcs1"], shard["pcs2"], shard, u)
+    names = [n for n, _, t in eng.variables() if t]
+    g = torch.from_numpy(np.concatenate([eng.get_gradient(n).ravel() for n in names])).cuda()
+    dist.all_reduce(g)
+    eng.set_variables(P32)   # the EMA shadows moved; same starting point for the real step
+    r = eng.train_step(shard["pcs1"], shard["pcs2"], shard, u)
+    assert eng.get_option("comm_buckets") == (3 if overlap else 0)
+    w1 = np.concatenate([eng.get_variable(n).ravel() for n in names])
+    out[overlap] = w1
+    # momentum-free check of the summed gradient: first Adam step moves by lr * sign(g) wherever |g| is not tiny
+    gs = (g / world).cpu().numpy()
+    w0 = np.concatenate([np.asarray(P32[n], np.float32).ravel() for n in names])
+    big = np.abs(gs) > 1e-3 * np.abs(gs).max()
+    assert np.all(np.sign(w0[big] - w1[big]) == np.sign(gs[big])), "update direction does not follow the all-reduced gradient"
+    # every rank must hold identical parameters after the step
+    t = torch.from_numpy(w1).cuda()
+    lst = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(lst, t)
+    assert all(torch.equal(lst[0], x) for x in lst), "ranks diverged"
+    eng.close()
+np.testing.assert_array_equal(out[0], out[1])   # bucketed and single all-reduce give the same sums
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL2_OK rank", rank)
+"""
+
+
+def test_rccl_two_ranks_data_parallel_step(gpu_required, tmp_path):
+    """Two processes, two GPUs, the library's own RCCL communicator over xGMI: the data-parallel training step (local-BN shards,
+    sum all-reduce, 1/world scale, identical Adam) in both all-reduce modes.  Needs >= 2 visible GPUs; the pool's test boxes
+    have one, where this test skips -- it exists so that any 2+-GPU run of the suite exercises RCCL in the data path."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    script = tmp_path / "rccl2_worker.py"
+    script.write_text(RCCL2_WORKER % {"root": ROOT, "pkg": PKG})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.count("RCCL2_OK") == 2, r.stdout[-2000:] + r.stderr[-4000:]

@@ -173,14 +173,28 @@ def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
     return cfg, spec, P32, d, du
 
 
-def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4):
+def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4, fp32_conditioning=False):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
-    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`)."""
+    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`).
+    fp32_conditioning: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024 candidates each and
+    normalises 256-row batches of nearly equal pooled features; the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2 (gradients)
+    and 2e-4 (predictions) away from its fp64 evaluation.  The bars then become: HIP gradient error <= the fp32 oracle's own
+    worst relative error, HIP prediction error <= max(pred_tol, the fp32 oracle's own) -- i.e. the engine must be at least as
+    close to the exact result as a plain fp32 evaluation of the reference arithmetic is."""
     from tests import test_train_gpu as TT
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
     ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True)
+    if fp32_conditioning:
+        ep32, _, g32, _ = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True, dt=np.float32)
+        gs = max(float(np.abs(v).max()) for v in grads.values())
+        skip = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
+        rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs)
+                    for k in grads if k not in skip)
+        pred32 = max(float(np.abs(ep32[k] - ep_ref[k]).max()) for k in ep_ref)
+        print("fp32 oracle vs fp64 oracle: worst relative gradient error %.2e, worst prediction error %.2e" % (rel32, pred32))
+        tol, pred_tol = max(tol, rel32), max(pred_tol, pred32)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     assert eng.get_option("last_train_kernel") == expect_kernel
     worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
@@ -216,7 +230,7 @@ def test_train_fp32_full_size_matches_autograd(gpu_required):
     """BASELINE.json configs[2]'s shape in fp32: SynthCars widths, 256 pairs x 1024 points -- the kernel instantiations with the
     widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256."""
     cfg, spec, P32, d, du = _train_setup()
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True)
 
 
 def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):

@@ -29,8 +29,21 @@ def _free_port():
 
 
 class FakeEngine:
-    """Records what parallel.init_comm hands to the engine."""
+    """Records what parallel.init_comm hands to the engine; holds a few variables for average_ema_shadows."""
     calls = []
+
+    def __init__(self, rank=0):
+        self.vars = {"w": np.full((2, 3), 7.0 + rank, np.float32), "a/bn/moving_mean": np.full(4, 1.0 + 2 * rank, np.float32),
+                     "a/bn/moving_var": np.arange(4, dtype=np.float32) * (rank + 1)}
+
+    def variables(self):
+        return [("w", (2, 3), True), ("a/bn/moving_mean", (1, 4), False), ("a/bn/moving_var", (1, 4), False)]
+
+    def get_variable(self, name):
+        return self.vars[name]
+
+    def set_variable(self, name, value):
+        self.vars[name] = np.asarray(value, np.float32).reshape(self.vars[name].shape)
 
     @staticmethod
     def comm_unique_id():
@@ -67,10 +80,27 @@ def _worker(rank, world, port, q):
             assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
         # 2. communicator rendezvous
-        eng = FakeEngine()
+        eng = FakeEngine(rank)
         uid = parallel.init_comm(eng, dist)
         assert uid == bytes(range(128)) and eng.calls[-1] == (rank, world, uid)
         assert parallel.broadcast_bytes(dist, b"xyz" if rank == 0 else None) == b"xyz"
+        # 2b. one permutation per epoch for all ranks (rank 0's), each rank takes its slice of every global batch
+        perm = list(np.random.default_rng(100 + rank).permutation(16))          # ranks would disagree ...
+        perm = parallel.broadcast_object(dist, perm)
+        assert perm == list(np.random.default_rng(100).permutation(16))         # ... everyone now holds rank 0's
+        B = 8
+        lo_b, hi_b = parallel.shard_range(B, rank, world)
+        mine = [perm[b * B + lo_b:b * B + hi_b] for b in range(2)]
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        seen = sorted(int(x) for r in got for bt in r for x in bt)
+        assert seen == list(range(16))                                           # an epoch is one pass: no duplicates, none skipped
+        # 2c. EMA shadows (non-trainable variables) are averaged across ranks, trainable ones are left alone
+        assert parallel.average_ema_shadows(eng, dist) == 2
+        np.testing.assert_allclose(eng.vars["a/bn/moving_mean"], np.full(4, 2.0))           # mean of 1 and 3
+        np.testing.assert_allclose(eng.vars["a/bn/moving_var"], np.arange(4) * 1.5)
+        np.testing.assert_array_equal(eng.vars["w"], np.full((2, 3), 7.0 + rank, np.float32))
+        assert abs(parallel.mean_scalar(dist, 1.0 + rank) - 1.5) < 1e-12
         # 3. unequal row gather (eval predictions)
         counts = [3, 2]
         local = np.full((counts[rank], 4), float(rank + 1), np.float32)

@@ -144,3 +144,35 @@ def test_packed_loader_is_bit_identical_to_reference_batches(tiny):
     np.testing.assert_array_equal(b3[2], G["lb3_translations"])
     np.testing.assert_array_equal(b3[7], G["lb3_pc2angles"])
     prov._packed = None
+
+
+def test_packed_cache_is_rebuilt_when_the_dataset_changes(tiny):
+    """The cache carries a manifest (example count, newest modification time); a changed dataset must not silently reuse it,
+    and a build never leaves a half-written table under its final name."""
+    from alignnet3d import packed
+    prov, cfg = tiny["provider"], tiny["config"].configGlobal
+    base = cfg.data.basepath
+    cache = os.path.join(base, "packed_cache")
+    prov.use_packed_cache()
+    assert packed.cache_is_current(base, cache)
+    man = json.load(open(os.path.join(cache, "manifest.json")))
+    assert man["n_examples"] == len(J["ds_meta"])
+    assert not [f for f in os.listdir(cache) if ".tmp" in f]
+    stamp = os.stat(os.path.join(cache, "ids.npy")).st_mtime_ns
+    prov.use_packed_cache()                                  # current: not rebuilt
+    assert os.stat(os.path.join(cache, "ids.npy")).st_mtime_ns == stamp
+    # a new example appears in the dataset
+    src = sorted(os.listdir(os.path.join(base, "meta")))[0]
+    new = "%08d" % 9999
+    import shutil
+    for sub, ext in (("meta", ".json"), ("pointcloud1", ".npy"), ("pointcloud2", ".npy")):
+        shutil.copy(os.path.join(base, sub, src[:-5] + ext), os.path.join(base, sub, new + ext))
+    try:
+        assert not packed.cache_is_current(base, cache)
+        ds = prov.use_packed_cache()
+        assert len(ds) == len(J["ds_meta"]) + 1 and packed.cache_is_current(base, cache)
+    finally:
+        for sub, ext in (("meta", ".json"), ("pointcloud1", ".npy"), ("pointcloud2", ".npy")):
+            os.remove(os.path.join(base, sub, new + ext))
+        prov._packed = None
+    assert not packed.cache_is_current(base, cache)

@@ -63,28 +63,47 @@ def test_snappy_block_decoding():
 
 
 def test_variable_mapping_follows_tf_names():
+    """Checkpoint names as TF 1.x writes them (derivation in tf_bundle.tf_shadow_name): the EMA slot is named by the VARIABLE
+    scope (`siamese/...` for both towers) followed by the moments op's NAME-scope path (`siamese/...` or `siamese_1/...`)."""
+    assert tb.tf_shadow_name("siamese/transformer1/embedding/conv1/bn/moving_mean") == \
+        "siamese/transformer1/embedding/conv1/bn/siamese/transformer1/embedding/conv1/bn/moments/Squeeze/ExponentialMovingAverage"
+    assert tb.tf_shadow_name("siamese_1/transformer1/embedding/conv1/bn/moving_var") == \
+        "siamese/transformer1/embedding/conv1/bn/siamese_1/transformer1/embedding/conv1/bn/moments/Squeeze_1/ExponentialMovingAverage"
+    assert tb.tf_shadow_name("siamese_1/transformer2/mlp/fc2/bn/moving_mean") == \
+        "siamese/transformer2/mlp/fc2/bn/siamese_1/transformer2/mlp/fc2/bn/moments/Squeeze/ExponentialMovingAverage"
+    assert tb.tf_shadow_name("fc1/bn/moving_var") == "fc1/bn/fc1/bn/moments/Squeeze_1/ExponentialMovingAverage"
+    assert tb.tf_shadow_name("fc1/weights") is None
     spec = R.NetSpec()
     engine_vars = [(n, (int(np.prod(s[:-1])) if len(s) > 1 else 1, s[-1]), not n.endswith(("moving_mean", "moving_var")))
                    for n, s in R.param_names(spec)]
     ckpt = []
     for n, _, _ in engine_vars:
-        if n.endswith("/bn/moving_mean"):
-            sc = n[: -len("moving_mean")]
-            ckpt.append(sc + sc + "moments/Squeeze/ExponentialMovingAverage")
-        elif n.endswith("/bn/moving_var"):
-            sc = n[: -len("moving_var")]
-            ckpt.append(sc + sc + "moments/Squeeze_1/ExponentialMovingAverage")
+        if n.endswith(("/bn/moving_mean", "/bn/moving_var")):
+            ckpt.append(tb.tf_shadow_name(n))
         else:
             ckpt.append(n)
             ckpt.append(n + "/Adam")
             ckpt.append(n + "/Adam_1")
     ckpt += ["Variable", "beta1_power", "beta2_power"]
+    assert len(set(ckpt)) == len(ckpt)
+    # every tower-1 shadow shares the `siamese/<layer>/bn/` prefix with the tower-0 shadow of the same layer
+    assert sum(c.startswith("siamese/embedding/conv3/bn/") and c.endswith("ExponentialMovingAverage") for c in ckpt) == 4
+    assert not any(c.startswith("siamese_1/") and c.endswith("ExponentialMovingAverage") for c in ckpt)
     mapping, missing = tb.map_variables(engine_vars, ckpt)
     assert not missing and len(mapping) == len(engine_vars)
-    assert mapping["siamese_1/embedding/conv3/bn/moving_var"].endswith("Squeeze_1/ExponentialMovingAverage")
-    assert mapping["fc1/bn/moving_mean"].startswith("fc1/bn/") and "Squeeze/" in mapping["fc1/bn/moving_mean"]
+    assert len(set(mapping.values())) == len(mapping)
+    assert mapping["siamese_1/embedding/conv3/bn/moving_var"] == \
+        "siamese/embedding/conv3/bn/siamese_1/embedding/conv3/bn/moments/Squeeze_1/ExponentialMovingAverage"
+    assert mapping["siamese/embedding/conv3/bn/moving_mean"] == \
+        "siamese/embedding/conv3/bn/siamese/embedding/conv3/bn/moments/Squeeze/ExponentialMovingAverage"
+    assert mapping["fc1/bn/moving_mean"] == "fc1/bn/fc1/bn/moments/Squeeze/ExponentialMovingAverage"
+    # a checkpoint without tower-1 statistics: exactly those are reported missing
     mapping2, missing2 = tb.map_variables(engine_vars, [c for c in ckpt if "siamese_1/" not in c])
     assert missing2 and all(m.startswith("siamese_1/") for m in missing2)
+    # another outer spelling with the same unambiguous tail is still accepted
+    alt = [c.replace("siamese/embedding/conv3/bn/siamese_1/", "x/siamese_1/") for c in ckpt]
+    mapping3, missing3 = tb.map_variables(engine_vars, alt)
+    assert not missing3 and mapping3["siamese_1/embedding/conv3/bn/moving_var"].startswith("x/siamese_1/")
 
 
 @pytest.mark.gpu
@@ -102,6 +121,8 @@ def test_engine_export_import_roundtrip(gpu_required, tmp_path):
     t = tb.read_bundle(prefix)
     assert t["siamese/transformer1/embedding/conv1/weights"].shape == (1, 3, 1, 32)     # HWIO, utils/tf_util.py:148-152
     assert t["siamese/embedding/conv2/weights"].shape == (1, 1, 32, 64)
+    assert "siamese/embedding/conv2/bn/siamese_1/embedding/conv2/bn/moments/Squeeze_1/ExponentialMovingAverage" in t   # TF's slot name
+    assert not any(k.endswith(("moving_mean", "moving_var")) for k in t)
     eng2 = alignnet3d.Engine(cfg)
     mapping, missing = tb.load_into_engine(eng2, prefix)
     assert not missing and eng2.state()["step"] == 77
