@@ -1,30 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: AlignNet-3D point-cloud pairs/sec at N=1024 on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--workload pointnet|dgcnn]
 
-A "step" is one pass of the hot path (models/tp8.py get_model, eval mode, i.e. the
-reference's timed `sess.run`, train.py:447-449) over one batch of synthetic pairs that is
-already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: SynthCars widths,
-batch 256, N=1024, fp32.  With --gpus N (launched under torch.distributed.run, one rank per
-GPU) every rank processes its own batch of 256 pairs (weak scaling; pairs are independent in
-eval mode so there is no data-path collective); value = all pairs / max-over-ranks time.
+A "step" is one pass of the hot path (models/tp8.py get_model, eval mode, i.e. the reference's timed `sess.run`,
+train.py:447-449) over one batch of synthetic pairs that is already resident in HBM.  Workload at N=1 =
+BASELINE.json configs[1]: SynthCars widths, batch 256, N=1024, fp32.  With --gpus N (launched under
+torch.distributed.run, one rank per GPU) every rank processes its own batch of 256 pairs (weak scaling; pairs are
+independent in eval mode so the inference path has no data-path collective); value = all pairs / max-over-ranks time.
+For N > 1 the training leg runs by default as well: data-parallel steps with the library's RCCL all-reduce over xGMI.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel = pointnet_fused (the fused shared-MLP backbone).  achieved =
-               algorithmic FLOPs per step of that kernel (2 * 260,636,672 MAC per
-               cloud-triple * 2 clouds per pair) / its HIP-event time on the engine's stream,
-               measured inside the timed region.  peak = 157.3 TFLOP/s fp32 MFMA
-               (MI355X_MICROARCH.md).  traffic = HBM bytes per step from rocprofv3 PMC
-               (profiles/*_pmc_traffic.json: the dominant kernel's three launches of one step, collected
-               in separate --pmc passes), else null.
-  cpu_baseline the oracle ("port": unfused op-by-op NumPy fp32 restatement, eval mode) timed on
-               this box's host cores on a bounded sample (batch 32, repeated ~10-20 s).
+Prints ONE JSON line (rank 0).  Every timed leg (headline, `infer_bf16x3`, `train`, `train.bf16`) carries a `roofline`
+object: dominant kernel = the timed kernel with the largest HIP-event time inside that leg's timed region (events on the
+engine's own stream, alignnet_profile_read_kernel); achieved = the FLOPs that kernel's algorithm executes per step
+(`kernel_macs`) / its event time; peak = 157.3 TFLOP/s fp32 MFMA or 2500 TFLOP/s dense bf16 MFMA
+(MI355X_MICROARCH.md); traffic = HBM bytes of that kernel per step from the committed rocprofv3 PMC summary of the same
+command (profiles/r*_<leg>_pmc_traffic.json, separate --pmc passes, FETCH_SIZE doubled as the guide prescribes), else null.
+  pcie_inclusive  the reference's own methodology (train.py:447-449 times sess.run including the feed copy): pageable
+                  host buffers in, host buffers out, blocking alignnet_forward.  Never the headline `value`.
+  cpu_baseline    the oracle ("port": unfused op-by-op NumPy fp32 restatement, eval mode, batch 32 as the reference's
+                  timing mode train.py:557) on this box's host cores with 1 / 16 / all BLAS threads; value = the best.
 """
 import argparse
 import glob
 import json
+import math
 import os
+import re
 import sys
 import time
 
@@ -37,23 +39,30 @@ import numpy as np  # noqa: E402
 
 # algorithmic work (SURVEY.md 8d / BASELINE.md 2), SynthCars widths, N=1024, nb=50
 FLOPS_PER_PAIR_TOTAL = 1_047_688_704
+FLOPS_PER_PAIR_TRAIN_SURVEY = 3.14e9   # dense forward + dX + dW, the count a layer-by-layer backward would execute
 N_POINTS = 1024
+PEAK_F32, PEAK_BF16 = 157.3, 2500.0    # TFLOP/s, dense (MI355X_MICROARCH.md)
+K_NEIGHBOURS = 20                      # models/tp8.py:33
+
+
+def stage_widths(cfg):
+    o = cfg["model"]["options"]
+    return [o["s1transformer"][0], o["s2transformer"][0], o["embedding"]]
 
 
 def backbone_macs_per_cloud(cfg):
-    """MACs of the three fused backbones for one cloud (the dominant kernel's algorithmic work).
+    """MACs of the three fused backbones for one cloud (the dominant inference kernel's algorithmic work).
     dgcnn (models/tp8.py:30-46): edge convs widths[:-1] on k = 20 edges per point, then widths[-1] per point."""
-    o = cfg["model"]["options"]
     n = cfg["model"]["num_points"]
     dg = cfg["model"]["backbone"] == "dgcnn"
     tot = 0
-    for widths in (o["s1transformer"][0], o["s2transformer"][0], o["embedding"]):
+    for widths in stage_widths(cfg):
         if dg:
             cin, edge = 6, 0
             for c in widths[:-1]:
                 edge += cin * c
                 cin = c
-            tot += 20 * edge + cin * widths[-1]
+            tot += K_NEIGHBOURS * edge + cin * widths[-1]
         else:
             cin = 3
             for c in widths:
@@ -62,13 +71,72 @@ def backbone_macs_per_cloud(cfg):
     return tot * n
 
 
-def cpu_baseline(cfg, seconds=12.0):
-    from oracle import alignnet_ref as R
+def _blocks(c):
+    """32 x 32 upper-triangle blocks of a c x c Gram matrix (what the Gram kernels execute)."""
+    t = (c + 31) // 32
+    return t * (t + 1) // 2 * 1024
+
+
+def kernel_macs(cfg, kernel, bf16):
+    """MACs per CLOUD, summed over the three stages, that `kernel`'s algorithm executes in this design:
+    the recompute of the cheap early layers is part of each pass, the dense backward through the C2 -> C3 lift is replaced by
+    the Gram identities.  3-layer backbones [C1, C2, C3] (the only trainable shape)."""
+    n = cfg["model"]["num_points"]
+    dg = cfg["model"]["backbone"] == "dgcnn"
+    if kernel == "backbone":
+        return backbone_macs_per_cloud(cfg)
+    if kernel == "knn":
+        return n * n * 3                       # distance products, one graph per cloud (VALU work, not MFMA)
+    k0 = 6 if dg else 3
+    rows = n * K_NEIGHBOURS if dg else n       # edge rows per cloud in the DGCNN branch
+    tot = 0
+    for (c1, c2, c3) in [w[:3] for w in stage_widths(cfg)]:
+        if kernel == "train_fwd_phase3":       # h1, h2 recomputed from xyz, z3 = h2 W3 (+ the Gram of h2 inside the bf16 kernel)
+            tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if bf16 and not dg else 0)
+        elif kernel == "train_fwd_phase2":     # fp32: h1 + Gram(h1) (statistics of z2 from the Gram); bf16: h1 + z2 = h1 W2
+            tot += n * (k0 * c1 + (c1 * c2 if bf16 else _blocks(c1)))
+        elif kernel == "train_gram_h2":
+            tot += n * _blocks(c2)
+        elif kernel == "train_bwd_b2":         # h1, h2 recomputed (pointnet), dh2 = h2 Q3
+            tot += n * ((0 if dg else k0 * c1 + c1 * c2) + c2 * c2)
+        elif kernel == "train_bwd_b1":         # h1 recomputed, dh1 = dy2 V2 + h1 Q2, U2 = h1^T dy2, Pdy = x'^T dy1
+            tot += n * (k0 * c1 + c2 * c1 + c1 * c1 + c1 * c2 + 4 * c1)
+        elif kernel == "dg_train_fwd":         # per edge row: K=6 lift, z2 = h1 W2, Gram(h1)
+            tot += rows * (k0 * c1 + c1 * c2 + _blocks(c1))
+        elif kernel == "dg_train_bwd_edge":    # per edge row: lift, h1 Q2 dense, the two sparse products at 1/k density, Pdy chain
+            tot += rows * (k0 * c1 + c1 * c1 + 2 * c1 * c2 // K_NEIGHBOURS + 8 * c1)
+    return tot
+
+
+KERNEL_IN_PROFILE = {   # bench kernel key -> substring of the kernel name in profiles/*_pmc_by_kernel.json
+    "train_fwd_phase3": "train_fwd_phase23<3", "train_fwd_phase2": "train_fwd_gram1|train_fwd_phase23<2", "train_gram_h2": "gram_h2_kernel", "train_bwd_b2": "train_bwd_b2",
+    "train_bwd_b1": "train_bwd_b1", "dg_train_fwd": "dg_train_fwd", "dg_train_bwd_edge": "dg_train_bwd_edge", "knn": "knn_kernel"}
+
+
+def pmc_traffic(leg_tag, kernel_substr):
+    """HBM bytes per step of one kernel from the newest committed rocprofv3 PMC summary of this leg, or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%spmc_traffic.json" % (leg_tag + "_" if leg_tag else ""))),
+                   key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+    files = [f for f in files if re.fullmatch(r"r\d+_%spmc_traffic\.json" % (leg_tag + "_" if leg_tag else ""), os.path.basename(f))]
+    if not files:
+        return None
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        j = json.load(open(files[-1]))
+        for name, v in (j.get("kernels") or {}).items():
+            if any(alt in name for alt in kernel_substr.split("|")):
+                return {"bytes_per_step": v["hbm_bytes_per_step"], "bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(files[-1])}
+        if kernel_substr in ("pointnet_fused",) and j.get("backbone_hbm_bytes_per_step"):   # round-1 layout
+            return {"bytes_per_step": j["backbone_hbm_bytes_per_step"], "bytes_per_launch": j.get("backbone_hbm_bytes_per_launch"),
+                    "source": os.path.basename(files[-1])}
     except Exception:
-        threads = os.cpu_count() or 1
+        return None
+    return None
+
+
+def cpu_baseline(cfg, seconds_per_setting=6.0):
+    from oracle import alignnet_ref as R
+    from threadpoolctl import threadpool_limits, threadpool_info
+    allc = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     spec = R.NetSpec.from_cfg(cfg)
     P = R.init_params(spec, 0, np.float32)
     for k in P:  # plausible eval-mode shadows (SURVEY 8d): mean 0, var 1
@@ -76,31 +144,23 @@ def cpu_baseline(cfg, seconds=12.0):
             P[k] = np.ones_like(P[k])
     B = 32  # the reference's own timing mode uses bs=32 (train.py:557)
     d = R.synth_pairs(B, spec.num_points, seed=1234, dtype=np.float32)
-    R.get_model(P, spec, d["pcs1"], d["pcs2"])  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        R.get_model(P, spec, d["pcs1"], d["pcs2"])
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 200:
-            break
-    return {"value": round(B * n / dt, 2), "unit": "pairs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} x batch {B} (N={spec.num_points}, SynthCars widths, eval mode), unfused NumPy fp32 oracle, "
-                      f"{dt:.1f} s wall, forward only (cf. reference train.py:447-449)"}
-
-
-def pmc_traffic():
-    """HBM bytes per step from a committed rocprofv3 PMC summary, if one exists."""
-    import re
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
-                   if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))   # the exact-fp32 inference profile of a round
-    if not files:
-        return None
-    try:
-        j = json.load(open(files[-1]))
-        return j.get("backbone_hbm_bytes_per_step") or j.get("hbm_bytes_per_step")
-    except Exception:
-        return None
+    sweep = []
+    for threads in sorted({1, min(16, allc), allc}):
+        with threadpool_limits(limits=threads):
+            R.get_model(P, spec, d["pcs1"], d["pcs2"])  # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                R.get_model(P, spec, d["pcs1"], d["pcs2"])
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt >= seconds_per_setting or n >= 200:
+                    break
+        sweep.append({"threads": threads, "value": round(B * n / dt, 2), "batches": n, "seconds": round(dt, 1)})
+    best = max(sweep, key=lambda s: s["value"])
+    return {"value": best["value"], "unit": "pairs/s", "cores": best["threads"], "kind": "port", "host_cores": os.cpu_count(),
+            "sweep": sweep,
+            "sample": f"batches of {B} pairs (N={spec.num_points}, SynthCars widths, eval mode), unfused NumPy fp32 oracle, "
+                      f"~{seconds_per_setting:.0f} s per thread setting, forward only (cf. reference train.py:447-449); value = best setting"}
 
 
 def main():
@@ -117,10 +177,14 @@ def main():
                          "opt-in split-bf16 mode (three bf16 MFMAs per fp32 product, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
-    ap.add_argument("--train-leg", action="store_true", help="also run the training leg when --gpus > 1 (RCCL all-reduce)")
+    ap.add_argument("--no-split-leg", action="store_true")
+    ap.add_argument("--no-pcie-leg", action="store_true")
+    ap.add_argument("--train-leg", action="store_true", help="(kept for compatibility: the training leg now runs by default, also for --gpus > 1)")
+    ap.add_argument("--allreduce-overlap", type=int, default=1, help="data-parallel training: bucketed all-reduce next to the backward (1) or one call after it (0)")
     ap.add_argument("--workload", choices=["pointnet", "dgcnn"], default="pointnet",
                     help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (--mode train: fp32 only)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
+    ap.add_argument("--min-leg-seconds", type=float, default=0.35, help="secondary legs are timed for at least this long")
     args = ap.parse_args()
 
     import torch
@@ -132,17 +196,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > ndev:
+        # one rank per GPU is the contract; sharing a device would report n_gpus ranks' worth of throughput from fewer GPUs
+        raise SystemExit(f"{local_world} ranks on this node but only {ndev} GPU(s) visible: refusing to share devices")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank %= max(torch.cuda.device_count(), 1)   # more ranks than GPUs: share devices rather than fail
         torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        except Exception as e:   # the inference path has no data-path collective: a barrier and one max are all it needs
-            print(f"[bench] nccl backend unavailable ({e}); using gloo for the barrier / max-over-ranks", file=sys.stderr, flush=True)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -150,9 +216,9 @@ def main():
     npts = args.points or (4096 if args.workload == "dgcnn" else N_POINTS)
     cfg["model"]["num_points"] = npts
     cfg["model"]["backbone"] = args.workload
-    if args.workload == "dgcnn":
-        args.no_train_leg = True
-        args.no_cpu_baseline = True
+    dg = args.workload == "dgcnn"
+    if dg:
+        args.no_train_leg = args.no_cpu_baseline = args.no_split_leg = args.no_pcie_leg = True
     cfg["training"]["batch_size"] = args.batch * world
     B = args.batch
     eng = alignnet3d.Engine(cfg, device=local_rank, seed=0)
@@ -167,15 +233,19 @@ def main():
     nb2 = 2 * cfg["model"]["angles"]["num_bins"]
     outs = {k: torch.empty(B, nb2 if "logits" in k else 3, device=dev) for k in alignnet3d.OUTPUT_NAMES}
     ptrs = {k: v.data_ptr() for k, v in outs.items()}
-
     lab = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
            ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
     lab_ptrs = {k: v.data_ptr() for k, v in lab.items()}
-    want_train = args.mode == "train" or (not args.no_train_leg and (world == 1 or args.train_leg))
+    want_train = args.mode == "train" or not args.no_train_leg
+    rccl_ranks = 0
     if world > 1 and want_train:
         # data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed
         from alignnet3d import parallel
         parallel.init_comm(eng, dist)
+        eng.set_option("allreduce_overlap", args.allreduce_overlap)
+        rccl_ranks = eng.get_option("comm_world")
+        if rccl_ranks != world:
+            raise SystemExit(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
 
     def train_step():
         eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
@@ -183,17 +253,10 @@ def main():
     def infer_step():
         eng.forward_device(p1.data_ptr(), p2.data_ptr(), B, ptrs)
 
-    step = train_step if args.mode == "train" else infer_step
-    if args.mode == "infer" and args.infer_dtype == "bf16x3":
-        eng.set_option("infer_matmul_bf16x3", 1)
-    if args.mode == "train" and args.train_dtype == "bf16":
-        eng.set_option("train_matmul_bf16", 1)
-
     def max_over_ranks(x):
         if dist is None:
             return x
-        on_gpu = dist.get_backend() == "nccl"
-        t = torch.tensor([x], device=dev if on_gpu else "cpu", dtype=torch.float64)
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -204,129 +267,167 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_enable(True)
-    eng.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_read(reset=True)
-    eng.profile_enable(False)
-
-    dt = max_over_ranks(dt)
-
-    # secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline value)
-    split_info = None
-    if args.mode == "infer" and args.workload == "pointnet" and args.infer_dtype == "f32":
-        ref_out = {k: v.clone() for k, v in outs.items()}
-        eng.set_option("infer_matmul_bf16x3", 1)
-        ksteps = max(10, args.steps // 2)
-        for _ in range(3):
-            infer_step()
+    def time_leg(step, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between two fences; max over ranks.  Returns (seconds, kernel profile)."""
+        for _ in range(warmup):
+            step()
         fence()
         eng.profile_enable(True)
         eng.profile_read(reset=True)
-        t1 = time.perf_counter()
-        for _ in range(ksteps):
-            infer_step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
         fence()
-        sdt = time.perf_counter() - t1
-        sprof = eng.profile_read(reset=True)
+        dt = time.perf_counter() - t0
+        kern = eng.profile_kernels()
+        eng.profile_read(reset=True)
         eng.profile_enable(False)
-        sdt = max_over_ranks(sdt)
+        return max_over_ranks(dt), kern
+
+    def steps_for(step, floor):
+        """Number of steps that fills --min-leg-seconds (secondary legs), from two timed probe steps."""
+        step(); fence()
+        t0 = time.perf_counter()
+        step(); step(); fence()
+        est = max_over_ranks((time.perf_counter() - t0) / 2)
+        return max(floor, int(math.ceil(args.min_leg_seconds / max(est, 1e-6))))
+
+    def roofline(kern, steps, bf16, leg_tag, backbone_name):
+        """The leg's dominant timed kernel against the matrix-pipe roofline."""
+        if not kern:
+            return None
+        cand = {k: v for k, v in kern.items() if k not in ("allreduce", "optimizer")}
+        name = max(cand, key=lambda k: cand[k][0])
+        ms, launches = cand[name]
+        flops = 2.0 * kernel_macs(cfg, name, bf16) * 2 * B
+        # the bf16 MFMA pipe is the bound of a kernel whose dominant products run on it: backbone (split), phase 2/3 and B2 in bf16 mode
+        on_bf16 = bf16 and name in ("backbone", "train_fwd_phase2", "train_fwd_phase3", "train_bwd_b2")
+        peak = (PEAK_BF16 / 3.0 if name == "backbone" else PEAK_BF16) if on_bf16 else PEAK_F32
+        ms_step = ms / steps
+        ach = flops / (ms_step * 1e-3) / 1e12 if ms_step > 0 and flops > 0 else None
+        prof_name = backbone_name if name == "backbone" else KERNEL_IN_PROFILE.get(name, name)
+        tr = pmc_traffic(leg_tag, prof_name)
+        r = {"bound": "mfma" if name != "knn" else "valu", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+             "frac": None if ach is None else round(ach / peak, 4), "traffic": None if tr is None else tr["bytes_per_step"],
+             "kernel": prof_name, "launches_per_step": launches / steps, "kernel_ms_per_step": round(ms_step, 4),
+             "avg_launch_us": round(ms / max(launches, 1) * 1e3, 2), "algorithmic_flops_per_step": flops,
+             "step_share": {k: round(v[0] / steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
+        if tr is not None:
+            r["traffic_source"] = tr["source"]
+        if on_bf16 and name == "backbone":
+            r["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
+        return r
+
+    # ---------------------------------------------------------------------------------------------------------- headline leg
+    if args.mode == "infer" and args.infer_dtype == "bf16x3":
+        eng.set_option("infer_matmul_bf16x3", 1)
+    if args.mode == "train" and args.train_dtype == "bf16":
+        eng.set_option("train_matmul_bf16", 1)
+    step = train_step if args.mode == "train" else infer_step
+    dt, kern = time_leg(step, args.steps, args.warmup)
+    head_bf16 = (args.mode == "train" and args.train_dtype == "bf16") or (args.mode == "infer" and args.infer_dtype == "bf16x3")
+    backbone_kernel = eng.last_backbone_kernel().split("<")[0] if args.mode == "infer" else "train"
+    if args.mode == "infer":
+        leg_tag = {("pointnet", "f32"): "", ("pointnet", "bf16x3"): "split", ("dgcnn", "f32"): "dgcnn", ("dgcnn", "bf16x3"): "dgcnn_split"}[(args.workload, args.infer_dtype)]
+    else:
+        leg_tag = "train_dgcnn" if dg else ("train_bf16" if args.train_dtype == "bf16" else "train")
+    head_roof = roofline(kern, args.steps, head_bf16, leg_tag, backbone_kernel)
+
+    # ------------------------------------------------- secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline)
+    split_info = None
+    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_split_leg:
+        ref_out = {k: v.clone() for k, v in outs.items()}
+        eng.set_option("infer_matmul_bf16x3", 1)
+        ksteps = steps_for(infer_step, 10)
+        sdt, skern = time_leg(infer_step, ksteps, 2)
         diff = max(float((outs[k] - ref_out[k]).abs().max().item()) for k in outs)
-        bb_ms = sprof["backbone_ms"] / ksteps
         split_info = {"value": round(world * B * ksteps / sdt, 1), "unit": "pairs/s", "ms_per_step": round(sdt / ksteps * 1e3, 4), "steps": ksteps,
                       "dtype": "bf16x3 (x = hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate)",
-                      "kernel_ms_per_step": round(bb_ms, 4),
-                      "bf16_mfma_tflops": round(3 * 2.0 * backbone_macs_per_cloud(cfg) * 2 * B / (bb_ms * 1e-3) / 1e12, 1) if bb_ms > 0 else None,
-                      "bf16_mfma_peak_tflops": 2500.0,
+                      "roofline": roofline(skern, ksteps, True, "split", eng.last_backbone_kernel().split("<")[0]),
                       "max_abs_diff_vs_exact_fp32_outputs": diff,
                       "what": "opt-in inference mode alignnet_set_option(infer_matmul_bf16x3); parity bar 1e-4 (tests/test_forward_gpu.py)"}
         eng.set_option("infer_matmul_bf16x3", 0)
 
-    # secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA), fp32
+    # ------------------------------- secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA)
     train_info = None
     if args.mode == "infer" and want_train:
         train_info = {}
         for tdtype in ("f32", "bf16"):
             eng.set_option("train_matmul_bf16", int(tdtype == "bf16"))
-            ksteps = max(3, args.steps // 5)
-            for _ in range(2):
-                train_step()
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(ksteps):
-                train_step()
-            fence()
-            tdt = time.perf_counter() - t1
-            tdt = max_over_ranks(tdt)
+            ksteps = steps_for(train_step, 5)
+            tdt, tkern = time_leg(train_step, ksteps, 1)
             leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
                    "steps": ksteps, "dtype": tdtype,
+                   "roofline": roofline(tkern, ksteps, tdtype == "bf16", "train_bf16" if tdtype == "bf16" else "train", "train"),
+                   "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY,
                    "what": "train step: batch-stat forward + loss + backward + " +
-                           ("RCCL all-reduce + " if world > 1 else "") + "Adam + EMA, local-BN data parallel" +
-                           ("; 128->C3 lift and its Gram on bf16 MFMA, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
+                           ("RCCL all-reduce (%s) + " % ("3 buckets overlapped with the backward" if args.allreduce_overlap else "one call after the backward")
+                            if world > 1 else "") + "Adam + EMA, local-BN data parallel" +
+                           ("; MFMA convs on bf16 operands, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
+            if world > 1:
+                leg["rccl_ranks"] = rccl_ranks
+                leg["allreduce_exposed_ms_per_step"] = round(tkern.get("allreduce", (0.0, 0))[0] / ksteps, 4)
             if tdtype == "f32":
                 train_info = leg
             else:
                 train_info["bf16"] = leg
         eng.set_option("train_matmul_bf16", 0)
 
+    # -------------- secondary leg: PCIe-inclusive inference, the reference's own timing methodology (train.py:447-449), rank 0's GPU only
+    pcie_info = None
+    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_pcie_leg and rank == 0:
+        for _ in range(2):
+            eng.forward(d["pcs1"], d["pcs2"])
+        kp = max(10, int(math.ceil(args.min_leg_seconds / 2.5e-3)))
+        t0 = time.perf_counter()
+        for _ in range(kp):
+            eng.forward(d["pcs1"], d["pcs2"])
+        pdt = time.perf_counter() - t0
+        pcie_info = {"value": round(B * kp / pdt, 1), "unit": "pairs/s", "ms_per_step": round(pdt / kp * 1e3, 4), "steps": kp, "n_gpus": 1,
+                     "what": "pageable host buffers in (2 x %.1f MB) and out, blocking alignnet_forward per batch -- the feed copy is inside the "
+                             "timed region as in the reference's timing (train.py:447-449); not the headline value" % (B * npts * 12 / 1e6)}
+    if dist is not None:
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        bb_flops_per_step = 2.0 * backbone_macs_per_cloud(cfg) * 2 * B
-        bb_ms_per_step = prof["backbone_ms"] / args.steps
-        achieved = bb_flops_per_step / (bb_ms_per_step * 1e-3) / 1e12 if bb_ms_per_step > 0 else None
-        peak = 157.3
         line = {
             "metric": "point-cloud pairs/sec at N=%d (inference, eval-mode forward)" % npts,
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("SynthCars widths inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[1])" % (B, npts))
-                       if args.workload == "pointnet" else
+                       if not dg else
                        ("SynthCars widths, DGCNN edge-conv branch (k=20), inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[4] shape)" % (B, npts)),
-                       "pairs_per_gpu": B, "num_points": npts, "parallelism": f"batch-split x{world} (no collective)"},
-            "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": pmc_traffic() if args.workload == "pointnet" and npts == N_POINTS and B == 256 else None,
-                         "kernel": "pointnet_fused" if args.workload == "pointnet" else "dgcnn_fused",
-                         "launches_per_step": prof["backbone_launches"] / args.steps,
-                         "kernel_ms_per_step": round(bb_ms_per_step, 4),
-                         "algorithmic_flops_per_step": bb_flops_per_step},
+                       "pairs_per_gpu": B, "num_points": npts, "parallelism": f"batch-split x{world} (no collective)", "devices_used": world},
+            "roofline": head_roof,
             "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2)
-            if world == 1 and args.workload == "pointnet" and npts == N_POINTS else None,
+            if world == 1 and not dg and npts == N_POINTS and args.mode == "infer" else None,
         }
         if args.mode == "train":
             line["metric"] = "point-cloud pairs/sec at N=%d (training step)" % npts
-            line["roofline"] = None
             line["dtype"] = args.train_dtype
             line["config"]["workload"] = ("KITTITrackletsCars-style training step (SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
                                           "(BASELINE.json configs[2])" % (B, npts, args.train_dtype))
-            if args.workload == "dgcnn":
+            if dg:
                 line["config"]["workload"] = ("training step, DGCNN edge-conv branch (k=20, SynthCars widths), batch=%d pairs/GPU, N=%d, f32 "
                                               "(BASELINE.json configs[4] shape)" % (B, npts))
-            line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients)" if world > 1 else "")
-            line["whole_path_tflops"] = None
+            line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients, %d ranks)" % rccl_ranks if world > 1 else "")
+            line["flops_per_pair_survey"] = FLOPS_PER_PAIR_TRAIN_SURVEY if not dg and npts == N_POINTS else None
+            if world > 1:
+                line["allreduce_exposed_ms_per_step"] = round(kern.get("allreduce", (0.0, 0))[0] / args.steps, 4)
         if args.mode == "infer" and args.infer_dtype == "bf16x3":
             line["dtype"] = "bf16x3"
             line["metric"] += " [split-bf16 backbone]"
             line["config"]["workload"] = line["config"]["workload"].replace("fp32", "split-bf16 products with fp32 accumulate")
-            line["roofline"]["peak"] = 2500.0 / 3.0
-            line["roofline"]["frac"] = None if achieved is None else round(achieved / (2500.0 / 3.0), 4)
-            line["roofline"]["kernel"] = "pointnet_split" if args.workload == "pointnet" else "dgcnn_split"
-            line["roofline"]["traffic"] = None
-            line["roofline"]["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
         if split_info is not None:
             line["infer_bf16x3"] = split_info
         if train_info is not None:
             line["train"] = train_info
-        if world == 1 and not args.no_cpu_baseline:
+        if pcie_info is not None:
+            line["pcie_inclusive"] = pcie_info
+        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     eng.close()

@@ -53,18 +53,21 @@ for line in open(os.path.join(out, "bench_trace.log")):
 if steps:
     fetch = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in pmc.values())
     write = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in pmc.values())
-    bb = {}
+    kernels = {}
     for k, v in pmc.items():
-        if "pointnet_fused" in k:
-            bb = v
-    bf, bw = bb.get("FETCH_SIZE", {}).get("sum", 0), bb.get("WRITE_SIZE", {}).get("sum", 0)
-    nbb = max(bb.get("FETCH_SIZE", {}).get("dispatches", 1), 1)
+        f, w = v.get("FETCH_SIZE", {}), v.get("WRITE_SIZE", {})
+        if not f and not w:
+            continue
+        n = max(f.get("dispatches", 0), w.get("dispatches", 0), 1)
+        b = (2 * f.get("sum", 0) + w.get("sum", 0)) * 1024
+        kernels[k] = {"hbm_bytes_per_launch": b / n, "hbm_bytes_per_step": b / steps, "launches": n,
+                      "FETCH_SIZE_KiB": f.get("sum", 0), "WRITE_SIZE_KiB": w.get("sum", 0)}
     json.dump({"tag": tag, "steps_profiled": steps,
                "hbm_bytes_per_step": (2 * fetch + write) * 1024 / steps,
-               "backbone_hbm_bytes_per_launch": (2 * bf + bw) * 1024 / nbb,
-               "backbone_hbm_bytes_per_step": (2 * bf + bw) * 1024 / steps,
-               "raw_KiB": {"FETCH_SIZE_all": fetch, "WRITE_SIZE_all": write, "FETCH_SIZE_backbone": bf, "WRITE_SIZE_backbone": bw},
-               "note": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024; the x2 is the gfx950 FETCH_SIZE correction for wide coalesced "
-                       "reads (an upper bound for narrow reads). Separate --pmc passes, warm-up steps included on both sides."},
+               "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])),
+               "raw_KiB": {"FETCH_SIZE_all": fetch, "WRITE_SIZE_all": write},
+               "note": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per kernel name (every kernel of the run, by its own name); the x2 is the "
+                       "gfx950 FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md, HBM: an upper bound for narrow reads; "
+                       "WRITE_SIZE uncalibrated). Separate --pmc passes, warm-up steps included on both sides."},
               open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("summary files:", sorted(os.listdir(dst)))
