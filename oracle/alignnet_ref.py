@@ -38,7 +38,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-BN_EPS = 1e-3  # utils/tf_util.py:491
+BN_EPS = float(np.float32(1e-3))  # utils/tf_util.py:491; the Python float 1e-3 enters the graph as a float32 constant (1.0000000475e-3)
 
 
 # --------------------------------------------------------------------------
@@ -301,8 +301,9 @@ def head_mlp(x, P, scope, widths, tower, keep, is_training, bn_decay, updates, d
         h = dense(h, P, base, bnb, True, is_training, bn_decay, updates)
     if keep is not None and is_training:
         assert dropout_u is not None, "training-mode dropout needs explicit uniforms"
-        mask = np.floor(h.dtype.type(keep) + dropout_u.astype(h.dtype))
-        h = h / h.dtype.type(keep) * mask
+        kp = h.dtype.type(np.float32(keep))   # keep_prob enters the graph as a float32 constant (0.7 -> 0.69999999)
+        mask = np.floor(kp + dropout_u.astype(h.dtype))
+        h = h / kp * mask
     nm = f"{scope}/fc{len(widths)}" if scope else f"fc{len(widths)}"
     base = nm if tower is None else f"siamese/{nm}"
     return dense(h, P, base, None, False, is_training, bn_decay, updates)
@@ -439,7 +440,7 @@ def angle_loss(logits, target_angles, nb):
     # for finite angles except sh/apc == nb by rounding, kept as-is (index error if so).
     ce = softmax_ce(logits[:, :nb], cls).mean()
     onehot_pick = logits[:, nb:][np.arange(logits.shape[0]), cls]  # [B]
-    label = res / (dt(np.pi) / dt(nb))  # [B,1] or [B,B]
+    label = res / dt(np.float32(np.pi / nb))  # [B,1] or [B,B]; the Python float np.pi / nb enters the graph as a float32 constant
     rl = huber(onehot_pick - label, dt(1.0))  # [B] - [B,1] -> [B,B]
     return np.array([ce + dt(20.0) * rl, ce, rl])
 
@@ -448,7 +449,7 @@ def angle_losses(logits, target_angles, nb, accept_inverted):
     """models/tp8.py:284-291: tf.cond picks the LARGER of (theta, theta+pi) (quirk A6(ii))."""
     a = angle_loss(logits, target_angles, nb)
     if accept_inverted:
-        b = angle_loss(logits, target_angles + target_angles.dtype.type(np.pi), nb)
+        b = angle_loss(logits, target_angles + target_angles.dtype.type(np.float32(np.pi)), nb)   # `+ np.pi`: a float32 constant in the graph
         return a if a[0] > b[0] else b
     return a
 

@@ -121,7 +121,8 @@ class TorchTp8:
             else:
                 h = self._layer(h, "siamese/" + nm, f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
         if keep is not None and training:
-            h = h / keep * torch.floor(keep + u)
+            kp = float(np.float32(keep))   # keep_prob enters the TF graph as a float32 constant
+            h = h / kp * torch.floor(kp + u)
         nm = f"{scope}/fc{len(widths)}" if scope else f"fc{len(widths)}"
         return self._layer(h, nm if tower is None else "siamese/" + nm, None, training, decay, act=False)
 
@@ -176,7 +177,7 @@ class TorchTp8:
         cls0 = cls[:, 0].long()
         ce = F.cross_entropy(logits[:, :nb], cls0)
         pick = (logits[:, nb:] * F.one_hot(cls0, nb).to(logits.dtype)).sum(1)  # [B]
-        lab = res / (np.pi / nb)  # [B,1] or [B,B]
+        lab = res / float(np.float32(np.pi / nb))  # [B,1] or [B,B]; Python floats enter the TF graph as float32 constants
         err = pick - lab  # broadcast to [B,B], as in the reference
         rl = F.huber_loss(err, torch.zeros_like(err), delta=1.0)
         return torch.stack([ce + 20.0 * rl, ce, rl])
@@ -184,7 +185,7 @@ class TorchTp8:
     def _angle_losses(self, logits, target):
         a = self._angle_loss(logits, target)
         if self.spec.accept_inverted_angle:
-            b = self._angle_loss(logits, target + np.pi)
+            b = self._angle_loss(logits, target + float(np.float32(np.pi)))
             return a if bool(a[0] > b[0]) else b
         return a
 
