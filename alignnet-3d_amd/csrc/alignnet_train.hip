@@ -941,8 +941,16 @@ extern "C" int alignnet_apply_gradients(alignnet_handle* h, float grad_scale)
   const dim3 grid((unsigned)((n + 255) / 256));
   ProfScope prof_scope(h, PK_OPTIMIZER);
   if (h->cfg.optimizer == 0) {
-    const double t = (double)(h->step + 1);
-    const float lr_t = (float)((double)st.learning_rate * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
+    // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) exactly as TF evaluates it: in float32, with the beta powers kept as float32
+    // products (one multiplication per step).  With the kernel's float32 (1 - beta) factors this makes the first step lr * sign(g)
+    // to the last bit of the arithmetic; double-precision powers here were 6.4e-6 off (1 - 0.999f != 0.001).
+    const int64_t t = h->step + 1;
+    if (h->adam_power_t > t || h->adam_power_t < 0) { h->adam_b1p = h->adam_b2p = 1.f; h->adam_power_t = 0; }
+    while (h->adam_power_t < t) {
+      h->adam_b1p *= 0.9f; h->adam_b2p *= 0.999f; h->adam_power_t++;
+      if (h->adam_b2p == 0.f) { h->adam_power_t = t; break; }   // both powers have underflowed: further products stay 0
+    }
+    const float lr_t = st.learning_rate * std::sqrt(1.f - h->adam_b2p) / (1.f - h->adam_b1p);
     hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, w->adam_v, n, grad_scale, lr_t, 0.9f, 0.999f, 1e-8f);
   } else {
     hipLaunchKernelGGL(momentum_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, n, grad_scale, st.learning_rate, h->cfg.momentum);

@@ -80,6 +80,10 @@ struct alignnet_handle {
   alignnet::Workspace ws;
   hipStream_t stream = nullptr;
   int64_t step = 0;
+  // tf.train.AdamOptimizer's beta1_power / beta2_power: float32 variables multiplied by beta once per step (adam.py _finish);
+  // cached for `adam_power_t` applied steps so that a step costs one multiplication (alignnet_apply_gradients)
+  float adam_b1p = 1.f, adam_b2p = 1.f;
+  int64_t adam_power_t = 0;
   int last_B = 0;
   int last_kernel = 0;             // which backbone instantiation the last eval forward launched (alignnet_get_option "last_backbone_kernel")
   int last_train_kernel = 0;       // same for the training step: bit 0 = compile-time widths (64, 128), bit 1 = bf16 operands, bit 2 = dgcnn

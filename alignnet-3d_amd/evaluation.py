@@ -66,6 +66,34 @@ def translate_transform_to_new_center_of_rotation(pred_translations, pred_angles
     return out
 
 
+def process_velocities(tracks, eval_dir, avg_window):
+    """Smoothed speed per track (evaluation.py:82-110): every run of consecutive frames of a (sequence, tracklet) becomes one track
+    that starts at rest one frame earlier; the speed at a frame is the norm (xy) of the mean velocity over the frames within
+    +- avg_window.  Writes <eval_dir>/velocities/track<id:09>.txt, one value per line, as the reference does; returns {id: [speeds]}."""
+    if eval_dir is None:
+        return None
+    vdir = eval_dir + "/velocities"
+    os.makedirs(vdir, exist_ok=True)
+    velocities = {}
+    for inter_id, traj in tracks.items():
+        frames = sorted(traj)
+        for start in [f for f in frames if f - 1 not in traj]:
+            tid = inter_id + start - 1      # the track begins with the pose before its first prediction
+            vel = [np.zeros(3)]             # (0, 0, 0) over 0.1 s
+            f = start
+            while f in traj:
+                t, dt = traj[f]
+                vel.append(np.asarray(t, np.float64) / dt)
+                f += 1
+            vel = np.asarray(vel)
+            speeds = [float(np.linalg.norm(vel[max(0, i - avg_window):i + avg_window + 1].mean(axis=0)[:2])) for i in range(len(vel))]
+            velocities[tid] = speeds
+            with open("%s/track%09d.txt" % (vdir, tid), "w") as fh:
+                for v in speeds:
+                    fh.write("%s\n" % v)
+    return velocities
+
+
 def _bucket():
     z = lambda: np.zeros(3, dtype=float)
     return dict(corr_levels_translation=z(), corr_levels_angles=z(), corr_levels=z(), mean_dist_translation=0.0,
@@ -96,16 +124,26 @@ def evaluate(cfg, val_idxs, all_pred_translations, all_pred_angles, all_gt_trans
     measures["test"] = {k: _bucket() for k, _ in _DIST_KEYS}
     base = cfg.data.basepath
     per_transform = []
+    tracks = {}
+    have_meta = os.path.isdir("%s/meta" % base)
     for i, vi in enumerate(val_idxs):
         # test/val membership as in evaluation.py:157-161.  The reference leaves `is_test` unbound for base paths
         # that contain neither marker (quirk A6(viii)); here such samples count as validation samples.
         is_test = False
+        meta = None
+        if have_meta:      # one read per sample serves the split (:157) and the velocity tracks (:215); the reference reads it twice
+            try:
+                with open("%s/meta/%s.json" % (base, str(vi).zfill(8))) as fh:
+                    meta = json.load(fh)
+            except OSError:
+                meta = None
         if "KITTI_tracklets" in base:
-            with open("%s/meta/%s.json" % (base, str(vi).zfill(8))) as fh:
-                meta = json.load(fh)
-            is_test = "trackids" in meta and meta["trackids"][0] in [2, 6, 7, 8, 10]
+            is_test = meta is not None and "trackids" in meta and meta["trackids"][0] in [2, 6, 7, 8, 10]
         elif "Synth" in base:
             is_test = i >= 1000
+        if meta is not None and "seq" in meta:   # evaluation.py:215-224: the UN-recentred prediction, 0.1 s between frames
+            inter = meta["seq"] * 10000000 + meta["trackids"][0] * 10000
+            tracks.setdefault(inter, {})[meta["frames"][1]] = (np.asarray(all_pred_translations[i], np.float64), 0.1)
         a, ga = float(np.ravel(all_pred_angles[i])[0]), float(np.ravel(all_gt_angles[i])[0])
         dt, lt = eval_translation(new_t[i], all_gt_translations[i])
         da, la = eval_angle(a, ga, accept_inverted_angle)
@@ -138,6 +176,8 @@ def evaluate(cfg, val_idxs, all_pred_translations, all_pred_angles, all_gt_trans
             b["mean_dist_angle"] /= n
             b["mean_sq_dist_translation"] = float(np.sqrt(b["mean_sq_dist_translation"] / n))
             b["mean_sq_dist_angle"] = float(np.sqrt(b["mean_sq_dist_angle"] / n))
+    if tracks:
+        process_velocities(tracks, eval_dir, avg_window)
     result = _summarise(measures)
     result.val = _summarise(measures["val"])
     result.test = _summarise(measures["test"])

@@ -515,11 +515,19 @@ def bn_decay_schedule(step, batch_size, ntrain, init, decay_step_epochs, rate, c
 
 
 def adam_step(w, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer: eps OUTSIDE the bias correction. t = 1,2,..."""
-    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-    m = b1 * m + (1 - b1) * g
-    v = b2 * v + (1 - b2) * g * g
-    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+    """tf.train.AdamOptimizer: eps OUTSIDE the bias correction. t = 1,2,...
+    TF evaluates the update in the variable's dtype, float32: beta, (1 - beta), epsilon and the running beta powers (one float32
+    multiplication per step) are float32 numbers -- 1 - float32(0.999) is 0.00099998713, not 0.001 -- and this restatement uses
+    exactly those constants (in whatever precision w, g, m, v come) so that step 1 is lr * g / (|g| + eps') as in TF."""
+    f = np.float32
+    b1f, b2f = f(b1), f(b2)
+    b1p, b2p = f(1), f(1)
+    for _ in range(int(t)):
+        b1p, b2p = f(b1p * b1f), f(b2p * b2f)
+    lr_t = float(f(lr)) * math.sqrt(float(f(1) - b2p)) / float(f(1) - b1p)
+    m = float(b1f) * m + float(f(1) - b1f) * g
+    v = float(b2f) * v + float(f(1) - b2f) * g * g
+    return w - lr_t * m / (np.sqrt(v) + float(f(eps))), m, v
 
 
 # --------------------------------------------------------------------------

@@ -206,7 +206,13 @@ class TorchTp8:
 
 
 def tf_adam(w, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
-    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-    m = b1 * m + (1 - b1) * g
-    v = b2 * v + (1 - b2) * g * g
-    return w - lr_t * m / (v.sqrt() + eps), m, v
+    """Same float32 constants as oracle/alignnet_ref.py adam_step (TF evaluates Adam in the variable's dtype)."""
+    f = np.float32
+    b1f, b2f = f(b1), f(b2)
+    b1p, b2p = f(1), f(1)
+    for _ in range(int(t)):
+        b1p, b2p = f(b1p * b1f), f(b2p * b2f)
+    lr_t = float(f(lr)) * math.sqrt(float(f(1) - b2p)) / float(f(1) - b1p)
+    m = float(b1f) * m + float(f(1) - b1f) * g
+    v = float(b2f) * v + float(f(1) - b2f) * g * g
+    return w - lr_t * m / (v.sqrt() + float(f(eps))), m, v

@@ -79,6 +79,88 @@ def make_dataset(root, rng, n=7):
     return files
 
 
+def make_eval_dataset(root, kind, n, rng):
+    """Only what evaluation.evaluate reads: meta/<id>.json (evaluation.py:157, 215).  kind "kitti": tracklet ids, sequence and
+    frame pairs, so that the test/val split by track id (:158-159) and the velocity tracks (:213-228, 82-110) are exercised."""
+    os.makedirs(os.path.join(root, "meta"), exist_ok=True)
+    metas = []
+    for i in range(n):
+        m = {"rel_angle": float(rng.uniform(-1, 1))}
+        if kind == "kitti":
+            track = int(rng.choice([1, 2, 3, 6, 9, 10]))
+            frame = int(rng.integers(1, 14))
+            m.update({"trackids": [track, track], "seq": int(rng.integers(0, 3)), "frames": [frame - 1, frame]})
+            if i % 7 == 0:
+                del m["seq"]            # a sample outside any track
+        json.dump(m, open(os.path.join(root, "meta", "%08d.json" % i), "w"))
+        metas.append(m)
+    return metas
+
+
+class _LegacyRaggedNumpy:
+    """evaluation.process_velocities (evaluation.py:99) builds `np.array([(vec3, dt), ...])`.  The NumPy of the reference's era
+    (< 1.24) made an object array of shape (n, 2) out of that ragged list; NumPy 2 raises.  For the fixture run only, the
+    reference module's `np` is replaced by this proxy, which retries such a call with dtype=object (same values, same shape) and
+    forwards everything else untouched."""
+
+    def __init__(self, real):
+        self._np = real
+
+    def __getattr__(self, k):
+        return getattr(self._np, k)
+
+    def array(self, obj, *a, **k):
+        try:
+            return self._np.array(obj, *a, **k)
+        except ValueError:
+            return self._np.array(obj, dtype=object)
+
+
+def eval_fixtures(tmp, evaluation, config):
+    """evaluation.evaluate of the REFERENCE (evaluation.py:128-289) on synthetic predictions: the numbers of eval.json /
+    eval_180.json and the velocity track files.  Base paths are named so that `is_test` is bound (:158-161)."""
+    rng = np.random.default_rng(777)
+    out, meta_out = {}, {}
+    cfg = config.configGlobal
+    evaluation.np = _LegacyRaggedNumpy(np)
+    for kind, dirname, n in (("synth", "SynthEvalSet", 1012), ("kitti", "KITTI_tracklets_EvalSet", 60)):
+        root = os.path.join(tmp, dirname)
+        metas = make_eval_dataset(root, kind, n, rng)
+        vars(cfg.data)["basepath"] = root
+        val = list(range(n))
+        gt_t = rng.normal(size=(n, 3)) * 0.5
+        # a mix of very good, fair and poor predictions so that all three accuracy levels are populated
+        scale = rng.choice([0.01, 0.06, 0.15, 0.6], size=(n, 1))
+        pt = gt_t + rng.normal(size=(n, 3)) * scale
+        gt_a = rng.uniform(-np.pi, np.pi, size=(n, 1))
+        pa = gt_a + rng.normal(size=(n, 1)) * rng.choice([0.005, 0.05, 0.12, 1.0], size=(n, 1)) + np.pi * (rng.uniform(size=(n, 1)) < 0.2)
+        gt_c = rng.normal(size=(n, 3)) * np.array([9.0, 9.0, 0.3])      # centroid distances 0 .. 30 m: all range buckets
+        pc = gt_c + rng.normal(size=(n, 3)) * 0.2
+        pt[5] = gt_t[5] + 20000.0                                       # dist_transl > 10000: skipped (:166-167)
+        for k, v in (("val", np.asarray(val)), ("pred_t", pt), ("pred_a", pa), ("gt_t", gt_t), ("gt_a", gt_a), ("pred_c", pc), ("gt_c", gt_c)):
+            out["%s_%s" % (kind, k)] = v
+        meta_out[kind + "_meta"] = metas
+        meta_out[kind + "_dirname"] = dirname
+        for inv in (False, True):
+            ed = os.path.join(tmp, "evalout_%s_%d" % (kind, inv))
+            res, detail = evaluation.evaluate(cfg, val, pt, pa, gt_t, gt_a, pc, gt_c, eval_dir=ed, accept_inverted_angle=inv, detailed_eval=True,
+                                              mean_time=0.25)
+            written = json.load(open(os.path.join(ed, "eval_180.json" if inv else "eval.json")))
+            assert written == evaluation.ns_to_dict(res)
+            meta_out["%s_eval_%d" % (kind, inv)] = written
+            out["%s_detail_levels_%d" % (kind, inv)] = np.array([d[0] for d in detail])
+            out["%s_detail_dists_%d" % (kind, inv)] = np.array([[d[1], d[2]] for d in detail])
+            vdir = os.path.join(ed, "velocities")
+            tracks = {}
+            if os.path.isdir(vdir):
+                for f in sorted(os.listdir(vdir)):
+                    tracks[f] = [float(x) for x in open(os.path.join(vdir, f)).read().split()]
+            meta_out["%s_velocity_files_%d" % (kind, inv)] = tracks
+    np.savez_compressed(os.path.join(HERE, "eval_vectors.npz"), **out)
+    json.dump(meta_out, open(os.path.join(HERE, "eval_vectors.json"), "w"), indent=1, sort_keys=True)
+    print("eval fixtures:", len(out), "arrays,", sum(len(meta_out[k]) for k in meta_out if "velocity" in k), "velocity files")
+
+
 def main():
     stub_modules()
     sys.path.insert(0, os.path.join(REF, "tp_utils"))
@@ -164,6 +246,8 @@ def main():
         pt, pa = rng.normal(size=(5, 3)), rng.uniform(-3, 3, 5)
         out["ttc_in_t"], out["ttc_in_a"], out["ttc_in_c"], out["ttc_in_g"] = pt, pa, ctr, gctr
         out["ttc_out"] = pointcloud.translate_transform_to_new_center_of_rotation(pt, pa, ctr, gctr)
+
+        eval_fixtures(tmp, evaluation, config)
 
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     json.dump(meta_out, open(os.path.join(HERE, "reference_vectors.json"), "w"), indent=1, sort_keys=True)

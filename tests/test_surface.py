@@ -176,3 +176,57 @@ def test_packed_cache_is_rebuilt_when_the_dataset_changes(tiny):
             os.remove(os.path.join(base, sub, new + ext))
         prov._packed = None
     assert not packed.cache_is_current(base, cache)
+
+
+# ---- evaluation.evaluate against one full run of the REFERENCE's evaluate (tests/golden/make_golden.py eval_fixtures) -----------------
+EV = np.load(os.path.join(HERE, "golden", "eval_vectors.npz"))
+EJ = json.load(open(os.path.join(HERE, "golden", "eval_vectors.json")))
+
+
+def _close(a, b, path=""):
+    if isinstance(b, dict):
+        assert isinstance(a, dict) and sorted(a) == sorted(b), path
+        for k in b:
+            _close(a[k], b[k], path + "/" + k)
+    elif isinstance(b, list):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _close(x, y, "%s[%d]" % (path, i))
+    elif isinstance(b, float):
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.parametrize("kind", ["synth", "kitti"])
+def test_evaluate_numbers_match_the_reference(tiny, tmp_path, kind):
+    """eval.json / eval_180.json as the reference's evaluation.evaluate (evaluation.py:128-289) writes them for the same predictions:
+    every accuracy level, mean / rms distance, range bucket (5 / 10 / 15 / 20 m), the val / test split (sample index >= 1000 for
+    Synth* base paths, tracklet ids for KITTI_tracklets*), the > 10 km outlier skip, the per-transform details and the velocity
+    track files (evaluation.py:82-110, 213-228)."""
+    ev, cfg = tiny["evaluation"], tiny["config"].configGlobal
+    root = os.path.join(str(tmp_path), EJ[kind + "_dirname"])
+    os.makedirs(os.path.join(root, "meta"))
+    for i, m in enumerate(EJ[kind + "_meta"]):
+        json.dump(m, open(os.path.join(root, "meta", "%08d.json" % i), "w"))
+    old = cfg.data.basepath
+    vars(cfg.data)["basepath"] = root
+    try:
+        for inv in (0, 1):
+            ed = os.path.join(str(tmp_path), "out_%s_%d" % (kind, inv))
+            res, detail = ev.evaluate(cfg, [int(v) for v in EV[kind + "_val"]], EV[kind + "_pred_t"], EV[kind + "_pred_a"], EV[kind + "_gt_t"],
+                                      EV[kind + "_gt_a"], EV[kind + "_pred_c"], EV[kind + "_gt_c"], eval_dir=ed, accept_inverted_angle=bool(inv),
+                                      detailed_eval=True, mean_time=0.25)
+            written = json.load(open(os.path.join(ed, "eval_180.json" if inv else "eval.json")))
+            _close(written, EJ["%s_eval_%d" % (kind, inv)], "eval")
+            np.testing.assert_array_equal(np.array([d[0] for d in detail]), EV["%s_detail_levels_%d" % (kind, inv)])
+            np.testing.assert_allclose(np.array([[d[1], d[2]] for d in detail]), EV["%s_detail_dists_%d" % (kind, inv)], rtol=1e-12, atol=1e-12)
+            want = EJ["%s_velocity_files_%d" % (kind, inv)]
+            vdir = os.path.join(ed, "velocities")
+            got = {f: [float(x) for x in open(os.path.join(vdir, f)).read().split()] for f in sorted(os.listdir(vdir))} if os.path.isdir(vdir) else {}
+            assert sorted(got) == sorted(want)
+            for f in want:
+                np.testing.assert_allclose(got[f], want[f], rtol=1e-12, atol=1e-15, err_msg=f)
+        assert (kind == "kitti") == bool(want)
+    finally:
+        vars(cfg.data)["basepath"] = old

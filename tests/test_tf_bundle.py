@@ -131,3 +131,119 @@ def test_engine_export_import_roundtrip(gpu_required, tmp_path):
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
     eng.close(); eng2.close()
+
+
+# ---- a checkpoint assembled byte by byte from the published formats, independently of tf_bundle.write_bundle -------------------------
+def _crc32c_bitwise(data):
+    """CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), one bit at a time: deliberately not the table code of tf_bundle."""
+    c = 0xFFFFFFFF
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 & -(c & 1))
+    return c ^ 0xFFFFFFFF
+
+
+def _masked(data):
+    c = _crc32c_bitwise(data)
+    return struct.pack("<I", (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF)   # leveldb/TF crc32c::Mask
+
+
+def _vi(v):
+    out = b""
+    while v >= 0x80:
+        out += bytes([(v & 0x7F) | 0x80])
+        v >>= 7
+    return out + bytes([v])
+
+
+def _entry(shared, key_suffix, value):
+    return _vi(shared) + _vi(len(key_suffix)) + _vi(len(value)) + key_suffix + value
+
+
+def _snappy_with_copies(raw, needle):
+    """Raw snappy stream of `raw`: literals, except that every later occurrence of `needle` becomes a copy with a 2-byte offset
+    (tag kind 2) of its first occurrence -- so the reader's copy path is exercised, not only literals."""
+    out = _vi(len(raw))
+    first = raw.index(needle)
+    pos = lit_start = 0
+
+    def literal(chunk):
+        o = b""
+        while chunk:
+            part, chunk = chunk[:60], chunk[60:]
+            o += bytes([(len(part) - 1) << 2]) + part
+        return o
+    nxt = raw.find(needle, first + len(needle))
+    while nxt != -1:
+        out += literal(raw[lit_start:nxt])
+        out += bytes([((len(needle) - 1) << 2) | 2]) + struct.pack("<H", nxt - first)
+        lit_start = nxt + len(needle)
+        nxt = raw.find(needle, lit_start)
+    return out + literal(raw[lit_start:])
+
+
+def test_reads_a_checkpoint_assembled_by_hand(tmp_path):
+    """tensorflow/core/util/tensor_bundle + tensorflow/core/lib/io/table (LevelDB table format), written out byte by byte here:
+    BundleHeaderProto / BundleEntryProto protobuf bytes, key-prefix-compressed entries, restart arrays, block trailers (type +
+    masked CRC-32C from an independent bitwise implementation), one block stored snappy-compressed with real back-references, an
+    index block of block handles, the empty metaindex block and the 48-byte footer with the table magic."""
+    w = np.arange(6, dtype="<f4").reshape(2, 3) / 7
+    adam = (np.arange(6, dtype="<f4").reshape(2, 3) + 1) / 13
+    b64 = np.array([1.5, -2.25], "<f8")
+    step = np.array(31200, "<i4")
+    blobs = [("Variable", step, 3), ("a/weights", w, 1), ("a/weights/Adam", adam, 1), ("b", b64, 2)]   # (name, array, DataType enum)
+    data, entries = b"", {}
+    for name, arr, dt in blobs:
+        raw = arr.tobytes()
+        dims = b"".join(b"\x12" + _vi(len(d)) + d for d in (b"\x08" + _vi(s) for s in arr.shape))      # repeated TensorShapeProto.Dim{size}
+        e = b"\x08" + _vi(dt)                                       # 1: dtype
+        e += b"\x12" + _vi(len(dims)) + dims                        # 2: shape
+        if len(data):
+            e += b"\x20" + _vi(len(data))                           # 4: offset (0 is the proto3 default and is omitted)
+        e += b"\x28" + _vi(len(raw))                                # 5: size
+        e += b"\x35" + _masked(raw)                                 # 6: crc32c, fixed32 (masked)
+        entries[name] = e
+        data += raw
+    header = b"\x08\x01" + b"\x1a\x02\x08\x01"                      # num_shards = 1; version { producer = 1 }; endianness LITTLE = 0 omitted
+    one_restart = struct.pack("<II", 0, 1)                          # restart offsets [0], count 1
+    block1 = _entry(0, b"", header) + _entry(0, b"Variable", entries["Variable"]) + one_restart
+    block2 = (_entry(0, b"a/weights", entries["a/weights"]) + _entry(9, b"/Adam", entries["a/weights/Adam"]) +   # shares "a/weights"
+              _entry(0, b"b", entries["b"]) + one_restart)
+    comp2 = _snappy_with_copies(block2, b"\x12\x02\x08")            # the Dim sub-message prefix occurs in every entry
+    assert len(comp2) < len(block2) + 8 and tb._snappy_decompress(comp2) == block2
+    out = b""
+
+    def emit(body, ctype):
+        nonlocal out
+        off = len(out)
+        out += body + bytes([ctype]) + _masked(body + bytes([ctype]))
+        return _vi(off) + _vi(len(body))
+    h1 = emit(block1, 0)
+    h2 = emit(comp2, 1)
+    hmeta = emit(one_restart, 0)
+    index = _entry(0, b"Variable", h1) + _entry(0, b"c", h2) + struct.pack("<III", 0, len(_entry(0, b"Variable", h1)), 2)   # "c" >= every key of block 2
+    hidx = emit(index, 0)
+    footer = hmeta + hidx
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    prefix = str(tmp_path / "model-199")
+    open(prefix + ".index", "wb").write(out)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    ents, hdr = tb.read_index(prefix)
+    assert sorted(ents) == ["Variable", "a/weights", "a/weights/Adam", "b"] and hdr[1] == [1]
+    assert ents["a/weights/Adam"]["shape"] == (2, 3) and ents["a/weights/Adam"]["offset"] == 4 + 24
+    got = tb.read_bundle(prefix)
+    assert got["Variable"].dtype == np.int32 and got["Variable"].shape == () and int(got["Variable"]) == 31200
+    np.testing.assert_array_equal(got["a/weights"], w)
+    np.testing.assert_array_equal(got["a/weights/Adam"], adam)
+    np.testing.assert_array_equal(got["b"], b64)
+    assert got["b"].dtype == np.float64
+    # the writer must produce what this independent reader-side knowledge expects as well: same CRCs, same entry bytes
+    assert tb.mask_crc(tb.crc32c(data)) == struct.unpack("<I", _masked(data))[0]
+    assert tb._make_entry(1, (2, 3), 4, 24, struct.unpack("<I", _masked(w.tobytes()))[0]) == entries["a/weights"]
+    # one flipped byte inside the compressed block is caught by the block checksum
+    bad = bytearray(out)
+    bad[len(block1) + 5 + 3] ^= 0x40
+    open(prefix + ".index", "wb").write(bad)
+    with pytest.raises(ValueError, match="checksum"):
+        tb.read_index(prefix)
