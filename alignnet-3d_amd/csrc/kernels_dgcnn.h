@@ -350,18 +350,31 @@ template <int LD0 = 0, int LD1 = 0>
       if (item < CTE * 2) {
         const int m = item & 1;
         const float* arow = in + (m * 32 + (lane & 31)) * ldi + (lane >> 5) * 4;
-        f32x4 av[8];
-#pragma unroll
-        for (int kg = 0; kg < 8; ++kg) av[kg] = *reinterpret_cast<const f32x4*>(arow + min(kg, KG - 1) * 8);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (LD0) {
+          // shipped shape, 128-VGPR budget (two workgroups per CU): the A operands are requested two k-groups ahead instead of all
+          // eight up front (32 registers -> 12); an LDS round trip is ~1/4 of the 512 cycles two k-groups of MFMAs take
+          f32x4 a0 = *reinterpret_cast<const f32x4*>(arow), a1 = *reinterpret_cast<const f32x4*>(arow + 8), a2;
+#pragma unroll
+          for (int kg = 0; kg < 8; ++kg) {
+            if (kg + 2 < 8) a2 = *reinterpret_cast<const f32x4*>(arow + (kg + 2) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], breg[s][kg][q], acc, 0, 0, 0);
+            a0 = a1; a1 = a2;
+          }
+        } else {
+        f32x4 av[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) av[kg] = *reinterpret_cast<const f32x4*>(arow + min(kg, KG - 1) * 8);
 #pragma unroll
         for (int kg = 0; kg < 8; ++kg)
           if (kg < KG) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg][q], breg[s][kg][q], acc, 0, 0, 0);
           }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) best[s][r] = fmaxf(best[s][r], fmaf(acc[r], esc[s], esh[s]));
       }

@@ -109,7 +109,7 @@ def test_bf16_training_learns_like_fp32(gpu_required):
     """BASELINE.json configs[2]: with the 128 -> C3 lifts on bf16 MFMA the network must still learn.  120 Adam steps on fresh
     synthetic batches (64 pairs x 512 points, SynthCars widths) from the same initialisation and the same batch sequence:
     both runs must cut the training loss by >= 30 % (mean of the first vs the last 10 steps), end within 15 % of each other,
-    and give finite eval-mode predictions whose held-out translation error is within 25 % of each other (the two
+    and give finite eval-mode predictions whose held-out translation errors are within a factor of two of each other (the two
     trajectories diverge step by step, so only the trend is comparable)."""
     Bs, Ns, steps = 64, 512, 120
     cfg = alignnet3d.default_model_config()
@@ -134,7 +134,9 @@ def test_bf16_training_learns_like_fp32(gpu_required):
     for mode in (0, 1):
         assert final[mode][1] < 0.7 * final[mode][0], final
     assert abs(final[1][1] - final[0][1]) < 0.15 * final[0][1], final
-    assert final[1][2] < 1.25 * final[0][2] + 0.02, final
+    # held-out error after only 120 steps is a noisy statistic of a chaotic trajectory: the fp32 run alone moved from 0.62 to 0.39 when
+    # the optimiser's constants changed in the 7th digit (round 2).  Bound: within a factor of two of each other.
+    assert final[1][2] < 2.0 * final[0][2] + 0.05 and final[0][2] < 2.0 * final[1][2] + 0.05, final
 
 
 def test_dgcnn_training_learns(gpu_required):
