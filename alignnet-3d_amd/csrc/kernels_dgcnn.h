@@ -207,6 +207,12 @@ struct DgcnnArgs {
 };
 #define DG_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
+#ifndef DGLB
+#define DGLB 4
+#endif
+#ifndef DG_LIFTPRIO
+#define DG_LIFTPRIO 1   // measured (tools/ab_dgcnn_variants.sh): 0.777 -> 0.789 of the fp32-MFMA roofline at N = 4096; 3 gives the same
+#endif
 constexpr int kDgTile = 64;   // points per workgroup (two 32-row MFMA tiles)
 
 // LDS: es [64][8] | buf0 [64][ld0] | buf1 [64][ld1] | buf0' [64][ld0] (second lift buffer)
@@ -220,6 +226,15 @@ __device__ __forceinline__ void dg_gather(const DgcnnArgs& a, const float* pc, i
   const float* pj = pc + (size_t)j * 3;
   v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
   v[3] = pj[0] - p[0]; v[4] = pj[1] - p[1]; v[5] = pj[2] - p[2];
+}
+
+// software-pipelined form of the gather: the neighbour INDEX of slot s + 2 and the neighbour POINT of slot s + 1 are requested
+// at the top of slot s, so no load of a slot depends on another load of the same slot (index -> point was two exposed global
+// round trips in front of the edge features of every slot); the thread's own point is loaded once per tile.
+__device__ __forceinline__ int dg_nn_index(const DgcnnArgs& a, int cloud, int tile, int slot, int tid)
+{
+  const int n = min(tile * kDgTile + tid, a.N - 1);
+  return a.nn[((size_t)cloud * a.N + n) * a.k + min(slot, a.k - 1)];
 }
 
 __device__ __forceinline__ void dg_edge_to_lds(const float* xf, const float (&v)[6], float* e)
@@ -254,7 +269,7 @@ __device__ __forceinline__ DgLiftRegs dg_lift_load(const ConvLayerDev& L, int to
 }
 
 __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const float* es, float* out, int ldo, int tid,
-                                        const DgLiftRegs* regs = nullptr)
+                                        const DgLiftRegs* regs = nullptr, const float* wl = nullptr)
 {
   const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (L.cout + 7) & ~7;
@@ -263,7 +278,10 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     const int g = (c - c0) >> 5;
     float w[6];
     float sc, sh;
-    if (regs && g < 2) {
+    if (wl) {   // the layer's [w0..w5, scale, shift] rows staged in LDS by the caller (two 16-byte reads per channel)
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(wl + c * 8), q1 = *reinterpret_cast<const f32x4*>(wl + c * 8 + 4);
+      w[0] = q0[0]; w[1] = q0[1]; w[2] = q0[2]; w[3] = q0[3]; w[4] = q1[0]; w[5] = q1[1]; sc = q1[2]; sh = q1[3];
+    } else if (regs && g < 2) {
 #pragma unroll
       for (int d = 0; d < 6; ++d) w[d] = g ? regs->w[1][d] : regs->w[0][d];
       sc = g ? regs->sc[1] : regs->sc[0]; sh = g ? regs->sh[1] : regs->sh[0];
@@ -288,7 +306,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 // LD0 / LD1 != 0: the shipped shape compiled in -- widths [LD0 - 4, LD1 - 4, C3], three layers -- so that LDS strides, k-depths
 // and tile counts are constants (as for pointnet_fused: fewer address registers, no generic layer dispatch)
 template <int LD0 = 0, int LD1 = 0>
-[[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, LD0 ? 4 : 2) void dgcnn_fused(const DgcnnArgs a)
+[[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, LD0 ? DGLB : 2) void dgcnn_fused(const DgcnnArgs a)
 {
   const int ld0 = LD0 ? LD0 : a.ld[0], ld1 = LD1 ? LD1 : a.ld[1];
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,8 +317,13 @@ template <int LD0 = 0, int LD1 = 0>
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* es = smem;                                   // edge features of the slot being lifted
-  const int boff[2] = {kDgTile * 8, kDgTile * 8 + kDgTile * ld0};
-  const int boff0b = kDgTile * 8 + kDgTile * (ld0 + ld1);   // second lift buffer
+  // generic: es | buf0 | buf1 | buf0'.  Shipped shape (LD0): es | buf0 | buf0' | lift table [64][8] | W2 image [4][8][64][4], and
+  // buf1 (the pooled edge features, written after the neighbour loop when both lift buffers are dead) aliases buf0 / buf0'.
+  const int boff[2] = {kDgTile * 8, LD0 ? kDgTile * 8 : kDgTile * 8 + kDgTile * ld0};
+  const int boff0b = LD0 ? kDgTile * 8 + kDgTile * ld0 : kDgTile * 8 + kDgTile * (ld0 + ld1);   // second lift buffer
+  constexpr int kWlOff = kDgTile * 8 + kDgTile * 2 * (LD0 ? LD0 : 1);      // shipped shape only
+  constexpr int kW2Off = kWlOff + 64 * 8;
+  static_assert(!LD0 || kDgTile * LD1 <= 2 * kDgTile * LD0, "the pooled edge features must fit the two lift buffers they alias");
   const int nl = LD0 ? 3 : a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
   const int nvalid = min(kDgTile, a.N - tile * kDgTile);
   const bool two_edge_layers = nl == 3;               // pipelined path: lift (VALU) + one MFMA edge layer
@@ -321,7 +344,15 @@ template <int LD0 = 0, int LD1 = 0>
   // 8 k-groups x float4 are loaded once per workgroup instead of once per neighbour slot.
   const bool wreg = two_edge_layers && le_cin <= 64;
   f32x4 breg[kSlots][8];
-  if (wreg) {
+  if (LD0) {
+    // shipped shape: the 64 -> 128 layer's weight image (4 channel tiles x 8 k-groups x 1 KiB) is staged in LDS once per workgroup
+    // and every wave reads its item's fragments from there in each neighbour slot.  Keeping them in 32 registers per lane (the
+    // generic path below) does not fit the 128-VGPR budget of two workgroups per CU: it cost 12 spill slots per lane.
+    const f32x4* src = reinterpret_cast<const f32x4*>(LE.w);
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + kW2Off);
+#pragma unroll
+    for (int i = 0; i < (4 * 8 * 64) / (kWaves * 64); ++i) dst[i * kWaves * 64 + tid] = src[i * kWaves * 64 + tid];
+  } else if (wreg) {
     const int KG = (le_cin + 7) >> 3;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -354,15 +385,15 @@ template <int LD0 = 0, int LD1 = 0>
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if (LD0) {
-          // shipped shape, 128-VGPR budget (two workgroups per CU): the A operands are requested two k-groups ahead instead of all
-          // eight up front (32 registers -> 12); an LDS round trip is ~1/4 of the 512 cycles two k-groups of MFMAs take
-          f32x4 a0 = *reinterpret_cast<const f32x4*>(arow), a1 = *reinterpret_cast<const f32x4*>(arow + 8), a2;
+          if (s == 0) {   // 8 items = 8 waves: the second slot does not exist for C2 = 128
+            const f32x4* bl = reinterpret_cast<const f32x4*>(smem + kW2Off) + (item >> 1) * 8 * 64 + lane;
+            f32x4 av[8], bv[8];
 #pragma unroll
-          for (int kg = 0; kg < 8; ++kg) {
-            if (kg + 2 < 8) a2 = *reinterpret_cast<const f32x4*>(arow + (kg + 2) * 8);
+            for (int kg = 0; kg < 8; ++kg) { av[kg] = *reinterpret_cast<const f32x4*>(arow + kg * 8); bv[kg] = bl[kg * 64]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], breg[s][kg][q], acc, 0, 0, 0);
-            a0 = a1; a1 = a2;
+            for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg][q], bv[kg][q], acc, 0, 0, 0);
           }
         } else {
         f32x4 av[8];
@@ -400,24 +431,59 @@ template <int LD0 = 0, int LD1 = 0>
     // (A one-barrier variant that issued the VALU lift behind the wave's own MFMAs measured 13 % slower: a wave
     //  issues in order, so only OTHER waves' VALU work overlaps its MFMAs.)
     float v[6];
-    if (tid < kDgTile) { dg_gather(a, pc, cloud, tile, 0, tid, v); dg_edge_to_lds(xf, v, es + tid * 8); }
+    float own[3] = {0.f, 0.f, 0.f}, nb[3] = {0.f, 0.f, 0.f};
+    int jn = 0;   // neighbour index of the slot after next
+    if (tid < kDgTile) {
+      dg_gather(a, pc, cloud, tile, 0, tid, v);
+      own[0] = v[0]; own[1] = v[1]; own[2] = v[2];
+      jn = dg_nn_index(a, cloud, tile, 1, tid);
+      dg_edge_to_lds(xf, v, es + tid * 8);
+    }
+    // shipped shape (128-VGPR budget): the lift's weights / scale / shift live in LDS ([C1][8] floats behind the activation
+    // buffers) instead of 16 registers per thread -- with them the kernel needed 12 spill slots per lane, i.e. 44 B x 512 threads
+    // of scratch written once by each of the 65 k workgroups of a launch (1.3 GB of HBM writes, profiles/r01_dgcnn_pmc_by_kernel.json)
+    float* wl = LD0 ? smem + kWlOff : nullptr;
+    if (LD0 && tid < (LD0 - 4)) {
+      const ConvLayerDev& L0 = a.L[0];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) wl[tid * 8 + d] = L0.w[d * L0.cout + tid];
+      wl[tid * 8 + 6] = L0.scale[tower * L0.cout + tid];
+      wl[tid * 8 + 7] = L0.shift[tower * L0.cout + tid];
+    }
     __syncthreads();
-    const DgLiftRegs lregs = dg_lift_load(a.L[0], tower, tid);
-    dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, &lregs);
+    DgLiftRegs lregs;
+    if (!LD0) lregs = dg_lift_load(a.L[0], tower, tid);
+    dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, LD0 ? nullptr : &lregs, wl);
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
       if (slot == 5) DG_STAMP(0);
-      if (more && tid < kDgTile) dg_gather(a, pc, cloud, tile, slot + 1, tid, v);        // in flight during the MFMAs
+      if (more && tid < kDgTile) {                    // in flight during the MFMAs: x_j of slot + 1 (index already here), index of slot + 2
+        const float* pj = pc + (size_t)jn * 3;
+        nb[0] = pj[0]; nb[1] = pj[1]; nb[2] = pj[2];
+        jn = dg_nn_index(a, cloud, tile, slot + 2, tid);
+        asm volatile("" ::: "memory");                // keep the four requests in front of the MFMAs (hipcc sinks loads to their use)
+      }
       if (wreg) edge_mfma_reg(smem + ((slot & 1) ? boff0b : boff[0]), ld0);
       else edge_mfma(smem + ((slot & 1) ? boff0b : boff[0]), ld0);
       if (slot == 5) DG_STAMP(1);
-      if (more && tid < kDgTile) dg_edge_to_lds(xf, v, es + tid * 8);
+#if DG_LIFTPRIO
+      // the VALU / LDS phases of a slot run at raised priority: the co-resident workgroup's MFMA stream needs one issue slot per 64
+      // cycles and loses nothing, while a lift issued at equal priority next to it took 3x its stand-alone time
+      __builtin_amdgcn_s_setprio(DG_LIFTPRIO);
+#endif
+      if (more && tid < kDgTile) {
+        v[0] = own[0]; v[1] = own[1]; v[2] = own[2]; v[3] = nb[0] - own[0]; v[4] = nb[1] - own[1]; v[5] = nb[2] - own[2];
+        dg_edge_to_lds(xf, v, es + tid * 8);
+      }
       if (slot == 5) DG_STAMP(2);
       __syncthreads();
       if (slot == 5) DG_STAMP(3);
-      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, &lregs);
+      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, LD0 ? nullptr : &lregs, wl);
       if (slot == 5) DG_STAMP(4);
+#if DG_LIFTPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __syncthreads();
       if (slot == 5) DG_STAMP(5);
     }
@@ -474,9 +540,13 @@ template <int LD0 = 0, int LD1 = 0>
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     for (int ct = wave; ct < CT; ct += kWaves) {
       f32x16 acc[2];
-      // (the 128-VGPR instantiation spills a few registers: compiler-managed weight loads there, the hand-issued stream
-      //  is only safe in spill-free kernels)
-      if (LD0) mfma_rows<2, true, false>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+#ifndef DG_PC
+#define DG_PC 0
+#endif
+      // shipped shape: four waves per SIMD -- variant chosen by measurement (DG_PC: 0 compiler-managed loads, 1 hand-issued stream,
+      // 2 compiler-managed three k-groups deep); the generic instantiation (two waves per SIMD) keeps the hand-issued stream
+      if (LD0 && DG_PC == 0) mfma_rows<2, true, false>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
+      else if (LD0 && DG_PC == 2) mfma_rows_deep<2>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
       else mfma_rows<2>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc);
       const int col = ct * 32 + (lane & 31);
       const bool live = col < L.cout;

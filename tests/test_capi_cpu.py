@@ -70,3 +70,29 @@ def test_unbuilt_loss_variants_are_rejected():
     cfg["training"]["loss"] = {"loss": "separate", "options": {"soft_angle_classes": True}}
     with pytest.raises(AssertionError, match="soft_angle_classes"):
         make_c_config(cfg)
+
+
+def test_inference_kernels_are_spill_free():
+    """The fused inference backbones issue their weight stream by hand (inline-asm global loads retired with counted waits,
+    csrc/kernels_infer.h mfma_rows): a register the allocator spills or re-assigns while such a load is in flight is silently
+    corrupted, so these kernels must stay spill-free -- and scratch written once per workgroup was 1.3 GB of HBM traffic per
+    dgcnn_fused launch in round 1.  The build keeps hipcc's per-kernel resource remarks next to the objects (csrc/Makefile)."""
+    import re
+    path = os.path.join(ROOT, "alignnet-3d_amd", "csrc", "alignnet_api.remarks")
+    if not os.path.exists(path):
+        pytest.skip("no resource remarks next to the objects (library built by an older Makefile)")
+    text = open(path).read()
+    rows = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)",
+                      text, re.S)
+    seen = {}
+    for name, vgpr, scratch, occ, spill in rows:
+        for key in ("pointnet_fused", "dgcnn_fused", "pointnet_split", "dgcnn_split", "fc_mfma", "knn_kernel"):
+            if key in name:
+                seen.setdefault(key, []).append((name, int(vgpr), int(scratch), int(occ), int(spill)))
+    assert set(seen) == {"pointnet_fused", "dgcnn_fused", "pointnet_split", "dgcnn_split", "fc_mfma", "knn_kernel"}, sorted(seen)
+    for key, lst in seen.items():
+        for name, vgpr, scratch, occ, spill in lst:
+            assert spill == 0 and scratch == 0, (name, vgpr, scratch, spill)
+    # the shipped-shape DGCNN kernel runs two workgroups of eight waves per CU: <= 128 registers per lane
+    shipped = [r for r in seen["dgcnn_fused"] if "Li68ELi132E" in r[0]]
+    assert shipped and shipped[0][1] <= 128 and shipped[0][3] >= 4, shipped
