@@ -5,6 +5,7 @@
 #include "kernels_train_head.h"
 #include "kernels_train_bwd.h"
 #include "kernels_train_dgcnn.h"
+#include "kernels_train_generic.h"
 
 #include <algorithm>
 #include <cmath>
@@ -80,6 +81,11 @@ struct TrainWS {
   unsigned short* q3imgh = nullptr;   // bf16 images of Q3, both towers (train_bf16)
   unsigned short* wp2h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the hidden layers (train_bf16, no sign folding)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
+  // general-depth PointNet stages (kernels_train_generic.h): pre-BatchNorm activations of every layer stay in HBM
+  struct GenStage { float* X0; float* Z[kMaxConv]; float *mean[kMaxConv], *rstd[kMaxConv], *scale[kMaxConv], *shift[kMaxConv]; int* idx; } gen[3];
+  float *gen_d[2] = {nullptr, nullptr};   // gradient ping-pong buffers [2B*N][widest layer]
+  float *gen_part = nullptr, *gen_dwpart = nullptr, *gen_ppart = nullptr, *gen_cA = nullptr, *gen_cB = nullptr, *gen_wt = nullptr;
+  int gen_tiles = 0, gen_slabs = 0;
 };
 
 }  // namespace alignnet
@@ -121,15 +127,37 @@ static float* G(alignnet_handle* h, TrainWS* w, int pidx) { return w->grad + h->
 
 static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 7) / 8) * 256; }
 
+// A PointNet stage outside the shape the specialised kernels are built for (three conv layers, widths multiples of 32, C1, C2 <= 128,
+// C3 <= 1024) trains on the general layer-by-layer path -- e.g. the five-layer backbones of the reference's configs/default.json.
+static bool stage_generic(const alignnet_handle* h, int s)
+{
+  if (h->cfg.backbone == 1) return false;
+  const Stack& st = conv_of(h, s);
+  if (st.n != 3) return true;
+  const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
+  return C1 % 32 || C2 % 32 || C3 % 32 || C1 > 128 || C2 > 128 || C3 > 1024;
+}
+
 static int check_trainable_shape(alignnet_handle* h)
 {
   const bool dg = h->cfg.backbone == 1;
+  for (int s = 0; s < 3 && !dg; ++s)
+    if (stage_generic(h, s)) {
+      const Stack& st = conv_of(h, s);
+      for (int i = 0; i < st.n; ++i) {
+        const Layer& L = h->layers[st.first + i];
+        if (L.cout % 8) return fail(h, "training: conv widths must be multiples of 8 (layer " + L.name + ")");
+        if (L.cout > (i + 1 < st.n ? kGenMaxK : 4096))
+          return fail(h, "training (general-depth path): hidden conv widths are limited to " + std::to_string(kGenMaxK) + " channels, the last to 4096 (layer " + L.name + ")");
+      }
+    }
   if (dg && h->train_bf16) return fail(h, "training: the dgcnn backbone trains in fp32 only (unset train_matmul_bf16)");
   if (dg && (h->cfg.num_points > 64 * kKnnMaxPerLane || h->cfg.num_points < kDgK))
     return fail(h, "training: dgcnn needs 20 <= num_points <= 4096");
   for (int s = 0; s < 3; ++s) {
     const Stack& st = conv_of(h, s);
-    if (st.n != 3) return fail(h, "training supports 3-conv-layer backbones (all shipped dataset configs); got " + std::to_string(st.n));
+    if (stage_generic(h, s)) continue;
+    if (st.n != 3) return fail(h, "training: the dgcnn backbone supports 3-conv-layer stages; got " + std::to_string(st.n));
     const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
     if (C1 % 32 || C2 % 32 || C3 % 32) return fail(h, "training: conv widths must be multiples of 32");
     if (C1 > 128 || C2 > 128 || C3 > 1024) return fail(h, "training: conv widths limited to C1,C2 <= 128, C3 <= 1024");
@@ -162,8 +190,18 @@ static int ensure_train_ws(alignnet_handle* h, int B)
   const int N = h->cfg.num_points, nb2 = 2 * h->cfg.num_bins;
   const size_t B2 = 2 * (size_t)B, MN = B2 * N;
   int maxC = 8, maxC1 = 8, maxC2 = 8, maxC3 = 8, maxH = 8;
+  int genC = 0, genK = 8;   // widest layer / widest MFMA-layer input of the general-depth stages
   for (int s = 0; s < 3; ++s) {
     const Stack& st = conv_of(h, s);
+    {
+      const Stack& fs = fc_of(h, s);
+      for (int j = 0; j < fs.n; ++j) maxH = std::max(maxH, h->layers[fs.first + j].cout);
+    }
+    if (stage_generic(h, s)) {
+      for (int i = 0; i < st.n; ++i) { genC = std::max(genC, h->layers[st.first + i].cout); if (i) genK = std::max(genK, h->layers[st.first + i].cin); }
+      maxC3 = std::max(maxC3, h->layers[st.first + st.n - 1].cout);
+      continue;
+    }
     maxC1 = std::max(maxC1, h->layers[st.first].cout);
     maxC2 = std::max(maxC2, h->layers[st.first + 1].cout);
     maxC3 = std::max(maxC3, h->layers[st.first + 2].cout);
@@ -188,13 +226,26 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->center_mean = F(B2 * 3); w->s1c = F(B2 * 3); w->s2c = F(B2 * 3); w->theta = F(B2); w->cls = I(B2);
     for (int s = 0; s < 3; ++s) {
       const Stack& st = conv_of(h, s);
-      const int C[3] = {h->layers[st.first].cout, h->layers[st.first + 1].cout, h->layers[st.first + 2].cout};
+      const bool gen = stage_generic(h, s);
+      // specialised stages: [C1, C2, C3]; general-depth stages only need the stage interface (frame, pooled output and its gradient,
+      // frame gradients), sized by the LAST layer's width
+      const int Cl = h->layers[st.first + st.n - 1].cout;
+      const int C[3] = {gen ? 8 : h->layers[st.first].cout, gen ? 8 : h->layers[st.first + 1].cout, Cl};
       StageWS& S = w->st[s];
       S.xform = F(B2 * 12);
+      if (gen) {
+        TrainWS::GenStage& Gs = w->gen[s];
+        Gs.X0 = F(MN * 4);
+        for (int i = 0; i < st.n; ++i) {
+          const int c = h->layers[st.first + i].cout;
+          Gs.Z[i] = F(MN * c); Gs.mean[i] = F(2 * c); Gs.rstd[i] = F(2 * c); Gs.scale[i] = F(2 * c); Gs.shift[i] = F(2 * c);
+        }
+        Gs.idx = I(B2 * Cl);
+      }
       for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); S.rstd[l] = F(2 * C[l]); S.kk[l] = F(2 * C[l]); }
       S.sgn3 = F(2 * C[2]);
       S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
-      S.h2 = F(MN * C[1]);
+      S.h2 = F(gen ? 8 : MN * C[1]);
       S.gram2 = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
       S.pooled = F(B2 * C[2]); S.dP = F(B2 * C[2]);
       if (s < 2) { S.tower_stride = (long)B * C[2]; S.row_stride = C[2]; }
@@ -202,6 +253,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.gx = F(B2 * 3); S.grot = F(B2);
       const bool dgb = h->cfg.backbone == 1;
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
+      (void)gen;
       S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]); S.g1f = F(2 * (size_t)C[0] * C[0]);
       const Stack& fs = fc_of(h, s);
       const size_t M = s < 2 ? B2 : (size_t)B;
@@ -213,6 +265,16 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       const int ow = h->layers[fs.first + fs.n - 1].cout;
       w->o[s] = F(M * ow); w->d_o[s] = F(M * ow);
       w->head_din[s] = S.dP;
+    }
+    if (genC) {
+      const size_t M1 = (size_t)B * N;
+      w->gen_tiles = (int)((M1 + kGenTile - 1) / kGenTile); w->gen_slabs = (int)((M1 + kGenSlab - 1) / kGenSlab);
+      w->gen_d[0] = F(MN * genC); w->gen_d[1] = F(MN * genC);
+      w->gen_part = F((size_t)2 * w->gen_tiles * genC * 2);
+      w->gen_dwpart = F((size_t)2 * w->gen_slabs * genK * genC);
+      w->gen_ppart = F(B2 * 3 * (size_t)genC);
+      w->gen_cA = F(2 * genC); w->gen_cB = F(2 * genC);
+      w->gen_wt = F(img_floats(genC, genK) + 1024);
     }
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
@@ -245,7 +307,8 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     std::vector<PackJob> jobs;
     for (int s = 0; s < 3; ++s) {
       const Stack& st = conv_of(h, s);
-      const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout;
+      const bool gen = stage_generic(h, s);   // (general-depth stages do not use these images: harmless 8 x 8 jobs keep the table's layout)
+      const int C1 = gen ? 8 : h->layers[st.first].cout, C2 = gen ? 8 : h->layers[st.first + 1].cout;
       const size_t qimg = img_floats(C2, C2), vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
       for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q3 + (size_t)t * C2 * C2, w->q3img + t * qimg, C2, C2});
       for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q2 + (size_t)t * C1 * C1, w->q2img + t * q2img, C1, C1});
@@ -308,6 +371,7 @@ static int pack_all_weights(alignnet_handle* h)
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
   if (h->train_bf16)
     for (int s = 0; s < 3; ++s) {
+      if (stage_generic(h, s)) continue;   // the general-depth path computes in fp32 whatever the option says
       const Layer& L = h->layers[conv_of(h, s).first + 2];
       const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;   // per tower (sign of its gamma folded in)
       if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], 2 * n * sizeof(unsigned short)));
@@ -359,10 +423,93 @@ static int set_lds_attrs(alignnet_handle* h)
 }
 
 // ---------------------------------------------------------------------------------
+// general-depth PointNet stage (kernels_train_generic.h): forward with batch statistics, then backward
+// ---------------------------------------------------------------------------------
+static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema)
+{
+  TrainWS* w = tws(h);
+  StageWS& S = w->st[s];
+  TrainWS::GenStage& Gs = w->gen[s];
+  const Stack& st = conv_of(h, s);
+  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
+  for (int l = 0; l < st.n; ++l) {
+    const Layer& L = h->layers[st.first + l];
+    if (l == 0) {
+      GenL1Args a{Gs.X0, P(h, L.p_w), P(h, L.p_b), Gs.Z[0], w->gen_part, M, L.cout, tiles};
+      hipLaunchKernelGGL(gen_layer1_fwd, dim3(tiles, 2), dim3(256), 0, h->stream, a);
+    } else {
+      GenGemmArgs a{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], h->d_wp + L.off_wp, P(h, L.p_b), Gs.Z[l], w->gen_part, M, L.cin, L.cout, tiles};
+      hipLaunchKernelGGL(gen_gemm_fwd, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * (L.cin + 4) * sizeof(float), h->stream, a);
+    }
+    GenStatArgs f;
+    f.part = w->gen_part; f.tiles = tiles; f.M = M; f.C = L.cout;
+    for (int t = 0; t < 2; ++t) {
+      f.beta[t] = P(h, L.p_bn[t][0]); f.gamma[t] = P(h, L.p_bn[t][1]); f.mov_mean[t] = P(h, L.p_bn[t][2]); f.mov_var[t] = P(h, L.p_bn[t][3]);
+    }
+    f.bn_decay = bn_decay; f.update_ema = update_ema;
+    f.mean = Gs.mean[l]; f.rstd = Gs.rstd[l]; f.scale = Gs.scale[l]; f.shift = Gs.shift[l];
+    hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(256), 0, h->stream, f);
+  }
+  const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
+  GenPoolArgs pa{Gs.Z[Ll], Gs.scale[Ll], Gs.shift[Ll], B, N, Cl, S.pooled, S.tower_stride, S.row_stride, Gs.idx};
+  hipLaunchKernelGGL(gen_pool_fwd, dim3(2 * B, (Cl + 63) / 64), dim3(256), 0, h->stream, pa);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
+{
+  TrainWS* w = tws(h);
+  StageWS& S = w->st[s];
+  TrainWS::GenStage& Gs = w->gen[s];
+  const Stack& st = conv_of(h, s);
+  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles, slabs = w->gen_slabs;
+  const size_t R = (size_t)2 * M;
+  const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
+  float* dY = w->gen_d[0];
+  float* dYprev = w->gen_d[1];
+  HIP_TRY(h, hipMemsetAsync(dY, 0, R * Cl * sizeof(float), h->stream));
+  hipLaunchKernelGGL(gen_pool_bwd, dim3((unsigned)(((size_t)2 * B * Cl + 255) / 256)), dim3(256), 0, h->stream, S.dP, S.tower_stride, S.row_stride, Gs.idx, B, N, Cl, dY);
+  for (int l = Ll; l >= 0; --l) {
+    const Layer& L = h->layers[st.first + l];
+    const int C = L.cout, K = L.cin;
+    GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, M, C, tiles};
+    hipLaunchKernelGGL(gen_bn_bwd_reduce, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);
+    GenBnFinArgs f{w->gen_part, tiles, M, C, {G(h, w, L.p_bn[0][0]), G(h, w, L.p_bn[1][0])}, {G(h, w, L.p_bn[0][1]), G(h, w, L.p_bn[1][1])}, w->gen_cA, w->gen_cB};
+    hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(gen_bn_bwd_apply, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);   // dY is dZ_l from here on
+    if (l == 0) {
+      GenL1BwdArgs a{Gs.X0, dY, P(h, L.p_w), B, N, C, w->gen_ppart, S.gx, S.grot};
+      hipLaunchKernelGGL(gen_layer1_bwd, dim3(2 * B), dim3(256), 0, h->stream, a);
+      hipLaunchKernelGGL(gen_sum_partials, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, h->stream, w->gen_ppart, 2 * B, (size_t)3 * C, G(h, w, L.p_w));
+      break;
+    }
+    GenDwArgs dw{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], dY, w->gen_dwpart, M, K, C, slabs};
+    hipLaunchKernelGGL(gen_gemm_dw, dim3(slabs, 2, (C + 63) / 64), dim3(kGenWaves * 64), ((size_t)kGenTile * K + kGenTile * 64) * sizeof(float), h->stream, dw);
+    hipLaunchKernelGGL(gen_sum_partials, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, h->stream, w->gen_dwpart, 2 * slabs, (size_t)K * C, G(h, w, L.p_w));
+    hipLaunchKernelGGL(gen_pack_transposed, dim3(64), dim3(256), 0, h->stream, P(h, L.p_w), K, C, w->gen_wt);
+    GenDxArgs dx{dY, w->gen_wt, dYprev, M, K, C};
+    hipLaunchKernelGGL(gen_gemm_dx, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * 132 * sizeof(float), h->stream, dx);
+    std::swap(dY, dYprev);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // backbone forward (training mode) for stage s
 // ---------------------------------------------------------------------------------
 static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema)
 {
+  if (stage_generic(h, s)) return backbone_fwd_generic(h, s, p1, p2, B, bn_decay, update_ema);
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
   const Stack& st = conv_of(h, s);
@@ -639,6 +786,7 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
 // ---------------------------------------------------------------------------------
 static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B)
 {
+  if (stage_generic(h, s)) return backbone_bwd_generic(h, s, B);
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
   const Stack& st = conv_of(h, s);
@@ -847,7 +995,9 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
     for (int s = 0; s < 3; ++s) std_all = std_all && h->layers[conv_of(h, s).first].cout == 64 && h->layers[conv_of(h, s).first + 1].cout == 128;
-    h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0);
+    bool any_gen = false;
+    for (int s = 0; s < 3; ++s) any_gen = any_gen || stage_generic(h, s);
+    h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0) | (any_gen ? 8 : 0);
   }
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;
@@ -882,7 +1032,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (!do_backward) return 0;
 
   // ---- backward ----
-  const int CE = h->layers[h->emb_conv.first + 2].cout;
+  const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   h->comm_buckets = 0;
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
@@ -890,7 +1040,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
                      B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
   hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
-  const int C2l = h->layers[h->s2_conv.first + 2].cout, C1l = h->layers[h->s1_conv.first + 2].cout;
+  const int C2l = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout, C1l = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
   if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
   if (comm_overlap && comm_bucket(h, 1)) return 1;

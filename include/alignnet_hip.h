@@ -143,7 +143,9 @@ int alignnet_synchronize(alignnet_handle* h);
 /* dropout_u: optional host array of uniforms [0,1) used for the dropout masks, laid out
  * [s1 tower0 | s2 tower0 | s1 tower1 | s2 tower1 | pair head], each B x last-hidden-width;
  * NULL = draw on the device from cfg.seed and the step counter.
- * Shapes: three-conv backbones, widths multiples of 32, C1, C2 <= 128, C3 <= 1024 (every shipped config);
+ * Shapes: PointNet backbones of any depth (2 .. 6 conv layers, models/tp8.py:49-59), widths multiples of 8.  Three-layer stages with
+ * widths multiples of 32, C1, C2 <= 128, C3 <= 1024 (every shipped dataset config) run the fused recompute kernels; any other stage
+ * (e.g. the five-layer backbones of configs/default.json) runs the layer-by-layer path (fp32, hidden widths <= 256, last <= 4096);
  * backbone "dgcnn" (models/tp8.py:30-46, k = 20): fp32 only, C1 in {32, 64}, C2 in {64, 128}, 20 <= num_points <= 4096.
  * Anything else fails with a message (alignnet_last_error), it is never run on a fallback. */
 int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
@@ -249,7 +251,7 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
  * "comm_world": number of ranks of the RCCL communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
  * "last_train_kernel": bit mask of the most recent training step -- 1 = compile-time widths (64, 128), 2 = bf16 operands,
- *   4 = dgcnn backbone.
+ *   4 = dgcnn backbone, 8 = at least one stage ran the general-depth (layer-by-layer) path.
  * Unknown keys fail. */
 #define ALIGNNET_KERNEL_POINTNET_FUSED 1            /* pointnet_fused<128>: run-time widths */
 #define ALIGNNET_KERNEL_POINTNET_FUSED_64_128 2     /* pointnet_fused<128, 68, 132> */

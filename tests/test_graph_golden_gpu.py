@@ -42,7 +42,7 @@ def test_eval_forward_and_loss_match_executed_reference_graph(gpu_required, case
     eng.close()
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if len(META[c]["widths"]["s1"]) == 3 and len(META[c]["widths"]["emb"]) == 3])
+@pytest.mark.parametrize("case", CASES)   # incl. the four- / five-layer case: the general-depth training path
 def test_train_forward_loss_ema_match_executed_reference_graph(gpu_required, case):
     eng, d = _engine(case)
     assert abs(eng.state()["bn_decay"] - META[case]["bn_decay"]) < 1e-7

@@ -378,3 +378,90 @@ def test_gradients_wide_first_layers(gpu_required):
     print("wide first layers: worst relative gradient error", worst)
     assert not bad, bad
     eng.close()
+
+
+def _grad_check(eng, spec, grads, tol, skip_bn_bias=True):
+    gscale = max(float(np.abs(v).max()) for v in grads.values())
+    bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
+    bad, worst = {}, 0.0
+    for name in R.trainable_names(spec):
+        g = eng.get_gradient(name).astype(np.float64)
+        ref = grads[name].reshape(g.shape)
+        if name in bn_bias:
+            assert np.abs(g).max() == 0.0 and np.abs(ref).max() < 1e-9 * gscale, name
+            continue
+        err = float(np.abs(g - ref).max())
+        worst = max(worst, err / (float(np.abs(ref).max()) + 1e-6 * gscale))
+        if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
+            bad[name] = (err, float(np.abs(ref).max()))
+    return bad, worst
+
+
+GENERAL_DEPTH = {
+    # the reference's configs/default.json layer structure (five-layer s2 / embedding backbones, a wide first layer in s1), narrowed
+    "default_json_like": dict(s1=(128, 128, 160), s2=(32, 32, 32, 64, 128), emb=(32, 32, 32, 64, 160)),
+    # two and four layers, widths that are not multiples of 32, a hidden width above 128
+    "odd_shapes": dict(s1=(24, 40), s2=(16, 136, 48, 72), emb=(8, 16, 24, 200)),
+}
+
+
+@pytest.mark.parametrize("case,N,B", [("default_json_like", 100, 6), ("odd_shapes", 128, 5), ("default_json_like", 128, 8)])
+def test_general_depth_backbones_train(gpu_required, case, N, B):
+    """models/tp8.py:49-59 builds a conv layer per entry of `layer_sizes`, and the reference's configs/default.json:13-15 uses five.
+    Stages outside the specialised three-layer shape run the layer-by-layer path (csrc/kernels_train_generic.h): train-mode
+    predictions, loss, EMA updates and every gradient against torch autograd (fp64), same criteria as the three-layer tests.
+    N = 100 gives 64-row tiles that end inside a tower (B * N = 600 rows) and a partial last tile.
+    (Not every instance is comparable at this tolerance: at N = 64, B = 16, seed 9 two pooled maxima of one tower are 1.4e-5 apart --
+    the size of the fp32 forward error -- and a swapped arg-max row re-routes a gradient that is 17 % of one weight column; the fp32
+    evaluation of the oracle itself shows the same effect in the other tower.  tools/grad_report_generic.py prints both.)"""
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), **GENERAL_DEPTH[case])
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=9)
+    d = R.synth_pairs(B, N, seed=9, dtype=np.float32)
+    rng = np.random.default_rng(9)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    assert eng.get_option("last_train_kernel") & 8, "the general-depth path did not run"
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    for k, v in ema_ref.items():
+        np.testing.assert_allclose(eng.get_variable(k), v, rtol=1e-4, atol=1e-5, err_msg=k)
+    bad, worst = _grad_check(eng, spec, grads, 3e-3 if B >= 8 else 1e-2)
+    print(case, N, B, "general-depth path: loss", res["loss"], loss_ref, "worst relative gradient error", worst)
+    assert not bad, bad
+    # and a full optimiser step on it
+    r = eng.train_step(d["pcs1"], d["pcs2"], d)
+    assert r["step"] == 1 and np.isfinite(r["loss"])
+    eng.close()
+
+
+def test_reference_default_config_trains(gpu_required):
+    """The merged reference default config itself (configs/default.json: s1 [128,128,256], s2 / embedding [64,64,64,128,1024], 36
+    bins, no inverted angles) at N = 256: 40 Adam steps on fresh batches reduce the loss, eval afterwards is finite."""
+    cfg = alignnet3d.default_model_config()
+    o = cfg["model"]["options"]
+    o["s1transformer"] = [[128, 128, 256], [[512, 256], 0.7]]
+    o["s2transformer"] = [[64, 64, 64, 128, 1024], [[512, 256], 0.7]]
+    o["embedding"] = [64, 64, 64, 128, 1024]
+    o["early_stage_factor"] = 0.1
+    cfg["model"]["angles"] = {"num_bins": 36, "accept_inverted_angle": False}
+    cfg["model"]["num_points"] = 256
+    cfg["training"]["batch_size"] = 32
+    cfg["training"]["learning_rate"] = 0.002
+    cfg["data"]["ntrain"] = 3200
+    eng = alignnet3d.Engine(cfg, seed=3)
+    losses = []
+    for k in range(40):
+        d = R.synth_pairs(32, 256, seed=3000 + k, dtype=np.float32)
+        losses.append(eng.train_step(d["pcs1"], d["pcs2"], d)["loss"])
+    assert eng.get_option("last_train_kernel") & 8
+    held = R.synth_pairs(32, 256, seed=997, dtype=np.float32)
+    pred = eng.forward(held["pcs1"], held["pcs2"])["pred_translations"]
+    first, last = float(np.mean(losses[:5])), float(np.mean(losses[-5:]))
+    print("default.json widths: mean loss first / last 5 steps", first, last)
+    assert np.all(np.isfinite(losses)) and np.isfinite(pred).all() and last < 0.8 * first, (first, last)
+    eng.close()
