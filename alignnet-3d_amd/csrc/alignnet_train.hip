@@ -79,6 +79,7 @@ struct TrainWS {
   PackJob* pack_table = nullptr; int n_pack = 0;
   PackJob* stage_pack = nullptr;   // [3 stages][6]: Q3 t0,t1 | Q2 t0,t1, V2 t0,t1 (images rebuilt inside the backward)
   unsigned short* q3imgh = nullptr;   // bf16 images of Q3, both towers (train_bf16)
+  unsigned short* b1imgh = nullptr;   // bf16 images of V2 (128 -> 64) and Q2 (64 -> 64), both towers (train_bf16, shipped widths)
   unsigned short* wp2h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the hidden layers (train_bf16, no sign folding)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
   // general-depth PointNet stages (kernels_train_generic.h): pre-BatchNorm activations of every layer stay in HBM
@@ -114,6 +115,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->pack_table) hipFree(w->pack_table);
   if (w->stage_pack) hipFree(w->stage_pack);
   if (w->q3imgh) hipFree(w->q3imgh);
+  if (w->b1imgh) hipFree(w->b1imgh);
   for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); }
   delete w;
   h->train_ws = nullptr;
@@ -405,6 +407,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -941,6 +944,26 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;
+  if (pdy && std_w && h->train_bf16 && !getenv("ALIGNNET_B1_FP32")) {
+    // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16): bf16 images of V2 / Q2 per tower, then the kernel
+    constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // [CT = 2][KG][64 lanes][8]
+    if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
+    PackBf16Jobs pj;
+    for (int t = 0; t < 2; ++t) {
+      pj.src[t] = w->V2 + (size_t)t * C1 * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;
+      pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;
+    }
+    hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(8, 4), dim3(256), 0, h->stream, pj);
+    BwdB1hArgs bh;
+    bh.pcs[0] = p1; bh.pcs[1] = p2; bh.xform = S.xform; bh.B = B; bh.N = N;
+    bh.w1 = P(h, L[0]->p_w); bh.sc1 = S.scale[0]; bh.sh1 = S.shift[0];
+    bh.v2imgh = w->b1imgh; bh.q2imgh = w->b1imgh + 2 * kV2h; bh.v2_stride = (long)kV2h; bh.q2_stride = (long)kQ2h; bh.q2b = w->q2b;
+    bh.dy2_store = reinterpret_cast<const unsigned short*>(w->dy2);
+    bh.u2_part = b1.u2_part; bh.g1_part = b1.g1_part; bh.pdy_part = w->pdy_part;
+    const size_t ldsh = (size_t)kTT * 4 * sizeof(float) + ((size_t)kTT * 72 * 2 + (size_t)kTT * 136 + (size_t)128 * 72) * sizeof(unsigned short);
+    ProfScope prof_scope(h, PK_TRAIN_B1);
+    hipLaunchKernelGGL(train_bwd_b1_bf16, dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, bh);
+  } else
   { ProfScope prof_scope(h, PK_TRAIN_B1);
   if (pdy && std_w) hipLaunchKernelGGL((train_bwd_b1<64, 128, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
   else if (pdy) hipLaunchKernelGGL((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);

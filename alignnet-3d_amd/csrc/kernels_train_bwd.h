@@ -549,6 +549,179 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 }
 
 // ---------------------------------------------------------------------------------
+// Pass B1 on bf16 MFMA (train_matmul_bf16, the shipped widths C1 = 64, C2 = 128; replaces train_bwd_b1<64, 128, true> there).
+// In bf16 mode dy2 already arrives as bf16 from pass B2, so the fp32 kernel above spent its time converting that tile to fp32
+// and running 176 fp32 MFMAs (64 cycles each) per 64-row tile.  Here every operand tile is written ONCE, in bf16, by its
+// producer inside the kernel -- dy2 row-major + transposed while it is staged from HBM, h1 row-major + transposed by the lift --
+// and the four products run on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 5 x (4 + 8) ... 52 MFMAs of 32 cycles per tile:
+//   dh1 = dy2 V2 + h1 Q2 + q2b      A = row-major tiles, B = bf16 images of V2 / Q2 (pack_bf16_jobs_kernel)
+//   U2 += h1^T dy2, G1 += h1^T h1   A = h1 transposed, B = dy2 / h1 transposed, blocks register-resident for the whole cloud
+// Pdy = x'^T dy1 (3 x C1) and sum dy1 stay in fp32 on the VALU (four FMAs per accumulator element; x' in bf16 would put
+// 3-digit coordinates into the first layer's weight and frame gradients).  The backward treats the operand rounding as identity,
+// like the rest of the bf16 mode.
+// LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
+// ---------------------------------------------------------------------------------
+struct PackBf16Jobs { const float* src[4]; unsigned short* dst[4]; int K[4], C[4]; };
+// bf16 MFMA images (layout of pack_weights_bf16_kernel, no sign folding) of up to four small matrices in one launch: grid (blocks, 4)
+__global__ void pack_bf16_jobs_kernel(const PackBf16Jobs j)
+{
+  const int q = blockIdx.y;
+  const float* W = j.src[q];
+  if (!W) return;
+  const int K = j.K[q], C = j.C[q], KG = (K + 15) >> 4, CT = (C + 31) >> 5;
+  const size_t total = (size_t)CT * KG * 512;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int s8 = idx & 7, lane = (idx >> 3) & 63;
+    const size_t t = idx >> 9;
+    const int kg = t % KG, ct = t / KG;
+    const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
+    j.dst[q][idx] = to_bf16_bits((k < K && c < C) ? W[(size_t)k * C + c] : 0.f);
+  }
+}
+
+struct BwdB1hArgs {
+  const float* pcs[2]; const float* xform; int B, N;
+  const float* w1; const float *sc1, *sh1;                  // [3][64], [2][64]
+  const unsigned short* v2imgh; const unsigned short* q2imgh; long v2_stride, q2_stride;   // per-tower bf16 images: V2 [128 -> 64], Q2 [64 -> 64]
+  const float* q2b;                                         // [2][64]
+  const unsigned short* dy2_store;                          // [2B*N][128] bf16
+  float* u2_part; float* g1_part;                           // [2B][64*128], [2B][64*64] (upper blocks) or null (the forward kept Gram(h1))
+  double* pdy_part;                                         // [2B][4 = 2 row groups x 2 halves][4][64]
+};
+
+__global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArgs a)
+{
+  constexpr int C1 = 64, C2 = 128, ldx = C1 + 8, ldy = C2 + 8, ldT = kTT + 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;                                                        // [64][4] fp32
+  unsigned short* Xh = reinterpret_cast<unsigned short*>(smem + kTT * 4);   // h1    [64][72]
+  unsigned short* XhT = Xh + kTT * ldx;                                     // h1^T  [64][72]
+  unsigned short* Yh = XhT + C1 * ldT;                                      // dy2   [64][136]
+  unsigned short* YhT = Yh + kTT * ldy;                                     // dy2^T [128][72]
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  const bf16x8* v2img = reinterpret_cast<const bf16x8*>(a.v2imgh + tower * a.v2_stride);
+  const bf16x8* q2img = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2_stride);
+  const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
+  // register-resident blocks for the whole cloud: U2 (2 x 4 blocks) and, unless the forward kept it, the upper blocks of Gram(h1) (3)
+  constexpr int kAccSlots = 3, CT1 = 2, CT2 = 4;
+  const int nblk_u = CT1 * CT2, nblk = nblk_u + (a.g1_part ? CT1 * (CT1 + 1) / 2 : 0);
+  f32x16 gacc[kAccSlots];
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+  double pd[4] = {0.0, 0.0, 0.0, 0.0};
+  const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);   // this wave's dh1 item: 32 rows x 32 channels
+  const float qb = a.q2b[tower * C1 + col];
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    __syncthreads();
+    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    {   // dy2 tile: lane = row, wave-uniform 8-channel chunk; row-major 16-byte write + eight transposed 2-byte writes (consecutive lanes)
+      const unsigned short* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
+      const int row = lane;
+#pragma unroll
+      for (int it = 0; it < (C2 / 8) / kTW; ++it) {
+        const int q = wave + it * kTW;
+        uint4 pk = {0u, 0u, 0u, 0u};
+        if (row < nvalid) pk = *reinterpret_cast<const uint4*>(src + (size_t)row * C2 + q * 8);
+        *reinterpret_cast<uint4*>(Yh + row * ldy + q * 8) = pk;
+        const unsigned v[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          YhT[(q * 8 + 2 * e) * ldT + row] = (unsigned short)(v[e] & 0xffffu);
+          YhT[(q * 8 + 2 * e + 1) * ldT + row] = (unsigned short)(v[e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    {   // lift: thread (channel c0 + 32 g, rows 8 r0 .. 8 r0 + 7): eight bf16 values -> one 16-byte transposed write + eight row-major ones
+      const int c0 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int c = c0 + 32 * g;
+        unsigned short hv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int row = r0 * 8 + e;
+          const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+          const float acc = fmaf(p[2], l1w.wb[g], fmaf(p[1], l1w.wa[g], p[0] * l1w.w0[g]));
+          hv[e] = row < nvalid ? to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) : (unsigned short)0;
+          Xh[row * ldx + c] = hv[e];
+        }
+        uint4 pk;
+        pk.x = hv[0] | ((unsigned)hv[1] << 16); pk.y = hv[2] | ((unsigned)hv[3] << 16);
+        pk.z = hv[4] | ((unsigned)hv[5] << 16); pk.w = hv[6] | ((unsigned)hv[7] << 16);
+        *reinterpret_cast<uint4*>(XhT + c * ldT + r0 * 8) = pk;
+      }
+    }
+    __syncthreads();
+    // ---- U2 += h1^T dy2, G1 += h1^T h1: contraction over the tile's 64 rows = 4 bf16 k-groups ----
+#pragma unroll
+    for (int q = 0; q < kAccSlots; ++q) {
+      const int item = wave + q * kTW;
+      if (item < nblk) {
+        int it, jt;
+        const unsigned short* pb;
+        if (item < nblk_u) { it = item / CT2; jt = item % CT2; pb = YhT; }
+        else {
+          int rem = item - nblk_u; it = 0;
+          while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
+          jt = it + rem; pb = XhT;
+        }
+        const unsigned short* pa = XhT + (it * 32 + (lane & 31)) * ldT + half * 8;
+        pb += (jt * 32 + (lane & 31)) * ldT + half * 8;
+#pragma unroll
+        for (int kg = 0; kg < kTT / 16; ++kg)
+          gacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kg * 16), *reinterpret_cast<const bf16x8*>(pb + kg * 16),
+                                                            gacc[q], 0, 0, 0);
+      }
+    }
+    // ---- dh1 = dy2 V2 + h1 Q2 + q2b for this wave's (32 rows, 32 channels); dy1 = dh1 [h1 > 0]; Pdy on the VALU ----
+    {
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = qb;
+      mfma_rows_bf16_all<1, false>(Yh + rg * 32 * ldy, ldy, v2img + (size_t)ct * (C2 / 16) * 64, C2 / 16, lane, acc);
+      mfma_rows_bf16_all<1, false>(Xh + rg * 32 * ldx, ldx, q2img + (size_t)ct * (C1 / 16) * 64, C1 / 16, lane, acc);
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + acc_row(0, r, lane);
+        const unsigned short h1v = Xh[row * ldx + col];   // rows past nvalid hold 0
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float dy = h1v != 0 ? acc[0][r] : 0.f;
+        q0 = fmaf(p[0], dy, q0); q1 = fmaf(p[1], dy, q1); q2 = fmaf(p[2], dy, q2); q3 += dy;
+      }
+      pd[0] += (double)q0; pd[1] += (double)q1; pd[2] += (double)q2; pd[3] += (double)q3;   // one tile's fp32 sums folded into fp64
+    }
+  }
+  {
+    double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 4 * C1 + col;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dst[(size_t)d * C1] = pd[d];
+  }
+#pragma unroll
+  for (int q = 0; q < kAccSlots; ++q) {
+    const int item = wave + q * kTW;
+    if (item < nblk) {
+      const float zero[16] = {};
+      if (item < nblk_u) tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, item / CT2, item % CT2, C1, C2, gacc[q], lane, zero);
+      else {
+        int rem = item - nblk_u, it = 0;
+        while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
+        tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, it, it + rem, C1, C1, gacc[q], lane, zero);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // B0: dz1 = k1 (dy1 - dbeta1/M - zhat1 dgamma1/M); per cloud: P[d][c] = sum_n x'[n,d] dz1[n,c], S[c] = sum_n dz1[n,c]
 // then  gx[d] = sum_c W1[d,c] S[c],  grot = sum_c (W1[0,c] P[1][c] - W1[1,c] P[0][c])
 // grid: 2B workgroups of 256 threads
