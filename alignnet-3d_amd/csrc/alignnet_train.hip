@@ -28,7 +28,7 @@ static int fail(const alignnet_handle* h, const std::string& m) { h->err = m; re
 
 namespace alignnet {
 
-struct HeadLayerWS { float *z, *y, *mean, *var, *dz; };   // per hidden FC layer (with BN)
+struct HeadLayerWS { float *z, *y, *mean, *var, *dz, *dyb; };   // per hidden FC layer (with BN); dyb: d(y) from the next layer's dx GEMM
 
 struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float* xform;                  // [2B][12] input frame of this stage
@@ -262,7 +262,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       for (int j = 0; j < fs.n - 1; ++j) {
         const int wd = h->layers[fs.first + j].cout;
         HeadLayerWS& L = w->hl[s][j];
-        L.z = F(M * wd); L.y = F(M * wd); L.dz = F(M * wd); L.mean = F(2 * wd); L.var = F(2 * wd);
+        L.z = F(M * wd); L.y = F(M * wd); L.dz = F(M * wd); L.dyb = F(M * wd); L.mean = F(2 * wd); L.var = F(2 * wd);
       }
       const int ow = h->layers[fs.first + fs.n - 1].cout;
       w->o[s] = F(M * ow); w->d_o[s] = F(M * ow);
@@ -334,6 +334,20 @@ static void launch_gemm(alignnet_handle* h, const float* A, long sai, long sak, 
   hipLaunchKernelGGL(gemm_small, dim3((N + 31) / 32, (M + 31) / 32, batch), dim3(kGemmWaves * 64), 0, h->stream, g);
 }
 
+static GemmArgs gemm_args(const float* A, long sai, long sak, const float* Bm, long sbk, long sbj, float* C, long sci, long scj, int M, int N, int K)
+{
+  return GemmArgs{A, sai, sak, Bm, sbk, sbj, C, sci, scj, M, N, K, nullptr, 1.f, 0, 0, 0, 0};
+}
+static void launch_gemm_pair(alignnet_handle* h, const GemmArgs& g0, const GemmArgs& g1)
+{
+  GemmPair p;
+  p.g[0] = g0; p.g[1] = g1;
+  p.tx[0] = (g0.N + 31) / 32; p.tx[1] = (g1.N + 31) / 32;
+  p.n0 = p.tx[0] * ((g0.M + 31) / 32);
+  const int n1 = p.tx[1] * ((g1.M + 31) / 32);
+  hipLaunchKernelGGL(gemm_small2, dim3(p.n0 + n1), dim3(kGemmWaves * 64), 0, h->stream, p);
+}
+
 template <typename T>
 static void launch_reduce(alignnet_handle* h, const T* part, int S, long n, float* out, int towers = 2, float alpha = 1.f, int acc = 0)
 {
@@ -371,20 +385,25 @@ static int pack_all_weights(alignnet_handle* h)
     HIP_TRY(h, hipMemcpy(w->pack_table, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
-  if (h->train_bf16)
+  if (h->train_bf16) {
+    // bf16 images of every specialised stage's lift (one per tower: the sign of that tower's gamma folded in) and hidden layer, one launch
+    PackBf16Jobs pj{};
+    int nj = 0;
     for (int s = 0; s < 3; ++s) {
       if (stage_generic(h, s)) continue;   // the general-depth path computes in fp32 whatever the option says
       const Layer& L = h->layers[conv_of(h, s).first + 2];
-      const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;   // per tower (sign of its gamma folded in)
+      const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;   // per tower
       if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], 2 * n * sizeof(unsigned short)));
-      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024), 2), dim3(256), 0, h->stream,
-                         P(h, L.p_w), L.cin, L.cout, P(h, L.p_bn[0][1]), P(h, L.p_bn[1][1]), w->wp3h[s]);
+      for (int t = 0; t < 2; ++t) {
+        pj.src[nj] = P(h, L.p_w); pj.gamma[nj] = P(h, L.p_bn[t][1]); pj.dst[nj] = w->wp3h[s] + t * n; pj.K[nj] = L.cin; pj.C[nj] = L.cout; ++nj;
+      }
       const Layer& L2 = h->layers[conv_of(h, s).first + 1];   // hidden layer: one image, no sign folding
       const size_t n2 = (size_t)((L2.cout + 31) / 32) * ((L2.cin + 15) / 16) * 512;
       if (!w->wp2h[s]) HIP_TRY(h, hipMalloc(&w->wp2h[s], n2 * sizeof(unsigned short)));
-      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 1), dim3(256), 0, h->stream,
-                         P(h, L2.p_w), L2.cin, L2.cout, (const float*)nullptr, (const float*)nullptr, w->wp2h[s]);
+      pj.src[nj] = P(h, L2.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->wp2h[s]; pj.K[nj] = L2.cin; pj.C[nj] = L2.cout; ++nj;
     }
+    if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(32, nj), dim3(256), 0, h->stream, pj);
+  }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
 }
@@ -772,12 +791,10 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
     } else {
       launch_reduce<float>(h, dcur, M, (long)L.cout, G(h, w, L.p_b), 1);
     }
-    // dW = x^T dz  (TN)
-    launch_gemm(h, xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M);
-    // dx = dz W^T  (NT).  d(y_{j-1}) overwrites y_{j-1}: after the dW GEMM above y_{j-1} is dead (the BN backward of
-    // layer j-1 rebuilds the relu mask from z_{j-1}); the stream orders the two GEMMs.
-    float* dx = j == 0 ? din : w->hl[s][j - 1].y;
-    launch_gemm(h, dcur, L.cout, 1, P(h, L.p_w), 1, L.cout, dx, j == 0 ? ldin : L.cin, 1, M, L.cin, L.cout);
+    // dW = x^T dz (TN) and dx = dz W^T (NT) are independent (dx goes to its own buffer, not over y_{j-1}): one launch
+    float* dx = j == 0 ? din : w->hl[s][j - 1].dyb;
+    launch_gemm_pair(h, gemm_args(xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M),
+                     gemm_args(dcur, L.cout, 1, P(h, L.p_w), 1, L.cout, dx, j == 0 ? ldin : L.cin, 1, M, L.cin, L.cout));
     dcur = dx;
   }
   HIP_TRY(h, hipGetLastError());
@@ -817,15 +834,15 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const size_t qimg = img_floats(C2, C2);
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
-  hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
   const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
-  if (h->train_bf16) {
+  if (h->train_bf16 && !dg) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
-    for (int t = 0; t < 2; ++t)
-      hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((qimgh + 255) / 256), 1), dim3(256), 0, h->stream,
-                         w->Q3 + (size_t)t * C2 * C2, C2, C2, (const float*)nullptr, (const float*)nullptr, w->q3imgh + t * qimgh);
-  }
+    PackBf16Jobs pj{};
+    for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
+    hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(8, 2), dim3(256), 0, h->stream, pj);
+  } else
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
+  hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
   // ---- pass B2 ----
   BwdB2Args b2;
   b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
@@ -891,7 +908,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0, 2, w->k2, w->V2, 1, 2);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
+  const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
+  if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
   hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);
   if (dg) {
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
@@ -948,7 +966,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16): bf16 images of V2 / Q2 per tower, then the kernel
     constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // [CT = 2][KG][64 lanes][8]
     if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
-    PackBf16Jobs pj;
+    PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) {
       pj.src[t] = w->V2 + (size_t)t * C1 * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;
       pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;

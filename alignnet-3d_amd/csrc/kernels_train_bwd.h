@@ -561,13 +561,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // like the rest of the bf16 mode.
 // LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
 // ---------------------------------------------------------------------------------
-struct PackBf16Jobs { const float* src[4]; unsigned short* dst[4]; int K[4], C[4]; };
-// bf16 MFMA images (layout of pack_weights_bf16_kernel, no sign folding) of up to four small matrices in one launch: grid (blocks, 4)
+constexpr int kPackBf16Jobs = 9;
+struct PackBf16Jobs { const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs]; };
+// bf16 MFMA images (layout and sign folding of pack_weights_bf16_kernel: gamma null = none) of up to nine matrices in one launch,
+// grid (blocks, jobs): a training step re-packs 9 + 3 x 6 images, each its own 4.5 us launch before
 __global__ void pack_bf16_jobs_kernel(const PackBf16Jobs j)
 {
   const int q = blockIdx.y;
   const float* W = j.src[q];
   if (!W) return;
+  const float* gamma = j.gamma[q];
   const int K = j.K[q], C = j.C[q], KG = (K + 15) >> 4, CT = (C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 512;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -575,7 +578,9 @@ __global__ void pack_bf16_jobs_kernel(const PackBf16Jobs j)
     const size_t t = idx >> 9;
     const int kg = t % KG, ct = t / KG;
     const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
-    j.dst[q][idx] = to_bf16_bits((k < K && c < C) ? W[(size_t)k * C + c] : 0.f);
+    float v = 0.f;
+    if (k < K && c < C) v = (!gamma || gamma[c] >= 0.f) ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
+    j.dst[q][idx] = to_bf16_bits(v);
   }
 }
 

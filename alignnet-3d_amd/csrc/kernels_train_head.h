@@ -27,13 +27,13 @@ constexpr int kGemmWaves = 8, kGemmKC = 32, kGemmLd = 33;
 // in a private LDS region (no workgroup barrier in the loop): lanes run along whichever dimension has the smaller
 // stride, so row-major, transposed and column-scaled views all load coalesced; the next chunk's 32 loads are in
 // flight while the current chunk's 16 MFMAs run.
-__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a)
+__device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, int tile_y, int bz)
 {
   __shared__ float stage[kGemmWaves][2][kGemmKC * kGemmLd];   // [wave][A|B][k][i or j]; reused for the final reduction
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const float* A = a.A + blockIdx.z * a.batch_a;
-  const float* Bm = a.B + blockIdx.z * a.batch_b;
+  const int i0 = tile_y * 32, j0 = tile_x * 32;
+  const float* A = a.A + bz * a.batch_a;
+  const float* Bm = a.B + bz * a.batch_b;
   float* As = stage[wave][0];
   float* Bs = stage[wave][1];
   // K range of this wave: whole chunks
@@ -117,11 +117,23 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a)
 #pragma unroll
         for (int w = 0; w < kGemmWaves; ++w) v += red[(w * 16 + r) * 64 + lane];
         v = v * a.alpha + bias;
-        float* dst = a.C + blockIdx.z * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
+        float* dst = a.C + bz * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
         *dst = a.accumulate ? *dst + v : v;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a) { gemm_small_tile(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Two independent products in one launch (e.g. a head layer's dW = x^T dz and dx = dz W^T, 8 us each on their own): the tiles of
+// job 0 come first in the linear grid, then those of job 1.
+struct GemmPair { GemmArgs g[2]; int tx[2]; int n0; };
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small2(const GemmPair p)
+{
+  const int job = (int)blockIdx.x >= p.n0;
+  const int t = (int)blockIdx.x - job * p.n0;
+  gemm_small_tile(p.g[job], t % p.tx[job], t / p.tx[job], 0);
 }
 
 // counter-based uniform in [0,1) for dropout when the host supplies none (tf.nn.dropout draws
