@@ -384,7 +384,11 @@ static int pack_all_weights(alignnet_handle* h)
     HIP_TRY(h, hipMalloc(&w->pack_table, jobs.size() * sizeof(PackJob)));
     HIP_TRY(h, hipMemcpy(w->pack_table, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
+  // the fp32 MFMA images of the conv layers are read by the fp32 kernels, the dgcnn branch and the general-depth stages; in bf16 mode
+  // with only specialised PointNet stages nothing reads them (the heads use the raw matrices, the backbones the bf16 images below)
+  bool need_f32 = !h->train_bf16 || h->cfg.backbone == 1;
+  for (int s = 0; s < 3; ++s) need_f32 = need_f32 || stage_generic(h, s);
+  if (need_f32) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
   if (h->train_bf16) {
     // bf16 images of every specialised stage's lift (one per tower: the sign of that tower's gamma folded in) and hidden layer, one launch
     PackBf16Jobs pj{};
@@ -941,7 +945,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     layer2_weight_grad();
     DgB0Args z;
-    z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.pdy_part = w->pdy_part; z.slices = 4; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
@@ -962,7 +966,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;
-  if (pdy && std_w && h->train_bf16 && !getenv("ALIGNNET_B1_FP32")) {
+  const bool b1h = pdy && std_w && h->train_bf16 && !getenv("ALIGNNET_B1_FP32");
+  if (b1h) {
     // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16): bf16 images of V2 / Q2 per tower, then the kernel
     constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // [CT = 2][KG][64 lanes][8]
     if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
@@ -991,8 +996,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (pdy) {
     // first layer from the reduced quantities (kernels_train_dgcnn.h, D = 3)
     DgB0Args z;
-    z.pdy_part = w->pdy_part; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.pdy_part = w->pdy_part; z.slices = 4; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N; z.count = M;
+    if (b1h) z.slices = 1;   // train_bwd_b1_bf16 reduces the four partials itself
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
     hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);

@@ -591,7 +591,7 @@ struct BwdB1hArgs {
   const float* q2b;                                         // [2][64]
   const unsigned short* dy2_store;                          // [2B*N][128] bf16
   float* u2_part; float* g1_part;                           // [2B][64*128], [2B][64*64] (upper blocks) or null (the forward kept Gram(h1))
-  double* pdy_part;                                         // [2B][4 = 2 row groups x 2 halves][4][64]
+  double* pdy_part;                                         // [2B][4][64]: one slice per cloud (DgB0Args.slices = 1)
 };
 
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArgs a)
@@ -706,10 +706,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
       pd[0] += (double)q0; pd[1] += (double)q1; pd[2] += (double)q2; pd[3] += (double)q3;   // one tile's fp32 sums folded into fp64
     }
   }
-  {
-    double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 4 * C1 + col;
+  {   // one slice per cloud: the two half-waves by shuffle, the two row groups of a channel tile through LDS (the consumers read
+      // [2B][slices][4][64] doubles with a handful of workgroups: 4 MB at four slices was 17 us per launch)
 #pragma unroll
-    for (int d = 0; d < 4; ++d) dst[(size_t)d * C1] = pd[d];
+    for (int d = 0; d < 4; ++d) pd[d] += __shfl_xor(pd[d], 32);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);   // [2 channel tiles][4][32]
+    if (rg == 1 && half == 0) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) red[(ct * 4 + d) * 32 + (lane & 31)] = pd[d];
+    }
+    __syncthreads();
+    if (rg == 0 && half == 0) {
+      double* dst = a.pdy_part + (size_t)cloud * 4 * C1 + col;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dst[(size_t)d * C1] = pd[d] + red[(ct * 4 + d) * 32 + (lane & 31)];
+    }
   }
 #pragma unroll
   for (int q = 0; q < kAccSlots; ++q) {

@@ -740,7 +740,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
 // D = 6: DGCNN (e = [x_i, x_j - x_i]);  D = 3: the PointNet first layer (e = x'), where the same identities replace pass B0 and
 // the stored dy1: moments [2B][D + D(D+1)/2] = sum e | upper triangle of sum e e^T (row-major, d <= d2); Pdy [2B][4][D + 1][C1].
 struct DgB0Args {
-  const double* pdy_part;   // [2B][4][D + 1][C1]
+  const double* pdy_part;   // [2B][slices][D + 1][C1]
+  int slices;               // partial sums per cloud: 4 (row group x half-wave), or 1 when the producer reduced them itself
   const double* mom;        // [2B][D + D (D + 1) / 2]
   const float* w1; const float* b1; const float *mean1, *rstd1, *k1;   // [D][C1], [C1], [2][C1] x 3
   int B, C1, rows;          // rows per cloud (DGCNN: N * k)
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid
     for (int d = 0; d < D; ++d) w[d] = (double)a.w1[d * a.C1 + c];
     // four slices per iteration: 4 (D + 1) independent loads in flight instead of D + 1 (the loop is a chain of L2 round trips:
     // 17 us per launch with one slice per iteration and only ceil(C1 / 32) x 2 workgroups)
-    const int S = a.B * 4;
+    const int S = a.B * a.slices;
     for (int bs = g; bs < S; bs += 128) {
       double v[4][D + 1];
 #pragma unroll
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2
 #pragma unroll
     for (int d = 0; d < D + 1; ++d) {
       double s = 0.0;
-      for (int sl = 0; sl < 4; ++sl) s += a.pdy_part[(((size_t)cloud * 4 + sl) * (D + 1) + d) * a.C1 + c];
+      for (int sl = 0; sl < a.slices; ++sl) s += a.pdy_part[(((size_t)cloud * a.slices + sl) * (D + 1) + d) * a.C1 + c];
       pdy[d] = s;
     }
     const double k = (double)a.k1[t * a.C1 + c], rs = (double)a.rstd1[t * a.C1 + c];
