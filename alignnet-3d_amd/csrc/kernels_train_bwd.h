@@ -140,9 +140,15 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     B2_STAMP(1);
+    if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
+      layer1_to_lds_bf16_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, reinterpret_cast<unsigned short*>(X + kTT * ld0), ld0h, K16a,
+                                nvalid, tid);
+      __syncthreads();
+    } else {
     layer1_to_lds_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, X, ld0, nvalid, tid);
     __syncthreads();
-    if (BF16) {   // bf16 copy of h1 behind the fp32 one (X holds [64][ldb] floats; the fp32 h1 uses [64][ld0] of it)
+    }
+    if (BF16 && ACCUM) {   // bf16 copy of h1 behind the fp32 one (X holds [64][ldb] floats; the fp32 h1 uses [64][ld0] of it)
       unsigned short* Xh = reinterpret_cast<unsigned short*>(X + kTT * ld0);
       const int half_cols = K16a >> 1;
       for (int i = tid; i < kTT * half_cols; i += kTW * 64) {
@@ -203,6 +209,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     if (!GIVEN && a.s1_part && tid < sG * kC1) {   // column sums of h1 (only when the forward did not keep them): sG row groups x C1 columns
       const int c = tid % kC1, g = tid / kC1;
       float sm = 0.f;
+      if (BF16 && !ACCUM) {   // the column sums of the rounded h1: what the bf16 products of passes B2 / B1 see
+        const unsigned short* Xh = reinterpret_cast<const unsigned short*>(X + kTT * ld0);
+        for (int r = g; r < kTT; r += sG) sm += __uint_as_float((unsigned)Xh[r * ld0h + c] << 16);
+      } else
       for (int r = g; r < kTT; r += sG) sm += X[r * ld0 + c];
       s1c += (double)sm;
     }

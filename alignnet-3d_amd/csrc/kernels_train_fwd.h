@@ -193,6 +193,28 @@ __device__ __forceinline__ void layer1_to_lds_global(const float* __restrict__ x
   }
 }
 
+// the same lift written straight as a bf16 tile (row stride ldh elements, columns C1 .. K16 zero): pass B2 in bf16 mode consumes h1
+// only as the A operand of the bf16 hidden layer (and for its column sums), so the fp32 tile + conversion pass + barrier are not needed
+__device__ __forceinline__ void layer1_to_lds_bf16_global(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
+                                                          const float* __restrict__ sc, const float* __restrict__ sh,
+                                                          unsigned short* __restrict__ out16, int ldh, int K16, int nvalid, int tid)
+{
+  constexpr int kRowsPerPass = kTW * 2;
+  const int c0 = tid & 31, r0 = tid >> 5;
+  for (int c = c0; c < K16; c += 32) {
+    const bool live = c < C1;
+    const float w0 = live ? w1[c] : 0.f, wa = live ? w1[C1 + c] : 0.f, wb = live ? w1[2 * C1 + c] : 0.f;
+    const float s = live ? sc[c] : 0.f, t = live ? sh[c] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+      const int row = rr * kRowsPerPass + r0;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+      const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+      out16[row * ldh + c] = (row < nvalid && live) ? to_bf16_bits(fmaxf(fmaf(acc, s, t), 0.f)) : (unsigned short)0;
+    }
+  }
+}
+
 __device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---- bf16 operands (BASELINE.json configs[2]: "training ... bf16 with grad step"): the 128 -> C3 lift, 90 % of the
