@@ -447,13 +447,12 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   hipMemsetAsync(d_stamps, 0, 4 * 64 * sizeof(long long), h->stream);
   a.stamps = d_stamps;
 #endif
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const int TP = infer_tile_pts();
   // tiles per workgroup: as many as still leave every CU several workgroups (the pooled max is published once per workgroup)
@@ -476,11 +475,11 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
     const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
-    static bool sattr = false;
-    if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+    static PerDeviceOnce sattr;
+    if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     if (sc1 == 64 && sc2 == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
-      static bool sattr = false;
-      if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+      static PerDeviceOnce sattr;
+      if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
       hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_64_128;
     } else {
@@ -538,10 +537,9 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
     a.L[i].cin = L.cin; a.L[i].cout = L.cout;
   }
   (void)pooled_floats;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
   {
@@ -559,11 +557,11 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       const int dlda = ((dca + 15) & ~15) + 8, dldb = ((dcb + 15) & ~15) + 8;
       if (a.k > 3 * kWaves) return fail(h, "dgcnn split kernel: k limited to 24 neighbours");
       const size_t dlds = (size_t)2 * kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);
-      static bool dsattr = false;
-      if (!dsattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr = true; }
+      static PerDeviceOnce dsattr;
+      if (dsattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
       if (dca == 64 && dcb == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
-        static bool dsattr2 = false;
-        if (!dsattr2) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2 = true; }
+        static PerDeviceOnce dsattr2;
+        if (dsattr2.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
         hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT_64_128;
       } else {
@@ -574,8 +572,8 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
       if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
-        static bool sattr = false;
-        if (!sattr) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+        static PerDeviceOnce sattr;
+        if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
         hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED_64_128;
       } else {

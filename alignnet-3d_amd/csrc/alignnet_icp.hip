@@ -158,10 +158,9 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
   const long long budget = (150 * 1024) / 12;   // floats x 3 per point within one CU's LDS
   a.lds_points = (int)std::max<long long>(1, std::min(budget, max_n2));
   a.out = d_out; a.fitness = d_fr; a.rmse = d_fr + B; a.iters = d_it;
-  static bool attr = false;
-  if (!attr) {
+  static alignnet::PerDeviceOnce attr;
+  if (attr.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    attr = true;
   }
   hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 12, h->stream, a);
   HIP_TRY(h, hipGetLastError());

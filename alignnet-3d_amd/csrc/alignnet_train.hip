@@ -416,8 +416,8 @@ static size_t lds_train(int ld0, int ldb_or_ld1) { return ((size_t)kTT * 4 + (si
 
 static int set_lds_attrs(alignnet_handle* h)
 {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce done;
+  if (!done.need(h->cfg.device)) return 0;
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -444,7 +444,6 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
   return 0;
 }
 
@@ -458,12 +457,11 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
   TrainWS::GenStage& Gs = w->gen[s];
   const Stack& st = conv_of(h, s);
   const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
   }
   hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
   for (int l = 0; l < st.n; ++l) {

@@ -112,6 +112,19 @@ struct alignnet_handle {
 };
 
 namespace alignnet {
+// hipFuncSetAttribute (dynamic LDS size) applies to the CURRENT device only: every call site remembers per device ordinal whether it
+// has been done, so that a second handle on another GPU of the same process sets its own attributes (a process-global flag skipped them).
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  bool need(int device)
+  {
+    const unsigned long long bit = 1ull << (device & 63);
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+  }
+};
+
 // Brackets everything launched on h->stream during its lifetime with one event pair (only while h->prof is set).
 struct ProfScope {
   alignnet_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;

@@ -225,3 +225,42 @@ def test_rccl_two_ranks_data_parallel_step(gpu_required, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.count("RCCL2_OK") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_shipped_operating_point_through_config_py(gpu_required, tmp_path):
+    """The as-shipped operating point of the reference's dataset configs (configs/SynthCars.json / KITTITracklets*.json: N = 512,
+    batch 128, 50 bins, widths [64,128,256] / [64,128,512] / [64,128,1024], heads [512,256], keep 0.7 -- values restated here, the
+    files themselves stay in the reference) through config.py's merge over the defaults -> Engine: eval forward on the kernels
+    with the shipped widths compiled in, one training step in each arithmetic, schedule read-back."""
+    import config as cfgmod
+    root = tmp_path / "SynthSet"
+    _make_dataset(str(root))
+    user = {"data": {"basepath": str(root)}, "logging": {"basedir": str(tmp_path / "logs")},
+            "model": {"model": "tp8", "backbone": "pointnet", "num_points": 512,
+                      "options": {"angle_factor": 1.0, "early_stage_factor": 0.5,
+                                  "s1transformer": [[64, 128, 256], [[512, 256], 0.7]], "s2transformer": [[64, 128, 512], [[512, 256], 0.7]],
+                                  "embedding": [64, 128, 1024], "remaining_transform_prediction": [[512, 256], 0.7]},
+                      "angles": {"num_bins": 50, "accept_inverted_angle": True}},
+            "training": {"num_epochs": 200, "batch_size": 128, "learning_rate": 0.005,
+                         "lr_extension": {"mode": "decay", "per": "epoch", "step": 30, "rate": 0.5}}}
+    path = tmp_path / "SynthCarsLike.json"
+    json.dump(user, open(path, "w"))
+    cfgmod.reset_config()
+    cfg = cfgmod.load_config(str(path))
+    eng = alignnet3d.Engine(cfg)
+    assert (eng.num_points, eng.num_bins) == (512, 50)
+    d = R.synth_pairs(128, 512, seed=3, dtype=np.float32)
+    for name, shp, _ in eng.variables():
+        if name.endswith("moving_var"):
+            eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
+    out = eng.forward(d["pcs1"], d["pcs2"])
+    assert eng.last_backbone_kernel() == "pointnet_fused<64,128,k16>" and all(np.isfinite(v).all() for v in out.values())
+    st = eng.state()
+    assert abs(st["learning_rate"] - 0.005) < 1e-9 and abs(st["bn_decay"] - 0.5) < 1e-7
+    for bf16 in (0, 1):
+        eng.set_option("train_matmul_bf16", bf16)
+        r = eng.train_step(d["pcs1"], d["pcs2"], d)
+        assert np.isfinite(r["loss"]) and eng.get_option("last_train_kernel") == (1 | (2 if bf16 else 0))
+    assert eng.state()["step"] == 2
+    eng.close()
+    cfgmod.reset_config()

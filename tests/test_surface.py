@@ -230,3 +230,36 @@ def test_evaluate_numbers_match_the_reference(tiny, tmp_path, kind):
         assert (kind == "kitti") == bool(want)
     finally:
         vars(cfg.data)["basepath"] = old
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference only exists in the build container")
+def test_every_shipped_reference_config_marshals(tiny, monkeypatch):
+    """Each configs/*.json of the reference (read in place, build container only) through the drop-in's config.py merge and the
+    engine's config marshalling (make_c_config): num_points / bins / widths / keep probabilities / schedules arrive as written,
+    and nothing that the engine does not build (loss variants, backbones) slips through silently."""
+    import glob
+    from alignnet3d.engine import make_c_config
+    cfgmod = tiny["config"]
+    monkeypatch.setattr(cfgmod, "_read_split", lambda path: list(range(1000)))   # the datasets are not here: ntrain / nval only
+    seen = 0
+    for path in sorted(glob.glob("/root/reference/configs/*.json")):
+        user = json.load(open(path))
+        cfgmod.reset_config()
+        cfg = cfgmod.load_config(path)
+        assert cfg.name == os.path.basename(path)[:-5] and cfg.data.ntrain == 1000
+        c = make_c_config(cfg)
+        m = cfg.to_dict()["model"]
+        assert c.num_points == m["num_points"] and c.num_bins == m["angles"]["num_bins"]
+        assert c.backbone == {"pointnet": 0, "dgcnn": 1}[m["backbone"]]
+        assert list(c.s1_conv.w[:c.s1_conv.n]) == m["options"]["s1transformer"][0]
+        assert list(c.s2_conv.w[:c.s2_conv.n]) == m["options"]["s2transformer"][0]
+        assert list(c.emb_conv.w[:c.emb_conv.n]) == m["options"]["embedding"]
+        assert list(c.rem_fc.w[:c.rem_fc.n]) == m["options"]["remaining_transform_prediction"][0]
+        assert abs(c.s1_keep - m["options"]["s1transformer"][1][1]) < 1e-7
+        assert c.batch_size == cfg.training.batch_size and abs(c.learning_rate - cfg.training.learning_rate) < 1e-9
+        assert c.accept_inverted_angle == int(m["angles"]["accept_inverted_angle"])
+        if "model" in user and "num_points" in user["model"]:
+            assert c.num_points == user["model"]["num_points"]      # the user file wins over default.json
+        seen += 1
+    assert seen >= 8
+    cfgmod.reset_config()
