@@ -362,6 +362,14 @@ class Engine:
         self._check(self._lib.alignnet_debug_dropout_uniforms(self._h, B, _fp(a), a.size))
         return [a[i * B * w12:(i + 1) * B * w12].reshape(B, w12) for i in range(4)] + [a[4 * B * w12:].reshape(B, w3)]
 
+    def debug_knn_graph(self, B):
+        """The k = 20 neighbour graph the last eval-mode forward (of B pairs) built, dgcnn engines only: int32
+        [2, B, num_points, 20] (tower, pair, point, neighbour rank; utils/tf_util_dgcnn.py:638-676)."""
+        n = self.num_points
+        a = np.empty((2, B, n, 20), np.int32)
+        self._check(self._lib.alignnet_debug_knn_graph(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+        return a
+
     def grad_buffer(self):
         ptr, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.alignnet_grad_buffer(self._h, C.byref(ptr), C.byref(n)))

@@ -642,7 +642,7 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
   if (dg) {   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
     ProfScope prof_scope(h, PK_KNN);
-    hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn);
+    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn));
   }
   // stage 1 (tp8.py:108-109)
   if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
@@ -715,6 +715,20 @@ extern "C" int alignnet_forward(alignnet_handle* h, const float* pcs1, const flo
     if (host[i]) HIP_TRY(h, hipMemcpyAsync(host[i], w.outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return drain_profile(h);
+}
+
+// test hook: the kNN graph [2B][N][20] (tower 1's B clouds, then tower 2's) built by the last eval-mode forward of a dgcnn engine
+extern "C" int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!dst) return fail(h, "alignnet_debug_knn_graph: null argument");
+  if (h->cfg.backbone != 1 || !h->ws.d_nn || h->last_B < 1) return fail(h, "alignnet_debug_knn_graph: no dgcnn forward has run on this handle");
+  const size_t need = (size_t)2 * h->last_B * h->cfg.num_points * 20;
+  if (count != need) return fail(h, "alignnet_debug_knn_graph: count must be 2 * B * num_points * 20 of the last forward");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(dst, h->ws.d_nn, need * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 extern "C" int alignnet_synchronize(alignnet_handle* h)

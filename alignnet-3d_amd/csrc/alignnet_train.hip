@@ -1049,7 +1049,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
   if (h->cfg.backbone == 1) {   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
     ProfScope prof_scope(h, PK_KNN);
-    hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, B2), dim3(256), 0, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn);
+    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn));
   }
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;

@@ -11,190 +11,223 @@
 // frames differ by a rigid motion, which leaves the graph unchanged (SURVEY.md 8.A6 vii; ties at the k-th
 // neighbour aside).
 #pragma once
+#include "engine.h"
 #include "kernels_infer.h"
 
 namespace alignnet {
 
 constexpr int kKnnMaxPerLane = 64;   // N <= 64 * 64 = 4096 candidates per query
-constexpr int kKnnList = 256;        // survivors of the first bound that are selected from LDS
+constexpr int kKnnList = 128;        // survivors of the first bound that are selected from LDS
+constexpr int kKnnWaves = 8;         // waves per workgroup, one query point per wave and round
+constexpr int kKnnQueries = 256;     // query points per workgroup (the cloud's candidate table is built once for all of them)
 
-// order-preserving map float -> uint32 (handles the slightly negative "distances" the TF formula can produce)
+// order-preserving map float -> uint32 (handles the slightly negative "distances" the TF formula can produce) and its inverse
 __device__ __forceinline__ uint32_t fkey(float f)
 {
   const uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 #ifdef ALIGNNET_KNN_STAMP   // tools/microbench/knn_phases.hip: cycle stamps of one wave at the phase boundaries
 __device__ long long g_knn_stamp[8];
-#define KNN_STAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define KNN_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) g_knn_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define KNN_STAMP(i) do {} while (0)
 #endif
-// grid: (ceil(N / 4), 2B), block 256 = 4 waves, one query point per wave
-// PER: candidate slots per lane compiled in (N <= 64 PER): 64 for the full 4096-point range, 16 for N <= 1024 (a quarter of the
-// key registers, twice the waves per SIMD)
+
+// grid: (ceil(N / kKnnQueries), 2B), block 512 = 8 waves.  PER: candidate slots per lane compiled in (N <= 64 PER).
+//
+// The workgroup first builds the cloud's candidate table in LDS -- mean-centred x, y, z and |x|^2 per point, 16 bytes each, rows past
+// N padded with |x|^2 = +inf -- laid out for packed-fp32 arithmetic: entry (t2, lane) holds the candidates of slots 2 t2 and 2 t2 + 1
+// of that lane as {xA, xB, yA, yB} (plane 0) and {zA, zB, ppA, ppB} (plane 1), so that one 16-byte LDS read per plane feeds
+// v_pk_mul / v_pk_fma_f32 without register shuffles.  Each wave then takes one query point per round, keeps its 64 PER candidate
+// distances in registers as floats, and selects: an upper bound from the per-lane minima, survivors compacted into the wave's
+// LDS list, ranks within the list.
+//
+// Against the first form (candidates read from global memory for every query, integer keys for all of them) this removes, per
+// candidate and query: the three global loads and their address arithmetic (L1 was 47 % busy), the centring, |x|^2, the
+// float -> key conversion and the `j < N` select -- 19 VALU instructions down to 3 (5 packed operations and a min3 per pair).
+// (Two queries per wave halve the LDS reads but need 246 VGPRs, two waves per SIMD: the selection phases -- short dependent
+//  scalar / vector chains -- then ran unhidden and the kernel was no faster than the first form: DESIGN.md 4.5.)
 template <int PER = kKnnMaxPerLane>
-[[maybe_unused]] static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+[[maybe_unused]] static __global__ __launch_bounds__(kKnnWaves * 64, 4) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                  const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
 {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float knn_smem[];
+  f32x4* plane0 = reinterpret_cast<f32x4*>(knn_smem);                 // [PER / 2][64] {xA, xB, yA, yB}
+  f32x4* plane1 = plane0 + (PER / 2) * 64;                            // [PER / 2][64] {zA, zB, ppA, ppB}
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint2* list = reinterpret_cast<uint2*>(plane1 + (PER / 2) * 64) + wave * kKnnList;   // [8][kKnnList] {distance bits, point index}
   const int cloud = blockIdx.y, tower = cloud >= B, b = cloud - tower * B;
-  const int q = blockIdx.x * 4 + wave;
-  if (q >= N) return;
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   const float cx = center[cloud * 3], cy = center[cloud * 3 + 1], cz = center[cloud * 3 + 2];
-  const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
-  const float qq = qx * qx + qy * qy + qz * qz;   // reduce_sum(square(x)) (tf_util_dgcnn.py:655)
   KNN_STAMP(0);
-  uint32_t key[PER];
-  const int per = (N + 63) >> 6;
-  // Candidates are loaded eight slots at a time with clamped (always valid) indices and no branch around the loads: guarded
-  // by `if (j < N)` every slot's three loads were issued and waited for inside their own exec-masked block -- 64 exposed
-  // memory round trips per query (50 k of the 75 k cycles of a query at N = 4096).
-#pragma unroll
-  for (int t0 = 0; t0 < PER; t0 += 8) {
-    if (t0 < per) {
-      float px[8], py[8], pz[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = min((t0 + u) * 64 + lane, N - 1);
-        px[u] = pc[j * 3]; py[u] = pc[j * 3 + 1]; pz[u] = pc[j * 3 + 2];
-      }
-      // two candidates per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32): same operations per component
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        const f32x2 x = f32x2{px[u], px[u + 1]} - cx, y = f32x2{py[u], py[u + 1]} - cy, z = f32x2{pz[u], pz[u + 1]} - cz;
-        const f32x2 inner = -2.0f * (qx * x + qy * y + qz * z);          // -2 * matmul (:653-654)
-        const f32x2 d = qq + inner + (x * x + y * y + z * z);             // square + inner + square^T (:657)
-        key[t0 + u] = (t0 + u) * 64 + lane < N ? fkey(d[0]) : 0xffffffffu;
-        key[t0 + u + 1] = (t0 + u + 1) * 64 + lane < N ? fkey(d[1]) : 0xffffffffu;
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) key[t0 + u] = 0xffffffffu;
+  // ---- 0. candidate table ----
+  for (int j = tid; j < PER * 64; j += kKnnWaves * 64) {
+    const int t = j >> 6, half = t & 1, e = (t >> 1) * 64 + (j & 63);
+    float x = 0.f, y = 0.f, z = 0.f, pp = INFINITY;
+    if (j < N) {
+      x = pc[j * 3] - cx; y = pc[j * 3 + 1] - cy; z = pc[j * 3 + 2] - cz;
+      pp = fmaf(z, z, fmaf(y, y, x * x));                             // reduce_sum(square(x)) (tf_util_dgcnn.py:655)
     }
+    float* p0 = reinterpret_cast<float*>(plane0 + e);
+    float* p1 = reinterpret_cast<float*>(plane1 + e);
+    p0[half] = x; p0[2 + half] = y; p1[half] = z; p1[2 + half] = pp;
   }
+  __syncthreads();
   KNN_STAMP(1);
-  // ---- 1. upper bound: the k-th smallest of the 64 per-lane minima (k lanes hold a value <= it) ----
-  uint32_t lmin = 0xffffffffu;
-  // (the slot loops below test `per` once per block of eight slots: slots past N hold the sentinel key, which no bound admits;
-  //  a uniform `t < per` per slot made hipcc keep 64 such predicates in SGPRs across the loops -- 587 scalar spills)
+  const int per2 = (N + 127) >> 7;     // populated pair slots
+  const int qend = min(N, (int)(blockIdx.x + 1) * kKnnQueries);
+  for (int q = blockIdx.x * kKnnQueries + wave; q < qend; q += kKnnWaves) {
+    // ---- 1. distances of the wave's query to every candidate; per-lane minimum ----
+    KNN_STAMP(7);
+    float d[PER];
+    const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
+    const float qq = fmaf(qz, qz, fmaf(qy, qy, qx * qx));
+    // -2 * matmul (:653-654): the factor folded into the query, exact.  (The fused multiply-adds are spelled out so that every
+    //  evaluation of this formula -- here, the table above, tools/microbench/knn_phases.hip's brute force -- rounds alike.)
+    const f32x2 q2x = {-2.0f * qx, -2.0f * qx}, q2y = {-2.0f * qy, -2.0f * qy}, q2z = {-2.0f * qz, -2.0f * qz};
+    float lminf = INFINITY;
 #pragma unroll
-  for (int t0 = 0; t0 < PER; t0 += 8)
-    if (t0 < per) {
+    for (int t0 = 0; t0 < PER / 2; t0 += 4) {
+      if (t0 < per2) {
 #pragma unroll
-      for (int t = t0; t < t0 + 8; ++t) lmin = min(lmin, key[t]);
-    }
-  // (bisection over the upper 16 key bits only: the bound may be the top of the k-th minimum's 2^-7-wide bucket, which lets a few
-  //  more candidates through to the list and halves this phase)
-  uint32_t lo = 0u, hi = 0xffffu;
-  if (k <= 64) {
-    const uint32_t lmin16 = lmin >> 16;
-    while (lo < hi) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (__popcll(__ballot(lmin16 <= mid)) >= k) hi = mid; else lo = mid + 1;
-    }
-    lo = (lo << 16) | 0xffffu;
-    if (lo == 0xffffffffu) lo = 0xfffffffeu;   // never admit the sentinel keys of slots past N
-  } else lo = 0xfffffffeu;   // every real candidate; the sentinel keys (0xffffffff) of slots past N stay out without an index test
-  const uint32_t T0 = lo;
-  KNN_STAMP(2);
-  // ---- 2. compact the survivors (key <= T0), in increasing point index, into this wave's LDS list ----
-  __shared__ uint32_t s_key[4][kKnnList];
-  __shared__ int s_idx[4][kKnnList];
-  int M = 0;
+        for (int t2 = t0; t2 < t0 + 4; ++t2) {
+          const f32x4 a0 = plane0[t2 * 64 + lane], a1 = plane1[t2 * 64 + lane];
+          const f32x2 x = {a0[0], a0[1]}, y = {a0[2], a0[3]}, z = {a1[0], a1[1]}, pp = {a1[2], a1[3]};
+          const f32x2 inner = __builtin_elementwise_fma(q2z, z, __builtin_elementwise_fma(q2y, y, q2x * x));
+          const f32x2 dd = qq + inner + pp;                               // square + inner + square^T (:657)
+          d[2 * t2] = dd[0]; d[2 * t2 + 1] = dd[1];
+          lminf = fminf(lminf, fminf(dd[0], dd[1]));
+        }
+        asm volatile("" ::: "memory");   // eight table reads in flight, not all 64 (hoisted together they cost 182 spills at 128 VGPRs)
+      } else {
 #pragma unroll
-  for (int t0 = 0; t0 < PER; t0 += 8)
-    if (t0 < per) {
-#pragma unroll
-      for (int t = t0; t < t0 + 8; ++t) {
-        // about k + a few of the N candidates survive, so most 64-candidate slots hold none: skip those on the scalar unit
-        const bool sel = key[t] <= T0;   // T0 <= 0xfffffffe: no sentinel passes, no `t * 64 + lane < N` needed
-        const unsigned long long m = __ballot(sel);
-        if (m == 0ull) continue;
-        const int pos = M + __popcll(m & ((1ull << lane) - 1ull));
-        if (sel && pos < kKnnList) { s_key[wave][pos] = key[t]; s_idx[wave][pos] = t * 64 + lane; }
-        M += __popcll(m);
+        for (int t2 = t0; t2 < t0 + 4; ++t2) { d[2 * t2] = INFINITY; d[2 * t2 + 1] = INFINITY; }
       }
     }
-  int* out = nn + ((size_t)cloud * N + q) * k;
-  KNN_STAMP(3);
-  if (M <= 64) {
-    // ---- 3a'. the usual case, one list entry per lane: rank every entry among the others by its (key, index) pair --
-    //           one 64-bit compare per entry -- and let the entries of rank < k write themselves (nearest first; ties at
-    //           the k-th key go to the lower point indices as tf.nn.top_k).  A 32-step bisection was 5.2 k cycles. ----
-    const bool in = lane < M;
-    const unsigned long long mine = in ? ((unsigned long long)s_key[wave][lane] << 32) | (unsigned)s_idx[wave][lane] : ~0ull;
-    int rank = 0;
-    for (int i = 0; i < M; ++i) {
-      const unsigned long long other = __shfl(mine, i);   // uniform source lane: a v_readlane pair
-      rank += other < mine;
+    KNN_STAMP(2);
+    // ---- 2. upper bound: the k-th smallest of the 64 per-lane minima (k lanes hold a value <= it).  Bisection over the upper
+    //         16 key bits only: the bound may be the top of the k-th minimum's bucket, which lets a few more candidates through
+    //         to the list and halves this phase.  Clamped to FLT_MAX: the padding (+inf) never passes. ----
+    uint32_t lo = 0u, hi = 0xffffu;
+    if (k <= 64) {
+      const uint32_t lmin16 = fkey(lminf) >> 16;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (__popcll(__ballot(lmin16 <= mid)) >= k) hi = mid; else lo = mid + 1;
+      }
+      lo = (lo << 16) | 0xffffu;
+    } else lo = 0xffffffffu;
+    const uint32_t T0 = min(lo, 0xff7fffffu);   // fkey(FLT_MAX)
+    const float T0f = fkey_inv(T0);
+    KNN_STAMP(3);
+    // ---- 3. compact the survivors (d <= T0), in increasing point index, into this wave's LDS list ----
+    int M = 0;
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));   // (the 64 point indices t * 64 + lane are loop invariants: hoisted out of the query loop they held 64 VGPRs)
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      // about k + a few of the N candidates survive, so most 64-candidate slots hold none: skip those on the scalar unit
+      const bool sel = d[t] <= T0f;
+      const unsigned long long m = __ballot(sel);
+      if (__builtin_expect(m == 0ull, 1)) continue;   // the empty slot falls through: v_cmp + an untaken branch
+      const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, M));   // M + set bits below this lane
+      if (sel && pos < kKnnList) list[pos] = make_uint2(__float_as_uint(d[t]), (unsigned)(t * 64 + lane_q));
+      M += __popcll(m);
     }
-    if (in && rank < k) out[rank] = (int)(mine & 0xffffffffu);
+    int* out = nn + ((size_t)cloud * N + q) * k;
     KNN_STAMP(4);
-    KNN_STAMP(5);
-    return;
-  }
-  if (M <= kKnnList) {
-    // ---- 3a. k-th smallest of the list by bisection (<= 4 entries per lane), emit in list (= index) order ----
-    uint32_t lk[kKnnList / 64];
+    if (M <= 64) {
+      // ---- 4a. the usual case, one list entry per lane: rank every entry among the others by its (key, index) pair --
+      //          one 64-bit compare per entry -- and let the entries of rank < k write themselves (nearest first; ties at
+      //          the k-th key go to the lower point indices as tf.nn.top_k) ----
+      const bool in = lane < M;
+      const uint2 e = list[in ? lane : 0];
+      const unsigned long long mine = in ? ((unsigned long long)fkey(__uint_as_float(e.x)) << 32) | e.y : ~0ull;
+      int rank = 0;
+      for (int i = 0; i < M; i += 4) {   // lanes past M hold ~0: never below a list entry
 #pragma unroll
-    for (int u = 0; u < kKnnList / 64; ++u) lk[u] = u * 64 + lane < M ? s_key[wave][u * 64 + lane] : 0xffffffffu;
-    lo = 0u; hi = T0;
-    const int nU = (M + 63) >> 6;   // populated registers of the list (usually one)
-    while (lo < hi) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      int c = 0;
+        for (int v = 0; v < 4; ++v) {
+          const unsigned long long other = __shfl(mine, (i + v) & 63);   // uniform source lane: a v_readlane pair
+          rank += other < mine;
+        }
+      }
+      if (in && rank < k) out[rank] = (int)(mine & 0xffffffffu);
+      KNN_STAMP(5);
+    } else if (M <= kKnnList) {
+      // ---- 4b. k-th smallest of the list by bisection (<= 2 entries per lane), emit in list (= index) order ----
+      uint32_t lk[kKnnList / 64];
 #pragma unroll
-      for (int u = 0; u < kKnnList / 64; ++u)
-        if (u < nU) c += __popcll(__ballot(lk[u] <= mid));
-      if (c >= k) hi = mid; else lo = mid + 1;
+      for (int v = 0; v < kKnnList / 64; ++v) lk[v] = v * 64 + lane < M ? fkey(__uint_as_float(list[v * 64 + lane].x)) : 0xffffffffu;
+      lo = 0u; hi = T0;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int v = 0; v < kKnnList / 64; ++v) c += __popcll(__ballot(lk[v] <= mid));
+        if (c >= k) hi = mid; else lo = mid + 1;
+      }
+      const uint32_t T = lo;
+      int written = 0;
+      for (int pass = 0; pass < 2 && written < k; ++pass)
+#pragma unroll
+        for (int v = 0; v < kKnnList / 64; ++v) {
+          const bool sel = (pass == 0 ? lk[v] < T : lk[v] == T) && v * 64 + lane < M;
+          const unsigned long long m = __ballot(sel);
+          const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
+          if (sel && pos < k) out[pos] = (int)list[v * 64 + lane].y;
+          written += __popcll(m);
+        }
+    } else {
+      // ---- 4c. (rare: more than kKnnList survivors, i.e. many exact ties) full bisection over all candidates ----
+      lo = 0u; hi = T0;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const float midf = fkey_inv(mid);
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) c += d[t] <= midf;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (c >= k) hi = mid; else lo = mid + 1;
+      }
+      const float Tf = fkey_inv(lo);
+      int written = 0;
+      for (int pass = 0; pass < 2 && written < k; ++pass) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+          const bool sel = pass == 0 ? d[t] < Tf : d[t] == Tf;
+          const unsigned long long m = __ballot(sel);
+          const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
+          if (sel && pos < k) out[pos] = t * 64 + lane;
+          written += __popcll(m);
+        }
+      }
     }
-    const uint32_t T = lo;
-    KNN_STAMP(4);
-    int written = 0;
-    for (int pass = 0; pass < 2 && written < k; ++pass)
-#pragma unroll
-      for (int u = 0; u < kKnnList / 64; ++u) {
-        const bool sel = (pass == 0 ? lk[u] < T : lk[u] == T) && u * 64 + lane < M;
-        const unsigned long long m = __ballot(sel);
-        const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
-        if (sel && pos < k) out[pos] = s_idx[wave][u * 64 + lane];
-        written += __popcll(m);
-      }
-    KNN_STAMP(5);
-    return;
+    KNN_STAMP(6);
   }
-  // ---- 3b. (rare: more than kKnnList survivors) full bisection over all candidates ----
-  lo = 0u; hi = T0;
-  while (lo < hi) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    int c = 0;
-#pragma unroll
-    for (int t0 = 0; t0 < PER; t0 += 8)
-      if (t0 < per) {
-#pragma unroll
-        for (int t = t0; t < t0 + 8; ++t) c += key[t] <= mid;
-      }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (c >= k) hi = mid; else lo = mid + 1;
+}
+
+constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t)kKnnWaves * kKnnList * 8; }
+
+// the kNN graph of 2B clouds (N <= 4096, k <= N): nn [2B][N][k].  (static: the kernels are per translation unit, so is the flag)
+[[maybe_unused]] static hipError_t launch_knn(int device, hipStream_t stream, const float* p1, const float* p2, const float* center, int B, int N,
+                                              int k, int* nn)
+{
+  const dim3 grid((N + kKnnQueries - 1) / kKnnQueries, 2 * B), block(kKnnWaves * 64);
+  static PerDeviceOnce attr_done;
+  if (attr_done.need(device)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(16));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(32));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(64));
   }
-  const uint32_t T = lo;
-  int written = 0;
-  for (int pass = 0; pass < 2 && written < k; ++pass) {
-#pragma unroll
-    for (int t = 0; t < PER; ++t)
-      if ((t & ~7) < per) {
-        const bool sel = pass == 0 ? key[t] < T : key[t] == T;   // T <= T0 <= 0xfffffffe
-        const unsigned long long m = __ballot(sel);
-        const int pos = written + __popcll(m & ((1ull << lane) - 1ull));
-        if (sel && pos < k) out[pos] = t * 64 + lane;
-        written += __popcll(m);
-      }
-  }
+  if (N <= 1024) hipLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, p1, p2, center, B, N, k, nn);
+  else if (N <= 2048) hipLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, p1, p2, center, B, N, k, nn);
+  else hipLaunchKernelGGL(knn_kernel<64>, grid, block, knn_lds_bytes(64), stream, p1, p2, center, B, N, k, nn);
+  return hipGetLastError();
 }
 
 struct DgcnnArgs {
@@ -305,6 +338,9 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 
 // LD0 / LD1 != 0: the shipped shape compiled in -- widths [LD0 - 4, LD1 - 4, C3], three layers -- so that LDS strides, k-depths
 // and tile counts are constants (as for pointnet_fused: fewer address registers, no generic layer dispatch)
+#ifndef DG_LIFT_MFMA
+#define DG_LIFT_MFMA 1
+#endif
 template <int LD0 = 0, int LD1 = 0>
 [[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, LD0 ? DGLB : 2) void dgcnn_fused(const DgcnnArgs a)
 {
@@ -442,18 +478,54 @@ template <int LD0 = 0, int LD1 = 0>
     // shipped shape (128-VGPR budget): the lift's weights / scale / shift live in LDS ([C1][8] floats behind the activation
     // buffers) instead of 16 registers per thread -- with them the kernel needed 12 spill slots per lane, i.e. 44 B x 512 threads
     // of scratch written once by each of the 65 k workgroups of a launch (1.3 GB of HBM writes, profiles/r01_dgcnn_pmc_by_kernel.json)
-    float* wl = LD0 ? smem + kWlOff : nullptr;
-    if (LD0 && tid < (LD0 - 4)) {
+    float* wl = (LD0 && !DG_LIFT_MFMA) ? smem + kWlOff : nullptr;
+    if (LD0 && !DG_LIFT_MFMA && tid < (LD0 - 4)) {
       const ConvLayerDev& L0 = a.L[0];
 #pragma unroll
       for (int d = 0; d < 6; ++d) wl[tid * 8 + d] = L0.w[d * L0.cout + tid];
       wl[tid * 8 + 6] = L0.scale[tower * L0.cout + tid];
       wl[tid * 8 + 7] = L0.shift[tower * L0.cout + tid];
     }
+    // shipped shape, DG_LIFT_MFMA: the K = 6 lift runs on the matrix pipe as 16 x 16 x 4 tiles (k padded to 8 with zero weights and
+    // zero edge-feature columns): the [64 rows][64 channels] output is 16 tiles, two per wave, two instructions each; the wave's
+    // B fragments (2 tiles x 2 k-steps) and the tiles' scale / shift stay in 8 registers.  Per lane and slot: 4 LDS reads, 4 MFMAs,
+    // 8 fma+max, 8 LDS writes -- against 16 16-byte LDS reads and 64 VALU operations for the VALU form.
+    float lw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lsc[2] = {0.f, 0.f}, lsh[2] = {0.f, 0.f};
+    if (LD0 && DG_LIFT_MFMA) {
+      const ConvLayerDev& L0 = a.L[0];
+      if (tid < kDgTile) { es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f; }   // never written again (dg_edge_to_lds fills 0..5)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 16 * ((wave * 2 + i) & 3) + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kk = 4 * ks + (lane >> 4);
+          lw[i][ks] = kk < 6 ? L0.w[kk * (LD0 - 4) + c] : 0.f;
+        }
+        lsc[i] = L0.scale[tower * (LD0 - 4) + c];
+        lsh[i] = L0.shift[tower * (LD0 - 4) + c];
+      }
+    }
+    auto lift_mfma = [&](float* out) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int t = wave * 2 + i, rt = t >> 2, c = 16 * (t & 3) + (lane & 15);
+        const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], lw[i][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], lw[i][1], acc, 0, 0, 0);
+        float* o = out + (16 * rt + 4 * (lane >> 4)) * ld0 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * ld0] = fmaxf(fmaf(acc[r], lsc[i], lsh[i]), 0.f);
+      }
+    };
+    // (A one-barrier form -- edge features double-buffered too, each wave's lift MFMAs issued in front of its own edge MFMAs --
+    //  measured 0.776 of the roofline against 0.815 for the two-barrier loop below: DESIGN.md 4.5.)
     __syncthreads();
     DgLiftRegs lregs;
     if (!LD0) lregs = dg_lift_load(a.L[0], tower, tid);
-    dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, LD0 ? nullptr : &lregs, wl);
+    if (LD0 && DG_LIFT_MFMA) lift_mfma(smem + boff[0]);
+    else dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, LD0 ? nullptr : &lregs, wl);
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
@@ -479,7 +551,10 @@ template <int LD0 = 0, int LD1 = 0>
       if (slot == 5) DG_STAMP(2);
       __syncthreads();
       if (slot == 5) DG_STAMP(3);
-      if (more) dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, LD0 ? nullptr : &lregs, wl);
+      if (more) {
+        if (LD0 && DG_LIFT_MFMA) lift_mfma(smem + (((slot + 1) & 1) ? boff0b : boff[0]));
+        else dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, LD0 ? nullptr : &lregs, wl);
+      }
       if (slot == 5) DG_STAMP(4);
 #if DG_LIFTPRIO
       __builtin_amdgcn_s_setprio(0);

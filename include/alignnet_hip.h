@@ -171,6 +171,10 @@ int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t c
  * the current step counter when dropout_u is NULL, in the layout of dropout_u; count = B * (4 * w_hidden + w_pair_hidden).
  * A step run with these uniforms passed explicitly is bit-identical to the step that draws them itself. */
 int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, float* dst, size_t count);
+/* Test hook: the k-nearest-neighbour graph (k = 20, self included, nearest first, ties to the lower index as tf.nn.top_k;
+ * utils/tf_util_dgcnn.py:638-676) the last eval-mode forward of a dgcnn engine built: int32 [2B][num_points][20], tower 1's B
+ * clouds first.  count = 2 * B * num_points * 20. */
+int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
 
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
  *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */

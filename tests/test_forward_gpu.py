@@ -185,3 +185,60 @@ def test_forward_whole_cloud_workgroups_with_partial_tile(gpu_required, split):
     worst, unstable = compare_forward(ep, ref, spec.num_bins)
     print("worst abs err", max(worst.values()), "unstable pairs", unstable)
     assert unstable <= 64
+
+
+def _knn_graph(cfg, pcs1, pcs2):
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.forward(pcs1, pcs2)
+    g = eng.debug_knn_graph(len(pcs1))
+    eng.close()
+    return g
+
+
+@pytest.mark.parametrize("N,B", [(20, 2), (64, 3), (200, 3), (1024, 2), (1500, 2), (2048, 1), (3000, 1), (4096, 2)])
+def test_knn_graph_against_oracle(gpu_required, N, B):
+    """The neighbour graph itself (index work), read back through alignnet_debug_knn_graph, against the oracle's knn_indices
+    (utils/tf_util_dgcnn.py:638-671) evaluated in fp64 on the mean-centred clouds.  The kernel's distances are fp32, so a query's
+    list may differ from the fp64 one where two candidates are closer than fp32 resolves; the test therefore demands, for EVERY
+    query: 20 distinct in-range indices, nearest first and nothing nearer left out -- both up to the fp32 rounding of the distance
+    formula -- and counts the lists that are not identical to the oracle's (a handful per cloud at most).  N covers all three
+    compiled slot counts (16 / 32 / 64 per lane), partial pair slots and a cloud smaller than one wave."""
+    k = 20
+    d = R.synth_pairs(B, N, seed=77 + N, dtype=np.float32)
+    g = _knn_graph(small_cfg(N=N, backbone="dgcnn"), d["pcs1"], d["pcs2"])
+    assert g.shape == (2, B, N, k) and g.min() >= 0 and g.max() < N
+    differing = 0
+    for t, pcs in enumerate((d["pcs1"], d["pcs2"])):
+        x = pcs.astype(np.float64)
+        x = x - x.mean(axis=1, keepdims=True)
+        want = R.knn_indices(x, k)
+        sq = (x * x).sum(-1)
+        for b in range(B):
+            dist = sq[b][:, None] - 2.0 * x[b] @ x[b].T + sq[b][None, :]
+            got = g[t, b]
+            dg = np.take_along_axis(dist, got, axis=1)
+            eps = 64 * np.finfo(np.float32).eps * (sq[b][:, None] + sq[b].max())     # cancellation in |x|^2 - 2 x.y + |y|^2
+            assert all(len(set(r)) == k for r in got), "duplicate neighbour"
+            assert (np.diff(dg, axis=1) >= -eps).all(), "not nearest-first"
+            kth = np.sort(dist, axis=1)[:, k - 1:k]
+            assert (dg <= kth + eps).all(), "a listed neighbour is farther than the k-th nearest"
+            differing += int((got != want[b]).any(axis=1).sum())
+    print("kNN N=%d: %d of %d lists differ from the fp64 oracle's" % (N, differing, 2 * B * N))
+    assert differing <= max(2, (2 * B * N) // 200)
+
+
+@pytest.mark.parametrize("N", [64, 1536, 4096])
+def test_knn_graph_ties_bit_exact(gpu_required, N):
+    """Integer lattice points with an exactly representable, exactly zero mean: every distance is a small integer, exact in fp32, so
+    the graph must equal the oracle's index for index -- including the order within the many exact ties, where tf.nn.top_k (and the
+    oracle's stable sort) put the lower point index first."""
+    rng = np.random.default_rng(5 + N)
+    half = rng.integers(-6, 7, size=(2, N // 2, 3)).astype(np.float32)
+    pcs = np.concatenate([half, -half], axis=1)                       # mean exactly 0 in any summation order
+    pcs = pcs[:, rng.permutation(N)]
+    g = _knn_graph(small_cfg(N=N, backbone="dgcnn"), pcs[:1], pcs[1:])
+    want = R.knn_indices(pcs.astype(np.float64), 20)
+    np.testing.assert_array_equal(g[0, 0], want[0])
+    np.testing.assert_array_equal(g[1, 0], want[1])

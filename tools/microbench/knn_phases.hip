@@ -1,4 +1,4 @@
-// Cycle stamps of one kNN query wave at its phase boundaries (keying | bound | compaction | select | emit).
+// Cycle stamps of one kNN wave at its phase boundaries (table build | distances of two queries | then for the first query: bound | compaction | rank+emit | and the whole round).
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 -DALIGNNET_KNN_STAMP -I alignnet-3d_amd/csrc tools/microbench/knn_phases.hip -o tools/microbench/knn_phases
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,15 +15,16 @@ __global__ void knn_check(const float* pcs1, const float* pcs2, const float* cen
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   const float cx = center[cloud * 3], cy = center[cloud * 3 + 1], cz = center[cloud * 3 + 2];
   const float qx = pc[q * 3] - cx, qy = pc[q * 3 + 1] - cy, qz = pc[q * 3 + 2] - cz;
-  const float qq = qx * qx + qy * qy + qz * qz;
+  const float qq = fmaf(qz, qz, fmaf(qy, qy, qx * qx));
+  const float q2x = -2.0f * qx, q2y = -2.0f * qy, q2z = -2.0f * qz;
   unsigned long long prev = 0; bool first = true;
   unsigned long long want[32];
   for (int s = 0; s < k; ++s) {
     unsigned long long best = ~0ull;
     for (int j = 0; j < N; ++j) {
       const float x = pc[j * 3] - cx, y = pc[j * 3 + 1] - cy, z = pc[j * 3 + 2] - cz;
-      const float inner = -2.0f * (qx * x + qy * y + qz * z);
-      const unsigned long long kk = ((unsigned long long)fkey(qq + inner + (x * x + y * y + z * z)) << 32) | (unsigned)j;
+      const float inner = fmaf(q2z, z, fmaf(q2y, y, q2x * x));
+      const unsigned long long kk = ((unsigned long long)fkey(qq + inner + fmaf(z, z, fmaf(y, y, x * x))) << 32) | (unsigned)j;
       if ((first || kk > prev) && kk < best) best = kk;
     }
     want[s] = best; prev = best; first = false;
@@ -39,8 +40,8 @@ __global__ void knn_check(const float* pcs1, const float* pcs2, const float* cen
     for (int s = 0; s < k; ++s) {
       const int j = got[s];
       const float x = pc[j * 3] - cx, y = pc[j * 3 + 1] - cy, z = pc[j * 3 + 2] - cz;
-      const float inner = -2.0f * (qx * x + qy * y + qz * z);
-      printf("q %d cloud %d  got %4d key %08x | want %4d key %08x\n", q, cloud, j, fkey(qq + inner + (x * x + y * y + z * z)),
+      const float inner = fmaf(q2z, z, fmaf(q2y, y, q2x * x));
+      printf("q %d cloud %d  got %4d key %08x | want %4d key %08x\n", q, cloud, j, fkey(qq + inner + fmaf(z, z, fmaf(y, y, x * x))),
              (int)(want[s] & 0xffffffffu), (unsigned)(want[s] >> 32));
     }
   }
@@ -61,13 +62,13 @@ int main(int argc, char** argv)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(N <= 1024 ? knn_kernel<16> : N <= 2048 ? knn_kernel<32> : knn_kernel<64>, dim3((N + 3) / 4, 2 * B), dim3(256), 0, 0, d1, d2, dc, B, N, k, nn);
+    launch_knn(0, 0, d1, d2, dc, B, N, k, nn);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long st[8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_knn_stamp), sizeof(st));
-    printf("N=%d clouds=%d  %.3f ms | cycles: keying %lld bound %lld compaction %lld select %lld emit %lld\n", N, 2 * B, ms,
-           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4]);
+    printf("N=%d clouds=%d  %.3f ms | cycles: table %lld | last round: distances %lld bound %lld compaction %lld rank+emit %lld round %lld\n", N, 2 * B, ms,
+           st[1] - st[0], st[2] - st[7], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[7]);
   }
   int* dbad; hipMalloc(&dbad, 4); hipMemset(dbad, 0, 4);
   const int cb = 2 * B < 4 ? 2 * B : 4;   // check the first clouds
