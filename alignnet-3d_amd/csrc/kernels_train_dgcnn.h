@@ -178,6 +178,54 @@ __device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restr
   }
 }
 
+// The same lift on the matrix pipe (C1 a multiple of 16): k padded to 8 -- zero weights, and es columns 6 / 7 zeroed once by the
+// caller -- and the [64 rows][C1] output cut into 16 x 16 tiles (v_mfma_f32_16x16x4_f32, two instructions per tile), the tiles
+// dealt round-robin to the NW waves; a wave's B fragments and its tiles' scale / shift stay in registers.  Per lane and tile: two
+// 4-byte LDS reads, two MFMAs, four fma + max + select, four LDS writes -- the VALU form costs 16 rows x (two 16-byte reads +
+// 8 operations) per lane and ran 3.5x slower whenever the co-resident workgroup streamed MFMAs.
+template <int C1, int NW>
+struct DgtLiftM {
+  static constexpr int kCT = C1 / 16, kTiles = (kTT / 16) * kCT, kPer = kTiles / NW;
+  static_assert(C1 % 16 == 0 && kTiles % NW == 0, "lift tiles must divide over the waves");
+  float w[kPer][2], sc[kPer], sh[kPer];
+};
+
+template <int C1, int NW>
+__device__ __forceinline__ DgtLiftM<C1, NW> dgt_liftm_load(const float* __restrict__ w1, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, int wave, int lane)
+{
+  DgtLiftM<C1, NW> R;
+#pragma unroll
+  for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
+    const int t = wave * DgtLiftM<C1, NW>::kPer + i, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = 4 * ks + (lane >> 4);
+      R.w[i][ks] = kk < 6 ? w1[kk * C1 + c] : 0.f;
+    }
+    R.sc[i] = sc[c]; R.sh[i] = sh[c];
+  }
+  return R;
+}
+
+template <int C1, int NW>
+__device__ __forceinline__ void dgt_liftm(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, float* __restrict__ out, int ldo,
+                                          int nvalid, int wave, int lane)
+{
+#pragma unroll
+  for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
+    const int t = wave * DgtLiftM<C1, NW>::kPer + i, rt = t / DgtLiftM<C1, NW>::kCT, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
+    const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], R.w[i][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], R.w[i][1], acc, 0, 0, 0);
+    const int row0 = 16 * rt + 4 * (lane >> 4);
+    float* o = out + row0 * ldo + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * ldo] = row0 + r < nvalid ? fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f) : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // phase 2: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
 // edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
@@ -208,7 +256,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const float sgn = (live && a.gamma2[tower][col] < 0.f) ? -1.f : 1.f;
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
-  const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
+  const DgtLiftM<C1, kTW> lw = dgt_liftm_load<C1, kTW>(a.w1, sc1, sh1, wave, lane);
   // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups), with the column's sign(gamma2)
   // folded in (exact): the accumulator is sgn * (z2 - bias), so the extreme over the slots is a plain max and the sums are
   // those of sgn * (z2 - bias), put right at the end
@@ -238,9 +286,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   if (tid < kTT) {
     dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
     dg_edge_to_lds(xf, v, es + tid * 8);
+    es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift: never written again
   }
   __syncthreads();
-  dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8, ld0, min(kTT, a.N), tid);
+  dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8, ld0, min(kTT, a.N), wave, lane);
   __syncthreads();
   for (int it = 0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
@@ -322,7 +371,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     FE_STAMP(4);
     __syncthreads();
     FE_STAMP(5);
-    if (more) dgt_lift(lw, a.w1, C1, sc1, sh1, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), tid);
+    if (more) dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), wave, lane);
     FE_STAMP(6);
     __syncthreads();
     FE_STAMP(7);
@@ -460,7 +509,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
-  const DgtLiftW lw = dgt_lift_load(a.w1, C1, sc1, sh1, tid);
+  const DgtLiftM<C1, kBEW> lw = dgt_liftm_load<C1, kBEW>(a.w1, sc1, sh1, wave, lane);
+  if (tid < 2 * kTT) { smem[tid * 8 + 6] = 0.f; smem[tid * 8 + 7] = 0.f; }   // k padding of the MFMA lift in both es buffers: never written again
   // roles: waves [0, nitems) own one dh1 item (channel tile, 32-row group), nitems <= 4; waves 4..7 the sparse U2 units (P2)
   constexpr int nitems = CT1 * 2;
   // the dh1 waves keep their Q2 fragments in registers for the whole cloud (C1 <= 64: 8 k-groups); streaming them per slot
@@ -603,7 +653,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);
     }
     BE_STAMP(2);
-    dgt_lift<kBEW * 64>(lw, a.w1, C1, sc1, sh1, es, X, ld0, nvalid, tid);
+    dgt_liftm<C1, kBEW>(lw, es, X, ld0, nvalid, wave, lane);
     BE_STAMP(3);
     if (p1on) {   // D[row][8 ch ..] = sum_c dp[row,c] V2[c][8 ch ..] over the row's slot columns
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
