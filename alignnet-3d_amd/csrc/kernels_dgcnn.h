@@ -302,7 +302,7 @@ __device__ __forceinline__ DgLiftRegs dg_lift_load(const ConvLayerDev& L, int to
 }
 
 __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const float* es, float* out, int ldo, int tid,
-                                        const DgLiftRegs* regs = nullptr, const float* wl = nullptr)
+                                        const DgLiftRegs* regs = nullptr)
 {
   const int c0 = tid & 31, r0 = tid >> 5;
   const int cw = (L.cout + 7) & ~7;
@@ -311,10 +311,7 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
     const int g = (c - c0) >> 5;
     float w[6];
     float sc, sh;
-    if (wl) {   // the layer's [w0..w5, scale, shift] rows staged in LDS by the caller (two 16-byte reads per channel)
-      const f32x4 q0 = *reinterpret_cast<const f32x4*>(wl + c * 8), q1 = *reinterpret_cast<const f32x4*>(wl + c * 8 + 4);
-      w[0] = q0[0]; w[1] = q0[1]; w[2] = q0[2]; w[3] = q0[3]; w[4] = q1[0]; w[5] = q1[1]; sc = q1[2]; sh = q1[3];
-    } else if (regs && g < 2) {
+    if (regs && g < 2) {
 #pragma unroll
       for (int d = 0; d < 6; ++d) w[d] = g ? regs->w[1][d] : regs->w[0][d];
       sc = g ? regs->sc[1] : regs->sc[0]; sh = g ? regs->sh[1] : regs->sh[0];
@@ -338,9 +335,6 @@ __device__ __forceinline__ void dg_lift(const ConvLayerDev& L, int tower, const 
 
 // LD0 / LD1 != 0: the shipped shape compiled in -- widths [LD0 - 4, LD1 - 4, C3], three layers -- so that LDS strides, k-depths
 // and tile counts are constants (as for pointnet_fused: fewer address registers, no generic layer dispatch)
-#ifndef DG_LIFT_MFMA
-#define DG_LIFT_MFMA 1
-#endif
 template <int LD0 = 0, int LD1 = 0>
 [[maybe_unused]] static __global__ __launch_bounds__(kWaves * 64, LD0 ? DGLB : 2) void dgcnn_fused(const DgcnnArgs a)
 {
@@ -353,12 +347,14 @@ template <int LD0 = 0, int LD1 = 0>
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* es = smem;                                   // edge features of the slot being lifted
-  // generic: es | buf0 | buf1 | buf0'.  Shipped shape (LD0): es | buf0 | buf0' | lift table [64][8] | W2 image [4][8][64][4], and
+  // generic: es | buf0 | buf1 | buf0'.  Shipped shape (LD0): es | buf0 | buf0' | W2 image [4][8][64][4], and
   // buf1 (the pooled edge features, written after the neighbour loop when both lift buffers are dead) aliases buf0 / buf0'.
-  const int boff[2] = {kDgTile * 8, LD0 ? kDgTile * 8 : kDgTile * 8 + kDgTile * ld0};
-  const int boff0b = LD0 ? kDgTile * 8 + kDgTile * ld0 : kDgTile * 8 + kDgTile * (ld0 + ld1);   // second lift buffer
-  constexpr int kWlOff = kDgTile * 8 + kDgTile * 2 * (LD0 ? LD0 : 1);      // shipped shape only
-  constexpr int kW2Off = kWlOff + 64 * 8;
+  // (shipped shape: edge-feature rows 9 floats apart -- the MFMA lift reads them 4 bytes per lane, 16 rows per k, and at 8 floats
+  //  rows r and r + 8 share a bank: that was the kernel's 26 M LDS conflict cycles per launch)
+  constexpr int kEsLd = LD0 ? 9 : 8, kEs = kDgTile * kEsLd;
+  const int boff[2] = {kEs, LD0 ? kEs : kEs + kDgTile * ld0};
+  const int boff0b = LD0 ? kEs + kDgTile * ld0 : kEs + kDgTile * (ld0 + ld1);   // second lift buffer
+  constexpr int kW2Off = kEs + kDgTile * 2 * (LD0 ? LD0 : 1);      // shipped shape only
   static_assert(!LD0 || kDgTile * LD1 <= 2 * kDgTile * LD0, "the pooled edge features must fit the two lift buffers they alias");
   const int nl = LD0 ? 3 : a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
   const int nvalid = min(kDgTile, a.N - tile * kDgTile);
@@ -473,27 +469,17 @@ template <int LD0 = 0, int LD1 = 0>
       dg_gather(a, pc, cloud, tile, 0, tid, v);
       own[0] = v[0]; own[1] = v[1]; own[2] = v[2];
       jn = dg_nn_index(a, cloud, tile, 1, tid);
-      dg_edge_to_lds(xf, v, es + tid * 8);
+      dg_edge_to_lds(xf, v, es + tid * kEsLd);
     }
-    // shipped shape (128-VGPR budget): the lift's weights / scale / shift live in LDS ([C1][8] floats behind the activation
-    // buffers) instead of 16 registers per thread -- with them the kernel needed 12 spill slots per lane, i.e. 44 B x 512 threads
-    // of scratch written once by each of the 65 k workgroups of a launch (1.3 GB of HBM writes, profiles/r01_dgcnn_pmc_by_kernel.json)
-    float* wl = (LD0 && !DG_LIFT_MFMA) ? smem + kWlOff : nullptr;
-    if (LD0 && !DG_LIFT_MFMA && tid < (LD0 - 4)) {
-      const ConvLayerDev& L0 = a.L[0];
-#pragma unroll
-      for (int d = 0; d < 6; ++d) wl[tid * 8 + d] = L0.w[d * L0.cout + tid];
-      wl[tid * 8 + 6] = L0.scale[tower * L0.cout + tid];
-      wl[tid * 8 + 7] = L0.shift[tower * L0.cout + tid];
-    }
-    // shipped shape, DG_LIFT_MFMA: the K = 6 lift runs on the matrix pipe as 16 x 16 x 4 tiles (k padded to 8 with zero weights and
+    // shipped shape: the K = 6 lift runs on the matrix pipe as 16 x 16 x 4 tiles (k padded to 8 with zero weights and
     // zero edge-feature columns): the [64 rows][64 channels] output is 16 tiles, two per wave, two instructions each; the wave's
     // B fragments (2 tiles x 2 k-steps) and the tiles' scale / shift stay in 8 registers.  Per lane and slot: 4 LDS reads, 4 MFMAs,
-    // 8 fma+max, 8 LDS writes -- against 16 16-byte LDS reads and 64 VALU operations for the VALU form.
+    // 8 fma+max, 8 LDS writes -- against 16 16-byte LDS reads and 64 VALU operations for the VALU form (whose weights, at the 128-VGPR
+    // budget of two workgroups per CU, had to live in LDS or spill: profiles/r01_dgcnn_pmc_by_kernel.json, 1.3 GB of scratch writes).
     float lw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lsc[2] = {0.f, 0.f}, lsh[2] = {0.f, 0.f};
-    if (LD0 && DG_LIFT_MFMA) {
+    if (LD0) {
       const ConvLayerDev& L0 = a.L[0];
-      if (tid < kDgTile) { es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f; }   // never written again (dg_edge_to_lds fills 0..5)
+      if (tid < kDgTile) { es[tid * kEsLd + 6] = 0.f; es[tid * kEsLd + 7] = 0.f; }   // never written again (dg_edge_to_lds fills 0..5)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int c = 16 * ((wave * 2 + i) & 3) + (lane & 15);
@@ -510,7 +496,7 @@ template <int LD0 = 0, int LD1 = 0>
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int t = wave * 2 + i, rt = t >> 2, c = 16 * (t & 3) + (lane & 15);
-        const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+        const float* ar = es + (16 * rt + (lane & 15)) * kEsLd + (lane >> 4);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], lw[i][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], lw[i][1], acc, 0, 0, 0);
@@ -524,8 +510,8 @@ template <int LD0 = 0, int LD1 = 0>
     __syncthreads();
     DgLiftRegs lregs;
     if (!LD0) lregs = dg_lift_load(a.L[0], tower, tid);
-    if (LD0 && DG_LIFT_MFMA) lift_mfma(smem + boff[0]);
-    else dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, LD0 ? nullptr : &lregs, wl);
+    if (LD0) lift_mfma(smem + boff[0]);
+    else dg_lift(a.L[0], tower, es, smem + boff[0], ld0, tid, &lregs);
     __syncthreads();
     for (int slot = 0; slot < a.k; ++slot) {
       const bool more = slot + 1 < a.k;
@@ -546,14 +532,14 @@ template <int LD0 = 0, int LD1 = 0>
 #endif
       if (more && tid < kDgTile) {
         v[0] = own[0]; v[1] = own[1]; v[2] = own[2]; v[3] = nb[0] - own[0]; v[4] = nb[1] - own[1]; v[5] = nb[2] - own[2];
-        dg_edge_to_lds(xf, v, es + tid * 8);
+        dg_edge_to_lds(xf, v, es + tid * kEsLd);
       }
       if (slot == 5) DG_STAMP(2);
       __syncthreads();
       if (slot == 5) DG_STAMP(3);
       if (more) {
-        if (LD0 && DG_LIFT_MFMA) lift_mfma(smem + (((slot + 1) & 1) ? boff0b : boff[0]));
-        else dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, LD0 ? nullptr : &lregs, wl);
+        if (LD0) lift_mfma(smem + (((slot + 1) & 1) ? boff0b : boff[0]));
+        else dg_lift(a.L[0], tower, es, smem + (((slot + 1) & 1) ? boff0b : boff[0]), ld0, tid, &lregs);
       }
       if (slot == 5) DG_STAMP(4);
 #if DG_LIFTPRIO
