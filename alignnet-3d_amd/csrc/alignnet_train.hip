@@ -553,7 +553,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
-  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1) {
+  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, StatFinishArgs* keep = nullptr) {
     StatFinishArgs f;
     f.part = w->stat_part; f.B = nb < 0 ? B : nb; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
     for (int t = 0; t < 2; ++t) {
@@ -565,7 +565,16 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.sgn = nullptr; f.next_gamma[0] = f.next_gamma[1] = nullptr;
     if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
     f.rstd = S.rstd[l]; f.k = S.kk[l];
+    if (keep) { *keep = f; return; }   // launched by the caller together with independent reductions (stat_finish_reduce_kernel)
     hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, h->stream, f);
+  };
+  // the last layer's statistics finish + the reductions of the Gram / column-sum partials of h2: independent, one launch
+  auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) {
+    StatFinishArgs f;
+    finish(2, C3, 2, count, -1, &f);
+    ReduceJobs J{{ja, jb, ReduceJob{nullptr, 0, 0, 0, nullptr, 1.f, 0}}};
+    const long nmax = std::max(std::max(ja.n, jb.n), (long)C3);
+    hipLaunchKernelGGL(stat_finish_reduce_kernel, dim3((unsigned)((nmax + 31) / 32), 2, 3), dim3(1024), 0, h->stream, f, J, 2);
   };
   if (dg) {
     // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
@@ -609,8 +618,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
-    finish(2, C3, 2, count);
-    launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
+    finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
   hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
@@ -668,14 +676,15 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                          w->gram_part);
     }
   }
-  finish(2, C3, 2, count);
-  launch_reduce_multi(h, 2, rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
+  finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
   }
-  hipLaunchKernelGGL(centre_gram_kernel, dim3((C2 * C2 + 255) / 256, 2), dim3(256), 0, h->stream, S.gram2, S.s2, C2, count, S.m2);
-  const size_t tot = (size_t)2 * B * C3;
-  hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b),
-                     S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled, S.tower_stride, S.row_stride, S.zhat_star, S.idx,
-                     h->train_bf16 ? 1 : 0);
+  {   // centred Gram of h2 + pooled features: independent of each other, one launch
+    const size_t tot = (size_t)2 * B * C3;
+    const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
+                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, h->train_bf16 ? 1 : 0};
+    hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
+                       S.gram2, S.s2, C2, count, S.m2, pa);
+  }
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -830,9 +839,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
-  hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C2 * C3), dim3(256), 0, h->stream, w->Sp, (const float*)nullptr, S.m2, w->kdb3, w->GW,
-                     w->E3, C2, C3, G(h, w, L[2]->p_w));
-  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, w->E3, w->W3E, 0, 2, (const float*)nullptr, w->W3T, 1, 1);
+  // dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)  and  W3E[t] = W3 diag(E[t]), W3T = W3^T  (one launch: nothing in it depends on the other part)
+  hipLaunchKernelGGL(combine_scale_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 3), dim3(256), 0, h->stream, w->Sp, S.m2, w->kdb3, w->GW, w->E3,
+                     C2, C3, G(h, w, L[2]->p_w), W3, w->W3E, w->W3T);
   const size_t qimg = img_floats(C2, C2);
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
@@ -841,10 +850,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
-    hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(8, 2), dim3(256), 0, h->stream, pj);
-  } else
+    // (+ the pass's bias row q3b, which reads the same fresh Q3: one launch)
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C2, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b});
+  } else {
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
-  hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+    hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+  }
   // ---- pass B2 ----
   BwdB2Args b2;
   b2.pcs[0] = p1; b2.pcs[1] = p2; b2.xform = S.xform; b2.B = B; b2.N = N; b2.C1 = C1; b2.C2 = C2; b2.C3 = C3;
@@ -912,7 +923,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
   const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
   if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
-  hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);
+  if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
   if (dg) {
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
     DgBwdArgs e;
@@ -974,7 +985,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
       pj.src[t] = w->V2 + (size_t)t * C1 * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;
       pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;
     }
-    hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(8, 4), dim3(256), 0, h->stream, pj);
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 4), dim3(256), 0, h->stream, pj, 4, 8u, QBiasArgs{w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b});
     BwdB1hArgs bh;
     bh.pcs[0] = p1; bh.pcs[1] = p2; bh.xform = S.xform; bh.B = B; bh.N = N;
     bh.w1 = P(h, L[0]->p_w); bh.sc1 = S.scale[0]; bh.sh1 = S.shift[0];

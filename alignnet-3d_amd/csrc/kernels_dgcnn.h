@@ -634,7 +634,9 @@ template <int LD0 = 0, int LD1 = 0>
           if (row < nvalid) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
+      // (values only grow and start at 0: a tile that does not beat what is already there -- most of a cloud's 64 tiles -- skips the
+      //  atomic; a stale read can only cause a redundant one.  The per-tile atomics were 156 MB of write traffic per launch.)
+      if (lane < 32 && live && mx > dst[col]) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
     }
   }
   DG_STAMP(8);

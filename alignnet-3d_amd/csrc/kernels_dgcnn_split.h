@@ -248,7 +248,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
           if (row < nvalid) mx = fmaxf(mx, fmaf(acc[m][r], sc, sh));
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (lane < 32 && live) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));   // >= 0: monotone bit pattern
+      if (lane < 32 && live && mx > dst[col]) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));   // >= 0: monotone bit pattern; skipped when the tile does not beat the running max
     }
   }
 }

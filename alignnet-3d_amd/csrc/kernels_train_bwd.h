@@ -575,15 +575,14 @@ constexpr int kPackBf16Jobs = 9;
 struct PackBf16Jobs { const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs]; };
 // bf16 MFMA images (layout and sign folding of pack_weights_bf16_kernel: gamma null = none) of up to nine matrices in one launch,
 // grid (blocks, jobs): a training step re-packs 9 + 3 x 6 images, each its own 4.5 us launch before
-__global__ void pack_bf16_jobs_kernel(const PackBf16Jobs j)
+__device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsigned bx, int q, unsigned gx)
 {
-  const int q = blockIdx.y;
   const float* W = j.src[q];
   if (!W) return;
   const float* gamma = j.gamma[q];
   const int K = j.K[q], C = j.C[q], KG = (K + 15) >> 4, CT = (C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 512;
-  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+  for (size_t idx = bx * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gx * 256) {
     const int s8 = idx & 7, lane = (idx >> 3) & 63;
     const size_t t = idx >> 9;
     const int kg = t % KG, ct = t / KG;
@@ -593,6 +592,7 @@ __global__ void pack_bf16_jobs_kernel(const PackBf16Jobs j)
     j.dst[q][idx] = to_bf16_bits(v);
   }
 }
+__global__ __launch_bounds__(256) void pack_bf16_jobs_kernel(const PackBf16Jobs j) { pack_bf16_jobs_body(j, blockIdx.x, blockIdx.y, gridDim.x); }
 
 struct BwdB1hArgs {
   const float* pcs[2]; const float* xform; int B, N;
@@ -877,13 +877,13 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
 // grid (max over jobs of ceil(n/32), 2 towers, jobs).  Same summation order as reduce_slices_kernel.
 struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers; };
 struct ReduceJobs { ReduceJob j[3]; };
-__global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs jobs)
+__device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx, int t, int bz)
 {
   __shared__ double red[32][33];
-  const ReduceJob jb = jobs.j[blockIdx.z];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, t = blockIdx.y;
-  const long i = blockIdx.x * 32L + cl;
-  if (t >= jb.towers || blockIdx.x * 32L >= jb.n) return;
+  const ReduceJob jb = jobs.j[bz];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long i = bx * 32L + cl;
+  if (t >= jb.towers || bx * 32L >= jb.n) return;
   double s = 0.0;
   if (i < jb.n) {
     if (jb.is_double) { const double* p = static_cast<const double*>(jb.part); for (int k = g; k < jb.S; k += 32) s += p[((size_t)t * jb.S + k) * jb.n + i]; }
@@ -898,14 +898,23 @@ __global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs job
     jb.out[(size_t)t * jb.n + i] = (float)tot * jb.alpha;
   }
 }
+__global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs jobs) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// A layer's statistics finish and up to three slice reductions that do not depend on it, in one launch: grid (max of the two
+// x extents, 2 towers, njobs + 1), block 1024; z = njobs is the statistics finish.
+__global__ __launch_bounds__(1024) void stat_finish_reduce_kernel(const StatFinishArgs f, const ReduceJobs jobs, int njobs)
+{
+  if ((int)blockIdx.z < njobs) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z); return; }
+  const int gx = (f.C + 31) / 32;
+  if ((int)blockIdx.x < gx) stat_finish_body(f, blockIdx.x, blockIdx.y, gx);
+}
 
 // centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
-__global__ void centre_gram_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m)
+__device__ __forceinline__ void centre_gram_body(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m, unsigned bx, int t)
 {
   // Only the 32 x 32 blocks on or above the block diagonal are read (the bf16 forward accumulates just those); each of
   // their elements is centred and mirrored into the block below the diagonal by the same thread.
-  const int t = blockIdx.y;
-  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long e = bx * 256L + threadIdx.x;
   if (e >= (long)C * C) return;
   const int i = e / C, j = e % C;
   if (j == 0) m[t * C + i] = (float)((double)s[t * C + i] / M);
@@ -914,6 +923,19 @@ __global__ void centre_gram_kernel(float* __restrict__ G, const float* __restric
   const float v = (float)((double)Gt[e] - (double)s[t * C + i] * (double)s[t * C + j] / M);
   Gt[e] = v;
   if ((i >> 5) < (j >> 5)) Gt[(size_t)j * C + i] = v;
+}
+__global__ __launch_bounds__(256) void centre_gram_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m)
+{
+  centre_gram_body(G, s, C, M, m, blockIdx.x, blockIdx.y);
+}
+// the forward's last two small launches of a stage in one (independent of each other): blocks [0, 2 nG) centre the Gram of h2,
+// the rest finish the pooled features; block 256
+__global__ __launch_bounds__(256) void gram_pool_finish_kernel(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m,
+                                                               const PoolFinishArgs pa)
+{
+  const unsigned nG = (unsigned)((C * C + 255) / 256);
+  if (blockIdx.x < 2 * nG) centre_gram_body(G, s, C, M, m, blockIdx.x % nG, blockIdx.x / nG);
+  else pool_finish_body(pa, blockIdx.x - 2 * nG);
 }
 
 // last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0
@@ -1020,11 +1042,10 @@ __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict
 }
 
 // two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)
-__global__ void scale_cols2_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ colA, float* __restrict__ outA, int trA,
-                                   int towersA, const float* __restrict__ colB, float* __restrict__ outB, int trB, int towersB)
+__device__ __forceinline__ void scale_cols2_body(const float* __restrict__ W, int R, int C, const float* __restrict__ colA, float* __restrict__ outA, int trA,
+                                                 int towersA, const float* __restrict__ colB, float* __restrict__ outB, int trB, int towersB, unsigned bx, int t)
 {
-  const int t = blockIdx.y;
-  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long e = bx * 256L + threadIdx.x;
   if (e >= (long)R * C) return;
   const int i = e / C, j = e % C;
   const float wv = W[e];
@@ -1037,13 +1058,18 @@ __global__ void scale_cols2_kernel(const float* __restrict__ W, int R, int C, co
     outB[(size_t)t * R * C + (trB ? (size_t)j * R + i : (size_t)e)] = v;
   }
 }
+__global__ __launch_bounds__(256) void scale_cols2_kernel(const float* __restrict__ W, int R, int C, const float* __restrict__ colA, float* __restrict__ outA, int trA,
+                                                          int towersA, const float* __restrict__ colB, float* __restrict__ outB, int trB, int towersB)
+{
+  scale_cols2_body(W, R, C, colA, outA, trA, towersA, colB, outB, trB, towersB, blockIdx.x, blockIdx.y);
+}
 
 // dW[i][j] (+)= sum_t ( Sp[t][i][j]*spscale[t][j] - m[t][i]*kdb[t][j] + GW[t][i][j]*E[t][j] )
-__global__ void combine_dw_kernel(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
-                                  const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
-                                  int R, int C, float* __restrict__ dW)
+__device__ __forceinline__ void combine_dw_body(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
+                                                const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
+                                                int R, int C, float* __restrict__ dW, unsigned bx)
 {
-  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long e = bx * 256L + threadIdx.x;
   if (e >= (long)R * C) return;
   const int i = e / C, j = e % C;
   float s = 0.f;
@@ -1053,14 +1079,32 @@ __global__ void combine_dw_kernel(const float* __restrict__ Sp, const float* __r
   }
   dW[e] = s;
 }
+__global__ __launch_bounds__(256) void combine_dw_kernel(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
+                                                         const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
+                                                         int R, int C, float* __restrict__ dW)
+{
+  combine_dw_body(Sp, spscale, m, kdb, GW, E, R, C, dW, blockIdx.x);
+}
+// layer 3 of a stage: the weight gradient's combine and the two scaled copies of W3 the backward needs next, one launch
+// (grid (ceil(R C / 256), 3): y < 2 the copies of tower y, y = 2 the combine)
+__global__ __launch_bounds__(256) void combine_scale_kernel(const float* __restrict__ Sp, const float* __restrict__ m, const float* __restrict__ kdb,
+                                                            const float* __restrict__ GW, const float* __restrict__ E, int R, int C, float* __restrict__ dW,
+                                                            const float* __restrict__ W, float* __restrict__ WE, float* __restrict__ WT)
+{
+  if (blockIdx.y == 2) combine_dw_body(Sp, nullptr, m, kdb, GW, E, R, C, dW, blockIdx.x);
+  else scale_cols2_body(W, R, C, E, WE, 0, 2, nullptr, WT, 1, 1, blockIdx.x, blockIdx.y);
+}
 
 // qb[t][j] = -sum_i m[t][i] Q[t][i][j] - sum_c W[j][c] kdb[t][c] / M      (W: [R=Cin][C=Cout])
 // grid (Cin, 2), block 256: the two sums are spread over the block and reduced (fp64)
-__global__ __launch_bounds__(256) void qbias_kernel(const float* __restrict__ Q, const float* __restrict__ m, const float* __restrict__ W,
-                                                    const float* __restrict__ kdb, int Cin, int Cout, double M, float* __restrict__ qb)
+struct QBiasArgs { const float* Q; const float* m; const float* W; const float* kdb; int Cin, Cout; double M; float* qb; };
+__device__ __forceinline__ void qbias_body(const QBiasArgs& a, int j, int t)
 {
   __shared__ double red[4];
-  const int j = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  const float* __restrict__ Q = a.Q; const float* __restrict__ m = a.m; const float* __restrict__ W = a.W; const float* __restrict__ kdb = a.kdb;
+  float* __restrict__ qb = a.qb;
+  const int Cin = a.Cin, Cout = a.Cout, tid = threadIdx.x;
+  const double M = a.M;
   double s = 0.0;
   for (int i = tid; i < Cin; i += 256) s -= (double)m[t * Cin + i] * Q[((size_t)t * Cin + i) * Cin + j];
   for (int c = tid; c < Cout; c += 256) s -= (double)W[(size_t)j * Cout + c] * kdb[t * Cout + c] / M;
@@ -1069,6 +1113,19 @@ __global__ __launch_bounds__(256) void qbias_kernel(const float* __restrict__ Q,
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   if (tid == 0) qb[t * Cin + j] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void qbias_kernel(const float* __restrict__ Q, const float* __restrict__ m, const float* __restrict__ W,
+                                                    const float* __restrict__ kdb, int Cin, int Cout, double M, float* __restrict__ qb)
+{
+  qbias_body(QBiasArgs{Q, m, W, kdb, Cin, Cout, M, qb}, blockIdx.x, blockIdx.y);
+}
+
+// the bf16 images of a pass's Q / V matrices and the pass's bias row q_b (both read the same fresh Q), one launch:
+// grid (pack_gx + Cin, max(jobs, 2)), block 256: x < pack_gx packs job y, the rest is qbias_kernel's grid (Cin, 2)
+__global__ __launch_bounds__(256) void pack_qbias_kernel(const PackBf16Jobs j, int njobs, unsigned pack_gx, const QBiasArgs qa)
+{
+  if (blockIdx.x < pack_gx) { if ((int)blockIdx.y < njobs) pack_bf16_jobs_body(j, blockIdx.x, blockIdx.y, pack_gx); }
+  else if (blockIdx.y < 2) qbias_body(qa, blockIdx.x - pack_gx, blockIdx.y);
 }
 
 }  // namespace alignnet

@@ -892,12 +892,13 @@ struct StatFinishArgs {
   float* rstd; float* k;     // [2][C]: rsqrt(var+eps) and gamma*rsqrt(var+eps) (backward passes)
 };
 
-__global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs a)   // grid (ceil(C/32), 2), block 32 channels x 32 slice groups
+// (body and kernel apart: the step also runs it as one job of a merged launch, kernels_train_bwd.h)
+__device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx, int t, int gx)   // grid (gx = ceil(C/32), 2), block 32 channels x 32 slice groups
 {
   __shared__ double red[32][32][2];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = bx * 32 + cl;
   if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
-    for (int i = blockIdx.x * 1024 + threadIdx.x; i < a.next_C; i += gridDim.x * 1024) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
+    for (int i = bx * 1024 + threadIdx.x; i < a.next_C; i += gx * 1024) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
   const int S = a.B * a.slices;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
@@ -926,6 +927,7 @@ __global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs 
     a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
   }
 }
+__global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs a) { stat_finish_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 __global__ void sign_kernel(const float* __restrict__ gamma, int C, float* __restrict__ sgn)
 {
@@ -946,14 +948,20 @@ __global__ void rstd_k_kernel(const float* __restrict__ var, const float* __rest
 
 // pooled[t,b,c] = relu(scale*(sgn*ext - bias) + shift);  also keeps zhat* = (z* - mean)*rsqrt(var+eps) and the
 // final arg-extreme index (combining the two half-wave slices; first occurrence wins ties)
-__global__ void pool_finish_kernel(const float* __restrict__ ext, const int* __restrict__ idx2, const float* __restrict__ sgn,
-                                   const float* __restrict__ bias, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, const float* __restrict__ mean,
-                                   const float* __restrict__ var, int B, int C, float* __restrict__ pooled,
-                                   long tower_stride, long row_stride, float* __restrict__ zhat_star, int* __restrict__ idx,
-                                   int ext_excludes_bias)   // bf16 mode: ext = extreme of sgn*(z - bias)
+struct PoolFinishArgs {
+  const float* ext; const int* idx2; const float* sgn; const float* bias; const float* scale; const float* shift; const float* mean; const float* var;
+  int B, C; float* pooled; long tower_stride, row_stride; float* zhat_star; int* idx;
+  int ext_excludes_bias;   // bf16 mode: ext = extreme of sgn*(z - bias)
+};
+__device__ __forceinline__ void pool_finish_body(const PoolFinishArgs& a, unsigned bx)   // 256 threads per block, ceil(2 B C / 256) blocks
 {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const float* __restrict__ ext = a.ext; const int* __restrict__ idx2 = a.idx2; const float* __restrict__ sgn = a.sgn;
+  const float* __restrict__ bias = a.bias; const float* __restrict__ scale = a.scale; const float* __restrict__ shift = a.shift;
+  const float* __restrict__ mean = a.mean; const float* __restrict__ var = a.var;
+  float* __restrict__ pooled = a.pooled; float* __restrict__ zhat_star = a.zhat_star; int* __restrict__ idx = a.idx;
+  const int B = a.B, C = a.C, ext_excludes_bias = a.ext_excludes_bias;
+  const long tower_stride = a.tower_stride, row_stride = a.row_stride;
+  const size_t i = bx * (size_t)256 + threadIdx.x;
   if (i >= (size_t)2 * B * C) return;
   const int c = i % C, cloud = i / C, t = cloud >= B, b = cloud - t * B;
   const size_t h0 = ((size_t)cloud * 2) * C + c, h1 = h0 + C;
