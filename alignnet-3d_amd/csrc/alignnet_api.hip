@@ -523,9 +523,9 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
   for (int i = 0; i < st.n - 1; ++i) wmax[i & 1] = std::max(wmax[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
   a.ld[0] = wmax[0] + 4; a.ld[1] = wmax[1] + 4;
   // es [64][8] (+ [64][8] spare) | buf0 | buf1 | buf0' | lift table [C1 <= 64][8] (the shipped-shape instantiation)
-  // (the shipped-shape instantiation aliases buf1 onto the lift buffers and adds the 32 KiB W2 image: 69.8 KiB, two workgroups per CU)
+  // (the shipped-shape instantiation: 52.5 KiB, three workgroups per CU -- layout in kernels_dgcnn.h)
   const bool dg_std = a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST");
-  const size_t lds = dg_std ? ((size_t)kDgTile * 9 + (size_t)kDgTile * 2 * 68 + 4 * 8 * 64 * 4) * sizeof(float)   // es (row stride 9) | two lift buffers | W2 image
+  const size_t lds = dg_std ? ((size_t)kDgTile * 9 + (size_t)kDgTile * 68 + 4 * 8 * 64 * 4) * sizeof(float)   // es (row stride 9) | W2 image | one lift buffer
                             : ((size_t)kDgTile * 16 + (size_t)kDgTile * (2 * a.ld[0] + a.ld[1])) * sizeof(float);
   if (lds > 160 * 1024) return fail(h, "dgcnn hidden widths need more than 160 KiB of LDS per 64-point tile");
   if (h->layers[st.first + st.n - 2].cout > 256) return fail(h, "dgcnn: last edge-conv width limited to 256 channels");

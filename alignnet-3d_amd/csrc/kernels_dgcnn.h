@@ -241,7 +241,7 @@ struct DgcnnArgs {
 #define DG_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 #ifndef DGLB
-#define DGLB 4
+#define DGLB 6
 #endif
 #ifndef DG_LIFTPRIO
 #define DG_LIFTPRIO 1   // measured (tools/ab_dgcnn_variants.sh): 0.777 -> 0.789 of the fp32-MFMA roofline at N = 4096; 3 gives the same
@@ -347,15 +347,18 @@ template <int LD0 = 0, int LD1 = 0>
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* es = smem;                                   // edge features of the slot being lifted
-  // generic: es | buf0 | buf1 | buf0'.  Shipped shape (LD0): es | buf0 | buf0' | W2 image [4][8][64][4], and
-  // buf1 (the pooled edge features, written after the neighbour loop when both lift buffers are dead) aliases buf0 / buf0'.
+  // generic: es | buf0 | buf1 | buf0'.
   // (shipped shape: edge-feature rows 9 floats apart -- the MFMA lift reads them 4 bytes per lane, 16 rows per k, and at 8 floats
   //  rows r and r + 8 share a bank: that was the kernel's 26 M LDS conflict cycles per launch)
   constexpr int kEsLd = LD0 ? 9 : 8, kEs = kDgTile * kEsLd;
-  const int boff[2] = {kEs, LD0 ? kEs : kEs + kDgTile * ld0};
-  const int boff0b = LD0 ? kEs + kDgTile * ld0 : kEs + kDgTile * (ld0 + ld1);   // second lift buffer
-  constexpr int kW2Off = kEs + kDgTile * 2 * (LD0 ? LD0 : 1);      // shipped shape only
-  static_assert(!LD0 || kDgTile * LD1 <= 2 * kDgTile * LD0, "the pooled edge features must fit the two lift buffers they alias");
+  // Shipped shape: es | W2 image [4][8][64][4] | buf0 -- ONE lift buffer (the lift of slot s + 1 runs behind the barrier that ends slot
+  // s's MFMAs, so it can overwrite what they read), and the pooled edge features (buf1, written after the neighbour loop) alias the
+  // W2 image and the head of buf0, both dead by then: 52.5 KiB, THREE workgroups per CU (6 waves per SIMD at <= 80 VGPRs).
+  constexpr int kW2Off = kEs;                                       // shipped shape only
+  constexpr int kW2 = 4 * 8 * 64 * 4;
+  const int boff[2] = {LD0 ? kEs + kW2 : kEs, LD0 ? kEs : kEs + kDgTile * ld0};
+  const int boff0b = LD0 ? kEs + kW2 : kEs + kDgTile * (ld0 + ld1);   // second lift buffer (generic shape only)
+  static_assert(!LD0 || kDgTile * LD1 <= kW2 + kDgTile * LD0, "the pooled edge features must fit the regions they alias");
   const int nl = LD0 ? 3 : a.nlayers;                           // edge convs: layers 0 .. nl-2 ; point conv: layer nl-1
   const int nvalid = min(kDgTile, a.N - tile * kDgTile);
   const bool two_edge_layers = nl == 3;               // pipelined path: lift (VALU) + one MFMA edge layer
