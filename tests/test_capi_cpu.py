@@ -93,6 +93,9 @@ def test_inference_kernels_are_spill_free():
     for key, lst in seen.items():
         for name, vgpr, scratch, occ, spill in lst:
             assert spill == 0 and scratch == 0, (name, vgpr, scratch, spill)
-    # the shipped-shape DGCNN kernel runs two workgroups of eight waves per CU: <= 128 registers per lane
+    # the shipped-shape DGCNN kernel runs three workgroups of eight waves per CU (52.5 KiB of LDS each): <= 80 registers per lane
     shipped = [r for r in seen["dgcnn_fused"] if "Li68ELi132E" in r[0]]
-    assert shipped and shipped[0][1] <= 128 and shipped[0][3] >= 4, shipped
+    assert shipped and shipped[0][1] <= 80 and shipped[0][3] >= 6, shipped
+    # the kNN kernel for N <= 4096 keeps its 64 candidate distances per lane in registers at four waves per SIMD
+    knn64 = [r for r in seen["knn_kernel"] if "ILi64E" in r[0]]
+    assert knn64 and knn64[0][1] <= 128 and knn64[0][3] >= 4, knn64
