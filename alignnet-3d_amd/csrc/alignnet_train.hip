@@ -480,7 +480,7 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
     }
     f.bn_decay = bn_decay; f.update_ema = update_ema;
     f.mean = Gs.mean[l]; f.rstd = Gs.rstd[l]; f.scale = Gs.scale[l]; f.shift = Gs.shift[l];
-    hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(1024), 0, h->stream, f);
   }
   const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
   GenPoolArgs pa{Gs.Z[Ll], Gs.scale[Ll], Gs.shift[Ll], B, N, Cl, S.pooled, S.tower_stride, S.row_stride, Gs.idx};
@@ -508,7 +508,7 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
     GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, M, C, tiles};
     hipLaunchKernelGGL(gen_bn_bwd_reduce, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);
     GenBnFinArgs f{w->gen_part, tiles, M, C, {G(h, w, L.p_bn[0][0]), G(h, w, L.p_bn[1][0])}, {G(h, w, L.p_bn[0][1]), G(h, w, L.p_bn[1][1])}, w->gen_cA, w->gen_cB};
-    hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(1024), 0, h->stream, f);
     hipLaunchKernelGGL(gen_bn_bwd_apply, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);   // dY is dZ_l from here on
     if (l == 0) {
       GenL1BwdArgs a{Gs.X0, dY, P(h, L.p_w), B, N, C, w->gen_ppart, S.gx, S.grot};
@@ -516,9 +516,10 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
       hipLaunchKernelGGL(gen_sum_partials, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, h->stream, w->gen_ppart, 2 * B, (size_t)3 * C, G(h, w, L.p_w));
       break;
     }
-    GenDwArgs dw{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], dY, w->gen_dwpart, M, K, C, slabs};
-    hipLaunchKernelGGL(gen_gemm_dw, dim3(slabs, 2, (C + 63) / 64), dim3(kGenWaves * 64), ((size_t)kGenTile * K + kGenTile * 64) * sizeof(float), h->stream, dw);
-    hipLaunchKernelGGL(gen_sum_partials, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, h->stream, w->gen_dwpart, 2 * slabs, (size_t)K * C, G(h, w, L.p_w));
+    const int slab_rows = gen_slab_rows(C), lslabs = (M + slab_rows - 1) / slab_rows;   // <= slabs (the buffer's extent, 1024-row slabs)
+    GenDwArgs dw{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], dY, w->gen_dwpart, M, K, C, lslabs, slab_rows};
+    hipLaunchKernelGGL(gen_gemm_dw, dim3(lslabs, 2, (C + 63) / 64), dim3(kGenWaves * 64), ((size_t)kGenTile * K + kGenTile * 64) * sizeof(float), h->stream, dw);
+    hipLaunchKernelGGL(gen_sum_partials, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, h->stream, w->gen_dwpart, 2 * lslabs, (size_t)K * C, G(h, w, L.p_w));
     hipLaunchKernelGGL(gen_pack_transposed, dim3(64), dim3(256), 0, h->stream, P(h, L.p_w), K, C, w->gen_wt);
     GenDxArgs dx{dY, w->gen_wt, dYprev, M, K, C};
     hipLaunchKernelGGL(gen_gemm_dx, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * 132 * sizeof(float), h->stream, dx);

@@ -25,7 +25,10 @@ namespace alignnet {
 constexpr int kGenTile = 64;        // rows per workgroup tile (two 32-row MFMA tiles)
 constexpr int kGenWaves = 4;
 constexpr int kGenMaxK = 256;       // widest INPUT of an MFMA layer (LDS-resident A tile [64][K + 4])
-constexpr int kGenSlab = 1024;      // rows per dW partial
+constexpr int kGenSlab = 1024;      // rows per dW partial, times 1 .. 4 with the layer's width (gen_slab_rows)
+// wide layers have workgroups to spare along C (grid z): longer slabs there mean fewer partials to write and to sum (0.14 ms per layer
+// in gen_sum_partials at 1024 rows); narrow layers keep 1024 rows so that the launch still fills the chip
+inline int gen_slab_rows(int C) { const int f = C / 128; return kGenSlab * (f < 1 ? 1 : f > 4 ? 4 : f); }
 
 // ---- x' = (x - c) R for every point, [R][4] (w = 0) ------------------------------------------------------------------------------
 __global__ void gen_xform_kernel(const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ xform, int B, int N,
@@ -156,31 +159,63 @@ struct GenStatArgs {
   float* mean; float* rstd; float* scale; float* shift;   // [2][C]: y = z * scale + shift
 };
 
-__global__ __launch_bounds__(256) void gen_stat_finish(const GenStatArgs a)
+// (All tiles but a tower's last hold kGenTile rows, so the pairwise Chan merge -- a chain of fp64 divisions per partial, 4096 partials
+//  per column at B = 256, N = 1024: 0.4 ms per launch -- is replaced by its closed form over all partials: mean = sum n_b mean_b / M,
+//  M2 = sum [M2_b + n_b (mean_b - mean)^2]; two passes of independent loads, 16 tile groups per column.)
+__global__ __launch_bounds__(1024) void gen_stat_finish(const GenStatArgs a)
 {
-  __shared__ double red[4][64][3];
+  __shared__ double red[16][64];
+  __shared__ double bmean[64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, t = blockIdx.y;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (c < a.C)
-    for (int i = g; i < a.tiles; i += 4) {
-      const float* p = a.part + (((size_t)t * a.tiles + i) * a.C + c) * 2;
-      const double nb = (double)min(kGenTile, a.M - i * kGenTile), mb = p[0], m2b = p[1];
-      const double d = mb - mean, nt = n + nb;
-      mean += d * nb / nt;
-      m2 += m2b + d * d * n * nb / nt;
-      n = nt;
-    }
-  red[g][lane][0] = n; red[g][lane][1] = mean; red[g][lane][2] = m2;
-  __syncthreads();
-  if (g != 0 || c >= a.C) return;
-  for (int q = 1; q < 4; ++q) {
-    const double nb = red[q][lane][0], mb = red[q][lane][1], m2b = red[q][lane][2];
-    if (nb == 0.0) continue;
-    const double d = mb - mean, nt = n + nb;
-    mean += d * nb / nt;
-    m2 += m2b + d * d * n * nb / nt;
-    n = nt;
+  const bool live = c < a.C;
+  const float* base = a.part + ((size_t)t * a.tiles * a.C + (live ? c : 0)) * 2;
+  auto rows_of = [&](int i) { return (double)min(kGenTile, a.M - i * kGenTile); };
+  double s = 0.0;
+  if (live) {
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    int i = g;
+    for (; i + 48 < a.tiles; i += 64)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += rows_of(i + 16 * u) * (double)base[(size_t)(i + 16 * u) * a.C * 2];
+    for (; i < a.tiles; i += 16) s4[0] += rows_of(i) * (double)base[(size_t)i * a.C * 2];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   }
+  red[g][lane] = s;
+  __syncthreads();
+  if (g == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][lane];
+    bmean[lane] = tot / (double)a.M;
+  }
+  __syncthreads();
+  const double mean = bmean[lane];
+  s = 0.0;
+  if (live) {
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    int i = g;
+    for (; i + 48 < a.tiles; i += 64)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = base + (size_t)(i + 16 * u) * a.C * 2;
+        const double d = (double)p[0] - mean;
+        s4[u] += (double)p[1] + rows_of(i + 16 * u) * d * d;
+      }
+    for (; i < a.tiles; i += 16) {
+      const float* p = base + (size_t)i * a.C * 2;
+      const double d = (double)p[0] - mean;
+      s4[0] += (double)p[1] + rows_of(i) * d * d;
+    }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  __syncthreads();
+  red[g][lane] = s;
+  __syncthreads();
+  if (g != 0 || !live) return;
+  double m2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) m2 += red[q][lane];
+  const double n = (double)a.M;
   const float mf = (float)mean, vf = (float)(m2 / n);   // biased variance: mean of the squared difference from the mean (tf.nn.moments)
   const float rs = 1.0f / sqrtf(vf + kBnEps), k = a.gamma[t][c] * rs;
   a.mean[t * a.C + c] = mf;
@@ -266,21 +301,27 @@ __global__ __launch_bounds__(256) void gen_bn_bwd_reduce(const GenBnBwdArgs a)
 // sums of the tile partials in fp64 -> dbeta, dgamma (written into the gradient vector) and the pass-2 coefficients
 struct GenBnFinArgs { const float* part; int tiles, M, C; float* dbeta[2]; float* dgamma[2]; float* cA; float* cB; };
 
-__global__ __launch_bounds__(256) void gen_bn_bwd_finish(const GenBnFinArgs a)
+__global__ __launch_bounds__(1024) void gen_bn_bwd_finish(const GenBnFinArgs a)   // grid (ceil(C / 64), 2), block 16 tile groups x 64 columns
 {
-  __shared__ double red[4][64][2];
+  __shared__ double red[16][64][2];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, t = blockIdx.y;
   double s0 = 0.0, s1 = 0.0;
-  if (c < a.C)
-    for (int i = g; i < a.tiles; i += 4) {
-      const float* p = a.part + (((size_t)t * a.tiles + i) * a.C + c) * 2;
-      s0 += p[0]; s1 += p[1];
-    }
+  if (c < a.C) {
+    const float* base = a.part + ((size_t)t * a.tiles * a.C + c) * 2;
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    int i = g;
+    for (; i + 48 < a.tiles; i += 64)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float* p = base + (size_t)(i + 16 * u) * a.C * 2; a0[u] += p[0]; a1[u] += p[1]; }
+    for (; i < a.tiles; i += 16) { const float* p = base + (size_t)i * a.C * 2; a0[0] += p[0]; a1[0] += p[1]; }
+    s0 = (a0[0] + a0[1]) + (a0[2] + a0[3]); s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  }
   red[g][lane][0] = s0; red[g][lane][1] = s1;
   __syncthreads();
   if (g != 0 || c >= a.C) return;
-  s0 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
-  s1 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { s0 += red[q][lane][0]; s1 += red[q][lane][1]; }
   a.dbeta[t][c] = (float)s0;
   a.dgamma[t][c] = (float)s1;
   a.cA[t * a.C + c] = (float)(s0 / (double)a.M);
@@ -374,7 +415,7 @@ struct GenDwArgs {
   const float* Zprev; const float* scale; const float* shift;   // [R][K], [2][K]
   const float* dZ;                                              // [R][C]
   float* part;                                                  // [2 * slabs][K][C]
-  int M, K, C, slabs;
+  int M, K, C, slabs, slab_rows;
 };
 
 __global__ __launch_bounds__(kGenWaves * 64) void gen_gemm_dw(const GenDwArgs a)
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void gen_gemm_dw(const GenDwArgs a)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int rbeg = slab * kGenSlab, rend = min(a.M, rbeg + kGenSlab);
+  const int rbeg = slab * a.slab_rows, rend = min(a.M, rbeg + a.slab_rows);
   for (int t0 = rbeg; t0 < rend; t0 += kGenTile) {
     const int nvalid = min(kGenTile, rend - t0);
     const size_t row0 = (size_t)tower * a.M + t0;
