@@ -238,14 +238,19 @@ def main():
     lab_ptrs = {k: v.data_ptr() for k, v in lab.items()}
     want_train = args.mode == "train" or not args.no_train_leg
     rccl_ranks = 0
-    if world > 1 and want_train:
-        # data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed
+
+    def init_rccl():
+        """Data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed."""
+        nonlocal rccl_ranks
         from alignnet3d import parallel
         parallel.init_comm(eng, dist)
         eng.set_option("allreduce_overlap", args.allreduce_overlap)
         rccl_ranks = eng.get_option("comm_world")
         if rccl_ranks != world:
-            raise SystemExit(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
+            raise RuntimeError(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
+
+    if world > 1 and args.mode == "train":
+        init_rccl()   # the headline leg itself needs it: a failure here is fatal
 
     def train_step():
         eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
@@ -351,6 +356,9 @@ def main():
     # ------------------------------- secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA)
     train_info = None
     if args.mode == "infer" and want_train:
+      try:   # (a secondary leg must not cost the headline line: the communicator is created here, after the inference legs)
+        if world > 1:
+            init_rccl()
         train_info = {}
         for tdtype in ("f32", "bf16"):
             eng.set_option("train_matmul_bf16", int(tdtype == "bf16"))
@@ -372,6 +380,8 @@ def main():
             else:
                 train_info["bf16"] = leg
         eng.set_option("train_matmul_bf16", 0)
+      except Exception as e:   # noqa: BLE001 -- reported in the line, the other legs stand
+        train_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # -------------- secondary leg: PCIe-inclusive inference, the reference's own timing methodology (train.py:447-449), rank 0's GPU only
     pcie_info = None
