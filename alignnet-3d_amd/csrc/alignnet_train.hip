@@ -153,7 +153,9 @@ static int check_trainable_shape(alignnet_handle* h)
           return fail(h, "training (general-depth path): hidden conv widths are limited to " + std::to_string(kGenMaxK) + " channels, the last to 4096 (layer " + L.name + ")");
       }
     }
-  if (dg && h->train_bf16) return fail(h, "training: the dgcnn backbone trains in fp32 only (unset train_matmul_bf16)");
+  if (dg && h->train_bf16)   // (the bf16 edge conv: dg_train_fwd<C1, true>; the point conv and the backward stay fp32)
+    for (int s = 0; s < 3; ++s)
+      if (h->layers[conv_of(h, s).first].cout % 16) return fail(h, "training: train_matmul_bf16 with the dgcnn backbone needs a first edge width that is a multiple of 16");
   if (dg && (h->cfg.num_points > 64 * kKnnMaxPerLane || h->cfg.num_points < kDgK))
     return fail(h, "training: dgcnn needs 20 <= num_points <= 4096");
   for (int s = 0; s < 3; ++s) {
@@ -584,14 +586,18 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     d.pcs[0] = p1; d.pcs[1] = p2; d.xform = S.xform; d.nn = w->nn; d.B = B; d.N = N; d.k = kDgK; d.C1 = C1; d.C2 = C2; d.ld0 = a.ld[0];
     d.w1 = a.w1; d.b1 = a.b1; d.wp2 = a.wp2; d.b2 = a.b2; d.sc1 = a.sc1; d.sh1 = a.sh1; d.sc2 = a.sc2; d.sh2 = a.sh2;
     d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part; d.g1_part = w->g1_part;
-    const size_t dlds = ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
+    d.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
+    const size_t dlds = h->train_bf16 ? (size_t)kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * sizeof(unsigned short)
+                                      : ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
     finish(0, C1, 1, ecount);
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
   { ProfScope prof_scope(h, PK_DG_FWD);
-    if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    if (h->train_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_fwd<64, true>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    else if (h->train_bf16) hipLaunchKernelGGL((dg_train_fwd<32, true>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+    else if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
     else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
   }
     if (d.stamps) {
@@ -606,8 +612,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
       launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
-      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount, 0,
-                         w->stat_part);
+      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount,
+                         h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
     finish(1, C2, 1, ecount, 1);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
@@ -682,7 +688,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   {   // centred Gram of h2 + pooled features: independent of each other, one launch
     const size_t tot = (size_t)2 * B * C3;
     const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
-                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, h->train_bf16 ? 1 : 0};
+                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && !dg) ? 1 : 0};
     hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
                        S.gram2, S.s2, C2, count, S.m2, pa);
   }
@@ -837,7 +843,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, h->train_bf16 ? 1 : 0);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, (h->train_bf16 && !dg) ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   // dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)  and  W3E[t] = W3 diag(E[t]), W3T = W3^T  (one launch: nothing in it depends on the other part)

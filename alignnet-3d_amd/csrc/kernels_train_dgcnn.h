@@ -35,6 +35,7 @@ struct DgTrainArgs {
   int ld0;                        // LDS leading dim of the h1 tile
   const float* w1; const float* b1;   // [6][C1], [C1]
   const float* wp2; const float* b2;  // MFMA image of W2 [C1][C2], [C2]
+  const unsigned short* wp2h;         // bf16 MFMA image of W2 (dg_train_fwd<C1, true>), no sign folded
   const float *sc1, *sh1, *sc2, *sh2; // [2][C] batch-stat scale / shift (acc -> y)
   const float* gamma2[2];         // BatchNorm gamma of the second edge layer per tower (its sign picks max or min over the slots)
   double* mom;                    // [2B][27]                       (phase 1)
@@ -120,68 +121,12 @@ __global__ __launch_bounds__(256) void dg_train_phase1(const DgTrainArgs a)
 }
 
 // ---------------------------------------------------------------------------------
-// K = 6 lift on the VALU (256 threads): out[row][c] = relu((e . w[:,c]) * sc + sh), rows >= nvalid are written as 0.
-// Channel groups c0, c0 + 32 keep their weights in registers for the whole cloud; wider first layers reload per call.
+// K = 6 lift: out[row][c] = relu((e . w[:,c]) * sc + sh), rows >= nvalid are written as 0.
 // ---------------------------------------------------------------------------------
-struct DgtLiftW { float w[2][6]; float sc[2], sh[2]; };
-
-__device__ __forceinline__ DgtLiftW dgt_lift_load(const float* __restrict__ w1, int C1, const float* __restrict__ sc,
-                                                  const float* __restrict__ sh, int tid)
-{
-  DgtLiftW R;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int c = (tid & 31) + 32 * g;
-    const bool live = c < C1;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) R.w[g][d] = live ? w1[d * C1 + c] : 0.f;
-    R.sc[g] = live ? sc[c] : 0.f;
-    R.sh[g] = live ? sh[c] : 0.f;
-  }
-  return R;
-}
-
-template <int NT = kTW * 64>
-__device__ __forceinline__ void dgt_lift(const DgtLiftW& R, const float* __restrict__ w1, int C1, const float* __restrict__ sc,
-                                         const float* __restrict__ sh, const float* __restrict__ es, float* __restrict__ out, int ldo,
-                                         int nvalid, int tid)
-{
-  constexpr int kRG = NT / 32;                // row groups
-  const int c0 = tid & 31, r0 = tid >> 5;
-  const int cw = (C1 + 7) & ~7;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int c = c0 + 32 * g;
-    if (c < cw) {
-      float w[6], s, t;
-      if (g < 2) {
-#pragma unroll
-        for (int d = 0; d < 6; ++d) w[d] = R.w[g & 1][d];
-        s = R.sc[g & 1]; t = R.sh[g & 1];
-      } else {
-        const bool live = c < C1;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) w[d] = live ? w1[d * C1 + c] : 0.f;
-        s = live ? sc[c] : 0.f; t = live ? sh[c] : 0.f;
-      }
-#pragma unroll
-      for (int rr = 0; rr < kTT / kRG; ++rr) {
-        const int row = rr * kRG + r0;
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(es + row * 8);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(es + row * 8 + 4);
-        float acc = e0[0] * w[0];
-        acc = fmaf(e0[1], w[1], acc); acc = fmaf(e0[2], w[2], acc); acc = fmaf(e0[3], w[3], acc);
-        acc = fmaf(e1[0], w[4], acc); acc = fmaf(e1[1], w[5], acc);
-        out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
-      }
-    }
-  }
-}
-
-// The same lift on the matrix pipe (C1 a multiple of 16): k padded to 8 -- zero weights, and es columns 6 / 7 zeroed once by the
+// On the matrix pipe (C1 a multiple of 16): k padded to 8 -- zero weights, and es columns 6 / 7 zeroed once by the
 // caller -- and the [64 rows][C1] output cut into 16 x 16 tiles (v_mfma_f32_16x16x4_f32, two instructions per tile), the tiles
 // dealt round-robin to the NW waves; a wave's B fragments and its tiles' scale / shift stay in registers.  Per lane and tile: two
-// 4-byte LDS reads, two MFMAs, four fma + max + select, four LDS writes -- the VALU form costs 16 rows x (two 16-byte reads +
+// 4-byte LDS reads, two MFMAs, four fma + max + select, four LDS writes -- the VALU form (round 1) cost 16 rows x (two 16-byte reads +
 // 8 operations) per lane and ran 3.5x slower whenever the co-resident workgroup streamed MFMAs.
 template <int C1, int NW>
 struct DgtLiftM {
@@ -226,6 +171,33 @@ __device__ __forceinline__ void dgt_liftm(const DgtLiftM<C1, NW>& R, const float
   }
 }
 
+// bf16 mode: the same lift written straight as the two bf16 tiles the bf16 MFMAs read -- row-major Xh[row][ldh] (A operand of
+// z2 = h1 W2) and transposed XhT[c][ldT] (both operands of Gram(h1) = h1^T h1); a lane's four rows of a column are one 8-byte store
+// into the transposed tile.
+template <int C1, int NW>
+__device__ __forceinline__ void dgt_liftm_bf16(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, unsigned short* __restrict__ Xh, int ldh,
+                                               unsigned short* __restrict__ XhT, int ldT, int nvalid, int wave, int lane)
+{
+#pragma unroll
+  for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
+    const int t = wave * DgtLiftM<C1, NW>::kPer + i, rt = t / DgtLiftM<C1, NW>::kCT, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
+    const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], R.w[i][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], R.w[i][1], acc, 0, 0, 0);
+    const int row0 = 16 * rt + 4 * (lane >> 4);
+    unsigned short hb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hb[r] = row0 + r < nvalid ? to_bf16_bits(fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f)) : (unsigned short)0;
+      Xh[(row0 + r) * ldh + c] = hb[r];
+    }
+    uint2 pk;
+    pk.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16); pk.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+    *reinterpret_cast<uint2*>(XhT + c * ldT + row0) = pk;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // phase 2: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
 // edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
@@ -233,7 +205,11 @@ __device__ __forceinline__ void dgt_liftm(const DgtLiftM<C1, NW>& R, const float
 // ---------------------------------------------------------------------------------
 // C1 is a template parameter: with a compile-time LDS row stride the per-row tile addresses are immediate offsets; as
 // run-time values the compiler hoists them out of the slot loop into ~50 registers and spills.
-template <int C1>
+// BF16 ("train_matmul_bf16" with the dgcnn backbone): the edge conv behind the lift, z2 = h1 W2, and Gram(h1) run on
+// v_mfma_f32_32x32x16_bf16 with h1 and W2 rounded to bf16 (fp32 accumulate); the lift writes bf16 tiles, the column sums are those of
+// the rounded h1, and the statistics of z2 follow from the Gram of the rounded h1 with the rounded W2 (stat2_from_gram_kernel).
+// LDS: es [64][8] fp32 | per buffer Xh [64][C1 + 8] | XhT [C1][64 + 8] bf16.  Everything behind the accumulators is unchanged.
+template <int C1, bool BF16 = false>
 __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -247,6 +223,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   float* es = smem;
   constexpr int ld0 = C1 + 4;
   constexpr int KG2 = (C1 + 7) >> 3;   // <= 8 (C1 <= 64)
+  constexpr int ldh = C1 + 8, ldT = kTT + 8, KG16 = C1 / 16;   // bf16 tiles
+  constexpr int kBufH = kTT * ldh + C1 * ldT;                    // bf16 elements per lift buffer (Xh | XhT)
+  unsigned short* hbuf = reinterpret_cast<unsigned short*>(smem + kTT * 8);
   const int CT2 = (a.C2 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const int ct = wave, col = ct * 32 + (lane & 31);
@@ -260,12 +239,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   // the wave's W2 fragments stay in registers for the whole cloud (C1 <= 64: 8 k-groups), with the column's sign(gamma2)
   // folded in (exact): the accumulator is sgn * (z2 - bias), so the extreme over the slots is a plain max and the sums are
   // those of sgn * (z2 - bias), put right at the end
-  f32x4 breg[KG2];
+  f32x4 breg[BF16 ? 1 : KG2];
+  bf16x8 bregh[BF16 ? KG16 : 1];
   if (mine) {
+    if constexpr (BF16) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const unsigned flip = sgn < 0.f ? 0x80008000u : 0u;   // a lane's eight k values belong to one column: its sign, folded bit-wise
 #pragma unroll
-    for (int kg = 0; kg < KG2; ++kg) {
-      breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + kg) * 64 + lane];
-      breg[kg][0] *= sgn; breg[kg][1] *= sgn; breg[kg][2] *= sgn; breg[kg][3] *= sgn;
+      for (int kg = 0; kg < KG16; ++kg) {
+        u32x4 v = reinterpret_cast<const u32x4*>(a.wp2h)[((size_t)ct * KG16 + kg) * 64 + lane];
+        v[0] ^= flip; v[1] ^= flip; v[2] ^= flip; v[3] ^= flip;
+        bregh[kg] = __builtin_bit_cast(bf16x8, v);
+      }
+    } else {
+#pragma unroll
+      for (int kg = 0; kg < KG2; ++kg) {
+        breg[kg] = reinterpret_cast<const f32x4*>(a.wp2)[((size_t)ct * KG2 + kg) * 64 + lane];
+        breg[kg][0] *= sgn; breg[kg][1] *= sgn; breg[kg][2] *= sgn; breg[kg][3] *= sgn;
+      }
     }
   }
   double s1q[4] = {0.0, 0.0, 0.0, 0.0};
@@ -289,7 +280,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift: never written again
   }
   __syncthreads();
-  dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8, ld0, min(kTT, a.N), wave, lane);
+  if constexpr (BF16) dgt_liftm_bf16<C1, kTW>(lw, es, hbuf, ldh, hbuf + kTT * ldh, ldT, min(kTT, a.N), wave, lane);
+  else dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8, ld0, min(kTT, a.N), wave, lane);
   __syncthreads();
   for (int it = 0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
@@ -299,6 +291,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     FE_STAMP(0);
     if (more && tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);   // in flight during the MFMAs
     const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
+    const unsigned short* Xh = hbuf + (it & 1) * kBufH;
+    const unsigned short* XhT = Xh + kTT * ldh;
     if (slot == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -311,6 +305,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      if constexpr (BF16) {
+        const unsigned short* arow = Xh + (lane & 31) * ldh + half * 8;
+#pragma unroll
+        for (int kg = 0; kg < KG16; ++kg) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + kg * 16), bregh[kg], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + 32 * ldh + kg * 16), bregh[kg], acc[1], 0, 0, 0);
+        }
+      } else {
       const float* arow = X + (lane & 31) * ld0 + half * 4;
 #pragma unroll
       for (int kg = 0; kg < KG2; ++kg) {
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[kg][s], acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[kg][s], acc[1], 0, 0, 0);
         }
+      }
       }
       FE_STAMP(1);
 #pragma unroll
@@ -349,10 +352,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     // z2 = h1 W2 + b2 (linear in h1: stat2_from_gram_kernel) and the layer-2 weight gradient of the backward -- the 32 sums
     // per lane and slot this replaces were a third of the kernel's VALU work, and the kernel is bound by that, not by the matrix pipe
     if (wave < nG) {
+      if constexpr (BF16) {
+        const unsigned short* pa = XhT + (git * 32 + (lane & 31)) * ldT + half * 8;
+        const unsigned short* pb = XhT + (gjt * 32 + (lane & 31)) * ldT + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < kTT / 16; ++kk)
+          gacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kk * 16), *reinterpret_cast<const bf16x8*>(pb + kk * 16), gacc, 0, 0, 0);
+      } else {
       const float* pa = X + half * ld0 + git * 32 + (lane & 31);
       const float* pb = X + half * ld0 + gjt * 32 + (lane & 31);
 #pragma unroll 8
       for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
+      }
     }
     FE_STAMP(2);
     {   // column sums of h1 (rows past nvalid are zero): thread = (4 columns, one of kQG row groups), float4 reads
@@ -361,8 +372,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       f32x4 sm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < kTT / kQG; ++r) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(X + (g + r * kQG) * ld0 + cq * 4);
-        sm[0] += hv[0]; sm[1] += hv[1]; sm[2] += hv[2]; sm[3] += hv[3];
+        if constexpr (BF16) {
+          const uint2 hv = *reinterpret_cast<const uint2*>(Xh + (g + r * kQG) * ldh + cq * 4);
+          sm[0] += __uint_as_float(hv.x << 16); sm[1] += __uint_as_float(hv.x & 0xffff0000u);
+          sm[2] += __uint_as_float(hv.y << 16); sm[3] += __uint_as_float(hv.y & 0xffff0000u);
+        } else {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(X + (g + r * kQG) * ld0 + cq * 4);
+          sm[0] += hv[0]; sm[1] += hv[1]; sm[2] += hv[2]; sm[3] += hv[3];
+        }
       }
       s1q[0] += (double)sm[0]; s1q[1] += (double)sm[1]; s1q[2] += (double)sm[2]; s1q[3] += (double)sm[3];
     }
@@ -371,7 +388,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     FE_STAMP(4);
     __syncthreads();
     FE_STAMP(5);
-    if (more) dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), wave, lane);
+    if (more) {
+      if constexpr (BF16) {
+        unsigned short* nh = hbuf + ((it + 1) & 1) * kBufH;
+        dgt_liftm_bf16<C1, kTW>(lw, es, nh, ldh, nh + kTT * ldh, ldT, min(kTT, a.N - ntile * kTT), wave, lane);
+      } else dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), wave, lane);
+    }
     FE_STAMP(6);
     __syncthreads();
     FE_STAMP(7);

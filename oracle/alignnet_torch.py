@@ -44,8 +44,9 @@ class TorchTp8:
         self.checkpoint = checkpoint
         self.ema_updates: Dict[str, torch.Tensor] = {}
         # Model of the engine's "train_matmul_bf16" option (not a reference feature): the operands of the MFMA convs of
-        # every PointNet backbone (all but the K = 3 lift) are rounded to bf16 (round-to-nearest-even), products are
-        # accumulated exactly, and the backward treats the rounding as identity (straight-through).
+        # every PointNet backbone (all but the K = 3 lift) -- with the dgcnn backbone: of the edge convs behind the K = 6 lift --
+        # are rounded to bf16 (round-to-nearest-even), products are accumulated exactly, and the backward treats the rounding
+        # as identity (straight-through).
         self.bf16_lift = bf16_lift
 
     @staticmethod
@@ -99,7 +100,10 @@ class TorchTp8:
         h = torch.cat([cen, nbr - cen], -1).reshape(B * N * k, 2 * D)
         for i in range(len(widths) - 1):
             nm = f"{scope}/conv{i+1}"
-            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+            # bf16 option with the dgcnn backbone: the edge convs behind the K = 6 lift take rounded operands (the point conv
+            # below and the whole backward stay fp32 in the engine: DESIGN.md 4.5b)
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
+                            round_operands=self.bf16_lift and training and i >= 1)
         h = h.reshape(B * N, k, -1).amax(dim=1)
         nm = f"{scope}/conv{len(widths)}"
         h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)

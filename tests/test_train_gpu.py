@@ -309,6 +309,57 @@ def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol, std):
     eng.close()
 
 
+@pytest.mark.parametrize("N,B,std", [(128, 8, False), (96, 6, True)])
+def test_dgcnn_bf16_edge_conv_matches_rounded_oracle(gpu_required, N, B, std):
+    """"train_matmul_bf16" with the dgcnn backbone: the edge conv behind the K = 6 lift (z2 = h1 W2 over the B*N*k edge rows) and
+    Gram(h1) run on bf16 MFMA with h1 and W2 rounded to nearest even (dg_train_fwd<C1, true>); the statistics of z2 follow from the
+    Gram of the ROUNDED h1 with the rounded W2; the point conv and the whole backward stay fp32.  The oracle models the forward
+    exactly (TorchTp8(bf16_lift=True) rounds the operands of the edge convs i >= 1) with a straight-through backward that uses
+    the rounded operands, which the engine's fp32 backward does not (it recomputes h1 unrounded and uses the unrounded W2: one
+    bf16 ulp = 0.4 % per operand).  Tolerances (written here):
+      * batch statistics of the rounded edge conv (EMA shadows of conv2, averages over B*N*k rows): 1e-4 of the largest entry
+        and >= 10x closer to the rounded oracle than the fp32 step;
+      * predictions of samples whose yaw decode agrees: <= 5e-2, loss within 5e-3 (5e-2 with decode flips);
+      * whole gradient: cosine >= 0.97 with the rounded oracle's (0.85 with flips)."""
+    cfg, spec, P32, d, du = _setup_dgcnn(N, B, std=std)
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    stats = ["siamese/transformer1/embedding/conv2/bn/moving_mean", "siamese_1/transformer1/embedding/conv2/bn/moving_var"]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    res32 = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    ema32 = {k: eng.get_variable(k) for k in stats}
+    eng.set_variables(P32)
+    eng.set_option("train_matmul_bf16", 1)
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert res["loss"] != res32["loss"], "bf16 option had no effect"
+    assert eng.get_option("last_train_kernel") & 6 == 6   # bit 1: bf16 operands, bit 2: dgcnn
+    for k in stats:
+        got, ref = eng.get_variable(k), ema_ref[k]
+        e16, e32 = float(np.abs(got - ref).max()), float(np.abs(ema32[k] - ref).max())
+        print(k, "err vs rounded oracle %.2e (fp32 step: %.2e), scale %.2e" % (e16, e32, np.abs(ref).max()))
+        assert e16 <= 1e-4 * np.abs(ref).max() and e16 < 0.1 * e32, (k, e16, e32)
+    nb = spec.num_bins
+    flipped = np.zeros(B, bool)
+    for k in ("pred_pc1angle_logits", "pred_pc2angle_logits"):
+        flipped |= np.argmax(res[k][:, :nb], 1) != np.argmax(ep_ref[k][:, :nb], 1)
+    print("decode flips vs the rounded oracle:", int(flipped.sum()), "of", B)
+    assert flipped.sum() <= max(1, B // 8)
+    for k in ep_ref:
+        if k in ("pred_translations", "pred_remaining_angle_logits") and flipped.any():
+            continue   # the pair head normalises over the batch: a flipped sample moves every row of its output
+        per = np.abs(res[k] - ep_ref[k]).reshape(B, -1).max(1)[~flipped]
+        print(k, "median %.2e max %.2e" % (np.median(per), per.max()))
+        assert per.max() <= 5e-2, (k, per.max())
+    assert abs(res["loss"] - loss_ref) <= (5e-2 if flipped.any() else 5e-3) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    g = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
+    gr = np.concatenate([np.asarray(grads[n], np.float64).ravel() for n in R.trainable_names(spec)])
+    cos = float(g @ gr / (np.linalg.norm(g) * np.linalg.norm(gr)))
+    print("gradient cosine vs the rounded oracle: %.4f" % cos)
+    assert cos >= (0.85 if flipped.any() else 0.97), cos
+    eng.close()
+
+
 @pytest.mark.parametrize("backbone", ["pointnet", "dgcnn"])
 def test_negative_gammas(gpu_required, backbone):
     """BatchNorm gammas of mixed sign: the max-pools are taken as the extreme of sign(gamma)*z before the statistics
