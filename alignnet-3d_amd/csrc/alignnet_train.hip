@@ -282,7 +282,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     }
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
-    w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * 4 * maxC2);
+    w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
     w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(B2 * 4 * 7 * maxC1);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
@@ -438,6 +438,8 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -618,6 +620,18 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     finish(1, C2, 1, ecount, 1);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
     // point conv on the stored p
+    if (h->train_bf16) {
+      // bf16 operands (p rounded while it is staged, the sign-folded bf16 image of W3); Gram(p) and the column sums of the rounded p
+      // come out of the same pass (1024 / C2 row-group slices per cloud)
+      a.wp3h = w->wp3h[s];
+      const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
+                          ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
+      { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
+      if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+      else hipLaunchKernelGGL((train_fwd_phase23<3, true, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+      }
+      finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2));
+    } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -626,6 +640,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
     finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
+    }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
   hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
@@ -688,7 +703,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   {   // centred Gram of h2 + pooled features: independent of each other, one launch
     const size_t tot = (size_t)2 * B * C3;
     const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
-                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && !dg) ? 1 : 0};
+                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, h->train_bf16 ? 1 : 0};
     hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
                        S.gram2, S.s2, C2, count, S.m2, pa);
   }

@@ -373,12 +373,36 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     l2sc[q2] = live ? a.sc2[tower * kC2 + col] : 0.f;
     l2sh[q2] = live ? a.sh2[tower * kC2 + col] : 0.f;
   }
+  double gcs[4] = {0.0, 0.0, 0.0, 0.0};   // GIVEN && BF16: column sums of the rounded features, this thread's four columns
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     P3_STAMP(0);
-    if (GIVEN) {
+    if (GIVEN && BF16) {
+      // the given features (DGCNN: pooled edge features p, fp32 in HBM) rounded to bf16 on the way into the two tiles the bf16
+      // MFMAs read; the column sums are those of the ROUNDED values (centred Gram = exact covariance of one data matrix).
+      // 256 % (C2 / 4) == 0 (C2 = 64 / 128): a thread's four columns are the same in every trip.
+      const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      const int c4 = kC2 >> 2;
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = tid; i < kTT * c4; i += kTW * 64) {
+        const int row = i / c4, q = i % c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kC2 + q * 4);
+        unsigned short hb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hb[e] = to_bf16_bits(v[e]);
+          ls[e] += __uint_as_float((unsigned)hb[e] << 16);
+          bufT[(q * 4 + e) * ldT + row] = hb[e];
+        }
+        uint2 pk; pk.x = hb[0] | ((unsigned)hb[1] << 16); pk.y = hb[2] | ((unsigned)hb[3] << 16);
+        *reinterpret_cast<uint2*>(buf1h + row * ldh + q * 4) = pk;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gcs[e] += (double)ls[e];
+    } else if (GIVEN) {
       const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c4 = kC2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
@@ -669,6 +693,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         }
       }
     }
+  }
+  if (PHASE == 3 && BF16 && GIVEN) {   // colsum_part [cloud][256 / (C2 / 4) row groups][C2]
+    const int c4 = kC2 >> 2, q = tid % c4, g = tid / c4, slices = (kTW * 64) / c4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.colsum_part[((size_t)cloud * slices + g) * kC2 + q * 4 + e] = gcs[e];
   }
   if (PHASE == 3 && BF16) {
     // sum z = sg * S1 + n b,  sum z^2 = S2 + 2 b sg S1 + n b^2   (z = sg * acc + b; n = the lane's rows = N / 2)

@@ -100,13 +100,14 @@ class TorchTp8:
         h = torch.cat([cen, nbr - cen], -1).reshape(B * N * k, 2 * D)
         for i in range(len(widths) - 1):
             nm = f"{scope}/conv{i+1}"
-            # bf16 option with the dgcnn backbone: the edge convs behind the K = 6 lift take rounded operands (the point conv
-            # below and the whole backward stay fp32 in the engine: DESIGN.md 4.5b)
+            # bf16 option with the dgcnn backbone: the edge convs behind the K = 6 lift and the point conv below take rounded
+            # operands (the whole backward stays fp32 in the engine: DESIGN.md 4.5b)
             h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
                             round_operands=self.bf16_lift and training and i >= 1)
         h = h.reshape(B * N, k, -1).amax(dim=1)
         nm = f"{scope}/conv{len(widths)}"
-        h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+        h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
+                        round_operands=self.bf16_lift and training)
         return h.reshape(B, N, -1).amax(dim=1)
 
     def _backbone(self, *a):

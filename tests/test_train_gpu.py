@@ -310,24 +310,31 @@ def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol, std):
 
 
 @pytest.mark.parametrize("N,B,std", [(128, 8, False), (96, 6, True)])
-def test_dgcnn_bf16_edge_conv_matches_rounded_oracle(gpu_required, N, B, std):
-    """"train_matmul_bf16" with the dgcnn backbone: the edge conv behind the K = 6 lift (z2 = h1 W2 over the B*N*k edge rows) and
-    Gram(h1) run on bf16 MFMA with h1 and W2 rounded to nearest even (dg_train_fwd<C1, true>); the statistics of z2 follow from the
-    Gram of the ROUNDED h1 with the rounded W2; the point conv and the whole backward stay fp32.  The oracle models the forward
-    exactly (TorchTp8(bf16_lift=True) rounds the operands of the edge convs i >= 1) with a straight-through backward that uses
-    the rounded operands, which the engine's fp32 backward does not (it recomputes h1 unrounded and uses the unrounded W2: one
-    bf16 ulp = 0.4 % per operand).  Tolerances (written here):
-      * batch statistics of the rounded edge conv (EMA shadows of conv2, averages over B*N*k rows): 1e-4 of the largest entry
-        and >= 10x closer to the rounded oracle than the fp32 step;
-      * predictions of samples whose yaw decode agrees: <= 5e-2, loss within 5e-3 (5e-2 with decode flips);
-      * whole gradient: cosine >= 0.97 with the rounded oracle's (0.85 with flips)."""
+def test_dgcnn_bf16_convs_match_rounded_oracle(gpu_required, N, B, std):
+    """"train_matmul_bf16" with the dgcnn backbone: the edge conv behind the K = 6 lift (z2 = h1 W2 over the B*N*k edge rows, with
+    Gram(h1): dg_train_fwd<C1, true>) and the point conv (z3 = p W3, with Gram(p): train_fwd_phase23<3, true, true>) run on bf16
+    MFMA with their operands rounded to nearest even; the statistics of z2 follow from the Gram of the ROUNDED h1 with the rounded
+    W2; the whole backward stays fp32.  The oracle models the forward exactly (TorchTp8(bf16_lift=True) rounds the operands of the
+    edge convs i >= 1 and of the point conv) with a straight-through backward that uses the rounded operands, which the engine's
+    fp32 backward does not (it recomputes h1 unrounded and uses the unrounded weights: one bf16 ulp = 0.4 % per operand).
+    Tolerances (written here, those of the PointNet bf16 test):
+      * batch statistics of the rounded convs (EMA shadows of conv2 and conv3): 1e-4 of the largest entry and >= 10x closer to
+        the rounded oracle than the fp32 step;
+      * stage-1 centres: median per-sample error <= 1e-3, max <= 2e-2; later predictions of samples whose yaw decode agrees:
+        <= 1e-1; loss within 5e-3 (5e-2 with decode flips);
+      * whole gradient: cosine >= 0.93 with the rounded oracle's (0.85 with flips) and >= 3x closer (1 - cos) than the fp32 step's
+        gradient.  (Two max-pools -- over the k neighbours and over the points -- make this backbone's gradient far more sensitive
+        to which row wins a near-tie than PointNet's: at these batch sizes the UNROUNDED fp64 oracle's gradient has cosine
+        0.53 - 0.59 with the rounded oracle's; the engine's is at 0.958 - 0.962, every variable between 0.93 and 0.98.)"""
     cfg, spec, P32, d, du = _setup_dgcnn(N, B, std=std)
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
-    stats = ["siamese/transformer1/embedding/conv2/bn/moving_mean", "siamese_1/transformer1/embedding/conv2/bn/moving_var"]
+    stats = ["siamese/transformer1/embedding/conv2/bn/moving_mean", "siamese_1/transformer1/embedding/conv2/bn/moving_var",
+             "siamese/transformer1/embedding/conv3/bn/moving_mean", "siamese_1/transformer1/embedding/conv3/bn/moving_var"]
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
     res32 = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     ema32 = {k: eng.get_variable(k) for k in stats}
+    g32 = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
     eng.set_variables(P32)
     eng.set_option("train_matmul_bf16", 1)
     ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True)
@@ -350,13 +357,16 @@ def test_dgcnn_bf16_edge_conv_matches_rounded_oracle(gpu_required, N, B, std):
             continue   # the pair head normalises over the batch: a flipped sample moves every row of its output
         per = np.abs(res[k] - ep_ref[k]).reshape(B, -1).max(1)[~flipped]
         print(k, "median %.2e max %.2e" % (np.median(per), per.max()))
-        assert per.max() <= 5e-2, (k, per.max())
+        if "s1_" in k:
+            assert np.median(per) <= 1e-3 and per.max() <= 2e-2, (k, per.max())
+        assert per.max() <= 1e-1, (k, per.max())
     assert abs(res["loss"] - loss_ref) <= (5e-2 if flipped.any() else 5e-3) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
     g = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
     gr = np.concatenate([np.asarray(grads[n], np.float64).ravel() for n in R.trainable_names(spec)])
     cos = float(g @ gr / (np.linalg.norm(g) * np.linalg.norm(gr)))
-    print("gradient cosine vs the rounded oracle: %.4f" % cos)
-    assert cos >= (0.85 if flipped.any() else 0.97), cos
+    cos32 = float(g32 @ gr / (np.linalg.norm(g32) * np.linalg.norm(gr)))
+    print("gradient cosine vs the rounded oracle: %.4f (the fp32 step's gradient: %.4f)" % (cos, cos32))
+    assert cos >= (0.85 if flipped.any() else 0.93) and (1 - cos) < (0.7 if flipped.any() else 0.3) * (1 - cos32), (cos, cos32)
     eng.close()
 
 
