@@ -448,6 +448,10 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return 0;
 }
 
@@ -945,7 +949,14 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
   const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
   if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
-  if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
+  const bool dg_bf16 = dg && h->train_bf16;   // edge pass with h1 Q2 on bf16 MFMA: bf16 images of Q2, packed with the bias row
+  constexpr size_t kQ2hMax = 2 * 4 * 512;     // [CT1 <= 2][KG16 <= 4][64 lanes][8]
+  if (dg_bf16) {
+    if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (2 * 8 * 512 + kQ2hMax) * sizeof(unsigned short)));   // (the PointNet bf16 B1's allocation)
+    PackBf16Jobs pj{};
+    for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[t] = w->b1imgh + t * kQ2hMax; pj.K[t] = C1; pj.C[t] = C1; }
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b});
+  } else if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
   if (dg) {
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
     DgBwdArgs e;
@@ -953,12 +964,17 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.ld0 = ((C1 + 7) & ~7) + 4;
     e.w1 = P(h, L[0]->p_w); e.sc1 = S.scale[0]; e.sh1 = S.shift[0];
     e.v2 = w->V2; e.v2_stride = (long)C1 * C2; e.q2img = w->q2img; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
+    e.q2imgh = w->b1imgh; e.q2imgh_stride = (long)kQ2hMax;
     e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = nullptr; e.pdy_part = w->pdy_part;   // Gram(h1): the forward's
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
-    const size_t el = dg_bwd_edge_lds(C1, C2);
+    const size_t el = dg_bwd_edge_lds(C1, C2, dg_bf16);
   { ProfScope prof_scope(h, PK_DG_BWD_EDGE);
-    if (C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128>), eg, eb, el, h->stream, e);
+    if (dg_bf16 && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128, true>), eg, eb, el, h->stream, e);
+    else if (dg_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64, true>), eg, eb, el, h->stream, e);
+    else if (dg_bf16 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128, true>), eg, eb, el, h->stream, e);
+    else if (dg_bf16) hipLaunchKernelGGL((dg_train_bwd_edge<32, 64, true>), eg, eb, el, h->stream, e);
+    else if (C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128>), eg, eb, el, h->stream, e);
     else if (C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64>), eg, eb, el, h->stream, e);
     else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
     else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);

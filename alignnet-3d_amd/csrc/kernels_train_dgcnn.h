@@ -171,6 +171,29 @@ __device__ __forceinline__ void dgt_liftm(const DgtLiftM<C1, NW>& R, const float
   }
 }
 
+// bf16 mode of the backward edge pass: the fp32 tile holds the ROUNDED h1 (what the forward multiplied: U2 = h1^T dy2, the relu
+// mask and the sparse products read it) and a bf16 row-major copy feeds the h1 Q2 MFMAs
+template <int C1, int NW>
+__device__ __forceinline__ void dgt_liftm_both(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, float* __restrict__ out, int ldo,
+                                               unsigned short* __restrict__ Xh, int ldh, int nvalid, int wave, int lane)
+{
+#pragma unroll
+  for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
+    const int t = wave * DgtLiftM<C1, NW>::kPer + i, rt = t / DgtLiftM<C1, NW>::kCT, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
+    const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], R.w[i][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], R.w[i][1], acc, 0, 0, 0);
+    const int row0 = 16 * rt + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned short hb = row0 + r < nvalid ? to_bf16_bits(fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f)) : (unsigned short)0;
+      out[(row0 + r) * ldo + c] = __uint_as_float((unsigned)hb << 16);
+      Xh[(row0 + r) * ldh + c] = hb;
+    }
+  }
+}
+
 // bf16 mode: the same lift written straight as the two bf16 tiles the bf16 MFMAs read -- row-major Xh[row][ldh] (A operand of
 // z2 = h1 W2) and transposed XhT[c][ldT] (both operands of Gram(h1) = h1^T h1); a lane's four rows of a column are one 8-byte store
 // into the transposed tile.
@@ -487,6 +510,7 @@ struct DgBwdArgs {
   const float* w1; const float *sc1, *sh1;
   const float* v2; long v2_stride;     // per tower: V2 = (W2 diag(k2))^T  [C2][C1] row-major
   const float* q2img; long q2img_stride;   // per-tower MFMA image of Q2 [C1][C1]
+  const unsigned short* q2imgh; long q2imgh_stride;   // bf16 mode: per-tower bf16 MFMA image of Q2
   const float* q2b;                    // [2][C1]
   const float* dyp;                    // [2B*N][C2]  dp * [p > 0]   (pass B2, GIVEN)
   const unsigned char* argk;           // [2B*N][C2]
@@ -498,14 +522,16 @@ struct DgBwdArgs {
 // stamps 10..15: the tile-start block of iteration 40; stamp 16: iteration 45 (20 iterations = one tile after stamp 0)
 #define BE_TSTAMP(i, at) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == at) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
-static inline size_t dg_bwd_edge_lds(int C1, int C2)
+static inline size_t dg_bwd_edge_lds(int C1, int C2, bool bf16 = false)
 {
   const int ld0 = ((C1 + 7) & ~7) + 4;
   return ((size_t)2 * kTT * 8 + 2 * (size_t)kTT * ld0 + (size_t)kTT * (C2 + 4) + (size_t)C2 * (C1 + 4)) * sizeof(float) +
-         (size_t)kTT * C2 + kTT * 24 + (size_t)C2 * kTT + (size_t)C2 * 24;
+         (size_t)kTT * C2 + kTT * 24 + (size_t)C2 * kTT + (size_t)C2 * 24 + (bf16 ? (size_t)kTT * (C1 + 8) * sizeof(unsigned short) : 0);
 }
 
-template <int C1, int C2>
+// BF16 ("train_matmul_bf16", dgcnn): h1 is the ROUNDED h1 of the forward (fp32 tile of rounded values + a bf16 copy) and the dense
+// product h1_s Q2 runs on v_mfma_f32_32x32x16_bf16 (Q2 as a bf16 image); the sparse products, Pdy and all reductions stay fp32.
+template <int C1, int C2, bool BF16 = false>
 __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -526,6 +552,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   unsigned char* SLc = SO + kTT * 24;                                      // [C2][64]  rows of the column, grouped by slot
   unsigned char* SOc = SLc + C2 * kTT;                                   // [C2][24]
   unsigned char* AK = reinterpret_cast<unsigned char*>(D);                 // [64][C2] staging (tile start only)
+  constexpr int ldh = C1 + 8, KG16 = C1 / 16;
+  unsigned short* Xh = reinterpret_cast<unsigned short*>(SOc + C2 * 24);   // bf16 mode: h1 [64][C1 + 8]  (all sizes above are multiples of 16 bytes)
   constexpr int CT1 = (C1 + 31) >> 5, KGq = (C1 + 7) >> 3;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
@@ -537,10 +565,17 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   constexpr int nitems = CT1 * 2;
   // the dh1 waves keep their Q2 fragments in registers for the whole cloud (C1 <= 64: 8 k-groups); streaming them per slot
   // put eight dependent L2 round trips in front of every slot's MFMAs
-  f32x4 qreg[8];
+  f32x4 qreg[BF16 ? 1 : 8];
+  bf16x8 qregh[BF16 ? KG16 : 1];
   if (wave < nitems) {
+    if constexpr (BF16) {
+      const bf16x8* qh = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2imgh_stride);
 #pragma unroll
-    for (int kg = 0; kg < 8; ++kg) qreg[kg] = q2img[((size_t)(wave >> 1) * KGq + min(kg, KGq - 1)) * 64 + lane];
+      for (int kg = 0; kg < KG16; ++kg) qregh[kg] = qh[((size_t)(wave >> 1) * KG16 + kg) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) qreg[kg] = q2img[((size_t)(wave >> 1) * KGq + min(kg, KGq - 1)) * 64 + lane];
+    }
   }
   double pd[4];
   f32x16 pacc;
@@ -675,7 +710,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);
     }
     BE_STAMP(2);
-    dgt_liftm<C1, kBEW>(lw, es, X, ld0, nvalid, wave, lane);
+    if constexpr (BF16) dgt_liftm_both<C1, kBEW>(lw, es, X, ld0, Xh, ldh, nvalid, wave, lane);
+    else dgt_liftm<C1, kBEW>(lw, es, X, ld0, nvalid, wave, lane);
     BE_STAMP(3);
     if (p1on) {   // D[row][8 ch ..] = sum_c dp[row,c] V2[c][8 ch ..] over the row's slot columns
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -752,7 +788,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       }
       asm volatile("" ::: "memory");
       BE_STAMP(8);
-      {
+      if constexpr (BF16) {
+        const unsigned short* arow = Xh + (rg * 32 + (lane & 31)) * ldh + half * 8;
+#pragma unroll
+        for (int kg = 0; kg < KG16; ++kg)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + kg * 16), qregh[kg], acc[0], 0, 0, 0);
+      } else {
         const float* arow = X + (rg * 32 + (lane & 31)) * ld0 + half * 4;
 #pragma unroll
         for (int kg = 0; kg < 8; ++kg)
