@@ -92,7 +92,7 @@ def kernel_macs(cfg, kernel, bf16):
     tot = 0
     for (c1, c2, c3) in [w[:3] for w in stage_widths(cfg)]:
         if kernel == "train_fwd_phase3":       # h1, h2 recomputed from xyz, z3 = h2 W3 (+ the Gram of h2 inside the bf16 kernel)
-            tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if bf16 and not dg else 0)
+            tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if bf16 else 0)
         elif kernel == "train_fwd_phase2":     # fp32: h1 + Gram(h1) (statistics of z2 from the Gram); bf16: h1 + z2 = h1 W2
             tot += n * (k0 * c1 + (c1 * c2 if bf16 else _blocks(c1)))
         elif kernel == "train_gram_h2":
@@ -421,8 +421,8 @@ def main():
             line["config"]["workload"] = ("KITTITrackletsCars-style training step (SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
                                           "(BASELINE.json configs[2])" % (B, npts, args.train_dtype))
             if dg:
-                line["config"]["workload"] = ("training step, DGCNN edge-conv branch (k=20, SynthCars widths), batch=%d pairs/GPU, N=%d, f32 "
-                                              "(BASELINE.json configs[4] shape)" % (B, npts))
+                line["config"]["workload"] = ("training step, DGCNN edge-conv branch (k=20, SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
+                                              "(BASELINE.json configs[4] shape)" % (B, npts, "bf16 forward convs + h1 Q2, rest fp32" if args.train_dtype == "bf16" else "f32"))
             line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients, %d ranks)" % rccl_ranks if world > 1 else "")
             line["flops_per_pair_survey"] = FLOPS_PER_PAIR_TRAIN_SURVEY if not dg and npts == N_POINTS else None
             if world > 1:
