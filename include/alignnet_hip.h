@@ -146,7 +146,7 @@ int alignnet_synchronize(alignnet_handle* h);
  * Shapes: PointNet backbones of any depth (2 .. 6 conv layers, models/tp8.py:49-59), widths multiples of 8.  Three-layer stages with
  * widths multiples of 32, C1, C2 <= 128, C3 <= 1024 (every shipped dataset config) run the fused recompute kernels; any other stage
  * (e.g. the five-layer backbones of configs/default.json) runs the layer-by-layer path (fp32, hidden widths <= 256, last <= 4096);
- * backbone "dgcnn" (models/tp8.py:30-46, k = 20): fp32 only, C1 in {32, 64}, C2 in {64, 128}, 20 <= num_points <= 4096.
+ * backbone "dgcnn" (models/tp8.py:30-46, k = 20): C1 in {32, 64}, C2 in {64, 128}, 20 <= num_points <= 4096.
  * Anything else fails with a message (alignnet_last_error), it is never run on a fallback. */
 int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
                         const alignnet_labels* labels, int32_t B, const float* dropout_u,
@@ -240,7 +240,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "train_matmul_bf16" (0/1, default 0): training only -- the two MFMA convs of every backbone (the hidden 1x1 conv
  *   and the -> C3 feature lift, 96 % of the step's FLOPs, models/tp8.py:55-57), in the forward and in the backward's
  *   recompute, run on bf16 MFMA with fp32 accumulation (BASELINE.json configs[2]); statistics, pooling, the K = 3 lift,
- *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.
+ *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.  With the dgcnn backbone: the edge
+ *   conv behind the K = 6 lift and the point conv (forward), and the dense product h1 Q2 of the backward edge pass.
  * "infer_matmul_bf16x3" (0/1, default 0): eval-mode forward of 3-layer PointNet backbones (every shipped config) -- every
  *   fp32 operand of the two MFMA layers is written x = bf16(x) + bf16(x - bf16(x)) and each product is formed as
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
