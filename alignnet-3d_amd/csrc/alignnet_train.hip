@@ -503,7 +503,7 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
   StageWS& S = w->st[s];
   TrainWS::GenStage& Gs = w->gen[s];
   const Stack& st = conv_of(h, s);
-  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles, slabs = w->gen_slabs;
+  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
   const size_t R = (size_t)2 * M;
   const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
   float* dY = w->gen_d[0];

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // ---------------------------------------------------------------------------------
 constexpr int kPackBf16Jobs = 9;
 struct PackBf16Jobs { const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs]; };
-// bf16 MFMA images (layout and sign folding of pack_weights_bf16_kernel: gamma null = none) of up to nine matrices in one launch,
+// bf16 MFMA images (layout and sign folding as described in kernels_train_fwd.h; gamma null = no folding) of up to nine matrices in one launch,
 // grid (blocks, jobs): a training step re-packs 9 + 3 x 6 images, each its own 4.5 us launch before
 __device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsigned bx, int q, unsigned gx)
 {

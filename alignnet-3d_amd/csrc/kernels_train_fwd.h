@@ -33,7 +33,7 @@ struct TrainFwdArgs {
   const float* w1;         // [3][C1]
   const float* wp2;        // MFMA image of W2 [C1][C2]
   const float* wp3;        // MFMA image of W3 [C2][C3]
-  const unsigned short* wp3h;   // bf16 MFMA image of W3 (train_bf16 mode; see pack_weights_bf16_kernel)
+  const unsigned short* wp3h;   // bf16 MFMA image of W3 (train_bf16 mode; packed by pack_bf16_jobs_kernel)
   const unsigned short* wp2h;   // bf16 MFMA image of W2 (train_bf16 mode, no sign folding)
   const float *b1, *b2, *b3;       // conv biases (added before BN: utils/tf_util.py:161)
   const float *sc1, *sh1;  // [2][C1] batch-stat scale/shift of layer 1 (phase >= 2)
@@ -223,22 +223,7 @@ __device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 +
 // bf16 weight image: Wh[t][ct][kg][lane][8] = sign(gamma_t[c]) * W[16 kg + 8 (lane>>5) + s][c],  c = 32 ct + (lane&31)
 // (one 16-byte fragment per lane per MFMA).  The sign of the following BatchNorm's gamma is folded into the column
 // (exact), so that the kernel's accumulator is already sgn * (z - bias): the pooled extreme is a plain max.
-static __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int K, int C, const float* __restrict__ gamma0,
-                                                const float* __restrict__ gamma1, unsigned short* __restrict__ Wh)
-{
-  const int KG = (K + 15) >> 4, CT = (C + 31) >> 5, t = blockIdx.y;
-  const float* gamma = t ? gamma1 : gamma0;   // null: no sign folding (hidden layers)
-  const size_t total = (size_t)CT * KG * 512;
-  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int s8 = idx & 7, lane = (idx >> 3) & 63;
-    const size_t q = idx >> 9;
-    const int kg = q % KG, ct = q / KG;
-    const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
-    float v = 0.f;
-    if (k < K && c < C) v = (!gamma || gamma[c] >= 0.f) ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
-    Wh[(size_t)t * total + idx] = to_bf16_bits(v);
-  }
-}
+// (packed by pack_bf16_jobs_kernel, kernels_train_bwd.h: up to nine images per launch)
 
 // acc[m] = A[rows 32 m.., :16 KG] * W tile, A a bf16 LDS tile with row stride lda (elements), one bf16x8 read per MFMA
 template <int MR, bool CLEAR = true>
