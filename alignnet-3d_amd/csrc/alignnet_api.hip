@@ -748,6 +748,11 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   const std::string k(key);
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
   if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
+  if (k == "train_fused_tail") {
+    if (h->fused_tail != (value != 0)) h->train_ws_stale = true;   // the workspace is carved per setting
+    h->fused_tail = value != 0;
+    return 0;
+  }
   if (k == "infer_matmul_bf16x3") {
     if (h->infer_split != (value != 0)) h->folded = false;   // the split weight images are packed by the next eval forward
     h->infer_split = value != 0;
@@ -767,6 +772,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }
   if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
   if (k == "last_train_kernel") { *value = h->last_train_kernel; return 0; }
+  if (k == "train_fused_tail") { *value = h->fused_tail ? 1 : 0; return 0; }
   return fail(h, "alignnet_get_option: unknown key '" + k + "'");
 }
 

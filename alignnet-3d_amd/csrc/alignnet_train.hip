@@ -140,6 +140,21 @@ static bool stage_generic(const alignnet_handle* h, int s)
   return C1 % 32 || C2 % 32 || C3 % 32 || C1 > 128 || C2 > 128 || C3 > 1024;
 }
 
+// A general-depth stage whose LAST TWO layers fit the fused kernels (C_{n-2} in multiples of 32 up to 128, C_{n-1} in multiples of 32
+// up to 1024, first layer <= 128 wide): the layers up to n - 2 run layer by layer (kernels_train_generic.h), their output
+// h = relu(bn(Z_{n-2})) is materialised once ([B N, C_{n-2}]) and the last layer runs on the "given features" kernels of the DGCNN
+// branch -- phase 3 / pass B2 with GIVEN = true -- so that the [B N, C_last] tensors of an unfused last layer (2 GB each at
+// B = 256, N = 1024, C = 1024: 17 of default.json's 29 ms) never exist.  alignnet_set_option("train_fused_tail", 0) keeps the plain
+// layer-by-layer path (tests compare the two).
+static bool stage_hybrid(const alignnet_handle* h, int s)
+{
+  if (!stage_generic(h, s) || !h->fused_tail) return false;
+  const Stack& st = conv_of(h, s);
+  if (st.n < 3) return false;
+  const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + st.n - 2].cout, C3 = h->layers[st.first + st.n - 1].cout;
+  return C1 <= 128 && C1 % 8 == 0 && C2 % 32 == 0 && C2 <= 128 && C3 % 32 == 0 && C3 <= 1024;
+}
+
 static int check_trainable_shape(alignnet_handle* h)
 {
   const bool dg = h->cfg.backbone == 1;
@@ -187,7 +202,9 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     HIP_TRY(h, hipMemset(w->adam_m, 0, h->n_trainable * sizeof(float)));
     HIP_TRY(h, hipMemset(w->adam_v, 0, h->n_trainable * sizeof(float)));
   }
-  if (B <= w->cap) return 0;
+  if (B <= w->cap && !h->train_ws_stale) return 0;
+  B = std::max(B, w->cap);
+  h->train_ws_stale = false;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (w->base) { hipFree(w->base); w->base = nullptr; }
   for (int t = 0; t < 2; ++t) if (w->d_pcs[t]) { hipFree(w->d_pcs[t]); w->d_pcs[t] = nullptr; }
@@ -202,8 +219,10 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       for (int j = 0; j < fs.n; ++j) maxH = std::max(maxH, h->layers[fs.first + j].cout);
     }
     if (stage_generic(h, s)) {
-      for (int i = 0; i < st.n; ++i) { genC = std::max(genC, h->layers[st.first + i].cout); if (i) genK = std::max(genK, h->layers[st.first + i].cin); }
+      const bool hyb = stage_hybrid(h, s);   // the last layer belongs to the fused kernels: no [B N, C_last] buffers
+      for (int i = 0; i < st.n - (hyb ? 1 : 0); ++i) { genC = std::max(genC, h->layers[st.first + i].cout); if (i) genK = std::max(genK, h->layers[st.first + i].cin); }
       maxC3 = std::max(maxC3, h->layers[st.first + st.n - 1].cout);
+      if (hyb) maxC2 = std::max(maxC2, h->layers[st.first + st.n - 2].cout);
       continue;
     }
     maxC1 = std::max(maxC1, h->layers[st.first].cout);
@@ -230,11 +249,11 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->center_mean = F(B2 * 3); w->s1c = F(B2 * 3); w->s2c = F(B2 * 3); w->theta = F(B2); w->cls = I(B2);
     for (int s = 0; s < 3; ++s) {
       const Stack& st = conv_of(h, s);
-      const bool gen = stage_generic(h, s);
+      const bool gen = stage_generic(h, s), hyb = stage_hybrid(h, s);
       // specialised stages: [C1, C2, C3]; general-depth stages only need the stage interface (frame, pooled output and its gradient,
-      // frame gradients), sized by the LAST layer's width
+      // frame gradients), sized by the LAST layer's width; hybrid stages also the fused tail's buffers for [C_{n-2}, C_{n-1}]
       const int Cl = h->layers[st.first + st.n - 1].cout;
-      const int C[3] = {gen ? 8 : h->layers[st.first].cout, gen ? 8 : h->layers[st.first + 1].cout, Cl};
+      const int C[3] = {gen ? 8 : h->layers[st.first].cout, hyb ? h->layers[st.first + st.n - 2].cout : gen ? 8 : h->layers[st.first + 1].cout, Cl};
       StageWS& S = w->st[s];
       S.xform = F(B2 * 12);
       if (gen) {
@@ -242,14 +261,14 @@ static int ensure_train_ws(alignnet_handle* h, int B)
         Gs.X0 = F(MN * 4);
         for (int i = 0; i < st.n; ++i) {
           const int c = h->layers[st.first + i].cout;
-          Gs.Z[i] = F(MN * c); Gs.mean[i] = F(2 * c); Gs.rstd[i] = F(2 * c); Gs.scale[i] = F(2 * c); Gs.shift[i] = F(2 * c);
+          Gs.Z[i] = F((hyb && i == st.n - 1) ? 8 : MN * c); Gs.mean[i] = F(2 * c); Gs.rstd[i] = F(2 * c); Gs.scale[i] = F(2 * c); Gs.shift[i] = F(2 * c);
         }
         Gs.idx = I(B2 * Cl);
       }
       for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); S.rstd[l] = F(2 * C[l]); S.kk[l] = F(2 * C[l]); }
       S.sgn3 = F(2 * C[2]);
       S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
-      S.h2 = F(gen ? 8 : MN * C[1]);
+      S.h2 = F((gen && !hyb) ? 8 : MN * C[1]);
       S.gram2 = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
       S.pooled = F(B2 * C[2]); S.dP = F(B2 * C[2]);
       if (s < 2) { S.tower_stride = (long)B * C[2]; S.row_stride = C[2]; }
@@ -259,6 +278,11 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
       (void)gen;
       S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]); S.g1f = F(2 * (size_t)C[0] * C[0]);
+      if (hyb && pass) {   // the fused tail reads the statistics of the layers in front of it where the fused stages keep theirs
+        TrainWS::GenStage& Gs = w->gen[s];
+        S.scale[0] = Gs.scale[0]; S.shift[0] = Gs.shift[0];
+        S.mean[1] = Gs.mean[st.n - 2]; S.rstd[1] = Gs.rstd[st.n - 2]; S.scale[1] = Gs.scale[st.n - 2]; S.shift[1] = Gs.shift[st.n - 2];
+      }
       const Stack& fs = fc_of(h, s);
       const size_t M = s < 2 ? B2 : (size_t)B;
       for (int j = 0; j < fs.n - 1; ++j) {
@@ -311,8 +335,8 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     std::vector<PackJob> jobs;
     for (int s = 0; s < 3; ++s) {
       const Stack& st = conv_of(h, s);
-      const bool gen = stage_generic(h, s);   // (general-depth stages do not use these images: harmless 8 x 8 jobs keep the table's layout)
-      const int C1 = gen ? 8 : h->layers[st.first].cout, C2 = gen ? 8 : h->layers[st.first + 1].cout;
+      const bool gen = stage_generic(h, s), hyb = stage_hybrid(h, s);   // (general-depth stages do not use these images: harmless 8 x 8 jobs keep the table's layout)
+      const int C1 = gen ? 8 : h->layers[st.first].cout, C2 = hyb ? h->layers[st.first + st.n - 2].cout : gen ? 8 : h->layers[st.first + 1].cout;
       const size_t qimg = img_floats(C2, C2), vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
       for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q3 + (size_t)t * C2 * C2, w->q3img + t * qimg, C2, C2});
       for (int t = 0; t < 2; ++t) jobs.push_back(PackJob{w->Q2 + (size_t)t * C1 * C1, w->q2img + t * q2img, C1, C1});
@@ -458,7 +482,8 @@ static int set_lds_attrs(alignnet_handle* h)
 // ---------------------------------------------------------------------------------
 // general-depth PointNet stage (kernels_train_generic.h): forward with batch statistics, then backward
 // ---------------------------------------------------------------------------------
-static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema)
+// nl: layers to run (hybrid stages stop in front of the last one and do not pool: backbone_fwd_train takes over)
+static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema, int nl = -1)
 {
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
@@ -472,7 +497,9 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
-  for (int l = 0; l < st.n; ++l) {
+  const bool partial = nl >= 0;
+  if (!partial) nl = st.n;
+  for (int l = 0; l < nl; ++l) {
     const Layer& L = h->layers[st.first + l];
     if (l == 0) {
       GenL1Args a{Gs.X0, P(h, L.p_w), P(h, L.p_b), Gs.Z[0], w->gen_part, M, L.cout, tiles};
@@ -490,6 +517,7 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
     f.mean = Gs.mean[l]; f.rstd = Gs.rstd[l]; f.scale = Gs.scale[l]; f.shift = Gs.shift[l];
     hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(1024), 0, h->stream, f);
   }
+  if (partial) { HIP_TRY(h, hipGetLastError()); return 0; }
   const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
   GenPoolArgs pa{Gs.Z[Ll], Gs.scale[Ll], Gs.shift[Ll], B, N, Cl, S.pooled, S.tower_stride, S.row_stride, Gs.idx};
   hipLaunchKernelGGL(gen_pool_fwd, dim3(2 * B, (Cl + 63) / 64), dim3(256), 0, h->stream, pa);
@@ -497,7 +525,8 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
   return 0;
 }
 
-static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
+// given_dY: hybrid stages -- the fused tail has produced dY of layer n - 2 (w->dy2, already masked by [h > 0]): start there
+static int backbone_bwd_generic(alignnet_handle* h, int s, int B, float* given_dY = nullptr)
 {
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
@@ -506,11 +535,13 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
   const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
   const size_t R = (size_t)2 * M;
   const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
-  float* dY = w->gen_d[0];
-  float* dYprev = w->gen_d[1];
-  HIP_TRY(h, hipMemsetAsync(dY, 0, R * Cl * sizeof(float), h->stream));
-  hipLaunchKernelGGL(gen_pool_bwd, dim3((unsigned)(((size_t)2 * B * Cl + 255) / 256)), dim3(256), 0, h->stream, S.dP, S.tower_stride, S.row_stride, Gs.idx, B, N, Cl, dY);
-  for (int l = Ll; l >= 0; --l) {
+  float* dY = given_dY ? given_dY : w->gen_d[0];
+  float* dYprev = given_dY ? w->gen_d[0] : w->gen_d[1];
+  if (!given_dY) {
+    HIP_TRY(h, hipMemsetAsync(dY, 0, R * Cl * sizeof(float), h->stream));
+    hipLaunchKernelGGL(gen_pool_bwd, dim3((unsigned)(((size_t)2 * B * Cl + 255) / 256)), dim3(256), 0, h->stream, S.dP, S.tower_stride, S.row_stride, Gs.idx, B, N, Cl, dY);
+  }
+  for (int l = given_dY ? Ll - 1 : Ll; l >= 0; --l) {
     const Layer& L = h->layers[st.first + l];
     const int C = L.cout, K = L.cin;
     GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, M, C, tiles};
@@ -531,7 +562,8 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
     hipLaunchKernelGGL(gen_pack_transposed, dim3(64), dim3(256), 0, h->stream, P(h, L.p_w), K, C, w->gen_wt);
     GenDxArgs dx{dY, w->gen_wt, dYprev, M, K, C};
     hipLaunchKernelGGL(gen_gemm_dx, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * 132 * sizeof(float), h->stream, dx);
-    std::swap(dY, dYprev);
+    if (dY == given_dY) { dY = dYprev; dYprev = w->gen_d[1]; }   // (the tail's buffer is only as wide as its own layer: not a scratch for the others)
+    else std::swap(dY, dYprev);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -542,11 +574,13 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B)
 // ---------------------------------------------------------------------------------
 static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B, float bn_decay, int update_ema)
 {
-  if (stage_generic(h, s)) return backbone_fwd_generic(h, s, p1, p2, B, bn_decay, update_ema);
+  const bool hyb = stage_hybrid(h, s);
+  if (stage_generic(h, s) && !hyb) return backbone_fwd_generic(h, s, p1, p2, B, bn_decay, update_ema);
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
   const Stack& st = conv_of(h, s);
-  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + 1], &h->layers[st.first + 2]};
+  // (hybrid stages: "layer 2" / "layer 3" of the fused tail are the stage's last two layers; C1 only sizes LDS regions the tail does not use)
+  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + st.n - 2], &h->layers[st.first + st.n - 1]};
   const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
   TrainFwdArgs a;
   a.pcs[0] = p1; a.pcs[1] = p2; a.xform = S.xform; a.B = B; a.N = N; a.C1 = C1; a.C2 = C2; a.C3 = C3;
@@ -623,8 +657,19 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     finish(1, C2, 1, ecount, 1);
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
-    // point conv on the stored p
-    if (h->train_bf16) {
+  } else if (hyb) {
+    // layers 1 .. n - 1 layer by layer, then h = relu(bn(Z_{n-1})) once, with its column sums; sign(gamma) of the last layer
+    if (backbone_fwd_generic(h, s, p1, p2, B, bn_decay, update_ema, st.n - 1)) return 1;
+    const TrainWS::GenStage& Gs = w->gen[s];
+    const int c4 = C2 / 4;
+    hipLaunchKernelGGL(gen_apply_colsum, dim3(2 * B), dim3(c4 * (256 / c4)), 0, h->stream, Gs.Z[st.n - 2], Gs.scale[st.n - 2], Gs.shift[st.n - 2], B, N, C2, S.h2,
+                       w->colsum_part);
+    for (int t = 0; t < 2; ++t)
+      hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + (size_t)t * C3);
+  }
+  if (dg || hyb) {
+    // point conv on the stored features (DGCNN: p = max_k h2; hybrid: the output of the layer-by-layer part)
+    if (h->train_bf16 && dg) {
       // bf16 operands (p rounded while it is staged, the sign-folded bf16 image of W3); Gram(p) and the column sums of the rounded p
       // come out of the same pass (1024 / C2 row-group slices per cloud)
       a.wp3h = w->wp3h[s];
@@ -643,7 +688,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
-    finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 2 * B, (long)(C2), S.s2));
+    finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2));
     }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
@@ -707,7 +752,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   {   // centred Gram of h2 + pooled features: independent of each other, one launch
     const size_t tot = (size_t)2 * B * C3;
     const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
-                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, h->train_bf16 ? 1 : 0};
+                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && !hyb) ? 1 : 0};
     hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
                        S.gram2, S.s2, C2, count, S.m2, pa);
   }
@@ -843,14 +888,17 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
 // ---------------------------------------------------------------------------------
 static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B)
 {
-  if (stage_generic(h, s)) return backbone_bwd_generic(h, s, B);
+  const bool hyb = stage_hybrid(h, s);
+  if (stage_generic(h, s) && !hyb) return backbone_bwd_generic(h, s, B);
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];
   const Stack& st = conv_of(h, s);
-  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + 1], &h->layers[st.first + 2]};
+  // (hybrid stages: the fused tail's "layers 2 and 3" are the stage's last two; the layers in front of them follow layer by layer)
+  const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + st.n - 2], &h->layers[st.first + st.n - 1]};
   const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
   const double M = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
+  const bool given = dg || hyb;   // pass B2 on stored features, fp32
   const double Me = dg ? M * kDgK : M;   // rows behind the statistics of layers 1 and 2 (DGCNN: the B*N*k edge rows)
   const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
   auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
@@ -862,7 +910,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, (h->train_bf16 && !dg) ? 1 : 0);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, (h->train_bf16 && !given) ? 1 : 0);
   // GW[t] = Ghat2[t] W3  (both towers in one launch)
   launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
   // dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)  and  W3E[t] = W3 diag(E[t]), W3T = W3^T  (one launch: nothing in it depends on the other part)
@@ -872,7 +920,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
   const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
-  if (h->train_bf16 && !dg) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
+  if (h->train_bf16 && !given) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
@@ -894,7 +942,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part;
-  b2.s1_part = (!dg && !h->train_bf16 && !b2_accum && !getenv("ALIGNNET_PHASE2_LEGACY")) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
+  b2.s1_part = (!given && !h->train_bf16 && !b2_accum && !getenv("ALIGNNET_PHASE2_LEGACY")) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
@@ -902,8 +950,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.h2_given = S.h2;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   { ProfScope prof_scope(h, PK_TRAIN_B2);
-  if (dg && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (dg) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  if (given && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (given) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (std_w && !b2_accum && h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (std_w && !b2_accum) hipLaunchKernelGGL((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
@@ -920,6 +968,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     std::fprintf(stderr, "  total %lld\n", st[10] - st[0]);
   }
 
+  if (hyb) {   // w->dy2 = dL/dh [h > 0] of layer n - 1's output: the layers in front of the tail take it from here
+    HIP_TRY(h, hipGetLastError());
+    return backbone_bwd_generic(h, s, B, w->dy2);
+  }
   // ---- operators for B1 (the layer-2 weight gradient follows B1 when B1 accumulates U2 / Gram(h1)) ----
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
@@ -1091,7 +1143,9 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
     for (int s = 0; s < 3; ++s) std_all = std_all && h->layers[conv_of(h, s).first].cout == 64 && h->layers[conv_of(h, s).first + 1].cout == 128;
     bool any_gen = false;
     for (int s = 0; s < 3; ++s) any_gen = any_gen || stage_generic(h, s);
-    h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0) | (any_gen ? 8 : 0);
+    bool any_hyb = false;
+    for (int s = 0; s < 3; ++s) any_hyb = any_hyb || stage_hybrid(h, s);
+    h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0) | (any_gen ? 8 : 0) | (any_hyb ? 16 : 0);
   }
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;

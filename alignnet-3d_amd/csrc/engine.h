@@ -76,6 +76,8 @@ struct alignnet_handle {
   unsigned short* d_wps = nullptr; // split (hi, lo) bf16 weight images of the MFMA conv layers, built on demand
   std::vector<size_t> off_wps;     // per layer, in elements
   bool train_bf16 = false;         // alignnet_set_option("train_matmul_bf16"): bf16 operands for the dominant training GEMMs
+  bool fused_tail = true;          // alignnet_set_option("train_fused_tail"): general-depth stages run their last layer on the fused kernels
+  bool train_ws_stale = false;     // the training workspace was carved for another setting of fused_tail: re-carve on the next step
   bool folded = false;             // eval-mode scale/shift + packed weights are current
   alignnet::Workspace ws;
   hipStream_t stream = nullptr;
@@ -86,7 +88,7 @@ struct alignnet_handle {
   int64_t adam_power_t = 0;
   int last_B = 0;
   int last_kernel = 0;             // which backbone instantiation the last eval forward launched (alignnet_get_option "last_backbone_kernel")
-  int last_train_kernel = 0;       // same for the training step: bit 0 = compile-time widths (64, 128), bit 1 = bf16 operands, bit 2 = dgcnn
+  int last_train_kernel = 0;       // same for the training step: bit 0 = compile-time widths (64, 128), bit 1 = bf16 operands, bit 2 = dgcnn, bit 3 = general depth, bit 4 = fused tail
   // profiling
   bool prof = false;
   hipEvent_t ev[2] = {nullptr, nullptr};

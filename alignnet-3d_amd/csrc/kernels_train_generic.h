@@ -228,6 +228,51 @@ __global__ __launch_bounds__(1024) void gen_stat_finish(const GenStatArgs a)
   }
 }
 
+// ---- hybrid stages: h = relu(bn(Z)) materialised once for the fused tail (phase 3 / pass B2 with GIVEN features), with the cloud's
+//      column sums of h (one fp64 slice per cloud: the centred Gram of the tail needs them).
+//      grid (2B), block (C / 4) * (256 / (C / 4)): a thread owns four columns of every (256 / (C / 4))-th row -------------------------
+__global__ __launch_bounds__(256) void gen_apply_colsum(const float* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int B, int N, int C, float* __restrict__ H, double* __restrict__ colsum)
+{
+  __shared__ double red[32][128];
+  const int cloud = blockIdx.x, tower = cloud >= B, c4 = C >> 2, groups = blockDim.x / c4;
+  const int q = threadIdx.x % c4, g = threadIdx.x / c4;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + tower * C + q * 4), sh = *reinterpret_cast<const f32x4*>(shift + tower * C + q * 4);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int r0 = 0; r0 < N; r0 += 8 * groups) {   // eight rows in flight per thread
+    f32x4 z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + g + u * groups;
+      z[u] = r < N ? *reinterpret_cast<const f32x4*>(Z + ((size_t)cloud * N + r) * C + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + g + u * groups;
+      if (r < N) {
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[e] = fmaxf(fmaf(z[u][e], sc[e], sh[e]), 0.f); ls[e] += hv[e]; }
+        *reinterpret_cast<f32x4*>(H + ((size_t)cloud * N + r) * C + q * 4) = hv;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += (double)ls[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[g][q * 4 + e] = s[e];
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double t = 0.0;
+      for (int k = 0; k < groups; ++k) t += red[k][q * 4 + e];
+      colsum[(size_t)cloud * C + q * 4 + e] = t;
+    }
+  }
+}
+
 // ---- max over the N points of relu(bn(Z_L)) + arg-max row.  grid (2B, ceil(C / 64)), block 256 = 4 row groups x 64 columns --------
 struct GenPoolArgs { const float* Z; const float* scale; const float* shift; int B, N, C; float* pooled; long tower_stride, row_stride; int* idx; };
 

@@ -242,6 +242,11 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   recompute, run on bf16 MFMA with fp32 accumulation (BASELINE.json configs[2]); statistics, pooling, the K = 3 lift,
  *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.  With the dgcnn backbone: the edge
  *   conv behind the K = 6 lift and the point conv (forward), and the dense product h1 Q2 of the backward edge pass.
+ * "train_fused_tail" (0/1, default 1): training of backbones outside the fused kernels' shape (depth != 3, odd widths; e.g. the
+ *   five-layer backbones of configs/default.json): the layers up to the second-to-last run layer by layer, their output is kept once,
+ *   and the last layer -- 90 % of such a backbone's FLOPs -- runs on the fused phase-3 / pass-B2 kernels on the stored features
+ *   (when the last two widths fit: multiples of 32, <= 128 and <= 1024), so that the [B N, C_last] tensors never exist.  0 = every
+ *   layer layer by layer.  Same arithmetic up to summation order.
  * "infer_matmul_bf16x3" (0/1, default 0): eval-mode forward of 3-layer PointNet backbones (every shipped config) -- every
  *   fp32 operand of the two MFMA layers is written x = bf16(x) + bf16(x - bf16(x)) and each product is formed as
  *   x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation: three bf16 MFMAs instead of one fp32 MFMA (16x slower on
@@ -256,7 +261,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
  * "comm_world": number of ranks of the RCCL communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
  * "last_train_kernel": bit mask of the most recent training step -- 1 = compile-time widths (64, 128), 2 = bf16 operands,
- *   4 = dgcnn backbone, 8 = at least one stage ran the general-depth (layer-by-layer) path.
+ *   4 = dgcnn backbone, 8 = at least one stage ran the general-depth (layer-by-layer) path, 16 = with its last layer on the fused
+ *   kernels ("train_fused_tail").
  * Unknown keys fail. */
 #define ALIGNNET_KERNEL_POINTNET_FUSED 1            /* pointnet_fused<128>: run-time widths */
 #define ALIGNNET_KERNEL_POINTNET_FUSED_64_128 2     /* pointnet_fused<128, 68, 132> */

@@ -466,15 +466,19 @@ GENERAL_DEPTH = {
 }
 
 
-@pytest.mark.parametrize("case,N,B", [("default_json_like", 100, 6), ("odd_shapes", 128, 5), ("default_json_like", 128, 8)])
-def test_general_depth_backbones_train(gpu_required, case, N, B):
+@pytest.mark.parametrize("case,N,B,tail", [("default_json_like", 100, 6, 1), ("odd_shapes", 128, 5, 1), ("default_json_like", 128, 8, 1),
+                                           ("default_json_like", 100, 6, 0), ("default_json_like", 128, 8, 0)])
+def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     """models/tp8.py:49-59 builds a conv layer per entry of `layer_sizes`, and the reference's configs/default.json:13-15 uses five.
     Stages outside the specialised three-layer shape run the layer-by-layer path (csrc/kernels_train_generic.h): train-mode
     predictions, loss, EMA updates and every gradient against torch autograd (fp64), same criteria as the three-layer tests.
     N = 100 gives 64-row tiles that end inside a tower (B * N = 600 rows) and a partial last tile.
     (Not every instance is comparable at this tolerance: at N = 64, B = 16, seed 9 two pooled maxima of one tower are 1.4e-5 apart --
     the size of the fp32 forward error -- and a swapped arg-max row re-routes a gradient that is 17 % of one weight column; the fp32
-    evaluation of the oracle itself shows the same effect in the other tower.  tools/grad_report_generic.py prints both.)"""
+    evaluation of the oracle itself shows the same effect in the other tower.  tools/grad_report_generic.py prints both.)
+    tail: option "train_fused_tail" -- 1 (default): a stage whose last two widths fit the fused kernels (default_json_like's s2 and
+    embedding) runs only the layers in front of them layer by layer and the last layer on phase 3 / pass B2 with given features
+    (last_train_kernel bit 16); 0: every layer layer by layer.  Both against the same oracle at the same tolerances."""
     cfg = small_cfg(N=N, nb=12, fc=(64, 32), **GENERAL_DEPTH[case])
     cfg["training"]["batch_size"] = B
     spec, P32 = oracle_params(cfg, seed=9)
@@ -483,9 +487,12 @@ def test_general_depth_backbones_train(gpu_required, case, N, B):
     du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
+    assert eng.get_option("train_fused_tail") == 1
+    eng.set_option("train_fused_tail", tail)
     ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     assert eng.get_option("last_train_kernel") & 8, "the general-depth path did not run"
+    assert bool(eng.get_option("last_train_kernel") & 16) == (tail == 1 and case == "default_json_like"), eng.get_option("last_train_kernel")
     for k in ep_ref:
         np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
     assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
@@ -497,6 +504,34 @@ def test_general_depth_backbones_train(gpu_required, case, N, B):
     # and a full optimiser step on it
     r = eng.train_step(d["pcs1"], d["pcs2"], d)
     assert r["step"] == 1 and np.isfinite(r["loss"])
+    eng.close()
+
+
+def test_fused_tail_option_switches_in_place(gpu_required):
+    """"train_fused_tail" changes how the training workspace is carved: switching it on a live engine re-carves on the next step, and
+    the two settings agree with each other to summation-order noise (same parameters, same batch, same dropout uniforms)."""
+    cfg = small_cfg(N=128, nb=12, fc=(64, 32), **GENERAL_DEPTH["default_json_like"])
+    cfg["training"]["batch_size"] = 8
+    spec, P32 = oracle_params(cfg, seed=11)
+    d = R.synth_pairs(8, 128, seed=11, dtype=np.float32)
+    rng = np.random.default_rng(11)
+    us = [rng.uniform(size=(8, 32)).astype(np.float32) for _ in range(5)]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    out = {}
+    for tail in (1, 0, 1):
+        eng.set_variables(P32)
+        eng.set_option("train_fused_tail", tail)
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+        assert bool(eng.get_option("last_train_kernel") & 16) == bool(tail)
+        g = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
+        if tail in out:
+            np.testing.assert_array_equal(out[tail][1], g)   # back on the first setting: bit-identical
+        out[tail] = (res["loss"], g)
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * max(1.0, abs(out[0][0]))
+    err = np.abs(out[0][1] - out[1][1]).max() / np.abs(out[0][1]).max()
+    print("fused tail vs layer by layer: loss %.7f / %.7f, worst gradient difference %.2e of the largest entry" % (out[1][0], out[0][0], err))
+    assert err <= 5e-5
     eng.close()
 
 
