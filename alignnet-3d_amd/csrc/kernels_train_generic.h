@@ -12,7 +12,7 @@
 //              -> max over the points of relu(bn(Z_L)) with the arg-max row (tf_util.py:350-373).
 //   backward   dY_L scattered from the pooled gradient -> per layer, last to first:
 //              g = dY [y > 0];  dbeta = sum g, dgamma = sum g zhat;  dZ = k (g - dbeta/M - zhat dgamma/M)   (in place)
-//              dW_l = relu(bn(Z_{l-1}))^T dZ_l   (gen_gemm_dw: per-slab partials, summed in a fixed order)
+//              dW_l = relu(bn(Z_{l-1}))^T dZ_l   (gen_gemm_dw: per-slab partials, summed in a fixed order by reduce_slices_kernel)
 //              dY_{l-1} = dZ_l W_l^T             (gen_gemm_dx)
 //              first layer: per-cloud S = sum dZ_1, P = x'^T dZ_1 give dW_1 and the frame gradients gx / grot.
 // Biases in front of a BatchNorm get an exactly-zero gradient, as in the specialised path.
@@ -521,16 +521,6 @@ __global__ __launch_bounds__(kGenWaves * 64) void gen_gemm_dw(const GenDwArgs a)
       }
     }
   }
-}
-
-// out[e] = sum over the S partials (fixed order, fp64 accumulator)
-__global__ void gen_sum_partials(const float* __restrict__ part, int S, size_t n, float* __restrict__ out)
-{
-  const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  double s = 0.0;
-  for (int i = 0; i < S; ++i) s += part[(size_t)i * n + e];
-  out[e] = (float)s;
 }
 
 // ---- first layer backward.  Per cloud: S[c] = sum_n dZ1[n, c], P[d][c] = sum_n x'[n, d] dZ1[n, c]  (the cloud's share of dW_1), then
