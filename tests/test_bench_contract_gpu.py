@@ -1,0 +1,62 @@
+"""The driver's contract for bench.py: one JSON line on stdout with the agreed keys, the roofline and cpu_baseline objects, and
+internally consistent numbers (value = pairs / time).  Short runs -- this checks the line, not the speed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _run(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def _check_common(d, steps, warmup):
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    pairs = d["config"]["pairs_per_gpu"]
+    assert abs(d["value"] - pairs / (d["ms_per_step"] * 1e-3)) <= 2e-3 * d["value"]          # value = pairs / time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0.0 < r["frac"] < 1.0
+
+
+def test_default_line(gpu_required):
+    """`python bench.py` (inference headline, BASELINE.json configs[1]) with its secondary legs and the CPU baseline."""
+    d = _run("--steps", "10", "--warmup", "2", "--min-leg-seconds", "0.05")
+    _check_common(d, 10, 2)
+    assert d["dtype"] == "f32" and "N=1024" in d["metric"] and d["config"]["num_points"] == 1024 and d["config"]["pairs_per_gpu"] == 256
+    assert d["roofline"]["kernel"] == "pointnet_fused" and d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0.5
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["train"]["dtype"] == "f32" and d["train"]["bf16"]["dtype"] == "bf16" and d["train"]["bf16"]["value"] > d["train"]["value"]
+    assert d["pcie_inclusive"]["value"] < d["value"] * 1.05 and d["infer_bf16x3"]["max_abs_diff_vs_exact_fp32_outputs"] < 1e-4
+
+
+@pytest.mark.parametrize("args,kernel", [(("--mode", "train", "--train-dtype", "bf16"), "train_bwd_b2"),
+                                         (("--workload", "dgcnn", "--batch", "32", "--points", "1024"), "dgcnn_fused"),
+                                         (("--workload", "dgcnn", "--mode", "train", "--train-dtype", "bf16", "--batch", "32", "--points", "512"), "dg_train_bwd_edge")])
+def test_other_lines(gpu_required, args, kernel):
+    d = _run(*args, "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    _check_common(d, 5, 1)
+    assert d["roofline"]["kernel"].startswith(kernel), d["roofline"]["kernel"]
