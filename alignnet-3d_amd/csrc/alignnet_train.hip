@@ -985,7 +985,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
                        G(h, w, L[1]->p_w));
   };
-  const int sG = std::max(1, 256 / C1);
+  const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
   if (dg || fwd_gram)   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
     launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), w->s1),
                         rjob(S.s1e, 1, (long)(C1), w->m1, (float)(1.0 / Me)));

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool live = col < kC2;
   double db = 0.0, dg = 0.0, s1c = 0.0;
+  double s1v[4] = {0.0, 0.0, 0.0, 0.0};   // bf16, !ACCUM: column sums of the rounded h1 straight from the lift (columns c0 + 32 j, row group tid >> 5)
 
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
@@ -141,8 +142,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
     B2_STAMP(1);
     if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
+      float cst[4] = {0.f, 0.f, 0.f, 0.f};
       layer1_to_lds_bf16_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, reinterpret_cast<unsigned short*>(X + kTT * ld0), ld0h, K16a,
-                                nvalid, tid);
+                                nvalid, tid, &cst);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s1v[j] += (double)cst[j];
       __syncthreads();
     } else {
     layer1_to_lds_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, X, ld0, nvalid, tid);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int r = 0; r < kTT; r += 2) g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], g, 0, 0, 0);
       tile_commit(my_g1, kC1, it, jt, kC1, kC1, g, lane, old);
     }
-    if (!GIVEN && a.s1_part && tid < sG * kC1) {   // column sums of h1 (only when the forward did not keep them): sG row groups x C1 columns
+    if (!GIVEN && !(BF16 && !ACCUM) && a.s1_part && tid < sG * kC1) {   // column sums of h1 (only when the forward did not keep them): sG row groups x C1 columns
       const int c = tid % kC1, g = tid / kC1;
       float sm = 0.f;
       if (BF16 && !ACCUM) {   // the column sums of the rounded h1: what the bf16 products of passes B2 / B1 see
@@ -362,7 +366,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * kC2 + col) * 2;   // slice (half)
     d[0] = db; d[1] = dg;
   }
-  if (!GIVEN && a.s1_part && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
+  if (!GIVEN && BF16 && !ACCUM && a.s1_part) {   // [cloud][8 row groups][C1]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (tid & 31) + 32 * j;
+      if (c < kC1) a.s1_part[((size_t)cloud * 8 + (tid >> 5)) * kC1 + c] = s1v[j];
+    }
+  } else if (!GIVEN && a.s1_part && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------

@@ -197,21 +197,28 @@ __device__ __forceinline__ void layer1_to_lds_global(const float* __restrict__ x
 // only as the A operand of the bf16 hidden layer (and for its column sums), so the fp32 tile + conversion pass + barrier are not needed
 __device__ __forceinline__ void layer1_to_lds_bf16_global(const float* __restrict__ xs, const float* __restrict__ w1, int C1,
                                                           const float* __restrict__ sc, const float* __restrict__ sh,
-                                                          unsigned short* __restrict__ out16, int ldh, int K16, int nvalid, int tid)
+                                                          unsigned short* __restrict__ out16, int ldh, int K16, int nvalid, int tid,
+                                                          float (*csum)[4] = nullptr)
 {
+  // csum: the thread's share of the tile's column sums of the ROUNDED h1 -- columns c0 + 32 j, rows r0 + 8 rr -- added up as the values
+  // are produced (a separate pass over the tile was 16 dependent LDS reads per thread, 1.5 k cycles per tile in pass B2)
   constexpr int kRowsPerPass = kTW * 2;
   const int c0 = tid & 31, r0 = tid >> 5;
   for (int c = c0; c < K16; c += 32) {
     const bool live = c < C1;
     const float w0 = live ? w1[c] : 0.f, wa = live ? w1[C1 + c] : 0.f, wb = live ? w1[2 * C1 + c] : 0.f;
     const float s = live ? sc[c] : 0.f, t = live ? sh[c] : 0.f;
+    float cs = 0.f;
 #pragma unroll
     for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
       const int row = rr * kRowsPerPass + r0;
       const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
       const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
-      out16[row * ldh + c] = (row < nvalid && live) ? to_bf16_bits(fmaxf(fmaf(acc, s, t), 0.f)) : (unsigned short)0;
+      const unsigned short hb = (row < nvalid && live) ? to_bf16_bits(fmaxf(fmaf(acc, s, t), 0.f)) : (unsigned short)0;
+      out16[row * ldh + c] = hb;
+      cs += __uint_as_float((unsigned)hb << 16);
     }
+    if (csum) (*csum)[(c - c0) >> 5] = cs;
   }
 }
 
