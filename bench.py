@@ -14,8 +14,9 @@ Prints ONE JSON line (rank 0).  Every timed leg (headline, `infer_bf16x3`, `trai
 object: dominant kernel = the timed kernel with the largest HIP-event time inside that leg's timed region (events on the
 engine's own stream, alignnet_profile_read_kernel); achieved = the FLOPs that kernel's algorithm executes per step
 (`kernel_macs`) / its event time; peak = 157.3 TFLOP/s fp32 MFMA or 2500 TFLOP/s dense bf16 MFMA
-(MI355X_MICROARCH.md); traffic = HBM bytes of that kernel per step from the committed rocprofv3 PMC summary of the same
-command (profiles/r*_<leg>_pmc_traffic.json, separate --pmc passes, FETCH_SIZE doubled as the guide prescribes), else null.
+(MI355X_MICROARCH.md); traffic = HBM bytes of that kernel per launch (traffic_per_step: per step) from the committed rocprofv3 PMC
+summary of the same command (profiles/r*_<leg>_pmc_traffic.json, separate --pmc passes, FETCH_SIZE doubled as the guide prescribes;
+taken at the batch size of tools/refresh_profiles.sh's line for that leg), else null.
   pcie_inclusive  the reference's own methodology (train.py:447-449 times sess.run including the feed copy): pageable
                   host buffers in, host buffers out, blocking alignnet_forward.  Never the headline `value`.
   cpu_baseline    the oracle ("port": unfused op-by-op NumPy fp32 restatement, eval mode, batch 32 as the reference's
@@ -313,7 +314,9 @@ def main():
         prof_name = backbone_name if name == "backbone" else KERNEL_IN_PROFILE.get(name, name)
         tr = pmc_traffic(leg_tag, prof_name)
         r = {"bound": "mfma" if name != "knn" else "valu", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-             "frac": None if ach is None else round(ach / peak, 4), "traffic": None if tr is None else tr["bytes_per_step"],
+             "frac": None if ach is None else round(ach / peak, 4),
+             # HBM bytes of this kernel from the committed PMC passes ((2 FETCH_SIZE + WRITE_SIZE) KiB), per launch like `achieved`'s work
+             "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_per_step": None if tr is None else tr["bytes_per_step"],
              "kernel": prof_name, "launches_per_step": launches / steps, "kernel_ms_per_step": round(ms_step, 4),
              "avg_launch_us": round(ms / max(launches, 1) * 1e3, 2), "algorithmic_flops_per_step": flops,
              "step_share": {k: round(v[0] / steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
