@@ -418,7 +418,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     auto l2_item = [&](const int q2, const int item) {
       const int ct = item >> 1, rg = item & 1;
       f32x16 acc[1];
-      if (BF16)
+      if (BF16 && C1T != 0)   // every weight fragment requested up front: with the one-deep lookahead each of the four 32-cycle k-groups
+                              // waited for its own L2 round trip (layer 2: 4.4 k cycles per tile).  (Run-time widths: eight fragments, 66 spills.)
+        mfma_rows_bf16_all<1>(reinterpret_cast<const unsigned short*>(buf0) + rg * 32 * ld0h, ld0h,
+                              reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, acc);
+      else if (BF16)
         mfma_rows_bf16<1>(reinterpret_cast<const unsigned short*>(buf0) + rg * 32 * ld0h, ld0h,
                           reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, acc);
       else
