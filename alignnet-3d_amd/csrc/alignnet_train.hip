@@ -420,13 +420,15 @@ static int pack_all_weights(alignnet_handle* h)
     PackBf16Jobs pj{};
     int nj = 0;
     for (int s = 0; s < 3; ++s) {
-      if (stage_generic(h, s)) continue;   // the general-depth path computes in fp32 whatever the option says
-      const Layer& L = h->layers[conv_of(h, s).first + 2];
+      if (stage_generic(h, s) && !stage_hybrid(h, s)) continue;   // the layer-by-layer path computes in fp32 whatever the option says
+      const Stack& cst = conv_of(h, s);
+      const Layer& L = h->layers[cst.first + cst.n - 1];   // (hybrid stages: only the last layer, their fused tail, takes bf16 operands)
       const size_t n = (size_t)((L.cout + 31) / 32) * ((L.cin + 15) / 16) * 512;   // per tower
       if (!w->wp3h[s]) HIP_TRY(h, hipMalloc(&w->wp3h[s], 2 * n * sizeof(unsigned short)));
       for (int t = 0; t < 2; ++t) {
         pj.src[nj] = P(h, L.p_w); pj.gamma[nj] = P(h, L.p_bn[t][1]); pj.dst[nj] = w->wp3h[s] + t * n; pj.K[nj] = L.cin; pj.C[nj] = L.cout; ++nj;
       }
+      if (stage_hybrid(h, s)) continue;
       const Layer& L2 = h->layers[conv_of(h, s).first + 1];   // hidden layer: one image, no sign folding
       const size_t n2 = (size_t)((L2.cout + 31) / 32) * ((L2.cin + 15) / 16) * 512;
       if (!w->wp2h[s]) HIP_TRY(h, hipMalloc(&w->wp2h[s], n2 * sizeof(unsigned short)));
@@ -667,9 +669,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     for (int t = 0; t < 2; ++t)
       hipLaunchKernelGGL(sign_kernel, dim3((C3 + 255) / 256), dim3(256), 0, h->stream, P(h, L[2]->p_bn[t][1]), C3, S.sgn3 + (size_t)t * C3);
   }
+  // bf16 operands for the fused tail on given features (its staging loop needs 256 % (C2 / 4) == 0: C2 = 32, 64, 128)
+  const bool tail_bf16 = h->train_bf16 && (dg || (hyb && 256 % (C2 / 4) == 0));
   if (dg || hyb) {
     // point conv on the stored features (DGCNN: p = max_k h2; hybrid: the output of the layer-by-layer part)
-    if (h->train_bf16 && dg) {
+    if (tail_bf16) {
       // bf16 operands (p rounded while it is staged, the sign-folded bf16 image of W3); Gram(p) and the column sums of the rounded p
       // come out of the same pass (1024 / C2 row-group slices per cloud)
       a.wp3h = w->wp3h[s];
@@ -752,7 +756,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   {   // centred Gram of h2 + pooled features: independent of each other, one launch
     const size_t tot = (size_t)2 * B * C3;
     const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
-                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && !hyb) ? 1 : 0};
+                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && (!hyb || tail_bf16)) ? 1 : 0};
     hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
                        S.gram2, S.s2, C2, count, S.m2, pa);
   }

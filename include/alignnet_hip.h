@@ -240,7 +240,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "train_matmul_bf16" (0/1, default 0): training only -- the two MFMA convs of every backbone (the hidden 1x1 conv
  *   and the -> C3 feature lift, 96 % of the step's FLOPs, models/tp8.py:55-57), in the forward and in the backward's
  *   recompute, run on bf16 MFMA with fp32 accumulation (BASELINE.json configs[2]); statistics, pooling, the K = 3 lift,
- *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.  With the dgcnn backbone: the edge
+ *   the heads, gradient accumulation, optimiser state and the eval-mode forward stay fp32.  Backbones outside the fused shape: only
+ *   the last conv, when it runs as the fused tail ("train_fused_tail").  With the dgcnn backbone: the edge
  *   conv behind the K = 6 lift and the point conv (forward), and the dense product h1 Q2 of the backward edge pass.
  * "train_fused_tail" (0/1, default 1): training of backbones outside the fused kernels' shape (depth != 3, odd widths; e.g. the
  *   five-layer backbones of configs/default.json): the layers up to the second-to-last run layer by layer, their output is kept once,

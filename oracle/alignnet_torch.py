@@ -79,13 +79,26 @@ class TorchTp8:
             z = self._bn(z, bnbase, training, decay)
         return torch.relu(z) if act else z
 
+    @staticmethod
+    def bf16_conv_layers(widths):
+        """Which conv layers of a PointNet backbone the engine runs on bf16 MFMA under "train_matmul_bf16" (alignnet_train.hip:
+        stage_generic / stage_hybrid): every layer behind the K = 3 lift of a stage in the fused kernels' shape (three layers, widths in
+        multiples of 32, C1, C2 <= 128, C3 <= 1024); of any other stage only the last layer, when it runs as the fused tail
+        (last two widths in multiples of 32, <= 128 / <= 1024, first width <= 128) and its input width is 32, 64 or 128; else none."""
+        n = len(widths)
+        if n == 3 and all(c % 32 == 0 for c in widths) and widths[0] <= 128 and widths[1] <= 128 and widths[2] <= 1024:
+            return {1, 2}
+        if n >= 3 and widths[0] <= 128 and widths[0] % 8 == 0 and widths[-2] in (32, 64, 128) and widths[-1] % 32 == 0 and widths[-1] <= 1024:
+            return {n - 1}
+        return set()
+
     def _pointnet(self, x, scope, widths, tower, training, decay):
         B, N, _ = x.shape
         h = x.reshape(B * N, -1)
+        rounded = self.bf16_conv_layers(list(widths)) if (self.bf16_lift and training) else set()
         for i in range(len(widths)):
             nm = f"{scope}/conv{i+1}"
-            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
-                            round_operands=self.bf16_lift and training and i >= 1)
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay, round_operands=i in rounded)
         return h.reshape(B, N, -1).amax(dim=1)
 
     def _dgcnn(self, x, scope, widths, tower, training, decay):

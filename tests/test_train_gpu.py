@@ -510,6 +510,57 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     eng.close()
 
 
+def test_general_depth_bf16_tail_matches_rounded_oracle(gpu_required):
+    """"train_matmul_bf16" on general-depth backbones (default.json's five-layer s2 / embedding; four layers in s1): they take bf16
+    operands only in their last layer -- the fused tail (phase 3 on given features with the
+    features rounded while they are staged); the layers in front of it and the whole tail backward stay fp32.  The oracle rounds
+    exactly those layers (TorchTp8.bf16_conv_layers).  Criteria of the other bf16 tests: batch statistics of the rounded last layer
+    to 1e-4 of their scale and >= 10x closer than the fp32 step, loss within 1e-2 (5e-2 with decode flips; three tails in a row
+    feed each other's inputs here), gradient cosine >= 0.97 (0.85) and >= 3x closer (1 - cos) than the fp32 step's."""
+    B, N = 16, 128
+    # (stage 1 is given four layers here so that a fused tail sees inputs identical to the oracle's: stages 2 and 3 start from
+    #  stage 1's predicted centre / decoded yaw, which already carry the bf16 difference)
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), s1=(16, 32, 64, 128), s2=(32, 32, 32, 64, 128), emb=(32, 32, 32, 64, 160))
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=13)
+    d = R.synth_pairs(B, N, seed=13, dtype=np.float32)
+    rng = np.random.default_rng(13)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    stats = ["siamese/transformer1/embedding/conv4/bn/moving_mean", "siamese_1/transformer1/embedding/conv4/bn/moving_var"]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    res32 = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    ema32 = {k: eng.get_variable(k) for k in stats}
+    g32 = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
+    eng.set_variables(P32)
+    eng.set_option("train_matmul_bf16", 1)
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert eng.get_option("last_train_kernel") & 26 == 26   # bf16 operands, general depth, fused tail
+    assert res["loss"] != res32["loss"]
+    for k in stats:
+        got, ref = eng.get_variable(k), ema_ref[k]
+        e16, e32 = float(np.abs(got - ref).max()), float(np.abs(ema32[k] - ref).max())
+        print(k, "err vs rounded oracle %.2e (fp32 step: %.2e), scale %.2e" % (e16, e32, np.abs(ref).max()))
+        assert e16 <= 1e-4 * np.abs(ref).max() and e16 < 0.1 * e32, (k, e16, e32)
+    nb = spec.num_bins
+    flipped = np.zeros(B, bool)
+    for k in ("pred_pc1angle_logits", "pred_pc2angle_logits"):
+        flipped |= np.argmax(res[k][:, :nb], 1) != np.argmax(ep_ref[k][:, :nb], 1)
+    clean = not flipped.any()
+    print("decode flips:", int(flipped.sum()), "loss", res["loss"], loss_ref, "fp32 step's", res32["loss"])
+    assert flipped.sum() <= max(1, B // 8)
+    assert abs(res["loss"] - loss_ref) <= (1e-2 if clean else 5e-2) * max(1.0, abs(loss_ref))
+    g = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in R.trainable_names(spec)])
+    gr = np.concatenate([np.asarray(grads[n], np.float64).ravel() for n in R.trainable_names(spec)])
+    cos = float(g @ gr / (np.linalg.norm(g) * np.linalg.norm(gr)))
+    cos32 = float(g32 @ gr / (np.linalg.norm(g32) * np.linalg.norm(gr)))
+    print("gradient cosine vs the rounded oracle: %.4f (fp32 step's: %.4f)" % (cos, cos32))
+    assert cos > (0.97 if clean else 0.85) and (1 - cos) < (0.3 if clean else 0.7) * (1 - cos32), (cos, cos32)
+    eng.close()
+
+
 def test_fused_tail_option_switches_in_place(gpu_required):
     """"train_fused_tail" changes how the training workspace is carved: switching it on a live engine re-carves on the next step, and
     the two settings agree with each other to summation-order noise (same parameters, same batch, same dropout uniforms)."""
