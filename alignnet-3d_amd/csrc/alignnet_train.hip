@@ -468,6 +468,8 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, true, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b2<false, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -902,7 +904,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
   const double M = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
-  const bool given = dg || hyb;   // pass B2 on stored features, fp32
+  const bool given = dg || hyb;   // pass B2 on stored features
+  const bool given_bf16 = given && h->train_bf16 && 256 % (C2 / 4) == 0;   // ... with h2 Q3 on bf16 MFMA (same rule as the forward tail)
   const double Me = dg ? M * kDgK : M;   // rows behind the statistics of layers 1 and 2 (DGCNN: the B*N*k edge rows)
   const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
   auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
@@ -924,7 +927,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // Q3[t] = W3 (W3E[t])^T
   launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
   const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
-  if (h->train_bf16 && !given) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
+  if (h->train_bf16 && (!given || given_bf16)) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
@@ -954,7 +957,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.h2_given = S.h2;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   { ProfScope prof_scope(h, PK_TRAIN_B2);
-  if (given && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  if (given_bf16 && std_w) hipLaunchKernelGGL((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (given_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  else if (given && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (given) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (std_w && !b2_accum && h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (std_w && !b2_accum) hipLaunchKernelGGL((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);

@@ -128,7 +128,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     const bool first = tile == 0;
     __syncthreads();
     B2_STAMP(0);
-    if (GIVEN) {
+    if (GIVEN && BF16) {
+      // bf16 mode on given features: the tile is staged as the bf16 A operand of h2 Q3 only (the Y region takes the fp32 dy2 later);
+      // the epilogue reads the fp32 features it needs (mask, zhat) straight from memory
+      const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
+      unsigned short* Yh = reinterpret_cast<unsigned short*>(Y);
+      const int c4 = kC2 >> 2;
+      for (int i = tid; i < kTT * c4; i += kTW * 64) {
+        const int row = i / c4, q = i % c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kC2 + q * 4);
+        uint2 pk;
+        pk.x = (unsigned)to_bf16_bits(v[0]) | ((unsigned)to_bf16_bits(v[1]) << 16);
+        pk.y = (unsigned)to_bf16_bits(v[2]) | ((unsigned)to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2*>(Yh + row * ldbh + q * 4) = pk;
+      }
+    } else if (GIVEN) {
       const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c4 = kC2 >> 2;
       for (int i = tid; i < kTT * c4; i += kTW * 64) {
@@ -283,6 +298,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
+      float pgv[(GIVEN && BF16) ? 32 : 1];
+      if (GIVEN && BF16) {   // requested in front of the MFMAs, used behind them
+        const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2 + col;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(m, r, lane);
+            pgv[m * 16 + r] = (live && row < nvalid) ? src[(size_t)row * kC2] : 0.f;
+          }
+        asm volatile("" ::: "memory");
+      }
       if (BF16)
         mfma_rows_bf16_all<2, false>(reinterpret_cast<const unsigned short*>(Y), ldbh,
                                      reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (GIVEN) {
-            const float p = live ? Y[acc_row(m, r, lane) * ldb + col] : 0.f;
+            const float p = (GIVEN && BF16) ? pgv[(m * 16 + r) % ((GIVEN && BF16) ? 32 : 1)] : (live ? Y[acc_row(m, r, lane) * ldb + col] : 0.f);
             z2[m][r] = p > 0.f ? (p - sh) * isc : -INFINITY;   // the pre-BN accumulator at the arg-max slot (only used where p > 0)
           }
           const bool on = acc_row(m, r, lane) < nvalid && (GIVEN ? z2[m][r] != -INFINITY : fmaf(z2[m][r], sc, sh) > 0.f);
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(9);
     // ---- store dy2 (coalesced rows) and U2 += h1^T dy2 ----
     {
-      if (BF16) {   // dy2 travels to pass B1 as bf16 in this mode (half the 268 MB per stage)
+      if (BF16 && !GIVEN) {   // dy2 travels to pass B1 as bf16 in this mode (half the 268 MB per stage)
         unsigned short* dsth = reinterpret_cast<unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
         const int c8 = kC2 >> 3;
         for (int i = tid; i < nvalid * c8; i += kTW * 64) {
