@@ -513,7 +513,7 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
 def test_general_depth_bf16_tail_matches_rounded_oracle(gpu_required):
     """"train_matmul_bf16" on general-depth backbones (default.json's five-layer s2 / embedding; four layers in s1): they take bf16
     operands only in their last layer -- the fused tail (phase 3 on given features with the
-    features rounded while they are staged); the layers in front of it and the whole tail backward stay fp32.  The oracle rounds
+    features rounded while they are staged; pass B2 on given features with its dense product on bf16); the layers in front of it stay fp32.  The oracle rounds
     exactly those layers (TorchTp8.bf16_conv_layers).  Criteria of the other bf16 tests: batch statistics of the rounded last layer
     to 1e-4 of their scale and >= 10x closer than the fp32 step, loss within 1e-2 (5e-2 with decode flips; three tails in a row
     feed each other's inputs here), gradient cosine >= 0.97 (0.85) and >= 3x closer (1 - cos) than the fp32 step's."""
