@@ -453,6 +453,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.mark(h->cfg.device);
   }
   const int TP = infer_tile_pts();
   // tiles per workgroup: as many as still leave every CU several workgroups (the pooled max is published once per workgroup)
@@ -476,10 +477,10 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
     static PerDeviceOnce sattr;
-    if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+    if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
     if (sc1 == 64 && sc2 == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
       static PerDeviceOnce sattr;
-      if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+      if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
       hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_64_128;
     } else {
@@ -540,6 +541,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
   static PerDeviceOnce attr_set;
   if (attr_set.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.mark(h->cfg.device);
   }
   const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
   {
@@ -558,10 +560,10 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       if (a.k > 3 * kWaves) return fail(h, "dgcnn split kernel: k limited to 24 neighbours");
       const size_t dlds = (size_t)2 * kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);
       static PerDeviceOnce dsattr;
-      if (dsattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+      if (dsattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr.mark(h->cfg.device); }
       if (dca == 64 && dcb == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
         static PerDeviceOnce dsattr2;
-        if (dsattr2.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+        if (dsattr2.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2.mark(h->cfg.device); }
         hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT_64_128;
       } else {
@@ -573,7 +575,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
       if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
         static PerDeviceOnce sattr;
-        if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+        if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
         hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED_64_128;
       } else {
@@ -664,7 +666,8 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   return 0;
 }
 
-static int drain_profile(alignnet_handle* h)
+// (also called from alignnet_train.hip: a long profiled training loop must not grow prof_pending / create events without bound)
+int alignnet_drain_profile(alignnet_handle* h)
 {
   if (!h->prof) return 0;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -691,7 +694,7 @@ extern "C" int alignnet_forward_device(alignnet_handle* h, const float* d_pcs1, 
   float* outs[8] = {d_out->pred_translations, d_out->pred_remaining_angle_logits, d_out->pred_s1_pc1centers,
                     d_out->pred_s1_pc2centers, d_out->pred_s2_pc1centers, d_out->pred_s2_pc2centers,
                     d_out->pred_pc1angle_logits, d_out->pred_pc2angle_logits};
-  if (h->prof_pending.size() > 4096 && drain_profile(h)) return 1;
+  if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;
   return forward_device(h, d_pcs1, d_pcs2, B, outs);
 }
 
@@ -714,7 +717,7 @@ extern "C" int alignnet_forward(alignnet_handle* h, const float* pcs1, const flo
   for (int i = 0; i < 8; ++i)
     if (host[i]) HIP_TRY(h, hipMemcpyAsync(host[i], w.outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return drain_profile(h);
+  return alignnet_drain_profile(h);
 }
 
 // test hook: the kNN graph [2B][N][20] (tower 1's B clouds, then tower 2's) built by the last eval-mode forward of a dgcnn engine
@@ -748,6 +751,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   const std::string k(key);
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
   if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
+  if (k == "dropout_stream") { h->dropout_stream = (uint64_t)value; return 0; }
   if (k == "train_fused_tail") {
     if (h->fused_tail != (value != 0)) h->train_ws_stale = true;   // the workspace is carved per setting
     h->fused_tail = value != 0;
@@ -768,6 +772,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
   if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
   if (k == "allreduce_overlap") { *value = h->comm_overlap ? 1 : 0; return 0; }
+  if (k == "dropout_stream") { *value = (int64_t)h->dropout_stream; return 0; }
   if (k == "comm_world") { *value = h->comm ? h->comm_world : 0; return 0; }
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }
   if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
@@ -782,7 +787,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
 extern "C" int alignnet_profile_enable(alignnet_handle* h, int32_t on)
 {
   if (!h) return 1;
-  if (drain_profile(h)) return 1;
+  if (alignnet_drain_profile(h)) return 1;
   h->prof = on != 0;
   return 0;
 }
@@ -791,7 +796,7 @@ extern "C" int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, in
                                      int32_t reset)
 {
   if (!h) return 1;
-  if (drain_profile(h)) return 1;
+  if (alignnet_drain_profile(h)) return 1;
   if (backbone_ms) *backbone_ms = h->prof_backbone_ms;
   if (backbone_launches) *backbone_launches = h->prof_backbone_launches;
   if (total_ms) *total_ms = h->prof_total_ms;
@@ -805,7 +810,7 @@ extern "C" int alignnet_profile_read(alignnet_handle* h, double* backbone_ms, in
 extern "C" int alignnet_profile_read_kernel(alignnet_handle* h, const char* name, double* ms, int64_t* launches)
 {
   if (!h || !name) return 1;
-  if (drain_profile(h)) return 1;
+  if (alignnet_drain_profile(h)) return 1;
   for (int i = 0; i < PK_COUNT; ++i)
     if (std::strcmp(name, kProfKernelNames[i]) == 0) {
       if (ms) *ms = h->prof_ms[i];

@@ -161,6 +161,7 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
   static alignnet::PerDeviceOnce attr;
   if (attr.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+    attr.mark(h->cfg.device);
   }
   hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 12, h->stream, a);
   HIP_TRY(h, hipGetLastError());

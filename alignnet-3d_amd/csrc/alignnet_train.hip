@@ -480,6 +480,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done.mark(h->cfg.device);
   return 0;
 }
 
@@ -493,12 +494,13 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
   StageWS& S = w->st[s];
   TrainWS::GenStage& Gs = w->gen[s];
   const Stack& st = conv_of(h, s);
-  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
+  const int N = h->cfg.num_points, M = B * N, tiles = (M + kGenTile - 1) / kGenTile;   // of THIS call's batch (gen_part is sized for the workspace capacity, w->gen_tiles)
   static PerDeviceOnce attr;
   if (attr.need(h->cfg.device)) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr.mark(h->cfg.device);
   }
   hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
   const bool partial = nl >= 0;
@@ -536,7 +538,7 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B, float* given_d
   StageWS& S = w->st[s];
   TrainWS::GenStage& Gs = w->gen[s];
   const Stack& st = conv_of(h, s);
-  const int N = h->cfg.num_points, M = B * N, tiles = w->gen_tiles;
+  const int N = h->cfg.num_points, M = B * N, tiles = (M + kGenTile - 1) / kGenTile;   // of THIS call's batch (gen_part is sized for the workspace capacity, w->gen_tiles)
   const size_t R = (size_t)2 * M;
   const int Ll = st.n - 1, Cl = h->layers[st.first + Ll].cout;
   float* dY = given_dY ? given_dY : w->gen_d[0];
@@ -791,7 +793,7 @@ static BnRowsArgs bn_args(alignnet_handle* h, TrainWS* w, int s, int j, int M, i
     if (s < 2) { a.u = u_dev + (size_t)s * blk; a.u_set_stride = 2 * (long)blk; }
     else { a.u = u_dev + 4 * (size_t)rows_per_set * h->layers[fc_of(h, 0).first + fc_of(h, 0).n - 2].cout; a.u_set_stride = 0; }
   }
-  a.seed = h->cfg.seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->step * 16 + s * 4;
+  a.seed = h->dropout_seed_base() + s * 4;
   return a;
 }
 
@@ -820,7 +822,7 @@ extern "C" int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, fl
   float* d = nullptr;
   HIP_TRY(h, hipMalloc(&d, n * sizeof(float)));
   hipLaunchKernelGGL(dropout_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, B, w1, w3,
-                     h->cfg.seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->step * 16);
+                     h->dropout_seed_base());
   hipError_t e = hipMemcpyAsync(dst, d, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   hipFree(d);
@@ -1147,6 +1149,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   alignnet_get_state(h, &stt);
   const float bn_decay = stt.bn_decay;
   if (set_lds_attrs(h)) return 1;
+  if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;   // (as the eval forward does: ~15 event pairs per profiled step)
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
     for (int s = 0; s < 3; ++s) std_all = std_all && h->layers[conv_of(h, s).first].cout == 64 && h->layers[conv_of(h, s).first + 1].cout == 128;

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <atomic>
 
 #include "../../include/alignnet_hip.h"
 
@@ -59,6 +60,7 @@ struct DatasetTables { const float* pts[2]; const long long* off; long long n; }
 }
 struct alignnet_handle;
 bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out);   // alignnet_dataset.hip; false when none uploaded
+int alignnet_drain_profile(alignnet_handle* h);   // alignnet_api.hip: read back the pending profiling event pairs (synchronises the stream)
 
 struct alignnet_handle {
   alignnet_config cfg;
@@ -82,6 +84,7 @@ struct alignnet_handle {
   alignnet::Workspace ws;
   hipStream_t stream = nullptr;
   int64_t step = 0;
+  uint64_t dropout_stream = 0;     // alignnet_set_option("dropout_stream"): data-parallel ranks draw different dropout masks from one cfg.seed
   // tf.train.AdamOptimizer's beta1_power / beta2_power: float32 variables multiplied by beta once per step (adam.py _finish);
   // cached for `adam_power_t` applied steps so that a step costs one multiplication (alignnet_apply_gradients)
   float adam_b1p = 1.f, adam_b2p = 1.f;
@@ -102,6 +105,8 @@ struct alignnet_handle {
   // training / multi-GPU state (alignnet_train.hip)
   void* train_ws = nullptr;
   void* dataset_ws = nullptr;      // HBM-resident dataset + batch buffers (alignnet_dataset.hip)
+  // seed base of the device-side dropout stream at the current step counter (alignnet_train.hip: bn_args, dropout_uniforms_kernel)
+  uint64_t dropout_seed_base() const { return (cfg.seed + dropout_stream * 0xD1B54A32D192ED03ull) * 0x9E3779B97F4A7C15ull + (uint64_t)step * 16; }
   void* comm = nullptr;
   int comm_world = 1, comm_rank = 0;
   // gradient all-reduce in three buckets (stage 3 | stage 2 | stage 1 segment of the flat gradient) on a side stream, each issued as
@@ -116,15 +121,14 @@ struct alignnet_handle {
 namespace alignnet {
 // hipFuncSetAttribute (dynamic LDS size) applies to the CURRENT device only: every call site remembers per device ordinal whether it
 // has been done, so that a second handle on another GPU of the same process sets its own attributes (a process-global flag skipped them).
+// Usage: `if (once.need(dev)) { ...attribute calls (HIP_TRY returns on failure)...; once.mark(dev); }` -- the bit is set only after
+// every call succeeded, so a failed attempt is retried (and reported) by the next call instead of surfacing later as an opaque
+// LDS-size launch failure.  Atomic: handles on different GPUs may be driven from different threads.  Ordinals >= 64 are never
+// remembered (the attributes are then set on every call, which is harmless).
 struct PerDeviceOnce {
-  unsigned long long done = 0;
-  bool need(int device)
-  {
-    const unsigned long long bit = 1ull << (device & 63);
-    if (done & bit) return false;
-    done |= bit;
-    return true;
-  }
+  std::atomic<unsigned long long> done{0};
+  bool need(int device) const { return device < 0 || device >= 64 || !(done.load(std::memory_order_acquire) & (1ull << device)); }
+  void mark(int device) { if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release); }
 };
 
 // Brackets everything launched on h->stream during its lifetime with one event pair (only while h->prof is set).

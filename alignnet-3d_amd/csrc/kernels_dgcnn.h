@@ -220,9 +220,11 @@ constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t
   const dim3 grid((N + kKnnQueries - 1) / kKnnQueries, 2 * B), block(kKnnWaves * 64);
   static PerDeviceOnce attr_done;
   if (attr_done.need(device)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(16));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(32));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(64));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(16));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(32));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(64));
+    if (e != hipSuccess) return e;
+    attr_done.mark(device);
   }
   if (N <= 1024) hipLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, p1, p2, center, B, N, k, nn);
   else if (N <= 2048) hipLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, p1, p2, center, B, N, k, nn);

@@ -72,7 +72,12 @@ class Run:
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
             self.dist = dist
         import alignnet3d
+        if self.world > 1 and cfg.training.batch_size % self.world:
+            # the engine averages the ranks' gradients with a fixed 1 / world: unequal shards would be weighted equally
+            raise SystemExit("training.batch_size (%d) must be a multiple of the number of ranks (%d)" % (cfg.training.batch_size, self.world))
         self.engine = alignnet3d.Engine(cfg, device=self.local_rank if self.world > 1 else None)
+        if self.world > 1:
+            self.engine.set_option("dropout_stream", self.rank)   # same initialisation on every rank (seed 0), different dropout masks
         MODEL.bind_engine(self.engine)
         # optional, not a reference key: "training": {"matmul_dtype": "bf16"} (or ALIGNNET_TRAIN_BF16=1) runs the widest conv of
         # every backbone on bf16 MFMA during training (engine option train_matmul_bf16; evaluation stays fp32)

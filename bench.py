@@ -114,8 +114,10 @@ KERNEL_IN_PROFILE = {   # bench kernel key -> substring of the kernel name in pr
     "train_bwd_b1": "train_bwd_b1", "dg_train_fwd": "dg_train_fwd", "dg_train_bwd_edge": "dg_train_bwd_edge", "knn": "knn_kernel"}
 
 
-def pmc_traffic(leg_tag, kernel_substr):
-    """HBM bytes per step of one kernel from the newest committed rocprofv3 PMC summary of this leg, or None."""
+def pmc_traffic(leg_tag, kernel_substr, shape):
+    """HBM bytes per step of one kernel from the newest committed rocprofv3 PMC summary of this leg, or None.  `shape` =
+    (pairs per GPU, points per cloud) of the leg being reported: a summary taken at another shape (or one that does not say at
+    which -- rounds 1 / 2) is not quoted."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%spmc_traffic.json" % (leg_tag + "_" if leg_tag else ""))),
                    key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
     files = [f for f in files if re.fullmatch(r"r\d+_%spmc_traffic\.json" % (leg_tag + "_" if leg_tag else ""), os.path.basename(f))]
@@ -123,18 +125,19 @@ def pmc_traffic(leg_tag, kernel_substr):
         return None
     try:
         j = json.load(open(files[-1]))
+        sh = j.get("shape") or {}
+        if (sh.get("pairs_per_gpu"), sh.get("num_points")) != tuple(shape):
+            return None
         for name, v in (j.get("kernels") or {}).items():
             if any(alt in name for alt in kernel_substr.split("|")):
-                return {"bytes_per_step": v["hbm_bytes_per_step"], "bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(files[-1])}
-        if kernel_substr in ("pointnet_fused",) and j.get("backbone_hbm_bytes_per_step"):   # round-1 layout
-            return {"bytes_per_step": j["backbone_hbm_bytes_per_step"], "bytes_per_launch": j.get("backbone_hbm_bytes_per_launch"),
-                    "source": os.path.basename(files[-1])}
+                return {"bytes_per_step": v["hbm_bytes_per_step"], "bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(files[-1]),
+                        "commit": j.get("commit")}
     except Exception:
         return None
     return None
 
 
-def cpu_baseline(cfg, seconds_per_setting=6.0):
+def cpu_baseline(cfg, seconds_per_setting=4.0):
     from oracle import alignnet_ref as R
     from threadpoolctl import threadpool_limits, threadpool_info
     allc = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
@@ -164,6 +167,47 @@ def cpu_baseline(cfg, seconds_per_setting=6.0):
                       f"~{seconds_per_setting:.0f} s per thread setting, forward only (cf. reference train.py:447-449); value = best setting"}
 
 
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def self_launch(n):
+    """Re-execute this command under torch.distributed.run with one rank per GPU (RCCL over xGMI inside the library).
+    Refuses -- non-zero exit, message on stderr -- when the node shows fewer than n GPUs: ranks never share a device."""
+    import socket
+    import subprocess
+    ndev = visible_gpus()
+    if ndev < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible: refusing to share devices (one rank per GPU)\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def sclk_mhz(device):
+    """Current shader clock of one GPU from rocm-smi (None when it cannot be read)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        j = json.loads(out[out.index("{"):])
+        for card in j.values():
+            for k, v in card.items():
+                if "sclk" in k.lower() and "level" in k.lower():
+                    m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+                    if m:
+                        return int(m.group(1))
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +230,13 @@ def main():
                     help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (--mode train: fp32 only)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
     ap.add_argument("--min-leg-seconds", type=float, default=0.35, help="secondary legs are timed for at least this long")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) here instead of silently running one
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import alignnet3d
@@ -227,6 +277,10 @@ def main():
     for name, shp, _ in eng.variables():
         if name.endswith("moving_var"):
             eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
+
+    cpu_info = None
+    if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
+        cpu_info = cpu_baseline(cfg)   # before the GPU legs: they then run back to back at the end of the process
 
     d = synth_pairs(B, npts, seed=1234 + rank, dtype=np.float32)
     p1 = torch.from_numpy(d["pcs1"]).to(dev)
@@ -312,7 +366,7 @@ def main():
         ms_step = ms / steps
         ach = flops / (ms_step * 1e-3) / 1e12 if ms_step > 0 and flops > 0 else None
         prof_name = backbone_name if name == "backbone" else KERNEL_IN_PROFILE.get(name, name)
-        tr = pmc_traffic(leg_tag, prof_name)
+        tr = pmc_traffic(leg_tag, prof_name, (B, npts))
         r = {"bound": "mfma" if name != "knn" else "valu", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": None if ach is None else round(ach / peak, 4),
              # HBM bytes of this kernel from the committed PMC passes ((2 FETCH_SIZE + WRITE_SIZE) KiB), per launch like `achieved`'s work
@@ -321,7 +375,8 @@ def main():
              "avg_launch_us": round(ms / max(launches, 1) * 1e3, 2), "algorithmic_flops_per_step": flops,
              "step_share": {k: round(v[0] / steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
         if tr is not None:
-            r["traffic_source"] = tr["source"]
+            r["traffic_source"] = tr["source"]      # committed rocprofv3 --pmc summary of this same command and shape ...
+            r["traffic_commit"] = tr["commit"]      # ... taken at this commit of the tree (not measured inside this run)
         if on_bf16 and name == "backbone":
             r["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
         return r
@@ -340,6 +395,41 @@ def main():
     else:
         leg_tag = "train_dgcnn" if dg else ("train_bf16" if args.train_dtype == "bf16" else "train")
     head_roof = roofline(kern, args.steps, head_bf16, leg_tag, backbone_kernel)
+
+    # ---- the same step, back to back for >= --sustained-seconds: the K-step region above is a burst of tens of milliseconds; this one
+    #      is long enough for the clocks to settle (sclk sampled from rocm-smi while the queue is full, first and last chunk)
+    sustained = None
+    if args.sustained_seconds > 0:
+        per = max(dt / args.steps, 1e-5)
+        chunk = max(1, int(0.25 / per))
+        clk = [None, None]
+        fence()
+        n_s, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(chunk):
+                step()
+            n_s += chunk
+            if clk[0] is None and rank == 0:
+                clk[0] = sclk_mhz(local_rank) or 0
+            eng.synchronize()
+            last = time.perf_counter() - t0 >= args.sustained_seconds
+            if dist is not None:   # every rank leaves the loop in the same round
+                flag = torch.tensor([1.0 if last else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                last = bool(flag.item() > 0)
+            if last:
+                for _ in range(chunk):
+                    step()
+                n_s += chunk
+                if rank == 0:
+                    clk[1] = sclk_mhz(local_rank)
+                break
+        fence()
+        sdt_all = max_over_ranks(time.perf_counter() - t0)
+        sustained = {"value": round(world * B * n_s / sdt_all, 1), "unit": "pairs/s", "ms_per_step": round(sdt_all / n_s * 1e3, 4), "steps": n_s,
+                     "seconds": round(sdt_all, 2), "sclk_mhz_first_chunk": clk[0] or None, "sclk_mhz_last_chunk": clk[1],
+                     "what": "the headline step back to back (chunks of %d steps, one host synchronisation and two rocm-smi reads in between); "
+                             "`value` of the line stays the K-step figure" % chunk}
 
     # ------------------------------------------------- secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline)
     split_info = None
@@ -440,8 +530,10 @@ def main():
             line["train"] = train_info
         if pcie_info is not None:
             line["pcie_inclusive"] = pcie_info
-        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
-            line["cpu_baseline"] = cpu_baseline(cfg)
+        if sustained is not None:
+            line["sustained"] = sustained
+        if cpu_info is not None:
+            line["cpu_baseline"] = cpu_info
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

@@ -171,9 +171,11 @@ int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t c
  * the current step counter when dropout_u is NULL, in the layout of dropout_u; count = B * (4 * w_hidden + w_pair_hidden).
  * A step run with these uniforms passed explicitly is bit-identical to the step that draws them itself. */
 int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, float* dst, size_t count);
-/* Test hook: the k-nearest-neighbour graph (k = 20, self included, nearest first, ties to the lower index as tf.nn.top_k;
- * utils/tf_util_dgcnn.py:638-676) the last eval-mode forward of a dgcnn engine built: int32 [2B][num_points][20], tower 1's B
- * clouds first.  count = 2 * B * num_points * 20. */
+/* Test hook: the k-nearest-neighbour graph (k = 20, self included; the SET tf.nn.top_k selects, ties at the k-th distance to the
+ * lower index; utils/tf_util_dgcnn.py:638-676) the last eval-mode forward of a dgcnn engine built: int32 [2B][num_points][20],
+ * tower 1's B clouds first.  count = 2 * B * num_points * 20.  Order within a row: nearest first when the query's candidate list
+ * has <= 64 survivors (the usual case); queries with more survivors (clustered / duplicated points) emit their k entries in
+ * point-index order -- the max over the k neighbours is order-invariant, so compare rows as sets (sorted) where that can occur. */
 int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
 
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
@@ -257,6 +259,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient, each issued as soon
  *   as that stage's backward has written it -- so that only the last (smallest) bucket is exposed; 0 = one all-reduce of the whole
  *   vector after the backward.  Same sums either way.
+ * "dropout_stream" (default 0): selects one of 2^64 independent device-side dropout streams under the same cfg.seed; data-parallel
+ *   ranks set it to their rank so that they do not draw identical masks for their local rows (initialisation stays cfg.seed's).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped
  * widths 64 / 128 dispatch to kernels with the widths compiled in):
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;

@@ -41,8 +41,10 @@ def _check_common(d, steps, warmup):
 
 def test_default_line(gpu_required):
     """`python bench.py` (inference headline, BASELINE.json configs[1]) with its secondary legs and the CPU baseline."""
-    d = _run("--steps", "10", "--warmup", "2", "--min-leg-seconds", "0.05")
+    d = _run("--steps", "10", "--warmup", "2", "--min-leg-seconds", "0.05", "--sustained-seconds", "1.0")
     _check_common(d, 10, 2)
+    su = d["sustained"]
+    assert su["seconds"] >= 1.0 and su["steps"] > 10 and 0.7 * d["value"] < su["value"] < 1.2 * d["value"], su
     assert d["dtype"] == "f32" and "N=1024" in d["metric"] and d["config"]["num_points"] == 1024 and d["config"]["pairs_per_gpu"] == 256
     assert d["roofline"]["kernel"] == "pointnet_fused" and d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0.5
     c = d["cpu_baseline"]
@@ -57,6 +59,6 @@ def test_default_line(gpu_required):
                                          (("--workload", "dgcnn", "--batch", "32", "--points", "1024"), "dgcnn_fused"),
                                          (("--workload", "dgcnn", "--mode", "train", "--train-dtype", "bf16", "--batch", "32", "--points", "512"), "dg_train_bwd_edge")])
 def test_other_lines(gpu_required, args, kernel):
-    d = _run(*args, "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    d = _run(*args, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--sustained-seconds", "0")
     _check_common(d, 5, 1)
     assert d["roofline"]["kernel"].startswith(kernel), d["roofline"]["kernel"]

@@ -175,14 +175,15 @@ def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
     return cfg, spec, P32, d, du
 
 
-def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4, fp32_conditioning=False):
+def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4, fp32_conditioning=False,
+                                  grad_ceiling=2e-2, pred_ceiling=2e-4):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
     torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`).
     fp32_conditioning: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024 candidates each and
     normalises 256-row batches of nearly equal pooled features; the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2 (gradients)
     and 2e-4 (predictions) away from its fp64 evaluation.  The bars then become: HIP gradient error <= the fp32 oracle's own
     worst relative error, HIP prediction error <= max(pred_tol, the fp32 oracle's own) -- i.e. the engine must be at least as
-    close to the exact result as a plain fp32 evaluation of the reference arithmetic is."""
+    close to the exact result as a plain fp32 evaluation of the reference arithmetic is -- capped at grad_ceiling / pred_ceiling."""
     from tests import test_train_gpu as TT
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     eng = alignnet3d.Engine(cfg)
@@ -196,7 +197,9 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pre
                     for k in grads if k not in skip)
         pred32 = max(float(np.abs(ep32[k] - ep_ref[k]).max()) for k in ep_ref)
         print("fp32 oracle vs fp64 oracle: worst relative gradient error %.2e, worst prediction error %.2e" % (rel32, pred32))
-        tol, pred_tol = max(tol, rel32), max(pred_tol, pred32)
+        # conditioning-aware, but bounded: the bars may relax to the fp32 oracle's own error and no further than the fixed ceilings
+        # (a real 1 % gradient bug must not hide behind an ill-conditioned batch)
+        tol, pred_tol = min(max(tol, rel32), grad_ceiling), min(max(pred_tol, pred32), pred_ceiling)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     assert eng.get_option("last_train_kernel") == expect_kernel
     worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
@@ -248,3 +251,44 @@ def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 4 keeps the [B*N*k, C] autograd oracle in memory."""
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=1024, seed=7)
     _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True)
+
+
+def test_train_b2048_matches_autograd(gpu_required):
+    """BASELINE.json configs[3]'s arithmetic on ONE GPU: the global batch of 2048 pairs (KITTITrackletsCarsPersonsHard: SynthCars
+    widths) in a single step -- the [B, B] loss terms of models/tp8.py:279,327 at 4 M entries, the whole-batch tf.cond (:288), the
+    4096-row head BatchNorms, 4096 workgroups per backbone launch.  N = 128 keeps the fp64 autograd oracle at the cost of the
+    256 x 1024 test (the same 524 k points)."""
+    cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True)
+
+
+def test_train_dgcnn_n4096_matches_autograd(gpu_required):
+    """BASELINE.json configs[4]'s training half at its own N: DGCNN at N = 4096 (knn_kernel<64>, 64 tiles per cloud, SynthCars
+    widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 2 keeps the [B N k, C] oracle tensors
+    (327 k edge rows) and the [2B, N, N] distance matrices in memory."""
+    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=2, Nt=4096, seed=9)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, grad_ceiling=5e-2)
+
+
+def test_train_dgcnn_n4096_b512_runs(gpu_required):
+    """configs[4] at one GPU's share of the batch (4096 / 8 = 512 pairs, N = 4096): two full training steps (fp32, then bf16
+    convs) -- finite loss, the expected kernel instantiations, a parameter update -- and an eval forward afterwards."""
+    Bs, Ns = 512, 4096
+    cfg = alignnet3d.default_model_config()
+    cfg["model"]["num_points"] = Ns
+    cfg["model"]["backbone"] = "dgcnn"
+    cfg["training"]["batch_size"] = Bs
+    eng = alignnet3d.Engine(cfg, seed=3)
+    d = R.synth_pairs(Bs, Ns, seed=21, dtype=np.float32)
+    w0 = eng.get_variable("siamese/embedding/conv3/weights").copy()
+    r0 = eng.train_step(d["pcs1"], d["pcs2"], d)
+    assert eng.get_option("last_train_kernel") == 5 and np.isfinite(r0["loss"])
+    eng.set_option("train_matmul_bf16", 1)
+    r1 = eng.train_step(d["pcs1"], d["pcs2"], d)
+    assert eng.get_option("last_train_kernel") == 7 and np.isfinite(r1["loss"])
+    w1 = eng.get_variable("siamese/embedding/conv3/weights")
+    assert np.isfinite(w1).all() and np.abs(w1 - w0).max() > 0
+    out = eng.forward(d["pcs1"][:8], d["pcs2"][:8])
+    eng.close()
+    assert all(np.isfinite(v).all() for v in out.values())
+    print("dgcnn N=4096 B=512: losses", r0["loss"], r1["loss"])

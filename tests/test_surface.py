@@ -263,3 +263,27 @@ def test_every_shipped_reference_config_marshals(tiny, monkeypatch):
         seen += 1
     assert seen >= 8
     cfgmod.reset_config()
+
+
+def test_own_bench_configs_marshal(tiny, monkeypatch):
+    """alignnet-3d_amd/configs/*.json (this build's own files: the BASELINE.json workloads in the reference's schema) load through
+    config.py and marshal into the C config; the non-reference keys they use (training.matmul_dtype, training.sync_bn) survive the merge."""
+    import glob
+    from alignnet3d.engine import make_c_config
+    cfgmod = tiny["config"]
+    monkeypatch.setattr(cfgmod, "_read_split", lambda path: list(range(4096)))
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alignnet-3d_amd", "configs")
+    paths = sorted(glob.glob(os.path.join(here, "*.json")))
+    assert len(paths) >= 4
+    for path in paths:
+        cfgmod.reset_config()
+        cfg = cfgmod.load_config(path)
+        c = make_c_config(cfg)
+        assert c.num_points in (1024, 4096) and c.num_bins == 50 and list(c.emb_conv.w[:3]) == [64, 128, 1024]
+        if "dgcnn" in path:
+            assert c.backbone == 1 and c.num_points == 4096
+        if "bf16" in path:
+            assert cfg.training.matmul_dtype == "bf16"
+        if "b2048" in path:
+            assert cfg.training.sync_bn is True and c.batch_size == 2048
+    cfgmod.reset_config()

@@ -510,6 +510,37 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     eng.close()
 
 
+@pytest.mark.parametrize("tail", [1, 0])
+def test_general_depth_smaller_batch_after_larger(gpu_required, tail):
+    """One engine, B = 8 and then B = 5 (the workspace keeps the larger capacity): the layer-by-layer kernels must walk the tiles of
+    THIS call's B * N rows -- taking the tile count from the workspace capacity ran tiles past the batch's end, whose negative row
+    counts corrupted the batch statistics and EMA of every general-depth layer (round-2 advisor finding)."""
+    N = 100
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), **GENERAL_DEPTH["default_json_like"])
+    eng = None
+    for B in (8, 5):
+        cfg["training"]["batch_size"] = B
+        spec, P32 = oracle_params(cfg, seed=9)
+        d = R.synth_pairs(B, N, seed=9 + B, dtype=np.float32)
+        rng = np.random.default_rng(B)
+        du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+        if eng is None:
+            eng = alignnet3d.Engine(cfg)
+            eng.set_option("train_fused_tail", tail)
+        eng.set_variables(P32)      # (the EMA shadows too: every call starts from the same state as its oracle)
+        ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+        assert eng.get_option("last_train_kernel") & 8
+        for k in ep_ref:
+            np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg="B=%d %s" % (B, k))
+        assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (B, res["loss"], loss_ref)
+        for k, v in ema_ref.items():
+            np.testing.assert_allclose(eng.get_variable(k), v, rtol=1e-4, atol=1e-5, err_msg="B=%d %s" % (B, k))
+        bad, worst = _grad_check(eng, spec, grads, 3e-3 if B >= 8 else 1e-2)
+        assert not bad, (B, bad)
+    eng.close()
+
+
 def test_general_depth_bf16_tail_matches_rounded_oracle(gpu_required):
     """"train_matmul_bf16" on general-depth backbones (default.json's five-layer s2 / embedding; four layers in s1): they take bf16
     operands only in their last layer -- the fused tail (phase 3 on given features with the
