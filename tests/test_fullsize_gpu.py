@@ -250,7 +250,8 @@ def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
     SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 4 keeps the [B*N*k, C] autograd oracle in memory."""
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=1024, seed=7)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True)
+    # (two max-pools and 4-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 3.8e-2 from its fp64 one here)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, grad_ceiling=6e-2)
 
 
 def test_train_b2048_matches_autograd(gpu_required):
@@ -267,7 +268,7 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 2 keeps the [B N k, C] oracle tensors
     (327 k edge rows) and the [2B, N, N] distance matrices in memory."""
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=2, Nt=4096, seed=9)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, grad_ceiling=5e-2)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, grad_ceiling=6e-2)
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):
