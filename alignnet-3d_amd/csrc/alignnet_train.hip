@@ -38,7 +38,8 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float* ext; int* idx2;          // [2B][2 halves][C3] per-half extremes
   int* idx; float* zhat_star;     // [2B][C3] final arg-extreme index, zhat at the extreme
   float* h2;                     // [2B*N][C2]
-  float *gram2, *s2, *m2;        // [2][C2*C2], [2][C2], [2][C2]
+  float *gram2, *s2, *m2;        // [2][C2*C2] centred Gram of h2, [2][C2] column sums, [2][C2] column means
+  float* gram2raw;               // [2][C2*C2] Gram as reduced over the clouds (upper blocks), before centring
   float* pooled; long tower_stride, row_stride;    // forward output (layout of the consumer)
   float* dP;                     // dL/dpooled, same layout
   float *gx, *grot;              // [2B][3], [2B]
@@ -269,7 +270,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.sgn3 = F(2 * C[2]);
       S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
       S.h2 = F((gen && !hyb) ? 8 : MN * C[1]);
-      S.gram2 = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
+      S.gram2 = F(2 * (size_t)C[1] * C[1]); S.gram2raw = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
       S.pooled = F(B2 * C[2]); S.dP = F(B2 * C[2]);
       if (s < 2) { S.tower_stride = (long)B * C[2]; S.row_stride = C[2]; }
       else { S.tower_stride = C[2]; S.row_stride = 2L * C[2]; }
@@ -480,6 +481,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(stat3_pool_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done.mark(h->cfg.device);
   return 0;
 }
@@ -617,13 +619,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (keep) { *keep = f; return; }   // launched by the caller together with independent reductions (stat_finish_reduce_kernel)
     hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, h->stream, f);
   };
-  // the last layer's statistics finish + the reductions of the Gram / column-sum partials of h2: independent, one launch
+  // the reductions of the Gram / column-sum partials of h2 over the clouds (the last layer's statistics follow from them: stat3 below)
   auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) {
-    StatFinishArgs f;
-    finish(2, C3, 2, count, -1, &f);
-    ReduceJobs J{{ja, jb, ReduceJob{nullptr, 0, 0, 0, nullptr, 1.f, 0}}};
-    const long nmax = std::max(std::max(ja.n, jb.n), (long)C3);
-    hipLaunchKernelGGL(stat_finish_reduce_kernel, dim3((unsigned)((nmax + 31) / 32), 2, 3), dim3(1024), 0, h->stream, f, J, 2);
+    ja.out = S.gram2raw;
+    launch_reduce_multi(h, 2, ja, jb);
   };
   if (dg) {
     // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
@@ -757,12 +756,20 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   }
   finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
   }
-  {   // centred Gram of h2 + pooled features: independent of each other, one launch
-    const size_t tot = (size_t)2 * B * C3;
-    const PoolFinishArgs pa{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
-                            S.tower_stride, S.row_stride, S.zhat_star, S.idx, (h->train_bf16 && (!hyb || tail_bf16)) ? 1 : 0};
-    hipLaunchKernelGGL(gram_pool_finish_kernel, dim3((unsigned)(2 * ((C2 * C2 + 255) / 256) + (tot + 255) / 256)), dim3(256), 0, h->stream,
-                       S.gram2, S.s2, C2, count, S.m2, pa);
+  {   // statistics of the last layer from the Gram, EMA, pooled features, centred Gram + column means for the backward: one launch
+    Stat3Args f;
+    f.G = S.gram2raw; f.s = S.s2; f.W = P(h, L[2]->p_w); f.C2 = C2; f.C3 = C3; f.M = count;
+    f.round_w = (h->train_bf16 && (!(dg || hyb) || tail_bf16)) ? 1 : 0;   // the lift ran on bf16 operands
+    for (int t = 0; t < 2; ++t) {
+      f.beta[t] = P(h, L[2]->p_bn[t][0]); f.gamma[t] = P(h, L[2]->p_bn[t][1]);
+      f.mov_mean[t] = P(h, L[2]->p_bn[t][2]); f.mov_var[t] = P(h, L[2]->p_bn[t][3]);
+    }
+    f.bn_decay = bn_decay; f.update_ema = update_ema;
+    f.mean = S.mean[2]; f.var = S.var[2]; f.scale = S.scale[2]; f.shift = S.shift[2]; f.rstd = S.rstd[2]; f.k = S.kk[2];
+    f.Gc = S.gram2; f.m2 = S.m2;
+    f.pa = PoolFinishArgs{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
+                          S.tower_stride, S.row_stride, S.zhat_star, S.idx, 1};
+    hipLaunchKernelGGL(stat3_pool_finish_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), stat3_lds_bytes(C2), h->stream, f);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -975,6 +975,106 @@ __global__ __launch_bounds__(256) void gram_pool_finish_kernel(float* __restrict
   else pool_finish_body(pa, blockIdx.x - 2 * nG);
 }
 
+// ---------------------------------------------------------------------------------
+// Last conv layer of a stage, after phase 3: batch statistics of z3 = h2 W3 + b3 WITHOUT a pass over z3.  z3 is linear in h2, so
+// with the tower's column sums s = sum_n h2[n,:] and Gram G = sum_n h2^T h2 (both reduced over the clouds in fp64 by the launch
+// in front of this one) and the centred Gram Ghat = G - s s^T / M:
+//     mean_c = (s . w_c) / M + b_c,      var_c = w_c^T Ghat w_c / M        (biased, tf.nn.moments; no E[z^2] - E[z]^2 cancellation)
+// -- 128 x 128 multiply-adds per channel in fp64 instead of four VALU operations per element of the [B N, C3] tensor in phase 3's
+// epilogue and a [2B][2][C3][2] double slice per cloud.  train_matmul_bf16: h2 and G are those of the rounded h2, W3 is rounded
+// here (round_w), so the statistics are those of the bf16 product exactly.
+// The same launch finishes the stage's forward: EMA shadows (utils/tf_util.py:476-485), scale / shift / rstd / k for the backward,
+// the pooled features relu(bn(extreme)) with the arg-extreme row (pool_finish_body's arithmetic), and the centred Gram + column
+// means m2 the layer-3 identities of the backward read (kernels_train_bwd.h header).
+// grid (ceil(C3 / 32), 2 towers), block 1024 = 32 channels x 32 row groups; dynamic LDS: Ghat [C2][C2] floats, W3 columns
+// [C2][32] doubles, s [C2] doubles.
+// ---------------------------------------------------------------------------------
+struct Stat3Args {
+  const float* G;        // [2][C2*C2] reduced Gram, 32 x 32 blocks on / above the block diagonal valid
+  const float* s;        // [2][C2] reduced column sums
+  const float* W;        // [C2][C3]
+  int C2, C3; double M; int round_w;
+  const float* beta[2]; const float* gamma[2]; float* mov_mean[2]; float* mov_var[2];
+  float bn_decay; int update_ema;
+  float *mean, *var, *scale, *shift, *rstd, *k;   // [2][C3]
+  float* Gc; float* m2;  // out: centred Gram [2][C2*C2] (all blocks) and column means [2][C2]
+  PoolFinishArgs pa;     // ext / idx2 / sgn / bias / pooled / zhat_star / idx (scale, shift, mean, var: the arrays above)
+};
+
+__global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  __shared__ double red[32][32];
+  __shared__ float cst[4][32];   // mean, var, scale, shift of the block's channels
+  const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, cl = tid & 31, g = tid >> 5, c = blockIdx.x * 32 + cl;
+  float* Gs = smem3;                                                  // [C2][C2 + 1]
+  double* ws = reinterpret_cast<double*>(Gs + (((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1));   // [C2][32]
+  double* ss = ws + (size_t)C2 * 32;                                  // [C2]
+  const float* G = a.G + (size_t)t * C2 * C2;
+  for (int i = tid; i < C2; i += 1024) ss[i] = (double)a.s[t * C2 + i];
+  for (int e = tid; e < C2 * 32; e += 1024) {
+    const int i = e >> 5, cc = blockIdx.x * 32 + (e & 31);
+    float w = cc < C3 ? a.W[(size_t)i * C3 + cc] : 0.f;
+    if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
+    ws[e] = (double)w;
+  }
+  __syncthreads();
+  // centred Gram into LDS (mirroring the blocks below the diagonal); rows [r0, r1) of it also go to HBM for the backward
+  const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
+  for (int e = tid; e < C2 * C2; e += 1024) {
+    const int i = e / C2, j = e % C2;
+    const float raw = (i >> 5) <= (j >> 5) ? G[e] : G[(size_t)j * C2 + i];
+    const float v = (float)((double)raw - ss[i] * ss[j] / a.M);
+    Gs[i * (C2 + 1) + j] = v;
+    if (i >= r0 && i < r1) a.Gc[(size_t)t * C2 * C2 + e] = v;
+  }
+  if (blockIdx.x == 0) for (int i = tid; i < C2; i += 1024) a.m2[t * C2 + i] = (float)(ss[i] / a.M);
+  __syncthreads();
+  // q = w^T Ghat w: thread (channel cl, group g) takes the rows i = g, g + 32, ...
+  double q = 0.0;
+  for (int i = g; i < C2; i += 32) {
+    const float* gr = Gs + i * (C2 + 1);
+    double ti = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < C2; ++j) ti += (double)gr[j] * ws[j * 32 + cl];
+    q += ws[i * 32 + cl] * ti;
+  }
+  red[g][cl] = q;
+  __syncthreads();
+  if (g == 0 && c < C3) {
+    double Q = 0.0, sw = 0.0;
+    for (int k = 0; k < 32; ++k) Q += red[k][cl];
+    for (int i = 0; i < C2; ++i) sw += ss[i] * ws[i * 32 + cl];
+    const float bias = a.pa.bias[c];
+    const float mf = (float)(sw / a.M + (double)bias), vf = (float)fmax(Q / a.M, 0.0);
+    const float rs = 1.0f / sqrtf(vf + kBnEps), inv = a.gamma[t][c] * rs;
+    a.mean[t * C3 + c] = mf; a.var[t * C3 + c] = vf;
+    a.scale[t * C3 + c] = inv; a.shift[t * C3 + c] = (bias - mf) * inv + a.beta[t][c];
+    a.rstd[t * C3 + c] = rs; a.k[t * C3 + c] = inv;
+    if (a.update_ema) {
+      a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);
+      a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
+    }
+    cst[0][cl] = mf; cst[1][cl] = vf; cst[2][cl] = inv; cst[3][cl] = (bias - mf) * inv + a.beta[t][c];
+  }
+  __syncthreads();
+  if (c >= C3) return;
+  // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices)
+  const PoolFinishArgs& p = a.pa;
+  const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cl], rs = 1.0f / sqrtf(cst[1][cl] + kBnEps), sc = cst[2][cl], sh = cst[3][cl];
+  for (int b = g; b < p.B; b += 32) {
+    const int cloud = t * p.B + b;
+    const size_t h0 = ((size_t)cloud * 2) * C3 + c, h1 = h0 + C3, i = (size_t)cloud * C3 + c;
+    float e = p.ext[h0]; int bi = p.idx2[h0];
+    const float e1 = p.ext[h1]; const int b1 = p.idx2[h1];
+    if (e1 > e || (e1 == e && b1 < bi)) { e = e1; bi = b1; }
+    p.idx[i] = bi;
+    p.pooled[t * p.tower_stride + b * p.row_stride + c] = fmaxf(fmaf(e * sg, sc, sh), 0.f);
+    p.zhat_star[i] = (e * sg + bias - mf) * rs;
+  }
+}
+inline size_t stat3_lds_bytes(int C2) { return ((((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1)) * sizeof(float) + ((size_t)C2 * 32 + C2) * sizeof(double); }
+
 // last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0
 struct Prep3Args {
   const float* dP; long tower_stride, row_stride;   // dL/dpooled in the pooled layout

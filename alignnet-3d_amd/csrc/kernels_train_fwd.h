@@ -320,8 +320,6 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   const int KG2 = (kC1 + 7) >> 3, CT2 = (kC2 + 31) >> 5;
   const int KG3 = (kC2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT;
-  const int Cs = PHASE == 2 ? kC2 : a.C3;
-  double* my_stat = a.stat_part + ((size_t)cloud * 2 + half) * Cs * 2;          // [col][2] (phase 3; phase 2 uses 4 slices)
   float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * kC2 * kC2 : nullptr;
@@ -345,11 +343,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 
   const Layer1W l1w = layer1_load(a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, tid);
   constexpr int kBfSlots = 8;                 // channel tiles wave, wave + 4, ... of the lift: C3 <= 1024
-  float rs1[BF16 ? kBfSlots : 1], rs2[BF16 ? kBfSlots : 1], rbe[BF16 ? kBfSlots : 1];
+  float rbe[BF16 ? kBfSlots : 1];
   int rbi[BF16 ? kBfSlots : 1];
   if (BF16) {
 #pragma unroll
-    for (int q = 0; q < kBfSlots; ++q) { rs1[q] = 0.f; rs2[q] = 0.f; rbe[q] = -INFINITY; rbi[q] = 0; }
+    for (int q = 0; q < kBfSlots; ++q) { rbe[q] = -INFINITY; rbi[q] = 0; }
   }
 
   // layer-2 items of this wave (static slots): batch-stat scale / shift and the running sums stay in registers for the whole cloud
@@ -605,17 +603,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
               }
             }
           }
-          float s1 = 0.f, s2 = 0.f, mx[2] = {-INFINITY, -INFINITY};
+          // (sum z3 and sum z3^2 are not accumulated here: z3 is linear in h2, so they follow from the column sums and the Gram
+          //  of h2 that this pass produces anyway -- stat3_pool_finish_kernel; the epilogue is the key max alone)
+          float mx[2] = {-INFINITY, -INFINITY};
           if (nvalid == kTT) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int r = 0; r < 16; r += 2) {
-                const float v0 = acc[m][r], v1 = acc[m][r + 1];
-                s1 += v0; s2 = fmaf(v0, v0, s2);
-                s1 += v1; s2 = fmaf(v1, v1, s2);
-                const float k0 = __uint_as_float((__float_as_uint(v0) & ~15u) | (unsigned)r);
-                const float k1 = __uint_as_float((__float_as_uint(v1) & ~15u) | (unsigned)(r + 1));
+                const float k0 = __uint_as_float((__float_as_uint(acc[m][r]) & ~15u) | (unsigned)r);
+                const float k1 = __uint_as_float((__float_as_uint(acc[m][r + 1]) & ~15u) | (unsigned)(r + 1));
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[m]) : "v"(mx[m]), "v"(k0), "v"(k1));
               }
           } else {
@@ -624,15 +621,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const bool ok = acc_row(m, r, lane) < nvalid;
-                const float v = ok ? acc[m][r] : 0.f;
-                s1 += v; s2 = fmaf(v, v, s2);
-                const float k = ok ? __uint_as_float((__float_as_uint(v) & ~15u) | (unsigned)r) : -INFINITY;
+                const float k = ok ? __uint_as_float((__float_as_uint(acc[m][r]) & ~15u) | (unsigned)r) : -INFINITY;
                 asm("v_max_f32 %0, %1, %2" : "=v"(mx[m]) : "v"(mx[m]), "v"(k));
               }
           }
           const int msel = mx[1] > mx[0];   // near-ties resolve to the lower row block
           const float cand = msel ? mx[1] : mx[0];
-          rs1[q] += s1; rs2[q] += s2;
           if (cand > rbe[q]) { rbe[q] = cand; rbi[q] = tile * kTT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane); }
         }
       }
@@ -642,35 +636,34 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     for (int ct = wave; ct < CT3; ct += kTW) {
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
-      const float bias = live ? a.b3[col] : 0.f;
       const float sg = live ? a.sgn3[tower * a.C3 + col] : 1.f;
       float be = (first || !live) ? -INFINITY : my_ext[col];
       int bi = (first || !live) ? 0 : my_idx[col];
-      const double o0 = (first || !live) ? 0.0 : my_stat[col * 2], o1 = (first || !live) ? 0.0 : my_stat[col * 2 + 1];
-      asm volatile("" ::: "memory");   // keep the four loads above the MFMA loop (see tile_prefetch)
+      asm volatile("" ::: "memory");   // keep the two loads above the MFMA loop (see tile_prefetch)
       f32x16 acc[2];
       mfma_rows<2, true, true>(buf1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64, KG3, lane, acc);
-      const float z0 = acc[0][0] + bias;
-      float s1 = 0.f, s2 = 0.f; int cnt = 0;
+      // extreme of sgn * (z3 - bias) and its row.  The batch statistics of z3 are not accumulated here: z3 is linear in h2, so sum z3
+      // and sum z3^2 follow from the column sums and the Gram of h2 (stat3_pool_finish_kernel) -- the shifted fp32 sums, their fp64
+      // fold and the read-modify-write of a [C3][2] double slice per tile were half of this epilogue.
+      if (nvalid == kTT) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = acc_row(m, r, lane);
-          if (row < nvalid) {
-            const float z = acc[m][r] + bias, dlt = z - z0;
-            s1 += dlt; s2 = fmaf(dlt, dlt, s2); ++cnt;
-            const float v = z * sg;
-            if (v > be) { be = v; bi = tile * kTT + row; }
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[m][r] * sg;
+            if (v > be) { be = v; bi = tile * kTT + acc_row(m, r, lane); }
           }
-        }
-      if (live && !(a.dbg & 4)) {
-        const double zd = (double)z0, n = (double)cnt;
-        const double ls = (double)s1 + n * zd, lss = (double)s2 + 2.0 * zd * (double)s1 + n * zd * zd;
-        my_stat[col * 2] = o0 + ls;
-        my_stat[col * 2 + 1] = o1 + lss;
-        my_ext[col] = be; my_idx[col] = bi;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(m, r, lane);
+            const float v = acc[m][r] * sg;
+            if (row < nvalid && v > be) { be = v; bi = tile * kTT + row; }
+          }
       }
+      if (live && !(a.dbg & 4)) { my_ext[col] = be; my_idx[col] = bi; }
     }
   }
   if (!GIVEN && kRegSums) {
@@ -696,18 +689,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     for (int e = 0; e < 4; ++e) a.colsum_part[((size_t)cloud * slices + g) * kC2 + q * 4 + e] = gcs[e];
   }
   if (PHASE == 3 && BF16) {
-    // sum z = sg * S1 + n b,  sum z^2 = S2 + 2 b sg S1 + n b^2   (z = sg * acc + b; n = the lane's rows = N / 2)
-    int nrows = 0;
-    for (int r = (lane >> 5) * 4; r < a.N; r += 8) nrows += min(4, a.N - r);   // rows (r & 3) + 8 j + 4 half of every 64-row tile
 #pragma unroll
     for (int q = 0; q < kBfSlots; ++q) {
       const int col = (wave + q * kTW) * 32 + (lane & 31);
-      if (col < a.C3 && !(a.dbg & 4)) {
-        const double n = (double)nrows, bd = (double)a.b3[col], t1 = (double)a.sgn3[tower * a.C3 + col] * (double)rs1[q];
-        my_stat[col * 2] = t1 + n * bd;
-        my_stat[col * 2 + 1] = (double)rs2[q] + 2.0 * bd * t1 + n * bd * bd;
-        my_ext[col] = rbe[q]; my_idx[col] = rbi[q];
-      }
+      if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
     }
 #pragma unroll
     for (int q = 0; q < kGramSlots; ++q) {

@@ -199,7 +199,7 @@ def sclk_mhz(device):
         j = json.loads(out[out.index("{"):])
         for card in j.values():
             for k, v in card.items():
-                if "sclk" in k.lower() and "level" in k.lower():
+                if "sclk" in k.lower() and "speed" in k.lower():    # {"card0": {"sclk clock speed:": "(2400Mhz)", ...}}
                     m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
                     if m:
                         return int(m.group(1))

@@ -260,14 +260,15 @@ def test_train_b2048_matches_autograd(gpu_required):
     4096-row head BatchNorms, 4096 workgroups per backbone launch.  N = 128 keeps the fp64 autograd oracle at the cost of the
     256 x 1024 test (the same 524 k points)."""
     cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True)
+    # (2048-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 4e-2 from its fp64 one on the smallest gradients)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True, grad_ceiling=5e-2)
 
 
 def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     """BASELINE.json configs[4]'s training half at its own N: DGCNN at N = 4096 (knn_kernel<64>, 64 tiles per cloud, SynthCars
-    widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 2 keeps the [B N k, C] oracle tensors
-    (327 k edge rows) and the [2B, N, N] distance matrices in memory."""
-    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=2, Nt=4096, seed=9)
+    widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 4 (655 k edge rows, [2B, N, N] distance
+    matrices in the oracle; two-row batch statistics in the heads are singular, so not B = 2)."""
+    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=4096, seed=9)
     _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, grad_ceiling=6e-2)
 
 
