@@ -83,6 +83,7 @@ struct TrainWS {
   unsigned short* b1imgh = nullptr;   // bf16 images of V2 (128 -> 64) and Q2 (64 -> 64), both towers (train_bf16, shipped widths)
   unsigned short* wp2h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the hidden layers (train_bf16, no sign folding)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
+  unsigned short* w3th[3] = {nullptr, nullptr, nullptr};   // bf16 round(W3)^T [C3][C2] per stage: rows gathered by pass B2's sparse part (train_bf16, shipped widths)
   // general-depth PointNet stages (kernels_train_generic.h): pre-BatchNorm activations of every layer stay in HBM
   struct GenStage { float* X0; float* Z[kMaxConv]; float *mean[kMaxConv], *rstd[kMaxConv], *scale[kMaxConv], *shift[kMaxConv]; int* idx; } gen[3];
   float *gen_d[2] = {nullptr, nullptr};   // gradient ping-pong buffers [2B*N][widest layer]
@@ -117,7 +118,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->stage_pack) hipFree(w->stage_pack);
   if (w->q3imgh) hipFree(w->q3imgh);
   if (w->b1imgh) hipFree(w->b1imgh);
-  for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); }
+  for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); if (w->w3th[s]) hipFree(w->w3th[s]); }
   delete w;
   h->train_ws = nullptr;
 }
@@ -434,6 +435,10 @@ static int pack_all_weights(alignnet_handle* h)
       const size_t n2 = (size_t)((L2.cout + 31) / 32) * ((L2.cin + 15) / 16) * 512;
       if (!w->wp2h[s]) HIP_TRY(h, hipMalloc(&w->wp2h[s], n2 * sizeof(unsigned short)));
       pj.src[nj] = P(h, L2.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->wp2h[s]; pj.K[nj] = L2.cin; pj.C[nj] = L2.cout; ++nj;
+      if (h->cfg.backbone == 0 && L2.cin == 64 && L2.cout == 128) {   // pass B2's sparse part on the matrix pipe (train_bwd_b2: SPM)
+        if (!w->w3th[s]) HIP_TRY(h, hipMalloc(&w->w3th[s], (size_t)L.cin * L.cout * sizeof(unsigned short)));
+        pj.src[nj] = P(h, L.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->w3th[s]; pj.K[nj] = -L.cin; pj.C[nj] = L.cout; ++nj;
+      }
     }
     if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(32, nj), dim3(256), 0, h->stream, pj);
   }
@@ -481,7 +486,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(stat3_pool_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(stat3_pool_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (+ 8.5 KiB static)
   done.mark(h->cfg.device);
   return 0;
 }
@@ -962,9 +967,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
-  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra;
   b2.h2_given = S.h2;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  const bool spm = !given && std_w && !b2_accum && h->train_bf16;   // sparse rows on the matrix pipe: the X region holds h1 | R^T | S lo instead of an fp32 tile
+  b2.w3th = spm ? w->w3th[s] : nullptr;
+  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) : 0);
   { ProfScope prof_scope(h, PK_TRAIN_B2);
   if (given_bf16 && std_w) hipLaunchKernelGGL((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
   else if (given_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);

@@ -38,6 +38,7 @@ struct BwdB2Args {
   const float* gs;              // [2B][C3]  k3 * g0
   const int* idx;               // [2B][C3]
   const float* w3t;             // [C3][C2]
+  const unsigned short* w3th;   // bf16 [C3][C2]: round(W3)^T, rows gathered by the sparse part of the shipped-width bf16 instantiation
   float* dy2_store;             // [2B*N][C2]
   double* dbg2_part;            // [2B][2 halves][C2][2]  (dbeta2, dgamma2)
   float* u2_part;               // [2B][C1*C2]
@@ -71,9 +72,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
   const int ld0 = C1T ? C1T + 4 : a.ld0, ldb = (C1T && C2T) ? (C1T > C2T ? C1T : C2T) + 4 : a.ldb;
   const int ntiles = (a.N + kTT - 1) / kTT;
+  // SPM (the shipped widths in bf16 mode): the sparse rows of dh2 -- one non-zero of dy3 per (cloud, channel), at the arg-extreme row --
+  // as a small dense product on the matrix pipe instead of a read-modify-write scatter on the VALU:
+  //     dh2_sparse[64 rows, :] = S [64 x hits] . R [hits x C2],   S[row_j, j] = k3 g0 of hit j,   R[j, :] = round(W3)^T[c_j, :]
+  // per chunk of 64 hits of the tile: R is gathered from the bf16 table (transposed into the B-operand layout on the way into LDS),
+  // S is built as two bf16 tiles hi + lo (16 significant bits of the gradient), and 16 MFMAs per wave add the product to the
+  // accumulators that take h2 Q3.  The scatter it replaces gave every row to one wave (rows that win many channels: up to several
+  // hundred hits on one wave) and was half of the kernel.  Deterministic: fixed summation order.
+  constexpr bool SPM = BF16 && !ACCUM && !GIVEN && C1T == 64 && C2T == 128;
+  constexpr int kSpH = 64, kSpLd = kSpH + 8;                 // hits per chunk; row stride of the S / R^T tiles (conflict-free 16-byte reads)
+  constexpr int kXbytes = SPM ? (kTT * 72 + 128 * kSpLd + kTT * kSpLd) * 2 : 0;   // h1 bf16 | R^T | S lo   (X region of the SPM layout)
   float* xs = smem;
   float* X = smem + kTT * 4;
-  float* Y = X + kTT * ldb;
+  float* Y = SPM ? X + kXbytes / 4 : X + kTT * ldb;
+  unsigned short* spRT = reinterpret_cast<unsigned short*>(X) + kTT * 72;                    // [128][kSpLd]
+  unsigned short* spSl = spRT + 128 * kSpLd;                                                // [64][kSpLd]
+  unsigned short* spSh = reinterpret_cast<unsigned short*>(Y) + kTT * 136;                  // [64][kSpLd] behind the bf16 h2 tile
   int* hit_e = reinterpret_cast<int*>(Y + kTT * ldb);            // [C3] entry = channel | (row-in-tile << 16)
   float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
   int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
@@ -85,6 +99,43 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* my_u2 = a.u2_part + (size_t)cloud * kC1 * kC2;
   float* my_g1 = a.g1_part + (size_t)cloud * kC1 * kC1;
 
+  if constexpr (SPM) {
+    // ---- per-cloud hit list, ONE segment per tile (ordered by channel): wave w counts, then fills, the tiles t = w, w + 4, ... ----
+    static_assert(!SPM || kTW == 4, "tiles are dealt to four waves");
+    int* cnt = wtot;   // reuse: [ntiles] counts live in hoff's tail until the prefix sum  (hoff has kTW * (ntiles + 1) + kTW ints)
+    for (int t = wave; t < ntiles; t += kTW) {
+      int n = 0;
+      for (int base = 0; base < a.C3; base += 64) {
+        const int c = base + lane;
+        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+        n += __popcll(__ballot(id >= 0 && (id / kTT) == t));
+      }
+      if (lane == 0) hoff[ntiles + 1 + t] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc0 = 0;
+      for (int t = 0; t < ntiles; ++t) { hoff[t] = acc0; acc0 += hoff[ntiles + 1 + t]; }
+      hoff[ntiles] = acc0;
+    }
+    __syncthreads();
+    for (int t = wave; t < ntiles; t += kTW) {
+      int pos = hoff[t];
+      for (int base = 0; base < a.C3; base += 64) {
+        const int c = base + lane;
+        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+        const bool m = id >= 0 && (id / kTT) == t;
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+          const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+          hit_e[p] = c | ((id % kTT) << 16);
+          hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
+        }
+        pos += __popcll(mask);
+      }
+    }
+    (void)cnt;
+  } else
   // ---- per-cloud hit lists: wave w owns the arg-extreme rows with (row & 7) == w, ordered by tile then channel
   //      (fixed order => deterministic summation); built once, consumed tile by tile ----
   {
@@ -123,11 +174,85 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   double db = 0.0, dg = 0.0, s1c = 0.0;
   double s1v[4] = {0.0, 0.0, 0.0, 0.0};   // bf16, !ACCUM: column sums of the rounded h1 straight from the lift (columns c0 + 32 j, row group tid >> 5)
 
+  // SPM: tiles of one chunk of hits [hb, he), he - hb <= kSpH.  Thread roles -- gather: hit pair p = tid & 31, columns 16 q .. 16 q + 15
+  // (q = tid >> 5); S build: row r = tid >> 2, hit octets 2 (tid & 3), 2 (tid & 3) + 1.
+  unsigned spg0[8], spg1[8];   // the gathered 2 x 32 bytes of round(W3)^T, hits 2 p and 2 p + 1 (requested early, written into R^T by sp_write)
+  auto sp_request = [&](int hb, int he) {
+    const int pj = (tid & 31) * 2, q = tid >> 5;
+    const int ha = hb + pj, hbb = hb + pj + 1;
+    const int ca = ha < he ? (hit_e[ha] & 0xffff) : -1, cb = hbb < he ? (hit_e[hbb] & 0xffff) : -1;
+    const uint4* sa = reinterpret_cast<const uint4*>(a.w3th + (size_t)max(ca, 0) * kC2 + q * 16);
+    const uint4* sb = reinterpret_cast<const uint4*>(a.w3th + (size_t)max(cb, 0) * kC2 + q * 16);
+    const uint4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
+    const unsigned ma = ca >= 0 ? 0xffffffffu : 0u, mb = cb >= 0 ? 0xffffffffu : 0u;
+    spg0[0] = a0.x & ma; spg0[1] = a0.y & ma; spg0[2] = a0.z & ma; spg0[3] = a0.w & ma; spg0[4] = a1.x & ma; spg0[5] = a1.y & ma; spg0[6] = a1.z & ma; spg0[7] = a1.w & ma;
+    spg1[0] = b0.x & mb; spg1[1] = b0.y & mb; spg1[2] = b0.z & mb; spg1[3] = b0.w & mb; spg1[4] = b1.x & mb; spg1[5] = b1.y & mb; spg1[6] = b1.z & mb; spg1[7] = b1.w & mb;
+  };
+  auto sp_write = [&](int hb, int he) {
+    {   // R^T[n][j]: one dword = hits (2 p, 2 p + 1) of column n; the two half-waves of a wave walk i in opposite halves (bank spread)
+      const int pj = (tid & 31) * 2, q = tid >> 5, hsel = (tid >> 5) & 1;
+      // half-wave 1 starts eight columns further on (bank spread): its registers are rotated by selects, so that every register index
+      // below is a compile-time constant (hipcc folds an if / else over the two orders into one loop with a run-time index -> scratch)
+      unsigned r0[8], r1[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0[k] = hsel ? spg0[(k + 4) & 7] : spg0[k]; r1[k] = hsel ? spg1[(k + 4) & 7] : spg1[k]; }
+      unsigned short* base = spRT + (q * 16) * kSpLd + pj;
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        const unsigned x0 = r0[ii >> 1], x1 = r1[ii >> 1];
+        const unsigned v = (ii & 1) ? ((x0 >> 16) | (x1 & 0xffff0000u)) : ((x0 & 0xffffu) | (x1 << 16));
+        *reinterpret_cast<unsigned*>(base + ((ii + 8 * hsel) & 15) * kSpLd) = v;
+      }
+    }
+    {   // S hi / lo: S[row][j] = g_j where hit j lands on this row, else 0
+      const int r = tid >> 2;
+#pragma unroll
+      for (int oo = 0; oo < 2; ++oo) {
+        const int o = (tid & 3) * 2 + oo;
+        auto one = [&](int hi, unsigned& vh, unsigned& vl) {
+          const int hc = min(hi, he - 1);
+          const bool on = hi < he && (hit_e[hc] >> 16) == r;
+          const float g = on ? hit_g[hc] : 0.f;
+          vh = to_bf16_bits(g);
+          vl = to_bf16_bits(g - __uint_as_float(vh << 16));
+        };
+        auto two = [&](int k, unsigned& dh, unsigned& dl) {
+          unsigned h0, l0, h1, l1;
+          one(hb + o * 8 + 2 * k, h0, l0); one(hb + o * 8 + 2 * k + 1, h1, l1);
+          dh = h0 | (h1 << 16); dl = l0 | (l1 << 16);
+        };
+        uint4 ph, pl;
+        two(0, ph.x, pl.x); two(1, ph.y, pl.y); two(2, ph.z, pl.z); two(3, ph.w, pl.w);
+        *reinterpret_cast<uint4*>(spSh + r * kSpLd + o * 8) = ph;
+        *reinterpret_cast<uint4*>(spSl + r * kSpLd + o * 8) = pl;
+      }
+    }
+  };
+  auto sp_mfma = [&](int nh, f32x16 (&acc)[2]) {   // acc[m] += (S hi + S lo)[rows 32 m ..][:nh] . R^T[cols of this wave's tile]
+    const unsigned short* ah = spSh + (lane & 31) * kSpLd + half * 8;
+    const unsigned short* al = spSl + (lane & 31) * kSpLd + half * 8;
+    const unsigned short* bb = spRT + (wave * 32 + (lane & 31)) * kSpLd + half * 8;
+#pragma unroll
+    for (int kg = 0; kg < kSpH / 16; ++kg)
+      if (kg * 16 < nh) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bb + kg * 16);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ah + m * 32 * kSpLd + kg * 16), bv, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(al + m * 32 * kSpLd + kg * 16), bv, acc[m], 0, 0, 0);
+        }
+      }
+  };
+
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();
     B2_STAMP(0);
+    const int sp_h0 = SPM ? hoff[tile] : 0, sp_h1 = SPM ? hoff[tile + 1] : 0;
+    if (SPM && sp_h1 > sp_h0) {   // first chunk of this tile's hits: requested now, in LDS before the barrier in front of the dh2 MFMAs
+      sp_request(sp_h0, min(sp_h1, sp_h0 + kSpH));
+    }
     if (GIVEN && BF16) {
       // bf16 mode on given features: the tile is staged as the bf16 A operand of h2 Q3 only (the Y region takes the fp32 dy2 later);
       // the epilogue reads the fp32 features it needs (mask, zhat) straight from memory
@@ -158,7 +283,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(1);
     if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
       float cst[4] = {0.f, 0.f, 0.f, 0.f};
-      layer1_to_lds_bf16_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, reinterpret_cast<unsigned short*>(X + kTT * ld0), ld0h, K16a,
+      layer1_to_lds_bf16_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, reinterpret_cast<unsigned short*>(X + (SPM ? 0 : kTT * ld0)), ld0h, K16a,
                                 nvalid, tid, &cst);
 #pragma unroll
       for (int j = 0; j < 4; ++j) s1v[j] += (double)cst[j];
@@ -183,7 +308,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     //      32-row groups (one weight fragment feeds two MFMAs; C2 <= 128 -> CT2 <= 4 waves) ----
     if (ct < CT2) {
       if (BF16)
-        mfma_rows_bf16_all<2>(reinterpret_cast<const unsigned short*>(X + kTT * ld0), ld0h,
+        mfma_rows_bf16_all<2>(reinterpret_cast<const unsigned short*>(X + (SPM ? 0 : kTT * ld0)), ld0h,
                               reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
@@ -210,6 +335,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       }
     }
     }   // !GIVEN
+    if (SPM && sp_h1 > sp_h0) sp_write(sp_h0, min(sp_h1, sp_h0 + kSpH));   // (regions disjoint from h1 / h2: no barrier needed before)
     B2_STAMP(3);
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
     for (int item = wave; ACCUM && item < ((a.dbg & 32) ? 0 : CT1 * CT1); item += kTW) {
@@ -238,6 +364,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
 
     B2_STAMP(4);
+    if constexpr (!SPM) {
     // ---- sparse rows of dh2: X <- 0, then X[row][:] += g * W3[:, c] for this tile's hits ----
     for (int i = tid; i < kTT * ldb / 4; i += kTW * 64) reinterpret_cast<f32x4*>(X)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // ldb % 4 == 0
     __syncthreads();
@@ -289,6 +416,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     }
     __syncthreads();
 
+    }
+
     B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
     if (ct < CT2) {
@@ -297,7 +426,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
+        for (int r = 0; r < 16; ++r) acc[m][r] = SPM ? qb : (live ? X[acc_row(m, r, lane) * ldb + col] : 0.f) + qb;
       float pgv[(GIVEN && BF16) ? 32 : 1];
       if (GIVEN && BF16) {   // requested in front of the MFMAs, used behind them
         const float* src = a.h2_given + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2 + col;
@@ -315,6 +444,18 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
                                      reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
       else
         mfma_rows<2, false, false>(Y, ldb, q3img + (size_t)ct * KGq * 64, KGq, lane, acc);
+      if constexpr (SPM) {   // (CT2 == kTW: every wave is here, the barriers below are workgroup-wide)
+        for (int hb = sp_h0; hb < sp_h1; hb += kSpH) {
+          const int he = min(sp_h1, hb + kSpH);
+          if (hb > sp_h0) {   // further chunks of a crowded tile: rebuild the three tiles
+            __syncthreads();
+            sp_write(hb, he);
+            __syncthreads();
+          }
+          if (he < sp_h1) sp_request(he, min(sp_h1, he + kSpH));   // next chunk's rows travel under this chunk's MFMAs
+          sp_mfma(he - hb, acc);
+        }
+      }
       const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
       const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * kC2 + col] : 0.f;
       const float rs = live ? a.rstd2[tower * kC2 + col] : 0.f;
@@ -608,7 +749,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // like the rest of the bf16 mode.
 // LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
 // ---------------------------------------------------------------------------------
-constexpr int kPackBf16Jobs = 9;
+constexpr int kPackBf16Jobs = 12;
 struct PackBf16Jobs { const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs]; };
 // bf16 MFMA images (layout and sign folding as described in kernels_train_fwd.h; gamma null = no folding) of up to nine matrices in one launch,
 // grid (blocks, jobs): a training step re-packs 9 + 3 x 6 images, each its own 4.5 us launch before
@@ -617,6 +758,14 @@ __device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsig
   const float* W = j.src[q];
   if (!W) return;
   const float* gamma = j.gamma[q];
+  if (j.K[q] < 0) {   // K = -rows: a plain transposed bf16 table dst[c][k] = round(W[k][c]) (pass B2's sparse part gathers its rows)
+    const int K = -j.K[q], C = j.C[q];
+    for (size_t idx = bx * (size_t)256 + threadIdx.x; idx < (size_t)K * C; idx += (size_t)gx * 256) {
+      const int c = idx / K, k = idx % K;
+      j.dst[q][idx] = to_bf16_bits(W[(size_t)k * C + c]);
+    }
+    return;
+  }
   const int K = j.K[q], C = j.C[q], KG = (K + 15) >> 4, CT = (C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 512;
   for (size_t idx = bx * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gx * 256) {
