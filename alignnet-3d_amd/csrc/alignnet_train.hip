@@ -48,6 +48,26 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   double* mom;                   // [2B][27] moments of the edge feature
   float* s1e;                    // [2][C1] column sums of h1 (DGCNN: over the B*N*k edge rows), kept by the forward
   float* g1f;                    // [2][C1*C1] Gram(h1) of the forward (upper blocks), PointNet: statistics of z2 and the layer-2 weight gradient
+  // backward quantities that the stage's WEIGHT gradients read after the stage's backward has moved on (deferred work, see Deferred):
+  // one set per stage, so that the three stages' jobs can run together at the end of the step
+  float *gs, *E3, *kdb3, *Sp, *GW;                 // [2B][C3], [2][C3], [2][C3], [2][C2*C3], [2][C2*C3]
+  float *u2_part, *g1_part, *p_part;               // [2B][C1*C2], [2B][C1*C1], [2B][6*C1]
+  float *u2, *g1, *s1, *m1, *E2, *kdb2, *k2, *GW2; // [2][C1*C2], [2][C1*C1], [2][C1] x 2, [2][C2] x 3, [2][C1*C2]
+};
+
+// Work that only the optimiser waits for -- the weight gradients of the conv layers (sparse rows + Gram identities), of the head
+// layers (dW = x^T dz, bias sums) and the first layer's dW from its per-cloud partials -- is not launched where the backward
+// produces its inputs (about ten launches of 5 - 45 us per stage, on the critical path of the one stream) but collected and run
+// as five launches after the last stage's backward: all reductions | all sparse gathers, then all Gram centrings, all GEMMs, all
+// combines, each as one multi-job launch with three stages' worth of parallelism.
+struct Deferred {
+  bool on = false;
+  std::vector<ReduceJob> red;
+  std::vector<SparseDwJob> sp;
+  std::vector<CentreJob> cen;
+  std::vector<std::pair<GemmArgs, int>> gemm;   // (product, batch entries)
+  std::vector<CombineJob> comb;
+  void clear() { red.clear(); sp.clear(); cen.clear(); gemm.clear(); comb.clear(); }
 };
 
 struct TrainWS {
@@ -69,10 +89,10 @@ struct TrainWS {
   float *dy2, *dy1;
   int* nn;                       // DGCNN: [2B][N][20] neighbour indices
   double* pdy_part;              // DGCNN: [2B][4][7][C1]
-  double *dbg2_part, *dbg1_part, *s1_part; float *u2_part, *g1_part, *p_part;
-  float *dbg2, *dbg1, *u2, *g1, *s1, *m1;
-  float *E3, *kdb3, *gs, *Sp, *GW, *W3E, *W3T, *Q3, *q3b, *q3img;
-  float *E2, *kdb2, *k2, *rstd2, *W2E, *V2, *Q2, *q2b, *v2img, *q2img, *GW2;
+  double *dbg2_part, *dbg1_part, *s1_part;
+  float *dbg2, *dbg1;
+  float *W3E, *W3T, *Q3, *q3b, *q3img;
+  float *rstd2, *W2E, *V2, *Q2, *q2b, *v2img, *q2img;
   float *k1, *rstd1;
   float* outs[8];
   // optimiser
@@ -89,6 +109,7 @@ struct TrainWS {
   float *gen_d[2] = {nullptr, nullptr};   // gradient ping-pong buffers [2B*N][widest layer]
   float *gen_part = nullptr, *gen_dwpart = nullptr, *gen_ppart = nullptr, *gen_cA = nullptr, *gen_cB = nullptr, *gen_wt = nullptr;
   int gen_tiles = 0, gen_slabs = 0;
+  Deferred defer;
 };
 
 }  // namespace alignnet
@@ -280,6 +301,10 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
       (void)gen;
       S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]); S.g1f = F(2 * (size_t)C[0] * C[0]);
+      S.gs = F(B2 * C[2]); S.E3 = F(2 * C[2]); S.kdb3 = F(2 * C[2]); S.Sp = F(2 * (size_t)C[1] * C[2]); S.GW = F(2 * (size_t)C[1] * C[2]);
+      S.u2_part = F(B2 * (size_t)C[0] * C[1]); S.g1_part = F(B2 * (size_t)C[0] * C[0]); S.p_part = F(B2 * 6 * C[0]);
+      S.u2 = F(2 * (size_t)C[0] * C[1]); S.g1 = F(2 * (size_t)C[0] * C[0]); S.s1 = F(2 * C[0]); S.m1 = F(2 * C[0]);
+      S.E2 = F(2 * C[1]); S.kdb2 = F(2 * C[1]); S.k2 = F(2 * C[1]); S.GW2 = F(2 * (size_t)C[0] * C[1]);
       if (hyb && pass) {   // the fused tail reads the statistics of the layers in front of it where the fused stages keep theirs
         TrainWS::GenStage& Gs = w->gen[s];
         S.scale[0] = Gs.scale[0]; S.shift[0] = Gs.shift[0];
@@ -312,17 +337,13 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
     w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(B2 * 4 * 7 * maxC1);
     w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
-    w->u2_part = F(B2 * (size_t)maxC1 * maxC2); w->g1_part = F(B2 * (size_t)maxC1 * maxC1); w->p_part = F(B2 * 6 * maxC1);
-    w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1); w->u2 = F(2 * (size_t)maxC1 * maxC2); w->g1 = F(2 * (size_t)maxC1 * maxC1);
-    w->s1 = F(2 * maxC1); w->m1 = F(2 * maxC1);
-    w->E3 = F(2 * maxC3); w->kdb3 = F(2 * maxC3); w->gs = F(B2 * maxC3);
-    w->Sp = F(2 * (size_t)maxC2 * maxC3); w->GW = F(2 * (size_t)maxC2 * maxC3); w->W3E = F(2 * (size_t)maxC2 * maxC3);
+    w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1);
+    w->W3E = F(2 * (size_t)maxC2 * maxC3);
     w->W3T = F((size_t)maxC2 * maxC3); w->Q3 = F(2 * (size_t)maxC2 * maxC2); w->q3b = F(2 * maxC2);
     w->q3img = F(2 * (size_t)maxC2 * maxC2 + 1024);
-    w->E2 = F(2 * maxC2); w->kdb2 = F(2 * maxC2); w->k2 = F(2 * maxC2); w->rstd2 = F(2 * maxC2);
+    w->rstd2 = F(2 * maxC2);
     w->W2E = F(2 * (size_t)maxC1 * maxC2); w->V2 = F(2 * (size_t)maxC1 * maxC2); w->Q2 = F(2 * (size_t)maxC1 * maxC1);
     w->q2b = F(2 * maxC1); w->v2img = F(2 * (size_t)maxC1 * maxC2 + 1024); w->q2img = F(2 * (size_t)maxC1 * maxC1 + 1024);
-    w->GW2 = F(2 * (size_t)maxC1 * maxC2);
     w->k1 = F(2 * maxC1); w->rstd1 = F(2 * maxC1);
     const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
     for (int i = 0; i < 8; ++i) w->outs[i] = F((size_t)B * widths[i]);
@@ -400,6 +421,75 @@ static void launch_loss(alignnet_handle* h, const LossArgs& la)
   hipLaunchKernelGGL(loss_final_kernel, dim3((la.B + kLossCols - 1) / kLossCols), dim3(256), 0, h->stream, la, kLossGroups, nprep);
 }
 
+
+// ---- deferred weight-gradient work (struct Deferred): each helper either records the job or, with deferral off, launches it in place
+static void def_reduce(alignnet_handle* h, TrainWS* w, const ReduceJob& j)
+{
+  if (w->defer.on) { w->defer.red.push_back(j); return; }
+  ReduceJobs J{}; J.j[0] = j;
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((j.n + 31) / 32), 2, 1), dim3(1024), 0, h->stream, J);
+}
+static void def_sparse(alignnet_handle* h, TrainWS* w, const SparseDwJob& j)
+{
+  if (w->defer.on) { w->defer.sp.push_back(j); return; }
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3(j.C3, 2), dim3(j.C2 * (1024 / j.C2 > 8 ? 8 : 1024 / j.C2)), 0, h->stream, j.gs, j.idx, j.h2, j.B, j.N, j.C2, j.C3, j.Sp, j.h2_bf16);
+}
+static void def_centre(alignnet_handle* h, TrainWS* w, const CentreJob& j)
+{
+  if (w->defer.on) { w->defer.cen.push_back(j); return; }
+  hipLaunchKernelGGL(centre_gram_kernel, dim3((unsigned)(((size_t)j.C * j.C + 255) / 256), 2), dim3(256), 0, h->stream, j.G, j.s, j.C, j.M, j.m);
+}
+static void def_gemm(alignnet_handle* h, TrainWS* w, const GemmArgs& g, int batch = 1)
+{
+  if (w->defer.on) { w->defer.gemm.push_back({g, batch}); return; }
+  hipLaunchKernelGGL(gemm_small, dim3((g.N + 31) / 32, (g.M + 31) / 32, batch), dim3(kGemmWaves * 64), 0, h->stream, g);
+}
+static void def_combine(alignnet_handle* h, TrainWS* w, const CombineJob& j)
+{
+  if (w->defer.on) { w->defer.comb.push_back(j); return; }
+  hipLaunchKernelGGL(combine_dw_kernel, dim3((unsigned)(((size_t)j.R * j.C + 255) / 256)), dim3(256), 0, h->stream, j.Sp, j.spscale, j.m, j.kdb, j.GW, j.E, j.R, j.C, j.dW);
+}
+// the recorded jobs, five launches: reductions | sparse gathers -> Gram centrings -> GEMMs -> combines
+static int flush_deferred(alignnet_handle* h)
+{
+  TrainWS* w = tws(h);
+  Deferred& d = w->defer;
+  if (d.red.size() > (size_t)kReduceJobs || d.sp.size() > 3 || d.cen.size() > 3 || d.gemm.size() > (size_t)kGemmJobs || d.comb.size() > 6)
+    return fail(h, "flush_deferred: job table overflow");
+  if (!d.red.empty()) {
+    ReduceJobs J{}; long nmax = 0;
+    for (size_t i = 0; i < d.red.size(); ++i) { J.j[i] = d.red[i]; nmax = std::max(nmax, d.red[i].n); }
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, h->stream, J);
+  }
+  if (!d.sp.empty()) {
+    SparseDwJobs J{}; int cmax = 0;
+    for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); }
+    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3(cmax, 2, (unsigned)d.sp.size()), dim3(1024), 0, h->stream, J);
+  }
+  if (!d.cen.empty()) {
+    CentreJobs J{}; size_t emax = 0;
+    for (size_t i = 0; i < d.cen.size(); ++i) { J.j[i] = d.cen[i]; emax = std::max(emax, (size_t)d.cen[i].C * d.cen[i].C); }
+    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)d.cen.size()), dim3(256), 0, h->stream, J);
+  }
+  if (!d.gemm.empty()) {
+    GemmJobs J{}; int tot = 0;
+    for (size_t i = 0; i < d.gemm.size(); ++i) {
+      const GemmArgs& g = d.gemm[i].first;
+      J.g[i] = g; J.tx[i] = (g.N + 31) / 32; J.ty[i] = (g.M + 31) / 32; J.start[i] = tot;
+      tot += J.tx[i] * J.ty[i] * d.gemm[i].second;
+    }
+    J.start[d.gemm.size()] = tot; J.n = (int)d.gemm.size();
+    hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, h->stream, J);
+  }
+  if (!d.comb.empty()) {
+    CombineJobs J{}; size_t emax = 0;
+    for (size_t i = 0; i < d.comb.size(); ++i) { J.j[i] = d.comb[i]; emax = std::max(emax, (size_t)d.comb[i].R * d.comb[i].C); }
+    hipLaunchKernelGGL(combine_dw_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 1, (unsigned)d.comb.size()), dim3(256), 0, h->stream, J);
+  }
+  d.clear();
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
 
 static int pack_all_weights(alignnet_handle* h)
 {
@@ -635,7 +725,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     DgTrainArgs d;
     d.pcs[0] = p1; d.pcs[1] = p2; d.xform = S.xform; d.nn = w->nn; d.B = B; d.N = N; d.k = kDgK; d.C1 = C1; d.C2 = C2; d.ld0 = a.ld[0];
     d.w1 = a.w1; d.b1 = a.b1; d.wp2 = a.wp2; d.b2 = a.b2; d.sc1 = a.sc1; d.sh1 = a.sh1; d.sc2 = a.sc2; d.sh2 = a.sh2;
-    d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part; d.g1_part = w->g1_part;
+    d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part; d.g1_part = S.g1_part;
     d.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
     const size_t dlds = h->train_bf16 ? (size_t)kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * sizeof(unsigned short)
                                       : ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
@@ -661,7 +751,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
-      launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
+      launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
       hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount,
                          h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
@@ -714,13 +804,13 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     // phase 2 from s1 = sum h1 and G1 = sum h1^T h1 (kept for the backward)
     Gram1Args g;
     g.pcs[0] = p1; g.pcs[1] = p2; g.xform = S.xform; g.B = B; g.N = N; g.C1 = C1; g.ld0 = a.ld[0];
-    g.w1 = a.w1; g.sc1 = a.sc1; g.sh1 = a.sh1; g.g1_part = w->g1_part; g.s1_part = w->s1_part;
+    g.w1 = a.w1; g.sc1 = a.sc1; g.sh1 = a.sh1; g.g1_part = S.g1_part; g.s1_part = w->s1_part;
     const size_t glds = ((size_t)kTT * 4 + (size_t)kTT * g.ld0) * sizeof(float);
     if (h->train_bf16) hipLaunchKernelGGL(train_fwd_gram1<true>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     else if (C1 == 64) hipLaunchKernelGGL((train_fwd_gram1<false, 64>), dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
-    launch_reduce_multi(h, 2, rjob(w->g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
+    launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
     hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count,
                        h->train_bf16 ? 1 : 0, w->stat_part);
     finish(1, C2, 1, count, 1);
@@ -891,12 +981,12 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here); the whole gradient
       // vector is zeroed once per step, so nothing to do
     } else {
-      launch_reduce<float>(h, dcur, M, (long)L.cout, G(h, w, L.p_b), 1);
+      def_reduce(h, w, rjob(dcur, M, (long)L.cout, G(h, w, L.p_b), 1.f, 1));   // bias of the last (linear) layer
     }
-    // dW = x^T dz (TN) and dx = dz W^T (NT) are independent (dx goes to its own buffer, not over y_{j-1}): one launch
+    // dx = dz W^T (NT) is on the backward's critical path; dW = x^T dz (TN) waits for nothing but the optimiser (deferred)
     float* dx = j == 0 ? din : w->hl[s][j - 1].dyb;
-    launch_gemm_pair(h, gemm_args(xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M),
-                     gemm_args(dcur, L.cout, 1, P(h, L.p_w), 1, L.cout, dx, j == 0 ? ldin : L.cin, 1, M, L.cin, L.cout));
+    def_gemm(h, w, gemm_args(xin, 1, ldx, dcur, L.cout, 1, G(h, w, L.p_w), L.cout, 1, L.cin, L.cout, M));
+    launch_gemm(h, dcur, L.cout, 1, P(h, L.p_w), 1, L.cout, dx, j == 0 ? ldin : L.cin, 1, M, L.cin, L.cout);
     dcur = dx;
   }
   HIP_TRY(h, hipGetLastError());
@@ -929,27 +1019,37 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   Prep3Args p3;
   p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
-  p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = w->E3; p3.kdb = w->kdb3; p3.gs = w->gs;
+  p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = S.E3; p3.kdb = S.kdb3; p3.gs = S.gs;
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(C3, 2), dim3(C2 * (1024 / C2 > 8 ? 8 : 1024 / C2)), 0, h->stream, w->gs, S.idx, S.h2, B, N, C2, C3, w->Sp, (h->train_bf16 && !given) ? 1 : 0);
-  // GW[t] = Ghat2[t] W3  (both towers in one launch)
-  launch_gemm(h, S.gram2, C2, 1, W3, C3, 1, w->GW, C3, 1, C2, C3, C2, nullptr, 1.f, 0, 2, (long)C2 * C2, 0, (long)C2 * C3);
-  // dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)  and  W3E[t] = W3 diag(E[t]), W3T = W3^T  (one launch: nothing in it depends on the other part)
-  hipLaunchKernelGGL(combine_scale_kernel, dim3((unsigned)(((size_t)C2 * C3 + 255) / 256), 3), dim3(256), 0, h->stream, w->Sp, S.m2, w->kdb3, w->GW, w->E3,
-                     C2, C3, G(h, w, L[2]->p_w), W3, w->W3E, w->W3T);
+  // weight gradient of layer 3 (deferred: only the optimiser waits for it):  dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)
+  def_sparse(h, w, SparseDwJob{S.gs, S.idx, S.h2, B, N, C2, C3, S.Sp, (h->train_bf16 && !given) ? 1 : 0});
+  {
+    GemmArgs g = gemm_args(S.gram2, C2, 1, W3, C3, 1, S.GW, C3, 1, C2, C3, C2);   // GW[t] = Ghat2[t] W3, both towers
+    g.batch_a = (long)C2 * C2; g.batch_b = 0; g.batch_c = (long)C2 * C3;
+    def_gemm(h, w, g, 2);
+  }
+  def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w)});
   const size_t qimg = img_floats(C2, C2);
-  // Q3[t] = W3 (W3E[t])^T
-  launch_gemm(h, W3, C3, 1, w->W3E, 1, C3, w->Q3, C2, 1, C2, C2, C3, nullptr, 1.f, 0, 2, 0, (long)C2 * C3, (long)C2 * C2);
+  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
+  const bool spm = !given && std_w && !b2_accum && h->train_bf16;   // sparse rows on the matrix pipe: the X region holds h1 | R^T | S lo instead of an fp32 tile
+  // W3^T for the VALU form of pass B2's sparse rows (the matrix-pipe form gathers from the bf16 table packed at the start of the step)
+  if (!spm) hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, nullptr, w->W3E, 0, 0, nullptr, w->W3T, 1, 1);
+  {   // Q3[t] = W3 diag(E3[t]) W3^T: the per-k scale rides on the product's A operand (no W3 diag(E) copy)
+    GemmArgs g = gemm_args(W3, C3, 1, W3, 1, C3, w->Q3, C2, 1, C2, C2, C3);
+    g.batch_a = 0; g.batch_b = 0; g.batch_c = (long)C2 * C2; g.kscale = S.E3; g.batch_k = C3;
+    hipLaunchKernelGGL(gemm_small, dim3((C2 + 31) / 32, (C2 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
+  }
   const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
   if (h->train_bf16 && (!given || given_bf16)) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
     // (+ the pass's bias row q3b, which reads the same fresh Q3: one launch)
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C2, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b});
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C2, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q3, S.m2, W3, S.kdb3, C2, C3, M, w->q3b});
   } else {
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
-    hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, w->kdb3, C2, C3, M, w->q3b);
+    hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, S.kdb3, C2, C3, M, w->q3b);
   }
   // ---- pass B2 ----
   BwdB2Args b2;
@@ -958,18 +1058,15 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.w1 = P(h, L[0]->p_w); b2.wp2 = h->d_wp + L[1]->off_wp;
   b2.sc1 = S.scale[0]; b2.sh1 = S.shift[0]; b2.sc2 = S.scale[1]; b2.sh2 = S.shift[1];
   b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = S.rstd[1];
-  b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = w->gs; b2.idx = S.idx; b2.w3t = w->W3T;
+  b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = S.gs; b2.idx = S.idx; b2.w3t = w->W3T;
   b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
-  const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
-  b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = w->u2_part; b2.g1_part = w->g1_part;
+  b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = S.u2_part; b2.g1_part = S.g1_part;
   b2.s1_part = (!given && !h->train_bf16 && !b2_accum && !getenv("ALIGNNET_PHASE2_LEGACY")) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
-  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
-  const bool spm = !given && std_w && !b2_accum && h->train_bf16;   // sparse rows on the matrix pipe: the X region holds h1 | R^T | S lo instead of an fp32 tile
   b2.w3th = spm ? w->w3th[s] : nullptr;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) : 0);
   { ProfScope prof_scope(h, PK_TRAIN_B2);
@@ -1001,29 +1098,36 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !getenv("ALIGNNET_PHASE2_LEGACY");   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
-  auto layer2_weight_grad = [&]() {
-    if (fwd_gram || dg) launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(S.g1f, 1, (long)(C1 * C1), w->g1));
-    else launch_reduce_multi(h, 2, rjob(w->u2_part, B, (long)(C1 * C2), w->u2), rjob(w->g1_part, B, (long)(C1 * C1), w->g1));
-    hipLaunchKernelGGL(centre_gram_kernel, g256t((size_t)C1 * C1), dim3(256), 0, h->stream, w->g1, w->s1, C1, Me, w->m1);
-    // GW2[t] = Ghat1[t] W2
-    launch_gemm(h, w->g1, C1, 1, W2, C2, 1, w->GW2, C2, 1, C1, C2, C1, nullptr, 1.f, 0, 2, (long)C1 * C1, 0, (long)C1 * C2);
-    hipLaunchKernelGGL(combine_dw_kernel, g256((size_t)C1 * C2), dim3(256), 0, h->stream, w->u2, w->k2, w->m1, w->kdb2, w->GW2, w->E2, C1, C2,
-                       G(h, w, L[1]->p_w));
+  auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
+    def_reduce(h, w, rjob(S.u2_part, B, (long)(C1 * C2), S.u2));
+    if (fwd_gram || dg) def_reduce(h, w, rjob(S.g1f, 1, (long)(C1 * C1), S.g1));
+    else def_reduce(h, w, rjob(S.g1_part, B, (long)(C1 * C1), S.g1));
+    def_centre(h, w, CentreJob{S.g1, S.s1, C1, Me, S.m1});
+    {
+      GemmArgs g = gemm_args(S.g1, C1, 1, W2, C2, 1, S.GW2, C2, 1, C1, C2, C1);   // GW2[t] = Ghat1[t] W2
+      g.batch_a = (long)C1 * C1; g.batch_b = 0; g.batch_c = (long)C1 * C2;
+      def_gemm(h, w, g, 2);
+    }
+    def_combine(h, w, CombineJob{S.u2, S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w)});
   };
   const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
   if (dg || fwd_gram)   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
-    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), w->s1),
-                        rjob(S.s1e, 1, (long)(C1), w->m1, (float)(1.0 / Me)));
+    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), S.s1),
+                        rjob(S.s1e, 1, (long)(C1), S.m1, (float)(1.0 / Me)));
   else      // m1 = s1 / M (qbias needs it before B1)
-    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(w->s1_part, B * sG, (long)(C1), w->s1),
-                        rjob(w->s1_part, B * sG, (long)(C1), w->m1, (float)(1.0 / M)));
+    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(w->s1_part, B * sG, (long)(C1), S.s1),
+                        rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / M)));
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
                      P(h, L[1]->p_bn[1][1]), C2, Me, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
-                     G(h, w, L[1]->p_bn[1][1]), w->E2, w->kdb2, w->k2, w->rstd2);
+                     G(h, w, L[1]->p_bn[1][1]), S.E2, S.kdb2, S.k2, w->rstd2);
   if (!acc_in_b1) layer2_weight_grad();
-  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, w->E2, w->W2E, 0, 2, w->k2, w->V2, 1, 2);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
+  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, nullptr, w->W2E, 0, 0, S.k2, w->V2, 1, 2);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
-  launch_gemm(h, W2, C2, 1, w->W2E, 1, C2, w->Q2, C1, 1, C1, C1, C2, nullptr, 1.f, 0, 2, 0, (long)C1 * C2, (long)C1 * C1);
+  {   // Q2[t] = W2 diag(E2[t]) W2^T
+    GemmArgs g = gemm_args(W2, C2, 1, W2, 1, C2, w->Q2, C1, 1, C1, C1, C2);
+    g.batch_a = 0; g.batch_b = 0; g.batch_c = (long)C1 * C1; g.kscale = S.E2; g.batch_k = C2;
+    hipLaunchKernelGGL(gemm_small, dim3((C1 + 31) / 32, (C1 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
+  }
   const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
   if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
   const bool dg_bf16 = dg && h->train_bf16;   // edge pass with h1 Q2 on bf16 MFMA: bf16 images of Q2, packed with the bias row
@@ -1032,8 +1136,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (2 * 8 * 512 + kQ2hMax) * sizeof(unsigned short)));   // (the PointNet bf16 B1's allocation)
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[t] = w->b1imgh + t * kQ2hMax; pj.K[t] = C1; pj.C[t] = C1; }
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b});
-  } else if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b});
+  } else if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
   if (dg) {
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
     DgBwdArgs e;
@@ -1042,7 +1146,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.w1 = P(h, L[0]->p_w); e.sc1 = S.scale[0]; e.sh1 = S.shift[0];
     e.v2 = w->V2; e.v2_stride = (long)C1 * C2; e.q2img = w->q2img; e.q2img_stride = (long)q2img; e.q2b = w->q2b;
     e.q2imgh = w->b1imgh; e.q2imgh_stride = (long)kQ2hMax;
-    e.dyp = w->dy2; e.argk = S.argk; e.u2_part = w->u2_part; e.g1_part = nullptr; e.pdy_part = w->pdy_part;   // Gram(h1): the forward's
+    e.dyp = w->dy2; e.argk = S.argk; e.u2_part = S.u2_part; e.g1_part = nullptr; e.pdy_part = w->pdy_part;   // Gram(h1): the forward's
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2, dg_bf16);
@@ -1072,10 +1176,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.pdy_part = w->pdy_part; z.slices = 4; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
-    z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
+    z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
     hipLaunchKernelGGL(dg_b0_cloud<6>, dim3(2 * B), dim3(128), 0, h->stream, z);
-    launch_reduce<float>(h, w->p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1);
+    def_reduce(h, w, rjob(S.p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1.f, 1));
     HIP_TRY(h, hipGetLastError());
     return 0;
   }
@@ -1086,7 +1190,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.w1 = P(h, L[0]->p_w); b1.sc1 = S.scale[0]; b1.sh1 = S.shift[0]; b1.b1 = P(h, L[0]->p_b); b1.mean1 = S.mean[0]; b1.rstd1 = S.rstd[0];
   b1.v2img = w->v2img; b1.q2img = w->q2img; b1.v2img_stride = (long)vimg; b1.q2img_stride = (long)q2img; b1.q2b = w->q2b;
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
-  b1.u2_part = acc_in_b1 ? w->u2_part : nullptr; b1.g1_part = (acc_in_b1 && !fwd_gram) ? w->g1_part : nullptr;
+  b1.u2_part = acc_in_b1 ? S.u2_part : nullptr; b1.g1_part = (acc_in_b1 && !fwd_gram) ? S.g1_part : nullptr;
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;
@@ -1100,7 +1204,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
       pj.src[t] = w->V2 + (size_t)t * C1 * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;
       pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;
     }
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 4), dim3(256), 0, h->stream, pj, 4, 8u, QBiasArgs{w->Q2, w->m1, W2, w->kdb2, C1, C2, Me, w->q2b});
+    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 4), dim3(256), 0, h->stream, pj, 4, 8u, QBiasArgs{w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b});
     BwdB1hArgs bh;
     bh.pcs[0] = p1; bh.pcs[1] = p2; bh.xform = S.xform; bh.B = B; bh.N = N;
     bh.w1 = P(h, L[0]->p_w); bh.sc1 = S.scale[0]; bh.sh1 = S.shift[0];
@@ -1124,10 +1228,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N; z.count = M;
     if (b1h) z.slices = 1;   // train_bwd_b1_bf16 reduces the four partials itself
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
-    z.dbg1 = w->dbg1; z.p_part = w->p_part; z.gx = S.gx; z.grot = S.grot;
+    z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
     hipLaunchKernelGGL(dg_b0_cloud<3>, dim3(2 * B), dim3(128), 0, h->stream, z);
-    launch_reduce<float>(h, w->p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1);
+    def_reduce(h, w, rjob(S.p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1.f, 1));
     HIP_TRY(h, hipGetLastError());
     return 0;
   }
@@ -1140,10 +1244,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   BwdB0Args b0;
   b0.pcs[0] = p1; b0.pcs[1] = p2; b0.xform = S.xform; b0.B = B; b0.N = N; b0.C1 = C1;
   b0.w1 = P(h, L[0]->p_w); b0.b1 = P(h, L[0]->p_b); b0.mean1 = S.mean[0]; b0.rstd1 = S.rstd[0]; b0.k1 = S.kk[0]; b0.dbg1 = w->dbg1;
-  b0.count = M; b0.dy1_store = w->dy1; b0.p_part = w->p_part; b0.gx = S.gx; b0.grot = S.grot;
+  b0.count = M; b0.dy1_store = w->dy1; b0.p_part = S.p_part; b0.gx = S.gx; b0.grot = S.grot;
   hipLaunchKernelGGL(train_bwd_b0, dim3(2 * B), dim3(256), 1024 * 4 * sizeof(float) + 256 * 4 * sizeof(double) + (size_t)C1 * 4 * sizeof(float),
                      h->stream, b0);
-  launch_reduce<float>(h, w->p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1);
+  def_reduce(h, w, rjob(S.p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1.f, 1));
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -1172,6 +1276,10 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
     bool any_hyb = false;
     for (int s = 0; s < 3; ++s) any_hyb = any_hyb || stage_hybrid(h, s);
     h->last_train_kernel = (std_all ? 1 : 0) | (h->train_bf16 ? 2 : 0) | (h->cfg.backbone == 1 ? 4 : 0) | (any_gen ? 8 : 0) | (any_hyb ? 16 : 0);
+  }
+  for (int s = 0; s < 2; ++s) {   // pooled layout [tower][B rows][C]: the tower stride is THIS call's B (the workspace may be carved for a larger one)
+    const Stack& cs = conv_of(h, s);
+    w->st[s].tower_stride = (long)B * h->layers[cs.first + cs.n - 1].cout;
   }
   if (do_backward) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (pack_all_weights(h)) return 1;
@@ -1208,22 +1316,30 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   // ---- backward ----
   const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   h->comm_buckets = 0;
+  w->defer.clear();
+  w->defer.on = !getenv("ALIGNNET_NO_DEFER");   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
-  if (comm_overlap && comm_bucket(h, 2)) return 1;   // the stage-3 segment (embedding convs + pair head: 64 % of the vector) is final
   hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
                      B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
   hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
   const int C2l = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout, C1l = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
   if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
-  if (comm_overlap && comm_bucket(h, 1)) return 1;
   hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
   // s1c = o1 + center_mean  ->  d_o1 = d_s1c
   HIP_TRY(h, hipMemcpyAsync(w->d_o[0], w->d_s1c, (size_t)B2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
-  if (comm_overlap && comm_bucket(h, 0)) return 1;
+  const bool deferred = w->defer.on;
+  if (flush_deferred(h)) return 1;   // the weight gradients of all three stages: five multi-job launches
+  w->defer.on = false;
+  if (comm_overlap) {
+    // Data-parallel steps: the three segments of the flat gradient are final only now (without deferral each was final right after its
+    // stage's backward and travelled under the next stage's); they still go out as three buckets on the side stream, stage 3 first.
+    (void)deferred;
+    for (int sg = 2; sg >= 0; --sg) if (comm_bucket(h, sg)) return 1;
+  }
   HIP_TRY(h, hipGetLastError());
   return 0;
 }

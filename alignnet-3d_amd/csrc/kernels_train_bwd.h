@@ -1062,7 +1062,8 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
 // Several slice reductions in one launch (every launch costs >= 4.7 us on the one stream of a step, whatever its work):
 // grid (max over jobs of ceil(n/32), 2 towers, jobs).  Same summation order as reduce_slices_kernel.
 struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers; };
-struct ReduceJobs { ReduceJob j[3]; };
+constexpr int kReduceJobs = 16;
+struct ReduceJobs { ReduceJob j[kReduceJobs]; };
 __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx, int t, int bz)
 {
   __shared__ double red[32][33];
@@ -1284,14 +1285,15 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
 // Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
 // h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16).  The (index, weight) pairs of the channel are staged in
 // LDS first so that the row gathers are independent loads (4 in flight per thread).
-__global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                                         int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
+__device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                               int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int c, int t, int G)
 {
   constexpr int kStage = 1024;
   __shared__ double red[8][128];
   __shared__ int sidx[kStage];
   __shared__ float sgv[kStage];
-  const int c = blockIdx.x, t = blockIdx.y, k = threadIdx.x % C2, g = threadIdx.x / C2, G = blockDim.x / C2;   // G <= 8
+  const int k = threadIdx.x % C2, g = threadIdx.x / C2;   // G <= 8 row groups of C2 threads; threads past G * C2 only help staging
+  const bool worker = g < G;
   double s = 0.0;
   for (int b0 = 0; b0 < B; b0 += kStage) {
     const int nb = min(kStage, B - b0);
@@ -1302,7 +1304,7 @@ __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict
       sgv[i] = gs[cloud * C3 + c];
     }
     __syncthreads();
-    for (int i = g; i < nb; i += G * 4) {
+    for (int i = g; worker && i < nb; i += G * 4) {
       float hv[4], gv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1318,13 +1320,27 @@ __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict
       for (int u = 0; u < 4; ++u) s += (double)gv[u] * hv[u];
     }
   }
-  red[g][k] = s;
+  if (worker) red[g][k] = s;
   __syncthreads();
   if (g == 0) {
     double tot = 0.0;
     for (int q = 0; q < G; ++q) tot += red[q][k];
     Sp[((size_t)t * C2 + k) * C3 + c] = (float)tot;
   }
+}
+__global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                                         int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
+{
+  sparse_dw_body(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, blockIdx.x, blockIdx.y, blockDim.x / C2);
+}
+// the three stages' Sp in one launch (the weight gradients wait for nothing but the optimiser): grid (max C3, 2, jobs), block 1024
+struct SparseDwJob { const float* gs; const int* idx; const float* h2; int B, N, C2, C3; float* Sp; int h2_bf16; };
+struct SparseDwJobs { SparseDwJob j[3]; };
+__global__ __launch_bounds__(1024) void sparse_dw_jobs_kernel(const SparseDwJobs jobs)
+{
+  const SparseDwJob& q = jobs.j[blockIdx.z];
+  if (!q.gs || (int)blockIdx.x >= q.C3) return;
+  sparse_dw_body(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y, min(8, 1024 / q.C2));
 }
 
 // two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)
@@ -1379,6 +1395,24 @@ __global__ __launch_bounds__(256) void combine_scale_kernel(const float* __restr
 {
   if (blockIdx.y == 2) combine_dw_body(Sp, nullptr, m, kdb, GW, E, R, C, dW, blockIdx.x);
   else scale_cols2_body(W, R, C, E, WE, 0, 2, nullptr, WT, 1, 1, blockIdx.x, blockIdx.y);
+}
+
+// The elementwise tails of the deferred weight-gradient work, all layers of the step in one launch each:
+//   centre jobs: G <- G - s s^T / M (+ mirror), m = s / M            grid (max ceil(C^2 / 256), 2 towers, jobs)
+//   combine jobs: dW = sum_t (Sp spscale - m kdb^T + GW diag(E))      grid (max ceil(R C / 256), 1, jobs)
+struct CentreJob { float* G; const float* s; int C; double M; float* m; };
+struct CentreJobs { CentreJob j[3]; };
+__global__ __launch_bounds__(256) void centre_gram_jobs_kernel(const CentreJobs jobs)
+{
+  const CentreJob& q = jobs.j[blockIdx.z];
+  if (q.G) centre_gram_body(q.G, q.s, q.C, q.M, q.m, blockIdx.x, blockIdx.y);
+}
+struct CombineJob { const float* Sp; const float* spscale; const float* m; const float* kdb; const float* GW; const float* E; int R, C; float* dW; };
+struct CombineJobs { CombineJob j[6]; };
+__global__ __launch_bounds__(256) void combine_dw_jobs_kernel(const CombineJobs jobs)
+{
+  const CombineJob& q = jobs.j[blockIdx.z];
+  if (q.Sp) combine_dw_body(q.Sp, q.spscale, q.m, q.kdb, q.GW, q.E, q.R, q.C, q.dW, blockIdx.x);
 }
 
 // qb[t][j] = -sum_i m[t][i] Q[t][i][j] - sum_c W[j][c] kdb[t][c] / M      (W: [R=Cin][C=Cout])

@@ -19,6 +19,8 @@ struct GemmArgs {
   float alpha;
   int accumulate;      // C += ...
   long batch_a, batch_b, batch_c;   // element strides between batch entries (blockIdx.z)
+  const float* kscale = nullptr;    // [K] or null: C = sum_k A(i,k) kscale[k] B(k,j) -- e.g. Q = W diag(E) W^T without materialising W diag(E)
+  long batch_k = 0;                 // its stride between batch entries
 };
 
 constexpr int kGemmWaves = 8, kGemmKC = 32, kGemmLd = 33;
@@ -36,6 +38,7 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
   const float* Bm = a.B + bz * a.batch_b;
   float* As = stage[wave][0];
   float* Bs = stage[wave][1];
+  const float* ksc = a.kscale ? a.kscale + bz * a.batch_k : nullptr;
   // K range of this wave: whole chunks
   const int nchunks = (a.K + kGemmKC - 1) / kGemmKC, per = (nchunks + kGemmWaves - 1) / kGemmWaves;
   const int c0 = wave * per, c1 = min(nchunks, c0 + per);
@@ -68,6 +71,10 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
       for (int t = 0; t < 16; ++t) { ra[t] = pa[t][oa]; rb[t] = pb[t][ob]; }
 #pragma unroll
       for (int t = 0; t < 16; ++t) { ra[t] = (va >> t) & 1u ? ra[t] : 0.f; rb[t] = (vb >> t) & 1u ? rb[t] : 0.f; }
+      if (ksc) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int e = lane + 64 * t; ra[t] *= ksc[kc + (a_kfast ? e & 31 : e >> 5)]; }
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -75,7 +82,7 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
         const int ak = a_kfast ? e & 31 : e >> 5, bk = b_jfast ? e >> 5 : e & 31;
         const int ka = min(kc + ak, a.K - 1) - ak, kb = min(kc + bk, a.K - 1) - bk;   // clamped chunk offsets
         const float xa = pa[t][(size_t)ka * a.sa_k], xb = pb[t][(size_t)kb * a.sb_k];
-        ra[t] = (((va >> t) & 1u) && kc + ak < a.K) ? xa : 0.f;
+        ra[t] = (((va >> t) & 1u) && kc + ak < a.K) ? xa * (ksc ? ksc[min(kc + ak, a.K - 1)] : 1.f) : 0.f;
         rb[t] = (((vb >> t) & 1u) && kc + bk < a.K) ? xb : 0.f;
       }
     }
@@ -134,6 +141,19 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small2(const GemmPair p)
   const int job = (int)blockIdx.x >= p.n0;
   const int t = (int)blockIdx.x - job * p.n0;
   gemm_small_tile(p.g[job], t % p.tx[job], t / p.tx[job], 0);
+}
+
+// Any number (<= kGemmJobs) of independent products in one launch: the weight-gradient GEMMs of a whole step (nine head layers,
+// Ghat W of six conv layers) have nothing to wait for but the optimiser, so they run as one launch after the backward's critical
+// path.  Tiles are numbered job after job (start[] = prefix sums); a job's batch entries (GemmArgs.batch_*) are consecutive tiles.
+constexpr int kGemmJobs = 18;
+struct GemmJobs { GemmArgs g[kGemmJobs]; int tx[kGemmJobs], ty[kGemmJobs], start[kGemmJobs + 1]; int n; };
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small_jobs(const GemmJobs jp)   // (2.6 KB of kernel arguments: under the 4 KB limit)
+{
+  int j = 0;
+  while (j + 1 < jp.n && (int)blockIdx.x >= jp.start[j + 1]) ++j;   // uniform
+  const int t = (int)blockIdx.x - jp.start[j], per = jp.tx[j] * jp.ty[j];
+  gemm_small_tile(jp.g[j], (t % per) % jp.tx[j], (t % per) / jp.tx[j], t / per);
 }
 
 // counter-based uniform in [0,1) for dropout when the host supplies none (tf.nn.dropout draws
