@@ -864,7 +864,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.Gc = S.gram2; f.m2 = S.m2;
     f.pa = PoolFinishArgs{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
                           S.tower_stride, S.row_stride, S.zhat_star, S.idx, 1};
-    hipLaunchKernelGGL(stat3_pool_finish_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), stat3_lds_bytes(C2), h->stream, f);
+    hipLaunchKernelGGL(stat3_pool_finish_kernel, dim3((C3 + kS3C - 1) / kS3C, 2), dim3(1024), stat3_lds_bytes(C2), h->stream, f);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         if (m) {
           const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
           hit_e[p] = c | ((id % kTT) << 16);
-          hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
+          const float g = a.gs[(size_t)cloud * a.C3 + c];   // split once: bf16 hi | lo << 16 (16 significant bits)
+          const unsigned vh = to_bf16_bits(g), vl = to_bf16_bits(g - __uint_as_float(vh << 16));
+          reinterpret_cast<unsigned*>(hit_g)[p] = vh | (vl << 16);
         }
         pos += __popcll(mask);
       }
@@ -204,27 +206,23 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         *reinterpret_cast<unsigned*>(base + ((ii + 8 * hsel) & 15) * kSpLd) = v;
       }
     }
-    {   // S hi / lo: S[row][j] = g_j where hit j lands on this row, else 0
-      const int r = tid >> 2;
-#pragma unroll
-      for (int oo = 0; oo < 2; ++oo) {
-        const int o = (tid & 3) * 2 + oo;
-        auto one = [&](int hi, unsigned& vh, unsigned& vl) {
-          const int hc = min(hi, he - 1);
-          const bool on = hi < he && (hit_e[hc] >> 16) == r;
-          const float g = on ? hit_g[hc] : 0.f;
-          vh = to_bf16_bits(g);
-          vl = to_bf16_bits(g - __uint_as_float(vh << 16));
-        };
-        auto two = [&](int k, unsigned& dh, unsigned& dl) {
-          unsigned h0, l0, h1, l1;
-          one(hb + o * 8 + 2 * k, h0, l0); one(hb + o * 8 + 2 * k + 1, h1, l1);
-          dh = h0 | (h1 << 16); dl = l0 | (l1 << 16);
-        };
-        uint4 ph, pl;
-        two(0, ph.x, pl.x); two(1, ph.y, pl.y); two(2, ph.z, pl.z); two(3, ph.w, pl.w);
-        *reinterpret_cast<uint4*>(spSh + r * kSpLd + o * 8) = ph;
-        *reinterpret_cast<uint4*>(spSl + r * kSpLd + o * 8) = pl;
+    {   // S hi / lo: S[row_j][j] = g_j.  Wave w owns rows 16 w .. 16 w + 15 of both tiles: it clears them (wide stores) and then drops
+        // its hits in -- LDS operations of one wave complete in order, so no barrier between the two.  (Built row by row from the hit
+        // arrays -- 32 LDS reads and 16 selects per thread -- this block was 3 - 4 k cycles of every tile.)
+      constexpr int kRowQ = kSpLd * 2 / 16;   // 16-byte pieces per row (9)
+      const uint4 z = {0u, 0u, 0u, 0u};
+      for (int i = lane; i < 16 * kRowQ; i += 64) {
+        reinterpret_cast<uint4*>(spSh + wave * 16 * kSpLd)[i] = z;
+        reinterpret_cast<uint4*>(spSl + wave * 16 * kSpLd)[i] = z;
+      }
+      const int hi = hb + lane;
+      if (hi < he) {
+        const int r = hit_e[hi] >> 16;
+        if ((r >> 4) == wave) {
+          const unsigned pk = reinterpret_cast<const unsigned*>(hit_g)[hi];
+          spSh[r * kSpLd + lane] = (unsigned short)(pk & 0xffffu);
+          spSl[r * kSpLd + lane] = (unsigned short)(pk >> 16);
+        }
       }
     }
   };
@@ -244,6 +242,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       }
   };
 
+  TilePoint nextp = GIVEN ? TilePoint{0.f, 0.f, 0.f} : tile_point_request(pc, a.N, 0, tid);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
@@ -278,7 +277,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
       }
     } else {
-    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    tile_point_store(nextp, xf, xs, tid);
+    if (tile + 1 < ntiles) nextp = tile_point_request(pc, a.N, tile + 1, tid);   // in flight for the whole of this tile
     __syncthreads();
     B2_STAMP(1);
     if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
@@ -1068,9 +1068,42 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
 {
   __shared__ double red[32][33];
   const ReduceJob jb = jobs.j[bz];
+  if (t >= jb.towers) return;
+  if (!jb.is_double && jb.n >= 2048 && (jb.n & 3) == 0 && jb.S >= 32) {
+    // wide fp32 jobs (the per-cloud Gram / U2 partials: 16 k columns x hundreds of slices, tens of MB): a wave reads one slice row
+    // of 256 columns as 64 x 16 bytes (1 KB segments instead of the 128-byte ones of the narrow layout below), sixteen waves take
+    // the slices round robin with eight loads in flight each; fp64 accumulation, fixed order.  Block bx <-> columns [256 bx, 256 bx + 256).
+    __shared__ double wred[16][256];
+    const long c0 = bx * 256L;
+    if (c0 >= jb.n) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long col = c0 + lane * 4;
+    const float* p = static_cast<const float*>(jb.part) + (size_t)t * jb.S * jb.n;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (col < jb.n)
+      for (int k = wv; k < jb.S; k += 16 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ku = k + 16 * u;
+          v[u] = ku < jb.S ? *reinterpret_cast<const f32x4*>(p + (size_t)ku * jb.n + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0 += (double)v[u][0]; a1 += (double)v[u][1]; a2 += (double)v[u][2]; a3 += (double)v[u][3]; }
+      }
+    wred[wv][lane * 4 + 0] = a0; wred[wv][lane * 4 + 1] = a1; wred[wv][lane * 4 + 2] = a2; wred[wv][lane * 4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 256 && c0 + threadIdx.x < jb.n) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += wred[k][threadIdx.x];
+      jb.out[(size_t)t * jb.n + c0 + threadIdx.x] = (float)tot * jb.alpha;
+    }
+    return;
+  }
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const long i = bx * 32L + cl;
-  if (t >= jb.towers || bx * 32L >= jb.n) return;
+  if (bx * 32L >= jb.n) return;
   double s = 0.0;
   if (i < jb.n) {
     if (jb.is_double) { const double* p = static_cast<const double*>(jb.part); for (int k = g; k < jb.S; k += 32) s += p[((size_t)t * jb.S + k) * jb.n + i]; }
@@ -1136,8 +1169,8 @@ __global__ __launch_bounds__(256) void gram_pool_finish_kernel(float* __restrict
 // The same launch finishes the stage's forward: EMA shadows (utils/tf_util.py:476-485), scale / shift / rstd / k for the backward,
 // the pooled features relu(bn(extreme)) with the arg-extreme row (pool_finish_body's arithmetic), and the centred Gram + column
 // means m2 the layer-3 identities of the backward read (kernels_train_bwd.h header).
-// grid (ceil(C3 / 32), 2 towers), block 1024 = 32 channels x 32 row groups; dynamic LDS: Ghat [C2][C2] floats, W3 columns
-// [C2][32] doubles, s [C2] doubles.
+// grid (ceil(C3 / 8), 2 towers), block 1024 = 8 channels x 128 row groups; dynamic LDS: Ghat [C2][C2] floats, W3 columns
+// [C2][8] doubles, s [C2] doubles.
 // ---------------------------------------------------------------------------------
 struct Stat3Args {
   const float* G;        // [2][C2*C2] reduced Gram, 32 x 32 blocks on / above the block diagonal valid
@@ -1151,19 +1184,22 @@ struct Stat3Args {
   PoolFinishArgs pa;     // ext / idx2 / sgn / bias / pooled / zhat_star / idx (scale, shift, mean, var: the arrays above)
 };
 
+constexpr int kS3C = 8;   // channels per workgroup: (C3 / 8) x 2 workgroups -- 256 at C3 = 1024 (with 32 channels per workgroup the launch ran on 64 CUs: 45 us)
 __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem3[];
-  __shared__ double red[32][32];
-  __shared__ float cst[4][32];   // mean, var, scale, shift of the block's channels
-  const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, cl = tid & 31, g = tid >> 5, c = blockIdx.x * 32 + cl;
+  __shared__ double red[1024 / kS3C][kS3C];
+  __shared__ float cst[4][kS3C];   // mean, var, scale, shift of the block's channels
+  const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, cl = tid % kS3C, g = tid / kS3C, c = blockIdx.x * kS3C + cl;
+  constexpr int kG = 1024 / kS3C;                                     // row groups
   float* Gs = smem3;                                                  // [C2][C2 + 1]
-  double* ws = reinterpret_cast<double*>(Gs + (((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1));   // [C2][32]
-  double* ss = ws + (size_t)C2 * 32;                                  // [C2]
+  double* ws = reinterpret_cast<double*>(Gs + (((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1));   // [C2][kS3C]
+  double* ss = ws + (size_t)C2 * kS3C;                                // [C2]
   const float* G = a.G + (size_t)t * C2 * C2;
+  const double invM = 1.0 / a.M;
   for (int i = tid; i < C2; i += 1024) ss[i] = (double)a.s[t * C2 + i];
-  for (int e = tid; e < C2 * 32; e += 1024) {
-    const int i = e >> 5, cc = blockIdx.x * 32 + (e & 31);
+  for (int e = tid; e < C2 * kS3C; e += 1024) {
+    const int i = e / kS3C, cc = blockIdx.x * kS3C + (e % kS3C);
     float w = cc < C3 ? a.W[(size_t)i * C3 + cc] : 0.f;
     if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
     ws[e] = (double)w;
@@ -1172,31 +1208,31 @@ __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args
   // centred Gram into LDS (mirroring the blocks below the diagonal); rows [r0, r1) of it also go to HBM for the backward
   const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
   for (int e = tid; e < C2 * C2; e += 1024) {
-    const int i = e / C2, j = e % C2;
+    const int i = e / C2, j = e - i * C2;
     const float raw = (i >> 5) <= (j >> 5) ? G[e] : G[(size_t)j * C2 + i];
-    const float v = (float)((double)raw - ss[i] * ss[j] / a.M);
+    const float v = (float)((double)raw - ss[i] * (ss[j] * invM));
     Gs[i * (C2 + 1) + j] = v;
     if (i >= r0 && i < r1) a.Gc[(size_t)t * C2 * C2 + e] = v;
   }
-  if (blockIdx.x == 0) for (int i = tid; i < C2; i += 1024) a.m2[t * C2 + i] = (float)(ss[i] / a.M);
+  if (blockIdx.x == 0) for (int i = tid; i < C2; i += 1024) a.m2[t * C2 + i] = (float)(ss[i] * invM);
   __syncthreads();
-  // q = w^T Ghat w: thread (channel cl, group g) takes the rows i = g, g + 32, ...
+  // q = w^T Ghat w: thread (channel cl, group g) takes the rows i = g, g + kG, ...
   double q = 0.0;
-  for (int i = g; i < C2; i += 32) {
+  for (int i = g; i < C2; i += kG) {
     const float* gr = Gs + i * (C2 + 1);
-    double ti = 0.0;
+    double t0 = 0.0, t1 = 0.0;
 #pragma unroll 4
-    for (int j = 0; j < C2; ++j) ti += (double)gr[j] * ws[j * 32 + cl];
-    q += ws[i * 32 + cl] * ti;
+    for (int j = 0; j < C2; j += 2) { t0 += (double)gr[j] * ws[j * kS3C + cl]; t1 += (double)gr[j + 1] * ws[(j + 1) * kS3C + cl]; }
+    q += ws[i * kS3C + cl] * (t0 + t1);
   }
   red[g][cl] = q;
   __syncthreads();
   if (g == 0 && c < C3) {
     double Q = 0.0, sw = 0.0;
-    for (int k = 0; k < 32; ++k) Q += red[k][cl];
-    for (int i = 0; i < C2; ++i) sw += ss[i] * ws[i * 32 + cl];
+    for (int k = 0; k < kG; ++k) Q += red[k][cl];
+    for (int i = 0; i < C2; ++i) sw += ss[i] * ws[i * kS3C + cl];
     const float bias = a.pa.bias[c];
-    const float mf = (float)(sw / a.M + (double)bias), vf = (float)fmax(Q / a.M, 0.0);
+    const float mf = (float)(sw * invM + (double)bias), vf = (float)fmax(Q * invM, 0.0);
     const float rs = 1.0f / sqrtf(vf + kBnEps), inv = a.gamma[t][c] * rs;
     a.mean[t * C3 + c] = mf; a.var[t * C3 + c] = vf;
     a.scale[t * C3 + c] = inv; a.shift[t * C3 + c] = (bias - mf) * inv + a.beta[t][c];
@@ -1212,7 +1248,7 @@ __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args
   // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices)
   const PoolFinishArgs& p = a.pa;
   const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cl], rs = 1.0f / sqrtf(cst[1][cl] + kBnEps), sc = cst[2][cl], sh = cst[3][cl];
-  for (int b = g; b < p.B; b += 32) {
+  for (int b = g; b < p.B; b += kG) {
     const int cloud = t * p.B + b;
     const size_t h0 = ((size_t)cloud * 2) * C3 + c, h1 = h0 + C3, i = (size_t)cloud * C3 + c;
     float e = p.ext[h0]; int bi = p.idx2[h0];
@@ -1223,7 +1259,7 @@ __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args
     p.zhat_star[i] = (e * sg + bias - mf) * rs;
   }
 }
-inline size_t stat3_lds_bytes(int C2) { return ((((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1)) * sizeof(float) + ((size_t)C2 * 32 + C2) * sizeof(double); }
+inline size_t stat3_lds_bytes(int C2) { return ((((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1)) * sizeof(float) + ((size_t)C2 * kS3C + C2) * sizeof(double); }
 
 // last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0
 struct Prep3Args {
@@ -1304,10 +1340,10 @@ __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, con
       sgv[i] = gs[cloud * C3 + c];
     }
     __syncthreads();
-    for (int i = g; worker && i < nb; i += G * 4) {
-      float hv[4], gv[4];
+    for (int i = g; worker && i < nb; i += G * 8) {
+      float hv[8], gv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int iu = i + u * G;
         gv[u] = iu < nb ? sgv[iu] : 0.f;
         hv[u] = 0.f;
@@ -1317,7 +1353,7 @@ __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, con
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += (double)gv[u] * hv[u];
+      for (int u = 0; u < 8; ++u) s += (double)gv[u] * hv[u];
     }
   }
   if (worker) red[g][k] = s;

@@ -526,7 +526,7 @@ static inline size_t dg_bwd_edge_lds(int C1, int C2, bool bf16 = false)
 {
   const int ld0 = ((C1 + 7) & ~7) + 4;
   return ((size_t)2 * kTT * 8 + 2 * (size_t)kTT * ld0 + (size_t)kTT * (C2 + 4) + (size_t)C2 * (C1 + 4)) * sizeof(float) +
-         (size_t)kTT * C2 + kTT * 24 + (size_t)C2 * kTT + (size_t)C2 * 24 + (bf16 ? (size_t)kTT * (C1 + 8) * sizeof(unsigned short) : 0);
+         (size_t)kTT * (C2 + 4) + kTT * 24 + (size_t)C2 * (kTT + 4) + (size_t)C2 * 24 + (bf16 ? (size_t)kTT * (C1 + 8) * sizeof(unsigned short) : 0);
 }
 
 // BF16 ("train_matmul_bf16", dgcnn): h1 is the ROUNDED h1 of the forward (fp32 tile of rounded values + a bf16 copy) and the dense
@@ -547,11 +547,15 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   float* D = X + kTT * ld0;
   float* DP = D + kTT * ld0;
   float* V2 = DP + kTT * ldp;
-  unsigned char* SL = reinterpret_cast<unsigned char*>(V2 + C2 * ldv);   // [64][C2]  columns of the row, grouped by slot
-  unsigned char* SO = SL + kTT * C2;                                     // [64][24]  group offsets
-  unsigned char* SLc = SO + kTT * 24;                                      // [C2][64]  rows of the column, grouped by slot
-  unsigned char* SOc = SLc + C2 * kTT;                                   // [C2][24]
-  unsigned char* AK = reinterpret_cast<unsigned char*>(D);                 // [64][C2] staging (tile start only)
+  // byte tiles with row strides of 4 bytes more than a power of two: lanes that walk a COLUMN of them (the P2 team reads SLc[c][j] for 64
+  // consecutive c, the column-list build reads AK[row][c] for 64 rows) then fall into 64 different banks instead of 4 (stride 64 B:
+  // 16-way conflicts) or 2 (stride 128 B: 32-way) -- a third of this kernel's LDS cycles were bank conflicts (profiles/r02_train_dgcnn_pmc)
+  constexpr int ldsl = C2 + 4, ldsc = kTT + 4, ldak = C2 + 4;
+  unsigned char* SL = reinterpret_cast<unsigned char*>(V2 + C2 * ldv);   // [64][ldsl]  columns of the row, grouped by slot
+  unsigned char* SO = SL + kTT * ldsl;                                   // [64][24]  group offsets
+  unsigned char* SLc = SO + kTT * 24;                                      // [C2][ldsc]  rows of the column, grouped by slot
+  unsigned char* SOc = SLc + C2 * ldsc;                                  // [C2][24]
+  unsigned char* AK = reinterpret_cast<unsigned char*>(D);                 // [64][ldak] staging (tile start only)
   constexpr int ldh = C1 + 8, KG16 = C1 / 16;
   unsigned short* Xh = reinterpret_cast<unsigned short*>(SOc + C2 * 24);   // bf16 mode: h1 [64][C1 + 8]  (all sizes above are multiples of 16 bytes)
   constexpr int CT1 = (C1 + 31) >> 5, KGq = (C1 + 7) >> 3;
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         const bool ok = row < nvalid;
         *reinterpret_cast<f32x4*>(DP + row * ldp + q * 4) =
             ok ? *reinterpret_cast<const f32x4*>(a.dyp + base + (size_t)row * C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<unsigned*>(AK + row * C2 + q * 4) =
+        *reinterpret_cast<unsigned*>(AK + row * ldak + q * 4) =
             ok ? *reinterpret_cast<const unsigned*>(a.argk + base + (size_t)row * C2 + q * 4) : 0xffffffffu;
       }
       BE_TSTAMP(12, 40);
@@ -650,12 +654,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       for (int row = wave; row < kTT; row += kBEW) {   // row lists: lane <-> columns lane, lane + 64
         const int c0 = lane, c1 = lane + 64;
         const float d0 = DP[row * ldp + c0];
-        const int k0 = AK[row * C2 + c0];
+        const int k0 = AK[row * ldak + c0];
         const int a0 = d0 != 0.f ? k0 : 255;
         int a1 = 255;
         if constexpr (C2 > 64) {
           const float d1 = DP[row * ldp + c1];
-          const int k1 = AK[row * C2 + c1];
+          const int k1 = AK[row * ldak + c1];
           a1 = d1 != 0.f ? k1 : 255;
         }
         int pos = 0, offv = 0, l0 = 0, h0 = 0, l1 = 0, h1 = 0;
@@ -670,17 +674,17 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         if (lane <= kDgK) SO[row * 24 + lane] = (unsigned char)offv;
         const int s0 = a0 & 31, s1 = a1 & 31;   // (255 -> lane 31: fetched, not used)
         const int p0 = from_lane(s0, offv) + rank_in(from_lane(s0, l0), from_lane(s0, h0));
-        if (a0 < kDgK) SL[row * C2 + p0] = (unsigned char)c0;
+        if (a0 < kDgK) SL[row * ldsl + p0] = (unsigned char)c0;
         if constexpr (C2 > 64) {
           const int n0 = __popc(l0) + __popc(h0);   // lane s: the slot's entries among the first 64 columns
           const int p1 = from_lane(s1, offv) + from_lane(s1, n0) + rank_in(from_lane(s1, l1), from_lane(s1, h1));
-          if (a1 < kDgK) SL[row * C2 + p1] = (unsigned char)c1;
+          if (a1 < kDgK) SL[row * ldsl + p1] = (unsigned char)c1;
         }
       }
       BE_TSTAMP(14, 40);
       for (int c = wave; c < C2; c += kBEW) {        // column lists: lane <-> row
         const float dv = DP[lane * ldp + c];
-        const int kv = AK[lane * C2 + c];
+        const int kv = AK[lane * ldak + c];
         const int av = dv != 0.f ? kv : 255;
         int pos = 0, offv = 0, l0 = 0, h0 = 0;
         dg_static_for<0, kDgK>([&](auto S) {
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         if (lane <= kDgK) SOc[c * 24 + lane] = (unsigned char)offv;
         const int sv = av & 31;
         const int pp = from_lane(sv, offv) + rank_in(from_lane(sv, l0), from_lane(sv, h0));
-        if (av < kDgK) SLc[c * kTT + pp] = (unsigned char)lane;
+        if (av < kDgK) SLc[c * ldsc + pp] = (unsigned char)lane;
       }
 #undef DG_PARK3
 #undef DG_PARK2
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
       for (int j = j0; j < j1; j += 4) {
         int cc[4]; float g[4]; f32x4 w0[4], w1[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cc[u] = SL[p1row * C2 + min(j + u, j1 - 1)];
+        for (int u = 0; u < 4; ++u) cc[u] = SL[p1row * ldsl + min(j + u, j1 - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) g[u] = j + u < j1 ? DP[p1row * ldp + cc[u]] : 0.f;
 #pragma unroll
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         for (int j = j0; j < j1; j += 2) {   // two entries per trip (see P1)
           int rr[2]; float g[2]; f32x4 hv[2][kP2Q];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) rr[u] = SLc[p2c * kTT + min(j + u, j1 - 1)];
+          for (int u = 0; u < 2; ++u) rr[u] = SLc[p2c * ldsc + min(j + u, j1 - 1)];
 #pragma unroll
           for (int u = 0; u < 2; ++u) g[u] = j + u < j1 ? DP[rr[u] * ldp + p2c] : 0.f;
 #pragma unroll

@@ -91,6 +91,28 @@ __device__ __forceinline__ void load_tile_xform(const float* __restrict__ pc, co
   }
 }
 
+// the same in two halves -- request the tile's raw points (registers), transform + store them later -- so that a pass can ask for tile
+// t + 1 while it works on tile t (the load's HBM / L2 round trip sat exposed at the head of every tile: 2.1 - 2.6 k cycles in pass B2)
+struct TilePoint { float x, y, z; };
+__device__ __forceinline__ TilePoint tile_point_request(const float* __restrict__ pc, int N, int tile, int tid)
+{
+  TilePoint p = {0.f, 0.f, 0.f};
+  if (tid < kTT) {
+    const float* q = pc + (size_t)min(tile * kTT + tid, N - 1) * 3;
+    p.x = q[0]; p.y = q[1]; p.z = q[2];
+  }
+  return p;
+}
+__device__ __forceinline__ void tile_point_store(const TilePoint& p, const float* __restrict__ xf, float* __restrict__ xs, int tid)
+{
+  if (tid < kTT) {
+    const float x = p.x - xf[0], y = p.y - xf[1], z = p.z - xf[2];
+    xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+    xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+    xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+  }
+}
+
 // layer 1 on the VALU: out[row][c] = relu((x' . w[:,c]) * sc + sh); rows >= nvalid are written as 0.
 // Layer1W holds the thread's weights / scale / shift for its (<= 4) channel groups c0, c0 + 32, ...: loaded once per
 // workgroup (layer1_load) instead of once per tile -- the reload put an L2 round trip in front of every tile's first barrier.
