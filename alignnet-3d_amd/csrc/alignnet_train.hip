@@ -110,6 +110,7 @@ struct TrainWS {
   float *gen_part = nullptr, *gen_dwpart = nullptr, *gen_ppart = nullptr, *gen_cA = nullptr, *gen_cB = nullptr, *gen_wt = nullptr;
   int gen_tiles = 0, gen_slabs = 0;
   Deferred defer;
+  bool glue_folded = false;   // the last backbone backward ran the stage glue inside dg_b0_cloud (fwd_bwd_device skips the glue launches)
 };
 
 }  // namespace alignnet
@@ -432,7 +433,7 @@ static void def_reduce(alignnet_handle* h, TrainWS* w, const ReduceJob& j)
 static void def_sparse(alignnet_handle* h, TrainWS* w, const SparseDwJob& j)
 {
   if (w->defer.on) { w->defer.sp.push_back(j); return; }
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3(j.C3, 2), dim3(j.C2 * (1024 / j.C2 > 8 ? 8 : 1024 / j.C2)), 0, h->stream, j.gs, j.idx, j.h2, j.B, j.N, j.C2, j.C3, j.Sp, j.h2_bf16);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3((j.C3 + kSdC - 1) / kSdC, 2), dim3(kSdC * j.C2), 0, h->stream, j.gs, j.idx, j.h2, j.B, j.N, j.C2, j.C3, j.Sp, j.h2_bf16);
 }
 static void def_centre(alignnet_handle* h, TrainWS* w, const CentreJob& j)
 {
@@ -462,9 +463,9 @@ static int flush_deferred(alignnet_handle* h)
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, h->stream, J);
   }
   if (!d.sp.empty()) {
-    SparseDwJobs J{}; int cmax = 0;
-    for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); }
-    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3(cmax, 2, (unsigned)d.sp.size()), dim3(1024), 0, h->stream, J);
+    SparseDwJobs J{}; int cmax = 0, c2max = 0;
+    for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); c2max = std::max(c2max, d.sp[i].C2); }
+    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(kSdC * c2max), 0, h->stream, J);
   }
   if (!d.cen.empty()) {
     CentreJobs J{}; size_t emax = 0;
@@ -1014,6 +1015,14 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
   auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
   auto g256t = [](size_t n) { return dim3((unsigned)((n + 255) / 256), 2); };
+  w->glue_folded = false;
+  auto set_glue = [&](DgB0Args& z) {   // the glue towards the previous stage rides on dg_b0_cloud (its thread 0 per cloud)
+    if (getenv("ALIGNNET_NO_GLUE_FOLD") || s == 0) return;
+    const int nb = h->cfg.num_bins;
+    z.glue = s == 2 ? 3 : 2; z.xform = S.xform; z.pcls = w->cls; z.nb = nb;
+    z.d_s2c = w->d_s2c; z.d_o2 = w->d_o[1]; z.ldo2 = 3 + 2 * nb; z.d_s1c = w->d_s1c; z.d_o0 = w->d_o[0];
+    w->glue_folded = true;
+  };
 
   // ---- layer 3 (sparse + Gram identities) ----
   Prep3Args p3;
@@ -1111,24 +1120,29 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     def_combine(h, w, CombineJob{S.u2, S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w)});
   };
   const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
-  if (dg || fwd_gram)   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
-    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(S.s1e, 1, (long)(C1), S.s1),
-                        rjob(S.s1e, 1, (long)(C1), S.m1, (float)(1.0 / Me)));
-  else      // m1 = s1 / M (qbias needs it before B1)
-    launch_reduce_multi(h, 3, rjob(w->dbg2_part, 2 * B, (long)(C2 * 2), w->dbg2), rjob(w->s1_part, B * sG, (long)(C1), S.s1),
-                        rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / M)));
-  hipLaunchKernelGGL(prep_hidden_kernel, dim3((C2 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg2, S.var[1], P(h, L[1]->p_bn[0][1]),
-                     P(h, L[1]->p_bn[1][1]), C2, Me, G(h, w, L[1]->p_bn[0][0]), G(h, w, L[1]->p_bn[1][0]), G(h, w, L[1]->p_bn[0][1]),
-                     G(h, w, L[1]->p_bn[1][1]), S.E2, S.kdb2, S.k2, w->rstd2);
+  {   // totals of (dbeta2, dgamma2) over the clouds + the hidden layer's backward coefficients, and s1 / m1 = s1 / M (qbias needs it before B1): one launch
+    PrepHiddenArgs ph;
+    ph.part = w->dbg2_part; ph.S = 2 * B; ph.var = S.var[1]; ph.gamma[0] = P(h, L[1]->p_bn[0][1]); ph.gamma[1] = P(h, L[1]->p_bn[1][1]); ph.C = C2; ph.M = Me;
+    for (int t = 0; t < 2; ++t) { ph.dbeta[t] = G(h, w, L[1]->p_bn[t][0]); ph.dgamma[t] = G(h, w, L[1]->p_bn[t][1]); }
+    ph.E = S.E2; ph.kdb = S.kdb2; ph.kk = S.k2; ph.rstd = w->rstd2;
+    ReduceJobs J{};
+    if (dg || fwd_gram) {   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
+      J.j[0] = rjob(S.s1e, 1, (long)(C1), S.s1); J.j[1] = rjob(S.s1e, 1, (long)(C1), S.m1, (float)(1.0 / Me));
+    } else {
+      J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / M));
+    }
+    hipLaunchKernelGGL(prep_hidden_reduce_kernel, dim3((std::max(C1, C2) + 31) / 32, 2, 3), dim3(1024), 0, h->stream, ph, J);
+  }
   if (!acc_in_b1) layer2_weight_grad();
-  hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, nullptr, w->W2E, 0, 0, S.k2, w->V2, 1, 2);   // V2[t] = (W2 diag(k2))^T  [C2][C1]
+  const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
+  // V2[t] = (W2 diag(k2))^T  [C2][C1]  (the bf16 pass B1 packs its image straight from W2 and k2: no fp32 copy)
+  if (!b1_bf16) hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, nullptr, w->W2E, 0, 0, S.k2, w->V2, 1, 2);
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
   {   // Q2[t] = W2 diag(E2[t]) W2^T
     GemmArgs g = gemm_args(W2, C2, 1, W2, 1, C2, w->Q2, C1, 1, C1, C1, C2);
     g.batch_a = 0; g.batch_b = 0; g.batch_c = (long)C1 * C1; g.kscale = S.E2; g.batch_k = C2;
     hipLaunchKernelGGL(gemm_small, dim3((C1 + 31) / 32, (C1 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
   }
-  const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
   if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
   const bool dg_bf16 = dg && h->train_bf16;   // edge pass with h1 Q2 on bf16 MFMA: bf16 images of Q2, packed with the bias row
   constexpr size_t kQ2hMax = 2 * 4 * 512;     // [CT1 <= 2][KG16 <= 4][64 lanes][8]
@@ -1177,6 +1191,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
+    set_glue(z);
     hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
     hipLaunchKernelGGL(dg_b0_cloud<6>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1.f, 1));
@@ -1201,7 +1216,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
     PackBf16Jobs pj{};
     for (int t = 0; t < 2; ++t) {
-      pj.src[t] = w->V2 + (size_t)t * C1 * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;
+      pj.src[t] = W2; pj.tr[t] = 1; pj.rowscale[t] = S.k2 + (size_t)t * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;   // V2[t] = (W2 diag(k2[t]))^T
       pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;
     }
     hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 4), dim3(256), 0, h->stream, pj, 4, 8u, QBiasArgs{w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b});
@@ -1229,6 +1244,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (b1h) z.slices = 1;   // train_bwd_b1_bf16 reduces the four partials itself
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
+    set_glue(z);
     hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
     hipLaunchKernelGGL(dg_b0_cloud<3>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1.f, 1));
@@ -1320,15 +1336,19 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   w->defer.on = !getenv("ALIGNNET_NO_DEFER");   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
-  hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
-                     B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
-  hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
+  if (!w->glue_folded) {
+    hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
+                       B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
+    hipLaunchKernelGGL(stage2_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->d_s2c, B, w->d_o[1], 3 + nb2, w->d_s1c);
+  }
   const int C2l = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout, C1l = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
   if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
-  hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
-  // s1c = o1 + center_mean  ->  d_o1 = d_s1c
-  HIP_TRY(h, hipMemcpyAsync(w->d_o[0], w->d_s1c, (size_t)B2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (!w->glue_folded) {
+    hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
+    // s1c = o1 + center_mean  ->  d_o1 = d_s1c
+    HIP_TRY(h, hipMemcpyAsync(w->d_o[0], w->d_s1c, (size_t)B2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  }
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
   const bool deferred = w->defer.on;

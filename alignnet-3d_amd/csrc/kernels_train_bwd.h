@@ -750,7 +750,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
 // ---------------------------------------------------------------------------------
 constexpr int kPackBf16Jobs = 12;
-struct PackBf16Jobs { const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs]; };
+struct PackBf16Jobs {
+  const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs];
+  const float* rowscale[kPackBf16Jobs];   // null, or [K]: element (k, c) is multiplied by rowscale[k] before rounding
+  int tr[kPackBf16Jobs];                  // 1: the source is stored transposed, element (k, c) at src[c * K + k] -- e.g. V2 = (W2 diag(k2))^T straight from W2
+};
 // bf16 MFMA images (layout and sign folding as described in kernels_train_fwd.h; gamma null = no folding) of up to nine matrices in one launch,
 // grid (blocks, jobs): a training step re-packs 9 + 3 x 6 images, each its own 4.5 us launch before
 __device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsigned bx, int q, unsigned gx)
@@ -774,7 +778,10 @@ __device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsig
     const int kg = t % KG, ct = t / KG;
     const int k = 16 * kg + 8 * (lane >> 5) + s8, c = 32 * ct + (lane & 31);
     float v = 0.f;
-    if (k < K && c < C) v = (!gamma || gamma[c] >= 0.f) ? W[(size_t)k * C + c] : -W[(size_t)k * C + c];
+    if (k < K && c < C) {
+      const float x = (j.tr[q] ? W[(size_t)c * K + k] : W[(size_t)k * C + c]) * (j.rowscale[q] ? j.rowscale[q][k] : 1.f);
+      v = (!gamma || gamma[c] >= 0.f) ? x : -x;
+    }
     j.dst[q][idx] = to_bf16_bits(v);
   }
 }
@@ -1207,8 +1214,10 @@ __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args
   __syncthreads();
   // centred Gram into LDS (mirroring the blocks below the diagonal); rows [r0, r1) of it also go to HBM for the backward
   const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
+  const bool pow2 = (C2 & (C2 - 1)) == 0;
+  const int sh2 = 31 - __builtin_clz(C2);
   for (int e = tid; e < C2 * C2; e += 1024) {
-    const int i = e / C2, j = e - i * C2;
+    const int i = pow2 ? e >> sh2 : e / C2, j = e - i * C2;   // (a run-time division per element was a quarter of this kernel)
     const float raw = (i >> 5) <= (j >> 5) ? G[e] : G[(size_t)j * C2 + i];
     const float v = (float)((double)raw - ss[i] * (ss[j] * invM));
     Gs[i * (C2 + 1) + j] = v;
@@ -1216,20 +1225,38 @@ __global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args
   }
   if (blockIdx.x == 0) for (int i = tid; i < C2; i += 1024) a.m2[t * C2 + i] = (float)(ss[i] * invM);
   __syncthreads();
-  // q = w^T Ghat w: thread (channel cl, group g) takes the rows i = g, g + kG, ...
-  double q = 0.0;
-  for (int i = g; i < C2; i += kG) {
-    const float* gr = Gs + i * (C2 + 1);
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll 4
-    for (int j = 0; j < C2; j += 2) { t0 += (double)gr[j] * ws[j * kS3C + cl]; t1 += (double)gr[j + 1] * ws[(j + 1) * kS3C + cl]; }
-    q += ws[i * kS3C + cl] * (t0 + t1);
+  // q_c = w_c^T Ghat w_c for the block's 8 channels.  Thread (row i, j-slice): one Ghat element feeds eight multiply-adds (one per
+  // channel; the channels' weights come as four 16-byte LDS reads), so the LDS traffic per multiply-add is a fifth of a
+  // one-channel-per-thread loop's.  Then a butterfly over the lanes and a 16-way sum over the waves.
+  {
+    const int nsl = 1024 / C2 > 0 ? 1024 / C2 : 1;                 // j-slices (8 at C2 = 128)
+    const int i = tid % C2, js = tid / C2;
+    double acc8[kS3C];
+#pragma unroll
+    for (int k = 0; k < kS3C; ++k) acc8[k] = 0.0;
+    if (js < nsl) {
+      const int jw = (C2 + nsl - 1) / nsl, j0 = js * jw, j1 = min(C2, j0 + jw);
+      const float* gr = Gs + i * (C2 + 1);
+      for (int j = j0; j < j1; ++j) {
+        const double gv = (double)gr[j];
+#pragma unroll
+        for (int k = 0; k < kS3C; ++k) acc8[k] += gv * ws[j * kS3C + k];
+      }
+#pragma unroll
+      for (int k = 0; k < kS3C; ++k) acc8[k] *= ws[i * kS3C + k];
+    }
+#pragma unroll
+    for (int k = 0; k < kS3C; ++k) {
+      double v = acc8[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
   }
-  red[g][cl] = q;
   __syncthreads();
   if (g == 0 && c < C3) {
     double Q = 0.0, sw = 0.0;
-    for (int k = 0; k < kG; ++k) Q += red[k][cl];
+    for (int k = 0; k < 16; ++k) Q += red[k][cl];
     for (int i = 0; i < C2; ++i) sw += ss[i] * ws[i * kS3C + cl];
     const float bias = a.pa.bias[c];
     const float mf = (float)(sw * invM + (double)bias), vf = (float)fmax(Q * invM, 0.0);
@@ -1318,37 +1345,76 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
   if (rstd) rstd[t * C + c] = rs;
 }
 
+// hidden layer, straight from pass B2's per-cloud partials: the slice reduction of (dbeta2, dgamma2) and prep_hidden_kernel's
+// arithmetic in one launch, next to up to two independent slice reductions (s1, m1):
+// grid (max(ceil(C / 32), x extent of the jobs), 2, 1 + njobs), block 1024; z = 0 is the hidden-layer part.
+struct PrepHiddenArgs {
+  const double* part; int S;   // [2][S][C][2]
+  const float* var; const float* gamma[2]; int C; double M;
+  float* dbeta[2]; float* dgamma[2];
+  float *E, *kdb, *kk, *rstd;   // [2][C]
+};
+__global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHiddenArgs a, const ReduceJobs jobs)
+{
+  if (blockIdx.z > 0) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z - 1); return; }
+  __shared__ double red[32][32][2];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  if (blockIdx.x * 32 >= a.C) return;
+  double sb = 0.0, sg = 0.0;
+  if (c < a.C)
+    for (int k = g; k < a.S; k += 32) {
+      const double* p = a.part + (((size_t)t * a.S + k) * a.C + c) * 2;
+      sb += p[0]; sg += p[1];
+    }
+  red[g][cl][0] = sb; red[g][cl][1] = sg;
+  __syncthreads();
+  if (g != 0 || c >= a.C) return;
+  sb = 0.0; sg = 0.0;
+  for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
+  const float sbf = (float)sb, sgf = (float)sg;   // (as the two-launch form: totals rounded to fp32 first)
+  const float rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps), k = a.gamma[t][c] * rs;
+  a.dbeta[t][c] = sbf; a.dgamma[t][c] = sgf;
+  if (a.E) a.E[t * a.C + c] = (float)(-(double)k * rs * sgf / a.M);
+  if (a.kdb) a.kdb[t * a.C + c] = k * sbf;
+  if (a.kk) a.kk[t * a.C + c] = k;
+  if (a.rstd) a.rstd[t * a.C + c] = rs;
+}
+
 // Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
 // h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16).  The (index, weight) pairs of the channel are staged in
 // LDS first so that the row gathers are independent loads (4 in flight per thread).
+// One workgroup = kSdC consecutive channels of one tower: group g (C2 threads, one per column k of h2) owns channel c0 + g and walks
+// all B clouds with eight row gathers in flight.  The (index, weight) pairs of the kSdC channels are staged per 128 clouds as
+// 32-byte segments (one channel per workgroup read them 4 bytes at a time with a stride of C3: as much sector traffic as the
+// row gathers themselves).
+constexpr int kSdC = 8, kSdStage = 128;
 __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                               int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int c, int t, int G)
+                                               int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int cb, int t)
 {
-  constexpr int kStage = 1024;
-  __shared__ double red[8][128];
-  __shared__ int sidx[kStage];
-  __shared__ float sgv[kStage];
-  const int k = threadIdx.x % C2, g = threadIdx.x / C2;   // G <= 8 row groups of C2 threads; threads past G * C2 only help staging
-  const bool worker = g < G;
+  __shared__ int sidx[kSdStage][kSdC];
+  __shared__ float sgv[kSdStage][kSdC];
+  const int k = threadIdx.x % C2, g = threadIdx.x / C2, c0 = cb * kSdC, c = c0 + g;
+  const bool worker = g < kSdC && c < C3;
   double s = 0.0;
-  for (int b0 = 0; b0 < B; b0 += kStage) {
-    const int nb = min(kStage, B - b0);
+  for (int b0 = 0; b0 < B; b0 += kSdStage) {
+    const int nb = min(kSdStage, B - b0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-      const size_t cloud = (size_t)t * B + b0 + i;
-      sidx[i] = idx[cloud * C3 + c];
-      sgv[i] = gs[cloud * C3 + c];
+    for (int i = threadIdx.x; i < nb * kSdC; i += blockDim.x) {
+      const int bi = i / kSdC, cc = c0 + i % kSdC;
+      const size_t cloud = (size_t)t * B + b0 + bi;
+      sidx[bi][i % kSdC] = cc < C3 ? idx[cloud * C3 + cc] : 0;
+      sgv[bi][i % kSdC] = cc < C3 ? gs[cloud * C3 + cc] : 0.f;
     }
     __syncthreads();
-    for (int i = g; worker && i < nb; i += G * 8) {
+    for (int i = 0; worker && i < nb; i += 8) {
       float hv[8], gv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int iu = i + u * G;
-        gv[u] = iu < nb ? sgv[iu] : 0.f;
+        const int iu = i + u;
+        gv[u] = iu < nb ? sgv[min(iu, nb - 1)][g] : 0.f;
         hv[u] = 0.f;
         if (gv[u] != 0.f) {
-          const size_t e = (((size_t)t * B + b0 + iu) * N + sidx[iu]) * C2 + k;
+          const size_t e = (((size_t)t * B + b0 + iu) * N + sidx[iu][g]) * C2 + k;
           hv[u] = h2_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h2)[e] << 16) : h2[e];
         }
       }
@@ -1356,27 +1422,21 @@ __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, con
       for (int u = 0; u < 8; ++u) s += (double)gv[u] * hv[u];
     }
   }
-  if (worker) red[g][k] = s;
-  __syncthreads();
-  if (g == 0) {
-    double tot = 0.0;
-    for (int q = 0; q < G; ++q) tot += red[q][k];
-    Sp[((size_t)t * C2 + k) * C3 + c] = (float)tot;
-  }
+  if (worker) Sp[((size_t)t * C2 + k) * C3 + c] = (float)s;
 }
 __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
                                                          int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
 {
-  sparse_dw_body(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, blockIdx.x, blockIdx.y, blockDim.x / C2);
+  sparse_dw_body(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, blockIdx.x, blockIdx.y);
 }
-// the three stages' Sp in one launch (the weight gradients wait for nothing but the optimiser): grid (max C3, 2, jobs), block 1024
+// the three stages' Sp in one launch (the weight gradients wait for nothing but the optimiser): grid (max ceil(C3 / kSdC), 2, jobs), block kSdC * C2
 struct SparseDwJob { const float* gs; const int* idx; const float* h2; int B, N, C2, C3; float* Sp; int h2_bf16; };
 struct SparseDwJobs { SparseDwJob j[3]; };
 __global__ __launch_bounds__(1024) void sparse_dw_jobs_kernel(const SparseDwJobs jobs)
 {
   const SparseDwJob& q = jobs.j[blockIdx.z];
-  if (!q.gs || (int)blockIdx.x >= q.C3) return;
-  sparse_dw_body(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y, min(8, 1024 / q.C2));
+  if (!q.gs || (int)blockIdx.x * kSdC >= q.C3) return;
+  sparse_dw_body(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y);
 }
 
 // two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)

@@ -867,6 +867,10 @@ struct DgB0Args {
   float* dbg1;              // [2][C1][2] totals (dbeta1, dgamma1)
   float* p_part;            // [2B][D][C1]
   float* gx; float* grot;   // [2B][3], [2B]
+  // glue between the stages, folded into dg_b0_cloud (one thread per cloud does what stage3/2/1_glue_bwd_kernel do, kernels_train_head.h):
+  // 3 = after the stage-3 backbone (frame of stage 3: x3 = (p - s2c) R(-theta)), 2 = after the stage-2 backbone (x2 = p - s1c), 0 = none
+  int glue = 0; const float* xform = nullptr; const int* pcls = nullptr; int nb = 0;
+  float* d_s2c = nullptr; float* d_o2 = nullptr; int ldo2 = 0; float* d_s1c = nullptr; float* d_o0 = nullptr;
 };
 
 template <int D>
@@ -967,6 +971,27 @@ __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2
   __syncthreads();
   if (threadIdx.x < 3) a.gx[cloud * 3 + threadIdx.x] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x]);
   if (threadIdx.x == 3) a.grot[cloud] = (float)(red[0][3] + red[1][3]);
+  if (a.glue && threadIdx.x == 0) {
+    const float g0 = (float)(red[0][0] + red[1][0]), g1 = (float)(red[0][1] + red[1][1]), g2 = (float)(red[0][2] + red[1][2]), gr = (float)(red[0][3] + red[1][3]);
+    if (a.glue == 3) {
+      // x3 = (p - s2c) R(-theta):  dL/ds2c = -(gx R^T),  dL/dtheta = -grot -> the residual logit of the predicted class (tp8.py:298-301);
+      // s2c = o2[:, :3] + s1c (tp8.py:117):  d_o2[:, :3] = d_s2c,  d_s1c += d_s2c
+      const float* R = a.xform + cloud * 12 + 3;
+      float d[3];
+      d[0] = a.d_s2c[cloud * 3 + 0] - (g0 * R[0] + g1 * R[1] + g2 * R[2]);
+      d[1] = a.d_s2c[cloud * 3 + 1] - (g0 * R[3] + g1 * R[4] + g2 * R[5]);
+      d[2] = a.d_s2c[cloud * 3 + 2] - (g0 * R[6] + g1 * R[7] + g2 * R[8]);
+      const float pinb = (float)(3.141592653589793 / (double)a.nb);
+      a.d_o2[(size_t)cloud * a.ldo2 + 3 + a.nb + a.pcls[cloud]] += -gr * pinb;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { a.d_s2c[cloud * 3 + e] = d[e]; a.d_o2[(size_t)cloud * a.ldo2 + e] = d[e]; a.d_s1c[cloud * 3 + e] += d[e]; }
+    } else {
+      // x2 = p - s1c (tp8.py:113):  d_s1c -= gx;  s1c = o1 + center_mean:  d_o1 = d_s1c
+      const float gg[3] = {g0, g1, g2};
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { const float v = a.d_s1c[cloud * 3 + e] - gg[e]; a.d_s1c[cloud * 3 + e] = v; a.d_o0[cloud * 3 + e] = v; }
+    }
+  }
 }
 
 // first and second moments of the stage-frame points x' of every cloud (the D = 3 input of the two kernels above), fp64.  grid 2B
