@@ -433,7 +433,7 @@ static void def_reduce(alignnet_handle* h, TrainWS* w, const ReduceJob& j)
 static void def_sparse(alignnet_handle* h, TrainWS* w, const SparseDwJob& j)
 {
   if (w->defer.on) { w->defer.sp.push_back(j); return; }
-  hipLaunchKernelGGL(sparse_dw_kernel, dim3((j.C3 + kSdC - 1) / kSdC, 2), dim3(kSdC * j.C2), 0, h->stream, j.gs, j.idx, j.h2, j.B, j.N, j.C2, j.C3, j.Sp, j.h2_bf16);
+  hipLaunchKernelGGL(sparse_dw_kernel, dim3((j.C3 + kSdC - 1) / kSdC, 2), dim3(1024), 0, h->stream, j.gs, j.idx, j.h2, j.B, j.N, j.C2, j.C3, j.Sp, j.h2_bf16);
 }
 static void def_centre(alignnet_handle* h, TrainWS* w, const CentreJob& j)
 {
@@ -465,7 +465,8 @@ static int flush_deferred(alignnet_handle* h)
   if (!d.sp.empty()) {
     SparseDwJobs J{}; int cmax = 0, c2max = 0;
     for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); c2max = std::max(c2max, d.sp[i].C2); }
-    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(kSdC * c2max), 0, h->stream, J);
+    (void)c2max;
+    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(1024), 0, h->stream, J);
   }
   if (!d.cen.empty()) {
     CentreJobs J{}; size_t emax = 0;
@@ -713,11 +714,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
     f.rstd = S.rstd[l]; f.k = S.kk[l];
     if (keep) { *keep = f; return; }   // launched by the caller together with independent reductions (stat_finish_reduce_kernel)
-    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, h->stream, f);
+    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + kSfC - 1) / kSfC, 2), dim3(1024), 0, h->stream, f);
   };
   // the reductions of the Gram / column-sum partials of h2 over the clouds (the last layer's statistics follow from them: stat3 below)
   auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) {
-    ja.out = S.gram2raw;
+    ja.out = S.gram2raw; ja.upper_c = C2;   // (only the upper 32 x 32 blocks of the per-cloud Grams are valid -- and read)
     launch_reduce_multi(h, 2, ja, jb);
   };
   if (dg) {
@@ -1131,7 +1132,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     } else {
       J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / M));
     }
-    hipLaunchKernelGGL(prep_hidden_reduce_kernel, dim3((std::max(C1, C2) + 31) / 32, 2, 3), dim3(1024), 0, h->stream, ph, J);
+    hipLaunchKernelGGL(prep_hidden_reduce_kernel, dim3(std::max((C2 + kPhC - 1) / kPhC, (C1 + 31) / 32), 2, 3), dim3(1024), 0, h->stream, ph, J);
   }
   if (!acc_in_b1) layer2_weight_grad();
   const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)

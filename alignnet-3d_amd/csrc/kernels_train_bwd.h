@@ -1068,7 +1068,8 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
 
 // Several slice reductions in one launch (every launch costs >= 4.7 us on the one stream of a step, whatever its work):
 // grid (max over jobs of ceil(n/32), 2 towers, jobs).  Same summation order as reduce_slices_kernel.
-struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers; };
+struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers;
+                   int upper_c = 0; };   // upper_c = C > 0: the columns are a C x C matrix of which only the 32 x 32 blocks on / above the block diagonal are summed (Gram partials)
 constexpr int kReduceJobs = 16;
 struct ReduceJobs { ReduceJob j[kReduceJobs]; };
 __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx, int t, int bz)
@@ -1087,7 +1088,9 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
     const long col = c0 + lane * 4;
     const float* p = static_cast<const float*>(jb.part) + (size_t)t * jb.S * jb.n;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (col < jb.n)
+    bool valid = col < jb.n;
+    if (jb.upper_c > 0 && valid) { const int i = (int)(col / jb.upper_c), j = (int)(col - (long)i * jb.upper_c); valid = (i >> 5) <= (j >> 5); }
+    if (valid)
       for (int k = wv; k < jb.S; k += 16 * 8) {
         f32x4 v[8];
 #pragma unroll
@@ -1100,7 +1103,9 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
       }
     wred[wv][lane * 4 + 0] = a0; wred[wv][lane * 4 + 1] = a1; wred[wv][lane * 4 + 2] = a2; wred[wv][lane * 4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 256 && c0 + threadIdx.x < jb.n) {
+    bool wr = threadIdx.x < 256 && c0 + threadIdx.x < jb.n;
+    if (jb.upper_c > 0 && wr) { const long cc = c0 + threadIdx.x; const int i = (int)(cc / jb.upper_c), j = (int)(cc - (long)i * jb.upper_c); wr = (i >> 5) <= (j >> 5); }
+    if (wr) {
       double tot = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += wred[k][threadIdx.x];
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs job
 __global__ __launch_bounds__(1024) void stat_finish_reduce_kernel(const StatFinishArgs f, const ReduceJobs jobs, int njobs)
 {
   if ((int)blockIdx.z < njobs) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z); return; }
-  const int gx = (f.C + 31) / 32;
+  const int gx = (f.C + kSfC - 1) / kSfC;
   if ((int)blockIdx.x < gx) stat_finish_body(f, blockIdx.x, blockIdx.y, gx);
 }
 
@@ -1347,30 +1352,39 @@ __global__ void prep_hidden_kernel(const float* __restrict__ dbg /*[2][C][2]*/, 
 
 // hidden layer, straight from pass B2's per-cloud partials: the slice reduction of (dbeta2, dgamma2) and prep_hidden_kernel's
 // arithmetic in one launch, next to up to two independent slice reductions (s1, m1):
-// grid (max(ceil(C / 32), x extent of the jobs), 2, 1 + njobs), block 1024; z = 0 is the hidden-layer part.
+// grid (max(ceil(C / 8), x extent of the jobs), 2, 1 + njobs), block 1024; z = 0 is the hidden-layer part.
 struct PrepHiddenArgs {
   const double* part; int S;   // [2][S][C][2]
   const float* var; const float* gamma[2]; int C; double M;
   float* dbeta[2]; float* dgamma[2];
   float *E, *kdb, *kk, *rstd;   // [2][C]
 };
+constexpr int kPhC = 8;   // channels per workgroup: 128 slice groups x 8 channels (32 channels x 32 groups left the launch on 8 workgroups walking 16-deep load chains: 21 us)
 __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHiddenArgs a, const ReduceJobs jobs)
 {
   if (blockIdx.z > 0) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z - 1); return; }
-  __shared__ double red[32][32][2];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
-  if (blockIdx.x * 32 >= a.C) return;
+  __shared__ double red[1024 / kPhC][kPhC][2];
+  const int cl = threadIdx.x % kPhC, g = threadIdx.x / kPhC, c = blockIdx.x * kPhC + cl, t = blockIdx.y;
+  constexpr int kG = 1024 / kPhC;
+  if ((int)blockIdx.x * kPhC >= a.C) return;
   double sb = 0.0, sg = 0.0;
   if (c < a.C)
-    for (int k = g; k < a.S; k += 32) {
-      const double* p = a.part + (((size_t)t * a.S + k) * a.C + c) * 2;
-      sb += p[0]; sg += p[1];
+    for (int k = g; k < a.S; k += kG * 4) {
+      double v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ku = min(k + u * kG, a.S - 1);
+        const double* p = a.part + (((size_t)t * a.S + ku) * a.C + c) * 2;
+        v0[u] = p[0]; v1[u] = p[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (k + u * kG < a.S) { sb += v0[u]; sg += v1[u]; }
     }
   red[g][cl][0] = sb; red[g][cl][1] = sg;
   __syncthreads();
   if (g != 0 || c >= a.C) return;
   sb = 0.0; sg = 0.0;
-  for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
+  for (int q = 0; q < kG; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   const float sbf = (float)sb, sgf = (float)sg;   // (as the two-launch form: totals rounded to fp32 first)
   const float rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps), k = a.gamma[t][c] * rs;
   a.dbeta[t][c] = sbf; a.dgamma[t][c] = sgf;
@@ -1383,46 +1397,84 @@ __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHidd
 // Sp[t][k][c] = sum_b gs[b,c] * h2[(cloud, idx[b,c]), k]      grid (C3, 2), block (C2 <= 128) x 4 cloud groups
 // h2_bf16: the forward stored h2 as bf16 (train_matmul_bf16).  The (index, weight) pairs of the channel are staged in
 // LDS first so that the row gathers are independent loads (4 in flight per thread).
-// One workgroup = kSdC consecutive channels of one tower: group g (C2 threads, one per column k of h2) owns channel c0 + g and walks
-// all B clouds with eight row gathers in flight.  The (index, weight) pairs of the kSdC channels are staged per 128 clouds as
-// 32-byte segments (one channel per workgroup read them 4 bytes at a time with a stride of C3: as much sector traffic as the
-// row gathers themselves).
+// One workgroup = kSdC consecutive channels of one tower.  Thread (slot = tid / Q, piece = tid % Q) gathers 16-byte pieces (Q = the
+// row's 16-byte pieces: C2 / 8 in bf16, C2 / 4 in fp32): a wave-level load fetches 1 KB of rows instead of 128 B, four hits of a
+// channel in flight per thread; the slots' partial sums meet in LDS, channel after channel.  (One element per thread -- 2-byte
+// loads, 256 of them per thread -- ran at 0.9 TB/s.)  The (index, weight) pairs of the kSdC channels are staged per 128 clouds.
 constexpr int kSdC = 8, kSdStage = 128;
 __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
                                                int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int cb, int t)
 {
   __shared__ int sidx[kSdStage][kSdC];
   __shared__ float sgv[kSdStage][kSdC];
-  const int k = threadIdx.x % C2, g = threadIdx.x / C2, c0 = cb * kSdC, c = c0 + g;
-  const bool worker = g < kSdC && c < C3;
-  double s = 0.0;
+  __shared__ float part[64][132];          // [slot][column]: up to 64 slots x 128 columns (+4: bank spread)
+  const int tid = threadIdx.x, nt = blockDim.x, c0 = cb * kSdC;
+  const int per = h2_bf16 ? 8 : 4, Q = C2 / per;                  // elements per 16-byte piece, pieces per row
+  const int nslot = min(64, nt / Q), slot = tid / Q, piece = tid % Q;
+  const bool worker = slot < nslot;
+  double tot[kSdC];                                                // (threads tid < C2: the channel sums of column tid)
+#pragma unroll
+  for (int cc = 0; cc < kSdC; ++cc) tot[cc] = 0.0;
   for (int b0 = 0; b0 < B; b0 += kSdStage) {
     const int nb = min(kSdStage, B - b0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nb * kSdC; i += blockDim.x) {
+    for (int i = tid; i < nb * kSdC; i += nt) {
       const int bi = i / kSdC, cc = c0 + i % kSdC;
       const size_t cloud = (size_t)t * B + b0 + bi;
       sidx[bi][i % kSdC] = cc < C3 ? idx[cloud * C3 + cc] : 0;
       sgv[bi][i % kSdC] = cc < C3 ? gs[cloud * C3 + cc] : 0.f;
     }
     __syncthreads();
-    for (int i = 0; worker && i < nb; i += 8) {
-      float hv[8], gv[8];
+#pragma unroll 1
+    for (int cc = 0; cc < kSdC; ++cc) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (worker)
+        for (int i = slot; i < nb; i += nslot * 4) {
+          uint4 v[4]; float g[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int iu = i + u;
-        gv[u] = iu < nb ? sgv[min(iu, nb - 1)][g] : 0.f;
-        hv[u] = 0.f;
-        if (gv[u] != 0.f) {
-          const size_t e = (((size_t)t * B + b0 + iu) * N + sidx[iu][g]) * C2 + k;
-          hv[u] = h2_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h2)[e] << 16) : h2[e];
+          for (int u = 0; u < 4; ++u) {
+            const int iu = i + u * nslot;
+            g[u] = iu < nb ? sgv[min(iu, nb - 1)][cc] : 0.f;
+            v[u] = uint4{0u, 0u, 0u, 0u};
+            if (g[u] != 0.f) {
+              const size_t row = ((size_t)t * B + b0 + iu) * N + sidx[iu][cc];
+              v[u] = h2_bf16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(h2) + row * C2 + piece * 8)
+                             : *reinterpret_cast<const uint4*>(h2 + row * C2 + piece * 4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (h2_bf16) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc[2 * e] = fmaf(g[u], __uint_as_float(w4[e] << 16), acc[2 * e]);
+                acc[2 * e + 1] = fmaf(g[u], __uint_as_float(w4[e] & 0xffff0000u), acc[2 * e + 1]);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[u], __uint_as_float(w4[e]), acc[e]);
+            }
+          }
         }
-      }
+      __syncthreads();   // the previous channel's readers of `part` are done
+      if (worker) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += (double)gv[u] * hv[u];
+        for (int e = 0; e < 8; ++e) if (e < per) part[slot][piece * per + e] = acc[e];
+      }
+      __syncthreads();
+      if (tid < C2) {
+        double sum = 0.0;
+        for (int q = 0; q < nslot; ++q) sum += (double)part[q][tid];
+        tot[cc] += sum;
+      }
     }
   }
-  if (worker) Sp[((size_t)t * C2 + k) * C3 + c] = (float)s;
+  if (tid < C2) {
+#pragma unroll
+    for (int cc = 0; cc < kSdC; ++cc)
+      if (c0 + cc < C3) Sp[((size_t)t * C2 + tid) * C3 + c0 + cc] = (float)tot[cc];
+  }
 }
 __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
                                                          int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)

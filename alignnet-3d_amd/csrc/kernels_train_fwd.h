@@ -925,24 +925,32 @@ struct StatFinishArgs {
 };
 
 // (body and kernel apart: the step also runs it as one job of a merged launch, kernels_train_bwd.h)
-__device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx, int t, int gx)   // grid (gx = ceil(C/32), 2), block 32 channels x 32 slice groups
+constexpr int kSfC = 8;   // channels per workgroup (x 128 slice groups): with 32 x 32 a C = 64 layer ran on four workgroups walking 32-deep chains of loads
+__device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx, int t, int gx)   // grid (gx = ceil(C / kSfC), 2), block 1024
 {
-  __shared__ double red[32][32][2];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = bx * 32 + cl;
+  __shared__ double red[1024 / kSfC][kSfC][2];
+  constexpr int kG = 1024 / kSfC;
+  const int cl = threadIdx.x % kSfC, g = threadIdx.x / kSfC, c = bx * kSfC + cl;
   if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
     for (int i = bx * 1024 + threadIdx.x; i < a.next_C; i += gx * 1024) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
   const int S = a.B * a.slices;
   double s = 0.0, ss = 0.0;
   if (c < a.C)
-    for (int b = g; b < S; b += 32) {
-      const double* p = a.part + ((size_t)(t * S + b) * a.C + c) * 2;
-      s += p[0]; ss += p[1];
+    for (int b = g; b < S; b += kG * 4) {   // four slices per trip: eight independent loads in flight
+      double v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* p = a.part + ((size_t)(t * S + min(b + u * kG, S - 1)) * a.C + c) * 2;
+        v0[u] = p[0]; v1[u] = p[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (b + u * kG < S) { s += v0[u]; ss += v1[u]; }
     }
   red[g][cl][0] = s; red[g][cl][1] = ss;
   __syncthreads();
   if (g != 0 || c >= a.C) return;
   s = 0.0; ss = 0.0;
-  for (int q = 0; q < 32; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
+  for (int q = 0; q < kG; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
   const double mean = s / a.count;
   const double var = fmax(ss / a.count - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;
