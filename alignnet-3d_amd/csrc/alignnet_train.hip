@@ -103,6 +103,7 @@ struct TrainWS {
   unsigned short* b1imgh = nullptr;   // bf16 images of V2 (128 -> 64) and Q2 (64 -> 64), both towers (train_bf16, shipped widths)
   unsigned short* wp2h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the hidden layers (train_bf16, no sign folding)
   unsigned short* wp3h[3] = {nullptr, nullptr, nullptr};   // bf16 images of the three lift layers (train_bf16)
+  unsigned short* w2th[3] = {nullptr, nullptr, nullptr};   // bf16 MFMA images of round(W2)^T (K = C2, C = C1) per stage: dense edge backward of the dgcnn branch (train_bf16)
   unsigned short* w3th[3] = {nullptr, nullptr, nullptr};   // bf16 round(W3)^T [C3][C2] per stage: rows gathered by pass B2's sparse part (train_bf16, shipped widths)
   // general-depth PointNet stages (kernels_train_generic.h): pre-BatchNorm activations of every layer stay in HBM
   struct GenStage { float* X0; float* Z[kMaxConv]; float *mean[kMaxConv], *rstd[kMaxConv], *scale[kMaxConv], *shift[kMaxConv]; int* idx; } gen[3];
@@ -140,7 +141,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->stage_pack) hipFree(w->stage_pack);
   if (w->q3imgh) hipFree(w->q3imgh);
   if (w->b1imgh) hipFree(w->b1imgh);
-  for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); if (w->w3th[s]) hipFree(w->w3th[s]); }
+  for (int s = 0; s < 3; ++s) { if (w->wp3h[s]) hipFree(w->wp3h[s]); if (w->wp2h[s]) hipFree(w->wp2h[s]); if (w->w3th[s]) hipFree(w->w3th[s]); if (w->w2th[s]) hipFree(w->w2th[s]); }
   delete w;
   h->train_ws = nullptr;
 }
@@ -527,6 +528,11 @@ static int pack_all_weights(alignnet_handle* h)
       const size_t n2 = (size_t)((L2.cout + 31) / 32) * ((L2.cin + 15) / 16) * 512;
       if (!w->wp2h[s]) HIP_TRY(h, hipMalloc(&w->wp2h[s], n2 * sizeof(unsigned short)));
       pj.src[nj] = P(h, L2.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->wp2h[s]; pj.K[nj] = L2.cin; pj.C[nj] = L2.cout; ++nj;
+      if (h->cfg.backbone == 1) {   // dense edge backward (dg_train_bwd_edge_dense): image of W2^T, element (k = c2, c = c1) = W2[c1][c2]
+        const size_t nt = (size_t)((L2.cin + 31) / 32) * ((L2.cout + 15) / 16) * 512;
+        if (!w->w2th[s]) HIP_TRY(h, hipMalloc(&w->w2th[s], nt * sizeof(unsigned short)));
+        pj.src[nj] = P(h, L2.p_w); pj.gamma[nj] = nullptr; pj.tr[nj] = 1; pj.dst[nj] = w->w2th[s]; pj.K[nj] = L2.cout; pj.C[nj] = L2.cin; ++nj;
+      }
       if (h->cfg.backbone == 0 && L2.cin == 64 && L2.cout == 128) {   // pass B2's sparse part on the matrix pipe (train_bwd_b2: SPM)
         if (!w->w3th[s]) HIP_TRY(h, hipMalloc(&w->w3th[s], (size_t)L.cin * L.cout * sizeof(unsigned short)));
         pj.src[nj] = P(h, L.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->w3th[s]; pj.K[nj] = -L.cin; pj.C[nj] = L.cout; ++nj;
@@ -578,6 +584,10 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<32, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge<64, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(stat3_pool_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (+ 8.5 KiB static)
   done.mark(h->cfg.device);
   return 0;
@@ -1108,6 +1118,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !getenv("ALIGNNET_PHASE2_LEGACY");   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
+  bool u2_prescaled = false;
   auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
     def_reduce(h, w, rjob(S.u2_part, B, (long)(C1 * C2), S.u2));
     if (fwd_gram || dg) def_reduce(h, w, rjob(S.g1f, 1, (long)(C1 * C1), S.g1));
@@ -1118,7 +1129,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
       g.batch_a = (long)C1 * C1; g.batch_b = 0; g.batch_c = (long)C1 * C2;
       def_gemm(h, w, g, 2);
     }
-    def_combine(h, w, CombineJob{S.u2, S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w)});
+    def_combine(h, w, CombineJob{S.u2, u2_prescaled ? nullptr : S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w)});
   };
   const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
   {   // totals of (dbeta2, dgamma2) over the clouds + the hidden layer's backward coefficients, and s1 / m1 = s1 / M (qbias needs it before B1): one launch
@@ -1165,8 +1176,15 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2, dg_bf16);
+    const bool dense = dg_bf16 && !getenv("ALIGNNET_DG_SPARSE");   // bf16 mode: both dy2_s products as dense bf16 MFMAs on per-slot tiles
+    e.k2 = S.k2; e.w2th = w->w2th[s];
+    const size_t eld = dg_bwd_edge_dense_lds(C1, C2);
   { ProfScope prof_scope(h, PK_DG_BWD_EDGE);
-    if (dg_bf16 && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128, true>), eg, eb, el, h->stream, e);
+    if (dense && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge_dense<64, 128>), eg, eb, eld, h->stream, e);
+    else if (dense && C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge_dense<64, 64>), eg, eb, eld, h->stream, e);
+    else if (dense && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge_dense<32, 128>), eg, eb, eld, h->stream, e);
+    else if (dense) hipLaunchKernelGGL((dg_train_bwd_edge_dense<32, 64>), eg, eb, eld, h->stream, e);
+    else if (dg_bf16 && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128, true>), eg, eb, el, h->stream, e);
     else if (dg_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64, true>), eg, eb, el, h->stream, e);
     else if (dg_bf16 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128, true>), eg, eb, el, h->stream, e);
     else if (dg_bf16) hipLaunchKernelGGL((dg_train_bwd_edge<32, 64, true>), eg, eb, el, h->stream, e);
@@ -1175,6 +1193,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
     else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
   }
+    u2_prescaled = dense;   // the dense form accumulates U2 diag(k2)
     if (e.stamps) {
       long long st[19];
       hipStreamSynchronize(h->stream);

@@ -512,6 +512,8 @@ struct DgBwdArgs {
   const float* q2img; long q2img_stride;   // per-tower MFMA image of Q2 [C1][C1]
   const unsigned short* q2imgh; long q2imgh_stride;   // bf16 mode: per-tower bf16 MFMA image of Q2
   const float* q2b;                    // [2][C1]
+  const float* k2 = nullptr;           // [2][C2] gamma2 rstd2 (dense form: folded into the staged dp)
+  const unsigned short* w2th = nullptr;   // dense form: bf16 MFMA image of round(W2)^T (K = C2, C = C1), shared by the towers
   const float* dyp;                    // [2B*N][C2]  dp * [p > 0]   (pass B2, GIVEN)
   const unsigned char* argk;           // [2B*N][C2]
   float* u2_part; float* g1_part;      // [2B][C1*C2], [2B][C1*C1] (upper blocks)
@@ -841,6 +843,234 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
         const int q = d - 4 * half;   // this half-wave holds d = 4 half .. 4 half + 3 (d = 7 does not exist); the rest of the slice is zero
         dst[(size_t)d * C1] = (q >= 0 && q < 4) ? pd[q & 3] : 0.0;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// backward edge pass, dense form ("train_matmul_bf16" with the dgcnn backbone).  Same contract as dg_train_bwd_edge (same arguments,
+// same outputs), but the two products with dy2_s = dp [argk == s] -- 1 / k dense -- run on the matrix pipe as bf16 MFMAs instead of
+// as VALU walks over per-tile index lists:
+//     dh1_s = (dy2_s diag(k2)) round(W2)^T + h1_s Q2 + q2b          A = P masked (row-major, hi + lo),  B = image of W2^T (registers)
+//     U2'  += h1_s^T (dy2_s diag(k2))                               A = Xh^T,  B = P^T masked (hi + lo);   U2' = U2 diag(k2)
+// P = dp diag(k2) is split into bf16 hi + lo (16 significant bits) ONCE per tile, row-major and transposed, next to the arg-k bytes in
+// both layouts; per neighbour slot the MFMA operand fragments are masked on the way into the registers (8 bytes of arg-k per 16-byte
+// fragment: byte == slot -> keep), so nothing is rebuilt per slot.  h1 is the rounded h1 of the forward, W2 the rounded operand of
+// the forward (what the oracle's straight-through backward uses).  No row / column lists (48 k of a tile's 265 k cycles), no sparse
+// loops whose slowest lane sets the barrier, no fp32 copy of h1; the h1 tiles are double-buffered: one barrier per slot.
+// LDS: es [3][64][8] | 2 x (Xh [64][C1+8] | XhT [C1][72]) | Ph, Pl [64][C2+8] | PhT, PlT [C2][72] | AK [64][C2+4] | AKT [C2][72] bytes
+// ---------------------------------------------------------------------------------
+static inline size_t dg_bwd_edge_dense_lds(int C1, int C2)
+{
+  return (size_t)3 * kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * 2 +
+         (2 * (size_t)kTT * (C2 + 8) + 2 * (size_t)C2 * (kTT + 8)) * 2 + (size_t)kTT * (C2 + 4) + (size_t)C2 * (kTT + 8);
+}
+
+// 8 arg-k bytes (w0 = elements 0..3, w1 = 4..7) against the slot: 16-bit lane masks for the 8 bf16 values of a fragment
+__device__ __forceinline__ uint4 dg_slot_mask(unsigned w0, unsigned w1, unsigned slot4)
+{
+  const unsigned x0 = w0 ^ slot4, x1 = w1 ^ slot4;   // a zero byte <=> arg-k == slot
+  auto pair = [](unsigned x, int sh) {
+    return ((x >> sh) & 0xffu ? 0u : 0x0000ffffu) | ((x >> (sh + 8)) & 0xffu ? 0u : 0xffff0000u);
+  };
+  return uint4{pair(x0, 0), pair(x0, 16), pair(x1, 0), pair(x1, 16)};
+}
+__device__ __forceinline__ bf16x8 dg_masked(const unsigned short* p, const uint4& m)
+{
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  v.x &= m.x; v.y &= m.y; v.z &= m.z; v.w &= m.w;
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+template <int C1, int C2>
+__global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwdArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
+  constexpr int ldh = C1 + 8, ldT = kTT + 8, ldak = C2 + 4, ldd = C2 + 8;
+  constexpr int CT1 = C1 / 32, CT2 = C2 / 32, KG1 = C1 / 16, KG2 = C2 / 16;
+  constexpr int kXbuf = kTT * ldh + C1 * ldT;                       // bf16 elements of one (Xh | XhT) buffer
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem + 3 * kTT * 8);
+  unsigned short* Ph = Xb + 2 * kXbuf;
+  unsigned short* Pl = Ph + kTT * ldd;
+  unsigned short* PhT = Pl + kTT * ldd;
+  unsigned short* PlT = PhT + C2 * ldT;
+  unsigned char* AK = reinterpret_cast<unsigned char*>(PlT + C2 * ldT);   // [64][ldak]
+  unsigned char* AKT = AK + kTT * ldak;                                    // [C2][ldT]
+  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const float* sc1 = a.sc1 + tower * C1;
+  const float* sh1 = a.sh1 + tower * C1;
+  const DgtLiftM<C1, kBEW> lw = dgt_liftm_load<C1, kBEW>(a.w1, sc1, sh1, wave, lane);
+  if (tid < 3 * kTT) { smem[tid * 8 + 6] = 0.f; smem[tid * 8 + 7] = 0.f; }   // k padding of the MFMA lift in the three es buffers
+  // roles: waves [0, nitems) own one dh1 item (channel tile of C1, 32-row group); the others share the CT1 x CT2 tiles of U2
+  constexpr int nitems = CT1 * 2, nuw = kBEW - nitems, nut = CT1 * CT2, kUPer = (nut + nuw - 1) / nuw;
+  bf16x8 w2f[KG2], q2f[KG1];     // dh1 waves: B fragments of W2^T (K = C2) and Q2 (K = C1) for the wave's channel tile, whole cloud
+  if (wave < nitems) {
+    const bf16x8* wi = reinterpret_cast<const bf16x8*>(a.w2th);
+    const bf16x8* qh = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2imgh_stride);
+#pragma unroll
+    for (int kg = 0; kg < KG2; ++kg) w2f[kg] = wi[((size_t)(wave >> 1) * KG2 + kg) * 64 + lane];
+#pragma unroll
+    for (int kg = 0; kg < KG1; ++kg) q2f[kg] = qh[((size_t)(wave >> 1) * KG1 + kg) * 64 + lane];
+  }
+  f32x16 uacc[kUPer];
+#pragma unroll
+  for (int i = 0; i < kUPer; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uacc[i][r] = 0.f;
+  double pd[4];
+  f32x16 pacc;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) pd[d] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
+
+  // edge features run two slots ahead of the MFMAs: es(it + 1) is written while slot it is lifted (three buffers: the dh1 waves of a
+  // slow slot it may still be reading es(it) when a fast wave writes es(it + 2)), the gather of slot it + 2 is in flight meanwhile
+  float v[6];
+  auto gather_slot = [&](int j) {
+    const int jt = j / a.k, js = j - jt * a.k;
+    dgt_gather(pc, nnc, a.N, a.k, min(jt * kTT + tid, a.N - 1), js, v);
+  };
+  if (tid < kTT) {
+    gather_slot(0);
+    dg_edge_to_lds(xf, v, smem + tid * 8);
+    if (total > 1) gather_slot(1);
+  }
+  __syncthreads();
+  for (int it = 0; it < total; ++it) {
+    const int tile = it / a.k, slot = it - tile * a.k;
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    const bool more = it + 1 < total;
+    float* es = smem + (it % 3) * kTT * 8;
+    unsigned short* Xh = Xb + (it & 1) * kXbuf;
+    unsigned short* XhT = Xh + kTT * ldh;
+    if (slot == 0) {
+      __syncthreads();   // the previous tile's readers of the P / arg-k tiles are done
+      // P = dp diag(k2) as bf16 hi / lo, row-major and transposed, and the arg-k bytes in both layouts: once per tile
+      const size_t base = ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
+      constexpr int c8 = C2 / 8;
+      for (int item = tid; item < kTT * c8; item += kBEW * 64) {
+        const int r = item / c8, o = item % c8;
+        const bool ok = r < nvalid;
+        const float* src = a.dyp + base + (size_t)r * C2 + o * 8;
+        const f32x4 d0 = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 d1 = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(a.k2 + tower * C2 + o * 8), k1 = *reinterpret_cast<const f32x4*>(a.k2 + tower * C2 + o * 8 + 4);
+        uint2 ak = {0xffffffffu, 0xffffffffu};
+        if (ok) ak = *reinterpret_cast<const uint2*>(a.argk + base + (size_t)r * C2 + o * 8);
+        const float dv[8] = {d0[0] * k0[0], d0[1] * k0[1], d0[2] * k0[2], d0[3] * k0[3], d1[0] * k1[0], d1[1] * k1[1], d1[2] * k1[2], d1[3] * k1[3]};
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          hi[e] = to_bf16_bits(dv[e]);
+          lo[e] = to_bf16_bits(dv[e] - __uint_as_float(hi[e] << 16));
+          const unsigned akb = ((e < 4 ? ak.x : ak.y) >> (8 * (e & 3))) & 0xffu;
+          PhT[(o * 8 + e) * ldT + r] = (unsigned short)hi[e];
+          PlT[(o * 8 + e) * ldT + r] = (unsigned short)lo[e];
+          AKT[(o * 8 + e) * ldT + r] = (unsigned char)akb;
+        }
+        *reinterpret_cast<uint4*>(Ph + r * ldd + o * 8) = uint4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+        *reinterpret_cast<uint4*>(Pl + r * ldd + o * 8) = uint4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+        *reinterpret_cast<unsigned*>(AK + r * ldak + o * 8) = ak.x;
+        *reinterpret_cast<unsigned*>(AK + r * ldak + o * 8 + 4) = ak.y;
+      }
+    }
+    dgt_liftm_bf16<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
+    if (more && tid < kTT) {
+      dg_edge_to_lds(xf, v, smem + ((it + 1) % 3) * kTT * 8 + tid * 8);
+      if (it + 2 < total) gather_slot(it + 2);
+    }
+    __syncthreads();   // the slot's only barrier: h1 tiles (and at a tile start the P tiles) complete, es of the next slot written
+    const unsigned slot4 = (unsigned)slot * 0x01010101u;
+    if (wave < nitems) {
+      // ---- dh1 = (P masked) W2^T + h1_s Q2 + q2b ; dy1 = dh1 [h1 > 0] ; Pdy += e^T dy1 ----
+      const int ct = wave >> 1, rg = wave & 1;
+      const int col = ct * 32 + (lane & 31);
+      const float qb = a.q2b[tower * C1 + col];
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = qb;
+      const int ei = lane & 31;
+      float ev[16]; unsigned short xm[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        xm[r] = Xh[row * ldh + col];
+        ev[r] = es[row * 8 + (ei & 7)];
+      }
+      const int arow = rg * 32 + (lane & 31);
+      const unsigned short* ah = Ph + arow * ldd + half * 8;
+      const unsigned short* al = Pl + arow * ldd + half * 8;
+      const unsigned char* am = AK + arow * ldak + half * 8;
+#pragma unroll
+      for (int kg = 0; kg < KG2; ++kg) {
+        const uint4 m = dg_slot_mask(*reinterpret_cast<const unsigned*>(am + kg * 16), *reinterpret_cast<const unsigned*>(am + kg * 16 + 4), slot4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dg_masked(ah + kg * 16, m), w2f[kg], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dg_masked(al + kg * 16, m), w2f[kg], acc, 0, 0, 0);
+      }
+      const unsigned short* ax = Xh + arow * ldh + half * 8;
+#pragma unroll
+      for (int kg = 0; kg < KG1; ++kg)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ax + kg * 16), q2f[kg], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float dy = (row < nvalid && xm[r] != 0) ? acc[r] : 0.f;
+        const float ea = ei < 6 ? ev[r] : (ei == 6 ? 1.f : 0.f);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea, dy, pacc, 0, 0, 0);
+      }
+      if (slot == a.k - 1) {   // fp32 sums of one tile (k * 64 rows) folded into fp64
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pd[q] += (double)pacc[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
+      }
+    } else {
+      // ---- U2' tiles of this wave: (it2, jt2) += Xh^T[32 it2 .., rows] . (P^T masked)[32 jt2 .., rows]  (K = the tile's 64 rows) ----
+#pragma unroll
+      for (int i = 0; i < kUPer; ++i) {
+        const int u = (wave - nitems) + i * nuw;
+        if (u < nut) {
+          const int it2 = u / CT2, jt2 = u % CT2;
+          const int brow = jt2 * 32 + (lane & 31);
+          const unsigned short* pa = XhT + (it2 * 32 + (lane & 31)) * ldT + half * 8;
+          const unsigned short* ph = PhT + brow * ldT + half * 8;
+          const unsigned short* pl = PlT + brow * ldT + half * 8;
+          const unsigned char* pm = AKT + brow * ldT + half * 8;
+#pragma unroll
+          for (int kg = 0; kg < kTT / 16; ++kg) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(pa + kg * 16);
+            const uint2 mk = *reinterpret_cast<const uint2*>(pm + kg * 16);
+            const uint4 m = dg_slot_mask(mk.x, mk.y, slot4);
+            uacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dg_masked(ph + kg * 16, m), uacc[i], 0, 0, 0);
+            uacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dg_masked(pl + kg * 16, m), uacc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (wave >= nitems) {
+#pragma unroll
+    for (int i = 0; i < kUPer; ++i) {
+      const int u = (wave - nitems) + i * nuw;
+      if (u < nut) {
+        const float zero[16] = {};
+        tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, u / CT2, u % CT2, C1, C2, uacc[i], lane, zero);
+      }
+    }
+  } else {
+    const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
+    double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * C1 + col;
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+      const int q = d - 4 * half;
+      dst[(size_t)d * C1] = (q >= 0 && q < 4) ? pd[q & 3] : 0.0;
     }
   }
 }
