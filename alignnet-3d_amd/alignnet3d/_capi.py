@@ -72,6 +72,8 @@ SYMBOLS = {
     "alignnet_set_param": (C.c_int, [H, C.c_char_p, FP, C.c_size_t]),
     "alignnet_forward": (C.c_int, [H, FP, FP, C.c_int32, C.POINTER(Outputs)]),
     "alignnet_forward_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(Outputs)]),
+    "alignnet_forward_submit": (C.c_int, [H, FP, FP, C.c_int32, C.POINTER(Outputs)]),
+    "alignnet_forward_wait": (C.c_int, [H]),
     "alignnet_eval_loss": (C.c_int, [H, C.POINTER(Labels), C.c_int32, FP, FP]),
     "alignnet_synchronize": (C.c_int, [H]),
     "alignnet_train_step": (C.c_int, [H, FP, FP, C.POINTER(Labels), C.c_int32, FP, C.POINTER(StepResult), C.POINTER(Outputs)]),

@@ -202,6 +202,33 @@ class Engine:
         self._check(self._lib.alignnet_forward(self._h, _fp(p1), _fp(p2), p1.shape[0], C.byref(o)))
         return arrs
 
+    # ---- pipelined host path: up to two batches in flight, the copy-in of batch i + 1 under the forward of batch i ----
+    def forward_submit(self, pcs1, pcs2):
+        """Queue one batch (returns at once); the matching forward_wait() returns its outputs.  At most two submits without a wait."""
+        p1, p2 = self._check_pcs(pcs1, pcs2)
+        arrs, o = self._alloc_outputs(p1.shape[0])
+        self._check(self._lib.alignnet_forward_submit(self._h, _fp(p1), _fp(p2), p1.shape[0], C.byref(o)))
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        self._inflight.append(arrs)   # (the C side writes into these arrays at wait(): keep them alive)
+
+    def forward_wait(self):
+        self._check(self._lib.alignnet_forward_wait(self._h))
+        return self._inflight.pop(0)
+
+    def forward_stream(self, batches):
+        """Generator over an iterable of (pcs1, pcs2): yields each batch's outputs in order, with two batches in flight."""
+        pending = 0
+        for pcs1, pcs2 in batches:
+            if pending == 2:
+                yield self.forward_wait()
+                pending -= 1
+            self.forward_submit(pcs1, pcs2)
+            pending += 1
+        while pending:
+            yield self.forward_wait()
+            pending -= 1
+
     def forward_device(self, d_pcs1, d_pcs2, B, d_out_ptrs=None):
         """Device pointers (ints); d_out_ptrs: dict name -> device pointer, or None to skip copies out."""
         o = _capi.Outputs()

@@ -193,6 +193,8 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h);
 extern "C" int alignnet_dataset_free(alignnet_handle* h);
 extern "C" void alignnet_comm_free(alignnet_handle* h);
 
+namespace { void pipe_free(alignnet_handle* h); }   // pipelined host path, defined with alignnet_forward_submit below
+
 extern "C" void alignnet_destroy(alignnet_handle* h)
 {
   if (!h) return;
@@ -201,6 +203,7 @@ extern "C" void alignnet_destroy(alignnet_handle* h)
   alignnet_comm_free(h);
   alignnet_train_ws_free(h);
   alignnet_dataset_free(h);
+  pipe_free(h);
   free_ws(h);
   for (auto& pr : h->prof_pending) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
   for (auto& pr : h->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -696,6 +699,124 @@ extern "C" int alignnet_forward_device(alignnet_handle* h, const float* d_pcs1, 
                     d_out->pred_pc1angle_logits, d_out->pred_pc2angle_logits};
   if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;
   return forward_device(h, d_pcs1, d_pcs2, B, outs);
+}
+
+// ---------------------------------------------------------------------------------
+// Pipelined host path (include/alignnet_hip.h: alignnet_forward_submit / alignnet_forward_wait).  The blocking alignnet_forward
+// serialises copy-in -> forward -> copy-out per batch from pageable buffers (the reference's own timing, train.py:447-449, has the
+// feed copy inside the timed region too).  Here a batch goes through a pinned staging slot: its H2D copy runs on a copy stream while
+// the compute stream is still busy with the previous batch, the forward waits for it on an event, and the D2H of the outputs goes
+// through a third stream into pinned memory; two slots, so two batches are in flight.
+// ---------------------------------------------------------------------------------
+namespace {
+struct PipeSlot {
+  int cap = 0; int B = 0; bool busy = false;
+  float* h_in[2] = {nullptr, nullptr};      // pinned staging of pcs1 / pcs2
+  float* h_out = nullptr;                   // pinned staging of the eight outputs
+  float* d_in[2] = {nullptr, nullptr};
+  float* d_out = nullptr; float* d_outs[8];
+  size_t out_off[8];
+  alignnet_outputs user{};
+  hipEvent_t ev_in = nullptr, ev_fwd = nullptr, ev_out = nullptr;
+};
+struct Pipe { PipeSlot slot[2]; hipStream_t s_in = nullptr, s_out = nullptr; uint64_t submitted = 0, completed = 0; };
+
+void pipe_free(alignnet_handle* h)
+{
+  if (!h->pipe) return;
+  Pipe* p = static_cast<Pipe*>(h->pipe);
+  if (p->s_in) hipStreamSynchronize(p->s_in);
+  if (p->s_out) hipStreamSynchronize(p->s_out);
+  for (PipeSlot& s : p->slot) {
+    for (int t = 0; t < 2; ++t) { if (s.h_in[t]) hipHostFree(s.h_in[t]); if (s.d_in[t]) hipFree(s.d_in[t]); }
+    if (s.h_out) hipHostFree(s.h_out);
+    if (s.d_out) hipFree(s.d_out);
+    if (s.ev_in) hipEventDestroy(s.ev_in);
+    if (s.ev_fwd) hipEventDestroy(s.ev_fwd);
+    if (s.ev_out) hipEventDestroy(s.ev_out);
+  }
+  if (p->s_in) hipStreamDestroy(p->s_in);
+  if (p->s_out) hipStreamDestroy(p->s_out);
+  delete p;
+  h->pipe = nullptr;
+}
+}  // namespace
+
+extern "C" int alignnet_forward_wait(alignnet_handle* h)
+{
+  if (!h) return 1;
+  Pipe* p = static_cast<Pipe*>(h->pipe);
+  if (!p || p->completed == p->submitted) return fail(h, "alignnet_forward_wait: no batch in flight");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  PipeSlot& s = p->slot[p->completed & 1];
+  HIP_TRY(h, hipEventSynchronize(s.ev_out));
+  float* host[8] = {s.user.pred_translations, s.user.pred_remaining_angle_logits, s.user.pred_s1_pc1centers, s.user.pred_s1_pc2centers,
+                    s.user.pred_s2_pc1centers, s.user.pred_s2_pc2centers, s.user.pred_pc1angle_logits, s.user.pred_pc2angle_logits};
+  const int nb2 = 2 * h->cfg.num_bins;
+  const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+  for (int i = 0; i < 8; ++i)
+    if (host[i]) std::memcpy(host[i], s.h_out + s.out_off[i], (size_t)s.B * widths[i] * sizeof(float));
+  s.busy = false;
+  p->completed++;
+  return 0;
+}
+
+extern "C" int alignnet_forward_submit(alignnet_handle* h, const float* pcs1, const float* pcs2, int32_t B, const alignnet_outputs* out)
+{
+  if (!h) return 1;
+  if (!pcs1 || !pcs2 || !out) return fail(h, "alignnet_forward_submit: null argument");
+  if (B < 1) return fail(h, "alignnet_forward_submit: B must be >= 1");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!h->pipe) {
+    Pipe* np = new Pipe();
+    h->pipe = np;
+    HIP_TRY(h, hipStreamCreateWithFlags(&np->s_in, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&np->s_out, hipStreamNonBlocking));
+    for (PipeSlot& s : np->slot) {
+      HIP_TRY(h, hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&s.ev_fwd, hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+    }
+  }
+  Pipe* p = static_cast<Pipe*>(h->pipe);
+  if (p->submitted - p->completed >= 2) return fail(h, "alignnet_forward_submit: two batches are in flight already -- call alignnet_forward_wait first");
+  PipeSlot& s = p->slot[p->submitted & 1];
+  const int N = h->cfg.num_points, nb2 = 2 * h->cfg.num_bins;
+  const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
+  if (B > s.cap) {
+    for (int t = 0; t < 2; ++t) { if (s.h_in[t]) hipHostFree(s.h_in[t]); if (s.d_in[t]) hipFree(s.d_in[t]); s.h_in[t] = s.d_in[t] = nullptr; }
+    if (s.h_out) hipHostFree(s.h_out);
+    if (s.d_out) hipFree(s.d_out);
+    s.h_out = s.d_out = nullptr; s.cap = 0;
+    const size_t nin = (size_t)B * N * 3 * sizeof(float);
+    size_t tot = 0;
+    for (int i = 0; i < 8; ++i) { s.out_off[i] = tot; tot += ((size_t)B * widths[i] + 63) & ~(size_t)63; }
+    for (int t = 0; t < 2; ++t) { HIP_TRY(h, hipHostMalloc(&s.h_in[t], nin, hipHostMallocDefault)); HIP_TRY(h, hipMalloc(&s.d_in[t], nin)); }
+    HIP_TRY(h, hipHostMalloc(&s.h_out, tot * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(h, hipMalloc(&s.d_out, tot * sizeof(float)));
+    for (int i = 0; i < 8; ++i) s.d_outs[i] = s.d_out + s.out_off[i];
+    s.cap = B;
+  }
+  if (ensure_ws(h, B, false)) return 1;
+  const size_t nin = (size_t)B * N * 3 * sizeof(float);
+  std::memcpy(s.h_in[0], pcs1, nin);   // (host work: overlaps the previous batch's forward on the GPU)
+  std::memcpy(s.h_in[1], pcs2, nin);
+  HIP_TRY(h, hipMemcpyAsync(s.d_in[0], s.h_in[0], nin, hipMemcpyHostToDevice, p->s_in));
+  HIP_TRY(h, hipMemcpyAsync(s.d_in[1], s.h_in[1], nin, hipMemcpyHostToDevice, p->s_in));
+  HIP_TRY(h, hipEventRecord(s.ev_in, p->s_in));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, s.ev_in, 0));
+  if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;
+  if (forward_device(h, s.d_in[0], s.d_in[1], B, s.d_outs)) return 1;
+  HIP_TRY(h, hipEventRecord(s.ev_fwd, h->stream));
+  HIP_TRY(h, hipStreamWaitEvent(p->s_out, s.ev_fwd, 0));
+  size_t tot = s.out_off[7] + (((size_t)B * widths[7] + 63) & ~(size_t)63);
+  (void)tot;
+  for (int i = 0; i < 8; ++i)
+    HIP_TRY(h, hipMemcpyAsync(s.h_out + s.out_off[i], s.d_outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+  HIP_TRY(h, hipEventRecord(s.ev_out, p->s_out));
+  s.user = *out; s.B = B; s.busy = true;
+  p->submitted++;
+  return 0;
 }
 
 extern "C" int alignnet_forward(alignnet_handle* h, const float* pcs1, const float* pcs2, int32_t B, const alignnet_outputs* out)

@@ -105,6 +105,7 @@ struct alignnet_handle {
   // training / multi-GPU state (alignnet_train.hip)
   void* train_ws = nullptr;
   void* dataset_ws = nullptr;      // HBM-resident dataset + batch buffers (alignnet_dataset.hip)
+  void* pipe = nullptr;            // pipelined host path: two staging slots, copy streams, events (alignnet_api.hip: alignnet_forward_submit / _wait)
   // seed base of the device-side dropout stream at the current step counter (alignnet_train.hip: bn_args, dropout_uniforms_kernel)
   uint64_t dropout_seed_base() const { return (cfg.seed + dropout_stream * 0xD1B54A32D192ED03ull) * 0x9E3779B97F4A7C15ull + (uint64_t)step * 16; }
   void* comm = nullptr;

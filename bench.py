@@ -387,6 +387,14 @@ def main():
     if args.mode == "train" and args.train_dtype == "bf16":
         eng.set_option("train_matmul_bf16", 1)
     step = train_step if args.mode == "train" else infer_step
+    # clock spin-up, untimed and in addition to the W warm-up steps: the GPU sits in its low-power state (sclk ~100 MHz) while the CPU
+    # baseline runs, and a short (W + K)-step run would be timed on the ramp
+    spin_t0, spinup_steps = time.perf_counter(), 0
+    while time.perf_counter() - spin_t0 < 0.4:
+        for _ in range(8):
+            step()
+        eng.synchronize()
+        spinup_steps += 8
     dt, kern = time_leg(step, args.steps, args.warmup)
     head_bf16 = (args.mode == "train" and args.train_dtype == "bf16") or (args.mode == "infer" and args.infer_dtype == "bf16x3")
     backbone_kernel = eng.last_backbone_kernel().split("<")[0] if args.mode == "infer" else "train"
@@ -489,6 +497,21 @@ def main():
         pcie_info = {"value": round(B * kp / pdt, 1), "unit": "pairs/s", "ms_per_step": round(pdt / kp * 1e3, 4), "steps": kp, "n_gpus": 1,
                      "what": "pageable host buffers in (2 x %.1f MB) and out, blocking alignnet_forward per batch -- the feed copy is inside the "
                              "timed region as in the reference's timing (train.py:447-449); not the headline value" % (B * npts * 12 / 1e6)}
+        # the same host-to-host work through the pipelined path: pinned staging, copy-in of batch i + 1 under the forward of batch i
+        for _ in range(3):
+            eng.forward_submit(d["pcs1"], d["pcs2"]); eng.forward_wait()
+        t0 = time.perf_counter()
+        inflight = 0
+        for _ in range(kp):
+            if inflight == 2:
+                eng.forward_wait(); inflight -= 1
+            eng.forward_submit(d["pcs1"], d["pcs2"]); inflight += 1
+        while inflight:
+            eng.forward_wait(); inflight -= 1
+        qdt = time.perf_counter() - t0
+        pcie_info["pipelined"] = {"value": round(B * kp / qdt, 1), "unit": "pairs/s", "ms_per_step": round(qdt / kp * 1e3, 4), "steps": kp,
+                                  "what": "alignnet_forward_submit / _wait: the same pageable buffers in and out, two batches in flight (pinned staging, "
+                                          "H2D on a copy stream under the previous batch's forward, D2H on a third stream)"}
     if dist is not None:
         dist.barrier()
 
@@ -504,7 +527,7 @@ def main():
                        if not dg else
                        ("SynthCars widths, DGCNN edge-conv branch (k=20), inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[4] shape)" % (B, npts)),
                        "pairs_per_gpu": B, "num_points": npts, "parallelism": f"batch-split x{world} (no collective)", "devices_used": world},
-            "roofline": head_roof,
+            "roofline": head_roof, "spinup_steps_untimed": spinup_steps,
             "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2)
             if world == 1 and not dg and npts == N_POINTS and args.mode == "infer" else None,
         }

@@ -133,6 +133,15 @@ int alignnet_forward(alignnet_handle* h, const float* pcs1, const float* pcs2, i
  * Follow with alignnet_synchronize() before reading the outputs. */
 int alignnet_forward_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2,
                             int32_t B, const alignnet_outputs* d_out);
+/* Pipelined form of alignnet_forward for a stream of batches (the evaluation loop of train.py:432-462 issues one blocking
+ * sess.run per batch): submit() stages the batch in pinned memory and queues copy-in (copy stream), forward (compute stream) and
+ * copy-out (a third stream), then returns; wait() blocks until the OLDEST submitted batch is complete and its outputs are in the
+ * `out` buffers that were passed to its submit() (they must stay valid until then; pcs1 / pcs2 may be reused as soon as submit()
+ * returns).  At most two batches in flight: the copy-in of batch i + 1 runs under the forward of batch i.  Same results as
+ * alignnet_forward, bit for bit.  (alignnet_eval_loss refers to the most recently SUBMITTED batch.) */
+int alignnet_forward_submit(alignnet_handle* h, const float* pcs1, const float* pcs2, int32_t B,
+                            const alignnet_outputs* out);
+int alignnet_forward_wait(alignnet_handle* h);
 /* Eval-mode loss on the last forward's predictions (train.py:448 `loss` fetch). */
 int alignnet_eval_loss(alignnet_handle* h, const alignnet_labels* labels, int32_t B,
                        float* loss, float summaries[16]);

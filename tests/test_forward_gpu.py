@@ -242,3 +242,31 @@ def test_knn_graph_ties_bit_exact(gpu_required, N):
     want = R.knn_indices(pcs.astype(np.float64), 20)
     np.testing.assert_array_equal(g[0, 0], want[0])
     np.testing.assert_array_equal(g[1, 0], want[1])
+
+
+def test_pipelined_host_path_equals_blocking_forward(gpu_required):
+    """alignnet_forward_submit / _wait (pinned staging, copy-in of batch i + 1 under the forward of batch i, two batches in flight) give
+    the blocking alignnet_forward's outputs bit for bit, in order, for batches of different sizes; a third submit without a wait and
+    a wait with nothing in flight fail with a message."""
+    cfg = small_cfg(N=256)
+    spec, P32 = oracle_params(cfg)
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    batches = [R.synth_pairs(b, 256, seed=40 + i, dtype=np.float32) for i, b in enumerate((5, 9, 3, 9, 1, 7))]
+    want = [eng.forward(d["pcs1"], d["pcs2"]) for d in batches]
+    got = list(eng.forward_stream((d["pcs1"], d["pcs2"]) for d in batches))
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        for k in w_:
+            np.testing.assert_array_equal(g[k], w_[k])
+    with pytest.raises(alignnet3d.EngineError):
+        eng.forward_wait()
+    eng.forward_submit(batches[0]["pcs1"], batches[0]["pcs2"])
+    eng.forward_submit(batches[1]["pcs1"], batches[1]["pcs2"])
+    with pytest.raises(alignnet3d.EngineError):
+        eng.forward_submit(batches[2]["pcs1"], batches[2]["pcs2"])
+    eng._inflight.pop()   # (the failed submit's arrays)
+    a, b = eng.forward_wait(), eng.forward_wait()
+    np.testing.assert_array_equal(a["pred_translations"], want[0]["pred_translations"])
+    np.testing.assert_array_equal(b["pred_translations"], want[1]["pred_translations"])
+    eng.close()
