@@ -26,6 +26,14 @@ using namespace alignnet;
 
 static int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1; }
 
+// sync_bn (alignnet_set_option): every batch sum behind a BatchNorm -- forward moments, backward (dbeta, dgamma) totals, the Gram /
+// column-sum matrices the layer identities use -- is added over the data-parallel ranks between the kernel that forms this rank's
+// sum and the kernel that uses it (RCCL all-reduce on the compute stream; defined with the RCCL section).
+static int sync_world(const alignnet_handle* h) { return h->comm ? h->comm_world : h->sync_emulate_world; }
+static bool sync_on(const alignnet_handle* h) { return h->sync_bn && sync_world(h) > 1; }
+static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double);
+constexpr size_t kSyncBufDoubles = 4 * 4096;
+
 namespace alignnet {
 
 struct HeadLayerWS { float *z, *y, *mean, *var, *dz, *dyb; };   // per hidden FC layer (with BN); dyb: d(y) from the next layer's dx GEMM
@@ -67,7 +75,8 @@ struct Deferred {
   std::vector<CentreJob> cen;
   std::vector<std::pair<GemmArgs, int>> gemm;   // (product, batch entries)
   std::vector<CombineJob> comb;
-  void clear() { red.clear(); sp.clear(); cen.clear(); gemm.clear(); comb.clear(); }
+  std::vector<std::pair<float*, size_t>> sync_after_red;   // sync_bn: reduced matrices that are summed over the ranks before the centrings read them
+  void clear() { red.clear(); sp.clear(); cen.clear(); gemm.clear(); comb.clear(); sync_after_red.clear(); }
 };
 
 struct TrainWS {
@@ -183,6 +192,11 @@ static bool stage_hybrid(const alignnet_handle* h, int s)
 static int check_trainable_shape(alignnet_handle* h)
 {
   const bool dg = h->cfg.backbone == 1;
+  if (h->sync_bn)
+    for (int s = 0; s < 3; ++s) {
+      if (stage_generic(h, s)) return fail(h, "sync_bn: supported for the fused three-layer stages (every shipped dataset config) and the dgcnn branch, not for general-depth backbones");
+      if (!dg && h->layers[conv_of(h, s).first].cout > 64) return fail(h, "sync_bn: first conv width limited to 64");
+    }
   for (int s = 0; s < 3 && !dg; ++s)
     if (stage_generic(h, s)) {
       const Stack& st = conv_of(h, s);
@@ -227,6 +241,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     HIP_TRY(h, hipMemset(w->adam_m, 0, h->n_trainable * sizeof(float)));
     HIP_TRY(h, hipMemset(w->adam_v, 0, h->n_trainable * sizeof(float)));
   }
+  if (!h->sync_buf) HIP_TRY(h, hipMalloc(&h->sync_buf, kSyncBufDoubles * sizeof(double)));
   if (B <= w->cap && !h->train_ws_stale) return 0;
   B = std::max(B, w->cap);
   h->train_ws_stale = false;
@@ -449,7 +464,7 @@ static void def_gemm(alignnet_handle* h, TrainWS* w, const GemmArgs& g, int batc
 static void def_combine(alignnet_handle* h, TrainWS* w, const CombineJob& j)
 {
   if (w->defer.on) { w->defer.comb.push_back(j); return; }
-  hipLaunchKernelGGL(combine_dw_kernel, dim3((unsigned)(((size_t)j.R * j.C + 255) / 256)), dim3(256), 0, h->stream, j.Sp, j.spscale, j.m, j.kdb, j.GW, j.E, j.R, j.C, j.dW);
+  hipLaunchKernelGGL(combine_dw_kernel, dim3((unsigned)(((size_t)j.R * j.C + 255) / 256)), dim3(256), 0, h->stream, j.Sp, j.spscale, j.m, j.kdb, j.GW, j.E, j.R, j.C, j.dW, j.gscale);
 }
 // the recorded jobs, five launches: reductions | sparse gathers -> Gram centrings -> GEMMs -> combines
 static int flush_deferred(alignnet_handle* h)
@@ -463,6 +478,7 @@ static int flush_deferred(alignnet_handle* h)
     for (size_t i = 0; i < d.red.size(); ++i) { J.j[i] = d.red[i]; nmax = std::max(nmax, d.red[i].n); }
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, h->stream, J);
   }
+  for (auto& sr : d.sync_after_red) if (sync_sum(h, sr.first, sr.second, false)) return 1;
   if (!d.sp.empty()) {
     SparseDwJobs J{}; int cmax = 0, c2max = 0;
     for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); c2max = std::max(c2max, d.sp[i].C2); }
@@ -711,9 +727,12 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
-  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, StatFinishArgs* keep = nullptr) {
+  const bool sync = sync_on(h);
+  const double W = sync ? (double)sync_world(h) : 1.0;   // sync_bn: batch counts are the global batch's
+  // global_part: the partials are already sums over all ranks (statistics derived from all-reduced Gram / column sums)
+  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, bool global_part = false) -> int {
     StatFinishArgs f;
-    f.part = w->stat_part; f.B = nb < 0 ? B : nb; f.C = C; f.slices = slices; f.count = cnt; f.bias = P(h, L[l]->p_b);
+    f.part = w->stat_part; f.B = nb < 0 ? B : nb; f.C = C; f.slices = slices; f.count = cnt * W; f.bias = P(h, L[l]->p_b);
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L[l]->p_bn[t][0]); f.gamma[t] = P(h, L[l]->p_bn[t][1]);
       f.mov_mean[t] = P(h, L[l]->p_bn[t][2]); f.mov_var[t] = P(h, L[l]->p_bn[t][3]);
@@ -723,13 +742,22 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.sgn = nullptr; f.next_gamma[0] = f.next_gamma[1] = nullptr;
     if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
     f.rstd = S.rstd[l]; f.k = S.kk[l];
-    if (keep) { *keep = f; return; }   // launched by the caller together with independent reductions (stat_finish_reduce_kernel)
-    hipLaunchKernelGGL(stat_finish_kernel, dim3((C + kSfC - 1) / kSfC, 2), dim3(1024), 0, h->stream, f);
+    const dim3 grid((C + kSfC - 1) / kSfC, 2);
+    if (sync && !global_part) {   // this rank's (sum, sum of squares) -> all ranks' -> finish
+      f.totals_out = h->sync_buf;
+      hipLaunchKernelGGL(stat_finish_kernel, grid, dim3(1024), 0, h->stream, f);
+      if (sync_sum(h, h->sync_buf, (size_t)2 * C * 2, true)) return 1;
+      f.totals_out = nullptr; f.part = h->sync_buf; f.B = 1; f.slices = 1;
+    }
+    hipLaunchKernelGGL(stat_finish_kernel, grid, dim3(1024), 0, h->stream, f);
+    return 0;
   };
   // the reductions of the Gram / column-sum partials of h2 over the clouds (the last layer's statistics follow from them: stat3 below)
-  auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) {
+  auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) -> int {
     ja.out = S.gram2raw; ja.upper_c = C2;   // (only the upper 32 x 32 blocks of the per-cloud Grams are valid -- and read)
     launch_reduce_multi(h, 2, ja, jb);
+    if (sync && (sync_sum(h, S.gram2raw, (size_t)2 * C2 * C2, false) || sync_sum(h, S.s2, (size_t)2 * C2, false))) return 1;
+    return 0;
   };
   if (dg) {
     // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
@@ -742,7 +770,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t dlds = h->train_bf16 ? (size_t)kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * sizeof(unsigned short)
                                       : ((size_t)kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float);
     hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
-    finish(0, C1, 1, ecount);
+    if (finish(0, C1, 1, ecount)) return 1;
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
@@ -764,10 +792,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
       launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
-      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount,
+      if (sync && (sync_sum(h, S.g1f, (size_t)2 * C1 * C1, false) || sync_sum(h, S.s1e, (size_t)2 * C1, false))) return 1;
+      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount * W,
                          h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
-    finish(1, C2, 1, ecount, 1);
+    if (finish(1, C2, 1, ecount, 1, true)) return 1;
     hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
   } else if (hyb) {
     // layers 1 .. n - 1 layer by layer, then h = relu(bn(Z_{n-1})) once, with its column sums; sign(gamma) of the last layer
@@ -793,7 +822,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
       else hipLaunchKernelGGL((train_fwd_phase23<3, true, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
       }
-      finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2));
+      if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2))) return 1;
     } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -802,12 +831,12 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
-    finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2));
+    if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;
     }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
   hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
-  finish(0, C1, 1, count);
+  if (finish(0, C1, 1, count)) return 1;
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
   const int CT1f = (C1 + 31) / 32, CT2f = (C2 + 31) / 32;
   // fp32 only: the bf16 phase 2 is light on the matrix pipe (49 us) and a fp32 Gram there costs more than passes B1 / B2 save
@@ -823,9 +852,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
     launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
-    hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count,
+    if (sync && (sync_sum(h, S.g1f, (size_t)2 * C1 * C1, false) || sync_sum(h, S.s1e, (size_t)2 * C1, false))) return 1;
+    hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
                        h->train_bf16 ? 1 : 0, w->stat_part);
-    finish(1, C2, 1, count, 1);
+    if (finish(1, C2, 1, count, 1, true)) return 1;
   } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE2);
   if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
@@ -833,7 +863,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
-  finish(1, C2, 4, count);
+  if (finish(1, C2, 4, count)) return 1;
   }
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
@@ -861,11 +891,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                          w->gram_part);
     }
   }
-  finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2));
+  if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2))) return 1;
   }
   {   // statistics of the last layer from the Gram, EMA, pooled features, centred Gram + column means for the backward: one launch
     Stat3Args f;
-    f.G = S.gram2raw; f.s = S.s2; f.W = P(h, L[2]->p_w); f.C2 = C2; f.C3 = C3; f.M = count;
+    f.G = S.gram2raw; f.s = S.s2; f.W = P(h, L[2]->p_w); f.C2 = C2; f.C3 = C3; f.M = count * W;
     f.round_w = (h->train_bf16 && (!(dg || hyb) || tail_bf16)) ? 1 : 0;   // the lift ran on bf16 operands
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L[2]->p_bn[t][0]); f.gamma[t] = P(h, L[2]->p_bn[t][1]);
@@ -957,7 +987,14 @@ static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin,
       HeadLayerWS& HL = w->hl[s][j];
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
       BnRowsArgs a = bn_args(h, w, s, j, M, rows_per_set, bn_decay, update_ema, u_dev);
-      hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(kBnCols * kBnGroups), 0, h->stream, a);
+      const dim3 bgrid((L.cout + kBnCols - 1) / kBnCols, nsets);
+      if (sync_on(h)) {   // this rank's column sums -> all ranks' -> normalise with the global batch's moments
+        a.mode = 1; a.totals = h->sync_buf;
+        hipLaunchKernelGGL(bn_rows_fwd_kernel, bgrid, dim3(kBnCols * kBnGroups), 0, h->stream, a);
+        if (sync_sum(h, h->sync_buf, (size_t)nsets * L.cout * 2, true)) return 1;
+        a.mode = 2; a.world = sync_world(h);
+      }
+      hipLaunchKernelGGL(bn_rows_fwd_kernel, bgrid, dim3(kBnCols * kBnGroups), 0, h->stream, a);
       cur = HL.y; ldc = L.cout;
     } else {
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, w->o[s], L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
@@ -988,7 +1025,14 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
         const int src = L.p_bn[t][0] >= 0 ? t : 0;
         b.dbeta[t] = G(h, w, L.p_bn[src][0]); b.dgamma[t] = G(h, w, L.p_bn[src][1]);
       }
-      hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((L.cout + kBnCols - 1) / kBnCols, nsets), dim3(kBnCols * kBnGroups), 0, h->stream, b);
+      const dim3 bgrid((L.cout + kBnCols - 1) / kBnCols, nsets);
+      if (sync_on(h)) {
+        b.f.mode = 1; b.f.totals = h->sync_buf;
+        hipLaunchKernelGGL(bn_rows_bwd_kernel, bgrid, dim3(kBnCols * kBnGroups), 0, h->stream, b);
+        if (sync_sum(h, h->sync_buf, (size_t)nsets * L.cout * 2, true)) return 1;
+        b.f.mode = 2; b.f.world = sync_world(h);
+      }
+      hipLaunchKernelGGL(bn_rows_bwd_kernel, bgrid, dim3(kBnCols * kBnGroups), 0, h->stream, b);
       dcur = HL.dz;
       // bias feeds a BatchNorm: its gradient is identically zero (TF computes rounding noise here); the whole gradient
       // vector is zeroed once per step, so nothing to do
@@ -1018,11 +1062,14 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // (hybrid stages: the fused tail's "layers 2 and 3" are the stage's last two; the layers in front of them follow layer by layer)
   const Layer* L[3] = {&h->layers[st.first], &h->layers[st.first + st.n - 2], &h->layers[st.first + st.n - 1]};
   const int N = h->cfg.num_points, C1 = L[0]->cout, C2 = L[1]->cout, C3 = L[2]->cout;
-  const double M = (double)B * N;
+  const double M0 = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool given = dg || hyb;   // pass B2 on stored features
   const bool given_bf16 = given && h->train_bf16 && 256 % (C2 / 4) == 0;   // ... with h2 Q3 on bf16 MFMA (same rule as the forward tail)
-  const double Me = dg ? M * kDgK : M;   // rows behind the statistics of layers 1 and 2 (DGCNN: the B*N*k edge rows)
+  const bool sync = sync_on(h);
+  const double Wn = sync ? (double)sync_world(h) : 1.0;
+  const double Me = (dg ? M0 * kDgK : M0) * Wn;   // rows behind the statistics of layers 1 and 2 (DGCNN: the B*N*k edge rows); sync_bn: of all ranks
+  const double M = M0 * Wn;
   const float* W2 = P(h, L[1]->p_w); const float* W3 = P(h, L[2]->p_w);
   auto g256 = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
   auto g256t = [](size_t n) { return dim3((unsigned)((n + 255) / 256), 2); };
@@ -1040,6 +1087,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = S.E3; p3.kdb = S.kdb3; p3.gs = S.gs;
+  if (sync) {
+    p3.mode = 1; p3.totals = h->sync_buf;
+    hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
+    if (sync_sum(h, h->sync_buf, (size_t)2 * C3 * 2, true)) return 1;
+    p3.mode = 2;
+  }
   hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
   // weight gradient of layer 3 (deferred: only the optimiser waits for it):  dW3 = Sp - m2 (k db)^T + (Ghat2 W3) diag(E)
   def_sparse(h, w, SparseDwJob{S.gs, S.idx, S.h2, B, N, C2, C3, S.Sp, (h->train_bf16 && !given) ? 1 : 0});
@@ -1048,7 +1101,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     g.batch_a = (long)C2 * C2; g.batch_b = 0; g.batch_c = (long)C2 * C3;
     def_gemm(h, w, g, 2);
   }
-  def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w)});
+  def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w), (float)(1.0 / Wn)});
   const size_t qimg = img_floats(C2, C2);
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
@@ -1122,14 +1175,19 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
     def_reduce(h, w, rjob(S.u2_part, B, (long)(C1 * C2), S.u2));
     if (fwd_gram || dg) def_reduce(h, w, rjob(S.g1f, 1, (long)(C1 * C1), S.g1));
-    else def_reduce(h, w, rjob(S.g1_part, B, (long)(C1 * C1), S.g1));
+    else {
+      def_reduce(h, w, rjob(S.g1_part, B, (long)(C1 * C1), S.g1));
+      if (sync) {   // Gram(h1) of all ranks (the forward's, in the other two cases, already is)
+        w->defer.sync_after_red.push_back({S.g1, (size_t)2 * C1 * C1});
+      }
+    }
     def_centre(h, w, CentreJob{S.g1, S.s1, C1, Me, S.m1});
     {
       GemmArgs g = gemm_args(S.g1, C1, 1, W2, C2, 1, S.GW2, C2, 1, C1, C2, C1);   // GW2[t] = Ghat1[t] W2
       g.batch_a = (long)C1 * C1; g.batch_b = 0; g.batch_c = (long)C1 * C2;
       def_gemm(h, w, g, 2);
     }
-    def_combine(h, w, CombineJob{S.u2, u2_prescaled ? nullptr : S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w)});
+    def_combine(h, w, CombineJob{S.u2, u2_prescaled ? nullptr : S.k2, S.m1, S.kdb2, S.GW2, S.E2, C1, C2, G(h, w, L[1]->p_w), (float)(1.0 / Wn)});
   };
   const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
   {   // totals of (dbeta2, dgamma2) over the clouds + the hidden layer's backward coefficients, and s1 / m1 = s1 / M (qbias needs it before B1): one launch
@@ -1138,12 +1196,26 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     for (int t = 0; t < 2; ++t) { ph.dbeta[t] = G(h, w, L[1]->p_bn[t][0]); ph.dgamma[t] = G(h, w, L[1]->p_bn[t][1]); }
     ph.E = S.E2; ph.kdb = S.kdb2; ph.kk = S.k2; ph.rstd = w->rstd2;
     ReduceJobs J{};
+    const dim3 pgrid(std::max((C2 + kPhC - 1) / kPhC, (C1 + 31) / 32), 2, 3);
+    if (sync) {
+      // local (dbeta2, dgamma2) -> gradients + totals; s1 of this rank; then both over all ranks; then the coefficients and m1 = s1 / M
+      if (dg || fwd_gram) J.j[0] = rjob(S.s1e, 1, (long)(C1), S.s1);   // (already the global sums: the forward all-reduced them)
+      else J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1);
+      ph.mode = 1; ph.totals = h->sync_buf;
+      hipLaunchKernelGGL(prep_hidden_reduce_kernel, pgrid, dim3(1024), 0, h->stream, ph, J);
+      if (sync_sum(h, h->sync_buf, (size_t)2 * C2 * 2, true)) return 1;
+      if (!(dg || fwd_gram) && sync_sum(h, S.s1, (size_t)2 * C1, false)) return 1;
+      ph.mode = 2;
+      J.j[0] = rjob(S.s1, 1, (long)(C1), S.m1, (float)(1.0 / Me));
+      hipLaunchKernelGGL(prep_hidden_reduce_kernel, pgrid, dim3(1024), 0, h->stream, ph, J);
+    } else {
     if (dg || fwd_gram) {   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
       J.j[0] = rjob(S.s1e, 1, (long)(C1), S.s1); J.j[1] = rjob(S.s1e, 1, (long)(C1), S.m1, (float)(1.0 / Me));
     } else {
-      J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / M));
+      J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / Me));
     }
-    hipLaunchKernelGGL(prep_hidden_reduce_kernel, dim3(std::max((C2 + kPhC - 1) / kPhC, (C1 + 31) / 32), 2, 3), dim3(1024), 0, h->stream, ph, J);
+    hipLaunchKernelGGL(prep_hidden_reduce_kernel, pgrid, dim3(1024), 0, h->stream, ph, J);
+    }
   }
   if (!acc_in_b1) layer2_weight_grad();
   const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
@@ -1213,6 +1285,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     set_glue(z);
     hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    if (sync && sync_sum(h, w->dbg1, (size_t)2 * C1 * 2, false)) return 1;   // (dbeta1, dgamma1) of all ranks: the per-cloud part divides them by the global count
     hipLaunchKernelGGL(dg_b0_cloud<6>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1.f, 1));
     HIP_TRY(h, hipGetLastError());
@@ -1266,6 +1339,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     set_glue(z);
     hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    if (sync && sync_sum(h, w->dbg1, (size_t)2 * C1 * 2, false)) return 1;   // (dbeta1, dgamma1) of all ranks: the per-cloud part divides them by the global count
     hipLaunchKernelGGL(dg_b0_cloud<3>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1.f, 1));
     HIP_TRY(h, hipGetLastError());
@@ -1353,7 +1427,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   h->comm_buckets = 0;
   w->defer.clear();
-  w->defer.on = !getenv("ALIGNNET_NO_DEFER");   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
+  w->defer.on = !getenv("ALIGNNET_NO_DEFER") || sync_on(h);   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
   if (!w->glue_folded) {
@@ -1723,6 +1797,28 @@ static int comm_join(alignnet_handle* h)
   if (!h->comm || !h->comm_stream || h->comm_buckets != 3) return fail(h, "comm_join: the three gradient buckets were not issued");
   HIP_TRY(h, hipEventRecord(h->comm_ev[3], h->comm_stream));
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_ev[3], 0));
+  return 0;
+}
+
+template <typename T>
+__global__ void scale_buf_kernel(T* __restrict__ p, size_t n, T f)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] *= f;
+}
+
+// sum of one small buffer over the data-parallel ranks, in stream order on the compute stream.  Without a communicator the test hook
+// "sync_bn_emulate_world" = w stands for w ranks holding identical shards: every sum is w times this rank's.
+static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
+{
+  if (h->comm) {
+    const int rc = g_rccl.AllReduce(buf, buf, n, is_double ? 8 : 7, 0, h->comm, h->stream);   // ncclFloat64 = 8, ncclFloat32 = 7, ncclSum = 0
+    if (rc != 0) return fail(h, std::string("ncclAllReduce (sync_bn): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    return 0;
+  }
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (is_double) hipLaunchKernelGGL(scale_buf_kernel<double>, dim3(grid), dim3(256), 0, h->stream, static_cast<double*>(buf), n, (double)h->sync_emulate_world);
+  else hipLaunchKernelGGL(scale_buf_kernel<float>, dim3(grid), dim3(256), 0, h->stream, static_cast<float*>(buf), n, (float)h->sync_emulate_world);
   return 0;
 }
 

@@ -115,6 +115,12 @@ struct alignnet_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [stage] = segment ready on the compute stream; [3] = buckets done
   bool comm_overlap = true;        // alignnet_set_option("allreduce_overlap")
+  // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --
+  // the reference's single-device semantics at the global batch (utils/tf_util.py:474) -- instead of per rank.
+  bool sync_bn = false;
+  int sync_emulate_world = 1;      // test hook ("sync_bn_emulate_world"): without a communicator, every BN sum is multiplied by this many
+                                   // identical virtual ranks (a step must then reproduce the plain local-BN step on the same shard)
+  double* sync_buf = nullptr;      // staging for the per-layer totals that travel through the all-reduce
   int comm_buckets = 0;            // bucket all-reduces issued by the last training step (0: one all-reduce after the backward)
   mutable std::string err;
 };

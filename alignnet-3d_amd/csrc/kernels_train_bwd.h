@@ -1302,6 +1302,7 @@ struct Prep3Args {
   int B, C; double M;
   float* dbeta[2]; float* dgamma[2];
   float* E; float* kdb; float* gs;                  // [2][C], [2][C], [2B][C]
+  double* totals = nullptr; int mode = 0;           // sync_bn: 1 = local (dbeta, dgamma) -> gradients + totals [2][C][2] and gs; 2 = E / kdb from the all-reduced totals
 };
 
 __global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // grid (ceil(C/32), 2), block 32 channels x 32 cloud groups (the cloud loop is a chain of dependent loads)
@@ -1310,8 +1311,8 @@ __global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // gri
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
   float rs = 0.f, k = 0.f;
   double sb = 0.0, sg = 0.0;
-  if (c < a.C) {
-    rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps); k = a.gamma[t][c] * rs;
+  if (c < a.C) { rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps); k = a.gamma[t][c] * rs; }
+  if (c < a.C && a.mode != 2) {
     for (int b = g; b < a.B; b += 32) {
       const size_t pi = t * a.tower_stride + b * a.row_stride + c;
       const float g0 = a.pooled[pi] > 0.f ? a.dP[pi] : 0.f;
@@ -1325,8 +1326,9 @@ __global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // gri
   if (g != 0 || c >= a.C) return;
   sb = 0.0; sg = 0.0;
   for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
-  a.dbeta[t][c] = (float)sb;
-  a.dgamma[t][c] = (float)sg;
+  if (a.mode == 2) { sb = a.totals[((size_t)t * a.C + c) * 2]; sg = a.totals[((size_t)t * a.C + c) * 2 + 1]; }
+  else { a.dbeta[t][c] = (float)sb; a.dgamma[t][c] = (float)sg; }
+  if (a.mode == 1) { a.totals[((size_t)t * a.C + c) * 2] = sb; a.totals[((size_t)t * a.C + c) * 2 + 1] = sg; return; }
   a.E[t * a.C + c] = (float)(-(double)k * rs * sg / a.M);
   a.kdb[t * a.C + c] = (float)((double)k * sb);
 }
@@ -1358,6 +1360,7 @@ struct PrepHiddenArgs {
   const float* var; const float* gamma[2]; int C; double M;
   float* dbeta[2]; float* dgamma[2];
   float *E, *kdb, *kk, *rstd;   // [2][C]
+  double* totals = nullptr; int mode = 0;   // sync_bn: as Prep3Args
 };
 constexpr int kPhC = 8;   // channels per workgroup: 128 slice groups x 8 channels (32 channels x 32 groups left the launch on 8 workgroups walking 16-deep load chains: 21 us)
 __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHiddenArgs a, const ReduceJobs jobs)
@@ -1368,7 +1371,7 @@ __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHidd
   constexpr int kG = 1024 / kPhC;
   if ((int)blockIdx.x * kPhC >= a.C) return;
   double sb = 0.0, sg = 0.0;
-  if (c < a.C)
+  if (c < a.C && a.mode != 2)
     for (int k = g; k < a.S; k += kG * 4) {
       double v0[4], v1[4];
 #pragma unroll
@@ -1385,9 +1388,11 @@ __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHidd
   if (g != 0 || c >= a.C) return;
   sb = 0.0; sg = 0.0;
   for (int q = 0; q < kG; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
+  if (a.mode == 2) { sb = a.totals[((size_t)t * a.C + c) * 2]; sg = a.totals[((size_t)t * a.C + c) * 2 + 1]; }
   const float sbf = (float)sb, sgf = (float)sg;   // (as the two-launch form: totals rounded to fp32 first)
   const float rs = 1.0f / sqrtf(a.var[t * a.C + c] + kBnEps), k = a.gamma[t][c] * rs;
-  a.dbeta[t][c] = sbf; a.dgamma[t][c] = sgf;
+  if (a.mode != 2) { a.dbeta[t][c] = sbf; a.dgamma[t][c] = sgf; }
+  if (a.mode == 1) { a.totals[((size_t)t * a.C + c) * 2] = sb; a.totals[((size_t)t * a.C + c) * 2 + 1] = sg; return; }
   if (a.E) a.E[t * a.C + c] = (float)(-(double)k * rs * sgf / a.M);
   if (a.kdb) a.kdb[t * a.C + c] = k * sbf;
   if (a.kk) a.kk[t * a.C + c] = k;
@@ -1517,7 +1522,7 @@ __global__ __launch_bounds__(256) void scale_cols2_kernel(const float* __restric
 // dW[i][j] (+)= sum_t ( Sp[t][i][j]*spscale[t][j] - m[t][i]*kdb[t][j] + GW[t][i][j]*E[t][j] )
 __device__ __forceinline__ void combine_dw_body(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
                                                 const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
-                                                int R, int C, float* __restrict__ dW, unsigned bx)
+                                                int R, int C, float* __restrict__ dW, unsigned bx, float gscale = 1.f)
 {
   const long e = bx * 256L + threadIdx.x;
   if (e >= (long)R * C) return;
@@ -1525,15 +1530,16 @@ __device__ __forceinline__ void combine_dw_body(const float* __restrict__ Sp, co
   float s = 0.f;
   for (int t = 0; t < 2; ++t) {
     const size_t o = (size_t)t * R * C + e;
-    s += Sp[o] * (spscale ? spscale[t * C + j] : 1.f) - m[t * R + i] * kdb[t * C + j] + GW[o] * E[t * C + j];
+    // gscale (sync_bn: 1 / ranks): m, kdb, GW, E are then the GLOBAL batch's, the same on every rank, and the gradient all-reduce adds them ranks times
+    s += Sp[o] * (spscale ? spscale[t * C + j] : 1.f) + gscale * (GW[o] * E[t * C + j] - m[t * R + i] * kdb[t * C + j]);
   }
   dW[e] = s;
 }
 __global__ __launch_bounds__(256) void combine_dw_kernel(const float* __restrict__ Sp, const float* __restrict__ spscale, const float* __restrict__ m,
                                                          const float* __restrict__ kdb, const float* __restrict__ GW, const float* __restrict__ E,
-                                                         int R, int C, float* __restrict__ dW)
+                                                         int R, int C, float* __restrict__ dW, float gscale)
 {
-  combine_dw_body(Sp, spscale, m, kdb, GW, E, R, C, dW, blockIdx.x);
+  combine_dw_body(Sp, spscale, m, kdb, GW, E, R, C, dW, blockIdx.x, gscale);
 }
 // layer 3 of a stage: the weight gradient's combine and the two scaled copies of W3 the backward needs next, one launch
 // (grid (ceil(R C / 256), 3): y < 2 the copies of tower y, y = 2 the combine)
@@ -1555,12 +1561,12 @@ __global__ __launch_bounds__(256) void centre_gram_jobs_kernel(const CentreJobs 
   const CentreJob& q = jobs.j[blockIdx.z];
   if (q.G) centre_gram_body(q.G, q.s, q.C, q.M, q.m, blockIdx.x, blockIdx.y);
 }
-struct CombineJob { const float* Sp; const float* spscale; const float* m; const float* kdb; const float* GW; const float* E; int R, C; float* dW; };
+struct CombineJob { const float* Sp; const float* spscale; const float* m; const float* kdb; const float* GW; const float* E; int R, C; float* dW; float gscale = 1.f; };
 struct CombineJobs { CombineJob j[6]; };
 __global__ __launch_bounds__(256) void combine_dw_jobs_kernel(const CombineJobs jobs)
 {
   const CombineJob& q = jobs.j[blockIdx.z];
-  if (q.Sp) combine_dw_body(q.Sp, q.spscale, q.m, q.kdb, q.GW, q.E, q.R, q.C, q.dW, blockIdx.x);
+  if (q.Sp) combine_dw_body(q.Sp, q.spscale, q.m, q.kdb, q.GW, q.E, q.R, q.C, q.dW, blockIdx.x, q.gscale);
 }
 
 // qb[t][j] = -sum_i m[t][i] Q[t][i][j] - sum_c W[j][c] kdb[t][c] / M      (W: [R=Cin][C=Cout])

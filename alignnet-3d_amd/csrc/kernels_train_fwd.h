@@ -922,6 +922,8 @@ struct StatFinishArgs {
   float* sgn;                // [2][next_C] or null: sign(gamma) of the NEXT layer (needed by phase 3 before its own statistics)
   const float* next_gamma[2]; int next_C;
   float* rstd; float* k;     // [2][C]: rsqrt(var+eps) and gamma*rsqrt(var+eps) (backward passes)
+  double* totals_out = nullptr;   // sync_bn: only reduce the partials to [2][C][2] (sum, sum of squares) here; after the all-reduce over the
+                                  // ranks a second call finishes from them (part = the totals, B = slices = 1, count = the global count)
 };
 
 // (body and kernel apart: the step also runs it as one job of a merged launch, kernels_train_bwd.h)
@@ -951,6 +953,7 @@ __device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx
   if (g != 0 || c >= a.C) return;
   s = 0.0; ss = 0.0;
   for (int q = 0; q < kG; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
+  if (a.totals_out) { a.totals_out[((size_t)t * a.C + c) * 2] = s; a.totals_out[((size_t)t * a.C + c) * 2 + 1] = ss; return; }
   const double mean = s / a.count;
   const double var = fmax(ss / a.count - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;

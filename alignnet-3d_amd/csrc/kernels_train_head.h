@@ -180,6 +180,9 @@ struct BnRowsArgs {
   float keep;                       // <= 0: no dropout
   const float* u; long u_set_stride;   // uniforms [rows][C] per set (set s at u + s*u_set_stride), or null
   uint64_t seed;
+  // sync_bn (batch statistics over all data-parallel ranks): mode 1 = only the column sums -> totals [nsets][C][2] (forward: sum z, sum z^2;
+  // backward: sum g, sum g zhat), mode 2 = take them (all-reduced) from totals and do the rest, with world x the rows; 0 = one launch
+  double* totals = nullptr; int mode = 0; int world = 1;
 };
 
 __device__ __forceinline__ float dropout_scale(const BnRowsArgs& a, int set, int row_in_set, int c)
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const 
   const int cl = threadIdx.x % kBnCols, rg = threadIdx.x / kBnCols, c = blockIdx.x * kBnCols + cl, set = blockIdx.y;
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   double s = 0.0, ss = 0.0;
-  if (c < a.C)
+  if (c < a.C && a.mode != 2)
     for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
       float v[kBnU];
 #pragma unroll
@@ -211,7 +214,10 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const 
   if (c >= a.C) return;
   s = 0.0; ss = 0.0;
   for (int q = 0; q < kBnGroups; ++q) { s += red[q][cl][0]; ss += red[q][cl][1]; }
-  const double mean = s / R, var = fmax(ss / R - mean * mean, 0.0);
+  if (a.mode == 1) { if (rg == 0) { a.totals[((size_t)set * a.C + c) * 2] = s; a.totals[((size_t)set * a.C + c) * 2 + 1] = ss; } return; }
+  if (a.mode == 2) { s = a.totals[((size_t)set * a.C + c) * 2]; ss = a.totals[((size_t)set * a.C + c) * 2 + 1]; }
+  const double Rg = (double)R * a.world;
+  const double mean = s / Rg, var = fmax(ss / Rg - mean * mean, 0.0);
   const float mf = (float)mean, vf = (float)var;
   if (rg == 0) {
     a.mean[set * a.C + c] = mf; a.var[set * a.C + c] = vf;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
   float mf = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
   if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
   double sb = 0.0, sg = 0.0;
-  if (c < a.C)
+  if (c < a.C && a.mode != 2)
     for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
       float zv[kBnU], dv[kBnU];
 #pragma unroll
@@ -274,8 +280,14 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
   if (c >= a.C) return;
   sb = 0.0; sg = 0.0;
   for (int q = 0; q < kBnGroups; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
-  if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; }
-  const float mb = (float)(sb / R), mg = (float)(sg / R), k = gam * rstd;
+  if (a.mode == 1) {   // local sums: the parameter gradients (the gradient all-reduce adds the ranks') and this rank's share of the totals
+    if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; a.totals[((size_t)set * a.C + c) * 2] = sb; a.totals[((size_t)set * a.C + c) * 2 + 1] = sg; }
+    return;
+  }
+  if (a.mode == 2) { sb = a.totals[((size_t)set * a.C + c) * 2]; sg = a.totals[((size_t)set * a.C + c) * 2 + 1]; }
+  else if (rg == 0) { b.dbeta[set][c] = (float)sb; b.dgamma[set][c] = (float)sg; }
+  const double Rg = (double)R * a.world;
+  const float mb = (float)(sb / Rg), mg = (float)(sg / Rg), k = gam * rstd;
   for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
     float zv[kBnU], dv[kBnU];
 #pragma unroll

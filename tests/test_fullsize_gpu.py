@@ -176,7 +176,7 @@ def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
 
 
 def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4, fp32_conditioning=False,
-                                  grad_ceiling=8e-2, pred_ceiling=2.5e-4, loss_tol=1e-4):
+                                  grad_ceiling=8e-2, pred_ceiling=2.5e-4, loss_tol=1e-4, ema_tol=1e-4):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
     torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`).
     fp32_conditioning: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024 candidates each and
@@ -211,7 +211,7 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pre
     worst_ema = 0.0
     for k, v in ema_ref.items():
         got = eng.get_variable(k)
-        np.testing.assert_allclose(got, v, rtol=1e-4, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(got, v, rtol=ema_tol, atol=0.1 * ema_tol, err_msg=k)
         worst_ema = max(worst_ema, float(np.abs(got - v).max()))
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
@@ -271,7 +271,7 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 4 (655 k edge rows, [2B, N, N] distance
     matrices in the oracle; two-row batch statistics in the heads are singular, so not B = 2)."""
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=4096, seed=9)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, pred_ceiling=2e-2, loss_tol=2e-3)   # (kNN at N = 4096: the fp32 oracle's own predictions are 8e-3 from its fp64 ones)
+    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, pred_ceiling=2e-2, loss_tol=2e-3, ema_tol=3e-3)   # (kNN at N = 4096: the fp32 oracle's own predictions are 8e-3 from its fp64 ones)
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):

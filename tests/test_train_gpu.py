@@ -667,3 +667,42 @@ def test_reference_default_config_trains(gpu_required):
     print("default.json widths: mean loss first / last 10 steps", first, last)
     assert np.all(np.isfinite(losses)) and np.isfinite(pred).all() and last < 0.8 * first, (first, last)
     eng.close()
+
+
+@pytest.mark.parametrize("backbone,bf16,std", [("pointnet", 0, False), ("pointnet", 0, True), ("pointnet", 1, True), ("dgcnn", 0, True), ("dgcnn", 1, True)])
+def test_sync_bn_with_identical_virtual_ranks_reproduces_local_step(gpu_required, backbone, bf16, std):
+    """Option "sync_bn": every batch sum behind a BatchNorm (forward moments, the Gram / column-sum matrices the layer identities use,
+    the backward's dbeta / dgamma totals, the heads' row statistics) is added over the data-parallel ranks and divided by the GLOBAL
+    count -- the reference's single-device semantics at the global batch (utils/tf_util.py:474).  Real ranks need more than one GPU;
+    the test hook "sync_bn_emulate_world" = 3 stands for three ranks holding the SAME shard (each all-reduce becomes x 3): mean and
+    variance are then the shard's own, so predictions, loss, EMA shadows and every gradient must equal the plain local-BN step --
+    which they only do if every count carries its x world and every globally-summed gradient term its 1 / world."""
+    N, B = 128, 6
+    cfg, spec, P32, d, du = (_setup_dgcnn(N, B, std=std) if backbone == "dgcnn" else _setup(N, B, std=std))
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    out = {}
+    for mode in (0, 1):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("train_matmul_bf16", bf16)
+        if mode:
+            eng.set_option("sync_bn", 1)
+            eng.set_option("sync_bn_emulate_world", 3)
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+        grads = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
+        ema = {k: eng.get_variable(k) for k, _, tr in eng.variables() if not tr}
+        out[mode] = (res, grads, ema)
+        eng.close()
+    (r0, g0, e0), (r1, g1, e1) = out[0], out[1]
+    assert abs(r0["loss"] - r1["loss"]) <= 1e-6 * max(1.0, abs(r0["loss"]))
+    for k in ("pred_translations", "pred_remaining_angle_logits", "pred_s2_pc1centers", "pred_pc2angle_logits"):
+        np.testing.assert_allclose(r1[k], r0[k], rtol=2e-5, atol=2e-5, err_msg=k)
+    for k in e0:
+        np.testing.assert_allclose(e1[k], e0[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    gs = max(float(np.abs(v).max()) for v in g0.values())
+    worst = 0.0
+    for n in g0:
+        err = float(np.abs(g1[n] - g0[n]).max())
+        worst = max(worst, err / (float(np.abs(g0[n]).max()) + 1e-6 * gs))
+        assert err <= 2e-4 * float(np.abs(g0[n]).max()) + 2e-6 * gs, (n, err, float(np.abs(g0[n]).max()))
+    print(backbone, "bf16" if bf16 else "fp32", "sync_bn (3 identical virtual ranks) vs local step: worst relative gradient difference %.2e" % worst)

@@ -49,7 +49,7 @@ json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_by_kernel.json"), "w"), indent
 steps, shape = None, None
 for line in open(os.path.join(out, "bench_trace.log")):
     if line.startswith("{"):
-        j = json.loads(line); steps = j["steps"] + j["warmup"]
+        j = json.loads(line); steps = j["steps"] + j["warmup"] + j.get("spinup_steps_untimed", 0)   # every step the profiled process ran (one leg per profile run)
         shape = {"pairs_per_gpu": j["config"].get("pairs_per_gpu"), "num_points": j["config"].get("num_points")}
 commit = None
 for cand in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit"),):
