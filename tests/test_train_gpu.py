@@ -674,8 +674,8 @@ def test_sync_bn_with_identical_virtual_ranks_reproduces_local_step(gpu_required
     """Option "sync_bn": every batch sum behind a BatchNorm (forward moments, the Gram / column-sum matrices the layer identities use,
     the backward's dbeta / dgamma totals, the heads' row statistics) is added over the data-parallel ranks and divided by the GLOBAL
     count -- the reference's single-device semantics at the global batch (utils/tf_util.py:474).  Real ranks need more than one GPU;
-    the test hook "sync_bn_emulate_world" = 3 stands for three ranks holding the SAME shard (each all-reduce becomes x 3): mean and
-    variance are then the shard's own, so predictions, loss, EMA shadows and every gradient must equal the plain local-BN step --
+    the test hook "sync_bn_emulate_world" = 2 stands for two ranks holding the SAME shard (each all-reduce becomes x 2, exact in
+    binary floating point): mean and variance are then the shard's own, bit for bit, so predictions, loss, EMA shadows and every gradient must equal the plain local-BN step --
     which they only do if every count carries its x world and every globally-summed gradient term its 1 / world."""
     N, B = 128, 6
     cfg, spec, P32, d, du = (_setup_dgcnn(N, B, std=std) if backbone == "dgcnn" else _setup(N, B, std=std))
@@ -687,22 +687,29 @@ def test_sync_bn_with_identical_virtual_ranks_reproduces_local_step(gpu_required
         eng.set_option("train_matmul_bf16", bf16)
         if mode:
             eng.set_option("sync_bn", 1)
-            eng.set_option("sync_bn_emulate_world", 3)
+            eng.set_option("sync_bn_emulate_world", 2)
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
         grads = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
         ema = {k: eng.get_variable(k) for k, _, tr in eng.variables() if not tr}
         out[mode] = (res, grads, ema)
         eng.close()
     (r0, g0, e0), (r1, g1, e1) = out[0], out[1]
-    assert abs(r0["loss"] - r1["loss"]) <= 1e-6 * max(1.0, abs(r0["loss"]))
+    # x 3 and / 3 round differently from the single sum: differences are rounding-sized in fp32 (amplified by six-row batch statistics
+    # in the heads) and bf16-ulp-sized where a value sits on a rounding boundary of the bf16 operands; a missing x world or
+    # 1 / world would be a factor of 3 in a statistic or a gradient term
+    ptol, ltol, gtol = 1e-6, 1e-6, 1e-6   # (x 2 and / 2 are exact: nothing but a wrong factor can move a result)
+    assert abs(r0["loss"] - r1["loss"]) <= ltol * max(1.0, abs(r0["loss"]))
     for k in ("pred_translations", "pred_remaining_angle_logits", "pred_s2_pc1centers", "pred_pc2angle_logits"):
-        np.testing.assert_allclose(r1[k], r0[k], rtol=2e-5, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(r1[k], r0[k], rtol=ptol, atol=ptol, err_msg=k)
     for k in e0:
-        np.testing.assert_allclose(e1[k], e0[k], rtol=1e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(e1[k], e0[k], rtol=10 * ltol, atol=ltol, err_msg=k)
     gs = max(float(np.abs(v).max()) for v in g0.values())
     worst = 0.0
     for n in g0:
         err = float(np.abs(g1[n] - g0[n]).max())
         worst = max(worst, err / (float(np.abs(g0[n]).max()) + 1e-6 * gs))
-        assert err <= 2e-4 * float(np.abs(g0[n]).max()) + 2e-6 * gs, (n, err, float(np.abs(g0[n]).max()))
-    print(backbone, "bf16" if bf16 else "fp32", "sync_bn (3 identical virtual ranks) vs local step: worst relative gradient difference %.2e" % worst)
+        assert err <= gtol * float(np.abs(g0[n]).max()) + 1e-2 * gtol * gs, (n, err, float(np.abs(g0[n]).max()))
+    ga, gb = np.concatenate([g0[n].ravel() for n in g0]), np.concatenate([g1[n].ravel() for n in g0])
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > 0.9999999, cos
+    print(backbone, "bf16" if bf16 else "fp32", "sync_bn (2 identical virtual ranks) vs local step: worst relative gradient difference %.2e, cosine %.7f" % (worst, cos))
