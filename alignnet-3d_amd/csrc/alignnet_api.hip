@@ -875,6 +875,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
   if (k == "dropout_stream") { h->dropout_stream = (uint64_t)value; return 0; }
   if (k == "sync_bn") { h->sync_bn = value != 0; return 0; }
+  if (k == "global_loss") { h->global_loss = value != 0; return 0; }
   if (k == "sync_bn_emulate_world") { if (value < 1) return fail(h, "sync_bn_emulate_world must be >= 1"); h->sync_emulate_world = (int)value; return 0; }
   if (k == "train_fused_tail") {
     if (h->fused_tail != (value != 0)) h->train_ws_stale = true;   // the workspace is carved per setting
@@ -898,6 +899,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "allreduce_overlap") { *value = h->comm_overlap ? 1 : 0; return 0; }
   if (k == "dropout_stream") { *value = (int64_t)h->dropout_stream; return 0; }
   if (k == "sync_bn") { *value = h->sync_bn ? 1 : 0; return 0; }
+  if (k == "global_loss") { *value = h->global_loss ? 1 : 0; return 0; }
   if (k == "sync_bn_emulate_world") { *value = h->sync_emulate_world; return 0; }
   if (k == "comm_world") { *value = h->comm ? h->comm_world : 0; return 0; }
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }

@@ -32,6 +32,8 @@ static int fail(const alignnet_handle* h, const std::string& m) { h->err = m; re
 static int sync_world(const alignnet_handle* h) { return h->comm ? h->comm_world : h->sync_emulate_world; }
 static bool sync_on(const alignnet_handle* h) { return h->sync_bn && sync_world(h) > 1; }
 static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double);
+static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4);   // n4 four-byte elements per rank; dst = [world][n4]
+static bool gloss_on(const alignnet_handle* h) { return h->global_loss && sync_world(h) > 1; }
 constexpr size_t kSyncBufDoubles = 4 * 4096;
 
 namespace alignnet {
@@ -120,6 +122,9 @@ struct TrainWS {
   float *gen_part = nullptr, *gen_dwpart = nullptr, *gen_ppart = nullptr, *gen_cA = nullptr, *gen_cB = nullptr, *gen_wt = nullptr;
   int gen_tiles = 0, gen_slabs = 0;
   Deferred defer;
+  // global_loss: gathered end points / labels of all ranks, the loss gradient wrt all of them, scratch (carved for gl_cap global pairs)
+  float* gl_base = nullptr; int gl_cap = 0;
+  float *gl_s1c, *gl_s2c, *gl_o2, *gl_o3, *gl_theta, *gl_lab[6], *gl_d_s1c, *gl_d_s2c, *gl_d_o2, *gl_d_o3, *gl_scratch; int* gl_cls;
   bool glue_folded = false;   // the last backbone backward ran the stage glue inside dg_b0_cloud (fwd_bwd_device skips the glue launches)
 };
 
@@ -142,6 +147,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (!h->train_ws) return;
   TrainWS* w = static_cast<TrainWS*>(h->train_ws);
   if (w->base) hipFree(w->base);
+  if (w->gl_base) hipFree(w->gl_base);
   for (int t = 0; t < 2; ++t) if (w->d_pcs[t]) hipFree(w->d_pcs[t]);
   if (w->grad) hipFree(w->grad);
   if (w->adam_m) hipFree(w->adam_m);
@@ -1419,6 +1425,53 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   la.tr = lab[0]; la.c1 = lab[2]; la.c2 = lab[3]; la.a1 = lab[4]; la.a2 = lab[5];
   la.out = w->loss_out; la.d_s1c = w->d_s1c; la.d_s2c = w->d_s2c; la.d_o2 = w->d_o[1]; la.d_o3 = w->d_o[2]; la.scratch = w->loss_scratch;
   la.want_grad = do_backward;
+  if (gloss_on(h)) {
+    // The reference's loss couples every sample of the (global) batch: all-gather what the loss reads -- per tower, so that the gathered
+    // arrays keep the [tower 0 rows | tower 1 rows] layout -- run the same three kernels on the global batch, take this rank's rows of
+    // the gradient.  The loss is already divided by the global B: the gradient all-reduce sums (reduce_and_apply).
+    const int Wg = sync_world(h), Bg = B * Wg, rk = h->comm ? h->comm_rank : 0, ld = 3 + nb2;
+    if (Bg > w->gl_cap) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (w->gl_base) hipFree(w->gl_base);
+      const size_t B2g = 2 * (size_t)Bg;
+      size_t off = 0;
+      auto take = [&](size_t n) { const size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
+      const size_t o_s1c = take(B2g * 3), o_s2c = take(B2g * 3), o_o2 = take(B2g * ld), o_o3 = take((size_t)Bg * ld), o_th = take(B2g), o_cls = take(B2g);
+      const int lw[6] = {3, 1, 3, 3, 1, 1};
+      size_t o_lab[6];
+      for (int i = 0; i < 6; ++i) o_lab[i] = take((size_t)Bg * lw[i]);
+      const size_t o_ds1 = take(B2g * 3), o_ds2 = take(B2g * 3), o_do2 = take(B2g * ld), o_do3 = take((size_t)Bg * ld), o_scr = take(loss_scratch_floats(Bg));
+      HIP_TRY(h, hipMalloc(&w->gl_base, off * sizeof(float)));
+      float* b0 = w->gl_base;
+      w->gl_s1c = b0 + o_s1c; w->gl_s2c = b0 + o_s2c; w->gl_o2 = b0 + o_o2; w->gl_o3 = b0 + o_o3; w->gl_theta = b0 + o_th; w->gl_cls = reinterpret_cast<int*>(b0 + o_cls);
+      for (int i = 0; i < 6; ++i) w->gl_lab[i] = b0 + o_lab[i];
+      w->gl_d_s1c = b0 + o_ds1; w->gl_d_s2c = b0 + o_ds2; w->gl_d_o2 = b0 + o_do2; w->gl_d_o3 = b0 + o_do3; w->gl_scratch = b0 + o_scr;
+      w->gl_cap = Bg;
+    }
+    for (int t = 0; t < 2; ++t) {
+      if (sync_gather(h, w->s1c + (size_t)t * B * 3, w->gl_s1c + (size_t)t * Bg * 3, (size_t)B * 3)) return 1;
+      if (sync_gather(h, w->s2c + (size_t)t * B * 3, w->gl_s2c + (size_t)t * Bg * 3, (size_t)B * 3)) return 1;
+      if (sync_gather(h, w->o[1] + (size_t)t * B * ld, w->gl_o2 + (size_t)t * Bg * ld, (size_t)B * ld)) return 1;
+      if (sync_gather(h, w->theta + (size_t)t * B, w->gl_theta + (size_t)t * Bg, (size_t)B)) return 1;
+      if (sync_gather(h, w->cls + (size_t)t * B, w->gl_cls + (size_t)t * Bg, (size_t)B)) return 1;
+    }
+    if (sync_gather(h, w->o[2], w->gl_o3, (size_t)B * ld)) return 1;
+    const int lw[6] = {3, 1, 3, 3, 1, 1};
+    for (int i = 0; i < 6; ++i) if (sync_gather(h, lab[i], w->gl_lab[i], (size_t)B * lw[i])) return 1;
+    la.B = Bg; la.s1c = w->gl_s1c; la.s2c = w->gl_s2c; la.o2 = w->gl_o2; la.o3 = w->gl_o3; la.theta = w->gl_theta; la.pcls = w->gl_cls;
+    la.tr = w->gl_lab[0]; la.c1 = w->gl_lab[2]; la.c2 = w->gl_lab[3]; la.a1 = w->gl_lab[4]; la.a2 = w->gl_lab[5];
+    la.d_s1c = w->gl_d_s1c; la.d_s2c = w->gl_d_s2c; la.d_o2 = w->gl_d_o2; la.d_o3 = w->gl_d_o3; la.scratch = w->gl_scratch;
+    launch_loss(h, la);
+    if (do_backward) {
+      auto cp = [&](float* dst, const float* src, size_t n) { return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream); };
+      for (int t = 0; t < 2; ++t) {
+        HIP_TRY(h, cp(w->d_s1c + (size_t)t * B * 3, w->gl_d_s1c + ((size_t)t * Bg + (size_t)rk * B) * 3, (size_t)B * 3));
+        HIP_TRY(h, cp(w->d_s2c + (size_t)t * B * 3, w->gl_d_s2c + ((size_t)t * Bg + (size_t)rk * B) * 3, (size_t)B * 3));
+        HIP_TRY(h, cp(w->d_o[1] + (size_t)t * B * ld, w->gl_d_o2 + ((size_t)t * Bg + (size_t)rk * B) * ld, (size_t)B * ld));
+      }
+      HIP_TRY(h, cp(w->d_o[2], w->gl_d_o3 + (size_t)rk * B * ld, (size_t)B * ld));
+    }
+  } else
   launch_loss(h, la);
   HIP_TRY(h, hipGetLastError());
   if (!do_backward) return 0;
@@ -1598,7 +1651,7 @@ static int reduce_and_apply(alignnet_handle* h, int overlapped)
   if (h->comm) {
     ProfScope prof_scope(h, PK_ALLREDUCE);   // what the compute stream waits for: the part of the all-reduce the backward did not hide
     if (overlapped ? comm_join(h) : alignnet_comm_allreduce_grads(h)) return 1;
-    scale = 1.f / (float)h->comm_world;
+    scale = h->global_loss ? 1.f : 1.f / (float)h->comm_world;   // global_loss: the loss is already that of the global batch (divided by its B): sum
   }
   return alignnet_apply_gradients(h, scale);
 }
@@ -1708,6 +1761,7 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId passed by value = 128-byte struct
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1723,6 +1777,7 @@ bool load_rccl(std::string& err)
   g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclGetUniqueId"));
   g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(l, "ncclCommInitRank"));
   g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(l, "ncclAllReduce"));
+  g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(l, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(l, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(l, "ncclGetErrorString"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { err = "librccl.so lacks the expected nccl* symbols"; return false; }
@@ -1819,6 +1874,21 @@ static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
   const unsigned grid = (unsigned)((n + 255) / 256);
   if (is_double) hipLaunchKernelGGL(scale_buf_kernel<double>, dim3(grid), dim3(256), 0, h->stream, static_cast<double*>(buf), n, (double)h->sync_emulate_world);
   else hipLaunchKernelGGL(scale_buf_kernel<float>, dim3(grid), dim3(256), 0, h->stream, static_cast<float*>(buf), n, (float)h->sync_emulate_world);
+  return 0;
+}
+
+// all-gather of one small array (four-byte elements) over the data-parallel ranks, rank-major, in stream order on the compute stream;
+// without a communicator "sync_bn_emulate_world" = w stands for w ranks holding identical shards: w copies
+static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4)
+{
+  if (h->comm) {
+    if (!g_rccl.AllGather) return fail(h, "librccl.so lacks ncclAllGather");
+    const int rc = g_rccl.AllGather(src, dst, n4, 7, h->comm, h->stream);   // ncclFloat32 = 7 (four-byte elements; class ids travel as bits)
+    if (rc != 0) return fail(h, std::string("ncclAllGather (global_loss): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    return 0;
+  }
+  for (int r = 0; r < h->sync_emulate_world; ++r)
+    HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dst) + (size_t)r * n4 * 4, src, n4 * 4, hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
 

@@ -118,6 +118,9 @@ struct alignnet_handle {
   // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --
   // the reference's single-device semantics at the global batch (utils/tf_util.py:474) -- instead of per rank.
   bool sync_bn = false;
+  // alignnet_set_option("global_loss"): the loss (and its gradient) over the GLOBAL batch -- the [B, B] broadcast terms of models/tp8.py:279,327
+  // and the whole-batch tf.cond (:288) couple all samples -- from the all-gathered end points and labels; gradients are then summed, not averaged
+  bool global_loss = false;
   int sync_emulate_world = 1;      // test hook ("sync_bn_emulate_world"): without a communicator, every BN sum is multiplied by this many
                                    // identical virtual ranks (a step must then reproduce the plain local-BN step on the same shard)
   double* sync_buf = nullptr;      // staging for the per-layer totals that travel through the all-reduce

@@ -268,6 +268,16 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient, each issued as soon
  *   as that stage's backward has written it -- so that only the last (smallest) bucket is exposed; 0 = one all-reduce of the whole
  *   vector after the backward.  Same sums either way.
+ * "sync_bn" (0/1, default 0): data-parallel training with the reference's single-device BatchNorm semantics at the GLOBAL batch
+ *   (utils/tf_util.py:474): every batch sum behind a BatchNorm -- forward moments, the Gram / column-sum matrices of the layer
+ *   identities, the backward's (dbeta, dgamma) totals, the heads' row statistics -- is all-reduced over the ranks (RCCL, about thirty
+ *   small all-reduces per step) between the kernel that forms this rank's sum and the one that uses it.  Fused three-layer stages
+ *   and the dgcnn branch.  0: every rank normalises with its own shard's statistics ("local BN").
+ * "global_loss" (0/1, default 0): the loss and its gradient over the global batch -- the [B, B] broadcast terms (models/tp8.py:279,327)
+ *   and the whole-batch tf.cond (:288) couple all samples: end points and labels are all-gathered, every rank evaluates the same
+ *   global loss and keeps its rows of the gradient; the gradient all-reduce then sums instead of averaging.  With "sync_bn" a
+ *   data-parallel step is the reference's step at batch B x ranks.
+ * "sync_bn_emulate_world" (test hook, default 1): without a communicator, stand for this many ranks holding identical shards.
  * "dropout_stream" (default 0): selects one of 2^64 independent device-side dropout streams under the same cfg.seed; data-parallel
  *   ranks set it to their rank so that they do not draw identical masks for their local rows (initialisation stays cfg.seed's).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped

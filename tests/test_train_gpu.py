@@ -713,3 +713,37 @@ def test_sync_bn_with_identical_virtual_ranks_reproduces_local_step(gpu_required
     cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
     assert cos > 0.9999999, cos
     print(backbone, "bf16" if bf16 else "fp32", "sync_bn (2 identical virtual ranks) vs local step: worst relative gradient difference %.2e, cosine %.7f" % (worst, cos))
+
+
+@pytest.mark.parametrize("backbone,bf16", [("pointnet", 0), ("pointnet", 1), ("dgcnn", 0)])
+def test_global_loss_with_identical_virtual_ranks(gpu_required, backbone, bf16):
+    """Option "global_loss" (with "sync_bn"): end points and labels are all-gathered and the reference's loss -- whose [B, B] broadcast
+    terms (models/tp8.py:279,327) and whole-batch tf.cond (:288) couple all samples -- is evaluated on the global batch; each rank keeps
+    its rows of the gradient, the gradient all-reduce sums.  Two identical virtual ranks ("sync_bn_emulate_world" = 2: every gather
+    is two copies): the global batch is the shard twice, so every mean in the loss is the shard's own, the loss (divided by the
+    global B) is HALF the local step's, and this rank's share of the gradient a QUARTER of the local step's gradient (each sample
+    appears twice in means over 2B rows, and the loss carries 1 / (2B)) -- up to the order of the fp64 sums inside the loss."""
+    N, B = 128, 6
+    cfg, spec, P32, d, du = (_setup_dgcnn(N, B, std=True) if backbone == "dgcnn" else _setup(N, B, std=True))
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    out = {}
+    for mode in (0, 1):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("train_matmul_bf16", bf16)
+        if mode:
+            eng.set_option("sync_bn", 1); eng.set_option("global_loss", 1); eng.set_option("sync_bn_emulate_world", 2)
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+        out[mode] = (res, {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)})
+        eng.close()
+    (r0, g0), (r1, g1) = out[0], out[1]
+    assert abs(r1["loss"] - 0.5 * r0["loss"]) <= 1e-5 * abs(r0["loss"]), (r0["loss"], r1["loss"])
+    for k in ("pred_translations", "pred_remaining_angle_logits"):
+        np.testing.assert_array_equal(r1[k], r0[k])
+    gs = max(float(np.abs(v).max()) for v in g0.values())
+    worst = 0.0
+    for n in g0:
+        err = float(np.abs(g1[n] - 0.25 * g0[n]).max())
+        worst = max(worst, err / (0.25 * float(np.abs(g0[n]).max()) + 1e-6 * gs))
+        assert err <= 0.25 * (1e-4 * float(np.abs(g0[n]).max()) + 1e-6 * gs), (n, err, float(np.abs(g0[n]).max()))
+    print(backbone, "bf16" if bf16 else "fp32", "global_loss (2 identical virtual ranks): loss ratio %.7f, worst relative deviation of 4 x gradient %.2e" % (r1["loss"] / r0["loss"], worst))
