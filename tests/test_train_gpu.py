@@ -741,9 +741,14 @@ def test_global_loss_with_identical_virtual_ranks(gpu_required, backbone, bf16):
     for k in ("pred_translations", "pred_remaining_angle_logits"):
         np.testing.assert_array_equal(r1[k], r0[k])
     gs = max(float(np.abs(v).max()) for v in g0.values())
+    # fp32: every tensor to 1e-6 of its largest entry (measured 9e-7; tensors whose exact gradient is zero carry 1e-6-sized noise: the
+    # absolute floor).  bf16 operands: 2 - 4e-3 on the hidden layers of stage 1 (measured; the quarter-sized gradient rounds
+    # differently on its way through the bf16 dy2 / S tiles), bound 1e-2.
+    rtol = 1e-2 if bf16 else 1e-5
     worst = 0.0
     for n in g0:
         err = float(np.abs(g1[n] - 0.25 * g0[n]).max())
-        worst = max(worst, err / (0.25 * float(np.abs(g0[n]).max()) + 1e-6 * gs))
-        assert err <= 0.25 * (1e-4 * float(np.abs(g0[n]).max()) + 1e-6 * gs), (n, err, float(np.abs(g0[n]).max()))
+        if np.abs(g0[n]).max() > 1e-4 * gs:
+            worst = max(worst, err / (0.25 * float(np.abs(g0[n]).max())))
+        assert err <= 0.25 * (rtol * float(np.abs(g0[n]).max()) + 1e-6 * gs), (n, err, float(np.abs(g0[n]).max()))
     print(backbone, "bf16" if bf16 else "fp32", "global_loss (2 identical virtual ranks): loss ratio %.7f, worst relative deviation of 4 x gradient %.2e" % (r1["loss"] / r0["loss"], worst))
