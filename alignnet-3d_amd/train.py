@@ -89,6 +89,15 @@ class Run:
             logger.info("training with bf16 operands in the 128->C3 lifts")
         if self.dist is not None:
             parallel.init_comm(self.engine, self.dist)
+            # optional, not reference keys: "training": {"sync_bn": true, "global_loss": true} (or ALIGNNET_SYNC_BN=1 / ALIGNNET_GLOBAL_LOSS=1):
+            # batch statistics and the loss over the GLOBAL batch -- the reference's single-device step at batch_size;
+            # default: every rank normalises with / takes the loss of its own shard
+            if bool(getattr(cfg.training, "sync_bn", False)) or os.environ.get("ALIGNNET_SYNC_BN", "") not in ("", "0"):
+                self.engine.set_option("sync_bn", 1)
+                logger.info("BatchNorm statistics over all %d ranks (sync_bn)" % self.world)
+            if bool(getattr(cfg.training, "global_loss", False)) or os.environ.get("ALIGNNET_GLOBAL_LOSS", "") not in ("", "0"):
+                self.engine.set_option("global_loss", 1)
+                logger.info("loss over the global batch (global_loss)")
         self.device_data = None
         if os.environ.get("ALIGNNET_DEVICE_DATASET", "") not in ("", "0"):
             # whole dataset resident in HBM, batches resampled + jittered on the device (alignnet_dataset_*): same

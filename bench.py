@@ -230,6 +230,8 @@ def main():
                     help="dgcnn = BASELINE.json configs[4] shape: N=4096, edge-conv branch (--mode train: fp32 only)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default 1024; 4096 for dgcnn)")
     ap.add_argument("--min-leg-seconds", type=float, default=0.35, help="secondary legs are timed for at least this long")
+    ap.add_argument("--sync-bn", type=int, default=0, help="data-parallel training legs (--gpus > 1): 1 = BatchNorm statistics and the loss over the global batch "
+                                                             "(engine options sync_bn + global_loss: the reference's single-device semantics); 0 = local BN / local loss")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
     args = ap.parse_args()
@@ -300,6 +302,8 @@ def main():
         from alignnet3d import parallel
         parallel.init_comm(eng, dist)
         eng.set_option("allreduce_overlap", args.allreduce_overlap)
+        if args.sync_bn:
+            eng.set_option("sync_bn", 1); eng.set_option("global_loss", 1)
         rccl_ranks = eng.get_option("comm_world")
         if rccl_ranks != world:
             raise RuntimeError(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
@@ -471,7 +475,7 @@ def main():
                    "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY,
                    "what": "train step: batch-stat forward + loss + backward + " +
                            ("RCCL all-reduce (%s) + " % ("3 buckets overlapped with the backward" if args.allreduce_overlap else "one call after the backward")
-                            if world > 1 else "") + "Adam + EMA, local-BN data parallel" +
+                            if world > 1 else "") + "Adam + EMA, " + ("sync-BN + global-loss data parallel (the single-device step at the global batch)" if args.sync_bn else "local-BN data parallel") +
                            ("; MFMA convs on bf16 operands, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
             if world > 1:
                 leg["rccl_ranks"] = rccl_ranks

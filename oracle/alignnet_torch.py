@@ -37,8 +37,13 @@ def to_torch(P: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False)
 class TorchTp8:
     """Eager re-statement; `P` is a name->tensor dict using the oracle's names."""
 
-    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False, checkpoint: bool = False):
+    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False, checkpoint: bool = False, sync=None):
         self.spec, self.P = spec, P
+        # sync: data-parallel protocol of the engine's "sync_bn" / "global_loss" options restated (tests/test_parallel_cpu.py): an object with
+        # .world, .rank, .allreduce(t) (differentiable sum over the ranks) and .gather(t) (list of every rank's tensor, no gradient).
+        # BatchNorm moments are then those of the global batch; loss_global() evaluates the loss on the gathered batch, with the
+        # gradient flowing into this rank's rows only -- summed over the ranks, the parameter gradients are the single-device ones.
+        self.sync = sync
         # checkpoint: recompute each backbone in the backward instead of keeping its [B*N, C] activations (full-size batches:
         # 256 x 1024 points x 1024 channels in fp64 is 2 GB per tensor).  Same arithmetic, same gradients.
         self.checkpoint = checkpoint
@@ -57,6 +62,15 @@ class TorchTp8:
     def _bn(self, z, base, training, decay):
         P = self.P
         g, b = P[base + "/gamma"], P[base + "/beta"]
+        if training and self.sync is not None:
+            n = z.shape[0] * self.sync.world
+            m = self.sync.allreduce(z.sum(0)) / n
+            v = self.sync.allreduce(((z - m) ** 2).sum(0)) / n
+            with torch.no_grad():
+                d = 0.9 if decay is None else decay
+                self.ema_updates[base + "/moving_mean"] = d * P[base + "/moving_mean"] + (1 - d) * m
+                self.ema_updates[base + "/moving_var"] = d * P[base + "/moving_var"] + (1 - d) * v
+            return (z - m) * torch.rsqrt(v + BN_EPS) * g + b
         if training:
             # F.batch_norm(training=True) normalises with the biased batch variance,
             # which is tf.nn.moments' variance (utils/tf_util.py:474).
@@ -221,6 +235,18 @@ class TorchTp8:
         lt = s.early_stage_factor * (s1 + s2) + s3t
         la = s.early_stage_factor * ((la1[0] + la2[0]) / 2) + la3[0]
         return (lt + s.angle_factor * la) / translations.shape[0]
+
+
+def _loss_global(self, ep, labels):
+    """The loss on the all-gathered batch ("global_loss"): other ranks' rows enter as constants, this rank's with their graph."""
+    def glob(t):
+        parts = [x.detach() for x in self.sync.gather(t)]
+        parts[self.sync.rank] = t
+        return torch.cat(parts, 0)
+    return self.loss({k: glob(v) for k, v in ep.items()}, *[glob(x) for x in labels])
+
+
+TorchTp8.loss_global = _loss_global
 
 
 def tf_adam(w, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):

@@ -206,6 +206,27 @@ for overlap in (1, 0):
     assert all(torch.equal(lst[0], x) for x in lst), "ranks diverged"
     eng.close()
 np.testing.assert_array_equal(out[0], out[1])   # bucketed and single all-reduce give the same sums
+# sync_bn + global_loss: the data-parallel step is the single-device step at the global batch -- all-reduced gradient (summed) of
+# the shards against one engine (no communicator) that takes the whole batch
+eng = alignnet3d.Engine(cfg, device=rank)
+eng.set_variables(P32)
+parallel.init_comm(eng, dist)
+eng.set_option("sync_bn", 1); eng.set_option("global_loss", 1)
+rs = eng.train_forward_backward(shard["pcs1"], shard["pcs2"], shard, u)
+g = torch.from_numpy(np.concatenate([eng.get_gradient(n).ravel() for n in names])).cuda()
+dist.all_reduce(g)
+ema = {n: eng.get_variable(n) for n, _, t in eng.variables() if not t}
+eng.close()
+one = alignnet3d.Engine(cfg, device=rank)
+one.set_variables(P32)
+rf = one.train_forward_backward(d["pcs1"], d["pcs2"], d, [np.full((16, 32), 0.9, np.float32)] * 5)
+gf = np.concatenate([one.get_gradient(n).ravel() for n in names])
+assert abs(rs["loss"] - rf["loss"]) <= 1e-5 * abs(rf["loss"]), (rs["loss"], rf["loss"])
+np.testing.assert_allclose(g.cpu().numpy(), gf, rtol=2e-3, atol=2e-5 * np.abs(gf).max())
+for n, v in ema.items():
+    np.testing.assert_allclose(v, one.get_variable(n), rtol=1e-5, atol=1e-6, err_msg=n)
+np.testing.assert_allclose(rs["pred_translations"], rf["pred_translations"][lo:hi], rtol=1e-4, atol=1e-4)
+one.close()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL2_OK rank", rank)

@@ -120,6 +120,43 @@ def _worker(rank, world, port, q):
             ref = sum(_shard_grads(spec, P, d, *parallel.shard_range(8, r, world))[0] for r in range(world)) / world
             assert torch.allclose(g, ref, rtol=1e-12, atol=1e-14)
             assert float(g.abs().max()) > 0
+        # 5. "sync_bn" + "global_loss": BatchNorm moments over all ranks (differentiable all-reduce of the sums: its backward all-reduces
+        #    the gradient sums, which is what the engine's all-reduced (dbeta, dgamma) totals are), the loss on the gathered batch with
+        #    the gradient into this rank's rows only, gradients SUMMED -> the single-process gradient at the global batch
+        import torch.distributed.nn.functional as dfn
+        from oracle import alignnet_torch as T
+
+        class GlooSync:
+            world, rank = dist.get_world_size(), dist.get_rank()
+            @staticmethod
+            def allreduce(t):
+                return dfn.all_reduce(t.contiguous())
+            @staticmethod
+            def gather(t):
+                out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+                dist.all_gather(out, t.detach().contiguous())
+                return out
+
+        def grads_of(lo_, hi_, sync):
+            tp = T.to_torch(P, requires_grad=True)
+            tm = T.TorchTp8(spec, tp, sync=sync)
+            td = {k: torch.tensor(v[lo_:hi_]) for k, v in d.items()}
+            u = {k: torch.full((hi_ - lo_, 16), 0.9, dtype=torch.float64) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+            ep = tm.forward(td["pcs1"], td["pcs2"], True, 0.5, u)
+            labels = [td[k] for k in LABELS]
+            lossv = tm.loss_global(ep, labels) if sync is not None else tm.loss(ep, *labels)
+            lossv.backward()
+            names = sorted(k for k, v in tp.items() if v.requires_grad)
+            flat = torch.cat([(tp[k].grad if tp[k].grad is not None else torch.zeros_like(tp[k])).reshape(-1) for k in names])
+            return flat, float(lossv), {k: v.clone() for k, v in tm.ema_updates.items()}
+
+        gs_, loss_s, ema_s = grads_of(lo, hi, GlooSync)
+        dist.all_reduce(gs_, op=dist.ReduceOp.SUM)           # summed, not averaged: the loss is already the global batch's
+        ref_g, ref_loss, ref_ema = grads_of(0, 8, None)      # the same batch on one device
+        assert abs(loss_s - ref_loss) <= 1e-12 * abs(ref_loss), (loss_s, ref_loss)
+        assert torch.allclose(gs_, ref_g, rtol=1e-9, atol=1e-12 * float(ref_g.abs().max())), float((gs_ - ref_g).abs().max())
+        for k in ref_ema:
+            assert torch.allclose(ema_s[k], ref_ema[k], rtol=1e-12, atol=1e-14), k
         dist.barrier()
         q.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
