@@ -267,7 +267,7 @@ def test_every_shipped_reference_config_marshals(tiny, monkeypatch):
 
 def test_own_bench_configs_marshal(tiny, monkeypatch):
     """alignnet-3d_amd/configs/*.json (this build's own files: the BASELINE.json workloads in the reference's schema) load through
-    config.py and marshal into the C config; the non-reference key they use (training.matmul_dtype) survives the merge."""
+    config.py and marshal into the C config; the non-reference keys they use (training.matmul_dtype, training.sync_bn, training.global_loss) survive the merge."""
     import glob
     from alignnet3d.engine import make_c_config
     cfgmod = tiny["config"]
@@ -285,5 +285,5 @@ def test_own_bench_configs_marshal(tiny, monkeypatch):
         if "bf16" in path:
             assert cfg.training.matmul_dtype == "bf16"
         if "b2048" in path:
-            assert c.batch_size == 2048
+            assert cfg.training.sync_bn is True and cfg.training.global_loss is True and c.batch_size == 2048
     cfgmod.reset_config()
