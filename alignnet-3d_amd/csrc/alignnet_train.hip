@@ -560,6 +560,7 @@ static int pack_all_weights(alignnet_handle* h)
         pj.src[nj] = P(h, L.p_w); pj.gamma[nj] = nullptr; pj.dst[nj] = w->w3th[s]; pj.K[nj] = -L.cin; pj.C[nj] = L.cout; ++nj;
       }
     }
+    if (nj > kPackBf16Jobs) return fail(h, "pack_all_weights: job table overflow");
     if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(32, nj), dim3(256), 0, h->stream, pj);
   }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward

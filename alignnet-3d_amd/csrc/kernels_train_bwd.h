@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   // S is built as two bf16 tiles hi + lo (16 significant bits of the gradient), and 16 MFMAs per wave add the product to the
   // accumulators that take h2 Q3.  The scatter it replaces gave every row to one wave (rows that win many channels: up to several
   // hundred hits on one wave) and was half of the kernel.  Deterministic: fixed summation order.
-  constexpr bool SPM = BF16 && !ACCUM && !GIVEN && C1T == 64 && C2T == 128;
+  constexpr bool SPM = BF16 && !ACCUM && !GIVEN && C1T == 64 && C2T == 128;   // (on given features -- the dgcnn point conv -- it was measured too: 12 spilled registers next to the feature prefetch, 266 vs 249 us per launch)
   constexpr int kSpH = 64, kSpLd = kSpH + 8;                 // hits per chunk; row stride of the S / R^T tiles (conflict-free 16-byte reads)
   constexpr int kXbytes = SPM ? (kTT * 72 + 128 * kSpLd + kTT * kSpLd) * 2 : 0;   // h1 bf16 | R^T | S lo   (X region of the SPM layout)
   float* xs = smem;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // like the rest of the bf16 mode.
 // LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
 // ---------------------------------------------------------------------------------
-constexpr int kPackBf16Jobs = 12;
+constexpr int kPackBf16Jobs = 16;
 struct PackBf16Jobs {
   const float* src[kPackBf16Jobs]; const float* gamma[kPackBf16Jobs]; unsigned short* dst[kPackBf16Jobs]; int K[kPackBf16Jobs], C[kPackBf16Jobs];
   const float* rowscale[kPackBf16Jobs];   // null, or [K]: element (k, c) is multiplied by rowscale[k] before rounding

@@ -970,15 +970,28 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
         for (int e = 0; e < 8; ++e) {
           hi[e] = to_bf16_bits(dv[e]);
           lo[e] = to_bf16_bits(dv[e] - __uint_as_float(hi[e] << 16));
-          const unsigned akb = ((e < 4 ? ak.x : ak.y) >> (8 * (e & 3))) & 0xffu;
-          PhT[(o * 8 + e) * ldT + r] = (unsigned short)hi[e];
-          PlT[(o * 8 + e) * ldT + r] = (unsigned short)lo[e];
-          AKT[(o * 8 + e) * ldT + r] = (unsigned char)akb;
         }
         *reinterpret_cast<uint4*>(Ph + r * ldd + o * 8) = uint4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
         *reinterpret_cast<uint4*>(Pl + r * ldd + o * 8) = uint4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
         *reinterpret_cast<unsigned*>(AK + r * ldak + o * 8) = ak.x;
         *reinterpret_cast<unsigned*>(AK + r * ldak + o * 8 + 4) = ak.y;
+      }
+      __syncthreads();
+      // transposed copies, lanes along the columns (conflict-free: consecutive elements of a row in, 16 / 8 bytes of a column out; written
+      // element by element from the loop above the 2-byte stores of a wave fell into two banks)
+      for (int item = tid; item < C2 * (kTT / 8); item += kBEW * 64) {
+        const int c = item % C2, ro = item / C2;
+        unsigned wh[4], wl[4], wa[2] = {0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int rr = ro * 8 + e;
+          const unsigned h1 = Ph[rr * ldd + c], l1 = Pl[rr * ldd + c], a1 = AK[rr * ldak + c];
+          if (e & 1) { wh[e >> 1] |= h1 << 16; wl[e >> 1] |= l1 << 16; } else { wh[e >> 1] = h1; wl[e >> 1] = l1; }
+          wa[e >> 2] |= a1 << (8 * (e & 3));
+        }
+        *reinterpret_cast<uint4*>(PhT + c * ldT + ro * 8) = uint4{wh[0], wh[1], wh[2], wh[3]};
+        *reinterpret_cast<uint4*>(PlT + c * ldT + ro * 8) = uint4{wl[0], wl[1], wl[2], wl[3]};
+        *reinterpret_cast<uint2*>(AKT + c * ldT + ro * 8) = uint2{wa[0], wa[1]};
       }
     }
     dgt_liftm_bf16<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane);   // (this h1 buffer's readers, two slots back, are behind the last barrier)

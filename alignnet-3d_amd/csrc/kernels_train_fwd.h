@@ -407,13 +407,25 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         for (int e = 0; e < 4; ++e) {
           hb[e] = to_bf16_bits(v[e]);
           ls[e] += __uint_as_float((unsigned)hb[e] << 16);
-          bufT[(q * 4 + e) * ldT + row] = hb[e];
         }
         uint2 pk; pk.x = hb[0] | ((unsigned)hb[1] << 16); pk.y = hb[2] | ((unsigned)hb[3] << 16);
         *reinterpret_cast<uint2*>(buf1h + row * ldh + q * 4) = pk;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) gcs[e] += (double)ls[e];
+      // the transposed tile from the row-major one: lanes along the COLUMNS (reads: consecutive 2-byte elements of a row; writes:
+      // 16 bytes = eight rows of one column, row stride 36 dwords: conflict-free).  Written element by element from the load loop --
+      // lanes along q, 144 q dwords apart -- the 2-byte stores fell into four banks: 67 % of this kernel's LDS cycles were conflicts
+      // (profiles/r03_train_dgcnn_bf16_pmc_by_kernel.json, first pass).
+      __syncthreads();
+      for (int i = tid; i < kC2 * (kTT / 8); i += kTW * 64) {
+        const int c = i % kC2, ro = i / kC2;
+        unsigned wv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          wv[e] = (unsigned)buf1h[(ro * 8 + 2 * e) * ldh + c] | ((unsigned)buf1h[(ro * 8 + 2 * e + 1) * ldh + c] << 16);
+        *reinterpret_cast<uint4*>(bufT + c * ldT + ro * 8) = uint4{wv[0], wv[1], wv[2], wv[3]};
+      }
     } else if (GIVEN) {
       const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c4 = kC2 >> 2;
