@@ -117,7 +117,8 @@ struct TrainWS {
   unsigned short* w2th[3] = {nullptr, nullptr, nullptr};   // bf16 MFMA images of round(W2)^T (K = C2, C = C1) per stage: dense edge backward of the dgcnn branch (train_bf16)
   unsigned short* w3th[3] = {nullptr, nullptr, nullptr};   // bf16 round(W3)^T [C3][C2] per stage: rows gathered by pass B2's sparse part (train_bf16, shipped widths)
   // general-depth PointNet stages (kernels_train_generic.h): pre-BatchNorm activations of every layer stay in HBM
-  struct GenStage { float* X0; float* Z[kMaxConv]; float *mean[kMaxConv], *rstd[kMaxConv], *scale[kMaxConv], *shift[kMaxConv]; int* idx; } gen[3];
+  struct GenStage { float* X0; float* Z[kMaxConv]; float *mean[kMaxConv], *rstd[kMaxConv], *scale[kMaxConv], *shift[kMaxConv]; int* idx;
+                    float* P; int* argk; float *one, *zero; } gen[3];   // general dgcnn stages: pooled edge features [2B N][C], their arg-k slot, identity scale / shift
   float *gen_d[2] = {nullptr, nullptr};   // gradient ping-pong buffers [2B*N][widest layer]
   float *gen_part = nullptr, *gen_dwpart = nullptr, *gen_ppart = nullptr, *gen_cA = nullptr, *gen_cB = nullptr, *gen_wt = nullptr;
   int gen_tiles = 0, gen_slabs = 0;
@@ -171,9 +172,21 @@ static size_t img_floats(int K, int C) { return (size_t)((C + 31) / 32) * ((K + 
 
 // A PointNet stage outside the shape the specialised kernels are built for (three conv layers, widths multiples of 32, C1, C2 <= 128,
 // C3 <= 1024) trains on the general layer-by-layer path -- e.g. the five-layer backbones of the reference's configs/default.json.
+// The dgcnn stages the specialised edge kernels are built for: [C1, C2, C3] with C1 in {32, 64}, C2 in {64, 128}.
+static bool dg_special_shape(const alignnet_handle* h, int s)
+{
+  const Stack& st = conv_of(h, s);
+  if (st.n != 3) return false;
+  const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
+  if (C1 % 32 || C2 % 32 || C3 % 32 || C3 > 1024) return false;
+  const int CT1 = (C1 + 31) / 32;
+  return (C1 == 32 || C1 == 64) && (C2 == 64 || C2 == 128) && CT1 * 2 + CT1 * (CT1 + 1) / 2 <= kBEW && (size_t)C1 * C2 <= 8192 &&
+         dg_bwd_edge_lds(C1, C2) <= 160 * 1024;
+}
+
 static bool stage_generic(const alignnet_handle* h, int s)
 {
-  if (h->cfg.backbone == 1) return false;
+  if (h->cfg.backbone == 1) return !dg_special_shape(h, s);   // any other `sizes` list of models/tp8.py:38-41: layer by layer over the edge rows
   const Stack& st = conv_of(h, s);
   if (st.n != 3) return true;
   const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
@@ -188,7 +201,7 @@ static bool stage_generic(const alignnet_handle* h, int s)
 // layer-by-layer path (tests compare the two).
 static bool stage_hybrid(const alignnet_handle* h, int s)
 {
-  if (!stage_generic(h, s) || !h->fused_tail) return false;
+  if (!stage_generic(h, s) || !h->fused_tail || h->cfg.backbone == 1) return false;
   const Stack& st = conv_of(h, s);
   if (st.n < 3) return false;
   const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + st.n - 2].cout, C3 = h->layers[st.first + st.n - 1].cout;
@@ -203,8 +216,9 @@ static int check_trainable_shape(alignnet_handle* h)
       if (stage_generic(h, s)) return fail(h, "sync_bn: supported for the fused three-layer stages (every shipped dataset config) and the dgcnn branch, not for general-depth backbones");
       if (!dg && h->layers[conv_of(h, s).first].cout > 64) return fail(h, "sync_bn: first conv width limited to 64");
     }
-  for (int s = 0; s < 3 && !dg; ++s)
+  for (int s = 0; s < 3; ++s)
     if (stage_generic(h, s)) {
+      if (dg && conv_of(h, s).n < 2) return fail(h, "training: a dgcnn stage needs at least one edge conv and the point conv");
       const Stack& st = conv_of(h, s);
       for (int i = 0; i < st.n; ++i) {
         const Layer& L = h->layers[st.first + i];
@@ -215,19 +229,16 @@ static int check_trainable_shape(alignnet_handle* h)
     }
   if (dg && h->train_bf16)   // (the bf16 edge conv: dg_train_fwd<C1, true>; the point conv and the backward stay fp32)
     for (int s = 0; s < 3; ++s)
-      if (h->layers[conv_of(h, s).first].cout % 16) return fail(h, "training: train_matmul_bf16 with the dgcnn backbone needs a first edge width that is a multiple of 16");
+      if (!stage_generic(h, s) && h->layers[conv_of(h, s).first].cout % 16) return fail(h, "training: train_matmul_bf16 with the dgcnn backbone needs a first edge width that is a multiple of 16");
   if (dg && (h->cfg.num_points > 64 * kKnnMaxPerLane || h->cfg.num_points < kDgK))
     return fail(h, "training: dgcnn needs 20 <= num_points <= 4096");
   for (int s = 0; s < 3; ++s) {
     const Stack& st = conv_of(h, s);
     if (stage_generic(h, s)) continue;
-    if (st.n != 3) return fail(h, "training: the dgcnn backbone supports 3-conv-layer stages; got " + std::to_string(st.n));
     const int C1 = h->layers[st.first].cout, C2 = h->layers[st.first + 1].cout, C3 = h->layers[st.first + 2].cout;
     if (C1 % 32 || C2 % 32 || C3 % 32) return fail(h, "training: conv widths must be multiples of 32");
     if (C1 > 128 || C2 > 128 || C3 > 1024) return fail(h, "training: conv widths limited to C1,C2 <= 128, C3 <= 1024");
-    const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
-    if (dg && ((C1 != 32 && C1 != 64) || (C2 != 64 && C2 != 128) || CT1 * 2 + CT1 * (CT1 + 1) / 2 > kBEW || (size_t)C1 * C2 > 8192 || dg_bwd_edge_lds(C1, C2) > 160 * 1024))
-      return fail(h, "training: dgcnn edge-conv widths limited to C1 in {32, 64}, C2 in {64, 128} (e.g. 64,128)");
+    const int CT2 = (C2 + 31) / 32;
     (void)CT2;
   }
   return 0;
@@ -258,6 +269,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
   const size_t B2 = 2 * (size_t)B, MN = B2 * N;
   int maxC = 8, maxC1 = 8, maxC2 = 8, maxC3 = 8, maxH = 8;
   int genC = 0, genK = 8;   // widest layer / widest MFMA-layer input of the general-depth stages
+  size_t genRC = 0, genPart = 0, genDW = 0;   // per tower, the largest over the layer-by-layer tensors of: rows x width (gradient ping-pong buffers), tiles x width (statistics partials), slabs x K x C (dW partials)
   for (int s = 0; s < 3; ++s) {
     const Stack& st = conv_of(h, s);
     {
@@ -266,7 +278,13 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     }
     if (stage_generic(h, s)) {
       const bool hyb = stage_hybrid(h, s);   // the last layer belongs to the fused kernels: no [B N, C_last] buffers
-      for (int i = 0; i < st.n - (hyb ? 1 : 0); ++i) { genC = std::max(genC, h->layers[st.first + i].cout); if (i) genK = std::max(genK, h->layers[st.first + i].cin); }
+      for (int i = 0; i < st.n - (hyb ? 1 : 0); ++i) {
+        genC = std::max(genC, h->layers[st.first + i].cout); if (i) genK = std::max(genK, h->layers[st.first + i].cin);
+        const size_t rows = (size_t)B * N * ((h->cfg.backbone == 1 && i < st.n - 1) ? kDgK : 1);   // per tower
+        genRC = std::max(genRC, rows * h->layers[st.first + i].cout);
+        genPart = std::max(genPart, ((rows + kGenTile - 1) / kGenTile) * h->layers[st.first + i].cout);
+        if (i) genDW = std::max(genDW, ((rows + kGenSlab - 1) / kGenSlab) * h->layers[st.first + i].cin * h->layers[st.first + i].cout);
+      }
       maxC3 = std::max(maxC3, h->layers[st.first + st.n - 1].cout);
       if (hyb) maxC2 = std::max(maxC2, h->layers[st.first + st.n - 2].cout);
       continue;
@@ -304,12 +322,16 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.xform = F(B2 * 12);
       if (gen) {
         TrainWS::GenStage& Gs = w->gen[s];
-        Gs.X0 = F(MN * 4);
+        const bool dgg = h->cfg.backbone == 1;            // general dgcnn stage: the layers in front of the last one live on the B N k edge rows
+        const size_t ME = dgg ? MN * kDgK : MN;
+        Gs.X0 = F(dgg ? ME * 8 : MN * 4);
         for (int i = 0; i < st.n; ++i) {
           const int c = h->layers[st.first + i].cout;
-          Gs.Z[i] = F((hyb && i == st.n - 1) ? 8 : MN * c); Gs.mean[i] = F(2 * c); Gs.rstd[i] = F(2 * c); Gs.scale[i] = F(2 * c); Gs.shift[i] = F(2 * c);
+          Gs.Z[i] = F((hyb && i == st.n - 1) ? 8 : (i < st.n - 1 ? ME : MN) * c); Gs.mean[i] = F(2 * c); Gs.rstd[i] = F(2 * c); Gs.scale[i] = F(2 * c); Gs.shift[i] = F(2 * c);
         }
         Gs.idx = I(B2 * Cl);
+        const int Cp = dgg ? h->layers[st.first + st.n - 2].cout : 8;
+        Gs.P = F(dgg ? MN * Cp : 8); Gs.argk = I(dgg ? MN * Cp : 8); Gs.one = F(2 * Cp); Gs.zero = F(2 * Cp);
       }
       for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); S.rstd[l] = F(2 * C[l]); S.kk[l] = F(2 * C[l]); }
       S.sgn3 = F(2 * C[2]);
@@ -345,12 +367,12 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       w->head_din[s] = S.dP;
     }
     if (genC) {
-      const size_t M1 = (size_t)B * N;
+      const size_t M1 = (size_t)B * N * (h->cfg.backbone == 1 ? kDgK : 1);   // rows per tower of the widest layer-by-layer tensors (dgcnn: edge rows)
       w->gen_tiles = (int)((M1 + kGenTile - 1) / kGenTile); w->gen_slabs = (int)((M1 + kGenSlab - 1) / kGenSlab);
-      w->gen_d[0] = F(MN * genC); w->gen_d[1] = F(MN * genC);
-      w->gen_part = F((size_t)2 * w->gen_tiles * genC * 2);
-      w->gen_dwpart = F((size_t)2 * w->gen_slabs * genK * genC);
-      w->gen_ppart = F(B2 * 3 * (size_t)genC);
+      w->gen_d[0] = F(2 * genRC); w->gen_d[1] = F(2 * genRC);
+      w->gen_part = F(2 * genPart * 2);
+      w->gen_dwpart = F(2 * std::max(genDW, (size_t)8));
+      w->gen_ppart = F(B2 * 6 * (size_t)genC);
       w->gen_cA = F(2 * genC); w->gen_cB = F(2 * genC);
       w->gen_wt = F(img_floats(genC, genK) + 1024);
     }
@@ -634,20 +656,37 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(gen_gemm_dx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr.mark(h->cfg.device);
   }
-  hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
+  // dgcnn (models/tp8.py:30-46): the layers in front of the last one are edge convs over the B N k edge rows, the last one is the point
+  // conv over the B N rows of max-over-k features
+  const bool dg = h->cfg.backbone == 1;
+  const int ME = dg ? M * kDgK : M, tiles_e = (ME + kGenTile - 1) / kGenTile;
+  if (dg) hipLaunchKernelGGL(gen_edge_kernel, dim3((unsigned)(((size_t)2 * ME + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, w->nn, B, N, kDgK, Gs.X0);
+  else hipLaunchKernelGGL(gen_xform_kernel, dim3((unsigned)(((size_t)2 * M + 255) / 256)), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, Gs.X0);
   const bool partial = nl >= 0;
   if (!partial) nl = st.n;
   for (int l = 0; l < nl; ++l) {
     const Layer& L = h->layers[st.first + l];
+    const bool edge = dg && l < st.n - 1;
+    const int rows = edge ? ME : M, lt = edge ? tiles_e : tiles;
     if (l == 0) {
-      GenL1Args a{Gs.X0, P(h, L.p_w), P(h, L.p_b), Gs.Z[0], w->gen_part, M, L.cout, tiles};
-      hipLaunchKernelGGL(gen_layer1_fwd, dim3(tiles, 2), dim3(256), 0, h->stream, a);
-    } else {
-      GenGemmArgs a{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], h->d_wp + L.off_wp, P(h, L.p_b), Gs.Z[l], w->gen_part, M, L.cin, L.cout, tiles};
+      GenL1Args a{Gs.X0, P(h, L.p_w), P(h, L.p_b), Gs.Z[0], w->gen_part, rows, L.cout, lt};
+      if (dg) hipLaunchKernelGGL(gen_layer1e_fwd, dim3(lt, 2), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL(gen_layer1_fwd, dim3(lt, 2), dim3(256), 0, h->stream, a);
+    } else if (dg && !edge) {
+      // max over the k neighbours of relu(bn(Z_{n-2})) (utils/tf_util_dgcnn.py: reduce_max over the k axis) -> P [2 B N][K] and the slot
+      // it came from; the point conv reads P through identity scale / shift (P >= 0: the relu of gen_gemm_fwd's staging is a no-op)
+      GenPoolArgs pk{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], M, kDgK, L.cin, Gs.P, (long)M * L.cin, (long)L.cin, Gs.argk};
+      hipLaunchKernelGGL(gen_pool_fwd, dim3(2 * M, (L.cin + 63) / 64), dim3(256), 0, h->stream, pk);
+      hipLaunchKernelGGL(gen_fill_kernel, dim3((2 * L.cin + 255) / 256), dim3(256), 0, h->stream, Gs.one, (size_t)2 * L.cin, 1.f);
+      hipLaunchKernelGGL(gen_fill_kernel, dim3((2 * L.cin + 255) / 256), dim3(256), 0, h->stream, Gs.zero, (size_t)2 * L.cin, 0.f);
+      GenGemmArgs a{Gs.P, Gs.one, Gs.zero, h->d_wp + L.off_wp, P(h, L.p_b), Gs.Z[l], w->gen_part, M, L.cin, L.cout, tiles};
       hipLaunchKernelGGL(gen_gemm_fwd, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * (L.cin + 4) * sizeof(float), h->stream, a);
+    } else {
+      GenGemmArgs a{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], h->d_wp + L.off_wp, P(h, L.p_b), Gs.Z[l], w->gen_part, rows, L.cin, L.cout, lt};
+      hipLaunchKernelGGL(gen_gemm_fwd, dim3(lt, 2), dim3(kGenWaves * 64), (size_t)kGenTile * (L.cin + 4) * sizeof(float), h->stream, a);
     }
     GenStatArgs f;
-    f.part = w->gen_part; f.tiles = tiles; f.M = M; f.C = L.cout;
+    f.part = w->gen_part; f.tiles = lt; f.M = rows; f.C = L.cout;
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L.p_bn[t][0]); f.gamma[t] = P(h, L.p_bn[t][1]); f.mov_mean[t] = P(h, L.p_bn[t][2]); f.mov_var[t] = P(h, L.p_bn[t][3]);
     }
@@ -679,27 +718,39 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B, float* given_d
     HIP_TRY(h, hipMemsetAsync(dY, 0, R * Cl * sizeof(float), h->stream));
     hipLaunchKernelGGL(gen_pool_bwd, dim3((unsigned)(((size_t)2 * B * Cl + 255) / 256)), dim3(256), 0, h->stream, S.dP, S.tower_stride, S.row_stride, Gs.idx, B, N, Cl, dY);
   }
+  const bool dg = h->cfg.backbone == 1;   // (never with given_dY: dgcnn stages are not hybrid)
+  const int ME = dg ? M * kDgK : M, tiles_e = (ME + kGenTile - 1) / kGenTile;
   for (int l = given_dY ? Ll - 1 : Ll; l >= 0; --l) {
     const Layer& L = h->layers[st.first + l];
     const int C = L.cout, K = L.cin;
-    GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, M, C, tiles};
-    hipLaunchKernelGGL(gen_bn_bwd_reduce, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);
-    GenBnFinArgs f{w->gen_part, tiles, M, C, {G(h, w, L.p_bn[0][0]), G(h, w, L.p_bn[1][0])}, {G(h, w, L.p_bn[0][1]), G(h, w, L.p_bn[1][1])}, w->gen_cA, w->gen_cB};
+    const bool edge = dg && l < Ll, pointconv = dg && l == Ll;
+    const int rows = edge ? ME : M, lt = edge ? tiles_e : tiles;
+    GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, rows, C, lt};
+    hipLaunchKernelGGL(gen_bn_bwd_reduce, dim3(lt, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);
+    GenBnFinArgs f{w->gen_part, lt, rows, C, {G(h, w, L.p_bn[0][0]), G(h, w, L.p_bn[1][0])}, {G(h, w, L.p_bn[0][1]), G(h, w, L.p_bn[1][1])}, w->gen_cA, w->gen_cB};
     hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(1024), 0, h->stream, f);
-    hipLaunchKernelGGL(gen_bn_bwd_apply, dim3(tiles, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);   // dY is dZ_l from here on
+    hipLaunchKernelGGL(gen_bn_bwd_apply, dim3(lt, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);   // dY is dZ_l from here on
     if (l == 0) {
-      GenL1BwdArgs a{Gs.X0, dY, P(h, L.p_w), B, N, C, w->gen_ppart, S.gx, S.grot};
-      hipLaunchKernelGGL(gen_layer1_bwd, dim3(2 * B), dim3(256), 0, h->stream, a);
-      launch_reduce<float>(h, w->gen_ppart, 2 * B, (long)3 * C, G(h, w, L.p_w), 1);   // (32 slice groups per column block: one thread per element walking all partials was 0.12 ms per layer)
+      GenL1BwdArgs a{Gs.X0, dY, P(h, L.p_w), B, dg ? N * kDgK : N, C, w->gen_ppart, S.gx, S.grot};
+      if (dg) hipLaunchKernelGGL(gen_layer1e_bwd, dim3(2 * B), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL(gen_layer1_bwd, dim3(2 * B), dim3(256), 0, h->stream, a);
+      launch_reduce<float>(h, w->gen_ppart, 2 * B, (long)(dg ? 6 : 3) * C, G(h, w, L.p_w), 1);   // (32 slice groups per column block: one thread per element walking all partials was 0.12 ms per layer)
       break;
     }
-    const int slab_rows = gen_slab_rows(C), lslabs = (M + slab_rows - 1) / slab_rows;   // <= slabs (the buffer's extent, 1024-row slabs)
-    GenDwArgs dw{Gs.Z[l - 1], Gs.scale[l - 1], Gs.shift[l - 1], dY, w->gen_dwpart, M, K, C, lslabs, slab_rows};
+    const int slab_rows = gen_slab_rows(C), lslabs = (rows + slab_rows - 1) / slab_rows;   // <= slabs (the buffer's extent, 1024-row slabs)
+    GenDwArgs dw{pointconv ? Gs.P : Gs.Z[l - 1], pointconv ? Gs.one : Gs.scale[l - 1], pointconv ? Gs.zero : Gs.shift[l - 1], dY, w->gen_dwpart, rows, K, C, lslabs, slab_rows};
     hipLaunchKernelGGL(gen_gemm_dw, dim3(lslabs, 2, (C + 63) / 64), dim3(kGenWaves * 64), ((size_t)kGenTile * K + kGenTile * 64) * sizeof(float), h->stream, dw);
     launch_reduce<float>(h, w->gen_dwpart, 2 * lslabs, (long)K * C, G(h, w, L.p_w), 1);
     hipLaunchKernelGGL(gen_pack_transposed, dim3(64), dim3(256), 0, h->stream, P(h, L.p_w), K, C, w->gen_wt);
-    GenDxArgs dx{dY, w->gen_wt, dYprev, M, K, C};
-    hipLaunchKernelGGL(gen_gemm_dx, dim3(tiles, 2), dim3(kGenWaves * 64), (size_t)kGenTile * 132 * sizeof(float), h->stream, dx);
+    GenDxArgs dx{dY, w->gen_wt, dYprev, rows, K, C};
+    hipLaunchKernelGGL(gen_gemm_dx, dim3(lt, 2), dim3(kGenWaves * 64), (size_t)kGenTile * 132 * sizeof(float), h->stream, dx);
+    if (pointconv) {
+      // dYprev is dP [2 B N][K]: scatter it to the edge row each maximum came from (dZ_L in dY is spent: the zeroed edge gradient takes
+      // its place, so dY stays the current gradient and there is no swap)
+      HIP_TRY(h, hipMemsetAsync(dY, 0, (size_t)2 * ME * K * sizeof(float), h->stream));
+      hipLaunchKernelGGL(gen_pool_bwd, dim3((unsigned)(((size_t)2 * M * K + 255) / 256)), dim3(256), 0, h->stream, dYprev, (long)M * K, (long)K, Gs.argk, M, kDgK, K, dY);
+      continue;
+    }
     if (dY == given_dY) { dY = dYprev; dYprev = w->gen_d[1]; }   // (the tail's buffer is only as wide as its own layer: not a scratch for the others)
     else std::swap(dY, dYprev);
   }
@@ -1062,6 +1113,7 @@ static int head_bwd_train(alignnet_handle* h, int s, const float* in, long ldin,
 static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const float* p2, int B)
 {
   const bool hyb = stage_hybrid(h, s);
+  tws(h)->glue_folded = false;   // (before the layer-by-layer return: a folded glue of the stage behind this one must not carry over)
   if (stage_generic(h, s) && !hyb) return backbone_bwd_generic(h, s, B);
   TrainWS* w = tws(h);
   StageWS& S = w->st[s];

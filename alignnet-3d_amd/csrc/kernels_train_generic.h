@@ -574,4 +574,133 @@ __global__ __launch_bounds__(256) void gen_layer1_bwd(const GenL1BwdArgs a)
   if (threadIdx.x == 3) a.grot[cloud] = (float)fin[3];
 }
 
+// =================================================================================================================================
+// DGCNN backbones of any widths / depth (models/tp8.py:30-46 loops over `sizes[:-1]` for the edge convs): the same layer-by-layer
+// machinery over the B N k EDGE rows (row = ((tower B + b) N + n) k + slot), fed by three kernels of its own:
+//   gen_edge_kernel      E = [x_i', (x_j - x_i) R]  per edge row, [rows][8] (columns 6, 7 zero)      (utils/tf_util_dgcnn.py:674-706)
+//   gen_layer1e_fwd      Z_1 = E W_1 + b_1 (K = 6, VALU) + tile statistics
+//   gen_layer1e_bwd      per cloud: S = sum dZ_1, P = E^T dZ_1 -> dW_1 partials and the frame gradients gx / grot
+// The max over the k neighbours and the max over the points are gen_pool_fwd / gen_pool_bwd with (clouds, rows per cloud) =
+// (2 B N, k) and (2 B, N); the point conv takes the pooled edge features through identity scale / shift arrays.
+// =================================================================================================================================
+__global__ void gen_edge_kernel(const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ xform, const int* __restrict__ nn,
+                                int B, int N, int k, float* __restrict__ E)
+{
+  const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (r >= (size_t)2 * B * N * k) return;
+  const size_t pt = r / k;
+  const int cloud = (int)(pt / N), n = (int)(pt - (size_t)cloud * N), tower = cloud >= B, b = cloud - tower * B;
+  const float* pc = (tower ? p2 : p1) + (size_t)b * N * 3;
+  const float* xf = xform + (size_t)cloud * 12;
+  const int j = nn[r];
+  const float* p = pc + (size_t)n * 3;
+  const float* pj = pc + (size_t)j * 3;
+  const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
+  const float dx = pj[0] - p[0], dy = pj[1] - p[1], dz = pj[2] - p[2];
+  f32x4 a, c;
+  a[0] = x * xf[3] + y * xf[6] + z * xf[9];
+  a[1] = x * xf[4] + y * xf[7] + z * xf[10];
+  a[2] = x * xf[5] + y * xf[8] + z * xf[11];
+  a[3] = dx * xf[3] + dy * xf[6] + dz * xf[9];
+  c[0] = dx * xf[4] + dy * xf[7] + dz * xf[10];
+  c[1] = dx * xf[5] + dy * xf[8] + dz * xf[11];
+  c[2] = 0.f; c[3] = 0.f;
+  reinterpret_cast<f32x4*>(E)[2 * r] = a;
+  reinterpret_cast<f32x4*>(E)[2 * r + 1] = c;
+}
+
+// grid (tiles, 2 towers), block 256 = 4 row groups x 64 columns (as gen_layer1_fwd, K = 6, rows of 8 floats)
+__global__ __launch_bounds__(256) void gen_layer1e_fwd(const GenL1Args a)
+{
+  __shared__ float red[4][64][2];
+  const int tile = blockIdx.x, tower = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int nvalid = min(kGenTile, a.M - tile * kGenTile);
+  const size_t row0 = (size_t)tower * a.M + (size_t)tile * kGenTile;
+  auto zrow = [&](size_t row, const float (&w)[6], float bb) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(a.X0)[2 * row], y = reinterpret_cast<const f32x4*>(a.X0)[2 * row + 1];
+    return fmaf(y[1], w[5], fmaf(y[0], w[4], fmaf(x[3], w[3], fmaf(x[2], w[2], fmaf(x[1], w[1], fmaf(x[0], w[0], bb))))));
+  };
+  for (int c0 = 0; c0 < a.C; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < a.C;
+    float w[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) w[d] = live ? a.W[d * a.C + c] : 0.f;
+    const float bb = live ? a.bias[c] : 0.f;
+    const float shift = zrow(row0, w, bb);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = g; r < nvalid; r += 4) {
+      const float z = zrow(row0 + r, w, bb);
+      if (live) a.Z[(row0 + r) * a.C + c] = z;
+      const float d = z - shift;
+      s1 += d; s2 = fmaf(d, d, s2);
+    }
+    red[g][lane][0] = s1; red[g][lane][1] = s2;
+    __syncthreads();
+    if (g == 0 && live) {
+      s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+      s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+      gen_tile_stat(s1, s2, shift, nvalid, a.part + (((size_t)tower * a.tiles + tile) * a.C + c) * 2);
+    }
+    __syncthreads();
+  }
+}
+
+// grid 2B, block 256; a.N = rows per cloud (N k); Ppart [2B][6][C];  gx_d = sum_c w_dc S_c (d < 3: only the x_i' half translates with the
+// frame), grot = sum_c (w_0c P_1c - w_1c P_0c + w_3c P_4c - w_4c P_3c) (both halves rotate)
+__global__ __launch_bounds__(256) void gen_layer1e_bwd(const GenL1BwdArgs a)
+{
+  __shared__ float red[4][64][7];
+  __shared__ double fin[4];
+  const int cloud = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  if (threadIdx.x < 4) fin[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int c0 = 0; c0 < a.C; c0 += 64) {
+    const int c = c0 + lane;
+    const bool live = c < a.C;
+    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // S, P_0 .. P_5
+    if (live)
+      for (int n = g; n < a.N; n += 4) {
+        const size_t row = (size_t)cloud * a.N + n;
+        const f32x4 x = reinterpret_cast<const f32x4*>(a.X0)[2 * row], y = reinterpret_cast<const f32x4*>(a.X0)[2 * row + 1];
+        const float d = a.dZ[row * a.C + c];
+        v[0] += d;
+        v[1] = fmaf(x[0], d, v[1]); v[2] = fmaf(x[1], d, v[2]); v[3] = fmaf(x[2], d, v[3]);
+        v[4] = fmaf(x[3], d, v[4]); v[5] = fmaf(y[0], d, v[5]); v[6] = fmaf(y[1], d, v[6]);
+      }
+#pragma unroll
+    for (int e = 0; e < 7; ++e) red[g][lane][e] = v[e];
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) v[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+      double q[4] = {0.0, 0.0, 0.0, 0.0};
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.Ppart[((size_t)cloud * 6 + d) * a.C + c] = v[1 + d];
+        float w[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) w[d] = a.W[d * a.C + c];
+        q[0] = (double)w[0] * v[0]; q[1] = (double)w[1] * v[0]; q[2] = (double)w[2] * v[0];
+        q[3] = (double)w[0] * v[2] - (double)w[1] * v[1] + (double)w[3] * v[5] - (double)w[4] * v[4];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q[e] += __shfl_xor(q[e], o);
+        if (lane == 0) fin[e] += q[e];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) a.gx[cloud * 3 + threadIdx.x] = (float)fin[threadIdx.x];
+  if (threadIdx.x == 3) a.grot[cloud] = (float)fin[3];
+}
+
+__global__ void gen_fill_kernel(float* __restrict__ p, size_t n, float v)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 }  // namespace alignnet

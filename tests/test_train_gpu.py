@@ -511,6 +511,62 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     eng.close()
 
 
+DGCNN_GENERAL = {
+    # models/tp8.py:38-41 builds one edge conv per entry of sizes[:-1]: three edge convs, an odd first width, a single edge conv
+    "deep_odd": dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160)),
+    # a specialised stage (32, 64, .) between two layer-by-layer ones: the stage glue folded into the specialised edge kernels must
+    # not leak into the stage in front of it
+    "mixed": dict(s1=(24, 40, 96), s2=(32, 64, 128), emb=(16, 136, 48, 160)),
+}
+
+
+@pytest.mark.parametrize("case,N,B", [("deep_odd", 96, 6), ("mixed", 128, 5), ("deep_odd", 128, 8)])
+def test_dgcnn_general_widths_and_depth_train(gpu_required, case, N, B):
+    """DGCNN stages outside the specialised [C1 in {32, 64}, C2 in {64, 128}, C3] shape train layer by layer over the B N k edge rows
+    (csrc/kernels_train_generic.h: gen_edge_kernel / gen_layer1e_* + the general-depth kernels; max over k and over N through
+    gen_pool_*): predictions, loss, EMA and every gradient against torch autograd (fp64), the three-layer DGCNN tests' criteria.
+    The eval-mode forward of the same engine (the fused dgcnn kernels take any depth) against the oracle as well."""
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), backbone="dgcnn", **DGCNN_GENERAL[case])
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=11)
+    d = R.synth_pairs(B, N, seed=11, dtype=np.float32)
+    rng = np.random.default_rng(11)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    assert eng.get_option("last_train_kernel") & 12 == 12, "the layer-by-layer dgcnn path did not run"
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    for k, v in ema_ref.items():
+        np.testing.assert_allclose(eng.get_variable(k), v, rtol=1e-4, atol=1e-5, err_msg=k)
+    # (k-max per point and channel: the fp32 evaluation of the oracle itself is 1e-2 .. 3e-2 away from the fp64 one where a near-tie
+    # routes a gradient to another edge row -- test_dgcnn_gradients_match_autograd; bound: twice the fp32 oracle's own error)
+    _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32)
+    gs = max(float(np.abs(v).max()) for v in grads.values())
+    rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs) for k in grads)
+    bad, worst = _grad_check(eng, spec, grads, min(max(3e-3 if B >= 8 else 1e-2, 2.0 * rel32), 8e-2))   # (capped: "mixed" at B = 5 has an fp32-oracle error of 0.26)
+    print(case, N, B, "dgcnn layer-by-layer path: loss", res["loss"], loss_ref, "worst relative gradient error", worst, "fp32 oracle vs fp64 oracle:", rel32)
+    assert not bad, bad
+    r = eng.train_step(d["pcs1"], d["pcs2"], d)
+    assert r["step"] == 1 and np.isfinite(r["loss"])
+    # a smaller batch on the same workspace (tiles / slabs of THIS call, not of the capacity)
+    d2 = R.synth_pairs(B - 2, N, seed=12, dtype=np.float32)
+    fresh = alignnet3d.Engine(cfg)
+    fresh.set_variables({k: eng.get_variable(k) for k in P32})
+    r2 = eng.train_forward_backward(d2["pcs1"], d2["pcs2"], d2, [du[k][: B - 2] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    r3 = fresh.train_forward_backward(d2["pcs1"], d2["pcs2"], d2, [du[k][: B - 2] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    assert abs(r2["loss"] - r3["loss"]) <= 1e-6 * max(1.0, abs(r3["loss"])), (r2["loss"], r3["loss"])
+    gs = max(float(np.abs(fresh.get_gradient(n)).max()) for n in R.trainable_names(spec))
+    for name in R.trainable_names(spec):
+        a, b = eng.get_gradient(name).astype(np.float64), fresh.get_gradient(name).astype(np.float64)
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 1e-7 * gs, ("reused vs fresh engine", name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    fresh.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("tail", [1, 0])
 def test_general_depth_smaller_batch_after_larger(gpu_required, tail):
     """One engine, B = 8 and then B = 5 (the workspace keeps the larger capacity): the layer-by-layer kernels must walk the tiles of
