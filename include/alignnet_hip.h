@@ -155,7 +155,9 @@ int alignnet_synchronize(alignnet_handle* h);
  * Shapes: PointNet backbones of any depth (2 .. 6 conv layers, models/tp8.py:49-59), widths multiples of 8.  Three-layer stages with
  * widths multiples of 32, C1, C2 <= 128, C3 <= 1024 (every shipped dataset config) run the fused recompute kernels; any other stage
  * (e.g. the five-layer backbones of configs/default.json) runs the layer-by-layer path (fp32, hidden widths <= 256, last <= 4096);
- * backbone "dgcnn" (models/tp8.py:30-46, k = 20): C1 in {32, 64}, C2 in {64, 128}, 20 <= num_points <= 4096.
+ * backbone "dgcnn" (models/tp8.py:30-46, k = 20, 20 <= num_points <= 4096): [C1, C2, C3] with C1 in {32, 64}, C2 in {64, 128} (every
+ * shipped config) runs the fused edge kernels; any other list of 2 .. 6 widths (multiples of 8, edge convs <= 256) runs the same
+ * layer-by-layer path over the B N k edge rows (fp32).
  * Anything else fails with a message (alignnet_last_error), it is never run on a fallback. */
 int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2,
                         const alignnet_labels* labels, int32_t B, const float* dropout_u,
