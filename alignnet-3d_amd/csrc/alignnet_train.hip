@@ -151,6 +151,8 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   if (w->gl_base) hipFree(w->gl_base);
   for (int t = 0; t < 2; ++t) if (w->d_pcs[t]) hipFree(w->d_pcs[t]);
   if (w->grad) hipFree(w->grad);
+  if (h->side_stream) { hipStreamSynchronize(h->side_stream); hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
+  for (auto& e : h->side_ev) if (e) { hipEventDestroy(e); e = nullptr; }
   if (w->adam_m) hipFree(w->adam_m);
   if (w->adam_v) hipFree(w->adam_v);
   if (w->pack_table) hipFree(w->pack_table);
@@ -495,7 +497,7 @@ static void def_combine(alignnet_handle* h, TrainWS* w, const CombineJob& j)
   hipLaunchKernelGGL(combine_dw_kernel, dim3((unsigned)(((size_t)j.R * j.C + 255) / 256)), dim3(256), 0, h->stream, j.Sp, j.spscale, j.m, j.kdb, j.GW, j.E, j.R, j.C, j.dW, j.gscale);
 }
 // the recorded jobs, five launches: reductions | sparse gathers -> Gram centrings -> GEMMs -> combines
-static int flush_deferred(alignnet_handle* h)
+static int flush_deferred(alignnet_handle* h, hipStream_t stream)
 {
   TrainWS* w = tws(h);
   Deferred& d = w->defer;
@@ -504,19 +506,19 @@ static int flush_deferred(alignnet_handle* h)
   if (!d.red.empty()) {
     ReduceJobs J{}; long nmax = 0;
     for (size_t i = 0; i < d.red.size(); ++i) { J.j[i] = d.red[i]; nmax = std::max(nmax, d.red[i].n); }
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, h->stream, J);
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, stream, J);
   }
   for (auto& sr : d.sync_after_red) if (sync_sum(h, sr.first, sr.second, false)) return 1;
   if (!d.sp.empty()) {
     SparseDwJobs J{}; int cmax = 0, c2max = 0;
     for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); c2max = std::max(c2max, d.sp[i].C2); }
     (void)c2max;
-    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(1024), 0, h->stream, J);
+    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(1024), 0, stream, J);
   }
   if (!d.cen.empty()) {
     CentreJobs J{}; size_t emax = 0;
     for (size_t i = 0; i < d.cen.size(); ++i) { J.j[i] = d.cen[i]; emax = std::max(emax, (size_t)d.cen[i].C * d.cen[i].C); }
-    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)d.cen.size()), dim3(256), 0, h->stream, J);
+    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)d.cen.size()), dim3(256), 0, stream, J);
   }
   if (!d.gemm.empty()) {
     GemmJobs J{}; int tot = 0;
@@ -526,12 +528,12 @@ static int flush_deferred(alignnet_handle* h)
       tot += J.tx[i] * J.ty[i] * d.gemm[i].second;
     }
     J.start[d.gemm.size()] = tot; J.n = (int)d.gemm.size();
-    hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, h->stream, J);
+    hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, stream, J);
   }
   if (!d.comb.empty()) {
     CombineJobs J{}; size_t emax = 0;
     for (size_t i = 0; i < d.comb.size(); ++i) { J.j[i] = d.comb[i]; emax = std::max(emax, (size_t)d.comb[i].R * d.comb[i].C); }
-    hipLaunchKernelGGL(combine_dw_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 1, (unsigned)d.comb.size()), dim3(256), 0, h->stream, J);
+    hipLaunchKernelGGL(combine_dw_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 1, (unsigned)d.comb.size()), dim3(256), 0, stream, J);
   }
   d.clear();
   HIP_TRY(h, hipGetLastError());
@@ -1424,7 +1426,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
 // ---------------------------------------------------------------------------------
 // full forward + backward on device buffers
 // ---------------------------------------------------------------------------------
-static int comm_bucket(alignnet_handle* h, int stage);   // defined with the RCCL section below
+static int comm_bucket(alignnet_handle* h, int stage, hipStream_t after = nullptr);   // defined with the RCCL section below
 static int comm_join(alignnet_handle* h);
 
 static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, const float* const lab[6], int B, const float* u_dev,
@@ -1534,8 +1536,26 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   h->comm_buckets = 0;
   w->defer.clear();
   w->defer.on = !getenv("ALIGNNET_NO_DEFER") || sync_on(h);   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
+  // The deferred weight-gradient jobs of a stage go to a side stream as soon as that stage's backward is queued: they run under the next
+  // stage's head / prep chains (a few workgroups each, most of the chip idle), and in data-parallel steps the stage's gradient segment
+  // is final -- and its all-reduce bucket on its way -- two stages earlier than with one flush at the end.  sync_bn keeps the single
+  // flush on the compute stream (its reduced matrices are summed over the ranks between the job groups).
+  const bool side = w->defer.on && h->dw_side && !sync_on(h) && !getenv("ALIGNNET_NO_SIDE");
+  auto stage_flush = [&](int sg) -> int {
+    if (!side) return 0;
+    if (!h->side_stream) {
+      HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+      for (auto& e : h->side_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventRecord(h->side_ev[sg], h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->side_ev[sg], 0));
+    if (flush_deferred(h, h->side_stream)) return 1;
+    if (comm_overlap && comm_bucket(h, sg, h->side_stream)) return 1;
+    return 0;
+  };
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
+  if (stage_flush(2)) return 1;
   if (!w->glue_folded) {
     hipLaunchKernelGGL(stage3_glue_bwd_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->st[2].gx, w->st[2].grot, w->st[2].xform, w->cls,
                        B, nb, w->d_s2c, w->d_o[1], 3 + nb2);
@@ -1544,6 +1564,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int C2l = h->layers[h->s2_conv.first + h->s2_conv.n - 1].cout, C1l = h->layers[h->s1_conv.first + h->s1_conv.n - 1].cout;
   if (head_bwd_train(h, 1, w->st[1].pooled, C2l, w->st[1].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 1, p1, p2, B)) return 1;
+  if (stage_flush(1)) return 1;
   if (!w->glue_folded) {
     hipLaunchKernelGGL(stage1_glue_bwd_kernel, dim3((B2 * 3 + 127) / 128), dim3(128), 0, h->stream, w->st[1].gx, B, w->d_s1c);
     // s1c = o1 + center_mean  ->  d_o1 = d_s1c
@@ -1551,14 +1572,18 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   }
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
-  const bool deferred = w->defer.on;
-  if (flush_deferred(h)) return 1;   // the weight gradients of all three stages: five multi-job launches
-  w->defer.on = false;
-  if (comm_overlap) {
-    // Data-parallel steps: the three segments of the flat gradient are final only now (without deferral each was final right after its
-    // stage's backward and travelled under the next stage's); they still go out as three buckets on the side stream, stage 3 first.
-    (void)deferred;
-    for (int sg = 2; sg >= 0; --sg) if (comm_bucket(h, sg)) return 1;
+  if (side) {
+    if (stage_flush(0)) return 1;
+    HIP_TRY(h, hipEventRecord(h->side_ev[3], h->side_stream));   // the optimiser (compute stream) reads the whole gradient
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->side_ev[3], 0));
+    w->defer.on = false;
+  } else {
+    if (flush_deferred(h, h->stream)) return 1;   // the weight gradients of all three stages: five multi-job launches
+    w->defer.on = false;
+    if (comm_overlap) {
+      // Data-parallel steps: the three segments of the flat gradient are final only now; they go out as three buckets, stage 3 first.
+      for (int sg = 2; sg >= 0; --sg) if (comm_bucket(h, sg)) return 1;
+    }
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -1880,7 +1905,7 @@ extern "C" void alignnet_comm_free(alignnet_handle* h)
 // Bucket `stage` of the gradient all-reduce: the flat gradient is laid out [stage 1 | stage 2 | stage 3] (graph-construction order,
 // alignnet_api.hip), and the backward runs stage 3 -> 2 -> 1, writing only that stage's segment.  As soon as a segment is final
 // the side stream waits for it and all-reduces it over xGMI while the compute stream goes on with the next stage's backward.
-static int comm_bucket(alignnet_handle* h, int stage)
+static int comm_bucket(alignnet_handle* h, int stage, hipStream_t after)   // after: the stream whose work completes the segment (default: the compute stream)
 {
   if (!h->comm) return 0;
   TrainWS* w = tws(h);
@@ -1891,7 +1916,7 @@ static int comm_bucket(alignnet_handle* h, int stage)
   const size_t lo = h->params[h->layers[conv_of(h, stage).first].p_w].offset;
   const size_t hi = stage == 2 ? h->n_trainable : h->params[h->layers[conv_of(h, stage + 1).first].p_w].offset;
   if (hi <= lo || hi > h->n_trainable) return fail(h, "comm_bucket: gradient segments are not in stage order");
-  HIP_TRY(h, hipEventRecord(h->comm_ev[stage], h->stream));
+  HIP_TRY(h, hipEventRecord(h->comm_ev[stage], after ? after : h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ev[stage], 0));
   const int rc = g_rccl.AllReduce(w->grad + lo, w->grad + lo, hi - lo, 7, 0, h->comm, h->comm_stream);   // ncclFloat = 7, ncclSum = 0
   if (rc != 0) return fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));

@@ -115,6 +115,11 @@ struct alignnet_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [stage] = segment ready on the compute stream; [3] = buckets done
   bool comm_overlap = true;        // alignnet_set_option("allreduce_overlap")
+  // weight-gradient side stream: the deferred dW jobs of a stage (only the optimiser and the all-reduce wait for them) run here under the
+  // next stage's backward (alignnet_train.hip: flush_deferred); [stage] = that stage's backward done on the compute stream, [3] = all flushed
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool dw_side = false;            // alignnet_set_option("train_dw_side_stream")
   // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --
   // the reference's single-device semantics at the global batch (utils/tf_util.py:474) -- instead of per rank.
   bool sync_bn = false;

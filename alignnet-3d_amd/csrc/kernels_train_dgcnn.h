@@ -221,6 +221,35 @@ __device__ __forceinline__ void dgt_liftm_bf16(const DgtLiftM<C1, NW>& R, const 
   }
 }
 
+// The same lift, also returning bit (4 i + r) = [h1 > 0] for the wave's tile i, accumulator element r (the relu mask of the dense edge
+// backward, whose dh1 tiles are the wave's lift tiles: it never reads h1 back for the mask).
+template <int C1, int NW>
+__device__ __forceinline__ unsigned dgt_liftm_bf16_nz(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, unsigned short* __restrict__ Xh, int ldh,
+                                                      unsigned short* __restrict__ XhT, int ldT, int nvalid, int wave, int lane)
+{
+  unsigned nz = 0;
+#pragma unroll
+  for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
+    const int t = wave * DgtLiftM<C1, NW>::kPer + i, rt = t / DgtLiftM<C1, NW>::kCT, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
+    const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], R.w[i][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], R.w[i][1], acc, 0, 0, 0);
+    const int row0 = 16 * rt + 4 * (lane >> 4);
+    unsigned short hb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hb[r] = row0 + r < nvalid ? to_bf16_bits(fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f)) : (unsigned short)0;
+      Xh[(row0 + r) * ldh + c] = hb[r];
+      nz |= hb[r] ? 1u << (4 * i + r) : 0u;
+    }
+    uint2 pk;
+    pk.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16); pk.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+    *reinterpret_cast<uint2*>(XhT + c * ldT + row0) = pk;
+  }
+  return nz;
+}
+
 // ---------------------------------------------------------------------------------
 // phase 2: one workgroup (4 waves) per cloud walks (tile, slot); wave w owns channel tile w of the C2 <= 128
 // edge-conv outputs and both 32-row groups.  LDS: es [64][8] | X0 [64][ld0] | X1 [64][ld0] (lift double-buffered;
@@ -866,14 +895,19 @@ static inline size_t dg_bwd_edge_dense_lds(int C1, int C2)
          (2 * (size_t)kTT * (C2 + 8) + 2 * (size_t)C2 * (kTT + 8)) * 2 + (size_t)kTT * (C2 + 4) + (size_t)C2 * (kTT + 8);
 }
 
-// 8 arg-k bytes (w0 = elements 0..3, w1 = 4..7) against the slot: 16-bit lane masks for the 8 bf16 values of a fragment
+// 8 arg-k bytes (w0 = elements 0..3, w1 = 4..7) against the slot: 16-bit lane masks for the 8 bf16 values of a fragment.
+// All bytes are < 0x80 (slots 0 .. 19; 0x7f marks rows past the cloud), so byte-parallel arithmetic has no carries: x + 0x7f has its
+// top bit set iff the byte of x = w ^ slot is non-zero; the matching bytes become 0xff, v_perm_b32 doubles each byte into a 16-bit lane.
 __device__ __forceinline__ uint4 dg_slot_mask(unsigned w0, unsigned w1, unsigned slot4)
 {
-  const unsigned x0 = w0 ^ slot4, x1 = w1 ^ slot4;   // a zero byte <=> arg-k == slot
-  auto pair = [](unsigned x, int sh) {
-    return ((x >> sh) & 0xffu ? 0u : 0x0000ffffu) | ((x >> (sh + 8)) & 0xffu ? 0u : 0xffff0000u);
+  auto bytes = [&](unsigned wv) {
+    const unsigned x = wv ^ slot4;
+    const unsigned z = ~(x + 0x7f7f7f7fu) & 0x80808080u;   // 0x80 where arg-k == slot
+    return z | (z - (z >> 7));                              // 0xff there
   };
-  return uint4{pair(x0, 0), pair(x0, 16), pair(x1, 0), pair(x1, 16)};
+  const unsigned m0 = bytes(w0), m1 = bytes(w1);
+  return uint4{__builtin_amdgcn_perm(m0, m0, 0x01010000u), __builtin_amdgcn_perm(m0, m0, 0x03030202u),
+               __builtin_amdgcn_perm(m1, m1, 0x01010000u), __builtin_amdgcn_perm(m1, m1, 0x03030202u)};
 }
 __device__ __forceinline__ bf16x8 dg_masked(const unsigned short* p, const uint4& m)
 {
@@ -907,28 +941,41 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
   const float* sh1 = a.sh1 + tower * C1;
   const DgtLiftM<C1, kBEW> lw = dgt_liftm_load<C1, kBEW>(a.w1, sc1, sh1, wave, lane);
   if (tid < 3 * kTT) { smem[tid * 8 + 6] = 0.f; smem[tid * 8 + 7] = 0.f; }   // k padding of the MFMA lift in the three es buffers
-  // roles: waves [0, nitems) own one dh1 item (channel tile of C1, 32-row group); the others share the CT1 x CT2 tiles of U2
-  constexpr int nitems = CT1 * 2, nuw = kBEW - nitems, nut = CT1 * CT2, kUPer = (nut + nuw - 1) / nuw;
-  bf16x8 w2f[KG2], q2f[KG1];     // dh1 waves: B fragments of W2^T (K = C2) and Q2 (K = C1) for the wave's channel tile, whole cloud
-  if (wave < nitems) {
+  // Every wave owns the same share of both products (round 3: four dh1 waves at ~7 k cycles per slot were what the barrier waited for):
+  //   dh1  16-row group rg = wave >> 1, the NCT column tiles (16 wide) ct16 = (wave & 1) NCT + j -- exactly the tiles whose h1 the wave
+  //        lifts, so the relu mask [h1 > 0] stays in registers -- on v_mfma_f32_16x16x32_bf16; a masked A fragment feeds all NCT tiles;
+  //        Pdy on v_mfma_f32_16x16x4_f32 (the accumulator element r of lane group g IS the B operand of step r: rows 4 g + r)
+  //   U2'  P column tile jt2 = wave >> 1, K (row) half kh = wave & 1, both h1 column tiles: a masked B fragment feeds CT1 tiles; the two
+  //        K halves are summed through LDS after the last slot
+  constexpr int NCT = C1 / 32, K2 = C2 / 32, K1 = C1 / 32;
+  static_assert(kBEW == 8, "wave roles are laid out for eight waves");
+  const int rg = wave >> 1, chalf = wave & 1, g4 = lane >> 4, n16 = lane & 15;
+  bf16x8 w2f[NCT][K2], q2f[NCT][K1];   // B fragments of W2^T (K = C2) and Q2 (K = C1), read out of the 32x32x16 images
+  float qb[NCT];
+  {
     const bf16x8* wi = reinterpret_cast<const bf16x8*>(a.w2th);
     const bf16x8* qh = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2imgh_stride);
 #pragma unroll
-    for (int kg = 0; kg < KG2; ++kg) w2f[kg] = wi[((size_t)(wave >> 1) * KG2 + kg) * 64 + lane];
+    for (int j2 = 0; j2 < NCT; ++j2) {
+      const int ct16 = chalf * NCT + j2, ct32 = ct16 >> 1, l32 = (g4 & 1) * 32 + 16 * (ct16 & 1) + n16;   // image lane: k half, column
 #pragma unroll
-    for (int kg = 0; kg < KG1; ++kg) q2f[kg] = qh[((size_t)(wave >> 1) * KG1 + kg) * 64 + lane];
+      for (int kg = 0; kg < K2; ++kg) w2f[j2][kg] = wi[((size_t)ct32 * KG2 + 2 * kg + (g4 >> 1)) * 64 + l32];
+#pragma unroll
+      for (int kg = 0; kg < K1; ++kg) q2f[j2][kg] = qh[((size_t)ct32 * KG1 + 2 * kg + (g4 >> 1)) * 64 + l32];
+      qb[j2] = a.q2b[tower * C1 + ct16 * 16 + n16];
+    }
   }
-  f32x16 uacc[kUPer];
+  f32x16 uacc[CT1];
 #pragma unroll
-  for (int i = 0; i < kUPer; ++i)
+  for (int i = 0; i < CT1; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) uacc[i][r] = 0.f;
-  double pd[4];
-  f32x16 pacc;
+  double pd[NCT][4];
+  f32x4 pacc[NCT];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) pd[d] = 0.0;
+  for (int j2 = 0; j2 < NCT; ++j2)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
+    for (int d = 0; d < 4; ++d) { pd[j2][d] = 0.0; pacc[j2][d] = 0.f; }
 
   // edge features run two slots ahead of the MFMAs: es(it + 1) is written while slot it is lifted (three buffers: the dh1 waves of a
   // slow slot it may still be reading es(it) when a fast wave writes es(it + 2)), the gather of slot it + 2 is in flight meanwhile
@@ -962,7 +1009,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
         const f32x4 d0 = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 d1 = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 k0 = *reinterpret_cast<const f32x4*>(a.k2 + tower * C2 + o * 8), k1 = *reinterpret_cast<const f32x4*>(a.k2 + tower * C2 + o * 8 + 4);
-        uint2 ak = {0xffffffffu, 0xffffffffu};
+        uint2 ak = {0x7f7f7f7fu, 0x7f7f7f7fu};   // (rows past the cloud: no slot; < 0x80 for dg_slot_mask)
         if (ok) ak = *reinterpret_cast<const uint2*>(a.argk + base + (size_t)r * C2 + o * 8);
         const float dv[8] = {d0[0] * k0[0], d0[1] * k0[1], d0[2] * k0[2], d0[3] * k0[3], d1[0] * k1[0], d1[1] * k1[1], d1[2] * k1[2], d1[3] * k1[3]};
         unsigned hi[8], lo[8];
@@ -994,96 +1041,113 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
         *reinterpret_cast<uint2*>(AKT + c * ldT + ro * 8) = uint2{wa[0], wa[1]};
       }
     }
-    dgt_liftm_bf16<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
+    const unsigned nz = dgt_liftm_bf16_nz<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
     if (more && tid < kTT) {
       dg_edge_to_lds(xf, v, smem + ((it + 1) % 3) * kTT * 8 + tid * 8);
       if (it + 2 < total) gather_slot(it + 2);
     }
     __syncthreads();   // the slot's only barrier: h1 tiles (and at a tile start the P tiles) complete, es of the next slot written
     const unsigned slot4 = (unsigned)slot * 0x01010101u;
-    if (wave < nitems) {
+    {
       // ---- dh1 = (P masked) W2^T + h1_s Q2 + q2b ; dy1 = dh1 [h1 > 0] ; Pdy += e^T dy1 ----
-      const int ct = wave >> 1, rg = wave & 1;
-      const int col = ct * 32 + (lane & 31);
-      const float qb = a.q2b[tower * C1 + col];
-      f32x16 acc;
+      const int arow = rg * 16 + n16;
+      const unsigned short* ah = Ph + arow * ldd + g4 * 8;
+      const unsigned short* al = Pl + arow * ldd + g4 * 8;
+      const unsigned char* am = AK + arow * ldak + g4 * 8;
+      const unsigned short* ax = Xh + arow * ldh + g4 * 8;
+      f32x4 acc[NCT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = qb;
-      const int ei = lane & 31;
-      float ev[16]; unsigned short xm[16];
+      for (int j2 = 0; j2 < NCT; ++j2) acc[j2] = f32x4{qb[j2], qb[j2], qb[j2], qb[j2]};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        xm[r] = Xh[row * ldh + col];
-        ev[r] = es[row * 8 + (ei & 7)];
+      for (int kg = 0; kg < K2; ++kg) {
+        const uint4 m = dg_slot_mask(*reinterpret_cast<const unsigned*>(am + kg * 32), *reinterpret_cast<const unsigned*>(am + kg * 32 + 4), slot4);
+        const bf16x8 fh = dg_masked(ah + kg * 32, m), fl = dg_masked(al + kg * 32, m);
+#pragma unroll
+        for (int j2 = 0; j2 < NCT; ++j2) {
+          acc[j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, w2f[j2][kg], acc[j2], 0, 0, 0);
+          acc[j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, w2f[j2][kg], acc[j2], 0, 0, 0);
+        }
       }
-      const int arow = rg * 32 + (lane & 31);
-      const unsigned short* ah = Ph + arow * ldd + half * 8;
-      const unsigned short* al = Pl + arow * ldd + half * 8;
-      const unsigned char* am = AK + arow * ldak + half * 8;
 #pragma unroll
-      for (int kg = 0; kg < KG2; ++kg) {
-        const uint4 m = dg_slot_mask(*reinterpret_cast<const unsigned*>(am + kg * 16), *reinterpret_cast<const unsigned*>(am + kg * 16 + 4), slot4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dg_masked(ah + kg * 16, m), w2f[kg], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dg_masked(al + kg * 16, m), w2f[kg], acc, 0, 0, 0);
+      for (int kg = 0; kg < K1; ++kg) {
+        const bf16x8 fx = *reinterpret_cast<const bf16x8*>(ax + kg * 32);
+#pragma unroll
+        for (int j2 = 0; j2 < NCT; ++j2) acc[j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, q2f[j2][kg], acc[j2], 0, 0, 0);
       }
-      const unsigned short* ax = Xh + arow * ldh + half * 8;
+      float ea[4];   // A operand of the Pdy steps: e[row 4 g + r][d = n16] for d < 6, a row of ones (d = 6) for sum dy1
 #pragma unroll
-      for (int kg = 0; kg < KG1; ++kg)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ax + kg * 16), q2f[kg], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float dy = (row < nvalid && xm[r] != 0) ? acc[r] : 0.f;
-        const float ea = ei < 6 ? ev[r] : (ei == 6 ? 1.f : 0.f);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea, dy, pacc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        const float ev = es[(rg * 16 + 4 * g4 + r) * 8 + (n16 & 7)];
+        ea[r] = n16 < 6 ? ev : (n16 == 6 ? 1.f : 0.f);
       }
-      if (slot == a.k - 1) {   // fp32 sums of one tile (k * 64 rows) folded into fp64
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pd[q] += (double)pacc[q];
+      for (int j2 = 0; j2 < NCT; ++j2)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const float dy = ((nz >> (4 * j2 + r)) & 1u) ? acc[j2][r] : 0.f;   // (rows past the cloud lift to h1 = 0)
+          pacc[j2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[r], dy, pacc[j2], 0, 0, 0);
+        }
+      if (slot == a.k - 1) {   // fp32 sums of one tile (k * 16 rows) folded into fp64
+#pragma unroll
+        for (int j2 = 0; j2 < NCT; ++j2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { pd[j2][q] += (double)pacc[j2][q]; pacc[j2][q] = 0.f; }
       }
-    } else {
-      // ---- U2' tiles of this wave: (it2, jt2) += Xh^T[32 it2 .., rows] . (P^T masked)[32 jt2 .., rows]  (K = the tile's 64 rows) ----
+    }
+    {
+      // ---- U2' tiles (it2, jt2) += Xh^T[32 it2 .., rows] . (P^T masked)[32 jt2 .., rows] over this wave's half of the tile's 64 rows ----
+      const int jt2 = wave >> 1, kh = wave & 1;
+      if (jt2 < CT2) {
+        const int brow = jt2 * 32 + (lane & 31);
+        const unsigned short* ph = PhT + brow * ldT + half * 8;
+        const unsigned short* pl = PlT + brow * ldT + half * 8;
+        const unsigned char* pm = AKT + brow * ldT + half * 8;
 #pragma unroll
-      for (int i = 0; i < kUPer; ++i) {
-        const int u = (wave - nitems) + i * nuw;
-        if (u < nut) {
-          const int it2 = u / CT2, jt2 = u % CT2;
-          const int brow = jt2 * 32 + (lane & 31);
-          const unsigned short* pa = XhT + (it2 * 32 + (lane & 31)) * ldT + half * 8;
-          const unsigned short* ph = PhT + brow * ldT + half * 8;
-          const unsigned short* pl = PlT + brow * ldT + half * 8;
-          const unsigned char* pm = AKT + brow * ldT + half * 8;
+        for (int kk = 0; kk < kTT / 32; ++kk) {
+          const int kg = kh * (kTT / 32) + kk;
+          const uint2 mk = *reinterpret_cast<const uint2*>(pm + kg * 16);
+          const uint4 m = dg_slot_mask(mk.x, mk.y, slot4);
+          const bf16x8 bh = dg_masked(ph + kg * 16, m), bl = dg_masked(pl + kg * 16, m);
 #pragma unroll
-          for (int kg = 0; kg < kTT / 16; ++kg) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(pa + kg * 16);
-            const uint2 mk = *reinterpret_cast<const uint2*>(pm + kg * 16);
-            const uint4 m = dg_slot_mask(mk.x, mk.y, slot4);
-            uacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dg_masked(ph + kg * 16, m), uacc[i], 0, 0, 0);
-            uacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dg_masked(pl + kg * 16, m), uacc[i], 0, 0, 0);
+          for (int it2 = 0; it2 < CT1; ++it2) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(XhT + (it2 * 32 + (lane & 31)) * ldT + half * 8 + kg * 16);
+            uacc[it2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, uacc[it2], 0, 0, 0);
+            uacc[it2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl, uacc[it2], 0, 0, 0);
           }
         }
       }
     }
   }
-  if (wave >= nitems) {
+  __syncthreads();   // the last slot's readers of the P tiles are done: their LDS takes the K-half partials of U2'
+  {
+    float* red = reinterpret_cast<float*>(Ph);   // [CT2 * CT1 tiles][16][64]
+    const int jt2 = wave >> 1, kh = wave & 1;
+    if (kh == 1 && jt2 < CT2) {
 #pragma unroll
-    for (int i = 0; i < kUPer; ++i) {
-      const int u = (wave - nitems) + i * nuw;
-      if (u < nut) {
-        const float zero[16] = {};
-        tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, u / CT2, u % CT2, C1, C2, uacc[i], lane, zero);
+      for (int it2 = 0; it2 < CT1; ++it2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((jt2 * CT1 + it2) * 16 + r) * 64 + lane] = uacc[it2][r];
+    }
+    __syncthreads();
+    if (kh == 0 && jt2 < CT2) {
+#pragma unroll
+      for (int it2 = 0; it2 < CT1; ++it2) {
+        float other[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) other[r] = red[((jt2 * CT1 + it2) * 16 + r) * 64 + lane];
+        tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, it2, jt2, C1, C2, uacc[it2], lane, other);
       }
     }
-  } else {
-    const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
-    double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * C1 + col;
+  }
+  if (g4 < 2) {   // Pdy [cloud][slice = 16-row group][d][C1]: lane group g holds d = 4 g + q
 #pragma unroll
-    for (int d = 0; d < 7; ++d) {
-      const int q = d - 4 * half;
-      dst[(size_t)d * C1] = (q >= 0 && q < 4) ? pd[q & 3] : 0.0;
+    for (int j2 = 0; j2 < NCT; ++j2) {
+      const int col = (chalf * NCT + j2) * 16 + n16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = 4 * g4 + q;
+        if (d < 7) a.pdy_part[(((size_t)cloud * 4 + rg) * 7 + d) * C1 + col] = pd[j2][q];
+      }
     }
   }
 }

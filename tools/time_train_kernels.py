@@ -13,7 +13,8 @@ d = R.synth_pairs(B, N, dtype=np.float32)
 p1 = torch.tensor(d['pcs1']).cuda(); p2 = torch.tensor(d['pcs2']).cuda()
 lab = {k: torch.tensor(np.ascontiguousarray(d[k])).cuda() for k in ("translations","rel_angles","pc1_centers","pc2_centers","pc1_angles","pc2_angles")}
 lp = {k: v.data_ptr() for k, v in lab.items()}
-for _ in range(2): eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lp, B)
-eng.synchronize(); t = time.time(); K = 8
+K = int(os.environ.get('ALIGNNET_K', 8))
+for _ in range(2 if K <= 8 else K): eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lp, B)
+eng.synchronize(); t = time.time()
 for _ in range(K): eng.train_step_device(p1.data_ptr(), p2.data_ptr(), lp, B)
 eng.synchronize(); print("DBG=%s BF16=%s ms/step %.3f" % (os.environ.get("ALIGNNET_DBG", "0"), os.environ.get("ALIGNNET_BF16", "0"), (time.time() - t) / K * 1e3))
