@@ -221,13 +221,13 @@ __device__ __forceinline__ void dgt_liftm_bf16(const DgtLiftM<C1, NW>& R, const 
   }
 }
 
-// The same lift, also returning bit (4 i + r) = [h1 > 0] for the wave's tile i, accumulator element r (the relu mask of the dense edge
-// backward, whose dh1 tiles are the wave's lift tiles: it never reads h1 back for the mask).
+// The same lift, also handing back the wave's own h1 values (bf16 bits, tile i, accumulator element r): the relu mask [h1 > 0] of the
+// dense edge backward, whose dh1 tiles are the wave's lift tiles -- it never reads h1 back for the mask.
 template <int C1, int NW>
-__device__ __forceinline__ unsigned dgt_liftm_bf16_nz(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, unsigned short* __restrict__ Xh, int ldh,
-                                                      unsigned short* __restrict__ XhT, int ldT, int nvalid, int wave, int lane)
+__device__ __forceinline__ void dgt_liftm_bf16_keep(const DgtLiftM<C1, NW>& R, const float* __restrict__ es, unsigned short* __restrict__ Xh, int ldh,
+                                                    unsigned short* __restrict__ XhT, int ldT, int nvalid, int wave, int lane,
+                                                    unsigned short (&hv)[DgtLiftM<C1, NW>::kPer][4])
 {
-  unsigned nz = 0;
 #pragma unroll
   for (int i = 0; i < DgtLiftM<C1, NW>::kPer; ++i) {
     const int t = wave * DgtLiftM<C1, NW>::kPer + i, rt = t / DgtLiftM<C1, NW>::kCT, c = 16 * (t % DgtLiftM<C1, NW>::kCT) + (lane & 15);
@@ -236,18 +236,15 @@ __device__ __forceinline__ unsigned dgt_liftm_bf16_nz(const DgtLiftM<C1, NW>& R,
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], R.w[i][0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4], R.w[i][1], acc, 0, 0, 0);
     const int row0 = 16 * rt + 4 * (lane >> 4);
-    unsigned short hb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      hb[r] = row0 + r < nvalid ? to_bf16_bits(fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f)) : (unsigned short)0;
-      Xh[(row0 + r) * ldh + c] = hb[r];
-      nz |= hb[r] ? 1u << (4 * i + r) : 0u;
+      hv[i][r] = row0 + r < nvalid ? to_bf16_bits(fmaxf(fmaf(acc[r], R.sc[i], R.sh[i]), 0.f)) : (unsigned short)0;
+      Xh[(row0 + r) * ldh + c] = hv[i][r];
     }
     uint2 pk;
-    pk.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16); pk.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+    pk.x = (unsigned)hv[i][0] | ((unsigned)hv[i][1] << 16); pk.y = (unsigned)hv[i][2] | ((unsigned)hv[i][3] << 16);
     *reinterpret_cast<uint2*>(XhT + c * ldT + row0) = pk;
   }
-  return nz;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1041,7 +1038,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
         *reinterpret_cast<uint2*>(AKT + c * ldT + ro * 8) = uint2{wa[0], wa[1]};
       }
     }
-    const unsigned nz = dgt_liftm_bf16_nz<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
+    unsigned short hv[NCT][4];
+    dgt_liftm_bf16_keep<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane, hv);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
     if (more && tid < kTT) {
       dg_edge_to_lds(xf, v, smem + ((it + 1) % 3) * kTT * 8 + tid * 8);
       if (it + 2 < total) gather_slot(it + 2);
@@ -1084,7 +1082,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
       for (int j2 = 0; j2 < NCT; ++j2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float dy = ((nz >> (4 * j2 + r)) & 1u) ? acc[j2][r] : 0.f;   // (rows past the cloud lift to h1 = 0)
+          const float dy = hv[j2][r] ? acc[j2][r] : 0.f;   // (rows past the cloud lift to h1 = 0)
           pacc[j2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[r], dy, pacc[j2], 0, 0, 0);
         }
       if (slot == a.k - 1) {   // fp32 sums of one tile (k * 16 rows) folded into fp64
