@@ -270,6 +270,9 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient, each issued as soon
  *   as that stage's backward has written it -- so that only the last (smallest) bucket is exposed; 0 = one all-reduce of the whole
  *   vector after the backward.  Same sums either way.
+ * "train_dw_side_stream" (0/1, default 0): the weight-gradient jobs only the optimiser waits for are queued per stage on a second stream
+ *   (under the next stage's backward; data-parallel: that stage's all-reduce bucket leaves right behind them) instead of as one group
+ *   after the whole backward.  Same arithmetic, same summation order.  Slower on one GPU (measured).
  * "sync_bn" (0/1, default 0): data-parallel training with the reference's single-device BatchNorm semantics at the GLOBAL batch
  *   (utils/tf_util.py:474): every batch sum behind a BatchNorm -- forward moments, the Gram / column-sum matrices of the layer
  *   identities, the backward's (dbeta, dgamma) totals, the heads' row statistics -- is all-reduced over the ranks (RCCL, about thirty

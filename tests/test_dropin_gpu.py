@@ -142,6 +142,14 @@ def test_rccl_world1_and_device_entry_points(gpu_required):
     for name, _, _ in eng.variables():
         np.testing.assert_array_equal(eng.get_variable(name), ref.get_variable(name), err_msg=name)
     eng.set_option("allreduce_overlap", 1)
+    # the weight-gradient jobs flushed per stage on the side stream, each stage's bucket right behind its flush: same numbers, bit for bit
+    eng.set_option("train_dw_side_stream", 1)
+    a = eng.train_step(d["pcs1"], d["pcs2"], d, u)
+    b = ref.train_step(d["pcs1"], d["pcs2"], d, u)
+    assert eng.get_option("comm_buckets") == 3 and a["loss"] == b["loss"] and a["step"] == 3
+    for name, _, _ in eng.variables():
+        np.testing.assert_array_equal(eng.get_variable(name), ref.get_variable(name), err_msg=name)
+    eng.set_option("train_dw_side_stream", 0)
     # device-resident inputs: same numbers as the host-pointer entry points
     t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).cuda() for k in d}
     outs = {k: torch.empty(8, 24 if "logits" in k else 3, device="cuda") for k in alignnet3d.OUTPUT_NAMES}
