@@ -59,6 +59,23 @@ __device__ __forceinline__ void dgt_gather(const float* __restrict__ pc, const i
   v[3] = pj[0] - p[0]; v[4] = pj[1] - p[1]; v[5] = pj[2] - p[2];
 }
 
+// The same gather as two pipeline stages: the neighbour index of edge slot j (tile j / k, slot j % k) one step ahead of the point loads
+// that depend on it -- issued back to back, the index round trip (an L2 / HBM latency) stalls the gathering wave, and the whole
+// workgroup behind the slot's barrier, once per slot.
+__device__ __forceinline__ int dgt_index(const int* __restrict__ nnc, int N, int k, int j, int tid)
+{
+  const int jt = j / k, js = j - jt * k;
+  return nnc[(size_t)min(jt * kTT + tid, N - 1) * k + js];
+}
+__device__ __forceinline__ void dgt_points(const float* __restrict__ pc, int N, int k, int j, int tid, int nbr, float (&v)[6])
+{
+  const int n = min((j / k) * kTT + tid, N - 1);
+  const float* p = pc + (size_t)n * 3;
+  const float* pj = pc + (size_t)nbr * 3;
+  v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  v[3] = pj[0] - p[0]; v[4] = pj[1] - p[1]; v[5] = pj[2] - p[2];
+}
+
 // ---------------------------------------------------------------------------------
 // phase 1: moments of e per cloud -> statistics of z1.   grid 2B, block 256
 // ---------------------------------------------------------------------------------
@@ -323,8 +340,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   int bk[2][16];
 
   float v[6];
+  int jnext = 0;
   if (tid < kTT) {
     dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
+    if (total > 1) jnext = dgt_index(nnc, a.N, a.k, 1, tid);
     dg_edge_to_lds(xf, v, es + tid * 8);
     es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift: never written again
   }
@@ -336,9 +355,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool more = it + 1 < total;
-    const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
+    const int ntile = (it + 1) / a.k;
     FE_STAMP(0);
-    if (more && tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);   // in flight during the MFMAs
+    if (more && tid < kTT) {   // the points of slot it + 1 (in flight during the MFMAs) through the index loaded a slot ago; the index of slot it + 2
+      dgt_points(pc, a.N, a.k, it + 1, tid, jnext, v);
+      if (it + 2 < total) jnext = dgt_index(nnc, a.N, a.k, it + 2, tid);
+    }
     const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
     const unsigned short* Xh = hbuf + (it & 1) * kBufH;
     const unsigned short* XhT = Xh + kTT * ldh;
@@ -639,7 +661,11 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     }
   }
   float v[6];
-  if (tid < kTT) dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
+  int jnext = 0;
+  if (tid < kTT) {
+    dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
+    if (total > 1) jnext = dgt_index(nnc, a.N, a.k, 1, tid);
+  }
   for (int it = 0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
@@ -738,8 +764,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     BE_STAMP(1);
     __syncthreads();   // es and the lists are ready; every wave is done with the previous slot's X / D (and the arg-k staging)
     if (more && tid < kTT) {
-      const int ntile = (it + 1) / a.k, nslot = (it + 1) - ntile * a.k;
-      dgt_gather(pc, nnc, a.N, a.k, min(ntile * kTT + tid, a.N - 1), nslot, v);
+      dgt_points(pc, a.N, a.k, it + 1, tid, jnext, v);
+      if (it + 2 < total) jnext = dgt_index(nnc, a.N, a.k, it + 2, tid);
     }
     BE_STAMP(2);
     if constexpr (BF16) dgt_liftm_both<C1, kBEW>(lw, es, X, ld0, Xh, ldh, nvalid, wave, lane);
@@ -977,14 +1003,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
   // edge features run two slots ahead of the MFMAs: es(it + 1) is written while slot it is lifted (three buffers: the dh1 waves of a
   // slow slot it may still be reading es(it) when a fast wave writes es(it + 2)), the gather of slot it + 2 is in flight meanwhile
   float v[6];
-  auto gather_slot = [&](int j) {
-    const int jt = j / a.k, js = j - jt * a.k;
-    dgt_gather(pc, nnc, a.N, a.k, min(jt * kTT + tid, a.N - 1), js, v);
-  };
+  int jnext = 0;   // neighbour index of slot it + 3 at the top of iteration it: one step ahead of the point loads that need it
   if (tid < kTT) {
-    gather_slot(0);
+    dgt_points(pc, a.N, a.k, 0, tid, dgt_index(nnc, a.N, a.k, 0, tid), v);
     dg_edge_to_lds(xf, v, smem + tid * 8);
-    if (total > 1) gather_slot(1);
+    if (total > 1) dgt_points(pc, a.N, a.k, 1, tid, dgt_index(nnc, a.N, a.k, 1, tid), v);
+    if (total > 2) jnext = dgt_index(nnc, a.N, a.k, 2, tid);
   }
   __syncthreads();
   for (int it = 0; it < total; ++it) {
@@ -1042,7 +1066,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
     dgt_liftm_bf16_keep<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane, hv);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
     if (more && tid < kTT) {
       dg_edge_to_lds(xf, v, smem + ((it + 1) % 3) * kTT * 8 + tid * 8);
-      if (it + 2 < total) gather_slot(it + 2);
+      if (it + 2 < total) dgt_points(pc, a.N, a.k, it + 2, tid, jnext, v);
+      if (it + 3 < total) jnext = dgt_index(nnc, a.N, a.k, it + 3, tid);
     }
     __syncthreads();   // the slot's only barrier: h1 tiles (and at a tile start the P tiles) complete, es of the next slot written
     const unsigned slot4 = (unsigned)slot * 0x01010101u;
