@@ -286,12 +286,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
-  float* es = smem;
   constexpr int ld0 = C1 + 4;
   constexpr int KG2 = (C1 + 7) >> 3;   // <= 8 (C1 <= 64)
   constexpr int ldh = C1 + 8, ldT = kTT + 8, KG16 = C1 / 16;   // bf16 tiles
   constexpr int kBufH = kTT * ldh + C1 * ldT;                    // bf16 elements per lift buffer (Xh | XhT)
-  unsigned short* hbuf = reinterpret_cast<unsigned short*>(smem + kTT * 8);
+  float* const xbuf = smem + 2 * kTT * 8;   // behind the two edge-feature buffers
+  unsigned short* hbuf = reinterpret_cast<unsigned short*>(xbuf);
   const int CT2 = (a.C2 + 31) >> 5;
   const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
   const int ct = wave, col = ct * 32 + (lane & 31);
@@ -339,29 +339,46 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   f32x16 best[2];
   int bk[2][16];
 
+  // One barrier per slot: at iteration it the waves lift slot it + 1 (es[(it + 1) & 1] -> h buffer (it + 1) & 1) and wave 0 writes the
+  // edge features of slot it + 2 into es[it & 1] (last read by the lift of slot it, an iteration and a barrier ago) while the MFMAs
+  // of slot it read h buffer it & 1; the points of slot it + 3 and the neighbour index of slot it + 4 are in flight meanwhile.
+  // (Two barriers per slot -- features, barrier, lift, barrier -- left the matrix pipe idle during every lift.)
   float v[6];
   int jnext = 0;
+  auto es_of = [&](int j) { return smem + (j & 1) * kTT * 8; };
+  auto lift_slot = [&](int j) {
+    const int nv = min(kTT, a.N - (j / a.k) * kTT);
+    if constexpr (BF16) {
+      unsigned short* nh = hbuf + (j & 1) * kBufH;
+      dgt_liftm_bf16<C1, kTW>(lw, es_of(j), nh, ldh, nh + kTT * ldh, ldT, nv, wave, lane);
+    } else dgt_liftm<C1, kTW>(lw, es_of(j), xbuf + (j & 1) * kTT * ld0, ld0, nv, wave, lane);
+  };
   if (tid < kTT) {
-    dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
-    if (total > 1) jnext = dgt_index(nnc, a.N, a.k, 1, tid);
-    dg_edge_to_lds(xf, v, es + tid * 8);
-    es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift: never written again
+    smem[tid * 8 + 6] = 0.f; smem[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift in both buffers: never written again
+    smem[kTT * 8 + tid * 8 + 6] = 0.f; smem[kTT * 8 + tid * 8 + 7] = 0.f;
+    dgt_points(pc, a.N, a.k, 0, tid, dgt_index(nnc, a.N, a.k, 0, tid), v);
+    dg_edge_to_lds(xf, v, es_of(0) + tid * 8);
+    if (total > 1) {
+      dgt_points(pc, a.N, a.k, 1, tid, dgt_index(nnc, a.N, a.k, 1, tid), v);
+      dg_edge_to_lds(xf, v, es_of(1) + tid * 8);
+    }
+    if (total > 2) dgt_points(pc, a.N, a.k, 2, tid, dgt_index(nnc, a.N, a.k, 2, tid), v);
+    if (total > 3) jnext = dgt_index(nnc, a.N, a.k, 3, tid);
   }
   __syncthreads();
-  if constexpr (BF16) dgt_liftm_bf16<C1, kTW>(lw, es, hbuf, ldh, hbuf + kTT * ldh, ldT, min(kTT, a.N), wave, lane);
-  else dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8, ld0, min(kTT, a.N), wave, lane);
+  lift_slot(0);
   __syncthreads();
   for (int it = 0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
-    const bool more = it + 1 < total;
-    const int ntile = (it + 1) / a.k;
     FE_STAMP(0);
-    if (more && tid < kTT) {   // the points of slot it + 1 (in flight during the MFMAs) through the index loaded a slot ago; the index of slot it + 2
-      dgt_points(pc, a.N, a.k, it + 1, tid, jnext, v);
-      if (it + 2 < total) jnext = dgt_index(nnc, a.N, a.k, it + 2, tid);
+    if (it + 1 < total) lift_slot(it + 1);
+    if (it + 2 < total && tid < kTT) {
+      dg_edge_to_lds(xf, v, es_of(it) + tid * 8);   // slot it + 2
+      if (it + 3 < total) dgt_points(pc, a.N, a.k, it + 3, tid, jnext, v);
+      if (it + 4 < total) jnext = dgt_index(nnc, a.N, a.k, it + 4, tid);
     }
-    const float* X = smem + kTT * 8 + (it & 1) * kTT * ld0;
+    const float* X = xbuf + (it & 1) * kTT * ld0;
     const unsigned short* Xh = hbuf + (it & 1) * kBufH;
     const unsigned short* XhT = Xh + kTT * ldh;
     if (slot == 0) {
@@ -455,18 +472,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
       s1q[0] += (double)sm[0]; s1q[1] += (double)sm[1]; s1q[2] += (double)sm[2]; s1q[3] += (double)sm[3];
     }
     FE_STAMP(3);
-    if (more && tid < kTT) dg_edge_to_lds(xf, v, es + tid * 8);
-    FE_STAMP(4);
-    __syncthreads();
-    FE_STAMP(5);
-    if (more) {
-      if constexpr (BF16) {
-        unsigned short* nh = hbuf + ((it + 1) & 1) * kBufH;
-        dgt_liftm_bf16<C1, kTW>(lw, es, nh, ldh, nh + kTT * ldh, ldT, min(kTT, a.N - ntile * kTT), wave, lane);
-      } else dgt_liftm<C1, kTW>(lw, es, smem + kTT * 8 + ((it + 1) & 1) * kTT * ld0, ld0, min(kTT, a.N - ntile * kTT), wave, lane);
-    }
-    FE_STAMP(6);
-    __syncthreads();
+    __syncthreads();   // the slot's only barrier
     FE_STAMP(7);
   }
   if (wave < nG) {
