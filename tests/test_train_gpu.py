@@ -511,6 +511,48 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     eng.close()
 
 
+@pytest.mark.parametrize("backbone,bf16,widths", [("pointnet", 0, "std"), ("pointnet", 1, "std"), ("dgcnn", 0, "std"), ("dgcnn", 1, "std"),
+                                                  ("pointnet", 0, "deep"), ("dgcnn", 0, "deep")])
+def test_training_step_is_bitwise_reproducible(gpu_required, backbone, bf16, widths):
+    """No atomics on floats and fixed summation orders everywhere in the training path: the same batch twice on one engine, and once
+    on a second engine, gives bit-identical loss, predictions and gradients -- at a size with hundreds of workgroups in flight
+    (B = 48 pairs, N = 320: partial last tile), so that a missing barrier or a read of a buffer another workgroup is still writing
+    shows up as a difference.  Covers the fused PointNet kernels (fp32 / bf16), the DGCNN edge kernels (list form / dense bf16 form)
+    and the layer-by-layer paths."""
+    B, N = 48, 320
+    if widths == "std":
+        w = STD
+    elif backbone == "dgcnn":
+        w = dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160))
+    else:
+        w = dict(s1=(128, 128, 160), s2=(32, 32, 32, 64, 128), emb=(32, 32, 32, 64, 160))
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), backbone=backbone, **w)
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=21)
+    d = R.synth_pairs(B, N, seed=21, dtype=np.float32)
+    rng = np.random.default_rng(21)
+    du = [rng.uniform(size=(B, 32)).astype(np.float32) for _ in range(5)]
+    runs = []
+    for e in range(2):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        if bf16:
+            eng.set_option("train_matmul_bf16", 1)
+        for rep in range(2 if e == 0 else 1):
+            eng.set_variables(P32)   # (the EMA shadows too)
+            res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, du)
+            runs.append((res, {n: eng.get_gradient(n).copy() for n in R.trainable_names(spec)}))
+        eng.close()
+    res0, g0 = runs[0]
+    assert np.isfinite(res0["loss"])
+    for res, g in runs[1:]:
+        assert res["loss"] == res0["loss"], (res["loss"], res0["loss"])
+        for k in alignnet3d.OUTPUT_NAMES:
+            np.testing.assert_array_equal(res[k], res0[k], err_msg=k)
+        for n in g0:
+            np.testing.assert_array_equal(g[n], g0[n], err_msg=n)
+
+
 DGCNN_GENERAL = {
     # models/tp8.py:38-41 builds one edge conv per entry of sizes[:-1]: three edge convs, an odd first width, a single edge conv
     "deep_odd": dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160)),
