@@ -118,7 +118,9 @@ if v:
 for name, lab, tag, sub in (("%s_bench_train_dgcnn_n1024.json", "DGCNN training, fp32, N = 1024, B = 256", "train_dgcnn", "dg_train_bwd_edge"),
                             ("%s_bench_train_dgcnn_bf16_n1024.json", "DGCNN training, `train_matmul_bf16`, N = 1024, B = 256", "train_dgcnn_bf16", "dg_train_bwd_edge"),
                             ("%s_bench_train_dgcnn_n4096_b64.json", "DGCNN training, fp32, N = 4096, B = 64", None, None),
-                            ("%s_bench_train_dgcnn_bf16_n4096_b64.json", "DGCNN training, `train_matmul_bf16`, N = 4096, B = 64", None, None)):
+                            ("%s_bench_train_dgcnn_bf16_n4096_b64.json", "DGCNN training, `train_matmul_bf16`, N = 4096, B = 64", None, None),
+                            ("%s_bench_train_dgcnn_n4096_b512.json", "DGCNN training, fp32, N = 4096, B = 512 (BASELINE configs[4]'s per-GPU batch: 1024 clouds fill the 256 CUs, 128 do not)", None, None),
+                            ("%s_bench_train_dgcnn_bf16_n4096_b512.json", "DGCNN training, `train_matmul_bf16`, N = 4096, B = 512", None, None)):
     t = line(name % R)
     if not t:
         continue

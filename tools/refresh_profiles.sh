@@ -10,8 +10,10 @@ python bench.py --workload dgcnn --batch 512 --steps 4 --warmup 1 > gpurun_out/f
 python bench.py --workload dgcnn --batch 512 --steps 4 --warmup 1 --infer-dtype bf16x3 > gpurun_out/fin/${R}_bench_dgcnn_split.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --points 1024 --steps 10 --warmup 2 > gpurun_out/fin/${R}_bench_train_dgcnn_n1024.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --batch 64 --steps 5 --warmup 1 > gpurun_out/fin/${R}_bench_train_dgcnn_n4096_b64.json 2>/dev/null
+python bench.py --mode train --workload dgcnn --batch 512 --steps 2 --warmup 1 --sustained-seconds 0 > gpurun_out/fin/${R}_bench_train_dgcnn_n4096_b512.json 2>/dev/null   # BASELINE configs[4]'s per-GPU batch
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --points 1024 --steps 10 --warmup 2 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n1024.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 64 --steps 5 --warmup 1 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b64.json 2>/dev/null
+python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 512 --steps 3 --warmup 1 --sustained-seconds 0 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b512.json 2>/dev/null
 Q="--no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg --sustained-seconds 0"
 S="--sustained-seconds 0"
 bash tools/profile.sh ${R} --steps 20 --warmup 3 $Q > gpurun_out/fin/p_${R}.log 2>&1
