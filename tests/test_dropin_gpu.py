@@ -160,7 +160,7 @@ def test_rccl_world1_and_device_entry_points(gpu_required):
         np.testing.assert_array_equal(outs[k].cpu().numpy(), host[k])
     labels = {k: t[k].data_ptr() for k in ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
     r = eng.train_step_device(t["pcs1"].data_ptr(), t["pcs2"].data_ptr(), labels, 8, want_result=True)
-    assert r["step"] == 3 and np.isfinite(r["loss"]) and eng.get_option("comm_buckets") == 3
+    assert r["step"] == 4 and np.isfinite(r["loss"]) and eng.get_option("comm_buckets") == 3
     ptr, n = eng.grad_buffer()
     assert ptr and n == sum(s[0] * s[1] for _, s, tr in eng.variables() if tr)
     eng.close(); ref.close()
