@@ -874,6 +874,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
   if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
   if (k == "train_dw_side_stream") { h->dw_side = value != 0; return 0; }
+  if (k == "train_phase3_tile64") { h->p3_tile64 = value != 0; return 0; }
   if (k == "dropout_stream") { h->dropout_stream = (uint64_t)value; return 0; }
   if (k == "sync_bn") { h->sync_bn = value != 0; return 0; }
   if (k == "global_loss") { h->global_loss = value != 0; return 0; }
@@ -899,6 +900,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
   if (k == "allreduce_overlap") { *value = h->comm_overlap ? 1 : 0; return 0; }
   if (k == "train_dw_side_stream") { *value = h->dw_side ? 1 : 0; return 0; }
+  if (k == "train_phase3_tile64") { *value = h->p3_tile64 ? 1 : 0; return 0; }
   if (k == "dropout_stream") { *value = (int64_t)h->dropout_stream; return 0; }
   if (k == "sync_bn") { *value = h->sync_bn ? 1 : 0; return 0; }
   if (k == "global_loss") { *value = h->global_loss ? 1 : 0; return 0; }

@@ -2,6 +2,7 @@
 // (train.py:368) = forward with batch statistics + loss + backward + optimiser + EMA + step++.
 #include "engine.h"
 #include "kernels_train_fwd.h"
+#include "kernels_train_fwd_wide.h"
 #include "kernels_train_head.h"
 #include "kernels_train_bwd.h"
 #include "kernels_train_dgcnn.h"
@@ -612,6 +613,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -942,7 +944,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
   } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-    if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    // shipped widths: 128-point tiles (a weight fragment of the lift feeds four row tiles; kernels_train_fwd_wide.h)
+    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64")) hipLaunchKernelGGL(train_fwd_phase3_wide, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);

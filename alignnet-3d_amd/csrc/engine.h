@@ -120,6 +120,7 @@ struct alignnet_handle {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool dw_side = false;            // alignnet_set_option("train_dw_side_stream")
+  bool p3_tile64 = false;          // alignnet_set_option("train_phase3_tile64"): the forward's phase 3 on 64-point tiles (default: 128-point tiles, kernels_train_fwd_wide.h)
   // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --
   // the reference's single-device semantics at the global batch (utils/tf_util.py:474) -- instead of per rank.
   bool sync_bn = false;

@@ -553,6 +553,41 @@ def test_training_step_is_bitwise_reproducible(gpu_required, backbone, bf16, wid
             np.testing.assert_array_equal(g[n], g0[n], err_msg=n)
 
 
+@pytest.mark.parametrize("N,B", [(200, 16), (384, 12), (96, 16), (136, 16), (200, 8), (264, 16), (72, 16), (201, 12), (135, 10)])
+def test_phase3_tile_shapes_agree(gpu_required, N, B):
+    """The forward's phase 3 on 128-point tiles (default for the shipped widths 64 / 128: kernels_train_fwd_wide.h) against the same
+    phase on 64-point tiles (option train_phase3_tile64): the MFMA k-order is the same, so the lift's values -- hence the pooled
+    extremes -- are bit-identical; only the grouping of the column sums of h2 differs (fp32 partial sums per lane, added in fp64), which
+    the small-batch statistics amplify to ~1e-5 in the predictions: bounds a decade below the ones against the oracle.
+    N = 200: partial last tile in both shapes (72 / 8 rows); N = 96: a cloud smaller than one wide tile."""
+    cfg, spec, P32, d, du = _setup(N, B, std=True)
+    ul = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    out = []
+    for t64 in (0, 1):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("train_phase3_tile64", t64)
+        assert eng.get_option("train_phase3_tile64") == t64
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
+        out.append((res, {n: eng.get_gradient(n).copy() for n in R.trainable_names(spec)},
+                    {k: eng.get_variable(k).copy() for k, _, tr in eng.variables() if not tr}))
+        eng.close()
+    (ra, ga, ea), (rb, gb, eb) = out
+    assert abs(ra["loss"] - rb["loss"]) <= 2e-5 * max(1.0, abs(rb["loss"]))
+    for k in alignnet3d.OUTPUT_NAMES:
+        np.testing.assert_allclose(ra[k], rb[k], rtol=3e-5, atol=3e-5, err_msg=k)
+    for k in ea:
+        np.testing.assert_allclose(ea[k], eb[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    gscale = max(float(np.abs(v).max()) for v in gb.values())
+    # gradients: a 1e-6 difference in stage 1's output moves the points of the later stages, and a max-pool near-tie that falls the other
+    # way re-routes one channel's gradient.  Measured over these nine shapes: relative L2 of the whole gradient 4e-6 .. 5e-5 in seven of
+    # them, 7e-4 and 4e-3 in two (N = 200 at B = 16 but not at B = 8; N = 264) -- data-dependent flips, not a tile-remainder effect.
+    num = sum(float(((ga[n].astype(np.float64) - gb[n]) ** 2).sum()) for n in ga)
+    den = sum(float((gb[n].astype(np.float64) ** 2).sum()) for n in ga)
+    print("relative L2 difference of the whole gradient between the tile shapes:", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 <= 1e-2
+
+
 DGCNN_GENERAL = {
     # models/tp8.py:38-41 builds one edge conv per entry of sizes[:-1]: three edge convs, an odd first width, a single edge conv
     "deep_odd": dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160)),
