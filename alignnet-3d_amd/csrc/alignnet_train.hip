@@ -614,6 +614,7 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -932,7 +933,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-    if (std_w && !getenv("ALIGNNET_P3BF16_GENERIC")) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+    // shipped widths: 128-point tiles, the next tile's prologue under the lift (kernels_train_fwd_wide.h)
+    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64"))
+      hipLaunchKernelGGL(train_fwd_phase3_wide_bf16, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_bf16(), h->stream, a);
+    else if (std_w && !getenv("ALIGNNET_P3BF16_GENERIC")) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
   }
     if (a.stamps) {

@@ -98,13 +98,10 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     }
     if (tile + 1 < ntiles) request_xyz(tile + 1);
     __syncthreads();
-#ifndef X_NOL1
     layer1_wide(xs, l1w, smem + off0, tid);
-#endif
     __syncthreads();
 
     // ---- layer 2: h2 = relu(bn2(h1 W2 + b2)) -> LDS, column sums ----
-#ifndef X_NOL2
     {
       f32x16 acc[2];
       mfma_rows<2, true, true>(smem + off0 + rg2 * 64 * ld0, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct2 * KG2 * 64, KG2, lane, acc);
@@ -121,11 +118,9 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
         }
       cs2 += (double)lsum;
     }
-#endif
     __syncthreads();
 
     // ---- keep h2 for the Gram and the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-#ifndef X_NOSTORE
     if (!(a.dbg & 2)) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kWT) * C2;
       constexpr int c4 = C2 / 4;
@@ -136,7 +131,6 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
           *reinterpret_cast<f32x4*>(dst + (size_t)row * C2 + q * 4) = *reinterpret_cast<const f32x4*>(smem + off1 + row * ld1 + q * 4);
       }
     }
-#endif
 
     // ---- layer 3: z3 = h2 W3 + b3: extreme of sgn * (z3 - b3) over the cloud's points (statistics: stat3_pool_finish_kernel) ----
     // (not unrolled: with the four channel tiles unrolled hipcc keeps the A fragments -- the same LDS reads for every channel tile -- live
@@ -152,11 +146,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       asm volatile("" ::: "memory");
       f32x16 acc[4];
       mfma_rows<4, true, true>(smem + off1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64,
-#ifdef WIDE_KG_RT
-                               a.C2 >> 3,
-#else
                                KG3,
-#endif
                                lane, acc);
       // running extreme + its accumulator ordinal (16 m + r).  Spelled in asm with a counter register: written as
       // `if (v > e) { e = v; ei = <row constant>; }` hipcc materialises the 64 row constants in VGPRs, hoists them out of the tile loop
@@ -183,6 +173,286 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
     }
     a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------
+// bf16 operands (train_matmul_bf16, BASELINE.json configs[2]): the same phase on 128-point tiles, software-pipelined.
+// In bf16 the lift of a tile is only ~4 k matrix-pipe cycles per wave, so -- unlike fp32 -- the tile's prologue (K = 3 lift, hidden layer,
+// Gram, h2 store) is as long as the lift itself; the 64-point kernel hides it behind the second workgroup of the CU, but streams
+// every weight fragment for two row tiles only and is bound by that L2 -> CU stream (matrix pipe busy 0.28).  Here one workgroup of
+// eight waves owns the CU, a weight fragment feeds four row tiles, and the prologue of tile t + 1 runs under the lift of tile t:
+//   S0: { Gram(t), h2 store(t), K = 3 lift(t + 1) }  ||  lift(t), first half of the wave's channel tiles      -- barrier
+//   S1: { points(t + 2), hidden layer(t + 1) }       ||  lift(t), second half                                  -- barrier
+// with h2 double-buffered (row-major bf16 = A operand of the lift) and one transposed tile (both operands of the Gram).  Waves 0-3
+// take the prologue piece first, waves 4-7 the lift first, so that the two waves of a SIMD are in different kinds of work.
+// LDS: xs 2 KiB | h1 [128][72] bf16 | h2 2 x [128][136] bf16 | h2^T [128][136] bf16 = 123 KiB.
+// Outputs and layouts are those of train_fwd_phase23<3, true, false, 64, 128>.
+// ---------------------------------------------------------------------------------
+static inline size_t lds_p3_wide_bf16() { return (size_t)kWT * 4 * sizeof(float) + ((size_t)kWT * 72 + 3 * (size_t)kWT * 136) * sizeof(unsigned short); }
+
+__global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const TrainFwdArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int C1 = 64, C2 = 128, ld0h = C1 + 8, ldh = C2 + 8, ldT = kWT + 8, KG2 = C1 / 16, KG3 = C2 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  float* xs = smem;
+  unsigned short* h1h = reinterpret_cast<unsigned short*>(smem + kWT * 4);
+  unsigned short* h2h = h1h + kWT * ld0h;            // two tiles
+  unsigned short* bufT = h2h + 2 * kWT * ldh;
+  const int CT3 = (a.C3 + 31) >> 5;
+  const int nct = (CT3 - wave + kWW - 1) / kWW;       // channel tiles wave, wave + 8, ... of this wave (<= kWSlots)
+  const int nA = (nct + 1) >> 1;                      // ... of which the first nA are lifted in S0, the rest in S1
+  const int ntiles = (a.N + kWT - 1) / kWT;
+  const bool early = wave < kWW / 2;                  // prologue piece first
+
+  const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
+  // hidden-layer item of this wave: channel tile wave >> 1, row tiles 2 (wave & 1) + {0, 1}
+  const int ct2 = wave >> 1, rg2 = wave & 1, col2 = ct2 * 32 + (lane & 31);
+  const float sc2 = a.sc2[tower * C2 + col2], sh2 = a.sh2[tower * C2 + col2];
+  double cs2 = 0.0;
+  // the item's four weight fragments stay in registers for the whole cloud (requested per tile they were an exposed L2 round trip in
+  // front of eight MFMAs: 3 k cycles per tile)
+  bf16x8 w2f[KG2];
+#pragma unroll
+  for (int kg = 0; kg < KG2; ++kg) w2f[kg] = reinterpret_cast<const bf16x8*>(a.wp2h)[((size_t)ct2 * KG2 + kg) * 64 + lane];
+  // Gram: the ten upper 32 x 32 blocks on eight waves (blocks wave, wave + 8), register-resident for the whole cloud
+  constexpr int nblk = 10, CT2 = 4;
+  f32x16 gacc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
+  float rbe[kWSlots]; int rbi[kWSlots];
+#pragma unroll
+  for (int q = 0; q < kWSlots; ++q) { rbe[q] = -INFINITY; rbi[q] = 0; }
+  const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.wp3h) + (size_t)tower * CT3 * KG3 * 64;
+  bf16x8 wf[KG3];                                     // the lift's weight stream (lift3 below)
+  if (nct > 0) {
+#pragma unroll
+    for (int kg = 0; kg < KG3; ++kg) wf[kg] = wimg[((size_t)wave * KG3 + kg) * 64 + lane];
+  }
+
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  auto request_xyz = [&](int t) {
+    if (tid < kWT) {
+      const float* q = pc + (size_t)min(t * kWT + tid, a.N - 1) * 3;
+      nx = q[0]; ny = q[1]; nz = q[2];
+    }
+  };
+  auto store_xs = [&]() {
+    if (tid < kWT) {
+      const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
+      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+    }
+  };
+  // K = 3 lift of tile t -> h1h (bf16; rows past the cloud's end are zero)
+  auto lift = [&](int t) {
+    const int nvalid = min(kWT, a.N - t * kWT);
+    const int c0 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c = c0 + 32 * g;
+#pragma unroll
+      for (int rr = 0; rr < kWT / (kWW * 2); ++rr) {
+        const int row = rr * (kWW * 2) + r0;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        const float acc = fmaf(p[2], l1w.wb[g], fmaf(p[1], l1w.wa[g], p[0] * l1w.w0[g]));
+        h1h[row * ld0h + c] = row < nvalid ? to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) : (unsigned short)0;
+      }
+    }
+  };
+  // hidden layer of tile t: h2 = round(relu(bn2(h1 W2))) -> h2h[t & 1] (row-major) and bufT (transposed); column sums of the rounded values
+  auto hidden = [&](int t) {
+    const int nvalid = min(kWT, a.N - t * kWT);
+    unsigned short* dst = h2h + (t & 1) * kWT * ldh;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    {
+      const unsigned short* arow = h1h + (rg2 * 64 + (lane & 31)) * ld0h + (lane >> 5) * 8;
+#pragma unroll
+      for (int kg = 0; kg < KG2; ++kg)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + m * 32 * ld0h + kg * 16), w2f[kg], acc[m], 0, 0, 0);
+    }
+    float lsum = 0.f;
+    const int lim = nvalid - rg2 * 64 - 4 * half;   // row < nvalid  <=>  32 m + 8 (r >> 2) + (r & 3) < lim
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned short hb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = q * 4 + e, row = rg2 * 64 + acc_row(m, r, lane);
+          const float hv = m * 32 + (r & 3) + 8 * (r >> 2) < lim ? fmaxf(fmaf(acc[m][r], sc2, sh2), 0.f) : 0.f;
+          hb[e] = to_bf16_bits(hv);
+          lsum += __uint_as_float((unsigned)hb[e] << 16);
+          dst[row * ldh + col2] = hb[e];
+        }
+        // rows 8 q + 4 half + 0..3 of row tile m: consecutive in the transposed tile
+        uint2 pk; pk.x = hb[0] | ((unsigned)hb[1] << 16); pk.y = hb[2] | ((unsigned)hb[3] << 16);
+        *reinterpret_cast<uint2*>(bufT + col2 * ldT + rg2 * 64 + m * 32 + q * 8 + half * 4) = pk;
+      }
+    cs2 += (double)lsum;
+  };
+  auto gram = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int item = wave + q * kWW;
+      if (item < nblk) {
+        int it = 0, rem = item;
+        while (rem >= CT2 - it) { rem -= CT2 - it; ++it; }
+        const int jt = it + rem;
+        const unsigned short* pa = bufT + (it * 32 + (lane & 31)) * ldT + half * 8;
+        const unsigned short* pb = bufT + (jt * 32 + (lane & 31)) * ldT + half * 8;
+#pragma unroll
+        for (int kg = 0; kg < kWT / 16; ++kg)
+          gacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa + kg * 16),
+                                                            *reinterpret_cast<const bf16x8*>(pb + kg * 16), gacc[q], 0, 0, 0);
+      }
+    }
+  };
+  auto store_h2 = [&](int t) {
+    const int nvalid = min(kWT, a.N - t * kWT);
+    const unsigned short* src = h2h + (t & 1) * kWT * ldh;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)t * kWT) * C2;
+    constexpr int c8 = C2 / 8;
+#pragma unroll
+    for (int j = 0; j < kWT * c8 / (kWW * 64); ++j) {
+      const int i = tid + j * kWW * 64, row = i / c8, q = i % c8;
+      if (row < nvalid) *reinterpret_cast<f32x4*>(dst + (size_t)row * C2 + q * 8) = *reinterpret_cast<const f32x4*>(src + row * ldh + q * 8);
+    }
+  };
+  // lift of tile t for this wave's channel tile slots [q0, q1): acc = sgn * (z3 - b3) (sign folded into the bf16 image); the epilogue is
+  // the key max of train_fwd_phase23<3, true> (low 4 mantissa bits = accumulator register number), over four row tiles
+  auto lift3 = [&](int t, int q0, int q1) {
+    const int nvalid = min(kWT, a.N - t * kWT);
+    const unsigned short* arow = h2h + (t & 1) * kWT * ldh + (lane & 31) * ldh + (lane >> 5) * 8;
+    // (not unrolled over the slots: the A fragments are the same LDS reads for every channel tile and hipcc would keep them live across
+    //  unrolled copies; the slot's running extreme is selected in and out of its register by compares against the loop counter)
+#pragma unroll 1
+    for (int q = q0; q < q1; ++q) {
+      // wf[kg] holds the k-group's fragment of THIS channel tile; right behind the MFMAs that read it, it is re-requested for the next
+      // channel tile of the wave's cyclic stream (slots 0 .. nct - 1, tile after tile): seven k-groups = 0.9 k matrix-pipe cycles of lookahead
+      const int qn = q + 1 < nct ? q + 1 : 0;
+      const bf16x8* wpn = wimg + (size_t)(wave + qn * kWW) * KG3 * 64 + lane;
+      f32x16 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      bf16x8 av[4], an[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const bf16x8*>(arow + m * 32 * ldh);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kg = 0; kg < KG3; ++kg) {
+        if (kg + 1 < KG3) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const bf16x8*>(arow + m * 32 * ldh + (kg + 1) * 16);
+        }
+        asm volatile("" ::: "memory");   // the A fragments one k-group ahead, not all 32 up front (128 registers)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], wf[kg], acc[m], 0, 0, 0);
+        wf[kg] = wpn[kg * 64];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[m] = an[m];
+      }
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (nvalid == kWT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float k0 = __uint_as_float((__float_as_uint(acc[m][r]) & ~15u) | (unsigned)r);
+            const float k1 = __uint_as_float((__float_as_uint(acc[m][r + 1]) & ~15u) | (unsigned)(r + 1));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[m]) : "v"(mx[m]), "v"(k0), "v"(k1));
+          }
+      } else {
+        // rows past the cloud's end (zero rows of h2) never win.  lim is laundered per channel tile: the 64 compares are invariant in q,
+        // and hoisted out of the loop they are 64 SGPR pairs (140 scalar spills)
+        int lim = nvalid - 4 * half;
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = m * 32 + (r & 3) + 8 * (r >> 2) < lim;
+            const float k = ok ? __uint_as_float((__float_as_uint(acc[m][r]) & ~15u) | (unsigned)r) : -INFINITY;
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx[m]) : "v"(mx[m]), "v"(k));
+          }
+      }
+      // near-ties resolve to the lower row tile
+      int msel = 0; float cand = mx[0];
+#pragma unroll
+      for (int m = 1; m < 4; ++m)
+        if (mx[m] > cand) { cand = mx[m]; msel = m; }
+      const int ci = t * kWT + acc_row(msel, (int)(__float_as_uint(cand) & 15u), lane);
+#pragma unroll
+      for (int u = 0; u < kWSlots; ++u)
+        if (u == q && cand > rbe[u]) { rbe[u] = cand; rbi[u] = ci; }
+    }
+  };
+  auto pieceA = [&](int t, bool more) { if (!(a.dbg & 64)) gram(); if (!(a.dbg & 2)) store_h2(t); if (more && !(a.dbg & 256)) lift(t + 1); };
+
+  // ---- prologue of tile 0 (not overlapped) ----
+  request_xyz(0);
+  store_xs();
+  if (ntiles > 1) request_xyz(1);
+  __syncthreads();
+  lift(0);
+  __syncthreads();
+  if (ntiles > 1) store_xs();
+  hidden(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    // ---- S0 ----
+    if (early) pieceA(t, more);
+    if (!(a.dbg & 8)) lift3(t, 0, nA);
+    if (!early) pieceA(t, more);
+    if (t + 2 < ntiles) request_xyz(t + 2);
+    __syncthreads();
+    // ---- S1 ----
+    if (early && more && !(a.dbg & 128)) hidden(t + 1);
+    if (!(a.dbg & 8)) lift3(t, nA, nct);
+    if (!early && more && !(a.dbg & 128)) hidden(t + 1);
+    if (t + 2 < ntiles) store_xs();
+    __syncthreads();
+  }
+  {
+    float* my_ext = a.ext + ((size_t)cloud * 2 + half) * a.C3;
+    int* my_idx = a.idx + ((size_t)cloud * 2 + half) * a.C3;
+#pragma unroll
+    for (int q = 0; q < kWSlots; ++q) {
+      const int col = (wave + q * kWW) * 32 + (lane & 31);
+      if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
+    }
+    a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+    float* my_gram = a.gram_part + (size_t)cloud * C2 * C2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int item = wave + q * kWW;
+      if (item < nblk) {
+        int it = 0, rem = item;
+        while (rem >= CT2 - it) { rem -= CT2 - it; ++it; }
+        const float zero[16] = {};
+        tile_commit(my_gram, C2, it, it + rem, C2, C2, gacc[q], lane, zero);
+      }
+    }
   }
 }
 

@@ -99,3 +99,19 @@ def test_inference_kernels_are_spill_free():
     # the kNN kernel for N <= 4096 keeps its 64 candidate distances per lane in registers at four waves per SIMD
     knn64 = [r for r in seen["knn_kernel"] if "ILi64E" in r[0]]
     assert knn64 and knn64[0][1] <= 128 and knn64[0][3] >= 4, knn64
+
+
+def test_wide_phase3_kernels_are_spill_free():
+    """train_fwd_phase3_wide carries the same hand-issued weight stream (mfma_rows<4, true, true>) and must not spill either; its bf16
+    sibling keeps 8 weight fragments + 4 hidden-layer fragments + 2 Gram accumulators + 4 lift accumulators live and has no registers to
+    lose (csrc/kernels_train_fwd_wide.h)."""
+    import re
+    path = os.path.join(ROOT, "alignnet-3d_amd", "csrc", "alignnet_train.remarks")
+    if not os.path.exists(path):
+        pytest.skip("no resource remarks next to the objects (library built by an older Makefile)")
+    rows = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)",
+                      open(path).read(), re.S)
+    wide = [(n, int(v), int(sc), int(o), int(sp)) for n, v, sc, o, sp in rows if "train_fwd_phase3_wide" in n]
+    assert len(wide) == 2, wide
+    for name, vgpr, scratch, occ, spill in wide:
+        assert spill == 0 and scratch == 0 and occ >= 2, (name, vgpr, scratch, occ, spill)

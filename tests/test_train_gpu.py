@@ -553,13 +553,17 @@ def test_training_step_is_bitwise_reproducible(gpu_required, backbone, bf16, wid
             np.testing.assert_array_equal(g[n], g0[n], err_msg=n)
 
 
-@pytest.mark.parametrize("N,B", [(200, 16), (384, 12), (96, 16), (136, 16), (200, 8), (264, 16), (72, 16), (201, 12), (135, 10)])
-def test_phase3_tile_shapes_agree(gpu_required, N, B):
+@pytest.mark.parametrize("N,B,bf16", [(200, 16, 0), (384, 12, 0), (96, 16, 0), (136, 16, 0), (200, 8, 0), (264, 16, 0), (72, 16, 0), (201, 12, 0), (135, 10, 0),
+                                      (200, 16, 1), (384, 12, 1), (96, 16, 1), (264, 16, 1), (135, 10, 1)])
+def test_phase3_tile_shapes_agree(gpu_required, N, B, bf16):
     """The forward's phase 3 on 128-point tiles (default for the shipped widths 64 / 128: kernels_train_fwd_wide.h) against the same
     phase on 64-point tiles (option train_phase3_tile64): the MFMA k-order is the same, so the lift's values -- hence the pooled
     extremes -- are bit-identical; only the grouping of the column sums of h2 differs (fp32 partial sums per lane, added in fp64), which
     the small-batch statistics amplify to ~1e-5 in the predictions: bounds a decade below the ones against the oracle.
-    N = 200: partial last tile in both shapes (72 / 8 rows); N = 96: a cloud smaller than one wide tile."""
+    N = 200: partial last tile in both shapes (72 / 8 rows); N = 96: a cloud smaller than one wide tile.
+    bf16 = 1 (train_matmul_bf16): the pipelined kernel train_fwd_phase3_wide_bf16 against train_fwd_phase23<3, true, false, 64, 128>; the
+    rounded h2 and the lift are bit-identical again, but a 1e-7 difference in a later stage's input can fall on the other side of a bf16
+    rounding boundary (4e-3 of that element), so the bounds are those of two bf16 runs, not of two fp32 runs."""
     cfg, spec, P32, d, du = _setup(N, B, std=True)
     ul = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     out = []
@@ -567,17 +571,19 @@ def test_phase3_tile_shapes_agree(gpu_required, N, B):
         eng = alignnet3d.Engine(cfg)
         eng.set_variables(P32)
         eng.set_option("train_phase3_tile64", t64)
+        eng.set_option("train_matmul_bf16", bf16)
         assert eng.get_option("train_phase3_tile64") == t64
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
         out.append((res, {n: eng.get_gradient(n).copy() for n in R.trainable_names(spec)},
                     {k: eng.get_variable(k).copy() for k, _, tr in eng.variables() if not tr}))
         eng.close()
     (ra, ga, ea), (rb, gb, eb) = out
-    assert abs(ra["loss"] - rb["loss"]) <= 2e-5 * max(1.0, abs(rb["loss"]))
+    lt, pt, et = (2e-3, 5e-3, 1e-3) if bf16 else (2e-5, 3e-5, 1e-5)
+    assert abs(ra["loss"] - rb["loss"]) <= lt * max(1.0, abs(rb["loss"]))
     for k in alignnet3d.OUTPUT_NAMES:
-        np.testing.assert_allclose(ra[k], rb[k], rtol=3e-5, atol=3e-5, err_msg=k)
+        np.testing.assert_allclose(ra[k], rb[k], rtol=pt, atol=pt, err_msg=k)
     for k in ea:
-        np.testing.assert_allclose(ea[k], eb[k], rtol=1e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(ea[k], eb[k], rtol=et, atol=et * 0.1, err_msg=k)
     gscale = max(float(np.abs(v).max()) for v in gb.values())
     # gradients: a 1e-6 difference in stage 1's output moves the points of the later stages, and a max-pool near-tie that falls the other
     # way re-routes one channel's gradient.  Measured over these nine shapes: relative L2 of the whole gradient 4e-6 .. 5e-5 in seven of
@@ -585,7 +591,7 @@ def test_phase3_tile_shapes_agree(gpu_required, N, B):
     num = sum(float(((ga[n].astype(np.float64) - gb[n]) ** 2).sum()) for n in ga)
     den = sum(float((gb[n].astype(np.float64) ** 2).sum()) for n in ga)
     print("relative L2 difference of the whole gradient between the tile shapes:", (num / den) ** 0.5)
-    assert (num / den) ** 0.5 <= 1e-2
+    assert (num / den) ** 0.5 <= (1e-1 if bf16 else 1e-2)
 
 
 DGCNN_GENERAL = {
