@@ -216,7 +216,7 @@ static int check_trainable_shape(alignnet_handle* h)
   const bool dg = h->cfg.backbone == 1;
   if (h->sync_bn)
     for (int s = 0; s < 3; ++s) {
-      if (stage_generic(h, s)) return fail(h, "sync_bn: supported for the fused three-layer stages (every shipped dataset config) and the dgcnn branch, not for general-depth backbones");
+      if (stage_generic(h, s)) continue;   // layer by layer: the per-layer sums travel through gen_stat_finish / gen_bn_bwd_finish's sync modes
       if (!dg && h->layers[conv_of(h, s).first].cout > 64) return fail(h, "sync_bn: first conv width limited to 64");
     }
   for (int s = 0; s < 3; ++s)
@@ -697,6 +697,14 @@ static int backbone_fwd_generic(alignnet_handle* h, int s, const float* p1, cons
     }
     f.bn_decay = bn_decay; f.update_ema = update_ema;
     f.mean = Gs.mean[l]; f.rstd = Gs.rstd[l]; f.scale = Gs.scale[l]; f.shift = Gs.shift[l];
+    if (sync_on(h)) {   // this rank's sum -> all ranks' -> squared differences from the global mean -> all ranks' -> finish (global count)
+      f.tot = h->sync_buf; f.world = (double)sync_world(h);
+      f.mode = 1; hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(1024), 0, h->stream, f);
+      if (sync_sum(h, h->sync_buf, (size_t)2 * L.cout, true)) return 1;
+      f.mode = 2; hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(1024), 0, h->stream, f);
+      if (sync_sum(h, h->sync_buf + (size_t)2 * L.cout, (size_t)2 * L.cout, true)) return 1;
+      f.mode = 3;
+    }
     hipLaunchKernelGGL(gen_stat_finish, dim3((L.cout + 63) / 64, 2), dim3(1024), 0, h->stream, f);
   }
   if (partial) { HIP_TRY(h, hipGetLastError()); return 0; }
@@ -733,6 +741,12 @@ static int backbone_bwd_generic(alignnet_handle* h, int s, int B, float* given_d
     GenBnBwdArgs b{Gs.Z[l], dY, Gs.mean[l], Gs.rstd[l], Gs.scale[l], Gs.shift[l], w->gen_part, w->gen_cA, w->gen_cB, rows, C, lt};
     hipLaunchKernelGGL(gen_bn_bwd_reduce, dim3(lt, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);
     GenBnFinArgs f{w->gen_part, lt, rows, C, {G(h, w, L.p_bn[0][0]), G(h, w, L.p_bn[1][0])}, {G(h, w, L.p_bn[0][1]), G(h, w, L.p_bn[1][1])}, w->gen_cA, w->gen_cB};
+    if (sync_on(h)) {   // the coefficients of dZ = k (g - dbeta / M - zhat dgamma / M) from all ranks' totals; the gradient keeps this rank's sums
+      f.mode = 1; f.tot = h->sync_buf; f.world = (double)sync_world(h);
+      hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(1024), 0, h->stream, f);
+      if (sync_sum(h, h->sync_buf, (size_t)2 * C * 2, true)) return 1;
+      f.mode = 2;
+    }
     hipLaunchKernelGGL(gen_bn_bwd_finish, dim3((C + 63) / 64, 2), dim3(1024), 0, h->stream, f);
     hipLaunchKernelGGL(gen_bn_bwd_apply, dim3(lt, 2, (C + 63) / 64), dim3(256), 0, h->stream, b);   // dY is dZ_l from here on
     if (l == 0) {

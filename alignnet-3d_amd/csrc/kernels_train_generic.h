@@ -157,6 +157,11 @@ struct GenStatArgs {
   const float* beta[2]; const float* gamma[2]; float* mov_mean[2]; float* mov_var[2];
   float bn_decay; int update_ema;
   float* mean; float* rstd; float* scale; float* shift;   // [2][C]: y = z * scale + shift
+  // sync_bn (batch statistics over all data-parallel ranks, utils/tf_util.py:474 at the global batch): three launches with an all-reduce
+  // of `tot` between them.  mode 1: tot[t][c] = this rank's sum of z; mode 2: tot holds all ranks' sum -> tot[2 C + ...] = this rank's
+  // sum of squared differences from the GLOBAL mean; mode 3: tot holds both global sums -> statistics and EMA with the global count
+  // M * world.  mode 0: one launch, this rank's batch.
+  int mode = 0; double* tot = nullptr; double world = 1.0;
 };
 
 // (All tiles but a tower's last hold kGenTile rows, so the pairwise Chan merge -- a chain of fp64 divisions per partial, 4096 partials
@@ -170,8 +175,9 @@ __global__ __launch_bounds__(1024) void gen_stat_finish(const GenStatArgs a)
   const bool live = c < a.C;
   const float* base = a.part + ((size_t)t * a.tiles * a.C + (live ? c : 0)) * 2;
   auto rows_of = [&](int i) { return (double)min(kGenTile, a.M - i * kGenTile); };
+  const double nglob = (double)a.M * a.world;
   double s = 0.0;
-  if (live) {
+  if (live && a.mode <= 1) {
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
     int i = g;
     for (; i + 48 < a.tiles; i += 64)
@@ -186,12 +192,14 @@ __global__ __launch_bounds__(1024) void gen_stat_finish(const GenStatArgs a)
     double tot = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) tot += red[q][lane];
-    bmean[lane] = tot / (double)a.M;
+    if (a.mode == 1) { if (live) a.tot[t * a.C + c] = tot; }
+    else bmean[lane] = (a.mode >= 2 ? (live ? a.tot[t * a.C + c] : 0.0) : tot) / nglob;
   }
+  if (a.mode == 1) return;
   __syncthreads();
   const double mean = bmean[lane];
   s = 0.0;
-  if (live) {
+  if (live && a.mode != 3) {
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
     int i = g;
     for (; i + 48 < a.tiles; i += 64)
@@ -215,7 +223,9 @@ __global__ __launch_bounds__(1024) void gen_stat_finish(const GenStatArgs a)
   double m2 = 0.0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) m2 += red[q][lane];
-  const double n = (double)a.M;
+  if (a.mode == 2) { a.tot[(2 + t) * a.C + c] = m2; return; }
+  if (a.mode == 3) m2 = a.tot[(2 + t) * a.C + c];
+  const double n = nglob;
   const float mf = (float)mean, vf = (float)(m2 / n);   // biased variance: mean of the squared difference from the mean (tf.nn.moments)
   const float rs = 1.0f / sqrtf(vf + kBnEps), k = a.gamma[t][c] * rs;
   a.mean[t * a.C + c] = mf;
@@ -344,13 +354,23 @@ __global__ __launch_bounds__(256) void gen_bn_bwd_reduce(const GenBnBwdArgs a)
 }
 
 // sums of the tile partials in fp64 -> dbeta, dgamma (written into the gradient vector) and the pass-2 coefficients
-struct GenBnFinArgs { const float* part; int tiles, M, C; float* dbeta[2]; float* dgamma[2]; float* cA; float* cB; };
+struct GenBnFinArgs { const float* part; int tiles, M, C; float* dbeta[2]; float* dgamma[2]; float* cA; float* cB;
+                      // sync_bn: mode 1 = this rank's (dbeta, dgamma) -> the gradient and tot[t][c][2] (all-reduced by the host), mode 2 = the
+                      // coefficients from all ranks' totals and the global count M * world; mode 0 = both from this rank's sums
+                      int mode = 0; double* tot = nullptr; double world = 1.0; };
 
 __global__ __launch_bounds__(1024) void gen_bn_bwd_finish(const GenBnFinArgs a)   // grid (ceil(C / 64), 2), block 16 tile groups x 64 columns
 {
   __shared__ double red[16][64][2];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, t = blockIdx.y;
   double s0 = 0.0, s1 = 0.0;
+  if (a.mode == 2) {
+    if (g == 0 && c < a.C) {
+      a.cA[t * a.C + c] = (float)(a.tot[(t * a.C + c) * 2] / ((double)a.M * a.world));
+      a.cB[t * a.C + c] = (float)(a.tot[(t * a.C + c) * 2 + 1] / ((double)a.M * a.world));
+    }
+    return;
+  }
   if (c < a.C) {
     const float* base = a.part + ((size_t)t * a.tiles * a.C + c) * 2;
     double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
@@ -369,6 +389,7 @@ __global__ __launch_bounds__(1024) void gen_bn_bwd_finish(const GenBnFinArgs a) 
   for (int q = 0; q < 16; ++q) { s0 += red[q][lane][0]; s1 += red[q][lane][1]; }
   a.dbeta[t][c] = (float)s0;
   a.dgamma[t][c] = (float)s1;
+  if (a.mode == 1) { a.tot[(t * a.C + c) * 2] = s0; a.tot[(t * a.C + c) * 2 + 1] = s1; return; }
   a.cA[t * a.C + c] = (float)(s0 / (double)a.M);
   a.cB[t * a.C + c] = (float)(s1 / (double)a.M);
 }

@@ -273,11 +273,17 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "train_dw_side_stream" (0/1, default 0): the weight-gradient jobs only the optimiser waits for are queued per stage on a second stream
  *   (under the next stage's backward; data-parallel: that stage's all-reduce bucket leaves right behind them) instead of as one group
  *   after the whole backward.  Same arithmetic, same summation order.  Slower on one GPU (measured).
+ * "train_phase3_tile64" (0/1, default 0): the training forward's last conv layer + max-pool (phase 3) of the shipped widths 64 / 128 on
+ *   64-point tiles, two workgroups per CU (rounds 1 - 2) instead of 128-point tiles, one workgroup of eight waves per CU
+ *   (csrc/kernels_train_fwd_wide.h: a weight fragment of the lift feeds four row tiles instead of two).  Same lift values bit for bit; the
+ *   column sums of h2 are grouped differently.  A/B switch and test hook.
  * "sync_bn" (0/1, default 0): data-parallel training with the reference's single-device BatchNorm semantics at the GLOBAL batch
  *   (utils/tf_util.py:474): every batch sum behind a BatchNorm -- forward moments, the Gram / column-sum matrices of the layer
  *   identities, the backward's (dbeta, dgamma) totals, the heads' row statistics -- is all-reduced over the ranks (RCCL, about thirty
- *   small all-reduces per step) between the kernel that forms this rank's sum and the one that uses it.  Fused three-layer stages
- *   and the dgcnn branch.  0: every rank normalises with its own shard's statistics ("local BN").
+ *   small all-reduces per step) between the kernel that forms this rank's sum and the one that uses it.  Every backbone shape: fused
+ *   three-layer stages, the dgcnn branch, and stages that train layer by layer (any depth / widths: two all-reduces per layer forward --
+ *   the sum, then the squared differences from the global mean -- and one backward).  0: every rank normalises with its own shard's
+ *   statistics ("local BN").
  * "global_loss" (0/1, default 0): the loss and its gradient over the global batch -- the [B, B] broadcast terms (models/tp8.py:279,327)
  *   and the whole-batch tf.cond (:288) couple all samples: end points and labels are all-gathered, every rank evaluates the same
  *   global loss and keeps its rows of the gradient; the gradient all-reduce then sums instead of averaging.  With "sync_bn" a

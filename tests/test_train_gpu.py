@@ -854,6 +854,50 @@ def test_sync_bn_with_identical_virtual_ranks_reproduces_local_step(gpu_required
     print(backbone, "bf16" if bf16 else "fp32", "sync_bn (2 identical virtual ranks) vs local step: worst relative gradient difference %.2e, cosine %.7f" % (worst, cos))
 
 
+@pytest.mark.parametrize("backbone,tail", [("pointnet", 1), ("pointnet", 0), ("dgcnn", 1)])
+def test_sync_bn_general_depth_with_identical_virtual_ranks(gpu_required, backbone, tail):
+    """The same check for stages that train layer by layer (kernels_train_generic.h: any depth / widths, the reference's own
+    configs/default.json has five conv layers per backbone): gen_stat_finish forms this rank's sum, the all ranks' mean, this rank's
+    squared differences from THAT mean and the statistics with the global count in three launches around two all-reduces,
+    gen_bn_bwd_finish the backward coefficients from all ranks' (dbeta, dgamma).  PointNet: a hybrid stage (48, 96, 160), a five-layer
+    stage with a fused tail and a stage no fused kernel fits (40, 72, 104); with train_fused_tail off every stage runs layer by layer.
+    dgcnn: three edge convs, an odd width, a single edge conv."""
+    N, B = 128, 6
+    if backbone == "dgcnn":
+        w = dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160))
+    else:
+        w = dict(s1=(48, 96, 160), s2=(32, 32, 32, 64, 128), emb=(40, 72, 104))
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), backbone=backbone, **w)
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=5)
+    d = R.synth_pairs(B, N, seed=5, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    us = [rng.uniform(size=(B, 32)).astype(np.float32) for _ in range(5)]
+    out = {}
+    for mode in (0, 1):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("train_fused_tail", tail)
+        if mode:
+            eng.set_option("sync_bn", 1)
+            eng.set_option("sync_bn_emulate_world", 2)
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+        assert eng.get_option("last_train_kernel") & 8
+        out[mode] = (res, {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)},
+                     {k: eng.get_variable(k) for k, _, tr in eng.variables() if not tr})
+        eng.close()
+    (r0, g0, e0), (r1, g1, e1) = out[0], out[1]
+    assert abs(r0["loss"] - r1["loss"]) <= 1e-6 * max(1.0, abs(r0["loss"]))
+    for k in ("pred_translations", "pred_remaining_angle_logits", "pred_s2_pc1centers", "pred_pc2angle_logits"):
+        np.testing.assert_allclose(r1[k], r0[k], rtol=1e-6, atol=1e-6, err_msg=k)
+    for k in e0:
+        np.testing.assert_allclose(e1[k], e0[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    gs = max(float(np.abs(v).max()) for v in g0.values())
+    for n in g0:
+        err = float(np.abs(g1[n] - g0[n]).max())
+        assert err <= 1e-6 * float(np.abs(g0[n]).max()) + 1e-8 * gs, (n, err, float(np.abs(g0[n]).max()))
+
+
 @pytest.mark.parametrize("backbone,bf16", [("pointnet", 0), ("pointnet", 1), ("dgcnn", 0)])
 def test_global_loss_with_identical_virtual_ranks(gpu_required, backbone, bf16):
     """Option "global_loss" (with "sync_bn"): end points and labels are all-gathered and the reference's loss -- whose [B, B] broadcast
