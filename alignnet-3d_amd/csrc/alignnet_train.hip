@@ -613,7 +613,8 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -902,7 +903,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2))) return 1;
     } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-    if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64"))   // 128-point tiles (kernels_train_fwd_wide.h)
+      hipLaunchKernelGGL(train_fwd_phase3_wide<true>, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);
@@ -963,7 +966,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     // shipped widths: 128-point tiles (a weight fragment of the lift feeds four row tiles; kernels_train_fwd_wide.h)
-    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64")) hipLaunchKernelGGL(train_fwd_phase3_wide, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64")) hipLaunchKernelGGL(train_fwd_phase3_wide<false>, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
     else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }

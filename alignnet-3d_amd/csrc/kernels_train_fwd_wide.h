@@ -49,6 +49,9 @@ __device__ __forceinline__ void argmax_step(float v, float& e, int& eo, int& cnt
 }
 
 // fp32: exact fp32 MFMA, hand-issued weight stream (mfma_rows<4>: the inference kernel's inner loop)
+// GIVEN: the tile of hidden features is read from h2_store (the DGCNN branch's pooled edge features p = max_k h2, kernels_train_dgcnn.h)
+// instead of being recomputed from xyz; column sums and the store belong to the producer (as train_fwd_phase23<3, false, true>).
+template <bool GIVEN = false>
 __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -63,10 +66,11 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   const int CT3 = (a.C3 + 31) >> 5;
   const int ntiles = (a.N + kWT - 1) / kWT;
 
-  const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
+  Layer1W l1w = {};
+  if (!GIVEN) l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
   // layer-2 item of this wave: channel tile wave >> 1, 64-row group wave & 1 (a weight fragment feeds two row tiles)
   const int ct2 = wave >> 1, rg2 = wave & 1, col2 = ct2 * 32 + (lane & 31);
-  const float sc2 = a.sc2[tower * C2 + col2], sh2 = a.sh2[tower * C2 + col2];
+  const float sc2 = GIVEN ? 0.f : a.sc2[tower * C2 + col2], sh2 = GIVEN ? 0.f : a.sh2[tower * C2 + col2];
   double cs2 = 0.0;                       // column sum of h2: this lane's rows of column col2, whole cloud
   // running extreme of sgn * (z3 - bias) and its point, per (channel tile slot, lane): registers for the whole cloud
   float be[kWSlots], sg[kWSlots];
@@ -86,10 +90,21 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       nx = q[0]; ny = q[1]; nz = q[2];
     }
   };
-  request_xyz(0);
+  if (!GIVEN) request_xyz(0);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kWT, a.N - tile * kWT);
     if (tile) __syncthreads();            // the previous tile's readers are done with xs / h1 / h2
+    if (GIVEN) {
+      // rows past the cloud's end repeat its last row (they tie with it in the max; the index is clamped when it is written)
+      const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kWT) * C2;
+      constexpr int c4 = C2 / 4;
+#pragma unroll
+      for (int j = 0; j < kWT * c4 / (kWW * 64); ++j) {
+        const int i = tid + j * kWW * 64, row = i / c4, q = i % c4;
+        *reinterpret_cast<f32x4*>(smem + off1 + row * ld1 + q * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)min(row, nvalid - 1) * C2 + q * 4);
+      }
+      __syncthreads();
+    } else {
     if (tid < kWT) {
       const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
       xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
@@ -132,6 +147,8 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       }
     }
 
+    }   // !GIVEN
+
     // ---- layer 3: z3 = h2 W3 + b3: extreme of sgn * (z3 - b3) over the cloud's points (statistics: stat3_pool_finish_kernel) ----
     // (not unrolled: with the four channel tiles unrolled hipcc keeps the A fragments -- the same LDS reads for every channel tile -- live
     //  across them and spills; the slot's running extreme is selected in and out of its register by compares against the loop counter)
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       const int col = (wave + q * kWW) * 32 + (lane & 31);
       if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
     }
-    a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+    if (!GIVEN) a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
   }
 }
 

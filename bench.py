@@ -110,7 +110,7 @@ def kernel_macs(cfg, kernel, bf16):
 
 
 KERNEL_IN_PROFILE = {   # bench kernel key -> substring of the kernel name in profiles/*_pmc_by_kernel.json
-    "train_fwd_phase3": "train_fwd_phase23<3", "train_fwd_phase2": "train_fwd_gram1|train_fwd_phase23<2", "train_gram_h2": "gram_h2_kernel", "train_bwd_b2": "train_bwd_b2",
+    "train_fwd_phase3": "train_fwd_phase3_wide|train_fwd_phase23<3", "train_fwd_phase2": "train_fwd_gram1|train_fwd_phase23<2", "train_gram_h2": "gram_h2_kernel", "train_bwd_b2": "train_bwd_b2",
     "train_bwd_b1": "train_bwd_b1", "dg_train_fwd": "dg_train_fwd", "dg_train_bwd_edge": "dg_train_bwd_edge", "knn": "knn_kernel"}
 
 

@@ -554,7 +554,8 @@ def test_training_step_is_bitwise_reproducible(gpu_required, backbone, bf16, wid
 
 
 @pytest.mark.parametrize("N,B,bf16", [(200, 16, 0), (384, 12, 0), (96, 16, 0), (136, 16, 0), (200, 8, 0), (264, 16, 0), (72, 16, 0), (201, 12, 0), (135, 10, 0),
-                                      (200, 16, 1), (384, 12, 1), (96, 16, 1), (264, 16, 1), (135, 10, 1)])
+                                      (200, 16, 1), (384, 12, 1), (96, 16, 1), (264, 16, 1), (135, 10, 1),
+                                      (200, 8, -1), (136, 6, -1), (96, 8, -1)])
 def test_phase3_tile_shapes_agree(gpu_required, N, B, bf16):
     """The forward's phase 3 on 128-point tiles (default for the shipped widths 64 / 128: kernels_train_fwd_wide.h) against the same
     phase on 64-point tiles (option train_phase3_tile64): the MFMA k-order is the same, so the lift's values -- hence the pooled
@@ -563,8 +564,13 @@ def test_phase3_tile_shapes_agree(gpu_required, N, B, bf16):
     N = 200: partial last tile in both shapes (72 / 8 rows); N = 96: a cloud smaller than one wide tile.
     bf16 = 1 (train_matmul_bf16): the pipelined kernel train_fwd_phase3_wide_bf16 against train_fwd_phase23<3, true, false, 64, 128>; the
     rounded h2 and the lift are bit-identical again, but a 1e-7 difference in a later stage's input can fall on the other side of a bf16
-    rounding boundary (4e-3 of that element), so the bounds are those of two bf16 runs, not of two fp32 runs."""
-    cfg, spec, P32, d, du = _setup(N, B, std=True)
+    rounding boundary (4e-3 of that element), so the bounds are those of two bf16 runs, not of two fp32 runs.
+    bf16 = -1: the dgcnn backbone in fp32, whose point conv runs the same phase on the stored pooled edge features
+    (train_fwd_phase3_wide<true> against train_fwd_phase23<3, false, true, 64, 128>): nothing but the arg-max among copies of a
+    cloud's last row can differ."""
+    dg = bf16 < 0
+    bf16 = max(bf16, 0)
+    cfg, spec, P32, d, du = _setup_dgcnn(N, B, std=True) if dg else _setup(N, B, std=True)
     ul = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     out = []
     for t64 in (0, 1):

@@ -98,7 +98,7 @@ for tag, name, lab in (("train", "%s_bench_train_f32.json", "training step, fp32
         txt += "; %.0f launches/step, %.0f of them under 50 µs = %.2f ms/step" % (tot, small, small_us / 1e3)
     add(lab, txt, "`profiles/%s`, `profiles/%s_%s_kernel_stats.csv`" % (name % R, R, tag))
     pm = pmc(tag)
-    for sub in ("train_fwd_phase23<3", "train_bwd_b2", "train_bwd_b1"):
+    for sub in ("train_fwd_phase3_wide", "train_fwd_phase23<3", "train_bwd_b2", "train_bwd_b1"):
         k, v = find(pm, sub)
         if v:
             x = ratios(v)
