@@ -613,8 +613,10 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_bwd_b1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase3_wide_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<2, true, false, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_fwd_phase23<3, false, true, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -805,6 +807,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  // fp32 phase 3 of the shipped widths: 128-point tiles (kernels_train_fwd_wide.h), with the Gram of the hidden features accumulated in the same pass
+  const bool wide = std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64");
+  const bool wide_gram = wide && !getenv("ALIGNNET_P3_NOGRAM");
   const bool sync = sync_on(h);
   const double W = sync ? (double)sync_world(h) : 1.0;   // sync_bn: batch counts are the global batch's
   // global_part: the partials are already sums over all ranks (statistics derived from all-reduced Gram / column sums)
@@ -903,12 +908,47 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2))) return 1;
     } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64"))   // 128-point tiles (kernels_train_fwd_wide.h)
-      hipLaunchKernelGGL(train_fwd_phase3_wide<true>, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    if (wide_gram) hipLaunchKernelGGL((train_fwd_phase3_wide<true, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    else if (wide) hipLaunchKernelGGL((train_fwd_phase3_wide<true, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
     else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
-    { ProfScope prof_scope(h, PK_TRAIN_GRAM);
+    if (wide_gram && getenv("ALIGNNET_P3_EXTCHECK")) {   // debug: ext / idx of the GRAM variant against the plain one
+      std::vector<float> ea((size_t)2 * B * 2 * C3), eb(ea.size());
+      std::vector<int> ia(ea.size()), ib(ea.size());
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(ea.data(), S.ext, ea.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(ia.data(), S.idx2, ia.size() * 4, hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL((train_fwd_phase3_wide<true, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(eb.data(), S.ext, eb.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(ib.data(), S.idx2, ib.size() * 4, hipMemcpyDeviceToHost);
+      size_t nde = 0, ndi = 0, first = (size_t)-1;
+      for (size_t i = 0; i < ea.size(); ++i) { if (ea[i] != eb[i]) { ++nde; if (first == (size_t)-1) first = i; } if (ia[i] != ib[i]) ++ndi; }
+      std::fprintf(stderr, "EXTCHECK stage %d: %zu of %zu ext differ, %zu idx differ; first at %zu (cloud %zu half %zu col %zu): %g vs %g\n", s, nde, ea.size(), ndi, first,
+                   first == (size_t)-1 ? 0 : first / (2 * C3), first == (size_t)-1 ? 0 : (first / C3) & 1, first == (size_t)-1 ? 0 : first % C3,
+                   first == (size_t)-1 ? 0.f : ea[first], first == (size_t)-1 ? 0.f : eb[first]);
+    }
+    if (wide_gram && getenv("ALIGNNET_P3_GRAMCHECK")) {   // debug: the in-kernel Gram against gram_h2_kernel's, block by block
+      std::vector<float> ga((size_t)2 * B * C2 * C2), gb(ga.size());
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(ga.data(), w->gram_part, ga.size() * 4, hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL(gram_h2_kernel<128>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(gb.data(), w->gram_part, gb.size() * 4, hipMemcpyDeviceToHost);
+      for (int it = 0; it < 4; ++it)
+        for (int jt = it; jt < 4; ++jt) {
+          double worst = 0, mag = 0; int wc = -1;
+          for (int c = 0; c < 2 * B; ++c)
+            for (int i = 0; i < 32; ++i)
+              for (int j = 0; j < 32; ++j) {
+                const size_t o = (size_t)c * C2 * C2 + (size_t)(it * 32 + i) * C2 + jt * 32 + j;
+                const double e = std::fabs((double)ga[o] - gb[o]);
+                if (e > worst) { worst = e; wc = c; }
+                mag = std::max(mag, (double)std::fabs(gb[o]));
+              }
+          std::fprintf(stderr, "GRAMCHECK stage %d block (%d,%d): worst abs diff %.3e at cloud %d (max |G| %.3e)\n", s, it, jt, worst, wc, mag);
+        }
+    }
+    if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
     if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;
@@ -966,12 +1006,13 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     // shipped widths: 128-point tiles (a weight fragment of the lift feeds four row tiles; kernels_train_fwd_wide.h)
-    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64")) hipLaunchKernelGGL(train_fwd_phase3_wide<false>, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    if (wide_gram) hipLaunchKernelGGL((train_fwd_phase3_wide<false, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
+    else if (wide) hipLaunchKernelGGL((train_fwd_phase3_wide<false, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
     else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
     { ProfScope prof_scope(h, PK_TRAIN_GRAM);
-    if (!a.gram_inline)
+    if (!a.gram_inline && !wide_gram)
       hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
                          w->gram_part);
     }

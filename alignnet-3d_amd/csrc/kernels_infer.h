@@ -163,6 +163,11 @@ __device__ __forceinline__ f32x4 wload_issue(const f32x4* p)
 }
 __device__ __forceinline__ void wload_wait2(f32x4& v) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(v)::"memory"); }
 __device__ __forceinline__ void wload_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same wait, naming the three stream registers as read-write operands: look-ahead loads into them may still be in flight when the loop
+// ends, and only a (formal) use at the wait keeps the allocator from handing one of them to a new value BEFORE it -- an ordinary v_mov is not
+// ordered against an asm volatile statement.  (Seen in train_fwd_phase3_wide<true, true>: `v_mov_b32 v142, 0` -- the arg-max counter -- was
+// scheduled in front of the drain while `global_load_dwordx4 v[142:145]` was still outstanding, and the counter became a weight.)
+__device__ __forceinline__ void wload_drain(f32x4& b0, f32x4& b1, f32x4& b2) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2)::"memory"); }
 
 template <int MR>
 __device__ __forceinline__ void mfma_kgroup(const f32x4 (&av)[MR], const f32x4& bv, f32x16 (&acc)[MR])
@@ -256,7 +261,7 @@ __device__ __forceinline__ void mfma_rows(const float* __restrict__ A, int lda, 
     for (int m = 0; m < MR; ++m) a0[m] = a1[m];
   }
   KSTAMP();
-  wload_drain();   // look-ahead loads still in flight: retire them before the registers are reused
+  wload_drain(b0, b1, b2);   // look-ahead loads still in flight: retire them before the registers are reused
   KSTAMP();
 }
 

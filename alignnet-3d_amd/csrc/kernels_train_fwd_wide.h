@@ -41,7 +41,10 @@ __device__ __forceinline__ void layer1_wide(const float* __restrict__ xs, const 
 // select form of train_fwd_phase23<3>); cnt counts the calls
 __device__ __forceinline__ void argmax_step(float v, float& e, int& eo, int& cnt)
 {
+  // (gfx940 / gfx950: two wait states between a VALU write of VCC and a VALU read of it -- hipcc inserts them for its own instructions, not
+  //  inside an asm block; without the s_nop the selects can read the PREVIOUS compare's mask)
   asm volatile("v_cmp_gt_f32 vcc, %3, %0\n\t"
+               "s_nop 1\n\t"
                "v_cndmask_b32 %0, %0, %3, vcc\n\t"
                "v_cndmask_b32 %1, %1, %2, vcc\n\t"
                "v_add_u32 %2, 1, %2"
@@ -51,7 +54,11 @@ __device__ __forceinline__ void argmax_step(float v, float& e, int& eo, int& cnt
 // fp32: exact fp32 MFMA, hand-issued weight stream (mfma_rows<4>: the inference kernel's inner loop)
 // GIVEN: the tile of hidden features is read from h2_store (the DGCNN branch's pooled edge features p = max_k h2, kernels_train_dgcnn.h)
 // instead of being recomputed from xyz; column sums and the store belong to the producer (as train_fwd_phase23<3, false, true>).
-template <bool GIVEN = false>
+// GRAM: the Gram matrix h2^T h2 (upper 32 x 32 blocks, what gram_h2_kernel produces from the stored h2 in a pass of its own: 268 MB read per
+// launch) is accumulated here from the LDS tile, register-resident for the whole cloud.  Ten blocks on eight waves, balanced: wave w owns
+// block w over all rows and a quarter of the rows of block 8 (waves 0-3) or 9 (waves 4-7) -- 80 MFMAs per wave and tile next to the lift's
+// 1024; the four quarters meet in LDS after the last tile (fixed order: deterministic).
+template <bool GIVEN = false, bool GRAM = false>
 __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const TrainFwdArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,13 +80,23 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   const float sc2 = GIVEN ? 0.f : a.sc2[tower * C2 + col2], sh2 = GIVEN ? 0.f : a.sh2[tower * C2 + col2];
   double cs2 = 0.0;                       // column sum of h2: this lane's rows of column col2, whole cloud
   // running extreme of sgn * (z3 - bias) and its point, per (channel tile slot, lane): registers for the whole cloud
-  float be[kWSlots], sg[kWSlots];
+  float be[kWSlots];
   int bi[kWSlots];
 #pragma unroll
-  for (int q = 0; q < kWSlots; ++q) {
-    const int col = (wave + q * kWW) * 32 + (lane & 31);
-    be[q] = -INFINITY; bi[q] = 0;
-    sg[q] = col < a.C3 ? a.sgn3[tower * a.C3 + col] : 1.f;
+  for (int q = 0; q < kWSlots; ++q) { be[q] = -INFINITY; bi[q] = 0; }
+
+  // Gram blocks in the order (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+  f32x16 gacc[GRAM ? 2 : 1];
+  int git = 0, gjt = 0;
+  const int git1 = wave < 4 ? 2 : 3, gq = wave & 3;   // second unit: rows 32 gq .. 32 gq + 31 of block (2,3) / (3,3)
+  if (GRAM) {
+    int rem = wave;
+    while (rem >= 4 - git) { rem -= 4 - git; ++git; }
+    gjt = git + rem;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gacc[q][r] = 0.f;
   }
 
   // the tile's raw points are requested one tile ahead (threads 0 .. 127)
@@ -139,15 +156,40 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     if (!(a.dbg & 2)) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kWT) * C2;
       constexpr int c4 = C2 / 4;
+      // (the thread's eight row / column offsets are tile-invariant: hoisted out of the tile loop they are 16 address registers held -- or
+      //  spilled -- across the lift; laundering tid makes them a few integer operations per tile instead)
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
 #pragma unroll
       for (int j = 0; j < kWT * c4 / (kWW * 64); ++j) {
-        const int i = tid + j * kWW * 64, row = i / c4, q = i % c4;
+        const int i = tl + j * kWW * 64, row = i / c4, q = i % c4;
         if (row < nvalid)
           *reinterpret_cast<f32x4*>(dst + (size_t)row * C2 + q * 4) = *reinterpret_cast<const f32x4*>(smem + off1 + row * ld1 + q * 4);
       }
     }
 
     }   // !GIVEN
+
+    if (GRAM) {
+      const float* hb = smem + off1 + half * ld1 + (lane & 31);
+      const float* pa0 = hb + git * 32;
+      const float* pb0 = hb + gjt * 32;
+      const float* pa1 = hb + git1 * 32 + gq * 32 * ld1;
+      const float* pb1 = hb + 3 * 32 + gq * 32 * ld1;
+      if (nvalid == kWT) {
+#pragma unroll 8
+        for (int r = 0; r < kWT; r += 2) gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0[r * ld1], pb0[r * ld1], gacc[0], 0, 0, 0);
+#pragma unroll 8
+        for (int r = 0; r < 32; r += 2) gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1[r * ld1], pb1[r * ld1], gacc[1], 0, 0, 0);
+      } else {   // rows past the cloud's end hold copies of its last point (for the max): not part of the batch
+#pragma unroll 8
+        for (int r = 0; r < kWT; r += 2)
+          gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r + half < nvalid ? pa0[r * ld1] : 0.f, pb0[r * ld1], gacc[0], 0, 0, 0);
+#pragma unroll 8
+        for (int r = 0; r < 32; r += 2)
+          gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gq * 32 + r + half < nvalid ? pa1[r * ld1] : 0.f, pb1[r * ld1], gacc[1], 0, 0, 0);
+      }
+    }
 
     // ---- layer 3: z3 = h2 W3 + b3: extreme of sgn * (z3 - b3) over the cloud's points (statistics: stat3_pool_finish_kernel) ----
     // (not unrolled: with the four channel tiles unrolled hipcc keeps the A fragments -- the same LDS reads for every channel tile -- live
@@ -156,10 +198,12 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     for (int q = 0; q < kWSlots; ++q) {
       const int ct = wave + q * kWW;
       if (ct >= CT3) break;
-      float e = be[0], s = sg[0]; int ei = bi[0];
+      float e = be[0]; int ei = bi[0];
 #pragma unroll
       for (int u = 1; u < kWSlots; ++u)
-        if (u == q) { e = be[u]; ei = bi[u]; s = sg[u]; }
+        if (u == q) { e = be[u]; ei = bi[u]; }
+      // sign(gamma3) of the lane's column: requested in front of the MFMA loop (older than the weight stream: its first counted wait covers it)
+      const float s = ct * 32 + (lane & 31) < a.C3 ? a.sgn3[tower * a.C3 + ct * 32 + (lane & 31)] : 1.f;
       asm volatile("" ::: "memory");
       f32x16 acc[4];
       mfma_rows<4, true, true>(smem + off1, ld1, reinterpret_cast<const f32x4*>(a.wp3) + (size_t)ct * KG3 * 64,
@@ -190,6 +234,24 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
     }
     if (!GIVEN) a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+  }
+  if (GRAM) {
+    float* my_gram = a.gram_part + (size_t)cloud * C2 * C2;
+    const float zero[16] = {};
+    tile_commit(my_gram, C2, git, gjt, C2, C2, gacc[0], lane, zero);
+    __syncthreads();                       // every wave is done with the last tile's LDS reads
+    float* q4 = smem + off1;               // [8 waves][16][64]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q4[(wave * 16 + r) * 64 + lane] = gacc[1][r];
+    __syncthreads();
+    if (wave == 0 || wave == 4) {
+      f32x16 tot;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tot[r] = ((q4[((wave + 0) * 16 + r) * 64 + lane] + q4[((wave + 1) * 16 + r) * 64 + lane]) + q4[((wave + 2) * 16 + r) * 64 + lane]) +
+                 q4[((wave + 3) * 16 + r) * 64 + lane];
+      tile_commit(my_gram, C2, git1, 3, C2, C2, tot, lane, zero);
+    }
   }
 }
 

@@ -93,7 +93,9 @@ def kernel_macs(cfg, kernel, bf16):
     tot = 0
     for (c1, c2, c3) in [w[:3] for w in stage_widths(cfg)]:
         if kernel == "train_fwd_phase3":       # h1, h2 recomputed from xyz, z3 = h2 W3 (+ the Gram of h2 inside the bf16 kernel)
-            tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if bf16 else 0)
+            # (+ the Gram of h2: inside the bf16 kernels, and inside the fp32 128-point kernel of the shipped widths -- csrc/kernels_train_fwd_wide.h)
+            fused_gram = bf16 or ((c1, c2) == (64, 128) and not os.environ.get("ALIGNNET_P3_TILE64") and not os.environ.get("ALIGNNET_P3_NOGRAM"))
+            tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if fused_gram else 0)
         elif kernel == "train_fwd_phase2":     # fp32: h1 + Gram(h1) (statistics of z2 from the Gram); bf16: h1 + z2 = h1 W2
             tot += n * (k0 * c1 + (c1 * c2 if bf16 else _blocks(c1)))
         elif kernel == "train_gram_h2":
@@ -375,7 +377,7 @@ def main():
              "frac": None if ach is None else round(ach / peak, 4),
              # HBM bytes of this kernel from the committed PMC passes ((2 FETCH_SIZE + WRITE_SIZE) KiB), per launch like `achieved`'s work
              "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_per_step": None if tr is None else tr["bytes_per_step"],
-             "kernel": prof_name, "launches_per_step": launches / steps, "kernel_ms_per_step": round(ms_step, 4),
+             "kernel": prof_name.split("|")[0], "launches_per_step": launches / steps, "kernel_ms_per_step": round(ms_step, 4),
              "avg_launch_us": round(ms / max(launches, 1) * 1e3, 2), "algorithmic_flops_per_step": flops,
              "step_share": {k: round(v[0] / steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
         if tr is not None:

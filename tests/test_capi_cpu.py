@@ -112,6 +112,6 @@ def test_wide_phase3_kernels_are_spill_free():
     rows = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)",
                       open(path).read(), re.S)
     wide = [(n, int(v), int(sc), int(o), int(sp)) for n, v, sc, o, sp in rows if "train_fwd_phase3_wide" in n]
-    assert len(wide) == 3, wide
+    assert len(wide) == 5, wide
     for name, vgpr, scratch, occ, spill in wide:
         assert spill == 0 and scratch == 0 and occ >= 2, (name, vgpr, scratch, occ, spill)
