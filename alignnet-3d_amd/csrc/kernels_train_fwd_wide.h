@@ -37,18 +37,18 @@ __device__ __forceinline__ void layer1_wide(const float* __restrict__ xs, const 
   }
 }
 
-// e = max(e, v) with the ordinal of the winning element: strictly greater wins, so the first of equal values is kept (as the compare /
-// select form of train_fwd_phase23<3>); cnt counts the calls
-__device__ __forceinline__ void argmax_step(float v, float& e, int& eo, int& cnt)
+// One step of the running arg-max, e = max(e, v) with eo = 1 + the ordinal of the winning element (0: none yet); strictly greater wins, so
+// the first of equal values is kept (as the compare / select form of train_fwd_phase23<3>).  gfx940 / gfx950 need two wait states between
+// a VALU write of VCC and a VALU read of it; hipcc inserts them for its own instructions, not inside an asm block (without them the selects
+// can read the PREVIOUS compare's mask).  The two slots are filled with work: the next element's product vn = an * s and the counter.
+__device__ __forceinline__ void argmax_step(float v, float& e, int& eo, int& cnt, float an, float s, float& vn)
 {
-  // (gfx940 / gfx950: two wait states between a VALU write of VCC and a VALU read of it -- hipcc inserts them for its own instructions, not
-  //  inside an asm block; without the s_nop the selects can read the PREVIOUS compare's mask)
-  asm volatile("v_cmp_gt_f32 vcc, %3, %0\n\t"
-               "s_nop 1\n\t"
-               "v_cndmask_b32 %0, %0, %3, vcc\n\t"
-               "v_cndmask_b32 %1, %1, %2, vcc\n\t"
-               "v_add_u32 %2, 1, %2"
-               : "+v"(e), "+v"(eo), "+v"(cnt) : "v"(v) : "vcc");
+  asm volatile("v_cmp_gt_f32 vcc, %4, %0\n\t"
+               "v_mul_f32 %3, %5, %6\n\t"
+               "v_add_u32 %2, 1, %2\n\t"
+               "v_cndmask_b32 %0, %0, %4, vcc\n\t"
+               "v_cndmask_b32 %1, %1, %2, vcc"
+               : "+v"(e), "+v"(eo), "+v"(cnt), "=&v"(vn) : "v"(v), "v"(an), "v"(s) : "vcc");
 }
 
 // fp32: exact fp32 MFMA, hand-issued weight stream (mfma_rows<4>: the inference kernel's inner loop)
@@ -212,11 +212,14 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       // running extreme + its accumulator ordinal (16 m + r).  Spelled in asm with a counter register: written as
       // `if (v > e) { e = v; ei = <row constant>; }` hipcc materialises the 64 row constants in VGPRs, hoists them out of the tile loop
       // and the kernel needs 120 registers more (167 spills).  The ordinal is turned into the point index when the slot is written back.
-      int cnt = 0, eo = -1;
+      int cnt = 0, eo = 0;
+      float v = acc[0][0] * s, vn;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) argmax_step(acc[m][r] * s, e, eo, cnt);
+      for (int i = 0; i < 64; ++i) {
+        argmax_step(v, e, eo, cnt, acc[(i + 1 < 64 ? i + 1 : i) >> 4][(i + 1 < 64 ? i + 1 : i) & 15], s, vn);
+        v = vn;
+      }
+      --eo;
       // (rows past the cloud's end -- last tile of a cloud whose size is not a multiple of 128 -- are copies of the last point: they tie
       //  with it, a lane keeps the first of equal values = the lower row, and the index is clamped to N - 1 when it is written)
       if (eo >= 0) ei = tile * kWT + (eo >> 4) * 32 + (eo & 3) + 8 * ((eo & 15) >> 2) + 4 * half;
