@@ -4,9 +4,14 @@
 // Why a second tile shape: with 64-point tiles (train_fwd_phase23<3, ...>) a weight fragment of the 128 -> C3 lift feeds two
 // 32-row MFMA tiles, with 128-point tiles four -- half the L2 -> CU weight stream per FLOP.  The inference kernel measured exactly
 // this trade (0.76 of the fp32-MFMA roofline with two row tiles per fragment, 0.85 with four), and the 64-point
-// training kernel sat at 0.725.  One workgroup of eight waves per cloud (two per SIMD, 104 KiB of LDS: one workgroup per CU);
-// same outputs, same layouts as train_fwd_phase23<3> (ext / idx per lane half, column sums of h2 in four slices, h2 stored
-// row-major), so everything downstream is unchanged.
+// training kernel sat at 0.725.  One workgroup of eight waves per cloud (two per SIMD, one workgroup per CU); same outputs, same
+// layouts as train_fwd_phase23<3> (ext / idx per lane half, column sums of h2 in four slices, h2 stored row-major, upper Gram
+// blocks per cloud), so everything downstream is unchanged.
+//   train_fwd_phase3_wide<GIVEN, GRAM>   fp32: hand-issued weight stream, running arg-max in registers, optionally on given features
+//                                        (dgcnn / hybrid point conv) and with the Gram of the features in the same pass
+//   train_fwd_phase3_wide_bf16           bf16 operands: the next tile's prologue software-pipelined around the current tile's lift
+// Option "train_phase3_tile64" (or ALIGNNET_P3_TILE64=1) switches back to the 64-point kernels; tests/test_train_gpu.py::
+// test_phase3_tile_shapes_agree compares the two (bf16: bit-identical gradients).
 #pragma once
 #include "kernels_train_fwd.h"
 
