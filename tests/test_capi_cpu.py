@@ -115,3 +115,27 @@ def test_wide_phase3_kernels_are_spill_free():
     assert len(wide) == 5, wide
     for name, vgpr, scratch, occ, spill in wide:
         assert spill == 0 and scratch == 0 and occ >= 2, (name, vgpr, scratch, occ, spill)
+
+
+def test_no_register_is_rewritten_while_a_load_into_it_is_in_flight():
+    """The hand-issued weight stream of csrc/kernels_infer.h (mfma_rows: asm `global_load_dwordx4` retired by counted asm waits) is invisible to
+    the compiler's wait bookkeeping, so only the source's data flow keeps the allocator from giving a stream register to a new value before the
+    wait.  Round 3 found `v_mov_b32 v142, 0` in front of the final drain while `global_load_dwordx4 v[142:145]` was outstanding (nothing spilled:
+    the spill-free assertions above did not see it); the drain now names the stream registers.  tools/inflight_scan.py walks the disassembly of
+    the built code objects: every vector load is followed through straight-line code up to the wait that retires it, and no instruction in
+    between may write its destination."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import inflight_scan as S
+    # the scanner itself, on the instruction sequence that was the bug and on its fixed form
+    bug = "0000000000001000 <k>:\n\tglobal_load_dwordx4 v[142:145], v[186:187], off\n\ts_waitcnt vmcnt(2)\n\tv_mov_b32_e32 v142, 0\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n"
+    ok = "0000000000001000 <k>:\n\tglobal_load_dwordx4 v[142:145], v[186:187], off\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v142, 0\n\ts_endpgm\n"
+    assert len(S.scan(bug)[2]) == 1 and len(S.scan(ok)[2]) == 0
+    objdump = os.path.join(S.LLVM, "llvm-objdump")
+    objs = [os.path.join(ROOT, "alignnet-3d_amd", "csrc", n) for n in ("alignnet_api.o", "alignnet_train.o")]
+    if not os.path.exists(objdump) or not all(os.path.exists(o) for o in objs):
+        pytest.skip("no llvm-objdump / no objects next to the sources")
+    for o in objs:
+        nfun, nload, findings = S.scan(S.disassemble(o))
+        assert nfun > 10 and nload > 100, (o, nfun, nload)
+        assert not findings, findings[:5]
