@@ -11,7 +11,8 @@
 //                                        (dgcnn / hybrid point conv) and with the Gram of the features in the same pass
 //   train_fwd_phase3_wide_bf16           bf16 operands: the next tile's prologue software-pipelined around the current tile's lift
 // Option "train_phase3_tile64" (or ALIGNNET_P3_TILE64=1) switches back to the 64-point kernels; tests/test_train_gpu.py::
-// test_phase3_tile_shapes_agree compares the two (bf16: bit-identical gradients).
+// test_phase3_tile_shapes_agree compares the two (bf16: bit-identical gradients in the test's shapes; over random shapes about one case in three,
+// the others differ by a value pushed over a bf16 rounding boundary downstream of the regrouped column sums: tools/stress_tile_shapes.py).
 #pragma once
 #include "kernels_train_fwd.h"
 
