@@ -113,10 +113,26 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       nx = q[0]; ny = q[1]; nz = q[2];
     }
   };
-  if (!GIVEN) request_xyz(0);
+  auto store_xs = [&]() {
+    if (tid < kWT) {
+      const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
+      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+    }
+  };
+  // The K = 3 lift of tile t + 1 runs INSIDE the lift of tile t (behind the wave's first channel tile): h1's buffer is free once the hidden
+  // layer of tile t is done, so the points -> barrier -> lift -> barrier chain no longer sits in front of every tile's first MFMA.
+  if (!GIVEN) {
+    request_xyz(0);
+    store_xs();
+    if (ntiles > 1) request_xyz(1);
+    __syncthreads();
+    layer1_wide(xs, l1w, smem + off0, tid);
+  }
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kWT, a.N - tile * kWT);
-    if (tile) __syncthreads();            // the previous tile's readers are done with xs / h1 / h2
+    __syncthreads();            // h1 of this tile is complete; the previous tile's readers are done with h2
     if (GIVEN) {
       // rows past the cloud's end repeat its last row (they tie with it in the max; the index is clamped when it is written)
       const float* src = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kWT) * C2;
@@ -128,17 +144,6 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       }
       __syncthreads();
     } else {
-    if (tid < kWT) {
-      const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
-      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
-    }
-    if (tile + 1 < ntiles) request_xyz(tile + 1);
-    __syncthreads();
-    layer1_wide(xs, l1w, smem + off0, tid);
-    __syncthreads();
-
     // ---- layer 2: h2 = relu(bn2(h1 W2 + b2)) -> LDS, column sums ----
     {
       f32x16 acc[2];
@@ -157,6 +162,10 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
       cs2 += (double)lsum;
     }
     __syncthreads();
+    if (tile + 1 < ntiles) {   // (xs: last read by this tile's lift, a tile ago)
+      store_xs();
+      if (tile + 2 < ntiles) request_xyz(tile + 2);
+    }
 
     // ---- keep h2 for the Gram and the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
     if (!(a.dbg & 2)) {
@@ -202,8 +211,12 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     //  across them and spills; the slot's running extreme is selected in and out of its register by compares against the loop counter)
 #pragma unroll 1
     for (int q = 0; q < kWSlots; ++q) {
+      if (!GIVEN && q == 1 && tile + 1 < ntiles) {   // every wave, whatever its number of channel tiles
+        __syncthreads();
+        layer1_wide(xs, l1w, smem + off0, tid);
+      }
       const int ct = wave + q * kWW;
-      if (ct >= CT3) break;
+      if (ct >= CT3) continue;
       float e = be[0]; int ei = bi[0];
 #pragma unroll
       for (int u = 1; u < kWSlots; ++u)
