@@ -856,6 +856,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (finish(0, C1, 1, ecount)) return 1;
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
+    d.dbg = a.dbg;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
   { ProfScope prof_scope(h, PK_DG_FWD);
     if (h->train_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_fwd<64, true>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);

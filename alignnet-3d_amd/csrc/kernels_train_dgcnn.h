@@ -46,6 +46,7 @@ struct DgTrainArgs {
   double* colsum_part;            // [2B][2 halves][C2]   column sums of p
   double* s1_part;                // [2B][1024 / C1][C1]  column sums of h1 over all (point, slot) rows, per row group
   long long* stamps;              // debug (ALIGNNET_DBG & 32): cycle stamps of thread 0 / block 0, iteration 25
+  int dbg = 0;                    // ablation (timing only): bit 0 = no Gram(h1) MFMAs in dg_train_fwd
 };
 #define FE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     // Gram(h1) += h1_s^T h1_s (upper 32 x 32 blocks, one per wave): with the column sums below it gives the statistics of
     // z2 = h1 W2 + b2 (linear in h1: stat2_from_gram_kernel) and the layer-2 weight gradient of the backward -- the 32 sums
     // per lane and slot this replaces were a third of the kernel's VALU work, and the kernel is bound by that, not by the matrix pipe
-    if (wave < nG) {
+    if (wave < nG && !(a.dbg & 1)) {
       if constexpr (BF16) {
         const unsigned short* pa = XhT + (git * 32 + (lane & 31)) * ldT + half * 8;
         const unsigned short* pb = XhT + (gjt * 32 + (lane & 31)) * ldT + half * 8;
