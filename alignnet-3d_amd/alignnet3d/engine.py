@@ -410,6 +410,15 @@ class Engine:
             raise EngineError("alignnet_comm_unique_id failed (librccl not loadable?)")
         return bytes(buf)
 
+    @staticmethod
+    def comm_loopback_id():
+        """Id of a new in-process loopback group: `world` engines of this process on one device, one host thread each
+        (include/alignnet_hip.h: alignnet_comm_loopback_id) -- the multi-rank paths on a 1-GPU box."""
+        buf = (C.c_uint8 * 128)()
+        if _capi.load_library().alignnet_comm_loopback_id(buf) != 0:
+            raise EngineError("alignnet_comm_loopback_id failed")
+        return bytes(buf)
+
     def comm_init(self, rank, world, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.alignnet_comm_init(self._h, rank, world, buf))

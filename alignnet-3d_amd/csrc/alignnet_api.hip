@@ -132,6 +132,9 @@ extern "C" int alignnet_create(const alignnet_config* cfg, alignnet_handle** out
   if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return 1; }
 
   alignnet_handle* h = new alignnet_handle();
+#ifdef ALIGNNET_ABLATE
+  if (const char* e = getenv("ALIGNNET_DBG")) h->ablate_dbg = atoi(e);   // (the ablation build is the only one that reads the environment)
+#endif
   h->cfg = *cfg;
   const int nb2 = 2 * cfg->num_bins;
   h->s1_conv = conv_stack(h, "transformer1/embedding", cfg->s1_conv);
@@ -412,16 +415,11 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-static int infer_tile_pts()
-{
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ALIGNNET_TILE"); v = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 64) ? 64 : 128; }
-  return v;
-}
+static int infer_tile_pts(const alignnet_handle* h) { return (h->ab & AB_INFER_TILE64) ? 64 : 128; }
 
 static size_t backbone_lds_bytes(const alignnet_handle* h, const Stack& st, int ld[2])
 {
-  const int kTilePts = infer_tile_pts();
+  const int kTilePts = infer_tile_pts(h);
   int w[2] = {8, 8};
   for (int i = 0; i < st.n - 1; ++i) w[i & 1] = std::max(w[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
   ld[0] = w[0] + 4; ld[1] = w[1] + 4;
@@ -459,13 +457,12 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.mark(h->cfg.device);
   }
-  const int TP = infer_tile_pts();
+  const int TP = infer_tile_pts(h);
   // tiles per workgroup: as many as still leave every CU several workgroups (the pooled max is published once per workgroup)
   const int ntiles = (a.N + TP - 1) / TP;
   int per = ntiles;
   while (per > 1 && (long)2 * B * ((ntiles + per - 1) / per) < 512) per = (per + 1) / 2;   // >= two workgroups per CU
-  static const int per_env = getenv("ALIGNNET_TILES_PER_WG") ? atoi(getenv("ALIGNNET_TILES_PER_WG")) : 0;
-  if (per_env > 0) per = std::min(ntiles, per_env);
+  if (h->ab_tiles_per_wg > 0) per = std::min(ntiles, h->ab_tiles_per_wg);
   a.tiles_per_wg = per;
   const dim3 grid((ntiles + per - 1) / per, 2 * B);
   {
@@ -482,7 +479,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
     static PerDeviceOnce sattr;
     if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
-    if (sc1 == 64 && sc2 == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+    if (sc1 == 64 && sc2 == 128 && !(h->ab & AB_NO_LD_CONST)) {
       static PerDeviceOnce sattr;
       if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
       hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
@@ -492,17 +489,17 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT;
     }
   } else if (TP == 64) { hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_TP64; }
-  else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+  else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !(h->ab & AB_NO_LD_CONST)) {
     hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
     h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16;
-  } else if (a.ld[0] == 68 && a.ld[1] == 132 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
+  } else if (a.ld[0] == 68 && a.ld[1] == 132 && !(h->ab & AB_NO_LD_CONST)) {   // the shipped widths 64, 128
     hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
     h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128;
   } else { hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED; }
   }
   HIP_TRY(h, hipGetLastError());
 #ifdef ALIGNNET_KSTAMP
-  if (st.first == h->emb_conv.first && getenv("ALIGNNET_KSTAMP_PRINT")) {
+  if (st.first == h->emb_conv.first && true) {
     long long hs[4 * 64];
     hipStreamSynchronize(h->stream);
     hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost);
@@ -529,7 +526,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
   a.ld[0] = wmax[0] + 4; a.ld[1] = wmax[1] + 4;
   // es [64][8] (+ [64][8] spare) | buf0 | buf1 | buf0' | lift table [C1 <= 64][8] (the shipped-shape instantiation)
   // (the shipped-shape instantiation: 52.5 KiB, three workgroups per CU -- layout in kernels_dgcnn.h)
-  const bool dg_std = a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST");
+  const bool dg_std = a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !(h->ab & AB_NO_LD_CONST);
   const size_t lds = dg_std ? ((size_t)kDgTile * 9 + (size_t)kDgTile * 68 + 4 * 8 * 64 * 4) * sizeof(float)   // es (row stride 9) | W2 image | one lift buffer
                             : ((size_t)kDgTile * 16 + (size_t)kDgTile * (2 * a.ld[0] + a.ld[1])) * sizeof(float);
   if (lds > 160 * 1024) return fail(h, "dgcnn hidden widths need more than 160 KiB of LDS per 64-point tile");
@@ -559,13 +556,13 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       sa.B = B; sa.N = a.N; sa.k = a.k; sa.Ca = dca; sa.Cb = dcb; sa.C3 = h->layers[st.first + 2].cout;
       sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
       sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
-      sa.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+      sa.dbg = h->ablate_dbg;
       const int dlda = ((dca + 15) & ~15) + 8, dldb = ((dcb + 15) & ~15) + 8;
       if (a.k > 3 * kWaves) return fail(h, "dgcnn split kernel: k limited to 24 neighbours");
       const size_t dlds = (size_t)2 * kDgTile * 8 * sizeof(float) + ((size_t)4 * kDgTile * dlda + (size_t)2 * kDgTile * dldb) * sizeof(unsigned short);
       static PerDeviceOnce dsattr;
       if (dsattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr.mark(h->cfg.device); }
-      if (dca == 64 && dcb == 128 && !getenv("ALIGNNET_NO_LD_CONST")) {
+      if (dca == 64 && dcb == 128 && !(h->ab & AB_NO_LD_CONST)) {
         static PerDeviceOnce dsattr2;
         if (dsattr2.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2.mark(h->cfg.device); }
         hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
@@ -575,9 +572,9 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT;
       }
     } else {
-      const int dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+      const int dbg = h->ablate_dbg;
       a.stamps = (dbg & 64) ? reinterpret_cast<long long*>(h->ws.hid_a) : nullptr;   // scratch that is idle during the backbone
-      if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !getenv("ALIGNNET_NO_LD_CONST")) {   // the shipped widths 64, 128
+      if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !(h->ab & AB_NO_LD_CONST)) {   // the shipped widths 64, 128
         static PerDeviceOnce sattr;
         if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
         hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
@@ -889,6 +886,17 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
     h->infer_split = value != 0;
     return 0;
   }
+  if (k == "ab_tiles_per_wg") { if (value < 0) return fail(h, "ab_tiles_per_wg must be >= 0"); h->ab_tiles_per_wg = (int)value; return 0; }
+  for (const auto& ak : kAbKeys)
+    if (k == ak.key) {
+      const unsigned before = h->ab;
+      h->ab = value ? (h->ab | ak.bit) : (h->ab & ~ak.bit);
+      if ((before ^ h->ab) & AB_INFER_TILE64) h->folded = false;
+      return 0;
+    }
+#ifdef ALIGNNET_ABLATE
+  if (k == "ablate_dbg") { h->ablate_dbg = (int)value; return 0; }   // ablation build only: result-changing timing switches of the kernels
+#endif
   return fail(h, "alignnet_set_option: unknown key '" + k + "'");
 }
 
@@ -906,6 +914,10 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "global_loss") { *value = h->global_loss ? 1 : 0; return 0; }
   if (k == "sync_bn_emulate_world") { *value = h->sync_emulate_world; return 0; }
   if (k == "comm_world") { *value = h->comm ? h->comm_world : 0; return 0; }
+  if (k == "comm_order") { *value = h->comm_order; return 0; }
+  if (k == "ab_tiles_per_wg") { *value = h->ab_tiles_per_wg; return 0; }
+  if (k == "ab_mask") { *value = h->ab; return 0; }
+  for (const auto& ak : kAbKeys) if (k == ak.key) { *value = (h->ab & ak.bit) ? 1 : 0; return 0; }
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }
   if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
   if (k == "last_train_kernel") { *value = h->last_train_kernel; return 0; }

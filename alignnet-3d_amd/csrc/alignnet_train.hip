@@ -7,6 +7,7 @@
 #include "kernels_train_bwd.h"
 #include "kernels_train_dgcnn.h"
 #include "kernels_train_generic.h"
+#include "comm_loopback.h"
 
 #include <algorithm>
 #include <cmath>
@@ -214,6 +215,8 @@ static bool stage_hybrid(const alignnet_handle* h, int s)
 static int check_trainable_shape(alignnet_handle* h)
 {
   const bool dg = h->cfg.backbone == 1;
+  if (h->sync_bn && (h->ab & (AB_B1_LEGACY | AB_PHASE2_LEGACY)))   // those variants keep per-rank (dbeta1, dgamma1) / column sums: not summed over the ranks
+    return fail(h, "sync_bn: not available with the ab_b1_legacy / ab_phase2_legacy kernel variants");
   if (h->sync_bn)
     for (int s = 0; s < 3; ++s) {
       if (stage_generic(h, s)) continue;   // layer by layer: the per-layer sums travel through gen_stat_finish / gen_bn_bwd_finish's sync modes
@@ -497,44 +500,48 @@ static void def_combine(alignnet_handle* h, TrainWS* w, const CombineJob& j)
   if (w->defer.on) { w->defer.comb.push_back(j); return; }
   hipLaunchKernelGGL(combine_dw_kernel, dim3((unsigned)(((size_t)j.R * j.C + 255) / 256)), dim3(256), 0, h->stream, j.Sp, j.spscale, j.m, j.kdb, j.GW, j.E, j.R, j.C, j.dW, j.gscale);
 }
-// the recorded jobs, five launches: reductions | sparse gathers -> Gram centrings -> GEMMs -> combines
+// the recorded jobs, five launches: reductions | sparse gathers -> Gram centrings -> GEMMs -> combines.  A group that outgrows its
+// job table (deep heads: one dW product per FC layer, ALIGNNET_MAX_WIDTHS = 8 layers per head) goes out in several launches of the same kernel.
 static int flush_deferred(alignnet_handle* h, hipStream_t stream)
 {
   TrainWS* w = tws(h);
   Deferred& d = w->defer;
-  if (d.red.size() > (size_t)kReduceJobs || d.sp.size() > 3 || d.cen.size() > 3 || d.gemm.size() > (size_t)kGemmJobs || d.comb.size() > 6)
-    return fail(h, "flush_deferred: job table overflow");
-  if (!d.red.empty()) {
+  for (size_t i0 = 0; i0 < d.red.size(); i0 += kReduceJobs) {
+    const size_t nj = std::min(d.red.size() - i0, (size_t)kReduceJobs);
     ReduceJobs J{}; long nmax = 0;
-    for (size_t i = 0; i < d.red.size(); ++i) { J.j[i] = d.red[i]; nmax = std::max(nmax, d.red[i].n); }
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)d.red.size()), dim3(1024), 0, stream, J);
+    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.red[i0 + i]; nmax = std::max(nmax, d.red[i0 + i].n); }
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((nmax + 31) / 32), 2, (unsigned)nj), dim3(1024), 0, stream, J);
   }
   for (auto& sr : d.sync_after_red) if (sync_sum(h, sr.first, sr.second, false)) return 1;
-  if (!d.sp.empty()) {
-    SparseDwJobs J{}; int cmax = 0, c2max = 0;
-    for (size_t i = 0; i < d.sp.size(); ++i) { J.j[i] = d.sp[i]; cmax = std::max(cmax, d.sp[i].C3); c2max = std::max(c2max, d.sp[i].C2); }
-    (void)c2max;
-    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)d.sp.size()), dim3(1024), 0, stream, J);
+  constexpr size_t kSp = sizeof(SparseDwJobs::j) / sizeof(SparseDwJob), kCen = sizeof(CentreJobs::j) / sizeof(CentreJob), kComb = sizeof(CombineJobs::j) / sizeof(CombineJob);
+  for (size_t i0 = 0; i0 < d.sp.size(); i0 += kSp) {
+    const size_t nj = std::min(d.sp.size() - i0, kSp);
+    SparseDwJobs J{}; int cmax = 0;
+    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.sp[i0 + i]; cmax = std::max(cmax, d.sp[i0 + i].C3); }
+    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)nj), dim3(1024), 0, stream, J);
   }
-  if (!d.cen.empty()) {
+  for (size_t i0 = 0; i0 < d.cen.size(); i0 += kCen) {
+    const size_t nj = std::min(d.cen.size() - i0, kCen);
     CentreJobs J{}; size_t emax = 0;
-    for (size_t i = 0; i < d.cen.size(); ++i) { J.j[i] = d.cen[i]; emax = std::max(emax, (size_t)d.cen[i].C * d.cen[i].C); }
-    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)d.cen.size()), dim3(256), 0, stream, J);
+    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.cen[i0 + i]; emax = std::max(emax, (size_t)d.cen[i0 + i].C * d.cen[i0 + i].C); }
+    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)nj), dim3(256), 0, stream, J);
   }
-  if (!d.gemm.empty()) {
+  for (size_t i0 = 0; i0 < d.gemm.size(); i0 += kGemmJobs) {
+    const size_t nj = std::min(d.gemm.size() - i0, (size_t)kGemmJobs);
     GemmJobs J{}; int tot = 0;
-    for (size_t i = 0; i < d.gemm.size(); ++i) {
-      const GemmArgs& g = d.gemm[i].first;
+    for (size_t i = 0; i < nj; ++i) {
+      const GemmArgs& g = d.gemm[i0 + i].first;
       J.g[i] = g; J.tx[i] = (g.N + 31) / 32; J.ty[i] = (g.M + 31) / 32; J.start[i] = tot;
-      tot += J.tx[i] * J.ty[i] * d.gemm[i].second;
+      tot += J.tx[i] * J.ty[i] * d.gemm[i0 + i].second;
     }
-    J.start[d.gemm.size()] = tot; J.n = (int)d.gemm.size();
+    J.start[nj] = tot; J.n = (int)nj;
     hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, stream, J);
   }
-  if (!d.comb.empty()) {
+  for (size_t i0 = 0; i0 < d.comb.size(); i0 += kComb) {
+    const size_t nj = std::min(d.comb.size() - i0, kComb);
     CombineJobs J{}; size_t emax = 0;
-    for (size_t i = 0; i < d.comb.size(); ++i) { J.j[i] = d.comb[i]; emax = std::max(emax, (size_t)d.comb[i].R * d.comb[i].C); }
-    hipLaunchKernelGGL(combine_dw_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 1, (unsigned)d.comb.size()), dim3(256), 0, stream, J);
+    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.comb[i0 + i]; emax = std::max(emax, (size_t)d.comb[i0 + i].R * d.comb[i0 + i].C); }
+    hipLaunchKernelGGL(combine_dw_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 1, (unsigned)nj), dim3(256), 0, stream, J);
   }
   d.clear();
   HIP_TRY(h, hipGetLastError());
@@ -802,14 +809,14 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.stat_part = w->stat_part; a.ext = S.ext; a.idx = S.idx2; a.gram_part = w->gram_part; a.colsum_part = w->colsum_part;
   a.h2_store = S.h2; a.wp3h = nullptr;
   a.gram_inline = ((C2 + 31) / 32) * ((C2 + 31) / 32 + 1) / 2 > 3 * kTW;   // never for C2 <= 128
-  a.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+  a.dbg = h->ablate_dbg;
   a.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 32 : nullptr;
   const double count = (double)B * N;
   const bool dg = h->cfg.backbone == 1;
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   // fp32 phase 3 of the shipped widths: 128-point tiles (kernels_train_fwd_wide.h), with the Gram of the hidden features accumulated in the same pass
-  const bool wide = std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64");
-  const bool wide_gram = wide && !getenv("ALIGNNET_P3_NOGRAM");
+  const bool wide = std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64;
+  const bool wide_gram = wide && !(h->ab & AB_P3_NOGRAM);
   const bool sync = sync_on(h);
   const double W = sync ? (double)sync_world(h) : 1.0;   // sync_bn: batch counts are the global batch's
   // global_part: the partials are already sums over all ranks (statistics derived from all-reduced Gram / column sums)
@@ -914,6 +921,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
   }
+    #ifdef ALIGNNET_ABLATE
     if (wide_gram && getenv("ALIGNNET_P3_EXTCHECK")) {   // debug: ext / idx of the GRAM variant against the plain one
       std::vector<float> ea((size_t)2 * B * 2 * C3), eb(ea.size());
       std::vector<int> ia(ea.size()), ib(ea.size());
@@ -949,6 +957,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
           std::fprintf(stderr, "GRAMCHECK stage %d block (%d,%d): worst abs diff %.3e at cloud %d (max |G| %.3e)\n", s, it, jt, worst, wc, mag);
         }
     }
+#endif   // ALIGNNET_ABLATE
     if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM);
     hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
     }
@@ -961,7 +970,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
   const int CT1f = (C1 + 31) / 32, CT2f = (C2 + 31) / 32;
   // fp32 only: the bf16 phase 2 is light on the matrix pipe (49 us) and a fp32 Gram there costs more than passes B1 / B2 save
-  const bool fwd_gram = !h->train_bf16 && CT1f * CT2f + CT1f * (CT1f + 1) / 2 <= 3 * kTW && !getenv("ALIGNNET_PHASE2_LEGACY");   // cf. acc_in_b1 below
+  const bool fwd_gram = !h->train_bf16 && CT1f * CT2f + CT1f * (CT1f + 1) / 2 <= 3 * kTW && !(h->ab & AB_PHASE2_LEGACY);   // cf. acc_in_b1 below
   if (fwd_gram) {
     // phase 2 from s1 = sum h1 and G1 = sum h1^T h1 (kept for the backward)
     Gram1Args g;
@@ -992,9 +1001,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
     // shipped widths: 128-point tiles, the next tile's prologue under the lift (kernels_train_fwd_wide.h)
-    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64 && !getenv("ALIGNNET_P3_TILE64"))
+    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64)
       hipLaunchKernelGGL(train_fwd_phase3_wide_bf16, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_bf16(), h->stream, a);
-    else if (std_w && !getenv("ALIGNNET_P3BF16_GENERIC")) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+    else if (std_w && !(h->ab & AB_P3BF16_GENERIC)) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
     else hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
   }
     if (a.stamps) {
@@ -1203,7 +1212,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   auto g256t = [](size_t n) { return dim3((unsigned)((n + 255) / 256), 2); };
   w->glue_folded = false;
   auto set_glue = [&](DgB0Args& z) {   // the glue towards the previous stage rides on dg_b0_cloud (its thread 0 per cloud)
-    if (getenv("ALIGNNET_NO_GLUE_FOLD") || s == 0) return;
+    if ((h->ab & AB_NO_GLUE_FOLD) || s == 0) return;
     const int nb = h->cfg.num_bins;
     z.glue = s == 2 ? 3 : 2; z.xform = S.xform; z.pcls = w->cls; z.nb = nb;
     z.d_s2c = w->d_s2c; z.d_o2 = w->d_o[1]; z.ldo2 = 3 + 2 * nb; z.d_s1c = w->d_s1c; z.d_o0 = w->d_o[0];
@@ -1260,10 +1269,10 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.sc1 = S.scale[0]; b2.sh1 = S.shift[0]; b2.sc2 = S.scale[1]; b2.sh2 = S.shift[1];
   b2.b2 = P(h, L[1]->p_b); b2.mean2 = S.mean[1]; b2.rstd2 = S.rstd[1];
   b2.q3img = w->q3img; b2.q3img_stride = (long)qimg; b2.q3b = w->q3b; b2.gs = S.gs; b2.idx = S.idx; b2.w3t = w->W3T;
-  b2.dbg = getenv("ALIGNNET_DBG") ? atoi(getenv("ALIGNNET_DBG")) : 0;
+  b2.dbg = h->ablate_dbg;
   b2.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;   // scratch is free during the backward
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = S.u2_part; b2.g1_part = S.g1_part;
-  b2.s1_part = (!given && !h->train_bf16 && !b2_accum && !getenv("ALIGNNET_PHASE2_LEGACY")) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
+  b2.s1_part = (!given && !h->train_bf16 && !b2_accum && !(h->ab & AB_PHASE2_LEGACY)) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
   if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
@@ -1298,7 +1307,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // ---- operators for B1 (the layer-2 weight gradient follows B1 when B1 accumulates U2 / Gram(h1)) ----
   const int CT1 = (C1 + 31) / 32, CT2 = (C2 + 31) / 32;
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
-  const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !getenv("ALIGNNET_PHASE2_LEGACY");   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
+  const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !(h->ab & AB_PHASE2_LEGACY);   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
   bool u2_prescaled = false;
   auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
     def_reduce(h, w, rjob(S.u2_part, B, (long)(C1 * C2), S.u2));
@@ -1346,7 +1355,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
   }
   if (!acc_in_b1) layer2_weight_grad();
-  const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !getenv("ALIGNNET_B1_FP32") && !getenv("ALIGNNET_B1_LEGACY");   // (packs its own bf16 images of V2 / Q2 below)
+  const bool b1_bf16 = !dg && h->train_bf16 && C1 == 64 && C2 == 128 && !(h->ab & AB_B1_FP32) && !(h->ab & AB_B1_LEGACY);   // (packs its own bf16 images of V2 / Q2 below)
   // V2[t] = (W2 diag(k2))^T  [C2][C1]  (the bf16 pass B1 packs its image straight from W2 and k2: no fp32 copy)
   if (!b1_bf16) hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, nullptr, w->W2E, 0, 0, S.k2, w->V2, 1, 2);
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
@@ -1376,7 +1385,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
     const dim3 eg(2 * B), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2, dg_bf16);
-    const bool dense = dg_bf16 && !getenv("ALIGNNET_DG_SPARSE");   // bf16 mode: both dy2_s products as dense bf16 MFMAs on per-slot tiles
+    const bool dense = dg_bf16 && !(h->ab & AB_DG_SPARSE);   // bf16 mode: both dy2_s products as dense bf16 MFMAs on per-slot tiles
     e.k2 = S.k2; e.w2th = w->w2th[s];
     const size_t eld = dg_bwd_edge_dense_lds(C1, C2);
   { ProfScope prof_scope(h, PK_DG_BWD_EDGE);
@@ -1428,9 +1437,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.dy2_store = w->dy2; b1.dy1_store = w->dy1; b1.dbg1_part = w->dbg1_part; b1.dy2_bf16 = h->train_bf16 ? 1 : 0;
   b1.u2_part = acc_in_b1 ? S.u2_part : nullptr; b1.g1_part = (acc_in_b1 && !fwd_gram) ? S.g1_part : nullptr;
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
-  const bool pdy = C1 <= 64 && acc_in_b1 && !getenv("ALIGNNET_B1_LEGACY");   // one dh1 item per wave: no stored dy1, no pass B0
+  const bool pdy = C1 <= 64 && acc_in_b1 && !(h->ab & AB_B1_LEGACY);   // one dh1 item per wave: no stored dy1, no pass B0
   b1.pdy_part = w->pdy_part;
-  const bool b1h = pdy && std_w && h->train_bf16 && !getenv("ALIGNNET_B1_FP32");
+  const bool b1h = pdy && std_w && h->train_bf16 && !(h->ab & AB_B1_FP32);
   if (b1h) {
     // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16): bf16 images of V2 / Q2 per tower, then the kernel
     constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // [CT = 2][KG][64 lanes][8]
@@ -1495,6 +1504,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
 // ---------------------------------------------------------------------------------
 static int comm_bucket(alignnet_handle* h, int stage, hipStream_t after = nullptr);   // defined with the RCCL section below
 static int comm_join(alignnet_handle* h);
+static void comm_poison(alignnet_handle* h);   // loopback group: a failed rank must not leave the others waiting at the next rendezvous
 
 static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, const float* const lab[6], int B, const float* u_dev,
                           int do_backward, int update_ema, int comm_overlap = 0)
@@ -1602,23 +1612,34 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   h->comm_buckets = 0;
   w->defer.clear();
-  w->defer.on = !getenv("ALIGNNET_NO_DEFER") || sync_on(h);   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
+  w->defer.on = !(h->ab & AB_NO_DEFER) || sync_on(h);   // (ablation switch: every weight-gradient job launched where its inputs appear, as before round 3)
   // The deferred weight-gradient jobs of a stage go to a side stream as soon as that stage's backward is queued: they run under the next
   // stage's head / prep chains (a few workgroups each, most of the chip idle), and in data-parallel steps the stage's gradient segment
   // is final -- and its all-reduce bucket on its way -- two stages earlier than with one flush at the end.  sync_bn keeps the single
   // flush on the compute stream (its reduced matrices are summed over the ranks between the job groups).
-  const bool side = w->defer.on && h->dw_side && !sync_on(h) && !getenv("ALIGNNET_NO_SIDE");
+  const bool side = w->defer.on && h->dw_side && !sync_on(h);
+  // Data-parallel steps (communicator + "allreduce_overlap"): a stage's deferred jobs are flushed right behind that stage's backward, so
+  // that its segment of the flat gradient is final and its all-reduce bucket leaves on the comm stream UNDER the next stage's backward:
+  // stage 3's bucket (64 % of the vector for the shipped widths) travels under stages 2 and 1, stage 2's (23 %) under stage 1, only the
+  // last and smallest one (14 %) is exposed.  Without a communicator the three stages' jobs stay one group after the whole backward
+  // (five launches instead of fifteen: the one-GPU step does not pay for an overlap it does not need).
+  h->comm_order = 0;
   auto stage_flush = [&](int sg) -> int {
-    if (!side) return 0;
-    if (!h->side_stream) {
-      HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-      for (auto& e : h->side_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->comm_order = h->comm_order * 10 + 1 + sg;   // "comm_order": digit 1..3 = that stage's backward is queued, 4..6 = that stage's bucket is issued
+    if (side) {
+      if (!h->side_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        for (auto& e : h->side_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      HIP_TRY(h, hipEventRecord(h->side_ev[sg], h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->side_ev[sg], 0));
+      if (flush_deferred(h, h->side_stream)) return 1;
+      if (comm_overlap && comm_bucket(h, sg, h->side_stream)) return 1;
+      return 0;
     }
-    HIP_TRY(h, hipEventRecord(h->side_ev[sg], h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->side_ev[sg], 0));
-    if (flush_deferred(h, h->side_stream)) return 1;
-    if (comm_overlap && comm_bucket(h, sg, h->side_stream)) return 1;
-    return 0;
+    if (!comm_overlap) return 0;
+    if (w->defer.on && flush_deferred(h, h->stream)) return 1;
+    return comm_bucket(h, sg);
   };
   if (head_bwd_train(h, 2, w->st[2].pooled, 2L * CE, w->st[2].dP, B, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 2, p1, p2, B)) return 1;
@@ -1639,19 +1660,12 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   }
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
+  if (stage_flush(0)) return 1;
   if (side) {
-    if (stage_flush(0)) return 1;
     HIP_TRY(h, hipEventRecord(h->side_ev[3], h->side_stream));   // the optimiser (compute stream) reads the whole gradient
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->side_ev[3], 0));
-    w->defer.on = false;
-  } else {
-    if (flush_deferred(h, h->stream)) return 1;   // the weight gradients of all three stages: five multi-job launches
-    w->defer.on = false;
-    if (comm_overlap) {
-      // Data-parallel steps: the three segments of the flat gradient are final only now; they go out as three buckets, stage 3 first.
-      for (int sg = 2; sg >= 0; --sg) if (comm_bucket(h, sg)) return 1;
-    }
-  }
+  } else if (w->defer.on && flush_deferred(h, h->stream)) return 1;   // no communicator: the weight gradients of all three stages, five multi-job launches
+  w->defer.on = false;
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -1779,7 +1793,16 @@ static int train_fb_host(alignnet_handle* h, const float* pcs1, const float* pcs
   return fwd_bwd_device(h, w->d_pcs[0], w->d_pcs[1], w->labels, B, u_dev, 1, 1, comm_overlap);
 }
 
+static int alignnet_train_forward_backward_impl(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
+                                               int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out);
 extern "C" int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
+                                               int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+{
+  const int rc = alignnet_train_forward_backward_impl(h, pcs1, pcs2, labels, B, dropout_u, result, out);
+  if (rc) comm_poison(h);
+  return rc;
+}
+static int alignnet_train_forward_backward_impl(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels,
                                                int32_t B, const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
 {
   if (!h) return 1;
@@ -1801,7 +1824,16 @@ static int reduce_and_apply(alignnet_handle* h, int overlapped)
   return alignnet_apply_gradients(h, scale);
 }
 
+static int alignnet_train_step_impl(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
+                                   const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out);
 extern "C" int alignnet_train_step(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
+                                   const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
+{
+  const int rc = alignnet_train_step_impl(h, pcs1, pcs2, labels, B, dropout_u, result, out);
+  if (rc) comm_poison(h);
+  return rc;
+}
+static int alignnet_train_step_impl(alignnet_handle* h, const float* pcs1, const float* pcs2, const alignnet_labels* labels, int32_t B,
                                    const float* dropout_u, alignnet_step_result* result, const alignnet_outputs* out)
 {
   if (!h) return 1;
@@ -1813,7 +1845,16 @@ extern "C" int alignnet_train_step(alignnet_handle* h, const float* pcs1, const 
   return fetch_result(h, result, out, B, pre);
 }
 
+static int alignnet_train_step_device_impl(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2, const alignnet_labels* d_labels,
+                                          int32_t B, alignnet_step_result* result);
 extern "C" int alignnet_train_step_device(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2, const alignnet_labels* d_labels,
+                                          int32_t B, alignnet_step_result* result)
+{
+  const int rc = alignnet_train_step_device_impl(h, d_pcs1, d_pcs2, d_labels, B, result);
+  if (rc) comm_poison(h);
+  return rc;
+}
+static int alignnet_train_step_device_impl(alignnet_handle* h, const float* d_pcs1, const float* d_pcs2, const alignnet_labels* d_labels,
                                           int32_t B, alignnet_step_result* result)
 {
   if (!h) return 1;
@@ -1934,6 +1975,46 @@ bool load_rccl(std::string& err)
 // ncclCommInitRank takes ncclUniqueId BY VALUE; declare the real prototype for the call
 typedef int (*InitRankByValue)(void**, int, UniqueId, int);
 
+// What h->comm points to: an RCCL communicator (one process per GPU, xGMI) or a rank of an in-process loopback group (comm_loopback.h:
+// W handles of one process on one device -- the multi-rank code paths with distinct shards on a 1-GPU box).
+struct CommImpl { void* nccl = nullptr; LoopComm* loop = nullptr; };
+static CommImpl* comm_of(const alignnet_handle* h) { return static_cast<CommImpl*>(h->comm); }
+
+// sum of `n` floats / doubles over the ranks, in place, in stream order on `s`
+static int comm_allreduce(alignnet_handle* h, void* buf, size_t n, bool is_double, hipStream_t s, const char* what)
+{
+  CommImpl* c = comm_of(h);
+  if (c->loop) {
+    std::string err;
+    if (loop_collective(c->loop, is_double ? kLoopSumF64 : kLoopSumF32, buf, nullptr, n, s, err)) return fail(h, std::string(what) + ": " + err);
+    return 0;
+  }
+  const int rc = g_rccl.AllReduce(buf, buf, n, is_double ? 8 : 7, 0, c->nccl, s);   // ncclFloat64 = 8, ncclFloat32 = 7, ncclSum = 0
+  if (rc != 0) return fail(h, std::string("ncclAllReduce (") + what + "): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  return 0;
+}
+
+// dst[rank][n4] = every rank's n4 four-byte elements, in stream order on `s`
+static int comm_allgather(alignnet_handle* h, const void* src, void* dst, size_t n4, hipStream_t s)
+{
+  CommImpl* c = comm_of(h);
+  if (c->loop) {
+    std::string err;
+    if (loop_collective(c->loop, kLoopGather, const_cast<void*>(src), dst, n4, s, err)) return fail(h, "all-gather: " + err);
+    return 0;
+  }
+  if (!g_rccl.AllGather) return fail(h, "librccl.so lacks ncclAllGather");
+  const int rc = g_rccl.AllGather(src, dst, n4, 7, c->nccl, s);   // ncclFloat32 = 7 (four-byte elements; class ids travel as bits)
+  if (rc != 0) return fail(h, std::string("ncclAllGather (global_loss): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  return 0;
+}
+
+// A rank that fails between two collectives would leave the other ranks' threads waiting at the next rendezvous: break the group.
+static void comm_poison(alignnet_handle* h)
+{
+  if (h && h->comm && comm_of(h)->loop) comm_of(h)->loop->g->poison();
+}
+
 extern "C" int alignnet_comm_unique_id(uint8_t id[128])
 {
   std::string err;
@@ -1944,19 +2025,36 @@ extern "C" int alignnet_comm_unique_id(uint8_t id[128])
   return 0;
 }
 
+extern "C" int alignnet_comm_loopback_id(uint8_t id[128])
+{
+  if (!id) return 1;
+  loop_make_id(id);
+  return 0;
+}
+
 extern "C" int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128])
 {
   if (!h) return 1;
   if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, "alignnet_comm_init: bad arguments");
+  if (h->comm) return fail(h, "alignnet_comm_init: this handle already has a communicator");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (loop_is_id(id)) {
+    std::string err;
+    LoopComm* lc = loop_join(id, rank, world, h->cfg.device, err);
+    if (!lc) return fail(h, err);
+    CommImpl* c = new CommImpl(); c->loop = lc;
+    h->comm = c; h->comm_world = world; h->comm_rank = rank;
+    return 0;
+  }
   std::string err;
   if (!load_rccl(err)) return fail(h, err);
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
   UniqueId u;
   std::memcpy(u.internal, id, 128);
   void* comm = nullptr;
   const int rc = reinterpret_cast<InitRankByValue>(g_rccl.CommInitRank)(&comm, world, u, rank);
   if (rc != 0) return fail(h, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-  h->comm = comm; h->comm_world = world; h->comm_rank = rank;
+  CommImpl* c = new CommImpl(); c->nccl = comm;
+  h->comm = c; h->comm_world = world; h->comm_rank = rank;
   return 0;
 }
 
@@ -1964,7 +2062,13 @@ extern "C" void alignnet_comm_free(alignnet_handle* h)
 {
   if (!h) return;
   if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
-  if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  if (h->comm) {
+    CommImpl* c = comm_of(h);
+    if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+    if (c->loop) { if (h->stream) hipStreamSynchronize(h->stream); loop_leave(c->loop); }
+    delete c;
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+  }
   for (auto& e : h->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
   if (h->comm_stream) { hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
 }
@@ -1985,9 +2089,9 @@ static int comm_bucket(alignnet_handle* h, int stage, hipStream_t after)   // af
   if (hi <= lo || hi > h->n_trainable) return fail(h, "comm_bucket: gradient segments are not in stage order");
   HIP_TRY(h, hipEventRecord(h->comm_ev[stage], after ? after : h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ev[stage], 0));
-  const int rc = g_rccl.AllReduce(w->grad + lo, w->grad + lo, hi - lo, 7, 0, h->comm, h->comm_stream);   // ncclFloat = 7, ncclSum = 0
-  if (rc != 0) return fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  if (comm_allreduce(h, w->grad + lo, hi - lo, false, h->comm_stream, "gradient bucket")) return 1;
   h->comm_buckets++;
+  h->comm_order = h->comm_order * 10 + 4 + stage;
   return 0;
 }
 
@@ -2011,11 +2115,7 @@ __global__ void scale_buf_kernel(T* __restrict__ p, size_t n, T f)
 // "sync_bn_emulate_world" = w stands for w ranks holding identical shards: every sum is w times this rank's.
 static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
 {
-  if (h->comm) {
-    const int rc = g_rccl.AllReduce(buf, buf, n, is_double ? 8 : 7, 0, h->comm, h->stream);   // ncclFloat64 = 8, ncclFloat32 = 7, ncclSum = 0
-    if (rc != 0) return fail(h, std::string("ncclAllReduce (sync_bn): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-    return 0;
-  }
+  if (h->comm) return comm_allreduce(h, buf, n, is_double, h->stream, "sync_bn");
   const unsigned grid = (unsigned)((n + 255) / 256);
   if (is_double) hipLaunchKernelGGL(scale_buf_kernel<double>, dim3(grid), dim3(256), 0, h->stream, static_cast<double*>(buf), n, (double)h->sync_emulate_world);
   else hipLaunchKernelGGL(scale_buf_kernel<float>, dim3(grid), dim3(256), 0, h->stream, static_cast<float*>(buf), n, (float)h->sync_emulate_world);
@@ -2026,12 +2126,7 @@ static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
 // without a communicator "sync_bn_emulate_world" = w stands for w ranks holding identical shards: w copies
 static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4)
 {
-  if (h->comm) {
-    if (!g_rccl.AllGather) return fail(h, "librccl.so lacks ncclAllGather");
-    const int rc = g_rccl.AllGather(src, dst, n4, 7, h->comm, h->stream);   // ncclFloat32 = 7 (four-byte elements; class ids travel as bits)
-    if (rc != 0) return fail(h, std::string("ncclAllGather (global_loss): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-    return 0;
-  }
+  if (h->comm) return comm_allgather(h, src, dst, n4, h->stream);
   for (int r = 0; r < h->sync_emulate_world; ++r)
     HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dst) + (size_t)r * n4 * 4, src, n4 * 4, hipMemcpyDeviceToDevice, h->stream));
   return 0;
@@ -2044,9 +2139,7 @@ extern "C" int alignnet_comm_allreduce_grads(alignnet_handle* h)
   TrainWS* w = tws(h);
   if (!w->grad) return fail(h, "alignnet_comm_allreduce_grads: no gradients computed yet");
   // one bucket: the whole trainable vector (8.66 MB fp32 for the SynthCars widths), ncclFloat = 7, ncclSum = 0
-  const int rc = g_rccl.AllReduce(w->grad, w->grad, h->n_trainable, 7, 0, h->comm, h->stream);
-  if (rc != 0) return fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-  return 0;
+  return comm_allreduce(h, w->grad, h->n_trainable, false, h->stream, "gradient");
 }
 
 // ---------------------------------------------------------------------------------

@@ -58,6 +58,25 @@ struct Workspace {
 namespace alignnet {
 struct DatasetTables { const float* pts[2]; const long long* off; long long n; };   // device pointers of the uploaded dataset
 }
+// A/B dispatch overrides (alignnet_set_option "ab_<name>", default 0): each selects another kernel variant of the SAME arithmetic (an
+// earlier instantiation kept for same-box comparisons and as a test hook); results agree up to summation order.  The library reads
+// no environment variable: these replace the ALIGNNET_* switches of rounds 1 - 3.
+enum AbBit : unsigned {
+  AB_NO_LD_CONST = 1u << 0,       // eval backbones: run-time LDS strides instead of the instantiations with the shipped widths compiled in
+  AB_INFER_TILE64 = 1u << 1,      // eval PointNet backbone on 64-point tiles
+  AB_PHASE2_LEGACY = 1u << 2,     // fp32 training: phase 2 computes z2 and its statistics instead of deriving them from Gram(h1)
+  AB_B1_LEGACY = 1u << 3,         // pass B1 stores dy1 and pass B0 re-reads it (no Pdy accumulation)
+  AB_B1_FP32 = 1u << 4,           // bf16 training: pass B1 on fp32 MFMA
+  AB_P3BF16_GENERIC = 1u << 5,    // bf16 phase 3 (64-point tiles) with run-time widths
+  AB_P3_NOGRAM = 1u << 6,         // fp32 phase 3 without the fused Gram (gram_h2_kernel runs instead)
+  AB_NO_DEFER = 1u << 7,          // weight-gradient jobs launched where their inputs appear instead of as deferred multi-job launches
+  AB_DG_SPARSE = 1u << 8,         // bf16 dgcnn training: the index-list edge backward instead of the dense form
+  AB_NO_GLUE_FOLD = 1u << 9,      // the glue between the stages' backwards as separate launches
+};
+static const struct { const char* key; unsigned bit; } kAbKeys[] = {
+  {"ab_no_ld_const", AB_NO_LD_CONST}, {"ab_infer_tile64", AB_INFER_TILE64}, {"ab_phase2_legacy", AB_PHASE2_LEGACY}, {"ab_b1_legacy", AB_B1_LEGACY},
+  {"ab_b1_fp32", AB_B1_FP32}, {"ab_p3_bf16_generic", AB_P3BF16_GENERIC}, {"ab_p3_nogram", AB_P3_NOGRAM}, {"ab_no_defer", AB_NO_DEFER},
+  {"ab_dg_sparse", AB_DG_SPARSE}, {"ab_no_glue_fold", AB_NO_GLUE_FOLD}};
 struct alignnet_handle;
 bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out);   // alignnet_dataset.hip; false when none uploaded
 int alignnet_drain_profile(alignnet_handle* h);   // alignnet_api.hip: read back the pending profiling event pairs (synchronises the stream)
@@ -108,7 +127,7 @@ struct alignnet_handle {
   void* pipe = nullptr;            // pipelined host path: two staging slots, copy streams, events (alignnet_api.hip: alignnet_forward_submit / _wait)
   // seed base of the device-side dropout stream at the current step counter (alignnet_train.hip: bn_args, dropout_uniforms_kernel)
   uint64_t dropout_seed_base() const { return (cfg.seed + dropout_stream * 0xD1B54A32D192ED03ull) * 0x9E3779B97F4A7C15ull + (uint64_t)step * 16; }
-  void* comm = nullptr;
+  void* comm = nullptr;            // alignnet_train.hip: CommImpl (RCCL communicator or a rank of an in-process loopback group)
   int comm_world = 1, comm_rank = 0;
   // gradient all-reduce in three buckets (stage 3 | stage 2 | stage 1 segment of the flat gradient) on a side stream, each issued as
   // soon as that stage's backward has produced its segment; the optimiser waits for the last one (alignnet_train.hip: comm_bucket)
@@ -120,6 +139,9 @@ struct alignnet_handle {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool dw_side = false;            // alignnet_set_option("train_dw_side_stream")
+  unsigned ab = 0;                 // AbBit mask (alignnet_set_option "ab_*")
+  int ab_tiles_per_wg = 0;         // "ab_tiles_per_wg": eval PointNet backbone, point tiles per workgroup (0 = chosen from the grid size)
+  int ablate_dbg = 0;              // ablation build only (-DALIGNNET_ABLATE): the kernels' result-changing timing switches, from ALIGNNET_DBG
   bool p3_tile64 = false;          // alignnet_set_option("train_phase3_tile64"): the forward's phase 3 on 64-point tiles (default: 128-point tiles, kernels_train_fwd_wide.h)
   // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --
   // the reference's single-device semantics at the global batch (utils/tf_util.py:474) -- instead of per rank.
@@ -131,6 +153,7 @@ struct alignnet_handle {
                                    // identical virtual ranks (a step must then reproduce the plain local-BN step on the same shard)
   double* sync_buf = nullptr;      // staging for the per-layer totals that travel through the all-reduce
   int comm_buckets = 0;            // bucket all-reduces issued by the last training step (0: one all-reduce after the backward)
+  long long comm_order = 0;        // last training step, one decimal digit per event in issue order: 1..3 = backward of stage 1..3 queued, 4..6 = bucket of stage 1..3 issued
   mutable std::string err;
 };
 

@@ -11,6 +11,7 @@
 // frames differ by a rigid motion, which leaves the graph unchanged (SURVEY.md 8.A6 vii; ties at the k-th
 // neighbour aside).
 #pragma once
+#include "ablate.h"
 #include "engine.h"
 #include "kernels_infer.h"
 
@@ -240,7 +241,7 @@ struct DgcnnArgs {
   ConvLayerDev L[kMaxConv];   // L[0].w = raw [6][C1]; others packed images
   long long* stamps;          // debug (ALIGNNET_DBG & 64): cycle stamps of thread 0 / workgroup (1, 0) around neighbour slot 5
 };
-#define DG_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DG_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 #ifndef DGLB
 #define DGLB 6

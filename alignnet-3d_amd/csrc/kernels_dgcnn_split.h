@@ -9,6 +9,7 @@
 // fragments roll one channel tile ahead as in pointnet_split.
 // LDS: es [64][8] f32 | lift tiles [2 buffers][hi, lo][64][Ka+8] bf16 | point features [hi, lo][64][Kb+8] bf16 | es' [64][8] f32.
 #pragma once
+#include "ablate.h"
 #include "kernels_dgcnn.h"
 #include "kernels_infer_split.h"
 
@@ -176,12 +177,12 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
     write_es(slot);
     if (two) write_es(slot + 1);
     __syncthreads();
-    if (!(a.dbg & 2)) {
+    if (!(ALN_ABL(a.dbg, 2))) {
       dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
       if (two) dg_lift_split(a, tower, LW, es2, s16 + 2 * tsz, s16 + 3 * tsz, lda, Ka, tid);
     }
     __syncthreads();
-    if (!(a.dbg & 1)) {
+    if (!(ALN_ABL(a.dbg, 1))) {
       edge_conv(0);
       if (two) edge_conv(1);
     }
@@ -214,7 +215,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
   {
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     const int arow = (lane & 31) * ldb + half * 8;
-    for (int ct = wave; ct < ((a.dbg & 4) ? 0 : CT3); ct += kWaves) {
+    for (int ct = wave; ct < ((ALN_ABL(a.dbg, 4)) ? 0 : CT3); ct += kWaves) {
       const int col = ct * 32 + (lane & 31);
       const bool live = col < a.C3;
       const float sc = live ? a.sc3[tower * a.C3 + col] : 0.f, sh = live ? a.sh3[tower * a.C3 + col] : 0.f;

@@ -17,6 +17,7 @@
 //   B1: dh1 = dy2 V2 + (h1 - m1) Q2 + ... -> dy1 (stored), dbeta1/dgamma1
 //   B0: dz1 -> dW1 partials and the per-cloud input gradients (centre / yaw paths)
 #pragma once
+#include "ablate.h"
 #include "kernels_train_fwd.h"
 
 namespace alignnet {
@@ -52,7 +53,7 @@ struct BwdB2Args {
 // Work split in B2: item = (channel tile ct, 32-row group rg) = wave + 4*slot  (C2 <= 128 -> CT2*2 <= 8 items, two
 // static slots per wave), so the wave that produced z2 for an item also owns its dh2 and keeps z2 in registers.
 // LDS: xs | X [64][ldb] | Y [64][ldb] | hit list (entry, g)[C3] | per-wave tile offsets.
-#define B2_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define B2_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // BF16: the hidden layer is recomputed exactly as the bf16 forward did (bf16 h1 tile x bf16 W2 image), and the h2 Q3 product
 // of dh2 takes h2 and Q3 as bf16 operands; accumulation, sparse rows, BN backward and all reductions stay fp32 / fp64.
 // GIVEN (fp32, !ACCUM): Y is loaded from h2_given (the DGCNN branch's pooled edge features p = max_k h2) instead of being
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     if (SPM && sp_h1 > sp_h0) sp_write(sp_h0, min(sp_h1, sp_h0 + kSpH));   // (regions disjoint from h1 / h2: no barrier needed before)
     B2_STAMP(3);
     // Gram / column sums of h1 (X): needed by the statistics part of layer 2's backward
-    for (int item = wave; ACCUM && item < ((a.dbg & 32) ? 0 : CT1 * CT1); item += kTW) {
+    for (int item = wave; ACCUM && item < ((ALN_ABL(a.dbg, 32)) ? 0 : CT1 * CT1); item += kTW) {
       const int it = item / CT1, jt = item % CT1;
       const float* pa = X + half * ld0 + it * 32 + (lane & 31);
       const float* pb = X + half * ld0 + jt * 32 + (lane & 31);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     for (int i = tid; i < kTT * ldb / 4; i += kTW * 64) reinterpret_cast<f32x4*>(X)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // ldb % 4 == 0
     __syncthreads();
     B2_STAMP(5);
-    if (a.dbg & 8) {
+    if (ALN_ABL(a.dbg, 8)) {
       for (int base = 0; base < a.C3; base += 64) {
         const int c = base + lane;
         const int rel = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] - tile * kTT : -1;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         *reinterpret_cast<f32x4*>(dst + (size_t)row * kC2 + q * 4) = *reinterpret_cast<const f32x4*>(Y + row * ldb + q * 4);
       }
       }
-      for (int item = wave; ACCUM && item < ((a.dbg & 64) ? 0 : CT1 * CT2); item += kTW) {
+      for (int item = wave; ACCUM && item < ((ALN_ABL(a.dbg, 64)) ? 0 : CT1 * CT2); item += kTW) {
         const int it = item / CT2, jt = item % CT2;
         const float* pa = X + half * ld0 + it * 32 + (lane & 31);
         const float* pb = Y + half * ldb + jt * 32 + (lane & 31);

@@ -21,6 +21,7 @@
 //                      dy1 is never stored: the first layer is linear in e, so dbeta1, dgamma1, dW1 and the per-cloud
 //                      frame gradients follow from  Pdy = sum e^T dy1 (6 x C1), sum dy1 (C1)  and the moments of e.
 #pragma once
+#include "ablate.h"
 #include "kernels_train_bwd.h"
 #include "kernels_dgcnn.h"
 
@@ -48,7 +49,7 @@ struct DgTrainArgs {
   long long* stamps;              // debug (ALIGNNET_DBG & 32): cycle stamps of thread 0 / block 0, iteration 25
   int dbg = 0;                    // ablation (timing only): bit 0 = no Gram(h1) MFMAs in dg_train_fwd
 };
-#define FE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define FE_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ void dgt_gather(const float* __restrict__ pc, const int* __restrict__ nnc, int N, int k, int n, int slot,
                                            float (&v)[6])
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
-  const long long t_begin = a.stamps ? (long long)__builtin_readcyclecounter() : 0;   // (debug: whole-kernel cycles per workgroup)
+  const long long t_begin = ALN_STAMPS(a.stamps) ? (long long)__builtin_readcyclecounter() : 0;   // (debug: whole-kernel cycles per workgroup)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     // Gram(h1) += h1_s^T h1_s (upper 32 x 32 blocks, one per wave): with the column sums below it gives the statistics of
     // z2 = h1 W2 + b2 (linear in h1: stat2_from_gram_kernel) and the layer-2 weight gradient of the backward -- the 32 sums
     // per lane and slot this replaces were a third of the kernel's VALU work, and the kernel is bound by that, not by the matrix pipe
-    if (wave < nG && !(a.dbg & 1)) {
+    if (wave < nG && !(ALN_ABL(a.dbg, 1))) {
       if constexpr (BF16) {
         const unsigned short* pa = XhT + (git * 32 + (lane & 31)) * ldT + half * 8;
         const unsigned short* pb = XhT + (gjt * 32 + (lane & 31)) * ldT + half * 8;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const float zero[16] = {};
     tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
-  if (a.stamps && tid == 0) {   // stamps 8 / 9 / 10: longest and (2^40 - shortest) workgroup, workgroup 0 -- zeroed by the host
+  if (ALN_STAMPS(a.stamps) && tid == 0) {   // stamps 8 / 9 / 10: longest and (2^40 - shortest) workgroup, workgroup 0 -- zeroed by the host
     const long long d = (long long)__builtin_readcyclecounter() - t_begin;
     atomicMax(reinterpret_cast<unsigned long long*>(a.stamps + 8), (unsigned long long)d);
     atomicMax(reinterpret_cast<unsigned long long*>(a.stamps + 9), (unsigned long long)((1ll << 40) - d));
@@ -575,9 +576,9 @@ struct DgBwdArgs {
   double* pdy_part;                    // [2B][4 = 2 row groups x 2 halves][7][C1]: sum e_d dy1 (d < 6), sum dy1
   long long* stamps;                   // debug: cycle stamps of thread 0 / block 0 at the phase boundaries of iteration 25
 };
-#define BE_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BE_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // stamps 10..15: the tile-start block of iteration 40; stamp 16: iteration 45 (20 iterations = one tile after stamp 0)
-#define BE_TSTAMP(i, at) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && it == at) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BE_TSTAMP(i, at) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && it == at) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 static inline size_t dg_bwd_edge_lds(int C1, int C2, bool bf16 = false)
 {
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
     __syncthreads();
     BE_STAMP(5);
     if (wave >= 4) {
-      if (a.stamps && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[17] = (long long)__builtin_readcyclecounter();
+      if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[17] = (long long)__builtin_readcyclecounter();
       if (p2on) {   // U2[kP2W j ..][c] += sum over the column's slot rows of dp[row,c] h1_s[row][kP2W j ..]
         const int j0 = SOc[p2c * 24 + slot], j1 = SOc[p2c * 24 + slot + 1];
         for (int j = j0; j < j1; j += 2) {   // two entries per trip (see P1)
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
             }
         }
       }
-      if (a.stamps && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[18] = (long long)__builtin_readcyclecounter();
+      if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 256 && it == 25) a.stamps[18] = (long long)__builtin_readcyclecounter();
     }
     BE_STAMP(6);
     if (wave < nitems) {

@@ -15,6 +15,7 @@
 // One workgroup per cloud walks its 128-point tiles; sums are kept in fp64 per lane (sum, sum of
 // squares -> biased variance E[z^2]-E[z]^2 without fp32 cancellation), then one partial per cloud.
 #pragma once
+#include "ablate.h"
 #include "kernels_infer.h"
 
 namespace alignnet {
@@ -49,7 +50,7 @@ struct TrainFwdArgs {
   int dbg;                 // debug/ablation flags (0 in production)
   long long* stamps;       // debug (dbg & 32): cycle stamps of thread 0 / block 0 at the phase boundaries of tile 3
 };
-#define P3_STAMP(i) do { if (PHASE == 3 && a.stamps && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define P3_STAMP(i) do { if (PHASE == 3 && ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // Accumulate one 32x32 MFMA result tile into a lane-owned global matrix.  The old values are requested BEFORE the
 // MFMA loop that produces the new ones and pinned there (compiler memory barrier: hipcc otherwise sinks the loads
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 
   // Two workgroups share a CU and run identical per-tile timelines; started together they stay in lockstep and
   // their non-MFMA phases coincide.  Stagger the second resident wave of workgroups by about half a tile.
-  if (PHASE == 3 && (a.dbg & 16) && ((blockIdx.x / 256) & 1)) {
-    const int reps = (a.dbg >> 8) & 0xff;
+  if (PHASE == 3 && (ALN_ABL(a.dbg, 16)) && ((blockIdx.x / 256) & 1)) {
+    const int reps = ALN_ABL(a.dbg >> 8, 0xff);
     for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
@@ -532,14 +533,14 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 
     // ---- keep h2 for the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
     if (GIVEN) {
-    } else if (BF16 && !(a.dbg & 2)) {
+    } else if (BF16 && !(ALN_ABL(a.dbg, 2))) {
       unsigned short* dst = reinterpret_cast<unsigned short*>(a.h2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c8 = kC2 >> 3;
       for (int i = tid; i < nvalid * c8; i += kTW * 64) {
         const int row = i / c8, q = i % c8;
         *reinterpret_cast<f32x4*>(dst + (size_t)row * kC2 + q * 8) = *reinterpret_cast<const f32x4*>(buf1h + row * ldh + q * 8);
       }
-    } else if (!BF16 && !(a.dbg & 2)) {
+    } else if (!BF16 && !(ALN_ABL(a.dbg, 2))) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
       const int c4 = kC2 >> 2;
       for (int i = tid; i < nvalid * c4; i += kTW * 64) {
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 
     P3_STAMP(5);
     // ---- Gram: G += h2^T h2 (32x32 tiles of the C2 x C2 matrix), K = the tile's rows ----
-    if (BF16 && !(a.dbg & 1)) {
+    if (BF16 && !(ALN_ABL(a.dbg, 1))) {
       // upper-triangle blocks only (the Gram is symmetric; centre_gram_kernel mirrors them), register-resident for the
       // whole cloud: a per-tile read-modify-write of the 64 KiB per-cloud matrix does not stay in L2 (512 clouds in flight)
 #pragma unroll
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         }
       }
     }
-    for (int item = wave; !BF16 && item < (((a.dbg & 1) || !a.gram_inline) ? 0 : CT2 * CT2); item += kTW) {
+    for (int item = wave; !BF16 && item < (((ALN_ABL(a.dbg, 1)) || !a.gram_inline) ? 0 : CT2 * CT2); item += kTW) {
       const int it = item / CT2, jt = item % CT2;
       const float* pa = buf1 + half * ld1 + it * 32 + (lane & 31);
       const float* pb = buf1 + half * ld1 + jt * 32 + (lane & 31);
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 #pragma unroll
       for (int q = 0; q < kBfSlots; ++q) {
         const int ct = wave + q * kTW;
-        if (ct < CT3 && !(a.dbg & 8)) {
+        if (ct < CT3 && !(ALN_ABL(a.dbg, 8))) {
           f32x16 acc[2];
 #pragma unroll
           for (int m = 0; m < 2; ++m)
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
             if (row < nvalid && v > be) { be = v; bi = tile * kTT + row; }
           }
       }
-      if (live && !(a.dbg & 4)) { my_ext[col] = be; my_idx[col] = bi; }
+      if (live && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = be; my_idx[col] = bi; }
     }
   }
   if (!GIVEN && kRegSums) {
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
 #pragma unroll
     for (int q = 0; q < kBfSlots; ++q) {
       const int col = (wave + q * kTW) * 32 + (lane & 31);
-      if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
+      if (col < a.C3 && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
     }
 #pragma unroll
     for (int q = 0; q < kGramSlots; ++q) {

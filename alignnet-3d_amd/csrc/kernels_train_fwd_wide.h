@@ -14,6 +14,7 @@
 // test_phase3_tile_shapes_agree compares the two (bf16: bit-identical gradients in the test's shapes; over random shapes about one case in three,
 // the others differ by a value pushed over a bf16 rounding boundary downstream of the regrouped column sums: tools/stress_tile_shapes.py).
 #pragma once
+#include "ablate.h"
 #include "kernels_train_fwd.h"
 
 namespace alignnet {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     }
 
     // ---- keep h2 for the Gram and the sparse (arg-max) part of the backward: coalesced rows out of the LDS tile ----
-    if (!(a.dbg & 2)) {
+    if (!(ALN_ABL(a.dbg, 2))) {
       float* dst = a.h2_store + ((size_t)cloud * a.N + (size_t)tile * kWT) * C2;
       constexpr int c4 = C2 / 4;
       // (the thread's eight row / column offsets are tile-invariant: hoisted out of the tile loop they are 16 address registers held -- or
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
 #pragma unroll
     for (int q = 0; q < kWSlots; ++q) {
       const int col = (wave + q * kWW) * 32 + (lane & 31);
-      if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
+      if (col < a.C3 && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
     }
     if (!GIVEN) a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
   }
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
         if (u == q && cand > rbe[u]) { rbe[u] = cand; rbi[u] = ci; }
     }
   };
-  auto pieceA = [&](int t, bool more) { if (!(a.dbg & 64)) gram(); if (!(a.dbg & 2)) store_h2(t); if (more && !(a.dbg & 256)) lift(t + 1); };
+  auto pieceA = [&](int t, bool more) { if (!(ALN_ABL(a.dbg, 64))) gram(); if (!(ALN_ABL(a.dbg, 2))) store_h2(t); if (more && !(ALN_ABL(a.dbg, 256))) lift(t + 1); };
 
   // ---- prologue of tile 0 (not overlapped) ----
   request_xyz(0);
@@ -523,14 +524,14 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
     const bool more = t + 1 < ntiles;
     // ---- S0 ----
     if (early) pieceA(t, more);
-    if (!(a.dbg & 8)) lift3(t, 0, nA);
+    if (!(ALN_ABL(a.dbg, 8))) lift3(t, 0, nA);
     if (!early) pieceA(t, more);
     if (t + 2 < ntiles) request_xyz(t + 2);
     __syncthreads();
     // ---- S1 ----
-    if (early && more && !(a.dbg & 128)) hidden(t + 1);
-    if (!(a.dbg & 8)) lift3(t, nA, nct);
-    if (!early && more && !(a.dbg & 128)) hidden(t + 1);
+    if (early && more && !(ALN_ABL(a.dbg, 128))) hidden(t + 1);
+    if (!(ALN_ABL(a.dbg, 8))) lift3(t, nA, nct);
+    if (!early && more && !(ALN_ABL(a.dbg, 128))) hidden(t + 1);
     if (t + 2 < ntiles) store_xs();
     __syncthreads();
   }
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
 #pragma unroll
     for (int q = 0; q < kWSlots; ++q) {
       const int col = (wave + q * kWW) * 32 + (lane & 31);
-      if (col < a.C3 && !(a.dbg & 4)) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
+      if (col < a.C3 && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
     }
     a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
     float* my_gram = a.gram_part + (size_t)cloud * C2 * C2;

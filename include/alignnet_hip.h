@@ -192,6 +192,13 @@ int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
  *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */
 int alignnet_comm_unique_id(uint8_t id[128]);
+/* Id of a new IN-PROCESS loopback group (first bytes "ALN3LOOP"): alignnet_comm_init with such an id joins `world` handles of ONE
+ * process on ONE device, each driven by its own host thread, into a communicator whose collectives are stream-ordered device copies /
+ * sums with a host rendezvous (csrc/comm_loopback.h) instead of RCCL.  Every multi-rank code path of the engine -- sync_bn's per-layer
+ * sums, global_loss's gathers, the bucketed gradient all-reduce -- then runs with DIFFERENT shards on a 1-GPU box (tests/test_loopback_gpu.py:
+ * W = 2 / 8 ranks against one engine at the concatenated batch, BASELINE.json configs[3]).  All ranks must issue the same collectives in
+ * the same order (as with RCCL); a rank that fails breaks the group, the others return an error instead of waiting. */
+int alignnet_comm_loopback_id(uint8_t id[128]);
 int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
 int alignnet_comm_allreduce_grads(alignnet_handle* h);
 
@@ -267,9 +274,11 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   gfx950).  Outputs stay within the 1e-4 parity bar (measured 3e-6 against the fp64 oracle, like the exact path).
  *   Also covers the DGCNN branch with widths [<= 64, <= 128, C3]; other backbone shapes keep the exact-fp32 kernels.
  * "allreduce_overlap" (0/1, default 1): data-parallel training steps (alignnet_train_step*, communicator initialised) all-reduce the
- *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient, each issued as soon
- *   as that stage's backward has written it -- so that only the last (smallest) bucket is exposed; 0 = one all-reduce of the whole
- *   vector after the backward.  Same sums either way.
+ *   gradient in three buckets on a side stream -- the stage-3, stage-2 and stage-1 segment of the flat gradient.  A stage's deferred
+ *   weight-gradient jobs are flushed right behind that stage's backward, its bucket is issued at once and travels under the next stage's
+ *   backward, so that only the last (smallest, 14 % of the vector for the shipped widths) bucket is exposed; 0 = one all-reduce of the
+ *   whole vector after the backward.  Same sums either way.  (Without a communicator the three stages' jobs stay one group of five
+ *   launches after the whole backward.)
  * "train_dw_side_stream" (0/1, default 0): the weight-gradient jobs only the optimiser waits for are queued per stage on a second stream
  *   (under the next stage's backward; data-parallel: that stage's all-reduce bucket leaves right behind them) instead of as one group
  *   after the whole backward.  Same arithmetic, same summation order.  Slower on one GPU (measured).
@@ -291,10 +300,19 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "sync_bn_emulate_world" (test hook, default 1): without a communicator, stand for this many ranks holding identical shards.
  * "dropout_stream" (default 0): selects one of 2^64 independent device-side dropout streams under the same cfg.seed; data-parallel
  *   ranks set it to their rank so that they do not draw identical masks for their local rows (initialisation stays cfg.seed's).
+ * "ab_*" (0/1, default 0): A/B dispatch overrides -- each selects an earlier kernel variant of the SAME arithmetic for same-box comparisons
+ *   (results agree up to summation order; tests/test_train_gpu.py runs them against the default): "ab_no_ld_const", "ab_infer_tile64",
+ *   "ab_phase2_legacy", "ab_b1_legacy", "ab_b1_fp32", "ab_p3_bf16_generic", "ab_p3_nogram", "ab_no_defer", "ab_dg_sparse",
+ *   "ab_no_glue_fold" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic).
+ *   "ab_mask" (read-only) = the bits that are set; bench.py prints it.  The library reads NO environment variable; result-changing
+ *   ablation switches exist only in the separate ablation build (csrc/ablate.h, `make ablate`).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped
  * widths 64 / 128 dispatch to kernels with the widths compiled in):
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
- * "comm_world": number of ranks of the RCCL communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
+ * "comm_world": number of ranks of the communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
+ * "comm_order": issue order of the last training step's backward, one decimal digit per event: 1..3 = backward of stage 1..3 queued,
+ *   4..6 = all-reduce bucket of stage 1..3 issued (data-parallel step with "allreduce_overlap": 362514 -- every bucket leaves before the
+ *   next stage's backward is queued);
  * "last_train_kernel": bit mask of the most recent training step -- 1 = compile-time widths (64, 128), 2 = bf16 operands,
  *   4 = dgcnn backbone, 8 = at least one stage ran the general-depth (layer-by-layer) path, 16 = with its last layer on the fused
  *   kernels ("train_fused_tail").

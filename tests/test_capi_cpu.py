@@ -139,3 +139,28 @@ def test_no_register_is_rewritten_while_a_load_into_it_is_in_flight():
         nfun, nload, findings = S.scan(S.disassemble(o))
         assert nfun > 10 and nload > 100, (o, nfun, nload)
         assert not findings, findings[:5]
+
+
+def test_shipped_library_reads_no_environment_and_carries_no_ablation_switch():
+    """Round 3's library read ~20 ALIGNNET_* variables per training step, some of which (ALIGNNET_DBG) skipped work inside the kernels:
+    wrong gradients at a faster time, one variable away from a benchmark.  The shipped library now imports no getenv at all (A/B
+    kernel variants are alignnet_set_option "ab_*" keys, reported by bench.py) and the result-changing switches exist only in the
+    separate ablation build (csrc/ablate.h, `make ablate`): the ablation macro must be the constant 0 in this one."""
+    import subprocess
+    lib = os.path.join(ROOT, "alignnet-3d_amd", "libalignnet_hip.so")
+    nm = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True)
+    assert nm.returncode == 0, nm.stderr
+    undefined = {l.split()[-1].split("@")[0] for l in nm.stdout.splitlines() if l.strip()}
+    assert "getenv" not in undefined and "secure_getenv" not in undefined, "the shipped library must not read the environment"
+    raw = open(lib, "rb").read()
+    for name in (b"ALIGNNET_DBG", b"ALIGNNET_P3_NOGRAM", b"ALIGNNET_NO_DEFER", b"ALIGNNET_B1_LEGACY", b"ablate_dbg"):
+        assert name not in raw, name
+    src = os.path.join(ROOT, "alignnet-3d_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".h", ".hip")) and f != "ablate.h":
+            text = open(os.path.join(src, f)).read()
+            if f.endswith(".h"):   # device code (the host files only derive the stamp pointers from h->ablate_dbg, 0 in this build)
+                assert not re.search(r"\ba\.dbg\s*&", text), f"{f}: ablation test outside ALN_ABL()"
+            for m in re.finditer(r"getenv\(", text):
+                guard = text.rfind("#ifdef ALIGNNET_ABLATE", 0, m.start())
+                assert guard >= 0 and text.find("#endif", guard, m.start()) < 0, f"{f}: getenv outside an ALIGNNET_ABLATE block"
