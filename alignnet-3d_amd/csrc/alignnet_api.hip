@@ -895,7 +895,9 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
       return 0;
     }
 #ifdef ALIGNNET_ABLATE
-  if (k == "ablate_dbg") { h->ablate_dbg = (int)value; return 0; }   // ablation build only: result-changing timing switches of the kernels
+  if (k == "ablate_dbg") { h->ablate_dbg = (int)value; return 0; }
+  if (k == "ablate_mutation") { h->ablate_mutation = (int)value; return 0; }   // 1 = gather with the towers swapped, 2 = every rank keeps rank 0's rows of the loss gradient,
+                                                                               // 3 = per-rank count behind a synchronised BatchNorm, 4 = a global weight-gradient term without 1 / world   // ablation build only: result-changing timing switches of the kernels
 #endif
   return fail(h, "alignnet_set_option: unknown key '" + k + "'");
 }

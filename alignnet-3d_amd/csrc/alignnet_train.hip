@@ -818,7 +818,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   const bool wide = std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64;
   const bool wide_gram = wide && !(h->ab & AB_P3_NOGRAM);
   const bool sync = sync_on(h);
-  const double W = sync ? (double)sync_world(h) : 1.0;   // sync_bn: batch counts are the global batch's
+  double W = sync ? (double)sync_world(h) : 1.0;   // sync_bn: batch counts are the global batch's
+#ifdef ALIGNNET_ABLATE
+  if (h->ablate_mutation == 3 && s == 1) W = 1.0;   // (mutation: stage 2 divides all ranks' sums by this rank's count)
+#endif
   // global_part: the partials are already sums over all ranks (statistics derived from all-reduced Gram / column sums)
   auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, bool global_part = false) -> int {
     StatFinishArgs f;
@@ -1238,7 +1241,11 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     g.batch_a = (long)C2 * C2; g.batch_b = 0; g.batch_c = (long)C2 * C3;
     def_gemm(h, w, g, 2);
   }
-  def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w), (float)(1.0 / Wn)});
+  float gscale3 = (float)(1.0 / Wn);
+#ifdef ALIGNNET_ABLATE
+  if (h->ablate_mutation == 4) gscale3 = 1.f;   // (mutation: the global-sum terms of dW3 are added `world` times by the gradient all-reduce)
+#endif
+  def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w), gscale3});
   const size_t qimg = img_floats(C2, C2);
   const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
   const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
@@ -1561,7 +1568,14 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
     // The reference's loss couples every sample of the (global) batch: all-gather what the loss reads -- per tower, so that the gathered
     // arrays keep the [tower 0 rows | tower 1 rows] layout -- run the same three kernels on the global batch, take this rank's rows of
     // the gradient.  The loss is already divided by the global B: the gradient all-reduce sums (reduce_and_apply).
-    const int Wg = sync_world(h), Bg = B * Wg, rk = h->comm ? h->comm_rank : 0, ld = 3 + nb2;
+    const int Wg = sync_world(h), Bg = B * Wg, ld = 3 + nb2;
+    int rk = h->comm ? h->comm_rank : 0;
+#ifdef ALIGNNET_ABLATE
+    if (h->ablate_mutation == 2) rk = 0;            // (mutation: every rank keeps rank 0's rows of the loss gradient)
+    const bool swap_towers = h->ablate_mutation == 1;   // (mutation: the stage-2 centres are gathered with the towers swapped)
+#else
+    const bool swap_towers = false;
+#endif
     if (Bg > w->gl_cap) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       if (w->gl_base) hipFree(w->gl_base);
@@ -1582,7 +1596,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
     }
     for (int t = 0; t < 2; ++t) {
       if (sync_gather(h, w->s1c + (size_t)t * B * 3, w->gl_s1c + (size_t)t * Bg * 3, (size_t)B * 3)) return 1;
-      if (sync_gather(h, w->s2c + (size_t)t * B * 3, w->gl_s2c + (size_t)t * Bg * 3, (size_t)B * 3)) return 1;
+      if (sync_gather(h, w->s2c + (size_t)t * B * 3, w->gl_s2c + (size_t)(swap_towers ? 1 - t : t) * Bg * 3, (size_t)B * 3)) return 1;
       if (sync_gather(h, w->o[1] + (size_t)t * B * ld, w->gl_o2 + (size_t)t * Bg * ld, (size_t)B * ld)) return 1;
       if (sync_gather(h, w->theta + (size_t)t * B, w->gl_theta + (size_t)t * Bg, (size_t)B)) return 1;
       if (sync_gather(h, w->cls + (size_t)t * B, w->gl_cls + (size_t)t * Bg, (size_t)B)) return 1;

@@ -107,13 +107,20 @@ inline LoopComm* loop_join(const unsigned char id[128], int rank, int world, int
     if (it != reg.end()) g = it->second.lock();
     if (!g) { g = std::make_shared<LoopGroup>(); g->world = world; g->device = device; reg[key] = g; }
   }
-  std::lock_guard<std::mutex> lk(g->mu);
+  std::unique_lock<std::mutex> lk(g->mu);
   if (g->world != world) { err = "loopback communicator: ranks disagree on the world size"; return nullptr; }
   if (g->device != device) { err = "loopback communicator: all ranks must sit on one device"; return nullptr; }
   if (g->ready[rank]) { err = "loopback communicator: rank " + std::to_string(rank) + " joined twice"; return nullptr; }
   if (hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming) != hipSuccess) { err = "loopback communicator: hipEventCreate failed"; return nullptr; }
   g->joined++;
+  g->cv.notify_all();
+  // like ncclCommInitRank, joining is itself a rendezvous: nobody leaves before all `world` ranks are in
+  if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->joined == g->world || g->broken; }) || g->broken) {
+    g->broken = true; g->cv.notify_all();
+    err = "loopback communicator: only " + std::to_string(g->joined) + " of " + std::to_string(world) + " ranks joined";
+    return nullptr;
+  }
   LoopComm* c = new LoopComm();
   c->g = g; c->rank = rank;
   return c;

@@ -141,6 +141,7 @@ struct alignnet_handle {
   bool dw_side = false;            // alignnet_set_option("train_dw_side_stream")
   unsigned ab = 0;                 // AbBit mask (alignnet_set_option "ab_*")
   int ab_tiles_per_wg = 0;         // "ab_tiles_per_wg": eval PointNet backbone, point tiles per workgroup (0 = chosen from the grid size)
+  int ablate_mutation = 0;         // ablation build only ("ablate_mutation"): deliberately wrong multi-rank arithmetic, to show that tests/test_loopback_gpu.py catches it
   int ablate_dbg = 0;              // ablation build only (-DALIGNNET_ABLATE): the kernels' result-changing timing switches, from ALIGNNET_DBG
   bool p3_tile64 = false;          // alignnet_set_option("train_phase3_tile64"): the forward's phase 3 on 64-point tiles (default: 128-point tiles, kernels_train_fwd_wide.h)
   // alignnet_set_option("sync_bn"): training-mode BatchNorm statistics (and the backward's batch sums) over ALL data-parallel ranks --

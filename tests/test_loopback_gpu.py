@@ -6,6 +6,7 @@ couples all samples ([B, B] broadcasts models/tp8.py:279,327; whole-batch tf.con
 `global_loss` must therefore BE the single-device step at the concatenated batch: summed gradient, loss, EMA shadows, predictions.
 The checker is a single engine (no communicator) on the whole batch -- itself held to the oracle by tests/test_train_gpu.py and
 tests/test_fullsize_gpu.py -- plus, at B = 2048, the fp64 autograd oracle directly (BASELINE.json configs[3])."""
+import os
 import threading
 
 import numpy as np
@@ -13,7 +14,7 @@ import pytest
 
 import alignnet3d
 from oracle import alignnet_ref as R
-from tests.helpers import small_cfg, oracle_params
+from tests.helpers import small_cfg, oracle_params, logit_margin
 
 pytestmark = pytest.mark.gpu
 LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
@@ -96,6 +97,29 @@ def setup(backbone, N, B, std=True, seed=5, widths=None, fcw=32):
     return cfg, spec, P32, d, du
 
 
+def stable_setup(backbone, N, B, std, options, margin):
+    """setup() with the first data seed for which every pair's yaw class (the argmax of models/tp8.py:296, in both towers, train mode) is
+    decided by at least `margin` in the single engine: the sharded step then decodes the same classes, and the comparison is defined."""
+    for seed in range(5, 40):
+        cfg, spec, P32, d, du = setup(backbone, N, B, std=std, seed=seed)
+        single = single_engine(cfg, P32, d, du, options)
+        if float(yaw_margin(single[0], spec.num_bins).min()) >= margin:
+            return cfg, spec, P32, d, du, single
+    raise AssertionError("no seed with a yaw margin of %g" % margin)
+
+
+def decisive_yaw(P32, nb, cls=7, boost=8.0):
+    """Parameters whose stage-2 head decides the yaw class of every cloud by a wide margin (the bias of one class logit raised): with
+    thousands of pairs and a freshly initialised head some decodes (the argmax of models/tp8.py:296) always sit within rounding of a tie,
+    and one that falls the other way moves that pair's whole stage-3 branch, loss and gradient -- the comparison of two evaluations is then
+    undefined for that pair.  The residual logits still vary per cloud, so every pair keeps its own decoded angle."""
+    P = dict(P32)
+    b = np.array(P["siamese/transformer2/mlp/fc3/biases"], np.float32).copy()
+    b.reshape(-1)[3 + cls] += boost
+    P["siamese/transformer2/mlp/fc3/biases"] = b
+    return P
+
+
 def sharded_step(W, cfg, P32, d, du, options):
     """sync_bn + global_loss data-parallel forward/backward of W ranks on distinct shards, then the gradient all-reduce."""
     def body(r, eng):
@@ -111,38 +135,109 @@ def sharded_step(W, cfg, P32, d, du, options):
     return run_ranks(W, cfg, body, options=tuple(options) + (("sync_bn", 1), ("global_loss", 1)), variables=P32)
 
 
-def compare_with_single(ranks, single, gtol, ptol, ltol=2e-6, etol=2e-5, label=""):
+PRED = ("pred_translations", "pred_remaining_angle_logits", "pred_s1_pc1centers", "pred_s1_pc2centers", "pred_s2_pc1centers", "pred_s2_pc2centers",
+        "pred_pc1angle_logits", "pred_pc2angle_logits")
+
+
+def yaw_margin(res, nb):
+    """Smallest top-2 margin of the two towers' yaw class logits per pair: the argmax in the middle of the network (models/tp8.py:296) is
+    discontinuous, stage-3 outputs (and the gradient) of a pair are only comparable while both runs decode the same class."""
+    return np.minimum(logit_margin(res["pred_pc1angle_logits"], nb), logit_margin(res["pred_pc2angle_logits"], nb))
+
+
+def stage_of(name):
+    return "s1" if "transformer1" in name else "s2" if "transformer2" in name else "s3"
+
+
+def grad_metrics(ga, gb):
+    """whole-vector cosine / relative L2 of two gradient dicts, the same per backbone stage, and the worst tensor (error relative to the tensor's
+    own largest entry, tensors below 1 % of the largest gradient entry measured against that floor)."""
+    names = list(gb)
+    gs = max(float(np.abs(v).max()) for v in gb.values())
+    va, vb = np.concatenate([ga[n].ravel() for n in names]), np.concatenate([gb[n].ravel() for n in names])
+    out = dict(cos=float(va @ vb / (np.linalg.norm(va) * np.linalg.norm(vb))), rl2=float(np.linalg.norm(va - vb) / np.linalg.norm(vb)))
+    for st in ("s1", "s2", "s3"):
+        num = sum(float(np.sum((ga[n] - gb[n]) ** 2)) for n in names if stage_of(n) == st)
+        den = sum(float(np.sum(gb[n] ** 2)) for n in names if stage_of(n) == st)
+        out[st] = float(np.sqrt(num / den))
+    worst = max(names, key=lambda n: float(np.abs(ga[n] - gb[n]).max()) / (float(np.abs(gb[n]).max()) + 1e-2 * gs))
+    out["worst"] = (worst, float(np.abs(ga[worst] - gb[worst]).max()) / (float(np.abs(gb[worst]).max()) + 1e-2 * gs))
+    return out
+
+
+def one_ulp_sensitivity(cfg, P32, d, du, options, base):
+    """How far the SINGLE engine's own gradient moves when every input coordinate moves by ~1e-6 m (about one fp32 ulp at 10 m): each of the
+    2 B C3 max-pool winners per stage is an argmax over N points, and a winner that changes moves that (cloud, channel)'s whole gradient to
+    another point.  The sharded step differs from the single engine by rounding of the same size (its batch sums are added in another order),
+    so this is the noise floor any comparison of the two sits on."""
+    rng = np.random.default_rng(1)
+    d2 = dict(d)
+    for k in ("pcs1", "pcs2"):
+        d2[k] = (d[k] + 1e-6 * rng.standard_normal(d[k].shape)).astype(np.float32)
+    pert = single_engine(cfg, P32, d2, du, options)
+    return grad_metrics(pert[1], base[1])
+
+
+def compare_with_single(ranks, single, nb, label=""):
+    """Every difference between the W-rank step and the single engine at the concatenated batch, measured and printed (the committed
+    profiles/r04_gpu_tests_loopback.log keeps the lines the bars were set from); the caller asserts."""
     rf, gf, ef = single
     names = list(gf)
     gs = max(float(np.abs(v).max()) for v in gf.values())
-    worst, worst_name = 0.0, ""
+    stable = yaw_margin(rf, nb) > 1e-3
+    m = dict(loss=max(abs(rk["res"]["loss"] - rf["loss"]) / max(1.0, abs(rf["loss"])) for rk in ranks),
+             summaries=max(abs(a - b) / max(1.0, abs(b)) for rk in ranks for a, b in zip(rk["res"]["summaries"].values(), rf["summaries"].values())),
+             ema=max(float((np.abs(v - ef[n]) / (1.0 + np.abs(ef[n]))).max()) for rk in ranks for n, v in rk["ema"].items()))
+    pred, flips = 0.0, 0
     for rk in ranks:
-        assert abs(rk["res"]["loss"] - rf["loss"]) <= ltol * max(1.0, abs(rf["loss"])), (rk["res"]["loss"], rf["loss"])
-        for i, s in enumerate(rk["res"]["summaries"].values()):
-            assert abs(s - list(rf["summaries"].values())[i]) <= 10 * ltol * max(1.0, abs(s))
-        for k in ("pred_translations", "pred_remaining_angle_logits", "pred_s1_pc1centers", "pred_s2_pc2centers", "pred_pc1angle_logits", "pred_pc2angle_logits"):
-            np.testing.assert_allclose(rk["res"][k], rf[k][rk["lo"]:rk["hi"]], rtol=ptol, atol=ptol, err_msg=k)
-        for n, v in rk["ema"].items():
-            np.testing.assert_allclose(v, ef[n], rtol=etol, atol=etol, err_msg=n)
-        for n in names:   # every rank holds the same sums, bit for bit (the loopback sums in rank order on every rank)
+        st = stable[rk["lo"]:rk["hi"]]
+        for k in PRED:
+            a, b = rk["res"][k], rf[k][rk["lo"]:rk["hi"]]
+            if k in ("pred_translations", "pred_remaining_angle_logits"):
+                a, b = a[st], b[st]
+            if a.size:
+                pred = max(pred, float(np.abs(a - b).max()))
+        for k in ("pred_pc1angle_logits", "pred_pc2angle_logits"):
+            flips += int(np.sum(np.argmax(rk["res"][k][:, :nb], 1) != np.argmax(rf[k][rk["lo"]:rk["hi"], :nb], 1)))
+    m.update(pred=pred, unstable=int((~stable).sum()), yaw_flips=flips)
+    for rk in ranks:   # every rank holds the same sums, bit for bit (the loopback sums in rank order on every rank)
+        for n in names:
             np.testing.assert_array_equal(rk["summed"][n], ranks[0]["summed"][n], err_msg=n)
-    # the all-reduced gradient is the sum of the ranks' local ones ...
-    for n in names:
+    for n in names:    # the all-reduced gradient is the sum of the ranks' local ones
         tot = sum(rk["local"][n] for rk in ranks)
         np.testing.assert_allclose(ranks[0]["summed"][n], tot, rtol=1e-6, atol=1e-7 * gs, err_msg=n)
-    # ... and equals the single engine's gradient at the concatenated batch
-    for n in names:
-        err = float(np.abs(ranks[0]["summed"][n] - gf[n]).max())
-        rel = err / (float(np.abs(gf[n]).max()) + 1e-3 * gs)
-        if rel > worst:
-            worst, worst_name = rel, n
-        assert err <= gtol * float(np.abs(gf[n]).max()) + 1e-2 * gtol * gs, (n, err, float(np.abs(gf[n]).max()))
-    ga = np.concatenate([ranks[0]["summed"][n].ravel() for n in names]); gb = np.concatenate([gf[n].ravel() for n in names])
-    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
-    rl2 = float(np.linalg.norm(ga - gb) / np.linalg.norm(gb))
-    print("loopback %s: %d ranks vs one engine at the concatenated batch: loss %.7f / %.7f, whole gradient cosine %.8f, relative L2 %.2e, "
-          "worst tensor %s %.2e" % (label, len(ranks), ranks[0]["res"]["loss"], rf["loss"], cos, rl2, worst_name, worst))
-    return cos, rl2
+    m.update(grad_metrics(ranks[0]["summed"], gf))
+    print("loopback %s: %d ranks vs one engine at the concatenated batch: loss %.7f / %.7f (rel %.1e, summaries %.1e), predictions %.2e (%d pairs near a yaw tie "
+          "excluded from the stage-3 outputs, %d yaw classes differ), EMA %.2e, whole gradient cosine %.8f, relative L2 %.2e (stages 1 / 2 / 3: %.1e %.1e %.1e), "
+          "worst tensor %s %.2e" % (label, len(ranks), ranks[0]["res"]["loss"], rf["loss"], m["loss"], m["summaries"], m["pred"], m["unstable"], m["yaw_flips"],
+                                    m["ema"], m["cos"], m["rl2"], m["s1"], m["s2"], m["s3"], m["worst"][0], m["worst"][1]))
+    return m
+
+
+def check(m, loss, pred, ema, rl2, worst, cos=None):
+    assert m["yaw_flips"] == 0, m["yaw_flips"]
+    assert m["loss"] <= loss and m["summaries"] <= 20 * loss, (m["loss"], m["summaries"])
+    assert m["pred"] <= pred, m["pred"]
+    assert m["ema"] <= ema, m["ema"]
+    assert m["rl2"] <= rl2 and m["worst"][1] <= worst, (m["rl2"], m["worst"])
+    if cos is not None:
+        assert m["cos"] >= cos, m["cos"]
+
+
+# (loss, predictions, EMA, whole-gradient relative L2, worst tensor): 2 x the values this test printed when it was written
+# (profiles/r04_gpu_tests_loopback.log).  The runs are deterministic (fixed seeds, rank-order sums), so the margin is for other boxes' clocks
+# only.  Well-conditioned cases (widths 32 / 64; every layer-by-layer stage) sit at rounding level -- those are the cases that would catch a
+# wrong count, a missing 1 / world or a wrong row; the shipped widths 64 / 128 at N = 128 sit on their max-pool noise floor (one_ulp_sensitivity,
+# printed next to them): per stage, the sharded step is as far from the single engine as the single engine is from itself on inputs moved by one ulp.
+BARS = {
+    ("pointnet", 0, False): dict(loss=5e-6, pred=1e-4, ema=1e-5, rl2=2e-5, worst=3e-5),                 # measured 6.4e-6 / 1.1e-5
+    ("pointnet", 0, True): dict(loss=5e-6, pred=1e-4, ema=1e-5, rl2=2.5e-3, worst=1e-2),                 # 1.1e-3 / 4.9e-3; one-ulp floor 2.1e-3 / 5.3e-3
+    ("pointnet", 1, True): dict(loss=1.2e-3, pred=5e-2, ema=4e-3, rl2=1.7e-1, worst=2e-1),               # 8.2e-2 / 9.1e-2; floor 1.8e-1 / 2.3e-1
+    ("dgcnn", 0, True): dict(loss=5e-6, pred=1e-4, ema=1e-5, rl2=7e-3, worst=4e-2),                      # 3.4e-3 / 2.0e-2; floor 2.4e-3 / 8.3e-3
+    # (bf16 edge convs on 16 pairs x 128 points: two max-pools per stage on bf16-rounded operands -- the single engine itself moves by 0.29 on
+    #  inputs moved by one ulp; this case checks that the path runs on distinct shards and keeps the direction, the sums are the fp32 case's code)
+    ("dgcnn", 1, True): dict(loss=1.5e-2, pred=8e-2, ema=6e-3, rl2=0.6, worst=0.9, cos=0.9),             # 2.9e-1 / 4.5e-1; floor 2.9e-1 / 3.9e-1
+}
 
 
 @pytest.mark.parametrize("W", [2, 8])
@@ -151,20 +246,21 @@ def test_sharded_step_equals_single_engine(gpu_required, W, backbone, bf16, std)
     """W = 2 and 8 ranks with distinct shards of one batch of 16 pairs, every fused backbone mode (the modes of
     tests/test_train_gpu.py::test_sync_bn_*): loss, predictions, EMA shadows and the summed gradient equal one engine's step."""
     N, B = 128, 16
-    cfg, spec, P32, d, du = setup(backbone, N, B, std=std, seed=7 if backbone == "dgcnn" else 5)
     opts = (("train_matmul_bf16", bf16),)
-    single = single_engine(cfg, P32, d, du, opts)
+    cfg, spec, P32, d, du, single = stable_setup(backbone, N, B, std, opts, margin=0.05 if bf16 else 0.01)
     ranks = sharded_step(W, cfg, P32, d, du, opts)
-    # fp32: the shards' partial sums are added in another order than the single engine's (measured <= 3e-5 of a tensor's largest entry);
-    # bf16 operands: a value next to a rounding boundary of h2 / dy2 may round the other way (the same noise the rounded-oracle tests carry)
-    compare_with_single(ranks, single, gtol=(3e-2 if bf16 else 5e-4), ptol=(2e-2 if bf16 else 2e-5), ltol=(2e-4 if bf16 else 2e-6),
-                        etol=(2e-3 if bf16 else 2e-5), label="%s %s W=%d" % (backbone, "bf16" if bf16 else "fp32", W))
+    m = compare_with_single(ranks, single, spec.num_bins, label="%s %s %s W=%d" % (backbone, "bf16" if bf16 else "fp32", "64/128" if std else "32/64", W))
+    sens = one_ulp_sensitivity(cfg, P32, d, du, opts, single)
+    print("   single engine vs itself on inputs moved by one ulp: relative L2 %.2e (stages 1 / 2 / 3: %.1e %.1e %.1e), worst tensor %s %.2e" % (
+        sens["rl2"], sens["s1"], sens["s2"], sens["s3"], sens["worst"][0], sens["worst"][1]))
+    check(m, **BARS[(backbone, bf16, std)])
 
 
 @pytest.mark.parametrize("backbone,tail", [("pointnet", 1), ("pointnet", 0), ("dgcnn", 1)])
 def test_sharded_step_general_depth(gpu_required, backbone, tail):
     """Stages that train layer by layer (any depth / widths; gen_stat_finish's three launches around two all-reduces, gen_bn_bwd_finish's
-    coefficient totals) with four distinct shards."""
+    coefficient totals) with four distinct shards.  Every batch sum of that path is fp64: with train_fused_tail off (and for the dgcnn
+    path) the four-rank step reproduces the single engine to the last bits; the hybrid stages' fused tails add their max-pool noise."""
     N, B, W = 128, 16, 4
     if backbone == "dgcnn":
         w = dict(s1=(32, 32, 64, 96), s2=(48, 96, 128), emb=(64, 160))
@@ -174,7 +270,11 @@ def test_sharded_step_general_depth(gpu_required, backbone, tail):
     opts = (("train_fused_tail", tail),)
     single = single_engine(cfg, P32, d, du, opts)
     ranks = sharded_step(W, cfg, P32, d, du, opts)
-    compare_with_single(ranks, single, gtol=5e-4, ptol=2e-5, label="%s general depth tail=%d W=%d" % (backbone, tail, W))
+    m = compare_with_single(ranks, single, spec.num_bins, label="%s general depth tail=%d W=%d" % (backbone, tail, W))
+    if backbone == "pointnet" and tail:
+        check(m, loss=5e-6, pred=1e-4, ema=1e-5, rl2=2.6e-2, worst=4e-2)
+    else:
+        check(m, loss=1e-6, pred=1e-6, ema=1e-6, rl2=2e-6, worst=5e-6)
 
 
 def test_local_bn_averaged_gradient_is_mean_of_shard_gradients(gpu_required):
@@ -237,53 +337,114 @@ def test_collective_mismatch_and_failed_rank_do_not_hang(gpu_required):
 
 def test_configs3_partition_8x256_n1024(gpu_required):
     """BASELINE.json configs[3] at its real partition on one GPU: 8 ranks x 256 pairs, N = 1024, SynthCars widths, sync_bn +
-    global_loss, against ONE engine taking all 2048 pairs (4096-row head BatchNorms, the [B, B] loss terms at 4 M entries).  fp32 and
-    bf16 convs.  Also the first execution of B = 2048 x N = 1024 on the single engine at all."""
+    global_loss, against ONE engine taking all 2048 pairs (4096-row head BatchNorms, the [B, B] loss terms at 4 M entries; the first
+    execution of B = 2048 x N = 1024 on the single engine at all).  fp32 and bf16 convs.  At this size (12 M max-pool decisions, 4096
+    yaw decodes) some decisions always sit within rounding of a tie, so this is the property check: loss, EMA, predictions of the
+    yaw-stable pairs at rounding level; the gradient as close to the single engine's as the single engine's is to itself on inputs moved
+    by one ulp (printed; bars = 2 x the committed measurement, profiles/r04_gpu_tests_loopback.log)."""
     W, Bs, N = 8, 256, 1024
     cfg = alignnet3d.default_model_config()
     cfg["training"]["batch_size"] = W * Bs
     spec, P32 = oracle_params(cfg, seed=11)
+    P32 = decisive_yaw(P32, spec.num_bins)
     d = R.synth_pairs(W * Bs, N, seed=11, dtype=np.float32)
     rng = np.random.default_rng(11)
     du = {k: rng.uniform(size=(W * Bs, 256)).astype(np.float32) for k in U}
     for bf16 in (0, 1):
         opts = (("train_matmul_bf16", bf16),)
         single = single_engine(cfg, P32, d, du, opts)
-        assert np.isfinite(single[0]["loss"])
+        assert np.isfinite(single[0]["loss"]) and float(yaw_margin(single[0], spec.num_bins).min()) > 1.0
         ranks = sharded_step(W, cfg, P32, d, du, opts)
-        # full size: 2 M points per tower behind every batch statistic; the fp32 bars are 2 x what this test printed when it was
-        # written (profiles/r04_gpu_tests_fullsize.log), the per-tensor bar only has to catch a wrong factor or a wrong row
-        cos, rl2 = compare_with_single(ranks, single, gtol=(5e-2 if bf16 else 2e-3), ptol=(3e-2 if bf16 else 5e-5), ltol=(5e-4 if bf16 else 5e-6),
-                                       etol=(5e-3 if bf16 else 5e-5), label="configs[3] 8 x 256 x 1024 %s" % ("bf16" if bf16 else "fp32"))
-        assert cos > (0.9995 if bf16 else 0.999999) and rl2 < (3e-2 if bf16 else 1e-3), (cos, rl2)
+        m = compare_with_single(ranks, single, spec.num_bins, label="configs[3] 8 x 256 x 1024 %s" % ("bf16" if bf16 else "fp32"))
+        sens = one_ulp_sensitivity(cfg, P32, d, du, opts, single)
+        print("   single engine vs itself on inputs moved by one ulp: cosine %.6f, relative L2 %.2e (stages 1 / 2 / 3: %.1e %.1e %.1e), worst tensor %s %.2e" % (
+            sens["cos"], sens["rl2"], sens["s1"], sens["s2"], sens["s3"], sens["worst"][0], sens["worst"][1]))
+        # 2 x the committed measurement (fp32: loss 4e-9, EMA 3e-7, predictions 8e-5, relative L2 7.8e-3, cosine 0.99997; bf16: 3e-7, 1.2e-4, 3.4e-2, 8.8e-2, 0.9961)
+        bars = dict(loss=5e-6, ema=3e-4, pred=7e-2, rl2=0.18, cos=0.99) if bf16 else dict(loss=1e-6, ema=2e-6, pred=2e-4, rl2=1.6e-2, cos=0.9999)
+        assert m["yaw_flips"] == 0 and m["unstable"] == 0, (m["yaw_flips"], m["unstable"])   # (decisive_yaw: no pair of this batch sits near a yaw tie)
+        assert m["loss"] <= bars["loss"] and m["summaries"] <= 200 * bars["loss"] and m["ema"] <= bars["ema"] and m["pred"] <= bars["pred"], m
+        assert m["rl2"] <= bars["rl2"] and m["cos"] >= bars["cos"], (m["rl2"], m["cos"])
+        assert m["rl2"] <= 2.0 * sens["rl2"] + 1e-3, (m["rl2"], sens["rl2"])   # not further from the single engine than its own one-ulp noise floor
 
 
 def test_configs3_b2048_sharded_matches_autograd(gpu_required):
     """configs[3]'s arithmetic against the ORACLE through the sharded path: 8 ranks x 256 pairs at N = 128 (the shape of
-    tests/test_fullsize_gpu.py::test_train_b2048_matches_autograd, whose fp64 autograd oracle fits) -- loss, EMA and the all-reduced
-    gradient of the data-parallel step against torch autograd on the whole batch."""
+    tests/test_fullsize_gpu.py::test_train_b2048_matches_autograd, whose fp64 autograd oracle fits) -- loss, EMA, predictions and the
+    all-reduced gradient of the data-parallel step against torch autograd on the whole batch, with the single engine's distance to the
+    same oracle printed next to it (the sharded step must not be further from the oracle than the single engine is, up to the noise floor)."""
     from tests import test_train_gpu as TT
     W, Bs, N = 8, 256, 128
     cfg = alignnet3d.default_model_config()
     cfg["model"]["num_points"] = N
     cfg["training"]["batch_size"] = W * Bs
     spec, P32 = oracle_params(cfg, seed=11)
+    P32 = decisive_yaw(P32, spec.num_bins)
     d = R.synth_pairs(W * Bs, N, seed=11, dtype=np.float32)
     rng = np.random.default_rng(11)
     du = {k: rng.uniform(size=(W * Bs, 256)).astype(np.float32) for k in U}
     ranks = sharded_step(W, cfg, P32, d, du, ())
+    single = single_engine(cfg, P32, d, du, ())
     ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, 0.5, checkpoint=True)
     assert abs(ranks[0]["res"]["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (ranks[0]["res"]["loss"], loss_ref)
+    stable = yaw_margin(ep_ref, spec.num_bins) > 1e-3
     for rk in ranks:
+        st = stable[rk["lo"]:rk["hi"]]
         for k in ep_ref:
-            np.testing.assert_allclose(rk["res"][k], ep_ref[k][rk["lo"]:rk["hi"]], rtol=2.5e-4, atol=2.5e-4, err_msg=k)
+            a, b = rk["res"][k], ep_ref[k][rk["lo"]:rk["hi"]]
+            if k in ("pred_translations", "pred_remaining_angle_logits"):
+                a, b = a[st], b[st]
+            np.testing.assert_allclose(a, b, rtol=2.5e-4, atol=2.5e-4, err_msg=k)
     for k, v in ema_ref.items():
         np.testing.assert_allclose(ranks[0]["ema"][k], v, rtol=1e-4, atol=1e-5, err_msg=k)
     bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
     names = [n for n in R.trainable_names(spec) if n not in bn_bias]
-    gv = np.concatenate([ranks[0]["summed"][n].ravel() for n in names])
-    rv = np.concatenate([np.asarray(grads[n], np.float64).ravel() for n in names])
-    cos = float(gv @ rv / (np.linalg.norm(gv) * np.linalg.norm(rv)))
-    rl2 = float(np.linalg.norm(gv - rv) / np.linalg.norm(rv))
-    print("configs[3] sharded (8 x 256, N = 128) vs fp64 autograd: loss %.6f / %.6f, whole gradient cosine %.7f, relative L2 %.2e" % (ranks[0]["res"]["loss"], loss_ref, cos, rl2))
-    assert cos > 0.99999 and rl2 < 5e-3, (cos, rl2)
+    ref = {n: np.asarray(grads[n], np.float64).reshape(single[1][n].shape) for n in names}
+    ms = grad_metrics({n: ranks[0]["summed"][n] for n in names}, ref)
+    m1 = grad_metrics({n: single[1][n] for n in names}, ref)
+    print("configs[3] sharded (8 x 256, N = 128) vs fp64 autograd: loss %.6f / %.6f, whole gradient cosine %.7f, relative L2 %.2e (stages %.1e %.1e %.1e); "
+          "the single engine at B = 2048 vs the same oracle: cosine %.7f, relative L2 %.2e (stages %.1e %.1e %.1e)" % (
+              ranks[0]["res"]["loss"], loss_ref, ms["cos"], ms["rl2"], ms["s1"], ms["s2"], ms["s3"], m1["cos"], m1["rl2"], m1["s1"], m1["s2"], m1["s3"]))
+    assert ms["cos"] > 0.9999 and ms["rl2"] < 1.8e-2, (ms["cos"], ms["rl2"])   # (measured 0.99996 / 8.7e-3; the single engine 0.99998 / 6.0e-3)
+    assert ms["rl2"] <= 2.0 * m1["rl2"] + 1e-3, (ms["rl2"], m1["rl2"])
+
+
+MUTATION_WORKER = r"""
+import json, os, sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np
+import alignnet3d
+from tests import test_loopback_gpu as L
+cfg, spec, P32, d, du, single = L.stable_setup("pointnet", 128, 16, False, (), margin=0.01)
+out = {}
+for mut in range(5):
+    ranks = L.sharded_step(2, cfg, P32, d, du, (("ablate_mutation", mut),))
+    m = L.compare_with_single(ranks, single, spec.num_bins, label="mutation %%d" %% mut)
+    out[mut] = {k: (v if not isinstance(v, tuple) else list(v)) for k, v in m.items()}
+print("MUTATIONS " + json.dumps(out))
+"""
+
+
+def test_wrong_multi_rank_arithmetic_is_caught(gpu_required, tmp_path):
+    """The bars of this file against deliberately wrong multi-rank code: the ablation build of the library (csrc/ablate.h, `make ablate`;
+    never loaded by the product) can gather the stage-2 centres with the towers swapped (1), keep rank 0's rows of the loss gradient on
+    every rank (2), divide all ranks' BatchNorm sums by this rank's count (3), or leave the 1 / world off a weight-gradient term built
+    from global sums (4).  Mutation 0 (none) must meet the bars of the well-conditioned case; every other one must miss them by far."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "alignnet-3d_amd", "libalignnet_hip_ablate.so")
+    assert os.path.exists(lib), "libalignnet_hip_ablate.so not built (python __graft_entry__.py build)"
+    script = tmp_path / "mutations.py"
+    script.write_text(MUTATION_WORKER % {"root": root, "pkg": os.path.join(root, "alignnet-3d_amd")})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, ALIGNNET_HIP_LIB=lib))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    m = json.loads([l for l in r.stdout.splitlines() if l.startswith("MUTATIONS ")][0][len("MUTATIONS "):])
+    bars = BARS[("pointnet", 0, False)]
+    for mut, v in sorted(m.items()):
+        print("mutation %s: loss %.1e predictions %.1e EMA %.1e relative L2 %.1e worst tensor %.1e" % (mut, v["loss"], v["pred"], v["ema"], v["rl2"], v["worst"][1]))
+    ok = lambda v: v["loss"] <= bars["loss"] and v["pred"] <= bars["pred"] and v["ema"] <= bars["ema"] and v["rl2"] <= bars["rl2"] and v["worst"][1] <= bars["worst"]
+    assert ok(m["0"]), m["0"]
+    for mut in ("1", "2", "3", "4"):
+        assert not ok(m[mut]), (mut, m[mut])
+        assert m[mut]["rl2"] > 100 * bars["rl2"] or m[mut]["loss"] > 100 * bars["loss"], (mut, m[mut])   # not a near miss: orders of magnitude
