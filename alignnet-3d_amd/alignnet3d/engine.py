@@ -134,6 +134,7 @@ class Engine:
             raise EngineError(self._lib.alignnet_last_error(None).decode())
         self.num_points = self._c.num_points
         self.num_bins = self._c.num_bins
+        self._inflight = []   # output arrays of submitted, not yet waited-for batches (forward_submit / forward_wait)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -208,11 +209,11 @@ class Engine:
         p1, p2 = self._check_pcs(pcs1, pcs2)
         arrs, o = self._alloc_outputs(p1.shape[0])
         self._check(self._lib.alignnet_forward_submit(self._h, _fp(p1), _fp(p2), p1.shape[0], C.byref(o)))
-        if not hasattr(self, "_inflight"):
-            self._inflight = []
         self._inflight.append(arrs)   # (the C side writes into these arrays at wait(): keep them alive)
 
     def forward_wait(self):
+        if not self._inflight:
+            raise EngineError("forward_wait: no batch in flight")
         self._check(self._lib.alignnet_forward_wait(self._h))
         return self._inflight.pop(0)
 

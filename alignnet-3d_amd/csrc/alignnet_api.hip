@@ -196,7 +196,7 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h);
 extern "C" int alignnet_dataset_free(alignnet_handle* h);
 extern "C" void alignnet_comm_free(alignnet_handle* h);
 
-namespace { void pipe_free(alignnet_handle* h); }   // pipelined host path, defined with alignnet_forward_submit below
+namespace { void pipe_free(alignnet_handle* h); hipStream_t pipe_stream(alignnet_handle* h, int which); }   // pipelined host path, defined with alignnet_forward_submit below
 
 extern "C" void alignnet_destroy(alignnet_handle* h)
 {
@@ -738,6 +738,7 @@ void pipe_free(alignnet_handle* h)
   delete p;
   h->pipe = nullptr;
 }
+hipStream_t pipe_stream(alignnet_handle* h, int which) { Pipe* p = static_cast<Pipe*>(h->pipe); return which ? p->s_out : p->s_in; }
 }  // namespace
 
 extern "C" int alignnet_forward_wait(alignnet_handle* h)
@@ -799,19 +800,28 @@ extern "C" int alignnet_forward_submit(alignnet_handle* h, const float* pcs1, co
   const size_t nin = (size_t)B * N * 3 * sizeof(float);
   std::memcpy(s.h_in[0], pcs1, nin);   // (host work: overlaps the previous batch's forward on the GPU)
   std::memcpy(s.h_in[1], pcs2, nin);
-  HIP_TRY(h, hipMemcpyAsync(s.d_in[0], s.h_in[0], nin, hipMemcpyHostToDevice, p->s_in));
-  HIP_TRY(h, hipMemcpyAsync(s.d_in[1], s.h_in[1], nin, hipMemcpyHostToDevice, p->s_in));
-  HIP_TRY(h, hipEventRecord(s.ev_in, p->s_in));
-  HIP_TRY(h, hipStreamWaitEvent(h->stream, s.ev_in, 0));
-  if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;
-  if (forward_device(h, s.d_in[0], s.d_in[1], B, s.d_outs)) return 1;
-  HIP_TRY(h, hipEventRecord(s.ev_fwd, h->stream));
-  HIP_TRY(h, hipStreamWaitEvent(p->s_out, s.ev_fwd, 0));
-  size_t tot = s.out_off[7] + (((size_t)B * widths[7] + 63) & ~(size_t)63);
-  (void)tot;
-  for (int i = 0; i < 8; ++i)
-    HIP_TRY(h, hipMemcpyAsync(s.h_out + s.out_off[i], s.d_outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
-  HIP_TRY(h, hipEventRecord(s.ev_out, p->s_out));
+  // From the first enqueue on, a failure must not leave work of this slot in flight: `submitted` is not advanced, so the next submit
+  // reuses the same pinned / device buffers.  Everything queued so far is drained before the error is returned.
+  auto enqueue = [&]() -> int {
+    HIP_TRY(h, hipMemcpyAsync(s.d_in[0], s.h_in[0], nin, hipMemcpyHostToDevice, p->s_in));
+    HIP_TRY(h, hipMemcpyAsync(s.d_in[1], s.h_in[1], nin, hipMemcpyHostToDevice, p->s_in));
+    HIP_TRY(h, hipEventRecord(s.ev_in, p->s_in));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, s.ev_in, 0));
+    if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;
+    if (forward_device(h, s.d_in[0], s.d_in[1], B, s.d_outs)) return 1;
+    HIP_TRY(h, hipEventRecord(s.ev_fwd, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(p->s_out, s.ev_fwd, 0));
+    for (int i = 0; i < 8; ++i)
+      HIP_TRY(h, hipMemcpyAsync(s.h_out + s.out_off[i], s.d_outs[i], (size_t)B * widths[i] * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    HIP_TRY(h, hipEventRecord(s.ev_out, p->s_out));
+    return 0;
+  };
+  if (enqueue()) {
+    const std::string keep = h->err;
+    hipStreamSynchronize(p->s_in); hipStreamSynchronize(h->stream); hipStreamSynchronize(p->s_out);
+    h->err = keep;
+    return 1;
+  }
   s.user = *out; s.B = B; s.busy = true;
   p->submitted++;
   return 0;
@@ -858,6 +868,10 @@ extern "C" int alignnet_synchronize(alignnet_handle* h)
   if (!h) return 1;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->pipe) {   // the pipelined host path's copy streams (alignnet_forward_submit)
+    HIP_TRY(h, hipStreamSynchronize(pipe_stream(h, 0)));
+    HIP_TRY(h, hipStreamSynchronize(pipe_stream(h, 1)));
+  }
   return 0;
 }
 
@@ -870,7 +884,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   const std::string k(key);
   if (k == "train_matmul_bf16") { h->train_bf16 = value != 0; return 0; }
   if (k == "allreduce_overlap") { h->comm_overlap = value != 0; return 0; }
-  if (k == "train_dw_side_stream") { h->dw_side = value != 0; return 0; }
+  if (k == "train_dw_side_stream") { if (value < 0 || value > 2) return fail(h, "train_dw_side_stream: 0, 1 or 2"); h->dw_side = (int)value; return 0; }
   if (k == "train_phase3_tile64") { h->p3_tile64 = value != 0; return 0; }
   if (k == "dropout_stream") { h->dropout_stream = (uint64_t)value; return 0; }
   if (k == "sync_bn") { h->sync_bn = value != 0; return 0; }
@@ -909,7 +923,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "train_matmul_bf16") { *value = h->train_bf16 ? 1 : 0; return 0; }
   if (k == "infer_matmul_bf16x3") { *value = h->infer_split ? 1 : 0; return 0; }
   if (k == "allreduce_overlap") { *value = h->comm_overlap ? 1 : 0; return 0; }
-  if (k == "train_dw_side_stream") { *value = h->dw_side ? 1 : 0; return 0; }
+  if (k == "train_dw_side_stream") { *value = h->dw_side; return 0; }
   if (k == "train_phase3_tile64") { *value = h->p3_tile64 ? 1 : 0; return 0; }
   if (k == "dropout_stream") { *value = (int64_t)h->dropout_stream; return 0; }
   if (k == "sync_bn") { *value = h->sync_bn ? 1 : 0; return 0; }
@@ -917,6 +931,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "sync_bn_emulate_world") { *value = h->sync_emulate_world; return 0; }
   if (k == "comm_world") { *value = h->comm ? h->comm_world : 0; return 0; }
   if (k == "comm_order") { *value = h->comm_order; return 0; }
+  if (k == "sync_collectives") { *value = h->sync_collectives; return 0; }
   if (k == "ab_tiles_per_wg") { *value = h->ab_tiles_per_wg; return 0; }
   if (k == "ab_mask") { *value = h->ab; return 0; }
   for (const auto& ak : kAbKeys) if (k == ak.key) { *value = (h->ab & ak.bit) ? 1 : 0; return 0; }

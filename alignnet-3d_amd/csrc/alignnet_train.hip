@@ -34,6 +34,13 @@ static int fail(const alignnet_handle* h, const std::string& m) { h->err = m; re
 static int sync_world(const alignnet_handle* h) { return h->comm ? h->comm_world : h->sync_emulate_world; }
 static bool sync_on(const alignnet_handle* h) { return h->sync_bn && sync_world(h) > 1; }
 static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double);
+// two float buffers that the workspace carve laid out back to back travel as ONE all-reduce (a step's ~30 per-layer sums are latency-bound)
+static int sync_sum2(alignnet_handle* h, float* a, size_t na, float* b, size_t nb)
+{
+  if (b == a + na) return sync_sum(h, a, na + nb, false);
+  if (a == b + nb) return sync_sum(h, b, na + nb, false);
+  return sync_sum(h, a, na, false) || sync_sum(h, b, nb, false);
+}
 static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4);   // n4 four-byte elements per rank; dst = [world][n4]
 static bool gloss_on(const alignnet_handle* h) { return h->global_loss && sync_world(h) > 1; }
 constexpr size_t kSyncBufDoubles = 4 * 4096;
@@ -648,7 +655,6 @@ static int set_lds_attrs(alignnet_handle* h)
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dg_train_bwd_edge_dense<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(stat3_pool_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (+ 8.5 KiB static)
   done.mark(h->cfg.device);
   return 0;
 }
@@ -849,7 +855,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) -> int {
     ja.out = S.gram2raw; ja.upper_c = C2;   // (only the upper 32 x 32 blocks of the per-cloud Grams are valid -- and read)
     launch_reduce_multi(h, 2, ja, jb);
-    if (sync && (sync_sum(h, S.gram2raw, (size_t)2 * C2 * C2, false) || sync_sum(h, S.s2, (size_t)2 * C2, false))) return 1;
+    if (sync && (sync_sum2(h, S.gram2raw, (size_t)2 * C2 * C2, S.s2, (size_t)2 * C2))) return 1;
     return 0;
   };
   if (dg) {
@@ -886,7 +892,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
       launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
-      if (sync && (sync_sum(h, S.g1f, (size_t)2 * C1 * C1, false) || sync_sum(h, S.s1e, (size_t)2 * C1, false))) return 1;
+      if (sync && (sync_sum2(h, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1))) return 1;
       hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount * W,
                          h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
@@ -985,7 +991,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
     launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
-    if (sync && (sync_sum(h, S.g1f, (size_t)2 * C1 * C1, false) || sync_sum(h, S.s1e, (size_t)2 * C1, false))) return 1;
+    if (sync && (sync_sum2(h, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1))) return 1;
     hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
                        h->train_bf16 ? 1 : 0, w->stat_part);
     if (finish(1, C2, 1, count, 1, true)) return 1;
@@ -1045,7 +1051,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.Gc = S.gram2; f.m2 = S.m2;
     f.pa = PoolFinishArgs{S.ext, S.idx2, S.sgn3, P(h, L[2]->p_b), S.scale[2], S.shift[2], S.mean[2], S.var[2], B, C3, S.pooled,
                           S.tower_stride, S.row_stride, S.zhat_star, S.idx, 1};
-    hipLaunchKernelGGL(stat3_pool_finish_kernel, dim3((C3 + kS3C - 1) / kS3C, 2), dim3(1024), stat3_lds_bytes(C2), h->stream, f);
+    hipLaunchKernelGGL(stat3_pool_finish_kernel, dim3((C3 + kS3C - 1) / kS3C, 2), dim3(512), stat3_lds_bytes(C2), h->stream, f);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -1522,6 +1528,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   alignnet_get_state(h, &stt);
   const float bn_decay = stt.bn_decay;
   if (set_lds_attrs(h)) return 1;
+  h->sync_collectives = 0;
   if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;   // (as the eval forward does: ~15 event pairs per profiled step)
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
@@ -1631,7 +1638,10 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   // stage's head / prep chains (a few workgroups each, most of the chip idle), and in data-parallel steps the stage's gradient segment
   // is final -- and its all-reduce bucket on its way -- two stages earlier than with one flush at the end.  sync_bn keeps the single
   // flush on the compute stream (its reduced matrices are summed over the ranks between the job groups).
-  const bool side = w->defer.on && h->dw_side && !sync_on(h);
+  // "train_dw_side_stream": 1 = every stage's deferred jobs on a second (low-priority) stream right behind that stage's backward; 2 = only
+  // stage 3's (55 % of the deferred work: its sparse gather reads 134 MB of h2 rows) -- they then run under the head / prep chains of
+  // stages 2 and 1, where a handful of workgroups leave most of the chip idle; the rest stays one group after the backward
+  const int side_mode = (w->defer.on && !sync_on(h)) ? h->dw_side : 0;
   // Data-parallel steps (communicator + "allreduce_overlap"): a stage's deferred jobs are flushed right behind that stage's backward, so
   // that its segment of the flat gradient is final and its all-reduce bucket leaves on the comm stream UNDER the next stage's backward:
   // stage 3's bucket (64 % of the vector for the shipped widths) travels under stages 2 and 1, stage 2's (23 %) under stage 1, only the
@@ -1640,9 +1650,11 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   h->comm_order = 0;
   auto stage_flush = [&](int sg) -> int {
     h->comm_order = h->comm_order * 10 + 1 + sg;   // "comm_order": digit 1..3 = that stage's backward is queued, 4..6 = that stage's bucket is issued
-    if (side) {
+    if (side_mode == 1 || (side_mode == 2 && sg == 2)) {
       if (!h->side_stream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority: the passes on the compute stream go first wherever both want a CU
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, lo));
         for (auto& e : h->side_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }
       HIP_TRY(h, hipEventRecord(h->side_ev[sg], h->stream));
@@ -1675,10 +1687,11 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (head_bwd_train(h, 0, w->st[0].pooled, C1l, w->st[0].dP, B2, B, u_dev)) return 1;
   if (backbone_bwd_train(h, 0, p1, p2, B)) return 1;
   if (stage_flush(0)) return 1;
-  if (side) {
+  if (w->defer.on && flush_deferred(h, h->stream)) return 1;   // whatever is still recorded (no communicator: all three stages' weight gradients, five multi-job launches)
+  if (side_mode) {
     HIP_TRY(h, hipEventRecord(h->side_ev[3], h->side_stream));   // the optimiser (compute stream) reads the whole gradient
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->side_ev[3], 0));
-  } else if (w->defer.on && flush_deferred(h, h->stream)) return 1;   // no communicator: the weight gradients of all three stages, five multi-job launches
+  }
   w->defer.on = false;
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -2129,6 +2142,7 @@ __global__ void scale_buf_kernel(T* __restrict__ p, size_t n, T f)
 // "sync_bn_emulate_world" = w stands for w ranks holding identical shards: every sum is w times this rank's.
 static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
 {
+  h->sync_collectives++;
   if (h->comm) return comm_allreduce(h, buf, n, is_double, h->stream, "sync_bn");
   const unsigned grid = (unsigned)((n + 255) / 256);
   if (is_double) hipLaunchKernelGGL(scale_buf_kernel<double>, dim3(grid), dim3(256), 0, h->stream, static_cast<double*>(buf), n, (double)h->sync_emulate_world);
@@ -2140,6 +2154,7 @@ static int sync_sum(alignnet_handle* h, void* buf, size_t n, bool is_double)
 // without a communicator "sync_bn_emulate_world" = w stands for w ranks holding identical shards: w copies
 static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4)
 {
+  h->sync_collectives++;
   if (h->comm) return comm_allgather(h, src, dst, n4, h->stream);
   for (int r = 0; r < h->sync_emulate_world; ++r)
     HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dst) + (size_t)r * n4 * 4, src, n4 * 4, hipMemcpyDeviceToDevice, h->stream));

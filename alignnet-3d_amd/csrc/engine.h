@@ -138,7 +138,7 @@ struct alignnet_handle {
   // next stage's backward (alignnet_train.hip: flush_deferred); [stage] = that stage's backward done on the compute stream, [3] = all flushed
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool dw_side = false;            // alignnet_set_option("train_dw_side_stream")
+  int dw_side = 0;                 // alignnet_set_option("train_dw_side_stream"): 0 = off, 1 = every stage, 2 = stage 3 only
   unsigned ab = 0;                 // AbBit mask (alignnet_set_option "ab_*")
   int ab_tiles_per_wg = 0;         // "ab_tiles_per_wg": eval PointNet backbone, point tiles per workgroup (0 = chosen from the grid size)
   int ablate_mutation = 0;         // ablation build only ("ablate_mutation"): deliberately wrong multi-rank arithmetic, to show that tests/test_loopback_gpu.py catches it
@@ -154,6 +154,7 @@ struct alignnet_handle {
                                    // identical virtual ranks (a step must then reproduce the plain local-BN step on the same shard)
   double* sync_buf = nullptr;      // staging for the per-layer totals that travel through the all-reduce
   int comm_buckets = 0;            // bucket all-reduces issued by the last training step (0: one all-reduce after the backward)
+  int sync_collectives = 0;        // sync_bn / global_loss collectives (all-reduces of per-layer sums, gathers) the last training step issued ("sync_collectives")
   long long comm_order = 0;        // last training step, one decimal digit per event in issue order: 1..3 = backward of stage 1..3 queued, 4..6 = bucket of stage 1..3 issued
   mutable std::string err;
 };

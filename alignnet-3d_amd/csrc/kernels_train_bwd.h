@@ -1055,7 +1055,13 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
   const long i = blockIdx.x * 32L + cl;
   double s = 0.0;
   if (i < n)
-    for (int k = g; k < S; k += 32) s += (double)part[((size_t)t * S + k) * n + i];
+    for (int k = g; k < S; k += 32 * 8) {   // eight loads in flight per round trip, summed in slice order
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int ku = k + 32 * u; v[u] = ku < S ? part[((size_t)t * S + ku) * n + i] : T(0); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && i < n) {
@@ -1119,8 +1125,27 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
   if (bx * 32L >= jb.n) return;
   double s = 0.0;
   if (i < jb.n) {
-    if (jb.is_double) { const double* p = static_cast<const double*>(jb.part); for (int k = g; k < jb.S; k += 32) s += p[((size_t)t * jb.S + k) * jb.n + i]; }
-    else { const float* p = static_cast<const float*>(jb.part); for (int k = g; k < jb.S; k += 32) s += (double)p[((size_t)t * jb.S + k) * jb.n + i]; }
+    // eight independent loads per round trip (a job of thousands of slices x a few dozen columns -- the column sums of h1: 2048 x 64 --
+    // runs on two workgroups per tower and was a 64-deep chain of L2 round trips per thread: 21 us); same summation order as before
+    if (jb.is_double) {
+      const double* p = static_cast<const double*>(jb.part) + (size_t)t * jb.S * jb.n + i;
+      for (int k = g; k < jb.S; k += 32 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int ku = k + 32 * u; v[u] = ku < jb.S ? p[(size_t)ku * jb.n] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    } else {
+      const float* p = static_cast<const float*>(jb.part) + (size_t)t * jb.S * jb.n + i;
+      for (int k = g; k < jb.S; k += 32 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int ku = k + 32 * u; v[u] = ku < jb.S ? p[(size_t)ku * jb.n] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+      }
+    }
   }
   red[g][cl] = s;
   __syncthreads();
@@ -1197,102 +1222,110 @@ struct Stat3Args {
   PoolFinishArgs pa;     // ext / idx2 / sgn / bias / pooled / zhat_star / idx (scale, shift, mean, var: the arrays above)
 };
 
-constexpr int kS3C = 8;   // channels per workgroup: (C3 / 8) x 2 workgroups -- 256 at C3 = 1024 (with 32 channels per workgroup the launch ran on 64 CUs: 45 us)
-__global__ __launch_bounds__(1024) void stat3_pool_finish_kernel(const Stat3Args a)
+// Round 4: the quadratic forms on the fp64 matrix pipe.  Rounds 2 - 3 gave a workgroup 8 channels: every one of the 256 workgroups staged
+// and centred the whole 64 KB Gram in LDS to evaluate eight 128 x 128 forms on the VALU (28.6 us per launch, three launches per step).
+// Now a workgroup owns 16 channels; wave w forms T[16 rows i of tile w][16 channels] = Ghat[i, :] W[:, c] with C2 / 4
+// `v_mfma_f64_16x16x4_f64` -- A = the centred Gram row (centred in fp64 on the fly from the reduced upper blocks: no LDS staging, no
+// barrier), B = the W3 columns -- and q_c = sum_i W[i, c] T[i, c] is finished by two shuffles and an 8-way sum over the waves.
+// C/D layout of the f64 form (cdna_hip_programming.md 3): col = lane & 15, row = (lane >> 4) + 4 reg.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kS3C = 16;   // channels per workgroup; block = 8 waves (one 16-row tile of the Gram each: C2 <= 128)
+__global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args a)
 {
-  extern __shared__ __attribute__((aligned(16))) float smem3[];
-  __shared__ double red[1024 / kS3C][kS3C];
-  __shared__ float cst[4][kS3C];   // mean, var, scale, shift of the block's channels
-  const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, cl = tid % kS3C, g = tid / kS3C, c = blockIdx.x * kS3C + cl;
-  constexpr int kG = 1024 / kS3C;                                     // row groups
-  float* Gs = smem3;                                                  // [C2][C2 + 1]
-  double* ws = reinterpret_cast<double*>(Gs + (((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1));   // [C2][kS3C]
-  double* ss = ws + (size_t)C2 * kS3C;                                // [C2]
+  __shared__ double red[8][2][kS3C];   // [wave][q | s.w][channel]
+  __shared__ float cst[4][kS3C];       // mean, var, scale, shift of the block's channels
+  const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * kS3C, cj = lane & 15, kq = lane >> 4, c = c0 + cj;
   const float* G = a.G + (size_t)t * C2 * C2;
+  const float* sv = a.s + (size_t)t * C2;
   const double invM = 1.0 / a.M;
-  for (int i = tid; i < C2; i += 1024) ss[i] = (double)a.s[t * C2 + i];
-  for (int e = tid; e < C2 * kS3C; e += 1024) {
-    const int i = e / kS3C, cc = blockIdx.x * kS3C + (e % kS3C);
+  auto wcol = [&](int i, int cc) -> double {   // W3[i][cc], as the lift saw it
     float w = cc < C3 ? a.W[(size_t)i * C3 + cc] : 0.f;
     if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
-    ws[e] = (double)w;
+    return (double)w;
+  };
+  auto ghat = [&](int i, int j) -> double {   // centred Gram from the reduced upper 32 x 32 blocks
+    const float raw = (i >> 5) <= (j >> 5) ? G[(size_t)i * C2 + j] : G[(size_t)j * C2 + i];
+    return (double)raw - (double)sv[i] * ((double)sv[j] * invM);
+  };
+  double qp = 0.0, swp = 0.0;
+  if (wave * 16 < C2) {
+    const int i = wave * 16 + cj;          // A row of this lane
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < C2; k0 += 16) {  // four MFMAs per round: 8 loads in flight per lane
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = k0 + 4 * u + kq; av[u] = ghat(i, k); bv[u] = wcol(k, c); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ir = wave * 16 + kq + 4 * r;   // D row of register r
+      const double w = wcol(ir, c);
+      qp += w * acc[r];
+      swp += (double)sv[ir] * w;
+    }
   }
-  __syncthreads();
-  // centred Gram into LDS (mirroring the blocks below the diagonal); rows [r0, r1) of it also go to HBM for the backward
-  const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
-  const bool pow2 = (C2 & (C2 - 1)) == 0;
-  const int sh2 = 31 - __builtin_clz(C2);
-  for (int e = tid; e < C2 * C2; e += 1024) {
-    const int i = pow2 ? e >> sh2 : e / C2, j = e - i * C2;   // (a run-time division per element was a quarter of this kernel)
-    const float raw = (i >> 5) <= (j >> 5) ? G[e] : G[(size_t)j * C2 + i];
-    const float v = (float)((double)raw - ss[i] * (ss[j] * invM));
-    Gs[i * (C2 + 1) + j] = v;
-    if (i >= r0 && i < r1) a.Gc[(size_t)t * C2 * C2 + e] = v;
-  }
-  if (blockIdx.x == 0) for (int i = tid; i < C2; i += 1024) a.m2[t * C2 + i] = (float)(ss[i] * invM);
-  __syncthreads();
-  // q_c = w_c^T Ghat w_c for the block's 8 channels.  Thread (row i, j-slice): one Ghat element feeds eight multiply-adds (one per
-  // channel; the channels' weights come as four 16-byte LDS reads), so the LDS traffic per multiply-add is a fifth of a
-  // one-channel-per-thread loop's.  Then a butterfly over the lanes and a 16-way sum over the waves.
+  qp += __shfl_xor(qp, 16); qp += __shfl_xor(qp, 32);
+  swp += __shfl_xor(swp, 16); swp += __shfl_xor(swp, 32);
+  if (lane < kS3C) { red[wave][0][lane] = qp; red[wave][1][lane] = swp; }
+  // rows [r0, r1) of the centred Gram (all blocks) and the column means go to HBM for the backward
   {
-    const int nsl = 1024 / C2 > 0 ? 1024 / C2 : 1;                 // j-slices (8 at C2 = 128)
-    const int i = tid % C2, js = tid / C2;
-    double acc8[kS3C];
-#pragma unroll
-    for (int k = 0; k < kS3C; ++k) acc8[k] = 0.0;
-    if (js < nsl) {
-      const int jw = (C2 + nsl - 1) / nsl, j0 = js * jw, j1 = min(C2, j0 + jw);
-      const float* gr = Gs + i * (C2 + 1);
-      for (int j = j0; j < j1; ++j) {
-        const double gv = (double)gr[j];
-#pragma unroll
-        for (int k = 0; k < kS3C; ++k) acc8[k] += gv * ws[j * kS3C + k];
-      }
-#pragma unroll
-      for (int k = 0; k < kS3C; ++k) acc8[k] *= ws[i * kS3C + k];
+    const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
+    for (int e = tid; e < (r1 - r0) * C2; e += 512) {
+      const int i = r0 + e / C2, j = e % C2;
+      a.Gc[(size_t)t * C2 * C2 + (size_t)i * C2 + j] = (float)ghat(i, j);
     }
-#pragma unroll
-    for (int k = 0; k < kS3C; ++k) {
-      double v = acc8[k];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if ((tid & 63) == 0) red[tid >> 6][k] = v;
-    }
+    if (blockIdx.x == 0) for (int i = tid; i < C2; i += 512) a.m2[t * C2 + i] = (float)((double)sv[i] * invM);
   }
   __syncthreads();
-  if (g == 0 && c < C3) {
+  if (tid < kS3C && c0 + tid < C3) {
+    const int cc = c0 + tid;
     double Q = 0.0, sw = 0.0;
-    for (int k = 0; k < 16; ++k) Q += red[k][cl];
-    for (int i = 0; i < C2; ++i) sw += ss[i] * ws[i * kS3C + cl];
-    const float bias = a.pa.bias[c];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { Q += red[w][0][tid]; sw += red[w][1][tid]; }
+    const float bias = a.pa.bias[cc];
     const float mf = (float)(sw * invM + (double)bias), vf = (float)fmax(Q * invM, 0.0);
-    const float rs = 1.0f / sqrtf(vf + kBnEps), inv = a.gamma[t][c] * rs;
-    a.mean[t * C3 + c] = mf; a.var[t * C3 + c] = vf;
-    a.scale[t * C3 + c] = inv; a.shift[t * C3 + c] = (bias - mf) * inv + a.beta[t][c];
-    a.rstd[t * C3 + c] = rs; a.k[t * C3 + c] = inv;
+    const float rs = 1.0f / sqrtf(vf + kBnEps), inv = a.gamma[t][cc] * rs;
+    a.mean[t * C3 + cc] = mf; a.var[t * C3 + cc] = vf;
+    a.scale[t * C3 + cc] = inv; a.shift[t * C3 + cc] = (bias - mf) * inv + a.beta[t][cc];
+    a.rstd[t * C3 + cc] = rs; a.k[t * C3 + cc] = inv;
     if (a.update_ema) {
-      a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);
-      a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
+      a.mov_mean[t][cc] -= (1.f - a.bn_decay) * (a.mov_mean[t][cc] - mf);
+      a.mov_var[t][cc] -= (1.f - a.bn_decay) * (a.mov_var[t][cc] - vf);
     }
-    cst[0][cl] = mf; cst[1][cl] = vf; cst[2][cl] = inv; cst[3][cl] = (bias - mf) * inv + a.beta[t][c];
+    cst[0][tid] = mf; cst[1][tid] = vf; cst[2][tid] = inv; cst[3][tid] = (bias - mf) * inv + a.beta[t][cc];
   }
   __syncthreads();
   if (c >= C3) return;
-  // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices)
+  // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices):
+  // 16 channels x 32 cloud groups, four clouds in flight per thread
   const PoolFinishArgs& p = a.pa;
-  const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cl], rs = 1.0f / sqrtf(cst[1][cl] + kBnEps), sc = cst[2][cl], sh = cst[3][cl];
-  for (int b = g; b < p.B; b += kG) {
-    const int cloud = t * p.B + b;
-    const size_t h0 = ((size_t)cloud * 2) * C3 + c, h1 = h0 + C3, i = (size_t)cloud * C3 + c;
-    float e = p.ext[h0]; int bi = p.idx2[h0];
-    const float e1 = p.ext[h1]; const int b1 = p.idx2[h1];
-    if (e1 > e || (e1 == e && b1 < bi)) { e = e1; bi = b1; }
-    p.idx[i] = bi;
-    p.pooled[t * p.tower_stride + b * p.row_stride + c] = fmaxf(fmaf(e * sg, sc, sh), 0.f);
-    p.zhat_star[i] = (e * sg + bias - mf) * rs;
+  const int g = tid >> 4;
+  const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cj], rs = 1.0f / sqrtf(cst[1][cj] + kBnEps), sc = cst[2][cj], sh = cst[3][cj];
+  for (int b0 = g; b0 < p.B; b0 += 32 * 4) {
+    float e0[4], e1[4]; int i0[4], i1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = min(b0 + 32 * u, p.B - 1);
+      const size_t h0 = ((size_t)(t * p.B + b) * 2) * C3 + c, h1 = h0 + C3;
+      e0[u] = p.ext[h0]; i0[u] = p.idx2[h0]; e1[u] = p.ext[h1]; i1[u] = p.idx2[h1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 32 * u;
+      if (b >= p.B) break;
+      float e = e0[u]; int bi = i0[u];
+      if (e1[u] > e || (e1[u] == e && i1[u] < bi)) { e = e1[u]; bi = i1[u]; }
+      const size_t i = (size_t)(t * p.B + b) * C3 + c;
+      p.idx[i] = bi;
+      p.pooled[t * p.tower_stride + b * p.row_stride + c] = fmaxf(fmaf(e * sg, sc, sh), 0.f);
+      p.zhat_star[i] = (e * sg + bias - mf) * rs;
+    }
   }
 }
-inline size_t stat3_lds_bytes(int C2) { return ((((size_t)C2 * (C2 + 1) + 1) & ~(size_t)1)) * sizeof(float) + ((size_t)C2 * kS3C + C2) * sizeof(double); }
+inline size_t stat3_lds_bytes(int) { return 0; }   // (static LDS only since round 4)
 
 // last layer: per (tower, channel): dbeta3 = sum_b g0, dgamma3 = sum_b g0 zhat*, E, k*dbeta, gs = k*g0
 struct Prep3Args {

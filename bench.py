@@ -78,7 +78,10 @@ def _blocks(c):
     return t * (t + 1) // 2 * 1024
 
 
-def kernel_macs(cfg, kernel, bf16):
+P3_FUSED_GRAM = True   # fp32 phase 3 of the shipped widths accumulates Gram(h2) in the same pass (set from the engine's options in main())
+
+
+def kernel_macs(cfg, kernel, bf16, with_gram=True):
     """MACs per CLOUD, summed over the three stages, that `kernel`'s algorithm executes in this design:
     the recompute of the cheap early layers is part of each pass, the dense backward through the C2 -> C3 lift is replaced by
     the Gram identities.  3-layer backbones [C1, C2, C3] (the only trainable shape)."""
@@ -94,7 +97,7 @@ def kernel_macs(cfg, kernel, bf16):
     for (c1, c2, c3) in [w[:3] for w in stage_widths(cfg)]:
         if kernel == "train_fwd_phase3":       # h1, h2 recomputed from xyz, z3 = h2 W3 (+ the Gram of h2 inside the bf16 kernel)
             # (+ the Gram of h2: inside the bf16 kernels, and inside the fp32 128-point kernel of the shipped widths -- csrc/kernels_train_fwd_wide.h)
-            fused_gram = bf16 or ((c1, c2) == (64, 128) and not os.environ.get("ALIGNNET_P3_TILE64") and not os.environ.get("ALIGNNET_P3_NOGRAM"))
+            fused_gram = with_gram and (bf16 or ((c1, c2) == (64, 128) and P3_FUSED_GRAM))
             tot += (n * (c2 * c3) if dg else n * (k0 * c1 + c1 * c2 + c2 * c3)) + (n * _blocks(c2) if fused_gram else 0)
         elif kernel == "train_fwd_phase2":     # fp32: h1 + Gram(h1) (statistics of z2 from the Gram); bf16: h1 + z2 = h1 W2
             tot += n * (k0 * c1 + (c1 * c2 if bf16 else _blocks(c1)))
@@ -169,6 +172,162 @@ def cpu_baseline(cfg, seconds_per_setting=4.0):
                       f"~{seconds_per_setting:.0f} s per thread setting, forward only (cf. reference train.py:447-449); value = best setting"}
 
 
+ALLOWED_ENV = {"ALIGNNET_HIP_LIB"}   # another build of the same sources for same-box A/B runs; reported in the line as `options.library`
+
+
+def refuse_stray_environment():
+    """The library reads no environment variable (tests/test_capi_cpu.py), and a benchmark line must not depend on one either: any
+    ALIGNNET_* variable other than the documented switch above aborts the run (round 3: ALIGNNET_DBG skipped work inside the kernels)."""
+    stray = sorted(k for k in os.environ if k.startswith("ALIGNNET_") and k not in ALLOWED_ENV)
+    if stray:
+        sys.stderr.write("bench.py: refusing to run with %s set (kernel variants are engine options `ab_*`, reported in the line)\n" % ", ".join(stray))
+        raise SystemExit(2)
+
+
+def engine_options(eng):
+    """The option set the timed engine ran with (every key that changes which kernels run), for the JSON line."""
+    import alignnet3d
+    keys = ("train_matmul_bf16", "infer_matmul_bf16x3", "train_fused_tail", "train_phase3_tile64", "train_dw_side_stream", "allreduce_overlap",
+            "sync_bn", "global_loss", "ab_mask", "ab_tiles_per_wg")
+    o = {k: eng.get_option(k) for k in keys}
+    o["library"] = os.path.basename(alignnet3d.library_path())
+    try:   # the ablation build (csrc/ablate.h) knows this key; the shipped library does not
+        eng.set_option("ablate_dbg", 0)
+        o["ablation_build"] = True
+    except Exception:   # noqa: BLE001
+        o["ablation_build"] = False
+    return o
+
+
+def extra_legs(eng, local_rank, min_seconds):
+    """Short secondary legs appended to the default one-GPU inference run so that the driver's record carries BASELINE.json configs[4]
+    (DGCNN, N = 4096) and the SURVEY 8(f) rows: dgcnn inference at one GPU's share of configs[4] (512 pairs), dgcnn training steps
+    (fp32 / bf16 convs, 64 pairs), the batch loader (reference-style files vs packed cache on the host; HBM-resident dataset + device
+    sampler feeding training steps) and the ICP refinement.  About 6 s in total; never part of `value`."""
+    import tempfile
+    import torch
+    import alignnet3d
+    from alignnet3d.synth import synth_pairs
+    dev = torch.device("cuda", local_rank)
+    out = {}
+    t_begin = time.perf_counter()
+
+    def timed(step, sync, floor=3):
+        step(); sync()
+        t0 = time.perf_counter(); step(); sync()
+        est = max(time.perf_counter() - t0, 1e-5)
+        k = max(floor, int(math.ceil(min_seconds / est)))
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        sync()
+        return (time.perf_counter() - t0) / k, k
+
+    # ---- DGCNN branch (models/tp8.py:30-46), BASELINE.json configs[4]: N = 4096, 4096 pairs over 8 GPUs = 512 per GPU
+    try:
+        cfg = alignnet3d.default_model_config()
+        cfg["model"]["num_points"], cfg["model"]["backbone"] = 4096, "dgcnn"
+        Bi, Bt = 512, 64
+        cfg["training"]["batch_size"] = Bt
+        dg = alignnet3d.Engine(cfg, device=local_rank, seed=0)
+        for name, shp, _ in dg.variables():
+            if name.endswith("moving_var"):
+                dg.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
+        d = synth_pairs(Bi, 4096, seed=4321, dtype=np.float32)
+        p1, p2 = torch.from_numpy(d["pcs1"]).to(dev), torch.from_numpy(d["pcs2"]).to(dev)
+        lab = {k: torch.from_numpy(np.ascontiguousarray(d[k][:Bt])).to(dev) for k in ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")}
+        nb2 = 2 * cfg["model"]["angles"]["num_bins"]
+        outs = {k: torch.empty(Bi, nb2 if "logits" in k else 3, device=dev) for k in alignnet3d.OUTPUT_NAMES}
+        ptrs = {k: v.data_ptr() for k, v in outs.items()}
+        dg.profile_enable(True); dg.profile_read(reset=True)
+        sec, k = timed(lambda: dg.forward_device(p1.data_ptr(), p2.data_ptr(), Bi, ptrs), dg.synchronize, floor=2)
+        kern = dg.profile_kernels(); dg.profile_read(reset=True)
+        n_timed = k + 2
+        bb_ms = kern.get("backbone", (0.0, 0))[0] / n_timed
+        flops = 2.0 * backbone_macs_per_cloud(cfg) * 2 * Bi
+        out["dgcnn"] = {"infer": {"value": round(Bi / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": k, "pairs_per_step": Bi, "num_points": 4096,
+                                  "dtype": "f32", "kernel": dg.last_backbone_kernel(), "backbone_ms_per_step": round(bb_ms, 3),
+                                  "knn_ms_per_step": round(kern.get("knn", (0.0, 0))[0] / n_timed, 3),
+                                  "roofline_frac": round(flops / (bb_ms * 1e-3) / 1e12 / PEAK_F32, 4) if bb_ms > 0 else None,
+                                  "what": "BASELINE.json configs[4] at one GPU's share (512 of 4096 pairs), eval-mode forward, inputs in HBM"}}
+        labp = {k: v.data_ptr() for k, v in lab.items()}
+        for tdtype in ("f32", "bf16"):
+            dg.set_option("train_matmul_bf16", int(tdtype == "bf16"))
+            dg.profile_read(reset=True)
+            sec, k = timed(lambda: dg.train_step_device(p1.data_ptr(), p2.data_ptr(), labp, Bt), dg.synchronize, floor=2)
+            kern = dg.profile_kernels(); dg.profile_read(reset=True)
+            out["dgcnn"]["train_" + tdtype] = {"value": round(Bt / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": k, "pairs_per_step": Bt,
+                                               "num_points": 4096, "kernel_ms_per_step": {n: round(v[0] / (k + 2), 3) for n, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:5]},
+                                               "last_train_kernel": dg.get_option("last_train_kernel")}
+        dg.profile_enable(False)
+        dg.close()
+        del p1, p2, outs
+    except Exception as e:   # noqa: BLE001 -- a secondary leg must not cost the line
+        out["dgcnn"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- batch loader (SURVEY 8 f1): provider.load_batch on reference-style files vs the packed cache (host), then the HBM-resident dataset
+    n_ex, pts = 256, 1500
+    dd = synth_pairs(n_ex, pts, seed=99, dtype=np.float32)
+    try:
+        import config as cfgmod
+        import provider
+        with tempfile.TemporaryDirectory() as tmp:
+            root = os.path.join(tmp, "SynthBench")
+            for sub in ("meta", "pointcloud1", "pointcloud2", "split"):
+                os.makedirs(os.path.join(root, sub))
+            txt = lambda v: "\n".join("%.18e" % x for x in np.ravel(v)) + "\n"
+            for i in range(n_ex):
+                json.dump({"translation": txt(dd["translations"][i]), "rel_angle": float(dd["rel_angles"][i, 0]), "start_position": txt(dd["pc1_centers"][i]),
+                           "end_position": txt(dd["pc2_centers"][i]), "start_angle": float(dd["pc1_angles"][i, 0]), "end_angle": float(dd["pc2_angles"][i, 0])},
+                          open(os.path.join(root, "meta", "%08d.json" % i), "w"))
+                np.save(os.path.join(root, "pointcloud1", "%08d.npy" % i), dd["pcs1"][i]); np.save(os.path.join(root, "pointcloud2", "%08d.npy" % i), dd["pcs2"][i])
+            for f in ("train", "val"):
+                open(os.path.join(root, "split", f + ".txt"), "w").write("\n".join(map(str, range(n_ex))) + "\n")
+            cfgp = os.path.join(tmp, "c.json")
+            json.dump({"data": {"basepath": root}, "logging": {"basedir": tmp}, "model": {"num_points": 1024}, "training": {"batch_size": 128}}, open(cfgp, "w"))
+            cfgmod.reset_config()
+            cfgmod.load_config(cfgp)
+            idx = list(range(128))
+            np.random.seed(0); t = time.perf_counter(); a = provider.load_batch(idx); t_file = time.perf_counter() - t
+            t = time.perf_counter(); provider.use_packed_cache(); t_pack = time.perf_counter() - t
+            np.random.seed(0); t = time.perf_counter(); b = provider.load_batch(idx); t_packed = time.perf_counter() - t
+            same = all(np.array_equal(x, y) for x, y in zip(a, b))
+            cfgmod.reset_config()
+        out["loader"] = {"file_based_pairs_per_s": round(128 / t_file, 1), "packed_pairs_per_s": round(128 / t_packed, 1), "packing_seconds": round(t_pack, 3),
+                         "identical_batches": bool(same), "examples": n_ex, "points_per_cloud": pts,
+                         "what": "provider.load_batch (provider.py:85-136) of 128 examples resampled to N = 1024: per-example json + npy files as the reference reads them, "
+                                 "vs the packed cache (alignnet3d/packed.py), same seeded batch"}
+    except Exception as e:   # noqa: BLE001
+        out["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- HBM-resident dataset + device sampler feeding training steps, and the ICP refinement on the same uploaded clouds (SURVEY 8 f1, f4)
+    try:
+        import evaluation
+        off = np.zeros((n_ex + 1, 2), np.int64); off[1:, 0] = off[1:, 1] = np.arange(1, n_ex + 1) * pts
+        labt = np.concatenate([dd["translations"], dd["rel_angles"], dd["pc1_centers"], dd["pc2_centers"], dd["pc1_angles"], dd["pc2_angles"]], 1).astype(np.float32)
+        eng.upload_dataset(dd["pcs1"].reshape(-1, 3), dd["pcs2"].reshape(-1, 3), off, labt)
+        rng = np.random.default_rng(0)
+        inits = [evaluation.get_mat_angle(dd["translations"][i] + rng.normal(0, 0.05, 3), float(dd["rel_angles"][i, 0]) + rng.normal(0, 0.03), rotation_center=dd["pc1_centers"][i])
+                 for i in range(n_ex)]
+        rows = np.arange(n_ex)
+        eng.icp_refine_rows(rows, inits, 0.1, 30)
+        t = time.perf_counter(); res = eng.icp_refine_rows(rows, inits, 0.1, 30); dt = time.perf_counter() - t
+        out["icp"] = {"value": round(n_ex / dt, 1), "unit": "pairs/s", "pairs": n_ex, "points_per_cloud": pts, "ms": round(dt * 1e3, 2), "radius": 0.1, "max_iterations": 30,
+                      "mean_iterations": round(float(res["iterations"].mean()), 2), "mean_fitness": round(float(res["fitness"].mean()), 3),
+                      "what": "alignnet_icp_refine_dataset (icp.py:69-78 / train.py:463-484: point-to-point, rotation about z), seeded near the truth like the network's prediction"}
+        k = [0]
+        def srow():
+            eng.train_step_rows(rng.integers(0, n_ex, 256), seed=k[0]); k[0] += 1
+        sec, ks = timed(srow, eng.synchronize, floor=5)
+        out["loader"]["device_sampler_train"] = {"value": round(256 / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": ks,
+                                                 "what": "alignnet_train_step_dataset: batch of 256 drawn on the device from the HBM-resident dataset (resample with replacement + jitter, "
+                                                         "provider.py:60-71,97-98) + the fp32 training step, no host batch"}
+    except Exception as e:   # noqa: BLE001
+        out["icp"] = out.get("icp") or {"error": "%s: %s" % (type(e).__name__, e)}
+    out["seconds"] = round(time.perf_counter() - t_begin, 2)
+    return out
+
+
 def visible_gpus():
     import torch
     return torch.cuda.device_count()
@@ -236,7 +395,9 @@ def main():
                                                              "(engine options sync_bn + global_loss: the reference's single-device semantics); 0 = local BN / local loss")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short dgcnn / loader / icp legs the default --gpus 1 inference run appends")
     args = ap.parse_args()
+    refuse_stray_environment()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) here instead of silently running one
@@ -277,6 +438,11 @@ def main():
     cfg["training"]["batch_size"] = args.batch * world
     B = args.batch
     eng = alignnet3d.Engine(cfg, device=local_rank, seed=0)
+    opts0 = engine_options(eng)
+    if opts0["ablation_build"]:
+        raise SystemExit("bench.py: %s is the ablation build (result-changing timing switches compiled in): not benchmarked" % opts0["library"])
+    global P3_FUSED_GRAM
+    P3_FUSED_GRAM = not opts0["train_phase3_tile64"] and not (opts0["ab_mask"] & (1 << 6))   # csrc/engine.h: AB_P3_NOGRAM
     # eval-mode shadows: mean 0 / var 1 (a freshly initialised net has var 0 -> degenerate scale)
     for name, shp, _ in eng.variables():
         if name.endswith("moving_var"):
@@ -385,6 +551,12 @@ def main():
             r["traffic_commit"] = tr["commit"]      # ... taken at this commit of the tree (not measured inside this run)
         if on_bf16 and name == "backbone":
             r["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
+        if name == "train_fwd_phase3":
+            # extra passes never count as algorithmic work.  The Gram of h2 accumulated in this pass is this design's
+            # substitute for the dense dW of the lift, so both fractions are quoted: with it (`frac`) and on the lift alone.
+            lift = 2.0 * kernel_macs(cfg, name, bf16, with_gram=False) * 2 * B
+            r["algorithmic_flops_per_step_lift_only"] = lift
+            r["frac_lift_only"] = None if ach is None else round(lift / (ms_step * 1e-3) / 1e12 / peak, 4)
         return r
 
     # ---------------------------------------------------------------------------------------------------------- headline leg
@@ -518,6 +690,10 @@ def main():
         pcie_info["pipelined"] = {"value": round(B * kp / qdt, 1), "unit": "pairs/s", "ms_per_step": round(qdt / kp * 1e3, 4), "steps": kp,
                                   "what": "alignnet_forward_submit / _wait: the same pageable buffers in and out, two batches in flight (pinned staging, "
                                           "H2D on a copy stream under the previous batch's forward, D2H on a third stream)"}
+    # ---- short dgcnn / loader / icp legs (default one-GPU inference run only)
+    extra = None
+    if world == 1 and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
+        extra = extra_legs(eng, local_rank, args.min_leg_seconds)
     if dist is not None:
         dist.barrier()
 
@@ -563,6 +739,9 @@ def main():
             line["sustained"] = sustained
         if cpu_info is not None:
             line["cpu_baseline"] = cpu_info
+        if extra is not None:
+            line.update(extra_seconds=extra.pop("seconds"), **extra)
+        line["options"] = opts0
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

@@ -310,6 +310,7 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * widths 64 / 128 dispatch to kernels with the widths compiled in):
  * "last_backbone_kernel": ALIGNNET_KERNEL_* of the most recent eval-mode backbone launch;
  * "comm_world": number of ranks of the communicator (0 = none); "comm_buckets": bucket all-reduces the last step issued;
+ * "sync_collectives": sync_bn / global_loss collectives (per-layer all-reduces, gathers) the last training step issued;
  * "comm_order": issue order of the last training step's backward, one decimal digit per event: 1..3 = backward of stage 1..3 queued,
  *   4..6 = all-reduce bucket of stage 1..3 issued (data-parallel step with "allreduce_overlap": 362514 -- every bucket leaves before the
  *   next stage's backward is queued);

@@ -52,6 +52,14 @@ def test_default_line(gpu_required):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["train"]["dtype"] == "f32" and d["train"]["bf16"]["dtype"] == "bf16" and d["train"]["bf16"]["value"] > d["train"]["value"]
+    # the short legs that put BASELINE.json configs[4] and the SURVEY 8(f) rows into the driver's record
+    dgl = d["dgcnn"]
+    assert dgl["infer"]["num_points"] == 4096 and dgl["infer"]["pairs_per_step"] == 512 and dgl["infer"]["value"] > 1000 and dgl["infer"]["kernel"].startswith("dgcnn_fused")
+    assert dgl["train_f32"]["value"] > 100 and dgl["train_bf16"]["value"] > dgl["train_f32"]["value"] and dgl["train_bf16"]["last_train_kernel"] == 7
+    assert d["loader"]["identical_batches"] is True and d["loader"]["packed_pairs_per_s"] > d["loader"]["file_based_pairs_per_s"] and d["loader"]["device_sampler_train"]["value"] > 1000
+    assert d["icp"]["value"] > 100 and d["icp"]["mean_fitness"] > 0.5
+    assert d["options"]["ab_mask"] == 0 and d["options"]["ablation_build"] is False and d["options"]["library"] == "libalignnet_hip.so"
+    assert d["train"]["roofline"]["frac_lift_only"] < d["train"]["roofline"]["frac"]
     assert d["pcie_inclusive"]["value"] < d["value"] * 1.05 and d["pcie_inclusive"]["pipelined"]["value"] > 0.9 * d["pcie_inclusive"]["value"] and d["infer_bf16x3"]["max_abs_diff_vs_exact_fp32_outputs"] < 1e-4
 
 

@@ -50,3 +50,34 @@ def test_self_launch_refuses_more_ranks_than_gpus(monkeypatch, capsys):
     monkeypatch.setattr(subprocess, "call", lambda *a, **k: pytest.fail("must not spawn"))
     assert m.self_launch(2) != 0
     assert "refusing" in capsys.readouterr().err
+
+
+def test_bench_refuses_stray_alignnet_environment():
+    """Round 3's library read ALIGNNET_DBG & co. from the environment on every launch (work skipped inside the kernels, one variable away
+    from a benchmark).  The library reads none now; bench.py refuses to run when one is set, before it touches a GPU."""
+    env = dict(os.environ, ALIGNNET_DBG="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 2 and "ALIGNNET_DBG" in out.stderr and out.stdout.strip() == ""
+
+
+def test_pmc_traffic_per_step_is_per_launch_times_launches_per_step():
+    """tools/summarize_prof.py: the PMC passes are separate runs whose time-based spin-up makes different numbers of steps; round 3 divided
+    their bytes by the TRACE run's step count.  Per step = per launch x launches per step of the same pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import summarize_prof as S
+    pmc = {"pointnet_fused": {"FETCH_SIZE": {"sum": 4540.0 * 381, "dispatches": 381}, "WRITE_SIZE": {"sum": 1170.0 * 396, "dispatches": 396}},
+           "fc_mfma": {"FETCH_SIZE": {"sum": 100.0 * 1143, "dispatches": 1143}, "WRITE_SIZE": {"sum": 10.0 * 1188, "dispatches": 1188}}}
+    t = S.traffic_summary(pmc, 127, 132, {"pairs_per_gpu": 256, "num_points": 1024}, "t", "c")
+    k = t["kernels"]["pointnet_fused"]
+    assert abs(k["launches_per_step"] - 3.0) < 1e-9
+    assert abs(k["hbm_bytes_per_launch"] - (2 * 4540.0 + 1170.0) * 1024) < 1e-6
+    assert abs(k["hbm_bytes_per_step"] - 3 * k["hbm_bytes_per_launch"]) < 1e-6
+    assert abs(t["hbm_bytes_per_step"] - sum(v["hbm_bytes_per_step"] for v in t["kernels"].values())) < 1e-6
+    # and the committed summaries of this round obey it
+    import glob
+    import json
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r04_*pmc_traffic.json")):
+        for name, v in json.load(open(f))["kernels"].items():
+            assert abs(v["hbm_bytes_per_step"] - v["hbm_bytes_per_launch"] * v["launches_per_step"]) <= 1e-6 * max(1.0, v["hbm_bytes_per_step"]), (f, name)

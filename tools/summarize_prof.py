@@ -4,15 +4,18 @@ Usage: tools/summarize_prof.py gpurun_out/prof_r01 r01 [dest_dir]"""
 import glob, json, os, sqlite3, sys
 from collections import defaultdict
 
-out, tag = sys.argv[1], sys.argv[2]
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(out, "summary")
-os.makedirs(dst, exist_ok=True)
+if __name__ != "__main__":   # imported by tests/test_bench_launcher_cpu.py for traffic_summary(): nothing to read
+    out = tag = dst = None
+else:
+    out, tag = sys.argv[1], sys.argv[2]
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(out, "summary")
+    os.makedirs(dst, exist_ok=True)
 
 def short(n):
     return n.split("(")[0].replace("alignnet::", "")
 
 # 1. kernel-trace stats (rocprofv3 --kernel-trace --stats)
-for db in glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True):
+for db in (glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True) if out else []):
     c = sqlite3.connect(db)
     rows = list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as g:
@@ -35,44 +38,63 @@ for db in glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True):
 
 # 2. PMC passes (each in its own run, no tracing flags)
 pmc = defaultdict(dict)
-for db in glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True):
+for db in (glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True) if out else []):
     c = sqlite3.connect(db)
     acc, cnt = defaultdict(float), defaultdict(set)
     for name, ctr, val, did in c.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
         acc[(short(name), ctr)] += val; cnt[(short(name), ctr)].add(did)
     for (k, ctr), v in acc.items():
         pmc[k][ctr] = {"sum": v, "dispatches": len(cnt[(k, ctr)])}
-json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_by_kernel.json"), "w"), indent=1, sort_keys=True)
+if out:
+    json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_by_kernel.json"), "w"), indent=1, sort_keys=True)
 
-# 3. HBM traffic per bench step.  FETCH_SIZE / WRITE_SIZE are KiB.  gfx950: FETCH_SIZE tallies a 128-B
+# 3. HBM traffic per launch and per bench step.  FETCH_SIZE / WRITE_SIZE are KiB.  gfx950: FETCH_SIZE tallies a 128-B
 #    request as 64 B on wide coalesced streams (MI355X_MICROARCH.md, HBM) -> x2 on the read side.
-steps, shape = None, None
-for line in open(os.path.join(out, "bench_trace.log")):
-    if line.startswith("{"):
-        j = json.loads(line); steps = j["steps"] + j["warmup"] + j.get("spinup_steps_untimed", 0)   # every step the profiled process ran (one leg per profile run)
-        shape = {"pairs_per_gpu": j["config"].get("pairs_per_gpu"), "num_points": j["config"].get("num_points")}
-commit = None
-for cand in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit"),):
-    if os.path.exists(cand):
-        commit = open(cand).read().strip()
-if steps:
-    fetch = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in pmc.values())
-    write = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in pmc.values())
-    kernels = {}
+#    Every figure of a pass is normalised by THAT pass's own launch / step counts (the passes are separate runs whose time-based
+#    spin-up makes different numbers of steps; round 3 divided the PMC passes' bytes by the trace run's step count).
+def steps_of(log):
+    """every step the profiled process ran, from the bench line it printed (one leg per profile run), and the leg's shape"""
+    try:
+        for line in open(log):
+            if line.startswith("{"):
+                j = json.loads(line)
+                return (j["steps"] + j["warmup"] + j.get("spinup_steps_untimed", 0),
+                        {"pairs_per_gpu": j["config"].get("pairs_per_gpu"), "num_points": j["config"].get("num_points")})
+    except OSError:
+        pass
+    return None, None
+
+
+def traffic_summary(pmc, steps_fetch, steps_write, shape, tag, commit):
+    """pmc: {kernel: {counter: {"sum", "dispatches"}}}; steps_*: steps the FETCH_SIZE / WRITE_SIZE pass ran."""
+    kernels, tot = {}, 0.0
     for k, v in pmc.items():
         f, w = v.get("FETCH_SIZE", {}), v.get("WRITE_SIZE", {})
         if not f and not w:
             continue
-        n = max(f.get("dispatches", 0), w.get("dispatches", 0), 1)
-        b = (2 * f.get("sum", 0) + w.get("sum", 0)) * 1024
-        kernels[k] = {"hbm_bytes_per_launch": b / n, "hbm_bytes_per_step": b / steps, "launches": n,
+        nf, nw = max(f.get("dispatches", 0), 1), max(w.get("dispatches", 0), 1)
+        per_launch = (2 * f.get("sum", 0) / nf + w.get("sum", 0) / nw) * 1024
+        lps = (f.get("dispatches", 0) / steps_fetch) if f and steps_fetch else (w.get("dispatches", 0) / steps_write if steps_write else 0.0)
+        kernels[k] = {"hbm_bytes_per_launch": per_launch, "launches_per_step": lps, "hbm_bytes_per_step": per_launch * lps,
+                      "launches": max(f.get("dispatches", 0), w.get("dispatches", 0)),
                       "FETCH_SIZE_KiB": f.get("sum", 0), "WRITE_SIZE_KiB": w.get("sum", 0)}
-    json.dump({"tag": tag, "steps_profiled": steps, "shape": shape, "commit": commit,
-               "hbm_bytes_per_step": (2 * fetch + write) * 1024 / steps,
-               "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])),
-               "raw_KiB": {"FETCH_SIZE_all": fetch, "WRITE_SIZE_all": write},
-               "note": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per kernel name (every kernel of the run, by its own name); the x2 is the "
-                       "gfx950 FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md, HBM: an upper bound for narrow reads; "
-                       "WRITE_SIZE uncalibrated). Separate --pmc passes, warm-up steps included on both sides."},
-              open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print("summary files:", sorted(os.listdir(dst)))
+        tot += per_launch * lps
+    return {"tag": tag, "steps_profiled": {"FETCH_SIZE": steps_fetch, "WRITE_SIZE": steps_write}, "shape": shape, "commit": commit,
+            "hbm_bytes_per_step": tot,
+            "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])),
+            "note": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per kernel name; per launch = each pass's bytes / that pass's launches; per step = "
+                    "per launch x launches per step of the same pass (its own step count from its own bench line).  The x2 is the gfx950 "
+                    "FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md, HBM: an upper bound for narrow reads; WRITE_SIZE "
+                    "uncalibrated).  Separate --pmc passes, warm-up and spin-up steps included on both sides."}
+
+
+if __name__ == "__main__":
+    steps_f, shape = steps_of(os.path.join(out, "bench_pmc_FETCH_SIZE.log"))
+    steps_w, shape_w = steps_of(os.path.join(out, "bench_pmc_WRITE_SIZE.log"))
+    commit = None
+    cand = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")
+    if os.path.exists(cand):
+        commit = open(cand).read().strip()
+    if steps_f or steps_w:
+        json.dump(traffic_summary(pmc, steps_f, steps_w, shape or shape_w, tag, commit), open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print("summary files:", sorted(os.listdir(dst)))
