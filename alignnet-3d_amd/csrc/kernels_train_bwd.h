@@ -1248,17 +1248,40 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
     const float raw = (i >> 5) <= (j >> 5) ? G[(size_t)i * C2 + j] : G[(size_t)j * C2 + i];
     return (double)raw - (double)sv[i] * ((double)sv[j] * invM);
   };
+  // the pooled-feature part below does not depend on the statistics until its last step: its first eight clouds per thread are requested
+  // now and travel under the Gram loads and the MFMAs
+  const PoolFinishArgs& p = a.pa;
+  const int g = tid >> 4;
+  constexpr int kPre = 8;
+  float pe0[kPre], pe1[kPre]; int pi0[kPre], pi1[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int b = min(g + 32 * u, p.B - 1);
+    const size_t h0 = ((size_t)(t * p.B + b) * 2) * C3 + min(c, C3 - 1), h1 = h0 + C3;
+    pe0[u] = p.ext[h0]; pi0[u] = p.idx2[h0]; pe1[u] = p.ext[h1]; pi1[u] = p.idx2[h1];
+  }
   double qp = 0.0, swp = 0.0;
   if (wave * 16 < C2) {
     const int i = wave * 16 + cj;          // A row of this lane
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < C2; k0 += 16) {  // four MFMAs per round: 8 loads in flight per lane
-      double av[4], bv[4];
+    // every operand of the wave's C2 / 4 MFMAs is requested before the first one issues (C2 <= 128: 32 Gram + 32 weight + 32 column-sum values per lane)
+    float gr[32], wr[32], sr[32];
+    const float si = sv[i];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int k = k0 + 4 * u + kq; av[u] = ghat(i, k); bv[u] = wcol(k, c); }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    for (int m = 0; m < 32; ++m) {
+      const int k = min(4 * m + kq, C2 - 1);
+      gr[m] = (i >> 5) <= (k >> 5) ? G[(size_t)i * C2 + k] : G[(size_t)k * C2 + i];
+      wr[m] = c < C3 ? a.W[(size_t)k * C3 + c] : 0.f;
+      sr[m] = sv[k];
     }
+#pragma unroll
+    for (int m = 0; m < 32; ++m)
+      if (4 * m < C2) {
+        float w = wr[m];
+        if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
+        const double av = (double)gr[m] - (double)si * ((double)sr[m] * invM);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (double)w, acc, 0, 0, 0);
+      }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ir = wave * 16 + kq + 4 * r;   // D row of register r
@@ -1300,11 +1323,21 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   __syncthreads();
   if (c >= C3) return;
   // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices):
-  // 16 channels x 32 cloud groups, four clouds in flight per thread
-  const PoolFinishArgs& p = a.pa;
-  const int g = tid >> 4;
+  // 16 channels x 32 cloud groups; the first eight clouds per thread were requested at the top
   const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cj], rs = 1.0f / sqrtf(cst[1][cj] + kBnEps), sc = cst[2][cj], sh = cst[3][cj];
-  for (int b0 = g; b0 < p.B; b0 += 32 * 4) {
+  auto finish = [&](int b, float e, int bi, float e1, int b1) {
+    if (e1 > e || (e1 == e && b1 < bi)) { e = e1; bi = b1; }
+    const size_t i = (size_t)(t * p.B + b) * C3 + c;
+    p.idx[i] = bi;
+    p.pooled[t * p.tower_stride + b * p.row_stride + c] = fmaxf(fmaf(e * sg, sc, sh), 0.f);
+    p.zhat_star[i] = (e * sg + bias - mf) * rs;
+  };
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int b = g + 32 * u;
+    if (b < p.B) finish(b, pe0[u], pi0[u], pe1[u], pi1[u]);
+  }
+  for (int b0 = g + 32 * kPre; b0 < p.B; b0 += 32 * 4) {
     float e0[4], e1[4]; int i0[4], i1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1315,13 +1348,7 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int b = b0 + 32 * u;
-      if (b >= p.B) break;
-      float e = e0[u]; int bi = i0[u];
-      if (e1[u] > e || (e1[u] == e && i1[u] < bi)) { e = e1[u]; bi = i1[u]; }
-      const size_t i = (size_t)(t * p.B + b) * C3 + c;
-      p.idx[i] = bi;
-      p.pooled[t * p.tower_stride + b * p.row_stride + c] = fmaxf(fmaf(e * sg, sc, sh), 0.f);
-      p.zhat_star[i] = (e * sg + bias - mf) * rs;
+      if (b < p.B) finish(b, e0[u], i0[u], e1[u], i1[u]);
     }
   }
 }

@@ -175,7 +175,7 @@ int alignnet_train_forward_backward(alignnet_handle* h, const float* pcs1, const
                                     const float* dropout_u, alignnet_step_result* result,
                                     const alignnet_outputs* out);
 int alignnet_grad_buffer(alignnet_handle* h, float** d_grad, size_t* count);
-int alignnet_apply_gradients(alignnet_handle* h, float grad_scale);
+int alignnet_apply_gradients(alignnet_handle* h, float grad_scale);   /* consumes the gradient: the buffer reads zero afterwards */
 /* Debug/parity: copy the flat gradient of one variable to the host. */
 int alignnet_get_grad(alignnet_handle* h, const char* name, float* dst, size_t count);
 /* Debug/parity: the uniforms the device-side dropout stream (tf.nn.dropout's random_uniform, utils/tf_util.py:554-575) draws at
