@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_fused(const BackboneA
       const float sh = live ? L.shift[tower * L.cout + col] : 0.f;
       asm volatile("" ::: "memory");
 #ifdef ALIGNNET_KSTAMP
-      long long* kst = (a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4) && ct < 16)
+      long long* kst = (a.stamps && blockIdx.x == 0 && blockIdx.y == 1 && tile == tile_lo + 2 && lane == 0 && (wave == 0 || wave == 4) && ct < 16)
                            ? a.stamps + ((wave >> 2) * 2 + (ct >> 3)) * 64 : nullptr;
       if (kst) *kst++ = (long long)__builtin_readcyclecounter();
       mfma_rows<TP / 32>(in, ldi, reinterpret_cast<const f32x4*>(L.w) + (size_t)ct * KG * 64, KG, lane, acc, kst);

@@ -175,21 +175,22 @@ def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
     return cfg, spec, P32, d, du
 
 
-def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pred_tol=2e-4, fp32_conditioning=False,
-                                  grad_ceiling=8e-2, pred_ceiling=2.5e-4, loss_tol=1e-4, ema_tol=1e-4, whole_gradient=False):
+def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar, fp32_context=True):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
     torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`).
-    fp32_conditioning: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024 candidates each and
-    normalises 256-row batches of nearly equal pooled features; the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2 (gradients)
-    and 2e-4 (predictions) away from its fp64 evaluation.  The bars then become: HIP gradient error <= the fp32 oracle's own
-    worst relative error, HIP prediction error <= max(pred_tol, the fp32 oracle's own) -- i.e. the engine must be at least as
-    close to the exact result as a plain fp32 evaluation of the reference arithmetic is -- capped at grad_ceiling / pred_ceiling."""
+    Every bar is 2 x the value this test printed at this round's head (profiles/r04_gpu_tests_fullsize.log holds the `full size:` lines):
+    whole-gradient cosine / relative L2, the worst tensor (error relative to the tensor's own largest entry), predictions, loss, EMA.
+    Why the gradient sits at 1e-2 and not at rounding level: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024
+    candidates each and normalises 256-row batches of nearly equal pooled features; the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2
+    (worst tensor) away from its own fp64 evaluation (printed for context, not used as a bar any more), and the engine's own gradient
+    moves by 1.4e-2 when its inputs move by one ulp (tests/test_loopback_gpu.py prints that floor).  The small shapes of
+    tests/test_train_gpu.py (5e-4 per tensor) are what catches a 1 % gradient bug; this is the same arithmetic at BASELINE.json's sizes."""
     from tests import test_train_gpu as TT
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
     ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True)
-    if fp32_conditioning:
+    if fp32_context:
         ep32, _, g32, _ = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True, dt=np.float32)
         gs = max(float(np.abs(v).max()) for v in grads.values())
         skip = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
@@ -197,21 +198,15 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pre
                     for k in grads if k not in skip)
         pred32 = max(float(np.abs(ep32[k] - ep_ref[k]).max()) for k in ep_ref)
         print("fp32 oracle vs fp64 oracle: worst relative gradient error %.2e, worst prediction error %.2e" % (rel32, pred32))
-        # conditioning-aware, but bounded: the bars may relax to 1.5 x the fp32 oracle's own error (which tie of a max-pool an fp32
-        # evaluation breaks which way is rounding luck: the same engine measured 1.4e-2 and 6.3e-2 on this batch before / after a
-        # change of its epilogue's rounding, the fp32 oracle 5.6e-2) and never beyond the fixed ceilings; the small shapes of
-        # tests/test_train_gpu.py (5e-4) are what would catch a 1 % gradient bug
-        tol, pred_tol = min(max(tol, 1.5 * rel32), grad_ceiling), min(max(pred_tol, 1.5 * pred32), pred_ceiling)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     assert eng.get_option("last_train_kernel") == expect_kernel
     worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
-    for k in ep_ref:
-        np.testing.assert_allclose(res[k], ep_ref[k], rtol=pred_tol, atol=pred_tol, err_msg=k)
-    assert abs(res["loss"] - loss_ref) <= loss_tol * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
     worst_ema = 0.0
+    ema_fail = []
     for k, v in ema_ref.items():
         got = eng.get_variable(k)
-        np.testing.assert_allclose(got, v, rtol=ema_tol, atol=0.1 * ema_tol, err_msg=k)
+        if not np.allclose(got, v, rtol=ema_tol, atol=0.1 * ema_tol):
+            ema_fail.append(k)
         worst_ema = max(worst_ema, float(np.abs(got - v).max()))
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
@@ -225,7 +220,7 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pre
         err = float(np.abs(g - ref).max())
         if np.abs(ref).max() > 1e-6 * gscale:
             rel[name] = err / float(np.abs(ref).max())
-        if err > tol * float(np.abs(ref).max()) + 1e-5 * gscale:
+        if err > tensor_bar * float(np.abs(ref).max()) + 1e-5 * gscale:
             bad[name] = (err, float(np.abs(ref).max()))
     names = [n for n in R.trainable_names(spec) if n not in bn_bias]
     gv = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names])
@@ -235,20 +230,19 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, tol, expect_kernel, pre
     eng.close()
     print("full size: loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, whole gradient: cosine %.6f, relative L2 error %.2e, "
           "worst relative gradient errors %s" % (res["loss"], loss_ref, worst_pred, worst_ema, cos, rl2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
-    if whole_gradient:
-        # the fp32 kNN graph differs from the fp64 oracle's in near-ties (N = 4096), and four-row batch statistics in the heads amplify
-        # that into tens of per cent on the smallest tensors: the bar is on the whole gradient vector (an indexing bug at this N would
-        # leave nothing of the direction)
-        assert cos >= 0.995 and rl2 <= 0.1, (cos, rl2, bad)
-    else:
-        assert not bad, bad
+    assert worst_pred <= pred_tol, worst_pred
+    assert abs(res["loss"] - loss_ref) <= loss_tol * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    assert not ema_fail, ema_fail
+    assert cos >= cos_bar and rl2 <= rl2_bar, (cos, rl2)
+    assert not bad, bad
 
 
 def test_train_fp32_full_size_matches_autograd(gpu_required):
     """BASELINE.json configs[2]'s shape in fp32: SynthCars widths, 256 pairs x 1024 points -- the kernel instantiations with the
     widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256."""
     cfg, spec, P32, d, du = _train_setup()
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True)
+    # measured: predictions 1.3e-4, loss 1e-6, EMA 2.5e-6, cosine 0.999911, relative L2 1.3e-2, worst tensor fc1/weights 6.3e-2
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, cos_bar=0.9998, rl2_bar=2.7e-2, tensor_bar=0.125)
 
 
 def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):
@@ -266,7 +260,8 @@ def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     # (two max-pools and 4-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 3.8e-2 from its fp64 one here)
     # (EMA bound 2e-4: with the point conv on 128-point tiles one of the 512 fc1 moving means -- four-row batch statistics -- sits 1.4e-5 from the
     #  fp64 value at |v| = 0.03, just outside 1e-4 |v| + 1e-5)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, ema_tol=2e-4)
+    # measured: predictions 2.3e-4, loss 2e-6, EMA 4.1e-5, cosine 0.999965, relative L2 9.1e-3, worst tensor siamese_1/embedding/conv1/bn/beta 3.8e-2
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9999, rl2_bar=1.9e-2, tensor_bar=8e-2)
 
 
 def test_train_b2048_matches_autograd(gpu_required):
@@ -276,7 +271,8 @@ def test_train_b2048_matches_autograd(gpu_required):
     256 x 1024 test (the same 524 k points)."""
     cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
     # (2048-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 4e-2 from its fp64 one on the smallest gradients)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-3, expect_kernel=1, fp32_conditioning=True)
+    # measured: predictions 1.5e-4, loss 1e-6, EMA 8e-7, cosine 0.999979, relative L2 6.4e-3, worst tensor fc1/bn/beta 3.3e-2
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.99995, rl2_bar=1.3e-2, tensor_bar=7e-2)
 
 
 def test_train_dgcnn_n4096_matches_autograd(gpu_required):
@@ -284,7 +280,12 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 4 (655 k edge rows, [2B, N, N] distance
     matrices in the oracle; two-row batch statistics in the heads are singular, so not B = 2)."""
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=4096, seed=9)
-    _check_train_against_autograd(cfg, spec, P32, d, du, tol=1e-2, expect_kernel=5, fp32_conditioning=True, pred_ceiling=2e-2, loss_tol=2e-3, ema_tol=1e-2, whole_gradient=True)   # (kNN at N = 4096: the fp32 oracle's own predictions are 8e-3 from its fp64 ones)
+    # The fp32 kNN graph differs from the fp64 oracle's wherever the 20th and 21st neighbour of a query are closer than fp32 rounding of the
+    # distance expression (N = 4096: dozens of queries per cloud), and four-row batch statistics in the heads amplify one changed neighbour
+    # into per cents on the smallest tensors (siamese/embedding/conv3/bn/beta: 0.42 of its 1e-3-sized entries): the per-tensor bar only
+    # bounds that tensor, the whole-gradient bars carry the comparison.
+    # measured: predictions 4.4e-3 (the fp32 oracle's own: 7.7e-3), loss 2.2e-4, EMA 2.3e-3, cosine 0.999856, relative L2 1.7e-2
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=9e-3, loss_tol=5e-4, ema_tol=5e-3, cos_bar=0.9997, rl2_bar=3.4e-2, tensor_bar=0.85)
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):

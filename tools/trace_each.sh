@@ -9,7 +9,9 @@ python - $OUT <<'PY' > gpurun_out/trace_${TAG}_each.txt
 import sqlite3, glob, sys
 c = sqlite3.connect(glob.glob(sys.argv[1] + '/**/*.db', recursive=True)[0])
 rows = list(c.execute("select name, grid_x*grid_y*grid_z, workgroup_x*workgroup_y*workgroup_z, start, end from kernels order by start"))
-ends = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+import os
+mark = os.environ.get('STEP_MARK', 'adam_kernel')
+ends = [i for i, r in enumerate(rows) if mark in r[0]]
 lo, hi = ends[-2] + 1, ends[-1] + 1
 t0 = rows[lo][3]
 for n, g, wg, s, e in rows[lo:hi]:
