@@ -1469,11 +1469,11 @@ __global__ __launch_bounds__(1024) void prep_hidden_reduce_kernel(const PrepHidd
 // loads, 256 of them per thread -- ran at 0.9 TB/s.)  The (index, weight) pairs of the kSdC channels are staged per 128 clouds.
 constexpr int kSdC = 8, kSdStage = 128;
 __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
-                                               int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int cb, int t)
+                                               int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int cb, int t, unsigned char* lds)
 {
-  __shared__ int sidx[kSdStage][kSdC];
-  __shared__ float sgv[kSdStage][kSdC];
-  __shared__ float part[64][132];          // [slot][column]: up to 64 slots x 128 columns (+4: bank spread)
+  int (*sidx)[kSdC] = reinterpret_cast<int (*)[kSdC]>(lds);                                       // [kSdStage][kSdC]
+  float (*sgv)[kSdC] = reinterpret_cast<float (*)[kSdC]>(lds + kSdStage * kSdC * 4);               // [kSdStage][kSdC]
+  float (*part)[132] = reinterpret_cast<float (*)[132]>(lds + 2 * kSdStage * kSdC * 4);            // [slot][column]: up to 64 slots x 128 columns (+4: bank spread)
   const int tid = threadIdx.x, nt = blockDim.x, c0 = cb * kSdC;
   const int per = h2_bf16 ? 8 : 4, Q = C2 / per;                  // elements per 16-byte piece, pieces per row
   const int nslot = min(64, nt / Q), slot = tid / Q, piece = tid % Q;
@@ -1542,10 +1542,109 @@ __device__ __forceinline__ void sparse_dw_body(const float* __restrict__ gs, con
       if (c0 + cc < C3) Sp[((size_t)t * C2 + tid) * C3 + c0 + cc] = (float)tot[cc];
   }
 }
+// Round 4 form for row widths whose 16-byte pieces divide a wave (Q = 4, 8, 16, 32: every shipped width).  The loop above walks the
+// workgroup's eight channels one after the other -- two row gathers in flight per thread, two barriers and a 64-deep LDS column sum per
+// (channel, stage of 128 clouds): 32 barriers around 16 exposed HBM round trips, 115 us for the three stages' 235 MB of 256-byte rows
+// (2 TB/s).  Here a thread requests the rows of FOUR channels x its clouds of the stage at once (8 - 16 independent 16-byte loads),
+// keeps fp32 partial sums per channel in registers across the stages, and the slots meet once at the end: shuffles across the wave's
+// slots, one LDS slab per wave, a 16-way fp64 sum per output element.  Same sums up to the order of the fp32 partials; deterministic.
+template <bool BF16>
+__device__ __forceinline__ void sparse_dw_wide_body(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                                    int B, int N, int C2, int C3, float* __restrict__ Sp, int cb, int t, unsigned char* lds)
+{
+  constexpr int per = BF16 ? 8 : 4, kWavesSd = 16, kH = 4;   // kH channels per pass (register budget of a 1024-thread workgroup: 128 per lane)
+  int (*sidx)[kH] = reinterpret_cast<int (*)[kH]>(lds);                                          // [kSdStage][kH]
+  float (*sgv)[kH] = reinterpret_cast<float (*)[kH]>(lds + kSdStage * kH * 4);                    // [kSdStage][kH]
+  float (*part)[kH][132] = reinterpret_cast<float (*)[kH][132]>(lds + 2 * kSdStage * kH * 4);     // [kWavesSd][kH][132]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c0 = cb * kSdC;
+  const int Q = C2 / per, nslot = 1024 / Q, slot = tid / Q, piece = tid % Q;
+#pragma unroll 1
+  for (int hc = 0; hc < kSdC; hc += kH) {
+    float acc[kH][per];
+#pragma unroll
+    for (int q = 0; q < kH; ++q)
+#pragma unroll
+      for (int e = 0; e < per; ++e) acc[q][e] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += kSdStage) {
+      const int nb = min(kSdStage, B - b0);
+      __syncthreads();
+      for (int i = tid; i < nb * kH; i += 1024) {
+        const int bi = i / kH, cc = c0 + hc + i % kH;
+        const size_t cloud = (size_t)t * B + b0 + bi;
+        sidx[bi][i % kH] = cc < C3 ? idx[cloud * C3 + cc] : 0;
+        sgv[bi][i % kH] = cc < C3 ? gs[cloud * C3 + cc] : 0.f;
+      }
+      __syncthreads();
+      for (int i0 = slot; i0 < nb; i0 += 2 * nslot) {   // two clouds x four channels per round: eight rows in flight per thread
+        uint4 v[2][kH]; float g[2][kH];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < kH; ++q) {
+            const int iu = i0 + u * nslot;
+            g[u][q] = iu < nb ? sgv[min(iu, nb - 1)][q] : 0.f;
+            v[u][q] = uint4{0u, 0u, 0u, 0u};
+            if (g[u][q] != 0.f) {
+              const size_t row = ((size_t)t * B + b0 + iu) * N + sidx[iu][q];
+              v[u][q] = BF16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(h2) + row * C2 + piece * 8)
+                             : *reinterpret_cast<const uint4*>(h2 + row * C2 + piece * 4);
+            }
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < kH; ++q) {
+            const unsigned w4[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
+            if constexpr (BF16) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc[q][2 * e] = fmaf(g[u][q], __uint_as_float(w4[e] << 16), acc[q][2 * e]);
+                acc[q][2 * e + 1] = fmaf(g[u][q], __uint_as_float(w4[e] & 0xffff0000u), acc[q][2 * e + 1]);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[q][e] = fmaf(g[u][q], __uint_as_float(w4[e]), acc[q][e]);
+            }
+          }
+      }
+    }
+    // the wave's 64 / Q slots meet by shuffles (lanes piece, piece + Q, ...), then one slab per wave
+#pragma unroll
+    for (int q = 0; q < kH; ++q)
+#pragma unroll
+      for (int e = 0; e < per; ++e) {
+        float x = acc[q][e];
+        for (int o = Q; o < 64; o <<= 1) x += __shfl_xor(x, o);
+        if (lane < Q) part[wave][q][piece * per + e] = x;
+      }
+    __syncthreads();
+    for (int o = tid; o < kH * C2; o += 1024) {
+      const int q = o / C2, col = o - q * C2;
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWavesSd; ++w) sum += (double)part[w][q][col];
+      if (c0 + hc + q < C3) Sp[((size_t)t * C2 + col) * C3 + c0 + hc + q] = (float)sum;
+    }
+  }
+}
+__device__ __forceinline__ bool sparse_dw_wide_ok(int C2, int h2_bf16)
+{
+  const int Q = C2 / (h2_bf16 ? 8 : 4);
+  return C2 <= 128 && Q >= 4 && Q <= 64 && (Q & (Q - 1)) == 0 && C2 % (h2_bf16 ? 8 : 4) == 0;
+}
+__device__ __forceinline__ void sparse_dw_any(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
+                                              int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16, int cb, int t)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSdStage * kSdC * 4 + 64 * 132 * 4];   // (>= 2 * 128 * 4 * 4 + 16 * 4 * 132 * 4 of the wide form)
+  if (sparse_dw_wide_ok(C2, h2_bf16)) {   // (uniform per launch)
+    if (h2_bf16) sparse_dw_wide_body<true>(gs, idx, h2, B, N, C2, C3, Sp, cb, t, lds);
+    else sparse_dw_wide_body<false>(gs, idx, h2, B, N, C2, C3, Sp, cb, t, lds);
+  } else sparse_dw_body(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, cb, t, lds);
+}
 __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict__ gs, const int* __restrict__ idx, const float* __restrict__ h2,
                                                          int B, int N, int C2, int C3, float* __restrict__ Sp, int h2_bf16)
 {
-  sparse_dw_body(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, blockIdx.x, blockIdx.y);
+  sparse_dw_any(gs, idx, h2, B, N, C2, C3, Sp, h2_bf16, blockIdx.x, blockIdx.y);
 }
 // the three stages' Sp in one launch (the weight gradients wait for nothing but the optimiser): grid (max ceil(C3 / kSdC), 2, jobs), block kSdC * C2
 struct SparseDwJob { const float* gs; const int* idx; const float* h2; int B, N, C2, C3; float* Sp; int h2_bf16; };
@@ -1554,7 +1653,7 @@ __global__ __launch_bounds__(1024) void sparse_dw_jobs_kernel(const SparseDwJobs
 {
   const SparseDwJob& q = jobs.j[blockIdx.z];
   if (!q.gs || (int)blockIdx.x * kSdC >= q.C3) return;
-  sparse_dw_body(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y);
+  sparse_dw_any(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y);
 }
 
 // two scaled copies of one matrix in one launch: out_x[t] = W diag(col_x[t]) (transposed if tr_x), towers_x of them; grid (ceil(R*C/256), 2)
