@@ -344,6 +344,27 @@ __device__ __forceinline__ double block_sum(double v, double* red)
   return t;
 }
 
+// NV sums at once: one pair of barriers instead of NV (the loss kernels reduce five / six scalars per workgroup; one after the other that
+// was ten / twelve barriers of a latency-bound launch).  Same per-value summation order as block_sum.  red: [waves][NV] doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red)
+{
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NV + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w * NV + q];
+    v[q] = t;
+  }
+}
+
 __device__ __forceinline__ float huberf(float e, float d)
 {
   const float a = fabsf(e), q = fminf(a, d);
@@ -404,7 +425,7 @@ __device__ __forceinline__ const float* term_logits(const LossArgs& a, int term,
 // grid: ceil(3B/64) workgroups for the softmax rows (16 lanes per (term, row)) + one last workgroup for the Huber terms
 __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G)
 {
-  __shared__ double red[16];
+  __shared__ double red[16 * 6];
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
@@ -430,10 +451,9 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
         a.d_o2[(size_t)(B + b) * a.ldo2 + d] = 0.f;
       }
     }
-    for (int k = 0; k < 5; ++k) {
-      const double t = block_sum(h[k], red) / (3.0 * B);
-      if (tid == 0) S.hub[k] = (float)t;
-    }
+    block_sum_n<5>(h, red);
+    if (tid == 0)
+      for (int k = 0; k < 5; ++k) S.hub[k] = (float)(h[k] / (3.0 * B));
     return;
   }
   // ---- per-row class / residual targets and log-sum-exp for the three angle terms: 16 lanes per (term, row) ----
@@ -468,17 +488,17 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
       }
     }
   }
-  for (int term = 0; term < 3; ++term)
-    for (int v = 0; v < 2; ++v) {
-      const double t = block_sum(ce[term][v], red);
-      if (tid == 0) S.cep[(size_t)blockIdx.x * 6 + term * 2 + v] = t;
-    }
+  double cev[6] = {ce[0][0], ce[0][1], ce[1][0], ce[1][1], ce[2][0], ce[2][1]};
+  block_sum_n<6>(cev, red);
+  if (tid == 0)
+    for (int q = 0; q < 6; ++q) S.cep[(size_t)blockIdx.x * 6 + q] = cev[q];
 }
 
 // grid G: block g owns rows i in [g*R, (g+1)*R); thread j-strided over columns
 __global__ __launch_bounds__(256) void loss_pairs_kernel(const LossArgs a, int G)
 {
-  __shared__ double red[4];
+  __shared__ double red[4 * 6];
+  double rlv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x, g = blockIdx.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
@@ -506,9 +526,12 @@ __global__ __launch_bounds__(256) void loss_pairs_kernel(const LossArgs a, int G
         rl += (double)hl;
         S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sj;
       }
-      const double t = block_sum(rl, red);
-      if (tid == 0) S.rlp[((size_t)g * 3 + term) * 2 + v] = t;
+      rlv[term * 2 + v] = rl;
     }
+  block_sum_n<6>(rlv, red);
+  if (tid == 0)
+    for (int q = 0; q < 6; ++q)
+      if ((q & 1) < nvar) S.rlp[(size_t)g * 6 + q] = rlv[q];
 }
 
 constexpr int kLossCols = 8;   // columns j per workgroup of loss_final_kernel

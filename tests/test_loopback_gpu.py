@@ -131,7 +131,7 @@ def sharded_step(W, cfg, P32, d, du, options):
         eng.synchronize()
         summed = {n: eng.get_gradient(n).astype(np.float64) for n in names}
         ema = {n: eng.get_variable(n) for n, _, t in eng.variables() if not t}
-        return dict(res=res, local=local, summed=summed, ema=ema, lo=lo, hi=hi)
+        return dict(res=res, local=local, summed=summed, ema=ema, lo=lo, hi=hi, collectives=eng.get_option("sync_collectives"))
     return run_ranks(W, cfg, body, options=tuple(options) + (("sync_bn", 1), ("global_loss", 1)), variables=P32)
 
 
@@ -207,6 +207,8 @@ def compare_with_single(ranks, single, nb, label=""):
         tot = sum(rk["local"][n] for rk in ranks)
         np.testing.assert_allclose(ranks[0]["summed"][n], tot, rtol=1e-6, atol=1e-7 * gs, err_msg=n)
     m.update(grad_metrics(ranks[0]["summed"], gf))
+    m["collectives"] = ranks[0].get("collectives")
+    print("   sync_bn + global_loss collectives of the step (per-layer all-reduces + gathers):", m["collectives"])
     print("loopback %s: %d ranks vs one engine at the concatenated batch: loss %.7f / %.7f (rel %.1e, summaries %.1e), predictions %.2e (%d pairs near a yaw tie "
           "excluded from the stage-3 outputs, %d yaw classes differ), EMA %.2e, whole gradient cosine %.8f, relative L2 %.2e (stages 1 / 2 / 3: %.1e %.1e %.1e), "
           "worst tensor %s %.2e" % (label, len(ranks), ranks[0]["res"]["loss"], rf["loss"], m["loss"], m["summaries"], m["pred"], m["unstable"], m["yaw_flips"],
