@@ -598,18 +598,22 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
 }
 
 static int run_fc(alignnet_handle* h, const Layer& L, const float* in, long ldin, float* out, long ldout, int M,
-                  int rows_per_set, bool relu)
+                  int rows_per_set, bool relu, const FcArgs* finish = nullptr)
 {
   FcArgs a;
+  if (finish) a = *finish;   // the stage glue folded into this (last) layer's epilogue
   a.in = in; a.ldin = ldin; a.wp = h->d_wp + L.off_wp; a.scale = h->d_scale + L.off_ss; a.shift = h->d_shift + L.off_ss;
   a.out = out; a.ldout = ldout; a.M = M; a.K = L.cin; a.Nout = L.cout; a.relu = relu; a.rows_per_set = rows_per_set;
-  hipLaunchKernelGGL(fc_mfma, dim3((L.cout + 31) / 32, (M + 31) / 32), dim3(256), 0, h->stream, a);
+  const dim3 grid((L.cout + 31) / 32, (M + 31) / 32);
+  if (L.cin >= 1024) hipLaunchKernelGGL(fc_mfma<8>, grid, dim3(512), 0, h->stream, a);
+  else hipLaunchKernelGGL(fc_mfma<4>, grid, dim3(256), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
 
 // head MLP (models/tp8.py:75-82) in eval mode: dropout is the identity (tf_util.py:571-574)
-static int run_head(alignnet_handle* h, const Stack& st, const float* in, long ldin, float* out, long ldout, int M, int rows_per_set)
+static int run_head(alignnet_handle* h, const Stack& st, const float* in, long ldin, float* out, long ldout, int M, int rows_per_set,
+                    const FcArgs* finish = nullptr)
 {
   const float* cur = in; long ldc = ldin;
   float* pp[2] = {h->ws.hid_a, h->ws.hid_b};
@@ -618,7 +622,7 @@ static int run_head(alignnet_handle* h, const Stack& st, const float* in, long l
     const bool last = j == st.n - 1;
     float* dst = last ? out : pp[j & 1];
     const long ldd = last ? ldout : L.cout;
-    if (run_fc(h, L, cur, ldc, dst, ldd, M, rows_per_set, !last)) return 1;
+    if (run_fc(h, L, cur, ldc, dst, ldd, M, rows_per_set, !last, last ? finish : nullptr)) return 1;
     cur = dst; ldc = ldd;
   }
   return 0;
@@ -640,18 +644,19 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   const int CE = h->layers[h->emb_conv.first + h->emb_conv.n - 1].cout;
   const int B2 = 2 * B;
   if (h->prof) hipEventRecord(h->ev[0], h->stream);
-  // pool1 | pool2 | emb are carved back to back: one memset arms all three atomicMax targets
-  HIP_TRY(h, hipMemsetAsync(w.pool1, 0, (size_t)((char*)w.hid_a - (char*)w.pool1), h->stream));
-  hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean);
+  // pool1 | pool2 | emb are carved back to back: the centroid kernel arms all three atomicMax targets (a slice per workgroup)
+  hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean, w.pool1,
+                     (size_t)((char*)w.hid_a - (char*)w.pool1) / sizeof(float));
   if (dg) {   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
     ProfScope prof_scope(h, PK_KNN);
     HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn));
   }
   // stage 1 (tp8.py:108-109)
   if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;
-  if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B)) return 1;
-  hipLaunchKernelGGL(stage1_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w.o1, w.center_mean, B, w.s1c,
-                     w.xform, outs[2], outs[3]);
+  {   // (+ the stage-1 glue in the last layer's epilogue: s1 = head + center_mean, next frame, pred_s1 centres)
+    FcArgs fin; fin.finish = 1; fin.B = B; fin.addend = w.center_mean; fin.s1c = w.s1c; fin.xform = w.xform; fin.out_a = outs[2]; fin.out_b = outs[3];
+    if (run_head(h, h->s1_fc, w.pool1, C1, w.o1, 3, B2, B, &fin)) return 1;
+  }
   // stage 2 (tp8.py:113-125)
   if (backbone(h->s2_conv, w.pool2, (long)B * C2, C2, (size_t)B2 * C2)) return 1;
   if (run_head(h, h->s2_fc, w.pool2, C2, w.o2, 3 + nb2, B2, B)) return 1;
@@ -659,8 +664,10 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
                      w.xform, w.theta, w.cls, outs[4], outs[5], outs[6], outs[7]);
   // stage 3: embedding of the normalised clouds, concat (tp8.py:130,144,153) = row b holds [emb1 | emb2]
   if (backbone(h->emb_conv, w.emb, CE, 2L * CE, (size_t)B2 * CE)) return 1;
-  if (run_head(h, h->rem_fc, w.emb, 2L * CE, w.o3, 3 + nb2, B, B)) return 1;
-  hipLaunchKernelGGL(final_finish_kernel, dim3((B * (3 + nb2) + 255) / 256), dim3(256), 0, h->stream, w.o3, 3 + nb2, w.s2c, B, nb, outs[0], outs[1]);
+  {   // (+ the final glue in the last layer's epilogue: pred_translations = head[:, :3] + (s2c2 - s2c1), remaining-angle logits)
+    FcArgs fin; fin.finish = 3; fin.B = B; fin.nb = nb; fin.addend = w.s2c; fin.out_a = outs[0]; fin.out_b = outs[1];
+    if (run_head(h, h->rem_fc, w.emb, 2L * CE, w.o3, 3 + nb2, B, B, &fin)) return 1;
+  }
   if (h->prof) hipEventRecord(h->ev[1], h->stream);
   HIP_TRY(h, hipGetLastError());
   h->last_B = B;

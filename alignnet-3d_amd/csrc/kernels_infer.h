@@ -91,8 +91,14 @@ struct PackJob { const float* src; float* dst; int K, C; };
 // ---------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
                                                       int B, int N, float* __restrict__ xform,
-                                                      float* __restrict__ center_mean)
+                                                      float* __restrict__ center_mean, float* __restrict__ zero = nullptr, size_t nzero = 0)
 {
+  // eval forward: the pooled-feature buffers (atomicMax targets of the three backbones) are cleared here, a slice per workgroup,
+  // instead of by a memset launch of their own in front of this kernel
+  if (zero) {
+    const size_t per = (nzero + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < nzero ? lo + per : nzero;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) zero[i] = 0.f;
+  }
   const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B;
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   float s[3] = {0.f, 0.f, 0.f};
@@ -502,11 +508,21 @@ struct FcArgs {
   const float* wp; const float* scale; const float* shift;
   float* out; long ldout;
   int M, K, Nout, relu, rows_per_set;
+  // elementwise stage glue folded into the last head layer's epilogue (each was a 5 us launch of its own behind the layer):
+  //   finish = 1 (stage 1, models/tp8.py:109): s1 = head + center_mean -> s1c, next frame (s1, I), pred_s1 centres
+  //   finish = 3 (pair head, models/tp8.py:155-156): pred_translations = head[:, :3] + (s2c2 - s2c1), logits = head[:, 3:]
+  int finish = 0; int B = 0, nb = 0;
+  const float* addend = nullptr;   // finish 1: center_mean [2B][3]; finish 3: s2c [2B][3]
+  float* s1c = nullptr; float* xform = nullptr;
+  float* out_a = nullptr; float* out_b = nullptr;   // finish 1: pred_s1_pc1centers / pc2centers; finish 3: pred_translations / remaining logits (any may be null)
 };
 
-[[maybe_unused]] static __global__ __launch_bounds__(256) void fc_mfma(const FcArgs a)
+// NW waves split K (4: the usual head layer; 8 for K >= 1024 -- the pair head's first layer, K = 2048, ran 64 k-groups per wave on half
+// the chip's CUs with one wave per SIMD: 20.8 us)
+template <int NW>
+static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
 {
-  __shared__ float red[3][16][64];
+  __shared__ float red[NW - 1][16][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ct = blockIdx.x, mt = blockIdx.y;
   const int KG = a.K >> 3;   // K % 8 == 0 checked on the host
@@ -516,19 +532,33 @@ struct FcArgs {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int per = (KG + 3) >> 2, k0 = wave * per, k1 = min(KG, k0 + per);
-  // eight k-groups of operands are requested before their MFMAs (a one-deep lookahead exposed one memory round trip per
-  // k-group: 32 of them per wave at K = 1024)
-  for (int kg = k0; kg < k1; kg += 8) {
-    f32x4 av[8], bv[8];
+  const int per = (KG + NW - 1) / NW, k0 = wave * per, k1 = min(KG, k0 + per);
+  // the folded glue's addends are requested in front of the MFMA loop (loaded in the epilogue, each row's round trip sat exposed behind it)
+  float add0[16], add1[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+  for (int r = 0; r < 16; ++r) { add0[r] = 0.f; add1[r] = 0.f; }
+  if (a.finish && ct == 0) {   // (uniform: only the last layer's first column tile carries the three centre / translation columns)
+    const int col = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.M - 1);
+      add0[r] = col < 3 ? a.addend[row * 3 + col] : 0.f;
+      add1[r] = (a.finish == 3 && col < 3) ? a.addend[(a.B + row) * 3 + col] : 0.f;
+    }
+  }
+  // U k-groups of operands are requested before their MFMAs (a one-deep lookahead exposed one memory round trip per
+  // k-group: 32 of them per wave at K = 1024)
+  constexpr int U = 8;   // (sixteen with the eight-wave form was measured: 23.0 against 19.2 us for the K = 2048 layer)
+  for (int kg = k0; kg < k1; kg += U) {
+    f32x4 av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       const int kk = min(kg + u, k1 - 1);
       av[u] = *reinterpret_cast<const f32x4*>(arow + kk * 8);
       bv[u] = wp[(size_t)kk * 64];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       if (kg + u < k1) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][s], bv[u][s], acc, 0, 0, 0);
@@ -547,9 +577,25 @@ struct FcArgs {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < a.M) {
           const int set = row >= a.rows_per_set;
-          float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+          float v = acc[r];
+#pragma unroll
+          for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
           v = fmaf(v, a.scale[set * a.Nout + col], a.shift[set * a.Nout + col]);
-          a.out[(size_t)row * a.ldout + col] = a.relu ? fmaxf(v, 0.f) : v;
+          v = a.relu ? fmaxf(v, 0.f) : v;
+          a.out[(size_t)row * a.ldout + col] = v;
+          if (a.finish == 1 && col < 3) {   // row = cloud
+            const int tower = row >= a.B, b = row - tower * a.B;
+            const float s = v + add0[r];
+            a.s1c[row * 3 + col] = s;
+            a.xform[row * 12 + col] = s;
+            float* oc = tower ? a.out_b : a.out_a;
+            if (oc) oc[b * 3 + col] = s;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a.xform[row * 12 + 3 + 3 * col + i] = (i == col) ? 1.f : 0.f;   // row `col` of the identity
+          } else if (a.finish == 3) {       // row = pair
+            if (col < 3) { if (a.out_a) a.out_a[row * 3 + col] = v + (add1[r] - add0[r]); }
+            else if (a.out_b) a.out_b[(size_t)row * 2 * a.nb + (col - 3)] = v;
+          }
         }
       }
     }
