@@ -112,6 +112,7 @@ struct TrainWS {
   double *dbg2_part, *dbg1_part, *s1_part;
   float *dbg2, *dbg1;
   float *W3E, *W3T, *Q3, *q3b, *q3img;
+  float* u3;                     // [2][C3]: prep3_kernel's u, from which pass B2's bias row follows without Q3 (bf16 mode)
   float *rstd2, *W2E, *V2, *Q2, *q2b, *v2img, *q2img;
   float *k1, *rstd1;
   float* outs[8];
@@ -401,6 +402,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->W3E = F(2 * (size_t)maxC2 * maxC3);
     w->W3T = F((size_t)maxC2 * maxC3); w->Q3 = F(2 * (size_t)maxC2 * maxC2); w->q3b = F(2 * maxC2);
     w->q3img = F(2 * (size_t)maxC2 * maxC2 + 1024);
+    w->u3 = F(2 * (size_t)maxC3);
     w->rstd2 = F(2 * maxC2);
     w->W2E = F(2 * (size_t)maxC1 * maxC2); w->V2 = F(2 * (size_t)maxC1 * maxC2); w->Q2 = F(2 * (size_t)maxC1 * maxC1);
     w->q2b = F(2 * maxC1); w->v2img = F(2 * (size_t)maxC1 * maxC2 + 1024); w->q2img = F(2 * (size_t)maxC1 * maxC1 + 1024);
@@ -1235,6 +1237,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   p3.dP = S.dP; p3.tower_stride = S.tower_stride; p3.row_stride = S.row_stride; p3.pooled = S.pooled; p3.zhat_star = S.zhat_star;
   for (int t = 0; t < 2; ++t) { p3.gamma[t] = P(h, L[2]->p_bn[t][1]); p3.dbeta[t] = G(h, w, L[2]->p_bn[t][0]); p3.dgamma[t] = G(h, w, L[2]->p_bn[t][1]); }
   p3.var = S.var[2]; p3.B = B; p3.C = C3; p3.M = M; p3.E = S.E3; p3.kdb = S.kdb3; p3.gs = S.gs;
+  const size_t qimg = img_floats(C2, C2);
+  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
+  const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
+  const bool spm = !given && std_w && !b2_accum && h->train_bf16;   // sparse rows on the matrix pipe: the X region holds h1 | R^T | S lo instead of an fp32 tile
+  const bool q3_bf16 = h->train_bf16 && (!given || given_bf16);   // pass B2 reads only the bf16 images of Q3 in this mode
+  if (q3_bf16) { p3.u = w->u3; p3.m2 = S.m2; p3.W = P(h, L[2]->p_w); p3.C2 = C2; }
   if (sync) {
     p3.mode = 1; p3.totals = h->sync_buf;
     hipLaunchKernelGGL(prep3_kernel, dim3((C3 + 31) / 32, 2), dim3(1024), 0, h->stream, p3);
@@ -1254,25 +1262,20 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (h->ablate_mutation == 4) gscale3 = 1.f;   // (mutation: the global-sum terms of dW3 are added `world` times by the gradient all-reduce)
 #endif
   def_combine(h, w, CombineJob{S.Sp, nullptr, S.m2, S.kdb3, S.GW, S.E3, C2, C3, G(h, w, L[2]->p_w), gscale3});
-  const size_t qimg = img_floats(C2, C2);
-  const bool std_w = C1 == 64 && C2 == 128;   // every shipped config: instantiations with compile-time widths
-  const bool b2_accum = ((C1 + 31) / 32) * ((C2 + 31) / 32) + ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2 > 3 * kTW;   // else pass B1 does it
-  const bool spm = !given && std_w && !b2_accum && h->train_bf16;   // sparse rows on the matrix pipe: the X region holds h1 | R^T | S lo instead of an fp32 tile
   // W3^T for the VALU form of pass B2's sparse rows (the matrix-pipe form gathers from the bf16 table packed at the start of the step)
   if (!spm) hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C2 * C3), dim3(256), 0, h->stream, W3, C2, C3, nullptr, w->W3E, 0, 0, nullptr, w->W3T, 1, 1);
-  {   // Q3[t] = W3 diag(E3[t]) W3^T: the per-k scale rides on the product's A operand (no W3 diag(E) copy)
-    GemmArgs g = gemm_args(W3, C3, 1, W3, 1, C3, w->Q3, C2, 1, C2, C2, C3);
-    g.batch_a = 0; g.batch_b = 0; g.batch_c = (long)C2 * C2; g.kscale = S.E3; g.batch_k = C3;
-    hipLaunchKernelGGL(gemm_small, dim3((C2 + 31) / 32, (C2 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
-  }
   const size_t qimgh = (size_t)((C2 + 31) / 32) * ((C2 + 15) / 16) * 512;   // bf16 image elements per tower
-  if (h->train_bf16 && (!given || given_bf16)) {   // pass B2 reads only the bf16 images of Q3 in this mode: both towers in one launch, no fp32 image
+  GemmArgs gq3 = gemm_args(W3, C3, 1, W3, 1, C3, w->Q3, C2, 1, C2, C2, C3);   // Q3[t] = W3 diag(E3[t]) W3^T: the per-k scale rides on the product's A operand (no W3 diag(E) copy)
+  gq3.batch_a = 0; gq3.batch_b = 0; gq3.batch_c = (long)C2 * C2; gq3.kscale = S.E3; gq3.batch_k = C3;
+  if (q3_bf16) {
+    // one launch: the product with its bf16 operand image written from the epilogue + pass B2's bias row from prep3's u (no Q3 read-back, no pack launch)
     if (!w->q3imgh) HIP_TRY(h, hipMalloc(&w->q3imgh, 2 * (size_t)4 * 8 * 512 * sizeof(unsigned short)));   // C2 <= 128
-    PackBf16Jobs pj{};
-    for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q3 + (size_t)t * C2 * C2; pj.dst[t] = w->q3imgh + t * qimgh; pj.K[t] = C2; pj.C[t] = C2; }
-    // (+ the pass's bias row q3b, which reads the same fresh Q3: one launch)
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C2, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q3, S.m2, W3, S.kdb3, C2, C3, M, w->q3b});
+    gq3.img = w->q3imgh; gq3.batch_img = (long)qimgh;
+    const int tx = (C2 + 31) / 32, ntile = tx * tx;
+    hipLaunchKernelGGL(gemm_qimg_kernel, dim3(ntile + C2, 2), dim3(kGemmWaves * 64), 0, h->stream, gq3, tx, ntile,
+                       QBias2Args{W3, C2, C3, w->u3, nullptr, nullptr, nullptr, M, w->q3b}, PackBf16Jobs{}, 0, 0u);
   } else {
+    hipLaunchKernelGGL(gemm_small, dim3((C2 + 31) / 32, (C2 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, gq3);
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 2), dim3(256), 0, h->stream, w->stage_pack + s * 6);
     hipLaunchKernelGGL(qbias_kernel, dim3(C2, 2), dim3(256), 0, h->stream, w->Q3, S.m2, W3, S.kdb3, C2, C3, M, w->q3b);
   }
@@ -1374,20 +1377,31 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   // V2[t] = (W2 diag(k2))^T  [C2][C1]  (the bf16 pass B1 packs its image straight from W2 and k2: no fp32 copy)
   if (!b1_bf16) hipLaunchKernelGGL(scale_cols2_kernel, g256t((size_t)C1 * C2), dim3(256), 0, h->stream, W2, C1, C2, nullptr, w->W2E, 0, 0, S.k2, w->V2, 1, 2);
   const size_t vimg = img_floats(C2, C1), q2img = img_floats(C1, C1);
+  const bool dg_bf16 = dg && h->train_bf16;   // edge pass with h1 Q2 on bf16 MFMA: bf16 images of Q2, packed with the bias row
+  constexpr size_t kQ2hMax = 2 * 4 * 512;     // [CT1 <= 2][KG16 <= 4][64 lanes][8]
+  constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // bf16 pass B1 (64 / 128): [CT = 2][KG][64 lanes][8]
   {   // Q2[t] = W2 diag(E2[t]) W2^T
     GemmArgs g = gemm_args(W2, C2, 1, W2, 1, C2, w->Q2, C1, 1, C1, C1, C2);
     g.batch_a = 0; g.batch_b = 0; g.batch_c = (long)C1 * C1; g.kscale = S.E2; g.batch_k = C2;
-    hipLaunchKernelGGL(gemm_small, dim3((C1 + 31) / 32, (C1 + 31) / 32, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
+    const int tx = (C1 + 31) / 32, ntile = tx * tx;
+    const QBias2Args qa{W2, C1, C2, nullptr, S.m1, S.E2, S.kdb2, Me, w->q2b};   // (u formed in the bias-row blocks: C2 columns x a C1-long dot)
+    if (b1_bf16) {
+      // one launch: the product with its bf16 image, the bias row q2b, and the images of V2 = (W2 diag(k2))^T packed straight from W2 and k2
+      if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
+      g.img = w->b1imgh + 2 * kV2h; g.batch_img = (long)kQ2h;
+      PackBf16Jobs pj{};
+      for (int t = 0; t < 2; ++t) { pj.src[t] = W2; pj.tr[t] = 1; pj.rowscale[t] = S.k2 + (size_t)t * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1; }
+      hipLaunchKernelGGL(gemm_qimg_kernel, dim3(ntile + C1 + 8, 2), dim3(kGemmWaves * 64), 0, h->stream, g, tx, ntile, qa, pj, 2, 8u);
+    } else if (dg_bf16 && C2 <= 512) {
+      if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (2 * 8 * 512 + kQ2hMax) * sizeof(unsigned short)));   // (the PointNet bf16 B1's allocation)
+      g.img = w->b1imgh; g.batch_img = (long)kQ2hMax;
+      hipLaunchKernelGGL(gemm_qimg_kernel, dim3(ntile + C1, 2), dim3(kGemmWaves * 64), 0, h->stream, g, tx, ntile, qa, PackBf16Jobs{}, 0, 0u);
+    } else {
+      hipLaunchKernelGGL(gemm_small, dim3(tx, tx, 2), dim3(kGemmWaves * 64), 0, h->stream, g);
+      hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
+      hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b);
+    }
   }
-  if (!b1_bf16) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(16, 4), dim3(256), 0, h->stream, w->stage_pack + s * 6 + 2);
-  const bool dg_bf16 = dg && h->train_bf16;   // edge pass with h1 Q2 on bf16 MFMA: bf16 images of Q2, packed with the bias row
-  constexpr size_t kQ2hMax = 2 * 4 * 512;     // [CT1 <= 2][KG16 <= 4][64 lanes][8]
-  if (dg_bf16) {
-    if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (2 * 8 * 512 + kQ2hMax) * sizeof(unsigned short)));   // (the PointNet bf16 B1's allocation)
-    PackBf16Jobs pj{};
-    for (int t = 0; t < 2; ++t) { pj.src[t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[t] = w->b1imgh + t * kQ2hMax; pj.K[t] = C1; pj.C[t] = C1; }
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 2), dim3(256), 0, h->stream, pj, 2, 8u, QBiasArgs{w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b});
-  } else if (!b1_bf16) hipLaunchKernelGGL(qbias_kernel, dim3(C1, 2), dim3(256), 0, h->stream, w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b);   // (bf16 B1: with its images below)
   if (dg) {
     // ---- edge pass + first layer from the reduced quantities (kernels_train_dgcnn.h) ----
     DgBwdArgs e;
@@ -1456,15 +1470,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.pdy_part = w->pdy_part;
   const bool b1h = pdy && std_w && h->train_bf16 && !(h->ab & AB_B1_FP32);
   if (b1h) {
-    // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16): bf16 images of V2 / Q2 per tower, then the kernel
-    constexpr size_t kV2h = 2 * 8 * 512, kQ2h = 2 * 4 * 512;   // [CT = 2][KG][64 lanes][8]
-    if (!w->b1imgh) HIP_TRY(h, hipMalloc(&w->b1imgh, 2 * (kV2h + kQ2h) * sizeof(unsigned short)));
-    PackBf16Jobs pj{};
-    for (int t = 0; t < 2; ++t) {
-      pj.src[t] = W2; pj.tr[t] = 1; pj.rowscale[t] = S.k2 + (size_t)t * C2; pj.dst[t] = w->b1imgh + t * kV2h; pj.K[t] = C2; pj.C[t] = C1;   // V2[t] = (W2 diag(k2[t]))^T
-      pj.src[2 + t] = w->Q2 + (size_t)t * C1 * C1; pj.dst[2 + t] = w->b1imgh + 2 * kV2h + t * kQ2h; pj.K[2 + t] = C1; pj.C[2 + t] = C1;
-    }
-    hipLaunchKernelGGL(pack_qbias_kernel, dim3(8 + C1, 4), dim3(256), 0, h->stream, pj, 4, 8u, QBiasArgs{w->Q2, S.m1, W2, S.kdb2, C1, C2, Me, w->q2b});
+    // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16); the bf16 images of V2 / Q2 and the bias row came out of the Q2 launch above
     BwdB1hArgs bh;
     bh.pcs[0] = p1; bh.pcs[1] = p2; bh.xform = S.xform; bh.B = B; bh.N = N;
     bh.w1 = P(h, L[0]->p_w); bh.sc1 = S.scale[0]; bh.sh1 = S.shift[0];

@@ -19,6 +19,7 @@
 #pragma once
 #include "ablate.h"
 #include "kernels_train_fwd.h"
+#include "kernels_train_head.h"
 
 namespace alignnet {
 
@@ -1364,6 +1365,9 @@ struct Prep3Args {
   float* dbeta[2]; float* dgamma[2];
   float* E; float* kdb; float* gs;                  // [2][C], [2][C], [2B][C]
   double* totals = nullptr; int mode = 0;           // sync_bn: 1 = local (dbeta, dgamma) -> gradients + totals [2][C][2] and gs; 2 = E / kdb from the all-reduced totals
+  // optional (bf16 mode): u[t][c] = (m2[t] . W3[:, c]) E[t][c] + kdb[t][c] / M, from which pass B2's bias row follows without Q3:
+  // q3b[j] = -sum_i m2[i] Q3[i][j] - sum_c W3[j][c] kdb[c] / M = -sum_c W3[j][c] u[c]
+  float* u = nullptr; const float* m2 = nullptr; const float* W = nullptr; int C2 = 0;
 };
 
 __global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // grid (ceil(C/32), 2), block 32 channels x 32 cloud groups (the cloud loop is a chain of dependent loads)
@@ -1394,15 +1398,32 @@ __global__ __launch_bounds__(1024) void prep3_kernel(const Prep3Args a)   // gri
     }
   }
   red[g][cl][0] = sb; red[g][cl][1] = sg;
+  double vp = 0.0;   // this row group's share of m2 . W3[:, c]
+  if (a.u && a.mode != 1 && c < a.C)
+    for (int i = g; i < a.C2; i += 32) vp += (double)a.m2[t * a.C2 + i] * (double)a.W[(size_t)i * a.C + c];
   __syncthreads();
+  if (g == 0 && c < a.C) {
+    sb = 0.0; sg = 0.0;
+    for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
+  }
+  const bool with_u = a.u && a.mode != 1;
+  if (with_u) {
+    __syncthreads();
+    red[g][cl][0] = vp;
+    __syncthreads();
+  }
   if (g != 0 || c >= a.C) return;
-  sb = 0.0; sg = 0.0;
-  for (int q = 0; q < 32; ++q) { sb += red[q][cl][0]; sg += red[q][cl][1]; }
   if (a.mode == 2) { sb = a.totals[((size_t)t * a.C + c) * 2]; sg = a.totals[((size_t)t * a.C + c) * 2 + 1]; }
   else { a.dbeta[t][c] = (float)sb; a.dgamma[t][c] = (float)sg; }
   if (a.mode == 1) { a.totals[((size_t)t * a.C + c) * 2] = sb; a.totals[((size_t)t * a.C + c) * 2 + 1] = sg; return; }
-  a.E[t * a.C + c] = (float)(-(double)k * rs * sg / a.M);
-  a.kdb[t * a.C + c] = (float)((double)k * sb);
+  const float Ef = (float)(-(double)k * rs * sg / a.M), kdbf = (float)((double)k * sb);
+  a.E[t * a.C + c] = Ef;
+  a.kdb[t * a.C + c] = kdbf;
+  if (with_u) {
+    double v = 0.0;
+    for (int q = 0; q < 32; ++q) v += red[q][cl][0];
+    a.u[t * a.C + c] = (float)(v * (double)Ef + (double)kdbf / a.M);
+  }
 }
 
 // hidden layer (after its pass): E = -k r dgamma/M, kdb = k*dbeta, k, rstd from totals
@@ -1771,6 +1792,49 @@ __global__ __launch_bounds__(256) void pack_qbias_kernel(const PackBf16Jobs j, i
 {
   if (blockIdx.x < pack_gx) { if ((int)blockIdx.y < njobs) pack_bf16_jobs_body(j, blockIdx.x, blockIdx.y, pack_gx); }
   else if (blockIdx.y < 2) qbias_body(qa, blockIdx.x - pack_gx, blockIdx.y);
+}
+
+// Round 4: Q = W diag(E) W^T, its bf16 operand image, the pass's bias row and (pass B1) the images of V2, ONE launch -- was
+// gemm_small, then pack_qbias_kernel (which re-read the fresh Q), six times per step.  Blocks x < ntile: the product's 32 x 32 tiles with
+// the image written from the epilogue (GemmArgs.img);  x < ntile + R: bias row qb[t][j] = -sum_c W[j][c] u[t][c], with
+// u[c] = (m . W[:, c]) E[c] + kdb[c] / M given (prep3_kernel) or formed here (small layers);  the rest: pack jobs (V2).  grid (ntile + R + pack_gx, 2).
+struct QBias2Args { const float* W; int R, K; const float* u; const float* m; const float* E; const float* kdb; double M; float* qb; };
+__device__ __forceinline__ void qbias2_body(const QBias2Args& a, int j, int t)
+{
+  __shared__ double red2[8];
+  __shared__ float us[1024];
+  const int tid = threadIdx.x;
+  if (!a.u) {   // u of this tower, formed here for small layers (K <= 512 columns x an R-long dot each: the 64 -> 128 hidden layer); P row slices per column
+    __shared__ double up[512];
+    const int P = 512 / a.K, c = tid % a.K, pp = tid / a.K;
+    double v = 0.0;
+    if (pp < P)
+      for (int i = pp; i < a.R; i += P) v += (double)a.m[t * a.R + i] * (double)a.W[(size_t)i * a.K + c];
+    up[tid] = v;
+    __syncthreads();
+    if (tid < a.K) {
+      double tot = 0.0;
+      for (int q = 0; q < P; ++q) tot += up[q * a.K + tid];
+      us[tid] = (float)(tot * (double)a.E[t * a.K + tid] + (double)a.kdb[t * a.K + tid] / a.M);
+    }
+    __syncthreads();
+  }
+  double s = 0.0;
+  for (int c = tid; c < a.K; c += 512) s -= (double)a.W[(size_t)j * a.K + c] * (double)(a.u ? a.u[t * a.K + c] : us[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red2[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) { double tot = 0.0; for (int w = 0; w < 8; ++w) tot += red2[w]; a.qb[t * a.R + j] = (float)tot; }
+}
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_qimg_kernel(const GemmArgs g, int tx, int ntile, const QBias2Args qa, const PackBf16Jobs pj, int npack,
+                                                                    unsigned pack_gx)
+{
+  const int bx = blockIdx.x, t = blockIdx.y;
+  if (bx < ntile) { gemm_small_tile(g, bx % tx, bx / tx, t); return; }
+  if (bx < ntile + qa.R) { qbias2_body(qa, bx - ntile, t); return; }
+  if (threadIdx.x < 256)   // (the pack body strides by 256 threads per block)
+    for (int q = t; q < npack; q += 2) pack_bf16_jobs_body(pj, bx - ntile - qa.R, q, pack_gx);
 }
 
 }  // namespace alignnet

@@ -21,6 +21,10 @@ struct GemmArgs {
   long batch_a, batch_b, batch_c;   // element strides between batch entries (blockIdx.z)
   const float* kscale = nullptr;    // [K] or null: C = sum_k A(i,k) kscale[k] B(k,j) -- e.g. Q = W diag(E) W^T without materialising W diag(E)
   long batch_k = 0;                 // its stride between batch entries
+  // optional second output: C as a bf16 MFMA B-operand image (rows of C = the operand's k, columns = its channels; layout of
+  // pack_bf16_jobs_body: [ct][kg][lane][8], k = 16 kg + 8 (lane >> 5) + s, c = 32 ct + (lane & 31)) -- the backward's Q matrices are
+  // consumed only in that form, and a pack launch of their own behind the product cost 5.3 us, six times per step
+  unsigned short* img = nullptr; long batch_img = 0;
 };
 
 constexpr int kGemmWaves = 8, kGemmKC = 32, kGemmLd = 33;
@@ -126,6 +130,11 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
         v = v * a.alpha + bias;
         float* dst = a.C + bz * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
         *dst = a.accumulate ? *dst + v : v;
+        if (a.img) {
+          const int KGi = (a.M + 15) >> 4;
+          const size_t ii = ((((size_t)(j >> 5) * KGi + (row >> 4)) * 64 + (((row >> 3) & 1) * 32 + (j & 31))) << 3) + (row & 7);
+          a.img[bz * a.batch_img + ii] = to_bf16_bits(v);
+        }
       }
     }
   }
