@@ -4,7 +4,7 @@ stats, PMC sums) -- every figure in that table is computed here, none is typed b
 Usage: tools/design_table.py r03 [--write]     (--write replaces the block between the r-table markers in DESIGN.md)"""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
 
 
@@ -76,6 +76,19 @@ if b:
         add("host to host, blocking `alignnet_forward` (pageable buffers; the reference's own timing, train.py:447-449)", "%.1f k pairs/s (%.2f ms/step)" % (pc["value"] / 1e3, pc["ms_per_step"]), "bench `pcie_inclusive`; never `value`")
         if "pipelined" in pc:
             add("host to host, pipelined `alignnet_forward_submit / _wait`", "**%.1f k pairs/s** (%.2f ms/step) = %.3f of the device-resident rate" % (pc["pipelined"]["value"] / 1e3, pc["pipelined"]["ms_per_step"], pc["pipelined"]["value"] / b["value"]), "bench `pcie_inclusive.pipelined`")
+    if "dgcnn" in b and "infer" in b["dgcnn"]:
+        di = b["dgcnn"]["infer"]
+        add("short legs of the default line: DGCNN (BASELINE configs[4] shape, N = 4096)", "inference %.2f k pairs/s at %d pairs/step (`%s` at %.3f of the roofline, kNN %.1f ms of %.1f); training at %d pairs/step: fp32 %.2f k, bf16 convs %.2f k pairs/s"
+            % (di["value"] / 1e3, di["pairs_per_step"], di["kernel"], di["roofline_frac"] or 0, di["knn_ms_per_step"], di["ms_per_step"], b["dgcnn"]["train_f32"]["pairs_per_step"],
+               b["dgcnn"]["train_f32"]["value"] / 1e3, b["dgcnn"]["train_bf16"]["value"] / 1e3), "bench `dgcnn`")
+    if "loader" in b and "packed_pairs_per_s" in b["loader"]:
+        lo = b["loader"]
+        add("short legs: batch loader (SURVEY 8 f1)", "reference-style files %.1f k pairs/s, packed cache %.1f k pairs/s (identical batches: %s); HBM-resident dataset + device sampler feeding fp32 training steps: %.1f k pairs/s"
+            % (lo["file_based_pairs_per_s"] / 1e3, lo["packed_pairs_per_s"] / 1e3, lo["identical_batches"], lo.get("device_sampler_train", {}).get("value", 0) / 1e3), "bench `loader`")
+    if "icp" in b and "value" in b["icp"]:
+        ic = b["icp"]
+        add("short legs: ICP refinement (SURVEY 8 f4)", "%.1f k pairs/s (%d pairs x %d points, radius %.1f, <= %d iterations, mean %.1f; fitness %.2f)"
+            % (ic["value"] / 1e3, ic["pairs"], ic["points_per_cloud"], ic["radius"], ic["max_iterations"], ic["mean_iterations"], ic["mean_fitness"]), "bench `icp`")
     if "cpu_baseline" in b:
         c = b["cpu_baseline"]
         add("CPU baseline (\"port\": unfused NumPy fp32 oracle, B = 32), thread sweep", ", ".join("%.1f pairs/s on %d" % (x["value"], x["threads"]) for x in c["sweep"]) + " threads (%d host cores)" % c["host_cores"], "bench `cpu_baseline.sweep`")
@@ -91,6 +104,8 @@ for tag, name, lab in (("train", "%s_bench_train_f32.json", "training step, fp32
     share = t["roofline"]["step_share"]
     txt = "**%.1f k pairs/s** (%.3f ms/step): " % (t["value"] / 1e3, t["ms_per_step"]) + ", ".join("%s %.2f ms" % (k.replace("train_", ""), v) for k, v in list(share.items())[:4])
     txt += "; dominant `%s` at %.3f of the %s roofline" % (t["roofline"]["kernel"], t["roofline"]["frac"], "bf16-MFMA" if t["roofline"]["peak"] > 1000 else "fp32-MFMA")
+    if t["roofline"].get("frac_lift_only") is not None:
+        txt += " (%.3f on the lift alone, without the fused Gram's FLOPs)" % t["roofline"]["frac_lift_only"]
     if steps:
         tot = sum(v[0] for v in ks.values()) / steps
         small = sum(v[0] for v in ks.values() if v[2] < 50) / steps

@@ -3,7 +3,7 @@
 # Usage: tools/profile.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/...
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg}
+ARGS=${@:---steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg --no-extra-legs}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 # Run ON THE GPU BOX (via gpurun): every bench line and rocprofv3 summary that profiles/<round>_* holds, in one call.
 # Usage: bash tools/refresh_profiles.sh r02 [quick]
 set -u
-R=${1:-r03}
+R=${1:-r04}
 mkdir -p gpurun_out/fin
 python bench.py > gpurun_out/fin/${R}_bench.json 2>gpurun_out/fin/bench.err
 python bench.py --mode train --train-dtype f32 --steps 50 --warmup 5 > gpurun_out/fin/${R}_bench_train_f32.json 2>/dev/null
@@ -14,7 +14,7 @@ python bench.py --mode train --workload dgcnn --batch 512 --steps 2 --warmup 1 -
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --points 1024 --steps 10 --warmup 2 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n1024.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 64 --steps 5 --warmup 1 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b64.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 512 --steps 3 --warmup 1 --sustained-seconds 0 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b512.json 2>/dev/null
-Q="--no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg --sustained-seconds 0"
+Q="--no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg --no-extra-legs --sustained-seconds 0"
 S="--sustained-seconds 0"
 bash tools/profile.sh ${R} --steps 20 --warmup 3 $Q > gpurun_out/fin/p_${R}.log 2>&1
 bash tools/profile.sh ${R}_train --mode train --train-dtype f32 --steps 20 --warmup 3 $S > gpurun_out/fin/p_train.log 2>&1
