@@ -427,6 +427,10 @@ class Engine:
     def comm_allreduce_grads(self):
         self._check(self._lib.alignnet_comm_allreduce_grads(self._h))
 
+    def comm_average_shadows(self):
+        """Average the BatchNorm EMA shadows over the ranks of the engine's communicator (one all-reduce on the device)."""
+        self._check(self._lib.alignnet_comm_average_shadows(self._h))
+
     # ---- checkpoints (tf.train.Saver, train.py:220,252,268,281,317,321) -----------
     def save(self, path):
         self._check(self._lib.alignnet_save(self._h, str(path).encode()))

@@ -38,24 +38,30 @@ def mean_scalar(dist, x):
     return float(t.item()) / dist.get_world_size()
 
 
-def average_ema_shadows(engine, dist):
-    """All-reduce-average the non-trainable variables (the BatchNorm EMA shadows) across ranks.  Local-BN data parallelism
-    updates each rank's shadows from its own shard's batch statistics; averaging them (the mean of the per-rank EMAs is the EMA
-    of the per-rank means) keeps every rank's eval-mode model -- and the checkpoint rank 0 writes -- identical."""
+def average_ema_shadows(engine, dist=None):
+    """Average the non-trainable variables (the BatchNorm EMA shadows) across ranks.  Local-BN data parallelism updates each rank's
+    shadows from its own shard's batch statistics; averaging them (the mean of the per-rank EMAs is the EMA of the per-rank means)
+    keeps every rank's eval-mode model -- and the checkpoint rank 0 writes -- identical.  With the engine's own communicator (RCCL or
+    loopback) this is one all-reduce of the shadow segment on the device (alignnet_comm_average_shadows); without one, the values
+    travel through `dist` (a torch.distributed process group) on the host."""
+    n = sum(1 for _, _, trainable in engine.variables() if not trainable)
+    if not n:
+        return 0
+    if engine.get_option("comm_world") > 1:
+        engine.comm_average_shadows()
+        return n
     import numpy as np
     import torch
-    names = [(n, s) for n, s, trainable in engine.variables() if not trainable]
-    if not names:
-        return 0
-    flat = np.concatenate([np.asarray(engine.get_variable(n), np.float32).ravel() for n, _ in names])
+    names = [(nm, s) for nm, s, trainable in engine.variables() if not trainable]
+    flat = np.concatenate([np.asarray(engine.get_variable(nm), np.float32).ravel() for nm, _ in names])
     t = torch.from_numpy(flat)
     if dist.get_backend() == "nccl":
         t = t.cuda()
     dist.all_reduce(t)
     flat = (t.cpu().numpy() / dist.get_world_size()).astype(np.float32)
     off = 0
-    for n, (r, c) in names:
-        engine.set_variable(n, flat[off:off + r * c])
+    for nm, (r, c) in names:
+        engine.set_variable(nm, flat[off:off + r * c])
         off += r * c
     return len(names)
 

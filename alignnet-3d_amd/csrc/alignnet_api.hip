@@ -466,7 +466,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   a.tiles_per_wg = per;
   const dim3 grid((ntiles + per - 1) / per, 2 * B);
   {
-  ProfScope prof_scope(h, PK_BACKBONE);
+  ProfScope prof_scope(h, PK_BACKBONE, true);
   const int sc1 = h->layers[st.first].cout, sc2 = st.n == 3 ? h->layers[st.first + 1].cout : 0;
   if (h->infer_split && st.n == 3 && sc1 <= 16 * kSplitKB1 && sc2 <= 16 * kSplitKB2) {
     // split-bf16 backbone (opt-in): same tiling, three bf16 MFMAs per fp32 product
@@ -482,20 +482,20 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     if (sc1 == 64 && sc2 == 128 && !(h->ab & AB_NO_LD_CONST)) {
       static PerDeviceOnce sattr;
       if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
-      hipLaunchKernelGGL((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+      TIMED_LAUNCH((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, sa);
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_64_128;
     } else {
-      hipLaunchKernelGGL(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, h->stream, sa);
+      TIMED_LAUNCH(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, sa);
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT;
     }
-  } else if (TP == 64) { hipLaunchKernelGGL(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_TP64; }
+  } else if (TP == 64) { TIMED_LAUNCH(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_TP64; }
   else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !(h->ab & AB_NO_LD_CONST)) {
-    hipLaunchKernelGGL((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, h->stream, a);
+    TIMED_LAUNCH((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, a);
     h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16;
   } else if (a.ld[0] == 68 && a.ld[1] == 132 && !(h->ab & AB_NO_LD_CONST)) {   // the shipped widths 64, 128
-    hipLaunchKernelGGL((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
+    TIMED_LAUNCH((pointnet_fused<128, 68, 132>), grid, dim3(kWaves * 64), lds, a);
     h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128;
-  } else { hipLaunchKernelGGL(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, h->stream, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED; }
+  } else { TIMED_LAUNCH(pointnet_fused<128>, grid, dim3(kWaves * 64), lds, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED; }
   }
   HIP_TRY(h, hipGetLastError());
 #ifdef ALIGNNET_KSTAMP
@@ -546,7 +546,7 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
   }
   const dim3 grid((a.N + kDgTile - 1) / kDgTile, 2 * B);
   {
-  ProfScope prof_scope(h, PK_BACKBONE);
+  ProfScope prof_scope(h, PK_BACKBONE, true);
   {
     const int dca = h->layers[st.first].cout, dcb = st.n == 3 ? h->layers[st.first + 1].cout : 0;
     if (h->infer_split && st.n == 3 && dca <= 16 * kSplitKB1 && dcb <= 128) {
@@ -565,10 +565,10 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       if (dca == 64 && dcb == 128 && !(h->ab & AB_NO_LD_CONST)) {
         static PerDeviceOnce dsattr2;
         if (dsattr2.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dsattr2.mark(h->cfg.device); }
-        hipLaunchKernelGGL((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, h->stream, sa);
+        TIMED_LAUNCH((dgcnn_split<64, 128>), grid, dim3(kWaves * 64), dlds, sa);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT_64_128;
       } else {
-        hipLaunchKernelGGL(dgcnn_split<>, grid, dim3(kWaves * 64), dlds, h->stream, sa);
+        TIMED_LAUNCH(dgcnn_split<>, grid, dim3(kWaves * 64), dlds, sa);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_SPLIT;
       }
     } else {
@@ -577,10 +577,10 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
       if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && !(h->ab & AB_NO_LD_CONST)) {   // the shipped widths 64, 128
         static PerDeviceOnce sattr;
         if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dgcnn_fused<68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
-        hipLaunchKernelGGL((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, h->stream, a);
+        TIMED_LAUNCH((dgcnn_fused<68, 132>), grid, dim3(kWaves * 64), lds, a);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED_64_128;
       } else {
-        hipLaunchKernelGGL(dgcnn_fused<>, grid, dim3(kWaves * 64), lds, h->stream, a);
+        TIMED_LAUNCH(dgcnn_fused<>, grid, dim3(kWaves * 64), lds, a);
         h->last_kernel = ALIGNNET_KERNEL_DGCNN_FUSED;
       }
       if (a.stamps) {
@@ -648,8 +648,9 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean, w.pool1,
                      (size_t)((char*)w.hid_a - (char*)w.pool1) / sizeof(float));
   if (dg) {   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
-    ProfScope prof_scope(h, PK_KNN);
-    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn));
+    ProfScope prof_scope(h, PK_KNN, true);
+    prof_scope.used = true;
+    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w.center_mean, B, N, 20, w.d_nn, prof_scope.a, prof_scope.b));
   }
   // stage 1 (tp8.py:108-109)
   if (backbone(h->s1_conv, w.pool1, (long)B * C1, C1, (size_t)B2 * C1)) return 1;

@@ -878,11 +878,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
     d.dbg = a.dbg;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
-  { ProfScope prof_scope(h, PK_DG_FWD);
-    if (h->train_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_fwd<64, true>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
-    else if (h->train_bf16) hipLaunchKernelGGL((dg_train_fwd<32, true>), dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
-    else if (C1 == 64) hipLaunchKernelGGL(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
-    else hipLaunchKernelGGL(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, h->stream, d);
+  { ProfScope prof_scope(h, PK_DG_FWD, true);
+    if (h->train_bf16 && C1 == 64) TIMED_LAUNCH((dg_train_fwd<64, true>), dim3(2 * B), dim3(kTW * 64), dlds, d);
+    else if (h->train_bf16) TIMED_LAUNCH((dg_train_fwd<32, true>), dim3(2 * B), dim3(kTW * 64), dlds, d);
+    else if (C1 == 64) TIMED_LAUNCH(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, d);
+    else TIMED_LAUNCH(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, d);
   }
     if (d.stamps) {
       long long sv[11];
@@ -922,17 +922,17 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       a.wp3h = w->wp3h[s];
       const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                           ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
-      { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-      if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
-      else hipLaunchKernelGGL((train_fwd_phase23<3, true, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+      { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
+      if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
+      else TIMED_LAUNCH((train_fwd_phase23<3, true, true>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
       }
       if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2))) return 1;
     } else {
-  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
-    if (wide_gram) hipLaunchKernelGGL((train_fwd_phase3_wide<true, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
-    else if (wide) hipLaunchKernelGGL((train_fwd_phase3_wide<true, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
-    else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-    else hipLaunchKernelGGL((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
+    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<true, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    else if (wide) TIMED_LAUNCH((train_fwd_phase3_wide<true, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    else if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+    else TIMED_LAUNCH((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
   }
     #ifdef ALIGNNET_ABLATE
     if (wide_gram && getenv("ALIGNNET_P3_EXTCHECK")) {   // debug: ext / idx of the GRAM variant against the plain one
@@ -971,8 +971,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
         }
     }
 #endif   // ALIGNNET_ABLATE
-    if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM);
-    hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2, w->gram_part);
+    if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM, true);
+    TIMED_LAUNCH(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), S.h2, N, C2, w->gram_part);
     }
     if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;
     }
@@ -1000,11 +1000,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                        h->train_bf16 ? 1 : 0, w->stat_part);
     if (finish(1, C2, 1, count, 1, true)) return 1;
   } else {
-  { ProfScope prof_scope(h, PK_TRAIN_PHASE2);
-  if (h->train_bf16 && std_w) hipLaunchKernelGGL((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-  else if (h->train_bf16) hipLaunchKernelGGL((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-  else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-  else hipLaunchKernelGGL(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE2, true);
+  if (h->train_bf16 && std_w) TIMED_LAUNCH((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else if (h->train_bf16) TIMED_LAUNCH((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else if (std_w) TIMED_LAUNCH((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else TIMED_LAUNCH(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
   }
   if (finish(1, C2, 4, count)) return 1;
   }
@@ -1012,12 +1012,12 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     a.wp3h = w->wp3h[s];
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
-  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
     // shipped widths: 128-point tiles, the next tile's prologue under the lift (kernels_train_fwd_wide.h)
     if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64)
-      hipLaunchKernelGGL(train_fwd_phase3_wide_bf16, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_bf16(), h->stream, a);
-    else if (std_w && !(h->ab & AB_P3BF16_GENERIC)) hipLaunchKernelGGL((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
-    else hipLaunchKernelGGL((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, a);
+      TIMED_LAUNCH(train_fwd_phase3_wide_bf16, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_bf16(), a);
+    else if (std_w && !(h->ab & AB_P3BF16_GENERIC)) TIMED_LAUNCH((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
+    else TIMED_LAUNCH((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
   }
     if (a.stamps) {
       long long sv[8];
@@ -1027,16 +1027,16 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                    sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
     }
   } else {
-  { ProfScope prof_scope(h, PK_TRAIN_PHASE3);
+  { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
     // shipped widths: 128-point tiles (a weight fragment of the lift feeds four row tiles; kernels_train_fwd_wide.h)
-    if (wide_gram) hipLaunchKernelGGL((train_fwd_phase3_wide<false, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
-    else if (wide) hipLaunchKernelGGL((train_fwd_phase3_wide<false, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), h->stream, a);
-    else if (std_w) hipLaunchKernelGGL((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
-    else hipLaunchKernelGGL(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), h->stream, a);
+    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<false, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    else if (wide) TIMED_LAUNCH((train_fwd_phase3_wide<false, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    else if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+    else TIMED_LAUNCH(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
   }
-    { ProfScope prof_scope(h, PK_TRAIN_GRAM);
+    { ProfScope prof_scope(h, PK_TRAIN_GRAM, true);
     if (!a.gram_inline && !wide_gram)
-      hipLaunchKernelGGL(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), h->stream, S.h2, N, C2,
+      TIMED_LAUNCH(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), S.h2, N, C2,
                          w->gram_part);
     }
   }
@@ -1297,17 +1297,17 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) : 0);
-  { ProfScope prof_scope(h, PK_TRAIN_B2);
-  if (given_bf16 && std_w) hipLaunchKernelGGL((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (given_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (given && std_w) hipLaunchKernelGGL((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (given) hipLaunchKernelGGL((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (std_w && !b2_accum && h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (std_w && !b2_accum) hipLaunchKernelGGL((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (h->train_bf16 && b2_accum) hipLaunchKernelGGL((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (h->train_bf16) hipLaunchKernelGGL((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else if (b2_accum) hipLaunchKernelGGL(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
-  else hipLaunchKernelGGL(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, h->stream, b2);
+  { ProfScope prof_scope(h, PK_TRAIN_B2, true);
+  if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (given && std_w) TIMED_LAUNCH((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (given) TIMED_LAUNCH((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (std_w && !b2_accum && h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (std_w && !b2_accum) TIMED_LAUNCH((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (h->train_bf16 && b2_accum) TIMED_LAUNCH((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else if (b2_accum) TIMED_LAUNCH(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  else TIMED_LAUNCH(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
   }
   if (b2.stamps) {
     long long st[11];
@@ -1417,19 +1417,19 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     const bool dense = dg_bf16 && !(h->ab & AB_DG_SPARSE);   // bf16 mode: both dy2_s products as dense bf16 MFMAs on per-slot tiles
     e.k2 = S.k2; e.w2th = w->w2th[s];
     const size_t eld = dg_bwd_edge_dense_lds(C1, C2);
-  { ProfScope prof_scope(h, PK_DG_BWD_EDGE);
-    if (dense && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge_dense<64, 128>), eg, eb, eld, h->stream, e);
-    else if (dense && C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge_dense<64, 64>), eg, eb, eld, h->stream, e);
-    else if (dense && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge_dense<32, 128>), eg, eb, eld, h->stream, e);
-    else if (dense) hipLaunchKernelGGL((dg_train_bwd_edge_dense<32, 64>), eg, eb, eld, h->stream, e);
-    else if (dg_bf16 && C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128, true>), eg, eb, el, h->stream, e);
-    else if (dg_bf16 && C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64, true>), eg, eb, el, h->stream, e);
-    else if (dg_bf16 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128, true>), eg, eb, el, h->stream, e);
-    else if (dg_bf16) hipLaunchKernelGGL((dg_train_bwd_edge<32, 64, true>), eg, eb, el, h->stream, e);
-    else if (C1 == 64 && C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<64, 128>), eg, eb, el, h->stream, e);
-    else if (C1 == 64) hipLaunchKernelGGL((dg_train_bwd_edge<64, 64>), eg, eb, el, h->stream, e);
-    else if (C2 == 128) hipLaunchKernelGGL((dg_train_bwd_edge<32, 128>), eg, eb, el, h->stream, e);
-    else hipLaunchKernelGGL((dg_train_bwd_edge<32, 64>), eg, eb, el, h->stream, e);
+  { ProfScope prof_scope(h, PK_DG_BWD_EDGE, true);
+    if (dense && C1 == 64 && C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge_dense<64, 128>), eg, eb, eld, e);
+    else if (dense && C1 == 64) TIMED_LAUNCH((dg_train_bwd_edge_dense<64, 64>), eg, eb, eld, e);
+    else if (dense && C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge_dense<32, 128>), eg, eb, eld, e);
+    else if (dense) TIMED_LAUNCH((dg_train_bwd_edge_dense<32, 64>), eg, eb, eld, e);
+    else if (dg_bf16 && C1 == 64 && C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge<64, 128, true>), eg, eb, el, e);
+    else if (dg_bf16 && C1 == 64) TIMED_LAUNCH((dg_train_bwd_edge<64, 64, true>), eg, eb, el, e);
+    else if (dg_bf16 && C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge<32, 128, true>), eg, eb, el, e);
+    else if (dg_bf16) TIMED_LAUNCH((dg_train_bwd_edge<32, 64, true>), eg, eb, el, e);
+    else if (C1 == 64 && C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge<64, 128>), eg, eb, el, e);
+    else if (C1 == 64) TIMED_LAUNCH((dg_train_bwd_edge<64, 64>), eg, eb, el, e);
+    else if (C2 == 128) TIMED_LAUNCH((dg_train_bwd_edge<32, 128>), eg, eb, el, e);
+    else TIMED_LAUNCH((dg_train_bwd_edge<32, 64>), eg, eb, el, e);
   }
     u2_prescaled = dense;   // the dense form accumulates U2 diag(k2)
     if (e.stamps) {
@@ -1478,13 +1478,13 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     bh.dy2_store = reinterpret_cast<const unsigned short*>(w->dy2);
     bh.u2_part = b1.u2_part; bh.g1_part = b1.g1_part; bh.pdy_part = w->pdy_part;
     const size_t ldsh = (size_t)kTT * 4 * sizeof(float) + ((size_t)kTT * 72 * 2 + (size_t)kTT * 136 + (size_t)128 * 72) * sizeof(unsigned short);
-    ProfScope prof_scope(h, PK_TRAIN_B1);
-    hipLaunchKernelGGL(train_bwd_b1_bf16, dim3(2 * B), dim3(kTW * 64), ldsh, h->stream, bh);
+    ProfScope prof_scope(h, PK_TRAIN_B1, true);
+    TIMED_LAUNCH(train_bwd_b1_bf16, dim3(2 * B), dim3(kTW * 64), ldsh, bh);
   } else
-  { ProfScope prof_scope(h, PK_TRAIN_B1);
-  if (pdy && std_w) hipLaunchKernelGGL((train_bwd_b1<64, 128, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
-  else if (pdy) hipLaunchKernelGGL((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
-  else hipLaunchKernelGGL(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), h->stream, b1);
+  { ProfScope prof_scope(h, PK_TRAIN_B1, true);
+  if (pdy && std_w) TIMED_LAUNCH((train_bwd_b1<64, 128, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
+  else if (pdy) TIMED_LAUNCH((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
+  else TIMED_LAUNCH(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
   }
   if (acc_in_b1) layer2_weight_grad();
   if (pdy) {
@@ -1556,8 +1556,9 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (pack_all_weights(h)) return 1;
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
   if (h->cfg.backbone == 1) {   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
-    ProfScope prof_scope(h, PK_KNN);
-    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn));
+    ProfScope prof_scope(h, PK_KNN, true);
+    prof_scope.used = true;
+    HIP_TRY(h, launch_knn(h->cfg.device, h->stream, p1, p2, w->center_mean, B, N, kDgK, w->nn, prof_scope.a, prof_scope.b));
   }
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
@@ -1743,7 +1744,7 @@ extern "C" int alignnet_apply_gradients(alignnet_handle* h, float grad_scale)
   alignnet_get_state(h, &st);   // schedules use the pre-increment step (train.py:145-150,172)
   const size_t n = h->n_trainable;
   const dim3 grid((unsigned)((n + 255) / 256));
-  ProfScope prof_scope(h, PK_OPTIMIZER);
+  ProfScope prof_scope(h, PK_OPTIMIZER, true);
   if (h->cfg.optimizer == 0) {
     // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) exactly as TF evaluates it: in float32, with the beta powers kept as float32
     // products (one multiplication per step).  With the kernel's float32 (1 - beta) factors this makes the first step lr * sign(g)
@@ -1755,9 +1756,9 @@ extern "C" int alignnet_apply_gradients(alignnet_handle* h, float grad_scale)
       if (h->adam_b2p == 0.f) { h->adam_power_t = t; break; }   // both powers have underflowed: further products stay 0
     }
     const float lr_t = st.learning_rate * std::sqrt(1.f - h->adam_b2p) / (1.f - h->adam_b1p);
-    hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, w->adam_v, n, grad_scale, lr_t, 0.9f, 0.999f, 1e-8f);
+    TIMED_LAUNCH(adam_kernel, grid, dim3(256), 0, h->d_params, w->grad, w->adam_m, w->adam_v, n, grad_scale, lr_t, 0.9f, 0.999f, 1e-8f);
   } else {
-    hipLaunchKernelGGL(momentum_kernel, grid, dim3(256), 0, h->stream, h->d_params, w->grad, w->adam_m, n, grad_scale, st.learning_rate, h->cfg.momentum);
+    TIMED_LAUNCH(momentum_kernel, grid, dim3(256), 0, h->d_params, w->grad, w->adam_m, n, grad_scale, st.learning_rate, h->cfg.momentum);
   }
   HIP_TRY(h, hipGetLastError());
   w->grad_clean = true;
@@ -2170,6 +2171,24 @@ static int sync_gather(alignnet_handle* h, const void* src, void* dst, size_t n4
   if (h->comm) return comm_allgather(h, src, dst, n4, h->stream);
   for (int r = 0; r < h->sync_emulate_world; ++r)
     HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(dst) + (size_t)r * n4 * 4, src, n4 * 4, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+// Local-BN data parallelism updates each rank's BatchNorm EMA shadows from its own shard's statistics; averaging them across the ranks
+// (the mean of the per-rank EMAs is the EMA of the per-rank means) keeps every rank's eval-mode model -- and the checkpoint rank 0
+// writes -- identical.  The shadows are the non-trainable tail of the flat variable vector: one all-reduce + a scale, on the device.
+extern "C" int alignnet_comm_average_shadows(alignnet_handle* h)
+{
+  if (!h) return 1;
+  if (!h->comm) return fail(h, "alignnet_comm_average_shadows: communicator not initialised");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t n = h->n_total - h->n_trainable;
+  if (!n) return 0;
+  float* p = h->d_params + h->n_trainable;
+  if (comm_allreduce(h, p, n, false, h->stream, "EMA shadows")) { comm_poison(h); return 1; }
+  hipLaunchKernelGGL(scale_buf_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p, n, 1.f / (float)h->comm_world);
+  HIP_TRY(h, hipGetLastError());
+  h->folded = false;   // the eval-mode scale / shift are derived from the shadows
   return 0;
 }
 

@@ -1,6 +1,7 @@
 // Host-side engine state behind the opaque C handle (include/alignnet_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -172,23 +173,32 @@ struct PerDeviceOnce {
   void mark(int device) { if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release); }
 };
 
-// Brackets everything launched on h->stream during its lifetime with one event pair (only while h->prof is set).
+// Kernel timers (only while h->prof is set), two forms:
+//  - bind = false: brackets everything launched on h->stream during its lifetime with one recorded event pair.  Each record is a marker
+//    packet of its own in the queue (measured: ~5 us of bubble per event between dependent kernels);
+//  - bind = true: the scope only holds the pair, and the ONE kernel launched inside it with TIMED_LAUNCH carries the events on its own
+//    dispatch (hipExtLaunchKernelGGL start / stop events: the timestamps of the dispatch packet's completion signal, no extra packet).
+//    What is measured is then the kernel's own duration, as rocprofv3 --kernel-trace reports it.
 struct ProfScope {
-  alignnet_handle* h; int id; hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(alignnet_handle* h_, int id_) : h(h_), id(id_)
+  alignnet_handle* h; int id; hipEvent_t a = nullptr, b = nullptr; bool bind, used = false;
+  ProfScope(alignnet_handle* h_, int id_, bool bind_ = false) : h(h_), id(id_), bind(bind_)
   {
     if (!h->prof) return;
     if (!h->prof_pool.empty()) { a = h->prof_pool.back().first; b = h->prof_pool.back().second; h->prof_pool.pop_back(); }
     else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-    hipEventRecord(a, h->stream);
+    if (!bind) hipEventRecord(a, h->stream);
   }
   ~ProfScope()
   {
     if (!a) return;
-    hipEventRecord(b, h->stream);
+    if (bind && !used) { h->prof_pool.push_back({a, b}); return; }   // nothing was launched inside: the pair holds no (or stale) timestamps
+    if (!bind) hipEventRecord(b, h->stream);
     h->prof_pending.push_back(alignnet_handle::ProfEv{id, a, b});
   }
   ProfScope(const ProfScope&) = delete;
   ProfScope& operator=(const ProfScope&) = delete;
 };
+// the one kernel of a bind-mode ProfScope named `prof_scope` (with profiling off the events are null: a plain launch)
+#define TIMED_LAUNCH(kernel, grid, block, lds, ...) \
+  do { prof_scope.used = true; hipExtLaunchKernelGGL(kernel, grid, block, lds, h->stream, prof_scope.a, prof_scope.b, 0, __VA_ARGS__); } while (0)
 }  // namespace alignnet

@@ -216,7 +216,7 @@ constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t
 
 // the kNN graph of 2B clouds (N <= 4096, k <= N): nn [2B][N][k].  (static: the kernels are per translation unit, so is the flag)
 [[maybe_unused]] static hipError_t launch_knn(int device, hipStream_t stream, const float* p1, const float* p2, const float* center, int B, int N,
-                                              int k, int* nn)
+                                              int k, int* nn, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)   // (t0, t1: optional kernel timer, engine.h ProfScope)
 {
   const dim3 grid((N + kKnnQueries - 1) / kKnnQueries, 2 * B), block(kKnnWaves * 64);
   static PerDeviceOnce attr_done;
@@ -227,9 +227,9 @@ constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t
     if (e != hipSuccess) return e;
     attr_done.mark(device);
   }
-  if (N <= 1024) hipLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, p1, p2, center, B, N, k, nn);
-  else if (N <= 2048) hipLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, p1, p2, center, B, N, k, nn);
-  else hipLaunchKernelGGL(knn_kernel<64>, grid, block, knn_lds_bytes(64), stream, p1, p2, center, B, N, k, nn);
+  if (N <= 1024) hipExtLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
+  else if (N <= 2048) hipExtLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
+  else hipExtLaunchKernelGGL(knn_kernel<64>, grid, block, knn_lds_bytes(64), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
   return hipGetLastError();
 }
 

@@ -201,6 +201,10 @@ int alignnet_comm_unique_id(uint8_t id[128]);
 int alignnet_comm_loopback_id(uint8_t id[128]);
 int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
 int alignnet_comm_allreduce_grads(alignnet_handle* h);
+/* Average the BatchNorm EMA shadows (the non-trainable variables) over the ranks, on the device: local-BN data parallelism updates them
+ * from each rank's own shard (utils/tf_util.py:476-485); the drop-in train.py calls this once per epoch so that every rank's eval-mode
+ * model and rank 0's checkpoint agree.  (Identical already under "sync_bn".) */
+int alignnet_comm_average_shadows(alignnet_handle* h);
 
 /* ---- schedule read-back: sess.run([learning_rate, bn_decay]) train.py:298,
  *      sess.run(batch) train.py:261,272 */

@@ -333,6 +333,46 @@ def test_local_bn_averaged_gradient_is_mean_of_shard_gradients(gpu_required):
         assert np.allclose(step, 0.005, rtol=2e-3), (step.min(), step.max())
 
 
+def test_shadow_average_on_the_device(gpu_required):
+    """parallel.average_ema_shadows with an engine communicator: one all-reduce of the non-trainable tail on the device.  After local-BN
+    steps on different shards the ranks' EMA shadows differ; afterwards every rank holds their mean (summed in rank order, so bit-identical
+    everywhere), the trainable variables are untouched, and the eval-mode forward of all ranks agrees bit for bit."""
+    from alignnet3d import parallel
+    N, B, W = 128, 16, 4
+    cfg, spec, P32, d, du = setup("pointnet", N, B, std=True)
+    cfg["training"]["batch_size"] = B // W
+
+    def body(r, eng):
+        sd, su, lo, hi = shard(d, du, r, W)
+        eng.train_step(sd["pcs1"], sd["pcs2"], sd, su)
+        shadows = [n for n, _, t in eng.variables() if not t]
+        before = {n: eng.get_variable(n).copy() for n, _, _ in eng.variables()}
+        assert parallel.average_ema_shadows(eng) == len(shadows)
+        after = {n: eng.get_variable(n).copy() for n, _, _ in eng.variables()}
+        out = eng.forward(d["pcs1"][:4], d["pcs2"][:4])
+        return dict(shadows=shadows, before=before, after=after, out={k: np.asarray(v).copy() for k, v in out.items()})
+    ranks = run_ranks(W, cfg, body, variables=P32)
+    shadows = ranks[0]["shadows"]
+    assert len(shadows) > 0
+    differed = 0
+    for n in ranks[0]["before"]:
+        if n in shadows:
+            acc = ranks[0]["before"][n].astype(np.float32).copy()
+            for r in range(1, W):
+                acc = acc + ranks[r]["before"][n]
+            want = acc * np.float32(1.0 / W)
+            differed += int(not np.array_equal(ranks[0]["before"][n], ranks[1]["before"][n]))
+            for r in range(W):
+                np.testing.assert_array_equal(ranks[r]["after"][n], want, err_msg=n)
+        else:
+            for r in range(W):
+                np.testing.assert_array_equal(ranks[r]["after"][n], ranks[r]["before"][n], err_msg=n)
+    assert differed > 0           # the shards really produced different statistics
+    for r in range(1, W):
+        for k in ranks[0]["out"]:
+            np.testing.assert_array_equal(ranks[r]["out"][k], ranks[0]["out"][k], err_msg=k)
+
+
 def test_collective_mismatch_and_failed_rank_do_not_hang(gpu_required):
     """A rank that fails (or issues another collective) breaks the group: the other ranks return an error, nobody waits forever."""
     N, B, W = 128, 8, 2

@@ -45,6 +45,9 @@ class FakeEngine:
     def set_variable(self, name, value):
         self.vars[name] = np.asarray(value, np.float32).reshape(self.vars[name].shape)
 
+    def get_option(self, key):
+        return {"comm_world": 1}[key]       # no engine communicator: average_ema_shadows goes through the process group
+
     @staticmethod
     def comm_unique_id():
         return bytes(range(128))

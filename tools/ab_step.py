@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of the training step under engine options: alternates the option sets round-robin in ONE process (same clocks, same data) and
 prints the median ms/step of each.    tools/ab_step.py [--bf16 1] [--dgcnn 1] [--batch 256] [--points 1024] [--rounds 5] [--steps 60] "k=v,k=v" "k=v" ...
-An empty string "" is the default option set.  Options are alignnet_set_option keys (include/alignnet_hip.h)."""
+An empty string "" is the default option set; "prof=1" switches the engine's HIP-event kernel timers on.  Options are alignnet_set_option keys (include/alignnet_hip.h)."""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "alignnet-3d_amd")]
@@ -26,7 +26,9 @@ for sset in a.sets:
         if name.endswith("moving_var"): e.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
     e.set_option("train_matmul_bf16", a.bf16)
     for kv in filter(None, sset.split(",")):
-        k, v = kv.split("="); e.set_option(k, int(v))
+        k, v = kv.split("=")
+        if k == "prof": e.profile_enable(bool(int(v)))     # (pseudo-option: the HIP-event kernel timers bench.py's timed region runs under)
+        else: e.set_option(k, int(v))
     engs.append(e)
 nb2 = 2 * cfg["model"]["angles"]["num_bins"]
 outs = {k: torch.empty(a.batch, nb2 if "logits" in k else 3, device="cuda") for k in alignnet3d.OUTPUT_NAMES}; ptrs = {k: v.data_ptr() for k, v in outs.items()}
