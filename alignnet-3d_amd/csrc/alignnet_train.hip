@@ -537,16 +537,25 @@ static int flush_deferred(alignnet_handle* h, hipStream_t stream)
     for (size_t i = 0; i < nj; ++i) { J.j[i] = d.cen[i0 + i]; emax = std::max(emax, (size_t)d.cen[i0 + i].C * d.cen[i0 + i].C); }
     hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)nj), dim3(256), 0, stream, J);
   }
-  for (size_t i0 = 0; i0 < d.gemm.size(); i0 += kGemmJobs) {
-    const size_t nj = std::min(d.gemm.size() - i0, (size_t)kGemmJobs);
-    GemmJobs J{}; int tot = 0;
-    for (size_t i = 0; i < nj; ++i) {
-      const GemmArgs& g = d.gemm[i0 + i].first;
-      J.g[i] = g; J.tx[i] = (g.N + 31) / 32; J.ty[i] = (g.M + 31) / 32; J.start[i] = tot;
-      tot += J.tx[i] * J.ty[i] * d.gemm[i0 + i].second;
+  // the throughput-shaped products on 64 x 64 tiles (gemm_tile64_jobs), the rest on the K-split tiles; tiles numbered job after job
+  for (int big = 1; big >= 0; --big) {
+    std::vector<size_t> sel;
+    for (size_t i = 0; i < d.gemm.size(); ++i) if ((int)(gemm_job_is_big(d.gemm[i].first) && !(h->ab & AB_GEMM_JOBS_KSPLIT)) == big) sel.push_back(i);
+    // longest first: a workgroup's time is its K; with the deep products at the end of the grid they would run alone in a second round
+    std::stable_sort(sel.begin(), sel.end(), [&](size_t x, size_t y) { return d.gemm[x].first.K > d.gemm[y].first.K; });
+    const int ts = big ? kGemmT : 32;
+    for (size_t i0 = 0; i0 < sel.size(); i0 += kGemmJobs) {
+      const size_t nj = std::min(sel.size() - i0, (size_t)kGemmJobs);
+      GemmJobs J{}; int tot = 0;
+      for (size_t i = 0; i < nj; ++i) {
+        const GemmArgs& g = d.gemm[sel[i0 + i]].first;
+        J.g[i] = g; J.tx[i] = (g.N + ts - 1) / ts; J.ty[i] = (g.M + ts - 1) / ts; J.start[i] = tot;
+        tot += J.tx[i] * J.ty[i] * d.gemm[sel[i0 + i]].second;
+      }
+      J.start[nj] = tot; J.n = (int)nj;
+      if (big) hipLaunchKernelGGL(gemm_tile64_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, stream, J);
+      else hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, stream, J);
     }
-    J.start[nj] = tot; J.n = (int)nj;
-    hipLaunchKernelGGL(gemm_small_jobs, dim3(tot), dim3(kGemmWaves * 64), 0, stream, J);
   }
   for (size_t i0 = 0; i0 < d.comb.size(); i0 += kComb) {
     const size_t nj = std::min(d.comb.size() - i0, kComb);

@@ -1831,7 +1831,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_qimg_kernel(const GemmAr
                                                                     unsigned pack_gx)
 {
   const int bx = blockIdx.x, t = blockIdx.y;
-  if (bx < ntile) { gemm_small_tile(g, bx % tx, bx / tx, t); return; }
+  __shared__ float smem[kGemmSmemFloats];
+  if (bx < ntile) { gemm_small_tile(g, bx % tx, bx / tx, t, smem); return; }
   if (bx < ntile + qa.R) { qbias2_body(qa, bx - ntile, t); return; }
   if (threadIdx.x < 256)   // (the pack body strides by 256 threads per block)
     for (int q = t; q < npack; q += 2) pack_bf16_jobs_body(pj, bx - ntile - qa.R, q, pack_gx);

@@ -33,9 +33,10 @@ constexpr int kGemmWaves = 8, kGemmKC = 32, kGemmLd = 33;
 // in a private LDS region (no workgroup barrier in the loop): lanes run along whichever dimension has the smaller
 // stride, so row-major, transposed and column-scaled views all load coalesced; the next chunk's 32 loads are in
 // flight while the current chunk's 16 MFMAs run.
-__device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, int tile_y, int bz)
+constexpr int kGemmSmemFloats = kGemmWaves * 2 * kGemmKC * kGemmLd;   // 66 KiB: two workgroups per CU
+__device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, int tile_y, int bz, float* smem)
 {
-  __shared__ float stage[kGemmWaves][2][kGemmKC * kGemmLd];   // [wave][A|B][k][i or j]; reused for the final reduction
+  float (*stage)[2][kGemmKC * kGemmLd] = reinterpret_cast<float (*)[2][kGemmKC * kGemmLd]>(smem);   // [wave][A|B][k][i or j]; reused for the final reduction
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5;
   const int i0 = tile_y * 32, j0 = tile_x * 32;
   const float* A = a.A + bz * a.batch_a;
@@ -140,7 +141,105 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
   }
 }
 
-__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a) { gemm_small_tile(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_small(const GemmArgs a)
+{
+  __shared__ float smem[kGemmSmemFloats];
+  gemm_small_tile(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// The throughput form, for the products whose output is many tiles and whose K is a few hundred (the head layers' dW = x^T dz after the
+// backward: M x N up to 2048 x 512 over K = 256 / 512 rows).  One 64 x 64 output tile per workgroup: wave = (quadrant q, K group g);
+// an iteration stages 64 k of A and B once for all eight waves (16 loads per lane for 16 MFMAs, where the K-split form loads 32 and then
+// reduces eight partial tiles through LDS), group g taking the k range [32 g, 32 g + 32) of it; double-buffered, one barrier per
+// iteration.  The two groups' partial tiles are added in a fixed order (g = 0 first).  Plain products only: alpha / bias / accumulate as in
+// gemm_small_tile, no kscale, no image.
+constexpr int kGemmT = 64, kGemmTLd = 65, kGemmTK = 64;
+static_assert(2 * 2 * kGemmTK * kGemmTLd <= kGemmSmemFloats, "the 64 x 64 form's two stage buffers fit the K-split form's LDS");
+__device__ __forceinline__ void gemm_tile64(const GemmArgs& a, int tile_x, int tile_y, int bz, float* smem)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+  const int q = wave & 3, g = wave >> 2, qi = q >> 1, qj = q & 1;
+  const int i0 = tile_y * kGemmT, j0 = tile_x * kGemmT;
+  const float* A = a.A + bz * a.batch_a;
+  const float* Bm = a.B + bz * a.batch_b;
+  const bool a_kfast = a.sa_k <= a.sa_i, b_jfast = a.sb_j <= a.sb_k;
+  const float* pa[8];
+  const float* pb[8];
+  int la[8], lb[8];          // LDS offsets of this thread's eight A / B elements
+  unsigned va = 0u, vb = 0u, ka = 0u, kb = 0u;   // bit u: row / column inside the matrix; k offsets (6 bits each would not fit: kept in la / lb)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 512 * u;
+    const int ai = a_kfast ? e >> 6 : e & 63, ak = a_kfast ? e & 63 : e >> 6;
+    const int bj = b_jfast ? e & 63 : e >> 6, bk = b_jfast ? e >> 6 : e & 63;
+    pa[u] = A + (size_t)min(i0 + ai, a.M - 1) * a.sa_i + (size_t)ak * a.sa_k;
+    pb[u] = Bm + (size_t)bk * a.sb_k + (size_t)min(j0 + bj, a.N - 1) * a.sb_j;
+    la[u] = ak * kGemmTLd + ai; lb[u] = bk * kGemmTLd + bj;
+    va |= (unsigned)(i0 + ai < a.M) << u;
+    vb |= (unsigned)(j0 + bj < a.N) << u;
+  }
+  (void)ka; (void)kb;
+  float ra[8], rb[8];
+  const int niter = (a.K + kGemmTK - 1) / kGemmTK;
+  auto fetch = [&](int it) {
+    const int kc = it * kGemmTK;
+    if (kc + kGemmTK <= a.K) {
+      const size_t oa = (size_t)kc * a.sa_k, ob = (size_t)kc * a.sb_k;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ra[u] = pa[u][oa]; rb[u] = pb[u][ob]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ra[u] = (va >> u) & 1u ? ra[u] : 0.f; rb[u] = (vb >> u) & 1u ? rb[u] : 0.f; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = tid + 512 * u;
+        const int ak = a_kfast ? e & 63 : e >> 6, bk = b_jfast ? e >> 6 : e & 63;
+        const int kka = min(kc + ak, a.K - 1) - ak, kkb = min(kc + bk, a.K - 1) - bk;   // clamped offsets
+        const float xa = pa[u][(size_t)kka * a.sa_k], xb = pb[u][(size_t)kkb * a.sb_k];
+        ra[u] = (((va >> u) & 1u) && kc + ak < a.K) ? xa : 0.f;
+        rb[u] = (((vb >> u) & 1u) && kc + bk < a.K) ? xb : 0.f;
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  fetch(0);
+  for (int it = 0; it < niter; ++it) {
+    float* As = smem + (it & 1) * (2 * kGemmTK * kGemmTLd);
+    float* Bs = As + kGemmTK * kGemmTLd;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { As[la[u]] = ra[u]; Bs[lb[u]] = rb[u]; }
+    if (it + 1 < niter) fetch(it + 1);
+    __syncthreads();   // (the buffer written now was last read two iterations ago: every wave has passed the barrier of the iteration in between)
+    const float* Ag = As + (32 * g) * kGemmTLd + 32 * qi + (lane & 31);
+    const float* Bg = Bs + (32 * g) * kGemmTLd + 32 * qj + (lane & 31);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int k = 2 * s2 + half;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ag[k * kGemmTLd], Bg[k * kGemmTLd], acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = smem;   // [wave][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int j = j0 + 32 * qj + (lane & 31);
+  if (j < a.N) {
+    const float bias = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = 8 * g + rr;
+      const int row = i0 + 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < a.M) {
+        const float v = (red[(q * 16 + r) * 64 + lane] + red[((q + 4) * 16 + r) * 64 + lane]) * a.alpha + bias;
+        float* dst = a.C + bz * a.batch_c + (size_t)row * a.sc_i + (size_t)j * a.sc_j;
+        *dst = a.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
 
 // Two independent products in one launch (e.g. a head layer's dW = x^T dz and dx = dz W^T, 8 us each on their own): the tiles of
 // job 0 come first in the linear grid, then those of job 1.
@@ -149,7 +248,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small2(const GemmPair p)
 {
   const int job = (int)blockIdx.x >= p.n0;
   const int t = (int)blockIdx.x - job * p.n0;
-  gemm_small_tile(p.g[job], t % p.tx[job], t / p.tx[job], 0);
+  __shared__ float smem[kGemmSmemFloats];
+  gemm_small_tile(p.g[job], t % p.tx[job], t / p.tx[job], 0, smem);
 }
 
 // Any number (<= kGemmJobs) of independent products in one launch: the weight-gradient GEMMs of a whole step (nine head layers,
@@ -157,12 +257,24 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small2(const GemmPair p)
 // path.  Tiles are numbered job after job (start[] = prefix sums); a job's batch entries (GemmArgs.batch_*) are consecutive tiles.
 constexpr int kGemmJobs = 18;
 struct GemmJobs { GemmArgs g[kGemmJobs]; int tx[kGemmJobs], ty[kGemmJobs], start[kGemmJobs + 1]; int n; };
+__device__ __host__ inline bool gemm_job_is_big(const GemmArgs& g) { return !g.kscale && !g.img; }   // every plain product (a second launch for the few small ones costs more than their padding)
 __global__ __launch_bounds__(kGemmWaves * 64) void gemm_small_jobs(const GemmJobs jp)   // (2.6 KB of kernel arguments: under the 4 KB limit)
 {
+  __shared__ float smem[kGemmSmemFloats];
   int j = 0;
   while (j + 1 < jp.n && (int)blockIdx.x >= jp.start[j + 1]) ++j;   // uniform
   const int t = (int)blockIdx.x - jp.start[j], per = jp.tx[j] * jp.ty[j];
-  gemm_small_tile(jp.g[j], (t % per) % jp.tx[j], (t % per) / jp.tx[j], t / per);
+  gemm_small_tile(jp.g[j], (t % per) % jp.tx[j], (t % per) / jp.tx[j], t / per, smem);
+}
+// the same table form for the 64 x 64-tile jobs: a kernel of its own because the K-split body needs 216 registers (one workgroup per CU) and
+// this one runs two workgroups per CU (together in one kernel at 128 registers the K-split body spills 91)
+__global__ __launch_bounds__(kGemmWaves * 64, 4) void gemm_tile64_jobs(const GemmJobs jp)
+{
+  __shared__ float smem[kGemmSmemFloats];
+  int j = 0;
+  while (j + 1 < jp.n && (int)blockIdx.x >= jp.start[j + 1]) ++j;   // uniform
+  const int t = (int)blockIdx.x - jp.start[j], per = jp.tx[j] * jp.ty[j];
+  gemm_tile64(jp.g[j], (t % per) % jp.tx[j], (t % per) / jp.tx[j], t / per, smem);
 }
 
 // counter-based uniform in [0,1) for dropout when the host supplies none (tf.nn.dropout draws
