@@ -478,8 +478,7 @@ static void launch_reduce_multi(alignnet_handle* h, int njobs, ReduceJob a, Redu
 static void launch_loss(alignnet_handle* h, const LossArgs& la)
 {
   const int nprep = (3 * la.B + 63) / 64;   // softmax-row workgroups of loss_prep_kernel (+1 for the Huber terms)
-  hipLaunchKernelGGL(loss_prep_kernel, dim3(nprep + 1), dim3(1024), 0, h->stream, la, kLossGroups);
-  hipLaunchKernelGGL(loss_pairs_kernel, dim3(kLossGroups), dim3(256), 0, h->stream, la, kLossGroups);
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(nprep + 1 + kLossGroups), dim3(1024), 0, h->stream, la, kLossGroups, nprep);
   hipLaunchKernelGGL(loss_final_kernel, dim3((la.B + kLossCols - 1) / kLossCols), dim3(256), 0, h->stream, la, kLossGroups, nprep);
 }
 

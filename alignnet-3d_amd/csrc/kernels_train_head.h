@@ -505,11 +505,11 @@ __device__ __forceinline__ void angle2class(float angle, int nb, int* cls, float
   *res = sh - ((float)c * apc + apc * 0.5f);
 }
 
-// The loss runs as three small launches so that the B x B work (tp8.py:279,327 broadcasts) spreads over the chip:
-//   loss_prep_kernel     (1 block)    Huber terms + their gradients, per-row class / residual targets, log-sum-exp
-//   loss_pairs_kernel    (G blocks)   for a slice of rows i: partial sums over (i, j) of the residual Huber loss and of
-//                                     clip(pick_j - label_ij) per column j, for both variants (theta, theta + pi)
-//   loss_final_kernel    (1 block)    reduce the partials, tf.cond variant choice, totals, angle-term gradients
+// The loss runs as two small launches so that the B x B work (tp8.py:279,327 broadcasts) spreads over the chip:
+//   loss_prep_kernel     ceil(3B/64) blocks: per-row class / residual targets, log-sum-exp; 1 block: Huber terms + their gradients;
+//                        G blocks (loss_pairs_body): for a slice of rows i, partial sums over (i, j) of the residual Huber loss and of
+//                        clip(pick_j - label_ij) per column j, for both variants (theta, theta + pi) -- independent of the other blocks
+//   loss_final_kernel    reduce the partials, tf.cond variant choice, totals, angle-term gradients
 // Scratch layout (floats unless noted): see LossScratch.
 struct LossScratch {
   float* lse;      // [3][B]
@@ -543,14 +543,16 @@ __device__ __forceinline__ const float* term_logits(const LossArgs& a, int term,
   return term == 0 ? a.o2 + (size_t)row * a.ldo2 + 3 : term == 1 ? a.o2 + (size_t)(a.B + row) * a.ldo2 + 3 : a.o3 + (size_t)row * a.ldo3 + 3;
 }
 
-// grid: ceil(3B/64) workgroups for the softmax rows (16 lanes per (term, row)) + one last workgroup for the Huber terms
-__global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G)
+__device__ __forceinline__ void loss_pairs_body(const LossArgs& a, int G, int g, double* red);
+// grid: ceil(3B/64) workgroups for the softmax rows (16 lanes per (term, row)) + one workgroup for the Huber terms + G for the B x B part
+__global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G, int nprep)
 {
   __shared__ double red[16 * 6];
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
-  if (blockIdx.x == gridDim.x - 1) {
+  if ((int)blockIdx.x > nprep) { loss_pairs_body(a, G, (int)blockIdx.x - nprep - 1, red); return; }
+  if ((int)blockIdx.x == nprep) {
     // ---- Huber terms (tp8.py:312-323) ----
     double h[5] = {0, 0, 0, 0, 0};
     for (int e = tid; e < 3 * B; e += nt) {
@@ -615,40 +617,50 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
     for (int q = 0; q < 6; ++q) S.cep[(size_t)blockIdx.x * 6 + q] = cev[q];
 }
 
-// grid G: block g owns rows i in [g*R, (g+1)*R); thread j-strided over columns
-__global__ __launch_bounds__(256) void loss_pairs_kernel(const LossArgs a, int G)
+// block g of G owns rows i in [g*R, (g+1)*R); thread j-strided over columns.  Takes nothing from loss_prep's scratch: the picked residual
+// logit of column j and the label of row i are re-derived from the inputs (the same expressions, so the same bits), which lets these
+// blocks ride in loss_prep_kernel's launch instead of waiting for it (one launch and ~9 us less per step).
+__device__ __forceinline__ void loss_pairs_body(const LossArgs& a, int G, int g, double* red)
 {
-  __shared__ double red[4 * 6];
   double rlv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x, g = blockIdx.x;
+  const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
   const int R = (B + G - 1) / G, i0 = g * R, i1 = min(B, i0 + R);
   const int nvar = a.accept_inverted ? 2 : 1;
-  for (int term = 0; term < 3; ++term)
-    for (int v = 0; v < nvar; ++v) {
-      double rl = 0.0;
-      for (int j = tid; j < B; j += nt) {
-        const float pj = S.pick[(term * 2 + v) * B + j];
-        float sj = 0.f, hl = 0.f;
-        const float dth = term == 2 ? a.theta[B + j] - a.theta[j] : 0.f;
-        for (int i = i0; i < i1; ++i) {
-          float label;
-          if (term < 2) label = S.lab[(term * 2 + v) * B + i];
-          else {
-            int c; float r;
-            angle2class((a.a2[i] - a.a1[i]) - dth + (v ? pi : 0.f), nb, &c, &r);
-            label = r / pinb;
-          }
-          const float e = pj - label;
-          hl += huberf(e, 1.f);
-          sj += clipf(e, 1.f);
-        }
-        rl += (double)hl;
-        S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sj;
-      }
-      rlv[term * 2 + v] = rl;
+  const float dth0 = a.theta[B + 0] - a.theta[0];
+  for (int j = tid; j < B; j += nt) {
+    // pick_j as loss_prep_kernel forms it (class of row j's target angle, tp8.py:199 class_id[:, 0] for the pair term).  All six first: each
+    // is a label load -> class -> logit load chain, and one (term, variant) after the other that was six dependent L2 round trips per thread
+    const float a1j = a.a1[j], a2j = a.a2[j];
+    const float dth = a.theta[B + j] - a.theta[j];
+    float pj[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int term = q >> 1, v = q & 1;
+      const float tgt = term == 0 ? a1j : term == 1 ? a2j : (a2j - a1j) - dth0;
+      int cj; float rj;
+      angle2class(tgt + (v ? pi : 0.f), nb, &cj, &rj);
+      pj[q] = v < nvar ? term_logits(a, term, j)[nb + min(max(cj, 0), nb - 1)] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int term = q >> 1, v = q & 1;
+      if (v >= nvar) continue;
+      float sj = 0.f, hl = 0.f;
+      for (int i = i0; i < i1; ++i) {
+        int c; float r;
+        if (term < 2) angle2class((term == 0 ? a.a1[i] : a.a2[i]) + (v ? pi : 0.f), nb, &c, &r);
+        else angle2class((a.a2[i] - a.a1[i]) - dth + (v ? pi : 0.f), nb, &c, &r);
+        const float label = r / pinb;
+        const float e = pj[q] - label;
+        hl += huberf(e, 1.f);
+        sj += clipf(e, 1.f);
+      }
+      rlv[q] += (double)hl;
+      S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sj;
+    }
+  }
   block_sum_n<6>(rlv, red);
   if (tid == 0)
     for (int q = 0; q < 6; ++q)
