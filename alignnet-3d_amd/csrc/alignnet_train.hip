@@ -570,10 +570,11 @@ static int flush_deferred(alignnet_handle* h, hipStream_t stream)
 static int pack_all_weights(alignnet_handle* h)
 {
   TrainWS* w = tws(h);
-  if (!w->pack_table) {   // (src, dst, K, C) per MFMA layer, built once
+  if (!w->pack_table) {   // (src, dst, K, C) per MFMA conv layer, built once.  (The head layers' images are eval-only: fold_for_eval rebuilds every
+                          //  image when an eval forward follows a training step; packing them here too was 1.9 M of the step's 2.1 M elements.)
     std::vector<PackJob> jobs;
     for (const Layer& L : h->layers)
-      if (!L.first_conv) jobs.push_back(PackJob{P(h, L.p_w), h->d_wp + L.off_wp, L.cin, L.cout});
+      if (L.conv && !L.first_conv) jobs.push_back(PackJob{P(h, L.p_w), h->d_wp + L.off_wp, L.cin, L.cout});
     w->n_pack = (int)jobs.size();
     HIP_TRY(h, hipMalloc(&w->pack_table, jobs.size() * sizeof(PackJob)));
     HIP_TRY(h, hipMemcpy(w->pack_table, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
@@ -582,7 +583,7 @@ static int pack_all_weights(alignnet_handle* h)
   // with only specialised PointNet stages nothing reads them (the heads use the raw matrices, the backbones the bf16 images below)
   bool need_f32 = !h->train_bf16 || h->cfg.backbone == 1;
   for (int s = 0; s < 3; ++s) need_f32 = need_f32 || stage_generic(h, s);
-  if (need_f32) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, w->n_pack), dim3(256), 0, h->stream, w->pack_table);
+  if (need_f32 && w->n_pack) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(256, w->n_pack), dim3(256), 0, h->stream, w->pack_table);   // (<= 2 elements per thread)
   if (h->train_bf16) {
     // bf16 images of every specialised stage's lift (one per tower: the sign of that tower's gamma folded in) and hidden layer, one launch
     PackBf16Jobs pj{};
@@ -612,7 +613,7 @@ static int pack_all_weights(alignnet_handle* h)
       }
     }
     if (nj > kPackBf16Jobs) return fail(h, "pack_all_weights: job table overflow");
-    if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(32, nj), dim3(256), 0, h->stream, pj);
+    if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(128, nj), dim3(256), 0, h->stream, pj);   // (128 blocks per image: four elements per thread; with 32 a thread walked sixteen dependent-latency trips)
   }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
@@ -1458,7 +1459,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     set_glue(z);
-    hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_totals<6>, dim3((C1 + kB0C - 1) / kB0C, 2), dim3(1024), 0, h->stream, z);
     if (sync && sync_sum(h, w->dbg1, (size_t)2 * C1 * 2, false)) return 1;   // (dbeta1, dgamma1) of all ranks: the per-cloud part divides them by the global count
     hipLaunchKernelGGL(dg_b0_cloud<6>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)6 * C1, G(h, w, L[0]->p_w), 1.f, 1));
@@ -1504,7 +1505,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     set_glue(z);
-    hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + 31) / 32, 2), dim3(1024), 0, h->stream, z);
+    hipLaunchKernelGGL(dg_b0_totals<3>, dim3((C1 + kB0C - 1) / kB0C, 2), dim3(1024), 0, h->stream, z);
     if (sync && sync_sum(h, w->dbg1, (size_t)2 * C1 * 2, false)) return 1;   // (dbeta1, dgamma1) of all ranks: the per-cloud part divides them by the global count
     hipLaunchKernelGGL(dg_b0_cloud<3>, dim3(2 * B), dim3(128), 0, h->stream, z);
     def_reduce(h, w, rjob(S.p_part, 2 * B, (long)3 * C1, G(h, w, L[0]->p_w), 1.f, 1));

@@ -1211,31 +1211,33 @@ struct DgB0Args {
   float* d_s2c = nullptr; float* d_o2 = nullptr; int ldo2 = 0; float* d_s1c = nullptr; float* d_o0 = nullptr;
 };
 
+constexpr int kB0C = 8;   // channels per workgroup of dg_b0_totals (x 128 cloud groups): with 32 x 32 the fp32 PointNet step (C1 = 64, four slices per cloud) ran it
+                          // on four workgroups walking eight dependent trips of L2 round trips each -- 17 us per launch
 template <int D>
-__global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid (ceil(C1/32), 2), block 32 channels x 32 cloud groups
+__global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid (ceil(C1 / kB0C), 2), block kB0C channels x 128 cloud groups
 {
-  __shared__ double red[32][32][2];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  constexpr int kG = 1024 / kB0C;
+  __shared__ double red[kG][kB0C][2];
+  const int cl = threadIdx.x % kB0C, g = threadIdx.x / kB0C, c = blockIdx.x * kB0C + cl, t = blockIdx.y;
   double sdy = 0.0, wp = 0.0;
   if (c < a.C1) {
     double w[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = (double)a.w1[d * a.C1 + c];
-    // four slices per iteration: 4 (D + 1) independent loads in flight instead of D + 1 (the loop is a chain of L2 round trips:
-    // 17 us per launch with one slice per iteration and only ceil(C1 / 32) x 2 workgroups)
+    // four slices per iteration: 4 (D + 1) independent loads in flight
     const int S = a.B * a.slices;
-    for (int bs = g; bs < S; bs += 128) {
+    for (int bs = g; bs < S; bs += 4 * kG) {
       double v[4][D + 1];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int bu = min(bs + 32 * u, S - 1);
+        const int bu = min(bs + kG * u, S - 1);
         const double* p = a.pdy_part + ((size_t)t * S + bu) * (D + 1) * a.C1 + c;
 #pragma unroll
         for (int d = 0; d <= D; ++d) v[u][d] = p[(size_t)d * a.C1];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (bs + 32 * u < S) {
+        if (bs + kG * u < S) {
 #pragma unroll
           for (int d = 0; d < D; ++d) wp += w[d] * v[u][d];
           sdy += v[u][D];
@@ -1244,14 +1246,20 @@ __global__ __launch_bounds__(1024) void dg_b0_totals(const DgB0Args a)   // grid
   }
   red[g][cl][0] = sdy; red[g][cl][1] = wp;
   __syncthreads();
-  if (g != 0 || c >= a.C1) return;
+  // 128 partials per channel: sixteen lanes of a channel sum eight each, then a four-step shuffle (fixed order)
+  if (threadIdx.x >= kB0C * 16) return;
+  const int ch = threadIdx.x >> 4, part = threadIdx.x & 15, cc = blockIdx.x * kB0C + ch;
   sdy = 0.0; wp = 0.0;
-  for (int q = 0; q < 32; ++q) { sdy += red[q][cl][0]; wp += red[q][cl][1]; }
-  const double dg = (double)a.rstd1[t * a.C1 + c] * (wp + ((double)a.b1[c] - (double)a.mean1[t * a.C1 + c]) * sdy);
-  a.dbeta[t][c] = (float)sdy;
-  a.dgamma[t][c] = (float)dg;
-  a.dbg1[(t * a.C1 + c) * 2] = (float)sdy;
-  a.dbg1[(t * a.C1 + c) * 2 + 1] = (float)dg;
+#pragma unroll
+  for (int q = 0; q < kG / 16; ++q) { sdy += red[part * (kG / 16) + q][ch][0]; wp += red[part * (kG / 16) + q][ch][1]; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { sdy += __shfl_xor(sdy, o); wp += __shfl_xor(wp, o); }
+  if (part != 0 || cc >= a.C1) return;
+  const double dg = (double)a.rstd1[t * a.C1 + cc] * (wp + ((double)a.b1[cc] - (double)a.mean1[t * a.C1 + cc]) * sdy);
+  a.dbeta[t][cc] = (float)sdy;
+  a.dgamma[t][cc] = (float)dg;
+  a.dbg1[(t * a.C1 + cc) * 2] = (float)sdy;
+  a.dbg1[(t * a.C1 + cc) * 2 + 1] = (float)dg;
 }
 
 template <int D>
