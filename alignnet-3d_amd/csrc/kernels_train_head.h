@@ -72,13 +72,20 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile_x, i
     const int kc = c * kGemmKC;
     if (kc + kGemmKC <= a.K) {   // whole chunk inside K (always, for K % 32 == 0)
       const size_t oa = (size_t)kc * a.sa_k, ob = (size_t)kc * a.sb_k;
+      // the column scale travels with the operands (requested behind them it was a second L2 round trip per chunk: the Q = W diag(E) W^T
+      // products, K = 1024, took 16 us on 32 workgroups); k-fast lanes all need the same entry, one load
+      float kv[16];
+      if (ksc) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int e = lane + 64 * t; kv[t] = ksc[kc + (a_kfast ? e & 31 : e >> 5)]; }
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t) { ra[t] = pa[t][oa]; rb[t] = pb[t][ob]; }
 #pragma unroll
       for (int t = 0; t < 16; ++t) { ra[t] = (va >> t) & 1u ? ra[t] : 0.f; rb[t] = (vb >> t) & 1u ? rb[t] : 0.f; }
       if (ksc) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { const int e = lane + 64 * t; ra[t] *= ksc[kc + (a_kfast ? e & 31 : e >> 5)]; }
+        for (int t = 0; t < 16; ++t) ra[t] *= kv[t];
       }
     } else {
 #pragma unroll
@@ -322,11 +329,20 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const 
   const int cl = threadIdx.x % kBnCols, rg = threadIdx.x / kBnCols, c = blockIdx.x * kBnCols + cl, set = blockIdx.y;
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   double s = 0.0, ss = 0.0;
+  // the first trip's rows stay in registers for the second pass (with <= 256 rows per set -- every head of the shipped batch -- that is all of them:
+  // the apply pass then starts without its own L2 round trip)
+  float v0[kBnU];
+  bool have0 = false;
   if (c < a.C && a.mode != 2)
     for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
       float v[kBnU];
 #pragma unroll
       for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+      if (r == r0 + rg) {
+        have0 = true;
+#pragma unroll
+        for (int u = 0; u < kBnU; ++u) v0[u] = v[u];
+      }
 #pragma unroll
       for (int u = 0; u < kBnU; ++u) { s += (double)v[u]; ss += (double)v[u] * (double)v[u]; }
     }
@@ -350,8 +366,13 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const 
   const float inv = a.gamma[set][c] * (1.0f / sqrtf(vf + kBnEps)), sh = a.beta[set][c] - mf * inv;
   for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
     float v[kBnU];
+    if (r == r0 + rg && have0) {
 #pragma unroll
-    for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+      for (int u = 0; u < kBnU; ++u) v[u] = v0[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+    }
 #pragma unroll
     for (int u = 0; u < kBnU; ++u) {
       const int ru = r + u * kBnGroups;
@@ -377,6 +398,8 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
   float mf = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
   if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
   double sb = 0.0, sg = 0.0;
+  float zh0[kBnU], g0[kBnU];   // zhat and the masked gradient of the first trip's rows, kept for the second pass (see bn_rows_fwd_kernel)
+  bool have0 = false;
   if (c < a.C && a.mode != 2)
     for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
       float zv[kBnU], dv[kBnU];
@@ -386,14 +409,18 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
         zv[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f;
         dv[u] = ru < r1 ? b.dy[(size_t)ru * a.C + c] : 0.f;
       }
+      const bool first = r == r0 + rg;
+      if (first) have0 = true;
 #pragma unroll
       for (int u = 0; u < kBnU; ++u) {
         const int ru = r + u * kBnGroups;
+        float zh = 0.f, g = 0.f;
         if (ru < r1) {
-          const float zh = (zv[u] - mf) * rstd;
-          const float g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
+          zh = (zv[u] - mf) * rstd;
+          g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
           sb += g; sg += (double)g * zh;
         }
+        if (first) { zh0[u] = zh; g0[u] = g; }
       }
     }
   red[rg][cl][0] = sb; red[rg][cl][1] = sg;
@@ -410,6 +437,14 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
   const double Rg = (double)R * a.world;
   const float mb = (float)(sb / Rg), mg = (float)(sg / Rg), k = gam * rstd;
   for (int r = r0 + rg; r < r1; r += kBnGroups * kBnU) {
+    if (r == r0 + rg && have0) {
+#pragma unroll
+      for (int u = 0; u < kBnU; ++u) {
+        const int ru = r + u * kBnGroups;
+        if (ru < r1) b.dz[(size_t)ru * a.C + c] = k * (g0[u] - mb - zh0[u] * mg);
+      }
+      continue;
+    }
     float zv[kBnU], dv[kBnU];
 #pragma unroll
     for (int u = 0; u < kBnU; ++u) {
