@@ -1143,8 +1143,15 @@ static int head_fwd_train(alignnet_handle* h, int s, const float* in, long ldin,
     const Layer& L = h->layers[fs.first + j];
     if (j < fs.n - 1) {
       HeadLayerWS& HL = w->hl[s][j];
+      // few tiles and a deep K (the pair head's first layer: 128 tiles, K = 2048 = eight dependent chunks per wave, 20 us): the two K halves as
+      // two batch entries into (z, dz -- free until the backward), summed with the bias by the statistics pass that reads z anyway
+      const bool splitk = !sync_on(h) && L.cin >= 1024 && (L.cin & 63) == 0 && (long)((L.cout + 31) / 32) * ((M + 31) / 32) <= 128;
+      if (splitk) launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin / 2, nullptr, 1.f, 0, 2, L.cin / 2,
+                              (long)(L.cin / 2) * L.cout, HL.dz - HL.z);
+      else
       launch_gemm(h, cur, ldc, 1, P(h, L.p_w), L.cout, 1, HL.z, L.cout, 1, M, L.cout, L.cin, P(h, L.p_b));
       BnRowsArgs a = bn_args(h, w, s, j, M, rows_per_set, bn_decay, update_ema, u_dev);
+      if (splitk) { a.z2 = HL.dz; a.zbias = P(h, L.p_b); a.zw = HL.z; }
       const dim3 bgrid((L.cout + kBnCols - 1) / kBnCols, nsets);
       if (sync_on(h)) {   // this rank's column sums -> all ranks' -> normalise with the global batch's moments
         a.mode = 1; a.totals = h->sync_buf;

@@ -311,6 +311,9 @@ struct BnRowsArgs {
   // sync_bn (batch statistics over all data-parallel ranks): mode 1 = only the column sums -> totals [nsets][C][2] (forward: sum z, sum z^2;
   // backward: sum g, sum g zhat), mode 2 = take them (all-reduced) from totals and do the rest, with world x the rows; 0 = one launch
   double* totals = nullptr; int mode = 0; int world = 1;
+  // split-K producer (head_fwd_train: the pair head's first layer, K = 2048 on 128 tiles): z holds the first K half's product, z2 the second's,
+  // neither has the bias; the statistics pass forms z = z + z2 + zbias[c] and writes it back (each element belongs to one thread)
+  const float* z2 = nullptr; const float* zbias = nullptr; float* zw = nullptr;
 };
 
 __device__ __forceinline__ float dropout_scale(const BnRowsArgs& a, int set, int row_in_set, int c)
@@ -338,6 +341,17 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_fwd_kernel(const 
       float v[kBnU];
 #pragma unroll
       for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v[u] = ru < r1 ? a.z[(size_t)ru * a.C + c] : 0.f; }
+      if (a.z2) {
+        float v2[kBnU];
+        const float bias = a.zbias[c];
+#pragma unroll
+        for (int u = 0; u < kBnU; ++u) { const int ru = r + u * kBnGroups; v2[u] = ru < r1 ? a.z2[(size_t)ru * a.C + c] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < kBnU; ++u) {
+          const int ru = r + u * kBnGroups;
+          if (ru < r1) { v[u] = (v[u] + v2[u]) + bias; a.zw[(size_t)ru * a.C + c] = v[u]; }
+        }
+      }
       if (r == r0 + rg) {
         have0 = true;
 #pragma unroll
