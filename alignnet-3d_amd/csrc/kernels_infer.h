@@ -546,6 +546,9 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
       add1[r] = (a.finish == 3 && col < 3) ? a.addend[(a.B + row) * 3 + col] : 0.f;
     }
   }
+  // the epilogue's scale / shift of both BN sets likewise (wave 0 only uses them; both sets exist for every layer: fold_for_eval)
+  const int ecol = min(ct * 32 + (lane & 31), a.Nout - 1);
+  const float esc0 = a.scale[ecol], esh0 = a.shift[ecol], esc1 = a.scale[a.Nout + ecol], esh1 = a.shift[a.Nout + ecol];
   // U k-groups of operands are requested before their MFMAs (a one-deep lookahead exposed one memory round trip per
   // k-group: 32 of them per wave at K = 1024)
   constexpr int U = 8;   // (sixteen with the eight-wave form was measured: 23.0 against 19.2 us for the K = 2048 layer)
@@ -580,7 +583,7 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
           float v = acc[r];
 #pragma unroll
           for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
-          v = fmaf(v, a.scale[set * a.Nout + col], a.shift[set * a.Nout + col]);
+          v = fmaf(v, set ? esc1 : esc0, set ? esh1 : esh0);
           v = a.relu ? fmaxf(v, 0.f) : v;
           a.out[(size_t)row * a.ldout + col] = v;
           if (a.finish == 1 && col < 3) {   // row = cloud
