@@ -605,8 +605,11 @@ static int run_fc(alignnet_handle* h, const Layer& L, const float* in, long ldin
   a.in = in; a.ldin = ldin; a.wp = h->d_wp + L.off_wp; a.scale = h->d_scale + L.off_ss; a.shift = h->d_shift + L.off_ss;
   a.out = out; a.ldout = ldout; a.M = M; a.K = L.cin; a.Nout = L.cout; a.relu = relu; a.rows_per_set = rows_per_set;
   const dim3 grid((L.cout + 31) / 32, (M + 31) / 32);
-  if (L.cin >= 1024) hipLaunchKernelGGL(fc_mfma<8>, grid, dim3(512), 0, h->stream, a);
-  else hipLaunchKernelGGL(fc_mfma<4>, grid, dim3(256), 0, h->stream, a);
+  if (h->ab & AB_FC_DIRECT) {
+    if (L.cin >= 1024) hipLaunchKernelGGL(fc_mfma<8>, grid, dim3(512), 0, h->stream, a);
+    else hipLaunchKernelGGL(fc_mfma<4>, grid, dim3(256), 0, h->stream, a);
+  } else if (L.cin >= 1024) hipLaunchKernelGGL((fc_mfma<8, true>), grid, dim3(512), 0, h->stream, a);
+  else hipLaunchKernelGGL((fc_mfma<4, true>), grid, dim3(256), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }

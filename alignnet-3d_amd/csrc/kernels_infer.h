@@ -519,10 +519,15 @@ struct FcArgs {
 
 // NW waves split K (4: the usual head layer; 8 for K >= 1024 -- the pair head's first layer, K = 2048, ran 64 k-groups per wave on half
 // the chip's CUs with one wave per SIMD: 20.8 us)
-template <int NW>
+// STAGE: the A operand (32 input rows x the trip's 64 k) goes through a per-wave LDS tile, read from memory as 256-byte row segments.  Read straight
+// into the MFMA layout, a load instruction's 64 lanes touch 64 different 128-byte lines (16 bytes each of 32 rows, two halves), one L1 lookup per
+// lane; row by row it is 8 lines per instruction.
+constexpr int kFcLd = 68;   // floats per staged row: 64 + 4 (row stride = 4 mod 8 floats: conflict-free 16-byte reads, as in pointnet_fused)
+template <int NW, bool STAGE = false>
 static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
 {
   __shared__ float red[NW - 1][16][64];
+  __shared__ __attribute__((aligned(16))) float stageA[STAGE ? NW : 1][STAGE ? 32 * kFcLd : 4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ct = blockIdx.x, mt = blockIdx.y;
   const int KG = a.K >> 3;   // K % 8 == 0 checked on the host
@@ -554,11 +559,32 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
   constexpr int U = 8;   // (sixteen with the eight-wave form was measured: 23.0 against 19.2 us for the K = 2048 layer)
   for (int kg = k0; kg < k1; kg += U) {
     f32x4 av[U], bv[U];
+    if (STAGE) {
+      float* st = stageA[wave];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = u * 64 + lane, r = q >> 4, c16 = q & 15;          // 16-byte chunk c16 of row r's 64-float segment
+        const int kk = min(kg + (c16 >> 1), k1 - 1);                      // its k-group, clamped like the direct form
+        const int row_g = min(mt * 32 + r, a.M - 1);
+        av[u] = *reinterpret_cast<const f32x4*>(a.in + (size_t)row_g * a.ldin + kk * 8 + (c16 & 1) * 4);
+        bv[u] = wp[(size_t)min(kg + u, k1 - 1) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = u * 64 + lane, r = q >> 4, c16 = q & 15;
+        *reinterpret_cast<f32x4*>(st + r * kFcLd + c16 * 4) = av[u];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < U; ++u) av[u] = *reinterpret_cast<const f32x4*>(st + (lane & 31) * kFcLd + u * 8 + (lane >> 5) * 4);
+      __builtin_amdgcn_wave_barrier();
+    } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = min(kg + u, k1 - 1);
       av[u] = *reinterpret_cast<const f32x4*>(arow + kk * 8);
       bv[u] = wp[(size_t)kk * 64];
+    }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
