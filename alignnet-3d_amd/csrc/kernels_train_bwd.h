@@ -1240,11 +1240,6 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   const float* G = a.G + (size_t)t * C2 * C2;
   const float* sv = a.s + (size_t)t * C2;
   const double invM = 1.0 / a.M;
-  auto wcol = [&](int i, int cc) -> double {   // W3[i][cc], as the lift saw it
-    float w = cc < C3 ? a.W[(size_t)i * C3 + cc] : 0.f;
-    if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
-    return (double)w;
-  };
   auto ghat = [&](int i, int j) -> double {   // centred Gram from the reduced upper 32 x 32 blocks
     const float raw = (i >> 5) <= (j >> 5) ? G[(size_t)i * C2 + j] : G[(size_t)j * C2 + i];
     return (double)raw - (double)sv[i] * ((double)sv[j] * invM);
@@ -1261,6 +1256,16 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
     const size_t h0 = ((size_t)(t * p.B + b) * 2) * C3 + min(c, C3 - 1), h1 = h0 + C3;
     pe0[u] = p.ext[h0]; pi0[u] = p.idx2[h0]; pe1[u] = p.ext[h1]; pi1[u] = p.idx2[h1];
   }
+  // ... and so are the few values the later phases start from (each was a round trip of its own behind a barrier): the block's share of the
+  // centred Gram that goes back to HBM, the finishing threads' parameters, the pooled part's sign and bias
+  const int gper = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, gr0 = blockIdx.x * gper, gr1 = min(C2, gr0 + gper), gne = (gr1 - gr0) * C2;
+  const int ge_i = gr0 + min(tid, max(gne - 1, 0)) / C2, ge_j = min(tid, max(gne - 1, 0)) % C2;
+  const float ge_raw = (ge_i >> 5) <= (ge_j >> 5) ? G[(size_t)ge_i * C2 + ge_j] : G[(size_t)ge_j * C2 + ge_i];
+  const float ge_si = sv[ge_i], ge_sj = sv[ge_j];
+  const int fcc = min(c0 + (tid & (kS3C - 1)), C3 - 1);
+  const float f_bias = a.pa.bias[fcc], f_gamma = a.gamma[t][fcc], f_beta = a.beta[t][fcc];
+  const float f_mm = a.update_ema ? a.mov_mean[t][fcc] : 0.f, f_mv = a.update_ema ? a.mov_var[t][fcc] : 0.f;
+  const float p_sg = p.sgn[t * C3 + min(c, C3 - 1)], p_bias = p.bias[min(c, C3 - 1)];
   double qp = 0.0, swp = 0.0;
   if (wave * 16 < C2) {
     const int i = wave * 16 + cj;          // A row of this lane
@@ -1275,6 +1280,13 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
       wr[m] = c < C3 ? a.W[(size_t)k * C3 + c] : 0.f;
       sr[m] = sv[k];
     }
+    float wd[4], sd[4];   // the D rows' weights and column sums (needed right behind the MFMAs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ir = wave * 16 + kq + 4 * r;
+      wd[r] = c < C3 ? a.W[(size_t)ir * C3 + c] : 0.f;
+      sd[r] = sv[ir];
+    }
 #pragma unroll
     for (int m = 0; m < 32; ++m)
       if (4 * m < C2) {
@@ -1284,11 +1296,12 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (double)w, acc, 0, 0, 0);
       }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ir = wave * 16 + kq + 4 * r;   // D row of register r
-      const double w = wcol(ir, c);
+    for (int r = 0; r < 4; ++r) {   // D row of register r: wave * 16 + kq + 4 r
+      float wf = wd[r];
+      if (a.round_w) wf = __uint_as_float((unsigned)to_bf16_bits(wf) << 16);
+      const double w = (double)wf;
       qp += w * acc[r];
-      swp += (double)sv[ir] * w;
+      swp += (double)sd[r] * w;
     }
   }
   qp += __shfl_xor(qp, 16); qp += __shfl_xor(qp, 32);
@@ -1296,9 +1309,9 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   if (lane < kS3C) { red[wave][0][lane] = qp; red[wave][1][lane] = swp; }
   // rows [r0, r1) of the centred Gram (all blocks) and the column means go to HBM for the backward
   {
-    const int per = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * per, r1 = min(C2, r0 + per);
-    for (int e = tid; e < (r1 - r0) * C2; e += 512) {
-      const int i = r0 + e / C2, j = e % C2;
+    if (tid < gne) a.Gc[(size_t)t * C2 * C2 + (size_t)ge_i * C2 + ge_j] = (float)((double)ge_raw - (double)ge_si * ((double)ge_sj * invM));   // (= ghat(i, j))
+    for (int e = tid + 512; e < gne; e += 512) {
+      const int i = gr0 + e / C2, j = e % C2;
       a.Gc[(size_t)t * C2 * C2 + (size_t)i * C2 + j] = (float)ghat(i, j);
     }
     if (blockIdx.x == 0) for (int i = tid; i < C2; i += 512) a.m2[t * C2 + i] = (float)((double)sv[i] * invM);
@@ -1309,23 +1322,23 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
     double Q = 0.0, sw = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { Q += red[w][0][tid]; sw += red[w][1][tid]; }
-    const float bias = a.pa.bias[cc];
+    const float bias = f_bias;   // (tid < kS3C: fcc == cc)
     const float mf = (float)(sw * invM + (double)bias), vf = (float)fmax(Q * invM, 0.0);
-    const float rs = 1.0f / sqrtf(vf + kBnEps), inv = a.gamma[t][cc] * rs;
+    const float rs = 1.0f / sqrtf(vf + kBnEps), inv = f_gamma * rs;
     a.mean[t * C3 + cc] = mf; a.var[t * C3 + cc] = vf;
-    a.scale[t * C3 + cc] = inv; a.shift[t * C3 + cc] = (bias - mf) * inv + a.beta[t][cc];
+    a.scale[t * C3 + cc] = inv; a.shift[t * C3 + cc] = (bias - mf) * inv + f_beta;
     a.rstd[t * C3 + cc] = rs; a.k[t * C3 + cc] = inv;
     if (a.update_ema) {
-      a.mov_mean[t][cc] -= (1.f - a.bn_decay) * (a.mov_mean[t][cc] - mf);
-      a.mov_var[t][cc] -= (1.f - a.bn_decay) * (a.mov_var[t][cc] - vf);
+      a.mov_mean[t][cc] = f_mm - (1.f - a.bn_decay) * (f_mm - mf);
+      a.mov_var[t][cc] = f_mv - (1.f - a.bn_decay) * (f_mv - vf);
     }
-    cst[0][tid] = mf; cst[1][tid] = vf; cst[2][tid] = inv; cst[3][tid] = (bias - mf) * inv + a.beta[t][cc];
+    cst[0][tid] = mf; cst[1][tid] = vf; cst[2][tid] = inv; cst[3][tid] = (bias - mf) * inv + f_beta;
   }
   __syncthreads();
   if (c >= C3) return;
   // pooled features of the block's channels, all clouds of the tower (ext = extreme of sgn * (z - bias), both half-wave slices):
   // 16 channels x 32 cloud groups; the first eight clouds per thread were requested at the top
-  const float sg = p.sgn[t * C3 + c], bias = p.bias[c], mf = cst[0][cj], rs = 1.0f / sqrtf(cst[1][cj] + kBnEps), sc = cst[2][cj], sh = cst[3][cj];
+  const float sg = p_sg, bias = p_bias, mf = cst[0][cj], rs = 1.0f / sqrtf(cst[1][cj] + kBnEps), sc = cst[2][cj], sh = cst[3][cj];
   auto finish = [&](int b, float e, int bi, float e1, int b1) {
     if (e1 > e || (e1 == e && b1 < bi)) { e = e1; bi = b1; }
     const size_t i = (size_t)(t * p.B + b) * C3 + c;

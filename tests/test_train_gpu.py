@@ -589,7 +589,8 @@ def test_phase3_tile_shapes_agree(gpu_required, N, B, bf16):
     for k in alignnet3d.OUTPUT_NAMES:
         np.testing.assert_allclose(ra[k], rb[k], rtol=pt, atol=pt, err_msg=k)
     for k in ea:
-        np.testing.assert_allclose(ea[k], eb[k], rtol=et, atol=et * 0.1, err_msg=k)
+        # (absolute part: a head layer's moving mean is a sum of unit-scale pre-activations that nearly cancels -- measured 1.4e-6 on a mean of 0.015)
+        np.testing.assert_allclose(ea[k], eb[k], rtol=et, atol=et * 0.5, err_msg=k)
     gscale = max(float(np.abs(v).max()) for v in gb.values())
     # gradients: a 1e-6 difference in stage 1's output moves the points of the later stages, and a max-pool near-tie that falls the other
     # way re-routes one channel's gradient.  Measured over these nine shapes: relative L2 of the whole gradient 4e-6 .. 5e-5 in seven of
