@@ -949,6 +949,13 @@ __device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx
   if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
     for (int i = bx * 1024 + threadIdx.x; i < a.next_C; i += gx * 1024) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
   const int S = a.B * a.slices;
+  // the finishing thread's parameters travel with the partials (loaded behind the barrier they were a round trip of their own)
+  const int cq = min(c, a.C - 1);
+  float f_gamma = 0.f, f_bias = 0.f, f_beta = 0.f, f_mm = 0.f, f_mv = 0.f;
+  if (g == 0 && !a.totals_out) {
+    f_gamma = a.gamma[t][cq]; f_bias = a.bias[cq]; f_beta = a.beta[t][cq];
+    if (a.update_ema) { f_mm = a.mov_mean[t][cq]; f_mv = a.mov_var[t][cq]; }
+  }
   double s = 0.0, ss = 0.0;
   if (c < a.C)
     for (int b = g; b < S; b += kG * 4) {   // four slices per trip: eight independent loads in flight
@@ -972,15 +979,15 @@ __device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx
   const float mf = (float)mean, vf = (float)var;
   a.mean[t * a.C + c] = mf;
   a.var[t * a.C + c] = vf;
-  const float inv = a.gamma[t][c] * (1.0f / sqrtf(vf + kBnEps));
+  const float inv = f_gamma * (1.0f / sqrtf(vf + kBnEps));
   a.scale[t * a.C + c] = inv;
-  a.shift[t * a.C + c] = (a.bias[c] - mf) * inv + a.beta[t][c];
+  a.shift[t * a.C + c] = (f_bias - mf) * inv + f_beta;
   a.rstd[t * a.C + c] = 1.0f / sqrtf(vf + kBnEps);
   a.k[t * a.C + c] = inv;
   if (a.update_ema) {
     // ExponentialMovingAverage.apply: shadow -= (1 - decay) * (shadow - value)
-    a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);
-    a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
+    a.mov_mean[t][c] = f_mm - (1.f - a.bn_decay) * (f_mm - mf);
+    a.mov_var[t][c] = f_mv - (1.f - a.bn_decay) * (f_mv - vf);
   }
 }
 __global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs a) { stat_finish_body(a, blockIdx.x, blockIdx.y, gridDim.x); }

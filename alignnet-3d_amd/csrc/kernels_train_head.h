@@ -648,7 +648,9 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
       S.lse[term * B + i] = l;
       // target angle of row i (term 2: column 0 of T, tp8.py:199 class_id[:, 0])
       const float tgt = term == 0 ? a.a1[i] : term == 1 ? a.a2[i] : (a.a2[i] - a.a1[i]) - (a.theta[B + 0] - a.theta[0]);
-      for (int v = 0; v < nvar; ++v) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {   // (constant trip count: ce[][v] indexed by a run-time v lived in scratch memory)
+        if (v >= nvar) break;
         int c; float r;
         angle2class(tgt + (v ? pi : 0.f), nb, &c, &r);
         const int cc = min(max(c, 0), nb - 1);
@@ -692,22 +694,27 @@ __device__ __forceinline__ void loss_pairs_body(const LossArgs& a, int G, int g,
       angle2class(tgt + (v ? pi : 0.f), nb, &cj, &rj);
       pj[q] = v < nvar ? term_logits(a, term, j)[nb + min(max(cj, 0), nb - 1)] : 0.f;
     }
+    float sjv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hlv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = i0; i < i1; ++i) {   // (row loop outside, the six (term, variant) inside and fully unrolled: every array index is a constant -- a `continue`
+                                      //  in the unrolled loop had left pj[] in scratch memory)
+      const float a1i = a.a1[i], a2i = a.a2[i];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int term = q >> 1, v = q & 1;
+        int c; float r;
+        if (term < 2) angle2class((term == 0 ? a1i : a2i) + (v ? pi : 0.f), nb, &c, &r);
+        else angle2class((a2i - a1i) - dth + (v ? pi : 0.f), nb, &c, &r);
+        const float label = r / pinb;
+        const float e = pj[q] - label;
+        hlv[q] += huberf(e, 1.f);
+        sjv[q] += clipf(e, 1.f);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int term = q >> 1, v = q & 1;
-      if (v >= nvar) continue;
-      float sj = 0.f, hl = 0.f;
-      for (int i = i0; i < i1; ++i) {
-        int c; float r;
-        if (term < 2) angle2class((term == 0 ? a.a1[i] : a.a2[i]) + (v ? pi : 0.f), nb, &c, &r);
-        else angle2class((a.a2[i] - a.a1[i]) - dth + (v ? pi : 0.f), nb, &c, &r);
-        const float label = r / pinb;
-        const float e = pj[q] - label;
-        hl += huberf(e, 1.f);
-        sj += clipf(e, 1.f);
-      }
-      rlv[q] += (double)hl;
-      S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sj;
+      rlv[q] += (double)hlv[q];
+      if (v < nvar) S.sjp[(((size_t)g * 3 + term) * 2 + v) * B + j] = sjv[q];
     }
   }
   block_sum_n<6>(rlv, red);
