@@ -1,0 +1,72 @@
+"""The A/B dispatch overrides of alignnet_set_option ("ab_*", csrc/engine.h: AbBit) select an earlier kernel variant of the SAME arithmetic; they
+exist for same-box timing comparisons (tools/ab_step.py) and every one of them must keep computing the step: each is run here against the default
+dispatch on the same inputs.  Results agree up to summation order (fp32) / up to what two bf16 evaluations of one batch agree to."""
+import numpy as np
+import pytest
+
+import alignnet3d
+from oracle import alignnet_ref as R
+from tests import test_train_gpu as TT
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(cfg, P32, d, du, bf16, options):
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.set_option("train_matmul_bf16", bf16)
+    for k, v in options:
+        eng.set_option(k, v)
+    mask = eng.get_option("ab_mask")
+    ul = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
+    names = [n for n, _, tr in eng.variables() if tr]
+    g = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names])
+    eng.close()
+    return res, g, mask
+
+
+TRAIN_CASES = [
+    # (backbone, bf16, key)
+    ("pointnet", 0, "ab_phase2_legacy"), ("pointnet", 0, "ab_b1_legacy"), ("pointnet", 0, "ab_p3_nogram"), ("pointnet", 0, "ab_no_defer"),
+    ("pointnet", 0, "ab_no_glue_fold"), ("pointnet", 0, "ab_gemm_jobs_ksplit"),
+    ("pointnet", 1, "ab_b1_fp32"), ("pointnet", 1, "ab_p3_bf16_generic"), ("pointnet", 1, "ab_no_defer"), ("pointnet", 1, "ab_gemm_jobs_ksplit"),
+    ("dgcnn", 0, "ab_no_defer"), ("dgcnn", 1, "ab_dg_sparse"),
+]
+
+
+@pytest.mark.parametrize("backbone,bf16,key", TRAIN_CASES)
+def test_training_variant_matches_default(gpu_required, backbone, bf16, key):
+    N, B = 128, 8
+    cfg, spec, P32, d, du = (TT._setup_dgcnn if backbone == "dgcnn" else TT._setup)(N, B, std=True)
+    r0, g0, m0 = _step(cfg, P32, d, du, bf16, ())
+    r1, g1, m1 = _step(cfg, P32, d, du, bf16, ((key, 1),))
+    assert m0 == 0 and m1 != 0, (m0, m1)          # the key is known and sets its bit
+    rl2 = float(np.linalg.norm(g1 - g0) / np.linalg.norm(g0))
+    cos = float(g0 @ g1 / (np.linalg.norm(g0) * np.linalg.norm(g1)))
+    dl = abs(r1["loss"] - r0["loss"]) / max(1.0, abs(r0["loss"]))
+    dp = max(float(np.abs(np.asarray(r1[k]) - np.asarray(r0[k])).max()) for k in alignnet3d.OUTPUT_NAMES)
+    print("%s bf16=%d %s: loss %.1e predictions %.1e gradient relative L2 %.1e cosine %.7f" % (backbone, bf16, key, dl, dp, rl2, cos))
+    if bf16:   # two bf16 evaluations: a rounding-level difference upstream can flip a bf16 rounding or a max-pool winner downstream
+        assert dl <= 5e-3 and dp <= 5e-2 and cos >= 0.97, (dl, dp, rl2, cos)
+    else:      # same fp32 arithmetic, another summation order; a changed max-pool winner re-routes one channel's gradient
+        assert dl <= 2e-5 and dp <= 1e-4 and rl2 <= 2e-2 and cos >= 0.9998, (dl, dp, rl2, cos)
+
+
+@pytest.mark.parametrize("backbone,options", [
+    ("pointnet", (("ab_no_ld_const", 1),)), ("pointnet", (("ab_infer_tile64", 1),)), ("pointnet", (("ab_fc_direct", 1),)), ("pointnet", (("ab_tiles_per_wg", 1),)),
+    ("dgcnn", (("ab_no_ld_const", 1),)), ("dgcnn", (("ab_fc_direct", 1),)),
+])
+def test_inference_variant_matches_default(gpu_required, backbone, options):
+    N, B = 256, 8
+    cfg, spec, P32, d, du = (TT._setup_dgcnn if backbone == "dgcnn" else TT._setup)(N, B, std=True)
+    outs = []
+    for opts in ((), options):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        for k, v in opts:
+            eng.set_option(k, v)
+        outs.append({k: np.asarray(v).copy() for k, v in eng.forward(d["pcs1"], d["pcs2"]).items()})
+        eng.close()
+    for k in alignnet3d.OUTPUT_NAMES:
+        np.testing.assert_allclose(outs[1][k], outs[0][k], rtol=2e-5, atol=2e-5, err_msg="%s %s" % (options, k))
