@@ -103,6 +103,41 @@ def test_gradients_match_autograd(gpu_required, N, B, tol, std):
     eng.close()
 
 
+def test_deep_heads_flush_their_jobs_in_chunks(gpu_required):
+    """Six FC layers per head: 3 x 6 deferred dW products + the six of the conv layers = 24 jobs, more than one job table of the deferred
+    launches holds (kGemmJobs = 18; round 3 failed such a step with "job table overflow" after the backward had been queued -- ADVICE round 3).
+    flush_deferred chunks its tables; every gradient against autograd, and the same step with deferral off (ab_no_defer)."""
+    N, B = 128, 16
+    cfg = small_cfg(N=N, nb=12, fc=(64, 48, 40, 32, 24), s1=(32, 64, 96), s2=(32, 64, 128), emb=(32, 64, 160))
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=5)
+    d = R.synth_pairs(B, N, seed=5, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    du = {k: rng.uniform(size=(B, 24)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}   # (dropout sits behind the last hidden layer)
+    ul = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    got = []
+    for nodefer in (0, 1):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("ab_no_defer", nodefer)
+        if not nodefer:
+            _, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
+        got.append({n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)})
+        assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+        eng.close()
+    # six BatchNorm'd layers on 16-row statistics are badly conditioned (gradient entries of several hundred, the fp32 forward's rounding amplified
+    # layer by layer): against autograd the whole gradient is compared; the sharp check is deferred == in place
+    names = list(got[0])
+    ga = np.concatenate([got[0][n].ravel() for n in names]); gr = np.concatenate([grads[n].ravel() for n in names])
+    rl2 = float(np.linalg.norm(ga - gr) / np.linalg.norm(gr)); cos = float(ga @ gr / (np.linalg.norm(ga) * np.linalg.norm(gr)))
+    print("deep heads: whole gradient vs autograd: relative L2 %.2e, cosine %.6f" % (rl2, cos))
+    assert rl2 <= 2e-3 and cos >= 0.99999, (rl2, cos)   # measured 1.0e-4
+    gscale = float(np.abs(ga).max())
+    for n in names:
+        np.testing.assert_allclose(got[1][n], got[0][n], rtol=1e-4, atol=1e-5 * gscale, err_msg=n)   # deferred == in place, up to summation order
+
+
 def test_adam_step_and_state(gpu_required):
     cfg, spec, P32, d, du = _setup(128, 6)
     cfg["data"]["ntrain"] = 600
