@@ -828,18 +828,31 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   double pd[4] = {0.0, 0.0, 0.0, 0.0};
   const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);   // this wave's dh1 item: 32 rows x 32 channels
   const float qb = a.q2b[tower * C1 + col];
+  // the tile's points and its dy2 rows (16 KB of bf16 from HBM) are requested one tile ahead: loaded at the head of the tile, their round trip
+  // sat exposed in front of the first barrier of each of a cloud's 16 tiles
+  constexpr int kDyIt = (C2 / 8) / kTW;
+  TilePoint npt = tile_point_request(pc, a.N, 0, tid);
+  uint4 ndy[kDyIt];
+  auto dy_request = [&](int tile) {
+    const int nv = min(kTT, a.N - tile * kTT);
+    const unsigned short* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
+#pragma unroll
+    for (int it = 0; it < kDyIt; ++it) {
+      ndy[it] = uint4{0u, 0u, 0u, 0u};
+      if (lane < nv) ndy[it] = *reinterpret_cast<const uint4*>(src + (size_t)lane * C2 + (wave + it * kTW) * 8);
+    }
+  };
+  dy_request(0);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     __syncthreads();
-    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    tile_point_store(npt, xf, xs, tid);
     {   // dy2 tile: lane = row, wave-uniform 8-channel chunk; row-major 16-byte write + eight transposed 2-byte writes (consecutive lanes)
-      const unsigned short* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * C2;
       const int row = lane;
 #pragma unroll
-      for (int it = 0; it < (C2 / 8) / kTW; ++it) {
+      for (int it = 0; it < kDyIt; ++it) {
         const int q = wave + it * kTW;
-        uint4 pk = {0u, 0u, 0u, 0u};
-        if (row < nvalid) pk = *reinterpret_cast<const uint4*>(src + (size_t)row * C2 + q * 8);
+        const uint4 pk = ndy[it];
         *reinterpret_cast<uint4*>(Yh + row * ldy + q * 8) = pk;
         const unsigned v[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
@@ -849,6 +862,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
         }
       }
     }
+    if (tile + 1 < ntiles) { npt = tile_point_request(pc, a.N, tile + 1, tid); dy_request(tile + 1); }
     __syncthreads();
     {   // lift: thread (channel c0 + 32 g, rows 8 r0 .. 8 r0 + 7): eight bf16 values -> one 16-byte transposed write + eight row-major ones
       const int c0 = tid & 31, r0 = tid >> 5;
