@@ -387,6 +387,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
     l2sh[q2] = live ? a.sh2[tower * kC2 + col] : 0.f;
   }
   double gcs[4] = {0.0, 0.0, 0.0, 0.0};   // GIVEN && BF16: column sums of the rounded features, this thread's four columns
+  // phase 2: the next tile's points are requested while this tile computes (their round trip sat in front of every tile's first barrier);
+  // phase 3 has no register to spare for it (see kRegSums)
+  constexpr bool kPfPts = PHASE == 2 && !GIVEN;
+  TilePoint npt = {0.f, 0.f, 0.f};
+  if (kPfPts) npt = tile_point_request(pc, a.N, 0, tid);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
@@ -437,7 +442,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         *reinterpret_cast<f32x4*>(buf1 + row * ld1 + q * 4) = v;
       }
     } else {
-    load_tile_xform(pc, xf, a.N, tile, xs, tid);
+    if (kPfPts) {
+      tile_point_store(npt, xf, xs, tid);
+      if (tile + 1 < ntiles) npt = tile_point_request(pc, a.N, tile + 1, tid);
+    } else load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();
     P3_STAMP(1);
     // bf16 mode: the hidden layer's operands are bf16 too (h1 tile in the buf0 region, row stride K16(C1) + 8 elements)
