@@ -385,6 +385,7 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
     const size_t o_p1 = tot; tot += al(B2 * C1);
     const size_t o_p2 = tot; tot += al(B2 * C2);
     const size_t o_emb = tot; tot += al(B2 * CE);
+    const size_t o_hs = tot; tot += al(B2 * H);    // (directly behind the pooled buffers: cleared with them by the centroid kernel)
     const size_t o_ha = tot; tot += al(B2 * H);
     const size_t o_hb = tot; tot += al(B2 * H);
     const size_t o_o1 = tot; tot += al(B2 * 3);
@@ -398,7 +399,7 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
     w.xform = base + o_xform; w.center_mean = base + o_cm; w.s1c = base + o_s1c; w.s2c = base + o_s2c;
     w.theta = base + o_theta; w.cls = reinterpret_cast<int*>(base + o_cls);
     w.pool1 = base + o_p1; w.pool2 = base + o_p2; w.emb = base + o_emb;
-    w.hid_a = base + o_ha; w.hid_b = base + o_hb;
+    w.hid_a = base + o_ha; w.hid_b = base + o_hb; w.hid_s = base + o_hs;
     w.o1 = base + o_o1; w.o2 = base + o_o2; w.o3 = base + o_o3;
     for (int i = 0; i < 8; ++i) w.outs[i] = base + o_out[i];
     w.cap = B;
@@ -598,13 +599,15 @@ static int run_backbone_dgcnn(alignnet_handle* h, const Stack& st, const float* 
 }
 
 static int run_fc(alignnet_handle* h, const Layer& L, const float* in, long ldin, float* out, long ldout, int M,
-                  int rows_per_set, bool relu, const FcArgs* finish = nullptr)
+                  int rows_per_set, bool relu, const FcArgs* finish = nullptr, int ksplit = 1, const Layer* in_bn = nullptr)
 {
   FcArgs a;
   if (finish) a = *finish;   // the stage glue folded into this (last) layer's epilogue
   a.in = in; a.ldin = ldin; a.wp = h->d_wp + L.off_wp; a.scale = h->d_scale + L.off_ss; a.shift = h->d_shift + L.off_ss;
   a.out = out; a.ldout = ldout; a.M = M; a.K = L.cin; a.Nout = L.cout; a.relu = relu; a.rows_per_set = rows_per_set;
-  const dim3 grid((L.cout + 31) / 32, (M + 31) / 32);
+  a.ksplit = ksplit;
+  if (in_bn) { a.in_scale = h->d_scale + in_bn->off_ss; a.in_shift = h->d_shift + in_bn->off_ss; }   // (BN set 0: the pair head is not siamese)
+  const dim3 grid((L.cout + 31) / 32, (M + 31) / 32, ksplit);
   if (h->ab & AB_FC_DIRECT) {
     if (L.cin >= 1024) hipLaunchKernelGGL(fc_mfma<8>, grid, dim3(512), 0, h->stream, a);
     else hipLaunchKernelGGL(fc_mfma<4>, grid, dim3(256), 0, h->stream, a);
@@ -620,12 +623,22 @@ static int run_head(alignnet_handle* h, const Stack& st, const float* in, long l
 {
   const float* cur = in; long ldc = ldin;
   float* pp[2] = {h->ws.hid_a, h->ws.hid_b};
+  const Layer* split_bn = nullptr;
   for (int j = 0; j < st.n; ++j) {
     const Layer& L = h->layers[st.first + j];
     const bool last = j == st.n - 1;
     float* dst = last ? out : pp[j & 1];
     const long ldd = last ? ldout : L.cout;
-    if (run_fc(h, L, cur, ldc, dst, ldd, M, rows_per_set, !last, last ? finish : nullptr)) return 1;
+    // a deep first layer on few tiles (the pair head: K = 2048, 128 tiles) as two K halves onto the zeroed hid_s; the next layer finishes it
+    const bool split = j == 0 && !last && L.cin >= 2048 && ((L.cin / 8) % 2) == 0 && (L.cin % 8) == 0 && M <= rows_per_set &&
+                       (long)((L.cout + 31) / 32) * ((M + 31) / 32) <= 128 && !(h->ab & (AB_FC_DIRECT | AB_FC_NO_SPLITK));
+    if (split) {
+      if (run_fc(h, L, cur, ldc, h->ws.hid_s, L.cout, M, rows_per_set, false, nullptr, 2)) return 1;
+      cur = h->ws.hid_s; ldc = L.cout; split_bn = &L;
+      continue;
+    }
+    if (run_fc(h, L, cur, ldc, dst, ldd, M, rows_per_set, !last, last ? finish : nullptr, 1, split_bn)) return 1;
+    split_bn = nullptr;
     cur = dst; ldc = ldd;
   }
   return 0;

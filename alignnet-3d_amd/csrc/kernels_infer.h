@@ -515,6 +515,12 @@ struct FcArgs {
   const float* addend = nullptr;   // finish 1: center_mean [2B][3]; finish 3: s2c [2B][3]
   float* s1c = nullptr; float* xform = nullptr;
   float* out_a = nullptr; float* out_b = nullptr;   // finish 1: pred_s1_pc1centers / pc2centers; finish 3: pred_translations / remaining logits (any may be null)
+  // Two K halves (grid.z = 2, ksplit = 2; STAGE form only): a 32 x 32 tile over K = 2048 is 1024 MFMAs = 6.8 us of one CU's matrix pipe, and the pair
+  // head's first layer has only 128 tiles -- half the chip idles behind them.  Each half adds its raw partial tile onto a zeroed buffer (two addends
+  // onto zero: a + b = b + a, the result does not depend on who arrives first) and the NEXT layer applies this layer's folded BatchNorm + relu to its
+  // A operand while it stages it (in_scale / in_shift per input column, BN set 0).
+  int ksplit = 1;
+  const float* in_scale = nullptr; const float* in_shift = nullptr;
 };
 
 // NW waves split K (4: the usual head layer; 8 for K >= 1024 -- the pair head's first layer, K = 2048, ran 64 k-groups per wave on half
@@ -537,7 +543,8 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int per = (KG + NW - 1) / NW, k0 = wave * per, k1 = min(KG, k0 + per);
+  const int KGz = KG / a.ksplit, kz0 = (int)blockIdx.z * KGz;             // this workgroup's K range (ksplit divides KG: checked on the host)
+  const int per = (KGz + NW - 1) / NW, k0 = kz0 + wave * per, k1 = min(kz0 + KGz, k0 + per);
   // the folded glue's addends are requested in front of the MFMA loop (loaded in the epilogue, each row's round trip sat exposed behind it)
   float add0[16], add1[16];
 #pragma unroll
@@ -568,6 +575,16 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
         const int row_g = min(mt * 32 + r, a.M - 1);
         av[u] = *reinterpret_cast<const f32x4*>(a.in + (size_t)row_g * a.ldin + kk * 8 + (c16 & 1) * 4);
         bv[u] = wp[(size_t)min(kg + u, k1 - 1) * 64];
+      }
+      if (a.in_scale) {   // the producing layer's folded BatchNorm + relu, applied on the way into the tile (see FcArgs.ksplit)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c16 = (u * 64 + lane) & 15, kk = min(kg + (c16 >> 1), k1 - 1);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale + kk * 8 + (c16 & 1) * 4);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift + kk * 8 + (c16 & 1) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[u][e] = fmaxf(fmaf(av[u][e], sc[e], sh[e]), 0.f);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -609,6 +626,7 @@ static __global__ __launch_bounds__(NW * 64) void fc_mfma(const FcArgs a)
           float v = acc[r];
 #pragma unroll
           for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
+          if (a.ksplit > 1) { unsafeAtomicAdd(a.out + (size_t)row * a.ldout + col, v); continue; }   // raw partial tile; the consumer finishes it
           v = fmaf(v, set ? esc1 : esc0, set ? esh1 : esh0);
           v = a.relu ? fmaxf(v, 0.f) : v;
           a.out[(size_t)row * a.ldout + col] = v;
