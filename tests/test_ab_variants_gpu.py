@@ -54,7 +54,7 @@ def test_training_variant_matches_default(gpu_required, backbone, bf16, key):
 
 
 @pytest.mark.parametrize("backbone,options", [
-    ("pointnet", (("ab_no_ld_const", 1),)), ("pointnet", (("ab_infer_tile64", 1),)), ("pointnet", (("ab_fc_direct", 1),)), ("pointnet", (("ab_tiles_per_wg", 1),)),
+    ("pointnet", (("ab_no_ld_const", 1),)), ("pointnet", (("ab_infer_tile64", 1),)), ("pointnet", (("ab_fc_direct", 1),)), ("pointnet", (("ab_fc_no_splitk", 1),)), ("pointnet", (("ab_tiles_per_wg", 1),)),
     ("dgcnn", (("ab_no_ld_const", 1),)), ("dgcnn", (("ab_fc_direct", 1),)),
 ])
 def test_inference_variant_matches_default(gpu_required, backbone, options):
