@@ -60,6 +60,12 @@ def test_default_line(gpu_required):
     assert d["icp"]["value"] > 100 and d["icp"]["mean_fitness"] > 0.5
     assert d["options"]["ab_mask"] == 0 and d["options"]["ablation_build"] is False and d["options"]["library"] == "libalignnet_hip.so"
     assert d["train"]["roofline"]["frac_lift_only"] < d["train"]["roofline"]["frac"]
+    # `value` is timed under the per-kernel HIP-event timers (the contract's timed region); the line also carries the same K steps without them,
+    # and the secondary training legs time their value without them and repeat the K steps under them for the roofline
+    off = d["without_kernel_timers"]
+    assert 0.95 * d["value"] <= off["value"] <= 1.10 * d["value"] and abs(off["value"] * off["ms_per_step"] * 1e-3 - 256) < 1.0, off
+    for leg in (d["train"], d["train"]["bf16"]):
+        assert 0.9 * leg["ms_per_step"] <= leg["ms_per_step_under_kernel_timers"] <= 1.25 * leg["ms_per_step"], leg
     assert d["pcie_inclusive"]["value"] < d["value"] * 1.05 and d["pcie_inclusive"]["pipelined"]["value"] > 0.9 * d["pcie_inclusive"]["value"] and d["infer_bf16x3"]["max_abs_diff_vs_exact_fp32_outputs"] < 1e-4
 
 
