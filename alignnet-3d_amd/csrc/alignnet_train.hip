@@ -567,7 +567,9 @@ static int flush_deferred(alignnet_handle* h, hipStream_t stream)
   return 0;
 }
 
-static int pack_all_weights(alignnet_handle* h)
+// the step's weight images: queued into `start` (train_start_kernel launches them with the centroids) or, start == nullptr, launched here
+struct StartJobs { const PackJob* f32 = nullptr; int nf32 = 0; PackBf16Jobs pj{}; int nbf16 = 0; };
+static int pack_all_weights(alignnet_handle* h, StartJobs* start = nullptr)
 {
   TrainWS* w = tws(h);
   if (!w->pack_table) {   // (src, dst, K, C) per MFMA conv layer, built once.  (The head layers' images are eval-only: fold_for_eval rebuilds every
@@ -583,7 +585,10 @@ static int pack_all_weights(alignnet_handle* h)
   // with only specialised PointNet stages nothing reads them (the heads use the raw matrices, the backbones the bf16 images below)
   bool need_f32 = !h->train_bf16 || h->cfg.backbone == 1;
   for (int s = 0; s < 3; ++s) need_f32 = need_f32 || stage_generic(h, s);
-  if (need_f32 && w->n_pack) hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(256, w->n_pack), dim3(256), 0, h->stream, w->pack_table);   // (<= 2 elements per thread)
+  if (need_f32 && w->n_pack) {
+    if (start) { start->f32 = w->pack_table; start->nf32 = w->n_pack; }
+    else hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(256, w->n_pack), dim3(256), 0, h->stream, w->pack_table);   // (<= 2 elements per thread)
+  }
   if (h->train_bf16) {
     // bf16 images of every specialised stage's lift (one per tower: the sign of that tower's gamma folded in) and hidden layer, one launch
     PackBf16Jobs pj{};
@@ -613,7 +618,8 @@ static int pack_all_weights(alignnet_handle* h)
       }
     }
     if (nj > kPackBf16Jobs) return fail(h, "pack_all_weights: job table overflow");
-    if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(128, nj), dim3(256), 0, h->stream, pj);   // (128 blocks per image: four elements per thread; with 32 a thread walked sixteen dependent-latency trips)
+    if (nj && start) { start->pj = pj; start->nbf16 = nj; }
+    else if (nj) hipLaunchKernelGGL(pack_bf16_jobs_kernel, dim3(128, nj), dim3(256), 0, h->stream, pj);   // (128 blocks per image: four elements per thread; with 32 a thread walked sixteen dependent-latency trips)
   }
   h->folded = false;   // eval-mode scale/shift are rebuilt lazily by the next eval forward
   return 0;
@@ -1569,8 +1575,12 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   }
   if (do_backward && !w->grad_clean) HIP_TRY(h, hipMemsetAsync(w->grad, 0, h->n_trainable * sizeof(float), h->stream));   // incl. the BN-fed biases (exact zero)
   if (do_backward) w->grad_clean = false;   // (clean = the optimiser zeroed it behind its read: alignnet_apply_gradients)
-  if (pack_all_weights(h)) return 1;
-  hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w->st[0].xform, w->center_mean);
+  {
+    StartJobs sj;
+    if (pack_all_weights(h, &sj)) return 1;
+    hipLaunchKernelGGL(train_start_kernel, dim3(B2 + sj.nf32 * kStartF32Blocks + sj.nbf16 * kStartBf16Blocks), dim3(256), 0, h->stream, p1, p2, B, N,
+                       w->st[0].xform, w->center_mean, sj.f32, sj.nf32, sj.pj, sj.nbf16);
+  }
   if (h->cfg.backbone == 1) {   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
     ProfScope prof_scope(h, PK_KNN, true);
     prof_scope.used = true;

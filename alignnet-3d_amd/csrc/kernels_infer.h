@@ -52,12 +52,12 @@ constexpr float kBnEps = 1e-3f;   // utils/tf_util.py:491
 
 // all MFMA layers in one launch (training re-packs every step): grid (blocks, jobs)
 struct PackJob { const float* src; float* dst; int K, C; };
-[[maybe_unused]] static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ jobs)
+__device__ __forceinline__ void pack_weights_multi_body(const PackJob* __restrict__ jobs, unsigned bx, unsigned by, unsigned gx)
 {
-  const PackJob j = jobs[blockIdx.y];
+  const PackJob j = jobs[by];
   const int KG = (j.K + 7) >> 3, CT = (j.C + 31) >> 5;
   const size_t total = (size_t)CT * KG * 256;
-  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+  for (size_t idx = bx * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gx * blockDim.x) {
     const int s = idx & 3, lane = (idx >> 2) & 63;
     const size_t t = idx >> 8;
     const int kg = t % KG, ct = t / KG;
@@ -65,6 +65,7 @@ struct PackJob { const float* src; float* dst; int K, C; };
     j.dst[idx] = (k < j.K && c < j.C) ? j.src[(size_t)k * j.C + c] : 0.f;
   }
 }
+[[maybe_unused]] static __global__ void pack_weights_multi_kernel(const PackJob* __restrict__ jobs) { pack_weights_multi_body(jobs, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // scale/shift for one layer and one BN set; bn == nullptr -> plain bias.
 [[maybe_unused]] static __global__ void fold_bn_kernel(const float* __restrict__ bias, const float* __restrict__ beta,
@@ -89,17 +90,16 @@ struct PackJob { const float* src; float* dst; int K, C; };
 // (centre = mean, rotation = identity) and keeps the mean for tp8.py:109.
 // xform layout per cloud: c[3], R[9] row-major (p' = (p - c) @ R).
 // ---------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
-                                                      int B, int N, float* __restrict__ xform,
-                                                      float* __restrict__ center_mean, float* __restrict__ zero = nullptr, size_t nzero = 0)
+__device__ __forceinline__ void centroid_body(const float* __restrict__ pcs1, const float* __restrict__ pcs2, int B, int N, float* __restrict__ xform,
+                                              float* __restrict__ center_mean, float* __restrict__ zero, size_t nzero, int cloud, int nclouds)
 {
   // eval forward: the pooled-feature buffers (atomicMax targets of the three backbones) are cleared here, a slice per workgroup,
   // instead of by a memset launch of their own in front of this kernel
   if (zero) {
-    const size_t per = (nzero + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < nzero ? lo + per : nzero;
+    const size_t per = (nzero + nclouds - 1) / nclouds, lo = cloud * per, hi = lo + per < nzero ? lo + per : nzero;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) zero[i] = 0.f;
   }
-  const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B;
+  const int tower = cloud >= B, b = cloud - tower * B;
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   float s[3] = {0.f, 0.f, 0.f};
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -122,6 +122,12 @@ static __global__ __launch_bounds__(256) void centroid_kernel(const float* __res
     xform[cloud * 12 + threadIdx.x] = m;
   }
   if (threadIdx.x < 9) xform[cloud * 12 + 3 + threadIdx.x] = (threadIdx.x % 4 == 0) ? 1.f : 0.f;
+}
+static __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                      int B, int N, float* __restrict__ xform,
+                                                      float* __restrict__ center_mean, float* __restrict__ zero = nullptr, size_t nzero = 0)
+{
+  centroid_body(pcs1, pcs2, B, N, xform, center_mean, zero, nzero, blockIdx.x, gridDim.x);
 }
 
 // bf16 operands (training option train_matmul_bf16, inference option infer_matmul_bf16x3)
