@@ -524,17 +524,21 @@ static int flush_deferred(alignnet_handle* h, hipStream_t stream)
   }
   for (auto& sr : d.sync_after_red) if (sync_sum(h, sr.first, sr.second, false)) return 1;
   constexpr size_t kSp = sizeof(SparseDwJobs::j) / sizeof(SparseDwJob), kCen = sizeof(CentreJobs::j) / sizeof(CentreJob), kComb = sizeof(CombineJobs::j) / sizeof(CombineJob);
-  for (size_t i0 = 0; i0 < d.sp.size(); i0 += kSp) {
-    const size_t nj = std::min(d.sp.size() - i0, kSp);
-    SparseDwJobs J{}; int cmax = 0;
-    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.sp[i0 + i]; cmax = std::max(cmax, d.sp[i0 + i].C3); }
-    hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3((cmax + kSdC - 1) / kSdC, 2, (unsigned)nj), dim3(1024), 0, stream, J);
-  }
-  for (size_t i0 = 0; i0 < d.cen.size(); i0 += kCen) {
-    const size_t nj = std::min(d.cen.size() - i0, kCen);
-    CentreJobs J{}; size_t emax = 0;
-    for (size_t i = 0; i < nj; ++i) { J.j[i] = d.cen[i0 + i]; emax = std::max(emax, (size_t)d.cen[i0 + i].C * d.cen[i0 + i].C); }
-    hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)nj), dim3(256), 0, stream, J);
+  // gathers and Gram centrings in one launch where both exist (chunk by chunk; whatever is left of either goes alone)
+  {
+    size_t is = 0, ic = 0;
+    while (is < d.sp.size() || ic < d.cen.size()) {
+      const size_t ns = std::min(d.sp.size() - is, kSp), nc = std::min(d.cen.size() - ic, kCen);
+      SparseDwJobs J{}; CentreJobs Cj{}; int cmax = 0; size_t emax = 0;
+      for (size_t i = 0; i < ns; ++i) { J.j[i] = d.sp[is + i]; cmax = std::max(cmax, d.sp[is + i].C3); }
+      for (size_t i = 0; i < nc; ++i) { Cj.j[i] = d.cen[ic + i]; emax = std::max(emax, (size_t)d.cen[ic + i].C * d.cen[ic + i].C); }
+      if (ns) {
+        const unsigned gx = (unsigned)std::max<size_t>((cmax + kSdC - 1) / kSdC, (emax + 1023) / 1024);
+        hipLaunchKernelGGL(sparse_dw_jobs_kernel, dim3(gx, 2, (unsigned)(ns + nc)), dim3(1024), 0, stream, J, (int)ns, Cj);
+      } else
+        hipLaunchKernelGGL(centre_gram_jobs_kernel, dim3((unsigned)((emax + 255) / 256), 2, (unsigned)nc), dim3(256), 0, stream, Cj);
+      is += ns; ic += nc;
+    }
   }
   // the throughput-shaped products on 64 x 64 tiles (gemm_tile64_jobs), the rest on the K-split tiles; tiles numbered job after job
   for (int big = 1; big >= 0; --big) {

@@ -1196,11 +1196,15 @@ __global__ __launch_bounds__(1024) void stat_finish_reduce_kernel(const StatFini
 }
 
 // centred Gram: G[t][i][j] -= s[t][i]*s[t][j]/M ; m[t][i] = s[t][i]/M
+__device__ __forceinline__ void centre_gram_elem(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m, long e, int t);
 __device__ __forceinline__ void centre_gram_body(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m, unsigned bx, int t)
+{
+  centre_gram_elem(G, s, C, M, m, bx * 256L + threadIdx.x, t);
+}
+__device__ __forceinline__ void centre_gram_elem(float* __restrict__ G, const float* __restrict__ s, int C, double M, float* __restrict__ m, long e, int t)
 {
   // Only the 32 x 32 blocks on or above the block diagonal are read (the bf16 forward accumulates just those); each of
   // their elements is centred and mirrored into the block below the diagonal by the same thread.
-  const long e = bx * 256L + threadIdx.x;
   if (e >= (long)C * C) return;
   const int i = e / C, j = e % C;
   if (j == 0) m[t * C + i] = (float)((double)s[t * C + i] / M);
@@ -1721,8 +1725,17 @@ __global__ __launch_bounds__(1024) void sparse_dw_kernel(const float* __restrict
 // the three stages' Sp in one launch (the weight gradients wait for nothing but the optimiser): grid (max ceil(C3 / kSdC), 2, jobs), block kSdC * C2
 struct SparseDwJob { const float* gs; const int* idx; const float* h2; int B, N, C2, C3; float* Sp; int h2_bf16; };
 struct SparseDwJobs { SparseDwJob j[3]; };
-__global__ __launch_bounds__(1024) void sparse_dw_jobs_kernel(const SparseDwJobs jobs)
+struct CentreJob { float* G; const float* s; int C; double M; float* m; };
+struct CentreJobs { CentreJob j[3]; };
+// (+ the centring of the reduced Grams as further z planes of the same grid: they depend on the reductions only, like the gathers, and were a
+//  5 us launch of their own between them and the products)
+__global__ __launch_bounds__(1024) void sparse_dw_jobs_kernel(const SparseDwJobs jobs, int nsp, const CentreJobs cen)
 {
+  if ((int)blockIdx.z >= nsp) {
+    const CentreJob& c = cen.j[blockIdx.z - nsp];
+    if (c.G) centre_gram_elem(c.G, c.s, c.C, c.M, c.m, blockIdx.x * 1024L + threadIdx.x, blockIdx.y);
+    return;
+  }
   const SparseDwJob& q = jobs.j[blockIdx.z];
   if (!q.gs || (int)blockIdx.x * kSdC >= q.C3) return;
   sparse_dw_any(q.gs, q.idx, q.h2, q.B, q.N, q.C2, q.C3, q.Sp, q.h2_bf16, blockIdx.x, blockIdx.y);
@@ -1786,8 +1799,6 @@ __global__ __launch_bounds__(256) void combine_scale_kernel(const float* __restr
 // The elementwise tails of the deferred weight-gradient work, all layers of the step in one launch each:
 //   centre jobs: G <- G - s s^T / M (+ mirror), m = s / M            grid (max ceil(C^2 / 256), 2 towers, jobs)
 //   combine jobs: dW = sum_t (Sp spscale - m kdb^T + GW diag(E))      grid (max ceil(R C / 256), 1, jobs)
-struct CentreJob { float* G; const float* s; int C; double M; float* m; };
-struct CentreJobs { CentreJob j[3]; };
 __global__ __launch_bounds__(256) void centre_gram_jobs_kernel(const CentreJobs jobs)
 {
   const CentreJob& q = jobs.j[blockIdx.z];
