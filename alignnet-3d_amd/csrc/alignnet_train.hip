@@ -106,6 +106,7 @@ struct TrainWS {
   float* head_din[3];            // gradient wrt the head input (= dP of the stage)
   // transient backward buffers (shared by the stages)
   double* stat_part; float* gram_part; double* colsum_part;
+  bool moments_done[3] = {false, false, false};   // stage s's moments / phase-1 partials were formed by the kernel that wrote its frame (MomentsTail)
   float *dy2, *dy1;
   int* nn;                       // DGCNN: [2B][N][20] neighbour indices
   double* pdy_part;              // DGCNN: [2B][4][7][C1]
@@ -571,6 +572,18 @@ static int flush_deferred(alignnet_handle* h, hipStream_t stream)
   return 0;
 }
 
+// stage s is a specialised PointNet stage: its first layer's statistics come from the cloud's moments (backbone_fwd_train's last branch), which the
+// kernel writing the stage's frame can form right away
+static MomentsTail moments_tail_of(alignnet_handle* h, int s)
+{
+  MomentsTail mt;
+  if (h->cfg.backbone != 0 || stage_generic(h, s) || (h->ab & AB_NO_GLUE_FOLD)) return mt;
+  TrainWS* w = tws(h);
+  const Layer& L0 = h->layers[conv_of(h, s).first];
+  mt.mom = w->st[s].mom; mt.w1 = P(h, L0.p_w); mt.b1 = P(h, L0.p_b); mt.C1 = L0.cout; mt.stat_part = w->stat_part;
+  return mt;
+}
+
 // the step's weight images: queued into `start` (train_start_kernel launches them with the centroids) or, start == nullptr, launched here
 struct StartJobs { const PackJob* f32 = nullptr; int nf32 = 0; PackBf16Jobs pj{}; int nbf16 = 0; };
 static int pack_all_weights(alignnet_handle* h, StartJobs* start = nullptr)
@@ -997,7 +1010,9 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
-  hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
+  if (!w->moments_done[s])
+    hipLaunchKernelGGL(pn_moments_kernel, dim3(2 * B), dim3(256), 0, h->stream, p1, p2, S.xform, B, N, S.mom, a.w1, a.b1, C1, w->stat_part);
+  w->moments_done[s] = false;
   if (finish(0, C1, 1, count)) return 1;
   a.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
   const int CT1f = (C1 + 31) / 32, CT2f = (C2 + 31) / 32;
@@ -1582,8 +1597,10 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   {
     StartJobs sj;
     if (pack_all_weights(h, &sj)) return 1;
+    const MomentsTail mt = moments_tail_of(h, 0);
     hipLaunchKernelGGL(train_start_kernel, dim3(B2 + sj.nf32 * kStartF32Blocks + sj.nbf16 * kStartBf16Blocks), dim3(256), 0, h->stream, p1, p2, B, N,
-                       w->st[0].xform, w->center_mean, sj.f32, sj.nf32, sj.pj, sj.nbf16);
+                       w->st[0].xform, w->center_mean, sj.f32, sj.nf32, sj.pj, sj.nbf16, mt);
+    w->moments_done[0] = mt.mom != nullptr;
   }
   if (h->cfg.backbone == 1) {   // static kNN graph, once per cloud in the mean-centred frame (as the eval path: alignnet_api.hip)
     ProfScope prof_scope(h, PK_KNN, true);
@@ -1593,11 +1610,21 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   // stage 1
   if (backbone_fwd_train(h, 0, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 0, w->st[0].pooled, w->st[0].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
+  if (const MomentsTail mt = moments_tail_of(h, 1); mt.mom) {
+    hipLaunchKernelGGL(stage1_finish_moments_kernel, dim3(B2), dim3(256), 0, h->stream, w->o[0], w->center_mean, B, N, w->s1c, w->st[1].xform, w->outs[2],
+                       w->outs[3], p1, p2, mt);
+    w->moments_done[1] = true;
+  } else
   hipLaunchKernelGGL(stage1_finish_kernel, dim3((B2 + 127) / 128), dim3(128), 0, h->stream, w->o[0], w->center_mean, B, w->s1c,
                      w->st[1].xform, w->outs[2], w->outs[3]);
   // stage 2
   if (backbone_fwd_train(h, 1, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 1, w->st[1].pooled, w->st[1].row_stride, B2, B, bn_decay, update_ema, u_dev)) return 1;
+  if (const MomentsTail mt = moments_tail_of(h, 2); mt.mom) {
+    hipLaunchKernelGGL(stage2_finish_moments_kernel, dim3(B2), dim3(256), 0, h->stream, w->o[1], 3 + nb2, w->s1c, B, N, nb, w->s2c, w->st[2].xform, w->theta,
+                       w->cls, w->outs[4], w->outs[5], w->outs[6], w->outs[7], p1, p2, mt);
+    w->moments_done[2] = true;
+  } else
   hipLaunchKernelGGL(stage2_finish_kernel, dim3((B2 + 3) / 4), dim3(256), 0, h->stream, w->o[1], 3 + nb2, w->s1c, B, nb, w->s2c,
                      w->st[2].xform, w->theta, w->cls, w->outs[4], w->outs[5], w->outs[6], w->outs[7]);
   // stage 3

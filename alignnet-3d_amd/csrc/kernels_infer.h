@@ -666,12 +666,10 @@ __device__ __forceinline__ float floor_modf(float x, float y)   // tf.mod
 }
 
 // models/tp8.py:109: s1 = head + center_mean; next frame = (s1, I)
-static __global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
-                                     float* __restrict__ s1c, float* __restrict__ xform,
-                                     float* __restrict__ out_c1, float* __restrict__ out_c2)
+__device__ __forceinline__ void stage1_finish_cloud(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
+                                                    float* __restrict__ s1c, float* __restrict__ xform,
+                                                    float* __restrict__ out_c1, float* __restrict__ out_c2, int cloud)   // one thread
 {
-  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cloud >= 2 * B) return;
   const int tower = cloud >= B, b = cloud - tower * B;
   float* oc = tower ? out_c2 : out_c1;
   for (int d = 0; d < 3; ++d) {
@@ -682,18 +680,21 @@ static __global__ void stage1_finish_kernel(const float* __restrict__ o1, const 
   }
   for (int i = 0; i < 9; ++i) xform[cloud * 12 + 3 + i] = (i % 4 == 0) ? 1.f : 0.f;
 }
+static __global__ void stage1_finish_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B,
+                                     float* __restrict__ s1c, float* __restrict__ xform,
+                                     float* __restrict__ out_c1, float* __restrict__ out_c2)
+{
+  const int cloud = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloud < 2 * B) stage1_finish_cloud(o1, center_mean, B, s1c, xform, out_c1, out_c2, cloud);
+}
 
 // models/tp8.py:117-125 + :294-301,202-212: s2 centre, logits, in-graph yaw decode,
 // R = rot_z(-theta) (tp8.py:26-27), next frame = (s2, R).  One wave per cloud (block = 256 threads = 4 clouds).
-static __global__ __launch_bounds__(256) void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
-                                     float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
-                                     int* __restrict__ cls_out,
-                                     float* __restrict__ out_c1, float* __restrict__ out_c2,
-                                     float* __restrict__ out_l1, float* __restrict__ out_l2)
+__device__ __forceinline__ void stage2_finish_cloud(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
+                                                    float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
+                                                    int* __restrict__ cls_out, float* __restrict__ out_c1, float* __restrict__ out_c2,
+                                                    float* __restrict__ out_l1, float* __restrict__ out_l2, int cloud, int lane)   // one wave
 {
-  const int lane = threadIdx.x & 63;
-  const int cloud = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (cloud >= 2 * B) return;
   const int tower = cloud >= B, b = cloud - tower * B;
   const float* o = o2 + (size_t)cloud * ldo;
   float* oc = tower ? out_c2 : out_c1;
@@ -729,6 +730,15 @@ static __global__ __launch_bounds__(256) void stage2_finish_kernel(const float* 
     R[3] = sn; R[4] = c;  R[5] = 0.f;
     R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
   }
+}
+static __global__ __launch_bounds__(256) void stage2_finish_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int nb,
+                                     float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
+                                     int* __restrict__ cls_out,
+                                     float* __restrict__ out_c1, float* __restrict__ out_c2,
+                                     float* __restrict__ out_l1, float* __restrict__ out_l2)
+{
+  const int cloud = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cloud < 2 * B) stage2_finish_cloud(o2, ldo, s1c, B, nb, s2c, xform, theta_out, cls_out, out_c1, out_c2, out_l1, out_l2, cloud, threadIdx.x & 63);
 }
 
 // models/tp8.py:155-156 (one thread per output element)

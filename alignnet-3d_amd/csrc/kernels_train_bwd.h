@@ -788,19 +788,6 @@ __device__ __forceinline__ void pack_bf16_jobs_body(const PackBf16Jobs& j, unsig
   }
 }
 __global__ __launch_bounds__(256) void pack_bf16_jobs_kernel(const PackBf16Jobs j) { pack_bf16_jobs_body(j, blockIdx.x, blockIdx.y, gridDim.x); }
-// The first launch of a training step: the clouds' centroids (frame of stage 1) and, as further blocks of the same grid, the step's weight images --
-// the fp32 MFMA images of the conv layers and / or the bf16 images; nothing in one part reads what another writes.  (Three launches before: 6 us each.)
-constexpr int kStartF32Blocks = 256, kStartBf16Blocks = 128;   // blocks per image (<= 2 / 4 elements per thread)
-__global__ __launch_bounds__(256) void train_start_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2, int B, int N, float* __restrict__ xform,
-                                                          float* __restrict__ center_mean, const PackJob* __restrict__ f32jobs, int nf32, const PackBf16Jobs pj, int nbf16)
-{
-  int bx = blockIdx.x;
-  if (bx < 2 * B) { centroid_body(pcs1, pcs2, B, N, xform, center_mean, nullptr, 0, bx, 2 * B); return; }
-  bx -= 2 * B;
-  if (bx < nf32 * kStartF32Blocks) { pack_weights_multi_body(f32jobs, bx % kStartF32Blocks, bx / kStartF32Blocks, kStartF32Blocks); return; }
-  bx -= nf32 * kStartF32Blocks;
-  if (bx < nbf16 * kStartBf16Blocks) pack_bf16_jobs_body(pj, bx % kStartBf16Blocks, bx / kStartBf16Blocks, kStartBf16Blocks);
-}
 
 struct BwdB1hArgs {
   const float* pcs[2]; const float* xform; int B, N;

@@ -1343,14 +1343,14 @@ __global__ __launch_bounds__(128) void dg_b0_cloud(const DgB0Args a)   // grid 2
 // first and second moments of the stage-frame points x' of every cloud (the D = 3 input of the two kernels above), fp64.  grid 2B
 // With w1 / b1 / stat_part given it is also phase 1 of the PointNet forward: z1 = x' W1 + b1 is linear in x', so the per-channel
 // sum and sum of squares of z1 over the cloud follow from the nine moments (as dg_train_phase1 does for the edge layer).
-__global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
-                                                         const float* __restrict__ xform, int B, int N, double* __restrict__ mom,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1, int C1,
-                                                         double* __restrict__ stat_part)
+__device__ __forceinline__ void pn_moments_body(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                const float* __restrict__ xform, int B, int N, double* __restrict__ mom,
+                                                const float* __restrict__ w1, const float* __restrict__ b1, int C1,
+                                                double* __restrict__ stat_part, int cloud)   // 256 threads
 {
   __shared__ double red[4][9];
   __shared__ double tot[9];
-  const int cloud = blockIdx.x, tower = cloud >= B, b = cloud - tower * B, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tower = cloud >= B, b = cloud - tower * B, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* pc = (tower ? pcs2 : pcs1) + (size_t)b * N * 3;
   const float* xf = xform + (size_t)cloud * 12;
   double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1395,6 +1395,59 @@ __global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict
     stat_part[((size_t)cloud * C1 + c) * 2] = sw + n * bb;
     stat_part[((size_t)cloud * C1 + c) * 2 + 1] = qd + 2.0 * bb * sw + n * bb * bb;
   }
+}
+__global__ __launch_bounds__(256) void pn_moments_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                         const float* __restrict__ xform, int B, int N, double* __restrict__ mom,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int C1,
+                                                         double* __restrict__ stat_part)
+{
+  pn_moments_body(pcs1, pcs2, xform, B, N, mom, w1, b1, C1, stat_part, blockIdx.x);
+}
+
+// The moments of a stage's frame need nothing but that frame, and a frame is produced per cloud: the kernel that writes cloud c's frame -- the
+// start kernel (centroid), the stage-1 / stage-2 glue -- goes straight on to cloud c's moments (one workgroup per cloud, 256 threads), instead of a
+// launch of its own per stage.  mom == nullptr: no tail (the stage is not a specialised PointNet stage).
+struct MomentsTail { double* mom = nullptr; const float* w1 = nullptr; const float* b1 = nullptr; int C1 = 0; double* stat_part = nullptr; };
+__device__ __forceinline__ void moments_tail(const MomentsTail& mt, const float* pcs1, const float* pcs2, const float* xform, int B, int N, int cloud)
+{
+  if (!mt.mom) return;
+  __syncthreads();   // the frame just written by this workgroup (workgroup-scope release / acquire: it is read through the CU's own L1 / L2 path)
+  pn_moments_body(pcs1, pcs2, xform, B, N, mt.mom, mt.w1, mt.b1, mt.C1, mt.stat_part, cloud);
+}
+// The first launch of a training step: the clouds' centroids (frame of stage 1) and, as further blocks of the same grid, the step's weight images --
+// the fp32 MFMA images of the conv layers and / or the bf16 images; nothing in one part reads what another writes.  (Three launches before: 6 us each.)
+constexpr int kStartF32Blocks = 256, kStartBf16Blocks = 128;   // blocks per image (<= 2 / 4 elements per thread)
+__global__ __launch_bounds__(256) void train_start_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2, int B, int N, float* __restrict__ xform,
+                                                          float* __restrict__ center_mean, const PackJob* __restrict__ f32jobs, int nf32, const PackBf16Jobs pj, int nbf16,
+                                                          const MomentsTail mt)
+{
+  int bx = blockIdx.x;
+  if (bx < 2 * B) { centroid_body(pcs1, pcs2, B, N, xform, center_mean, nullptr, 0, bx, 2 * B); moments_tail(mt, pcs1, pcs2, xform, B, N, bx); return; }
+  bx -= 2 * B;
+  if (bx < nf32 * kStartF32Blocks) { pack_weights_multi_body(f32jobs, bx % kStartF32Blocks, bx / kStartF32Blocks, kStartF32Blocks); return; }
+  bx -= nf32 * kStartF32Blocks;
+  if (bx < nbf16 * kStartBf16Blocks) pack_bf16_jobs_body(pj, bx % kStartBf16Blocks, bx / kStartBf16Blocks, kStartBf16Blocks);
+}
+
+// stage-1 / stage-2 glue (kernels_infer.h: stage1_finish_cloud, stage2_finish_cloud) + the next stage's moments, one workgroup per cloud
+__global__ __launch_bounds__(256) void stage1_finish_moments_kernel(const float* __restrict__ o1, const float* __restrict__ center_mean, int B, int N,
+                                                                    float* __restrict__ s1c, float* __restrict__ xform, float* __restrict__ out_c1,
+                                                                    float* __restrict__ out_c2, const float* __restrict__ pcs1, const float* __restrict__ pcs2,
+                                                                    const MomentsTail mt)
+{
+  const int cloud = blockIdx.x;
+  if (threadIdx.x == 0) stage1_finish_cloud(o1, center_mean, B, s1c, xform, out_c1, out_c2, cloud);
+  moments_tail(mt, pcs1, pcs2, xform, B, N, cloud);
+}
+__global__ __launch_bounds__(256) void stage2_finish_moments_kernel(const float* __restrict__ o2, int ldo, const float* __restrict__ s1c, int B, int N, int nb,
+                                                                    float* __restrict__ s2c, float* __restrict__ xform, float* __restrict__ theta_out,
+                                                                    int* __restrict__ cls_out, float* __restrict__ out_c1, float* __restrict__ out_c2,
+                                                                    float* __restrict__ out_l1, float* __restrict__ out_l2, const float* __restrict__ pcs1,
+                                                                    const float* __restrict__ pcs2, const MomentsTail mt)
+{
+  const int cloud = blockIdx.x;
+  if (threadIdx.x < 64) stage2_finish_cloud(o2, ldo, s1c, B, nb, s2c, xform, theta_out, cls_out, out_c1, out_c2, out_l1, out_l2, cloud, threadIdx.x);
+  moments_tail(mt, pcs1, pcs2, xform, B, N, cloud);
 }
 
 }  // namespace alignnet
