@@ -1630,9 +1630,12 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   // stage 3
   if (backbone_fwd_train(h, 2, p1, p2, B, bn_decay, update_ema)) return 1;
   if (head_fwd_train(h, 2, w->st[2].pooled, w->st[2].row_stride, B, B, bn_decay, update_ema, u_dev)) return 1;
-  hipLaunchKernelGGL(final_finish_kernel, dim3((B * (3 + nb2) + 255) / 256), dim3(256), 0, h->stream, w->o[2], 3 + nb2, w->s2c, B, nb, w->outs[0], w->outs[1]);
+  const bool ff_fold = !gloss_on(h) && !(h->ab & AB_NO_GLUE_FOLD);   // (global loss: the loss kernels run on the gathered batch, the glue on this rank's rows)
+  if (!ff_fold)
+    hipLaunchKernelGGL(final_finish_kernel, dim3((B * (3 + nb2) + 255) / 256), dim3(256), 0, h->stream, w->o[2], 3 + nb2, w->s2c, B, nb, w->outs[0], w->outs[1]);
   // loss (+ gradient wrt the end points)
   LossArgs la;
+  if (ff_fold) { la.ff_net = w->o[2]; la.ff_ldn = 3 + nb2; la.ff_s2c = w->s2c; la.ff_B = B; la.ff_out_t = w->outs[0]; la.ff_out_l = w->outs[1]; }
   la.B = B; la.nb = nb; la.esf = h->cfg.early_stage_factor; la.af = h->cfg.angle_factor; la.accept_inverted = h->cfg.accept_inverted_angle;
   la.s1c = w->s1c; la.s2c = w->s2c; la.o2 = w->o[1]; la.ldo2 = 3 + nb2; la.o3 = w->o[2]; la.ldo3 = 3 + nb2; la.theta = w->theta; la.pcls = w->cls;
   la.tr = lab[0]; la.c1 = lab[2]; la.c2 = lab[3]; la.a1 = lab[4]; la.a2 = lab[5];

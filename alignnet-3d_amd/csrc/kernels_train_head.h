@@ -500,6 +500,9 @@ struct LossArgs {
   float* d_o3;                                 // [B][3+2nb]
   float* scratch;                              // >= 8*B floats + 4*B ints worth of space
   int want_grad;
+  // the pair head's output glue (kernels_infer.h: final_finish_kernel -- pred_translations = head[:, :3] + (s2c2 - s2c1), remaining-angle logits), spread over
+  // loss_prep_kernel's threads: elementwise on values the loss reads anyway, a 5 us launch of its own before.  ff_net == nullptr: not folded.
+  const float* ff_net = nullptr; int ff_ldn = 0; const float* ff_s2c = nullptr; int ff_B = 0; float* ff_out_t = nullptr; float* ff_out_l = nullptr;
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red)
@@ -600,6 +603,15 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const LossArgs a, int G
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x;
   const float pi = 3.14159274101257324f, pinb = (float)(3.141592653589793 / (double)nb);
   const LossScratch S = loss_scratch(a.scratch, B, G);
+  if (a.ff_net) {
+    const int w = 3 + 2 * nb;
+    for (int e = blockIdx.x * nt + tid; e < a.ff_B * w; e += gridDim.x * nt) {
+      const int b = e / w, i = e % w;
+      const float v = a.ff_net[(size_t)b * a.ff_ldn + i];
+      if (i < 3) { if (a.ff_out_t) a.ff_out_t[b * 3 + i] = v + (a.ff_s2c[(a.ff_B + b) * 3 + i] - a.ff_s2c[b * 3 + i]); }
+      else if (a.ff_out_l) a.ff_out_l[(size_t)b * 2 * nb + (i - 3)] = v;
+    }
+  }
   if ((int)blockIdx.x > nprep) { loss_pairs_body(a, G, (int)blockIdx.x - nprep - 1, red); return; }
   if ((int)blockIdx.x == nprep) {
     // ---- Huber terms (tp8.py:312-323) ----
