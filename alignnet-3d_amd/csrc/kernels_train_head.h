@@ -735,7 +735,7 @@ __device__ __forceinline__ void loss_pairs_body(const LossArgs& a, int G, int g,
       if ((q & 1) < nvar) S.rlp[(size_t)g * 6 + q] = rlv[q];
 }
 
-constexpr int kLossCols = 8;   // columns j per workgroup of loss_final_kernel
+constexpr int kLossCols = 2;   // columns j per workgroup of loss_final_kernel (with 8 a thread walked four trips of three dependent-latency terms: 16 us)
 
 // grid: ceil(B / kLossCols) workgroups of 256 threads.  Every workgroup repeats the (tiny) reduction of the partials and
 // the tf.cond choice, then writes the angle-term gradients of its own columns; workgroup 0 writes the scalars.
@@ -747,18 +747,37 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, int G
   const int B = a.B, nb = a.nb, tid = threadIdx.x, nt = blockDim.x, ln = tid & 63, wave = tid >> 6;
   const LossScratch S = loss_scratch(a.scratch, B, G);
   const int nvar = a.accept_inverted ? 2 : 1;
-  for (int q = wave; q < 6; q += nt >> 6) {   // one wave per (term, variant): partials summed across the lanes
-    const int term = q / 2, v = q % 2;
-    double rl = 0.0, ce = 0.0;
-    if (v < nvar) {
-      for (int g = ln; g < G; g += 64) rl += S.rlp[((size_t)g * 3 + term) * 2 + v];
-      for (int g = ln; g < nprep; g += 64) ce += S.cep[(size_t)g * 6 + q];
+  // the column sums S_j of BOTH variants are requested before the variant choice is known (behind it they were a round trip of their own):
+  // thread (e = tid >> 2, gq = tid & 3) sums rows gq, gq + 4, ... of column j0 + e % kLossCols for term e / kLossCols
+  float sjv[2] = {0.f, 0.f};
+  if (a.want_grad && tid < 3 * kLossCols * 4) {
+    const int e = tid >> 2, gq = tid & 3, term = e / kLossCols, j = blockIdx.x * kLossCols + e % kLossCols;
+    if (j < B)
+      for (int g = gq; g < G; g += 4) {
+        sjv[0] += S.sjp[(((size_t)g * 3 + term) * 2 + 0) * B + j];
+        if (nvar > 1) sjv[1] += S.sjp[(((size_t)g * 3 + term) * 2 + 1) * B + j];
+      }
+  }
+  {   // one wave per (term, variant), two of them for waves 0 / 1 (256 threads): partials summed across the lanes; both rounds' loads first
+    double rlq[2] = {0.0, 0.0}, ceq[2] = {0.0, 0.0};
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+      const int q = wave + qi * (int)(nt >> 6);
+      if (q < 6 && (q % 2) < nvar) {
+        for (int g = ln; g < G; g += 64) rlq[qi] += S.rlp[((size_t)g * 3 + q / 2) * 2 + q % 2];
+        for (int g = ln; g < nprep; g += 64) ceq[qi] += S.cep[(size_t)g * 6 + q];
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { rl += __shfl_xor(rl, o); ce += __shfl_xor(ce, o); }
-    if (ln == 0 && v < nvar) {
-      const float r = (float)(rl / ((double)B * B)), c = (float)(ce / B);
-      sres[term][v][0] = c + 20.0f * r; sres[term][v][1] = c; sres[term][v][2] = r;
+    for (int qi = 0; qi < 2; ++qi) {
+      const int q = wave + qi * (int)(nt >> 6), term = q / 2, v = q % 2;
+      double rl = rlq[qi], ce = ceq[qi];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { rl += __shfl_xor(rl, o); ce += __shfl_xor(ce, o); }
+      if (q < 6 && ln == 0 && v < nvar) {
+        const float r = (float)(rl / ((double)B * B)), c = (float)(ce / B);
+        sres[term][v][0] = c + 20.0f * r; sres[term][v][1] = c; sres[term][v][2] = r;
+      }
     }
   }
   __syncthreads();
@@ -781,9 +800,8 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, int G
   const int j0 = blockIdx.x * kLossCols;
   if (tid < 3 * kLossCols * 4) {   // S_j = sum over the G row slices; 4 lanes share one sum
     const int e = tid >> 2, gq = tid & 3, term = e / kLossCols, j = j0 + e % kLossCols;
-    float sj = 0.f;
-    if (j < B)
-      for (int g = gq; g < G; g += 4) sj += S.sjp[(((size_t)g * 3 + term) * 2 + schosen[term]) * B + j];
+    float sj = schosen[term] ? sjv[1] : sjv[0];   // (same rows in the same order as before)
+    (void)j; (void)gq;
     sj += __shfl_xor(sj, 1);
     sj += __shfl_xor(sj, 2);
     if (gq == 0) ssj[term][e % kLossCols] = sj;
