@@ -865,7 +865,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (h->ablate_mutation == 3 && s == 1) W = 1.0;   // (mutation: stage 2 divides all ranks' sums by this rank's count)
 #endif
   // global_part: the partials are already sums over all ranks (statistics derived from all-reduced Gram / column sums)
-  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, bool global_part = false) -> int {
+  auto fin_args = [&](int l, int C, int slices, double cnt, int nb = -1) -> StatFinishArgs {
     StatFinishArgs f;
     f.part = w->stat_part; f.B = nb < 0 ? B : nb; f.C = C; f.slices = slices; f.count = cnt * W; f.bias = P(h, L[l]->p_b);
     for (int t = 0; t < 2; ++t) {
@@ -877,6 +877,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     f.sgn = nullptr; f.next_gamma[0] = f.next_gamma[1] = nullptr;
     if (l == 1) { f.sgn = S.sgn3; f.next_gamma[0] = P(h, L[2]->p_bn[0][1]); f.next_gamma[1] = P(h, L[2]->p_bn[1][1]); f.next_C = C3; }
     f.rstd = S.rstd[l]; f.k = S.kk[l];
+    return f;
+  };
+  auto finish = [&](int l, int C, int slices, double cnt, int nb = -1, bool global_part = false) -> int {
+    StatFinishArgs f = fin_args(l, C, slices, cnt, nb);
     const dim3 grid((C + kSfC - 1) / kSfC, 2);
     if (sync && !global_part) {   // this rank's (sum, sum of squares) -> all ranks' -> finish
       f.totals_out = h->sync_buf;
@@ -1030,9 +1034,15 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const int sG1 = std::max(1, 256 / C1);
     launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
     if (sync && (sync_sum2(h, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1))) return 1;
+    // (statistics from the Gram and their finish in one launch; ab_phase2_legacy keeps the pass, ab_no_glue_fold the two launches)
+    if (!(h->ab & AB_NO_GLUE_FOLD))
+      hipLaunchKernelGGL(stat2_from_gram_finish_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
+                         h->train_bf16 ? 1 : 0, fin_args(1, C2, 1, count, 1));
+    else {
     hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
                        h->train_bf16 ? 1 : 0, w->stat_part);
     if (finish(1, C2, 1, count, 1, true)) return 1;
+    }
   } else {
   { ProfScope prof_scope(h, PK_TRAIN_PHASE2, true);
   if (h->train_bf16 && std_w) TIMED_LAUNCH((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);

@@ -826,12 +826,12 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
 
 // (sum z2, sum z2^2) per tower and channel from the reduced s1 [2][C1] and G1 [2][C1*C1] (upper 32 x 32 blocks valid), fp64.
 // round_w: the hidden layer runs on bf16 operands -- W2 as rounded.  grid (C2, 2), block 256.  out: [2][C2][2] doubles.
-__global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
-                                                              const float* __restrict__ b2, int C1, int C2, double M, int round_w,
-                                                              double* __restrict__ out)
+// (thread 0 returns true with the channel's (sum z2, sum z2^2) in *o0 / *o1)
+__device__ __forceinline__ bool stat2_from_gram_body(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+                                                     const float* __restrict__ b2, int C1, int C2, double M, int round_w, int c, int t, double* o0, double* o1)
 {
   __shared__ double red[4][2];
-  const int c = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   auto wv = [&](int i) { const float w = W2[(size_t)i * C2 + c]; return (double)(round_w ? __uint_as_float((unsigned)to_bf16_bits(w) << 16) : w); };
   const float* G = G1 + (size_t)t * C1 * C1;
   double q = 0.0, sw = 0.0;
@@ -847,8 +847,20 @@ __global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __res
   __syncthreads();
   if (tid == 0) {
     const double Q = red[0][0] + red[1][0] + red[2][0] + red[3][0], S = red[0][1] + red[1][1] + red[2][1] + red[3][1], bb = (double)b2[c];
-    out[((size_t)t * C2 + c) * 2] = S + M * bb;
-    out[((size_t)t * C2 + c) * 2 + 1] = Q + 2.0 * bb * S + M * bb * bb;
+    *o0 = S + M * bb;
+    *o1 = Q + 2.0 * bb * S + M * bb * bb;
+    return true;
+  }
+  return false;
+}
+__global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+                                                              const float* __restrict__ b2, int C1, int C2, double M, int round_w,
+                                                              double* __restrict__ out)
+{
+  double v0, v1;
+  if (stat2_from_gram_body(G1, s1, W2, b2, C1, C2, M, round_w, blockIdx.x, blockIdx.y, &v0, &v1)) {
+    out[((size_t)blockIdx.y * C2 + blockIdx.x) * 2] = v0;
+    out[((size_t)blockIdx.y * C2 + blockIdx.x) * 2 + 1] = v1;
   }
 }
 
@@ -999,6 +1011,32 @@ __device__ __forceinline__ void stat_finish_body(const StatFinishArgs& a, int bx
   }
 }
 __global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs a) { stat_finish_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
+
+// The hidden layer's statistics from Gram(h1) AND their finish in one launch (fp32 training; they were stat2_from_gram_kernel + stat_finish_kernel on a
+// [2][C2][2] "partial" table: a launch whose 16 workgroups each read two doubles per channel).  grid (C2, 2), block 256; f.part / B / slices unused.
+__global__ __launch_bounds__(256) void stat2_from_gram_finish_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+                                                                     const float* __restrict__ b2, int C1, int C2, double M, int round_w, const StatFinishArgs a)
+{
+  const int c = blockIdx.x, t = blockIdx.y;
+  if (a.sgn)   // sign(gamma) of the next layer, spread over this launch's threads
+    for (int i = c * 256 + threadIdx.x; i < a.next_C; i += C2 * 256) a.sgn[t * a.next_C + i] = a.next_gamma[t][i] >= 0.f ? 1.f : -1.f;
+  double s, ss;
+  if (!stat2_from_gram_body(G1, s1, W2, b2, C1, C2, M, round_w, c, t, &s, &ss)) return;
+  const double mean = s / a.count;
+  const double var = fmax(ss / a.count - mean * mean, 0.0);
+  const float mf = (float)mean, vf = (float)var;
+  a.mean[t * a.C + c] = mf;
+  a.var[t * a.C + c] = vf;
+  const float inv = a.gamma[t][c] * (1.0f / sqrtf(vf + kBnEps));
+  a.scale[t * a.C + c] = inv;
+  a.shift[t * a.C + c] = (a.bias[c] - mf) * inv + a.beta[t][c];
+  a.rstd[t * a.C + c] = 1.0f / sqrtf(vf + kBnEps);
+  a.k[t * a.C + c] = inv;
+  if (a.update_ema) {
+    a.mov_mean[t][c] -= (1.f - a.bn_decay) * (a.mov_mean[t][c] - mf);
+    a.mov_var[t][c] -= (1.f - a.bn_decay) * (a.mov_var[t][c] - vf);
+  }
+}
 
 __global__ void sign_kernel(const float* __restrict__ gamma, int C, float* __restrict__ sgn)
 {
