@@ -398,6 +398,24 @@ class Engine:
         self._check(self._lib.alignnet_debug_knn_graph(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
         return a
 
+    def debug_train_decisions(self, B):
+        """What the last training forward (of B pairs) decided -- the graph's discontinuous choices, for decision-pinned parity tests
+        (include/alignnet_hip.h: alignnet_debug_train_decisions).  dict: "yaw" int32 [2, B]; "pool" list over the three stages of
+        [2, B, C_last]; dgcnn engines also "slot" list of [2, B, N, C_edge] and "knn" [2, B, N, 20].  Tower outermost."""
+        o, n = self.cfg["model"]["options"], self.num_points
+        convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+
+        def get(kind, stage, shape):
+            a = np.empty(shape, np.int32)
+            self._check(self._lib.alignnet_debug_train_decisions(self._h, kind, stage, ip(a), a.size))
+            return a
+        out = {"yaw": get(0, 0, (2, B)), "pool": [get(1, s, (2, B, convs[s][-1])) for s in range(3)]}
+        if self.cfg["model"]["backbone"] == "dgcnn":
+            out["slot"] = [get(2, s, (2, B, n, convs[s][-2])) for s in range(3)]
+            out["knn"] = get(3, 0, (2, B, n, 20))
+        return out
+
     def grad_buffer(self):
         ptr, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.alignnet_grad_buffer(self._h, C.byref(ptr), C.byref(n)))

@@ -1588,6 +1588,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   const float bn_decay = stt.bn_decay;
   if (set_lds_attrs(h)) return 1;
   h->sync_collectives = 0;
+  h->last_train_B = B;
   if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;   // (as the eval forward does: ~15 event pairs per profiled step)
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
@@ -2046,6 +2047,50 @@ extern "C" int alignnet_get_grad(alignnet_handle* h, const char* name, float* ds
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(dst, w->grad + p.offset, count * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
+}
+
+// test hook (include/alignnet_hip.h): the discontinuous choices of the last training forward -- decoded yaw classes, the max-pool's
+// arg-max points, the dgcnn branch's arg-max neighbour slots and the neighbour table itself -- read back from the workspace
+extern "C" int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, int32_t stage, int32_t* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!dst) return fail(h, "alignnet_debug_train_decisions: null argument");
+  TrainWS* w = static_cast<TrainWS*>(h->train_ws);
+  const int B = h->last_train_B, N = h->cfg.num_points;
+  if (!w || !w->base || B < 1) return fail(h, "alignnet_debug_train_decisions: no training forward has run on this handle");
+  const bool dg = h->cfg.backbone == 1;
+  const size_t B2 = 2 * (size_t)B;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  auto copy_i32 = [&](const int* src, size_t n) -> int {
+    if (count != n) return fail(h, "alignnet_debug_train_decisions: count does not match the requested array (" + std::to_string(n) + " elements)");
+    HIP_TRY(h, hipMemcpy(dst, src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+  };
+  if (kind == ALIGNNET_DECISION_YAW_CLASS) return copy_i32(w->cls, B2);
+  if (kind == ALIGNNET_DECISION_KNN_GRAPH) {
+    if (!dg) return fail(h, "alignnet_debug_train_decisions: the neighbour table exists for the dgcnn backbone only");
+    return copy_i32(w->nn, B2 * N * kDgK);
+  }
+  if (stage < 0 || stage > 2) return fail(h, "alignnet_debug_train_decisions: stage must be 0, 1 or 2");
+  const Stack& st = conv_of(h, stage);
+  const bool gen = stage_generic(h, stage), hyb = stage_hybrid(h, stage);
+  if (kind == ALIGNNET_DECISION_POOL_POINT) {
+    const int Cl = h->layers[st.first + st.n - 1].cout;
+    return copy_i32((gen && !hyb) ? w->gen[stage].idx : w->st[stage].idx, B2 * Cl);
+  }
+  if (kind == ALIGNNET_DECISION_EDGE_SLOT) {
+    if (!dg) return fail(h, "alignnet_debug_train_decisions: neighbour slots exist for the dgcnn backbone only");
+    const int Ce = h->layers[st.first + st.n - 2].cout;   // width of the last edge conv = input width of the point conv
+    const size_t n = B2 * N * Ce;
+    if (gen) return copy_i32(w->gen[stage].argk, n);
+    if (count != n) return fail(h, "alignnet_debug_train_decisions: count does not match the requested array (" + std::to_string(n) + " elements)");
+    std::vector<unsigned char> bytes(n);   // the fused edge kernels keep one byte per (point, channel)
+    HIP_TRY(h, hipMemcpy(bytes.data(), w->st[stage].argk, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[i] = bytes[i];
+    return 0;
+  }
+  return fail(h, "alignnet_debug_train_decisions: unknown kind");
 }
 
 // ---------------------------------------------------------------------------------

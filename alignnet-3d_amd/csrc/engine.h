@@ -115,6 +115,7 @@ struct alignnet_handle {
   int64_t adam_power_t = 0;
   int last_B = 0;
   int last_kernel = 0;             // which backbone instantiation the last eval forward launched (alignnet_get_option "last_backbone_kernel")
+  int last_train_B = 0;            // pairs of the last training forward (alignnet_debug_train_decisions)
   int last_train_kernel = 0;       // same for the training step: bit 0 = compile-time widths (64, 128), bit 1 = bf16 operands, bit 2 = dgcnn, bit 3 = general depth, bit 4 = fused tail
   // profiling
   bool prof = false;

@@ -188,6 +188,20 @@ int alignnet_debug_dropout_uniforms(alignnet_handle* h, int32_t B, float* dst, s
  * has <= 64 survivors (the usual case); queries with more survivors (clustered / duplicated points) emit their k entries in
  * point-index order -- the max over the k neighbours is order-invariant, so compare rows as sets (sorted) where that can occur. */
 int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
+/* Test hook: what the last TRAINING forward on this handle DECIDED -- the discontinuous choices of the graph.  A parity test pins
+ * the oracle to them (after checking that each one is a maximum of the oracle's own values to within rounding), so that the rest of
+ * the comparison is continuous (tests/test_fullsize_gpu.py, oracle/alignnet_torch.py `pinned`).  All int32, towers outermost
+ * (tower 1's B clouds, then tower 2's), B = the batch of that call:
+ *   ALIGNNET_DECISION_YAW_CLASS   (stage ignored)  [2][B]              decoded yaw class, models/tp8.py:296
+ *   ALIGNNET_DECISION_POOL_POINT  stage 0..2       [2][B][C_last]      arg-max point of the max over points, utils/tf_util.py:350-373 / models/tp8.py:58
+ *   ALIGNNET_DECISION_EDGE_SLOT   stage 0..2, dgcnn [2][B][N][C_edge]  arg-max neighbour slot of the max over k, models/tp8.py:42
+ *   ALIGNNET_DECISION_KNN_GRAPH   (stage ignored), dgcnn [2][B][N][20] the neighbour table the step used (slot = position in the row)
+ * count must equal the element count of the requested array. */
+#define ALIGNNET_DECISION_YAW_CLASS 0
+#define ALIGNNET_DECISION_POOL_POINT 1
+#define ALIGNNET_DECISION_EDGE_SLOT 2
+#define ALIGNNET_DECISION_KNN_GRAPH 3
+int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, int32_t stage, int32_t* dst, size_t count);
 
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
  *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */

@@ -37,8 +37,24 @@ def to_torch(P: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False)
 class TorchTp8:
     """Eager re-statement; `P` is a name->tensor dict using the oracle's names."""
 
-    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False, checkpoint: bool = False, sync=None):
+    STAGES = {"transformer1/embedding": 0, "transformer2/embedding": 1, "embedding": 2}
+
+    def __init__(self, spec: NetSpec, P: Dict[str, torch.Tensor], bf16_lift: bool = False, checkpoint: bool = False, sync=None, pinned=None):
         self.spec, self.P = spec, P
+        # pinned: the DECISIONS of another evaluation of the same step (the HIP engine's, alignnet_debug_train_decisions) -- dict with
+        # "yaw" [2, B] decoded classes (models/tp8.py:296), "pool" three arrays [2, B, C_last] of arg-max points (utils/tf_util.py:350-373,
+        # models/tp8.py:58), and for dgcnn "slot" three arrays [2, B, N, C_edge] of arg-max neighbour slots (models/tp8.py:42) and "knn"
+        # [2, B, N, k] the neighbour table (utils/tf_util_dgcnn.py:638-676).  The oracle then GATHERS at those indices instead of
+        # max / argmax / top_k, which makes the rest of the graph continuous in its inputs: a comparison of two evaluations no longer
+        # sits on the noise floor of re-decided near-ties.  Each pinned decision is first checked against the oracle's own values:
+        # pin_report collects (what, worst gap between the true extreme and the value at the pinned index, scale of the values,
+        # number of entries whose index differs from the oracle's own first maximum) -- the caller asserts that the gaps are rounding.
+        self.pinned = pinned
+        self.pin_report = []
+        # record_decisions = True: the unpinned evaluation writes its own choices into self.decisions in the layout of `pinned`
+        # (tests/test_oracle.py: pinning the oracle to its own decisions must change nothing)
+        self.record_decisions = False
+        self.decisions = {"yaw": [None, None], "pool": [[None, None] for _ in range(3)], "slot": [[None, None] for _ in range(3)], "knn": [None, None]}
         # sync: data-parallel protocol of the engine's "sync_bn" / "global_loss" options restated (tests/test_parallel_cpu.py): an object with
         # .world, .rank, .allreduce(t) (differentiable sum over the ranks) and .gather(t) (list of every rank's tensor, no gradient).
         # BatchNorm moments are then those of the global batch; loss_global() evaluates the loss on the gathered batch, with the
@@ -113,7 +129,29 @@ class TorchTp8:
         for i in range(len(widths)):
             nm = f"{scope}/conv{i+1}"
             h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay, round_operands=i in rounded)
-        return h.reshape(B, N, -1).amax(dim=1)
+        return self._max_over(h.reshape(B, N, -1), "pool", scope, tower)
+
+    def _pin(self, kind, scope, tower):
+        if self.pinned is None or kind not in self.pinned:
+            return None
+        a = self.pinned[kind]
+        a = a[self.STAGES[scope]] if scope is not None else a
+        return torch.as_tensor(np.asarray(a[tower]), dtype=torch.long)
+
+    def _max_over(self, hh, kind, scope, tower):
+        """max over dim 1 of hh [R, n, C] (utils/tf_util.py:350-373) -- or, pinned, the gather at the given winners [R, C]."""
+        idx = self._pin(kind, scope, tower)
+        if idx is None:
+            if self.record_decisions:
+                with torch.no_grad():
+                    self.decisions[kind][self.STAGES[scope]][tower] = hh.argmax(dim=1).numpy()
+            return hh.amax(dim=1)
+        idx = idx.reshape(hh.shape[0], hh.shape[2])
+        out = hh.gather(1, idx[:, None, :])[:, 0]
+        with torch.no_grad():
+            top, own = hh.max(dim=1)
+            self.pin_report.append((f"{kind}:{scope}:{tower}", float((top - out).max()), float(top.abs().max()), int((own != idx).sum()), idx.numel()))
+        return out
 
     def _dgcnn(self, x, scope, widths, tower, training, decay):
         B, N, D = x.shape
@@ -122,6 +160,18 @@ class TorchTp8:
             xx = (x * x).sum(-1, keepdim=True)
             adj = xx - 2 * x @ x.transpose(1, 2) + xx.transpose(1, 2)
             idx = torch.sort(adj, dim=-1, stable=True).indices[..., :k]
+            pin = self._pin("knn", None, tower)
+            if pin is not None:
+                # the pinned table must be a k-nearest SET of every query up to rounding of the distances: its farthest member may not be
+                # farther than the true k-th distance by more than the reported gap (scale: the largest k-th distance)
+                kth = torch.sort(adj, dim=-1).values[..., k - 1]
+                far = adj.gather(2, pin).amax(-1)
+                self.pin_report.append((f"knn:{scope}:{tower}", float((far - kth).max()), float(kth.abs().max()),
+                                        int((torch.sort(pin, -1).values != torch.sort(idx, -1).values).any(-1).sum()), pin.shape[0] * pin.shape[1]))
+                assert int((torch.sort(pin, -1).values[..., 1:] == torch.sort(pin, -1).values[..., :-1]).sum()) == 0, "pinned neighbour table repeats an index"
+                idx = pin
+            elif self.record_decisions:
+                self.decisions["knn"][tower] = idx.numpy()
         nbr = torch.gather(x[:, None].expand(B, N, N, D), 2, idx[..., None].expand(B, N, k, D))
         cen = x[:, :, None, :].expand_as(nbr)
         h = torch.cat([cen, nbr - cen], -1).reshape(B * N * k, 2 * D)
@@ -131,11 +181,11 @@ class TorchTp8:
             # operands (the whole backward stays fp32 in the engine: DESIGN.md 4.5b)
             h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
                             round_operands=self.bf16_lift and training and i >= 1)
-        h = h.reshape(B * N, k, -1).amax(dim=1)
+        h = self._max_over(h.reshape(B * N, k, -1), "slot", scope, tower)
         nm = f"{scope}/conv{len(widths)}"
         h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
                         round_operands=self.bf16_lift and training)
-        return h.reshape(B, N, -1).amax(dim=1)
+        return self._max_over(h.reshape(B, N, -1), "pool", scope, tower)
 
     def _backbone(self, *a):
         fn = self._pointnet if self.spec.backbone == "pointnet" else self._dgcnn
@@ -159,10 +209,19 @@ class TorchTp8:
         return self._layer(h, nm if tower is None else "siamese/" + nm, None, training, decay, act=False)
 
     # -- decode -----------------------------------------------------------
-    def angles(self, logits):
+    def angles(self, logits, tower=None):
         nb = self.spec.num_bins
         pi = torch.tensor(np.float32(np.pi), dtype=logits.dtype)
         cls = torch.argmax(logits[:, :nb], dim=1)
+        pin = self._pin("yaw", None, tower) if tower is not None else None
+        if pin is not None:
+            with torch.no_grad():
+                lg = logits[:, :nb]
+                self.pin_report.append((f"yaw:{tower}", float((lg.amax(1) - lg.gather(1, pin[:, None])[:, 0]).max()), float(lg.abs().max()),
+                                        int((cls != pin).sum()), pin.numel()))
+            cls = pin
+        elif tower is not None and self.record_decisions:
+            self.decisions["yaw"][tower] = cls.numpy()
         res = (logits[:, nb:] * (pi / nb)).gather(1, cls[:, None])[:, 0]
         a = cls.to(logits.dtype) * (2.0 * pi / nb) + res
         return torch.remainder(a + pi, 2.0 * pi) - pi
@@ -177,7 +236,7 @@ class TorchTp8:
         o2 = self._mlp(f2, "transformer2/mlp", list(s.s2_fc) + [s.out_s2], tower, s.s2_keep, training, decay,
                        None if u is None else u[f"s2_{tower}"])
         s2c, lg = o2[:, :3] + s1c, o2[:, 3:]
-        a = -self.angles(lg)
+        a = -self.angles(lg, tower)
         c, sn, z, o = torch.cos(a), torch.sin(a), torch.zeros_like(a), torch.ones_like(a)
         R = torch.stack([c, -sn, z, sn, c, z, z, z, o], -1).reshape(-1, 3, 3)
         emb = self._backbone(torch.bmm(pcs - s2c[:, None], R), "embedding", s.emb_conv, tower, training, decay)
@@ -229,7 +288,7 @@ class TorchTp8:
         la1 = self._angle_losses(ep["pred_pc1angle_logits"], ang1)
         la2 = self._angle_losses(ep["pred_pc2angle_logits"], ang2)
         s3t = hub(ep["pred_translations"] - translations, 2.0)
-        p1, p2 = self.angles(ep["pred_pc1angle_logits"]), self.angles(ep["pred_pc2angle_logits"])
+        p1, p2 = self.angles(ep["pred_pc1angle_logits"], 0), self.angles(ep["pred_pc2angle_logits"], 1)
         tgt = (ang2 - ang1) - (p2 - p1)  # [B,1]-[B] -> [B,B]
         la3 = self._angle_losses(ep["pred_remaining_angle_logits"], tgt)
         lt = s.early_stage_factor * (s1 + s2) + s3t

@@ -1,5 +1,7 @@
-"""GPU: BASELINE.json's full inference size (SynthCars widths, B = 256, N = 1024), where the fp64 oracle is too slow
-to check every pair: size-independent properties of the path plus an oracle spot check on a subset."""
+"""GPU: BASELINE.json's full sizes.  Inference (configs[1]: SynthCars widths, B = 256, N = 1024): every pair against the fp64 oracle
+plus size-independent properties of the path.  Training (configs[2], [3]'s global batch, [4]'s N): every gradient against fp64
+autograd, once with the oracle deciding for itself and once PINNED to the engine's decisions (max-pool winners, yaw classes,
+neighbour slots, kNN graph), where the comparison is continuous and the bars are sharp."""
 import numpy as np
 import pytest
 
@@ -81,13 +83,25 @@ def test_pairs_are_independent_and_towers_swap(gpu_required, setup):
     np.testing.assert_array_equal(out["pred_pc2angle_logits"], base["pred_pc1angle_logits"])
 
 
-def test_oracle_spot_check(gpu_required, setup):
+def test_every_pair_against_the_fp64_oracle(gpu_required, setup):
+    """configs[1] at its own size: ALL 256 pairs of the batch against the fp64 NumPy oracle (eval-mode pairs are independent, so the
+    oracle walks the batch in chunks of 32 to bound its [rows, 1024] activations), north_star's 1e-4 bar on every output of every
+    pair (stage-3 outputs of pairs whose yaw decode sits within 1e-3 of a tie are counted and left out, as everywhere)."""
+    import time
     cfg, spec, P32, eng, d, base = setup
-    idx = np.arange(0, B, 32)
     P64 = {k: v.astype(np.float64) for k, v in P32.items()}
-    ref, _, _ = R.get_model(P64, spec, d["pcs1"][idx].astype(np.float64), d["pcs2"][idx].astype(np.float64))
-    worst, unstable = compare_forward({k: v[idx] for k, v in base.items()}, ref, spec.num_bins)
-    print("full-size spot check: worst abs err", max(worst.values()), "unstable", unstable)
+    t0 = time.time()
+    worst_all, unstable_all = {}, 0
+    for lo in range(0, B, 32):
+        sl = slice(lo, lo + 32)
+        ref, _, _ = R.get_model(P64, spec, d["pcs1"][sl].astype(np.float64), d["pcs2"][sl].astype(np.float64))
+        worst, unstable = compare_forward({k: v[sl] for k, v in base.items()}, ref, spec.num_bins)
+        unstable_all += unstable
+        for k, v in worst.items():
+            worst_all[k] = max(worst_all.get(k, 0.0), v)
+    print("full size, all %d pairs vs fp64 oracle: worst abs err %.3e (%s), unstable %d, oracle time %.1f s"
+          % (B, max(worst_all.values()), max(worst_all, key=worst_all.get), unstable_all, time.time() - t0))
+    assert unstable_all <= B // 16
 
 
 def test_training_reduces_loss_at_full_size(gpu_required):
@@ -175,74 +189,99 @@ def _train_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
     return cfg, spec, P32, d, du
 
 
-def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar, fp32_context=True):
-    """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
-    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`).
-    Every bar is 2 x the value this test printed at this round's head (profiles/r04_gpu_tests_fullsize.log holds the `full size:` lines):
-    whole-gradient cosine / relative L2, the worst tensor (error relative to the tensor's own largest entry), predictions, loss, EMA.
-    Why the gradient sits at 1e-2 and not at rounding level: at 256 x 1024 points the network takes 524 k max-pool decisions over 1024
-    candidates each and normalises 256-row batches of nearly equal pooled features; the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2
-    (worst tensor) away from its own fp64 evaluation (printed for context, not used as a bar any more), and the engine's own gradient
-    moves by 1.4e-2 when its inputs move by one ulp (tests/test_loopback_gpu.py prints that floor).  The small shapes of
-    tests/test_train_gpu.py (5e-4 per tensor) are what catches a 1 % gradient bug; this is the same arithmetic at BASELINE.json's sizes."""
-    from tests import test_train_gpu as TT
-    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
-    eng = alignnet3d.Engine(cfg)
-    eng.set_variables(P32)
-    ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True)
-    if fp32_context:
-        ep32, _, g32, _ = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], checkpoint=True, dt=np.float32)
-        gs = max(float(np.abs(v).max()) for v in grads.values())
-        skip = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
-        rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs)
-                    for k in grads if k not in skip)
-        pred32 = max(float(np.abs(ep32[k] - ep_ref[k]).max()) for k in ep_ref)
-        print("fp32 oracle vs fp64 oracle: worst relative gradient error %.2e, worst prediction error %.2e" % (rel32, pred32))
-    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
-    assert eng.get_option("last_train_kernel") == expect_kernel
-    worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
-    worst_ema = 0.0
-    ema_fail = []
-    for k, v in ema_ref.items():
-        got = eng.get_variable(k)
-        if not np.allclose(got, v, rtol=ema_tol, atol=0.1 * ema_tol):
-            ema_fail.append(k)
-        worst_ema = max(worst_ema, float(np.abs(got - v).max()))
+def _grad_compare(eng, spec, grads):
+    """engine gradient vs oracle gradient: ({tensor: max error / the tensor's own largest reference entry}, cosine, relative L2, scale)"""
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
-    bad, rel = {}, {}
+    rel, abs_err = {}, {}
     for name in R.trainable_names(spec):
         g = eng.get_gradient(name).astype(np.float64)
         ref = grads[name].reshape(g.shape)
         if name in bn_bias:
             assert np.abs(g).max() == 0.0 and np.abs(ref).max() < 1e-9 * gscale, name
             continue
-        err = float(np.abs(g - ref).max())
+        abs_err[name] = (float(np.abs(g - ref).max()), float(np.abs(ref).max()))
         if np.abs(ref).max() > 1e-6 * gscale:
-            rel[name] = err / float(np.abs(ref).max())
-        if err > tensor_bar * float(np.abs(ref).max()) + 1e-5 * gscale:
-            bad[name] = (err, float(np.abs(ref).max()))
+            rel[name] = abs_err[name][0] / abs_err[name][1]
     names = [n for n in R.trainable_names(spec) if n not in bn_bias]
     gv = np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names])
     rv = np.concatenate([np.asarray(grads[n], np.float64).ravel() for n in names])
     cos = float(gv @ rv / (np.linalg.norm(gv) * np.linalg.norm(rv)))
     rl2 = float(np.linalg.norm(gv - rv) / np.linalg.norm(rv))
+    return rel, abs_err, cos, rl2, gscale
+
+
+def _pin_gaps(report, tag):
+    """The oracle's check of every pinned decision: worst (true extreme - value at the engine's winner) / scale per kind, and how many of
+    the engine's winners are not the oracle's own first maximum (re-decided near-ties: the reason the unpinned comparison is blunt)."""
+    out = {}
+    for what, gap, scale, differ, total in report:
+        k = what.split(":")[0]
+        g, dn, tn = out.get(k, (0.0, 0, 0))
+        out[k] = (max(g, gap / max(scale, 1.0)), dn + differ, tn + total)
+    print(tag, "pinned decisions: " + ", ".join("%s worst gap %.2e of scale, %d of %d differ from the oracle's own choice" % (k, g, dn, tn) for k, (g, dn, tn) in sorted(out.items())))
+    return out
+
+
+def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar=8e-2,
+                                  tiny_tensors=(), pinned_pred_tol=1e-4, pinned_tensor_bar=1e-3, pinned_ema_tol=1e-4, gap_bar=1e-4):
+    """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
+    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`), twice:
+
+    (1) FREE: the oracle takes its own decisions.  At 256 x 1024 points the network takes 524 k max-pool decisions over 1024 candidates
+        each (utils/tf_util.py:350-373) and 512 yaw decodes (models/tp8.py:296); an fp32 evaluation re-decides the near-ties, and one
+        re-routed winner moves that (cloud, channel)'s whole gradient -- the SAME oracle evaluated in fp32 is 2e-2 .. 6e-2 (worst
+        tensor) from its fp64 evaluation.  Fixed bars, not derived from this implementation's own numbers: every tensor within 8e-2
+        of its own largest entry (`tiny_tensors`: tensors named by the caller whose entries are 1e-3 of the gradient's scale are held
+        to the whole-gradient bars only), whole gradient cosine / relative L2 as given.
+    (2) PINNED: the oracle gathers at the ENGINE's decisions (Engine.debug_train_decisions), after checking that every one of them is a
+        maximum of the oracle's own values to within `gap_bar` of their scale -- that check is the test of the arg-max kernels.  What
+        is left is continuous, and the comparison is sharp: every gradient tensor within 1e-3 of its largest entry, predictions 1e-4."""
+    from tests import test_train_gpu as TT
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    Bt = d["pcs1"].shape[0]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    decay = eng.state()["bn_decay"]
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert eng.get_option("last_train_kernel") == expect_kernel
+    decisions = eng.debug_train_decisions(Bt)
+    ema_got = None
+    failures = []
+    for mode in ("free", "pinned"):
+        rep = []
+        ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, decay, checkpoint=True, pinned=decisions if mode == "pinned" else None, report=rep)
+        if ema_got is None:
+            ema_got = {k: eng.get_variable(k) for k in ema_ref}
+        worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
+        worst_ema = max(float(np.abs(ema_got[k] - v).max()) for k, v in ema_ref.items())
+        etol = ema_tol if mode == "free" else min(ema_tol, pinned_ema_tol)
+        ema_fail = [k for k, v in ema_ref.items() if not np.allclose(ema_got[k], v, rtol=etol, atol=0.1 * etol)]
+        rel, abs_err, cos, rl2, gscale = _grad_compare(eng, spec, grads)
+        print("full size (%s): loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, whole gradient: cosine %.8f, relative L2 error %.2e, "
+              "worst relative gradient errors %s" % (mode, res["loss"], loss_ref, worst_pred, worst_ema, cos, rl2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
+        bar = tensor_bar if mode == "free" else pinned_tensor_bar
+        bad = {n: e for n, e in abs_err.items() if e[0] > bar * e[1] + 1e-5 * gscale and not (mode == "free" and n in tiny_tensors)}
+        if mode == "pinned":
+            gaps = _pin_gaps(rep[0], "full size:")
+            if any(g > gap_bar for g, _, _ in gaps.values()): failures.append(("pinned decision is not a maximum of the oracle's values", gaps))
+            if worst_pred > pinned_pred_tol: failures.append(("pinned predictions", worst_pred))
+            if cos < 0.999999 or rl2 > pinned_tensor_bar: failures.append(("pinned whole gradient", cos, rl2))
+        else:
+            if worst_pred > pred_tol: failures.append(("free predictions", worst_pred))
+            if cos < cos_bar or rl2 > rl2_bar: failures.append(("free whole gradient", cos, rl2))
+        if abs(res["loss"] - loss_ref) > (loss_tol if mode == "free" else min(loss_tol, 1e-5)) * max(1.0, abs(loss_ref)): failures.append((mode + " loss", res["loss"], loss_ref))
+        if ema_fail: failures.append((mode + " EMA", ema_fail[:4]))
+        if bad: failures.append((mode + " tensors", bad))
     eng.close()
-    print("full size: loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, whole gradient: cosine %.6f, relative L2 error %.2e, "
-          "worst relative gradient errors %s" % (res["loss"], loss_ref, worst_pred, worst_ema, cos, rl2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
-    assert worst_pred <= pred_tol, worst_pred
-    assert abs(res["loss"] - loss_ref) <= loss_tol * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
-    assert not ema_fail, ema_fail
-    assert cos >= cos_bar and rl2 <= rl2_bar, (cos, rl2)
-    assert not bad, bad
+    assert not failures, failures
 
 
 def test_train_fp32_full_size_matches_autograd(gpu_required):
     """BASELINE.json configs[2]'s shape in fp32: SynthCars widths, 256 pairs x 1024 points -- the kernel instantiations with the
     widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256."""
     cfg, spec, P32, d, du = _train_setup()
-    # measured: predictions 1.3e-4, loss 1e-6, EMA 2.5e-6, cosine 0.999911, relative L2 1.3e-2, worst tensor fc1/weights 6.3e-2
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, cos_bar=0.9998, rl2_bar=2.7e-2, tensor_bar=0.125)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, cos_bar=0.9995, rl2_bar=3e-2)
 
 
 def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):
@@ -253,6 +292,38 @@ def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):
     TT.bf16_check(cfg, spec, P32, d, du, B, expect_kernel=3, checkpoint=True)
 
 
+def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
+    """configs[2] at its own size, sharp: the bf16 step against the rounded-operand oracle PINNED to the engine's max-pool winners and
+    yaw classes.  Unpinned (the test above) the two sit at cosine 0.97 because the operand rounding re-decides near-tied winners; with
+    the decisions pinned what remains is the rounding of the operands themselves (an fp32-vs-fp64 difference in h2 moves ~1 % of its
+    entries to the neighbouring bf16 value: 2^-8 of one of 128 product terms): every gradient tensor within 2e-2 of its own largest
+    entry, whole gradient at cosine >= 0.9999, and every engine winner a maximum of the oracle's own rounded-operand values to
+    within 2e-2 of their scale."""
+    from tests import test_train_gpu as TT
+    cfg, spec, P32, d, du = _train_setup()
+    us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.set_option("train_matmul_bf16", 1)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
+    assert eng.get_option("last_train_kernel") == 3
+    rep = []
+    ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=True, checkpoint=True,
+                                                  pinned=eng.debug_train_decisions(B), report=rep)
+    worst_pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
+    rel, abs_err, cos, rl2, gscale = _grad_compare(eng, spec, grads)
+    eng.close()
+    print("full size bf16 (pinned): loss %.6f (oracle %.6f), worst prediction err %.2e, whole gradient: cosine %.8f, relative L2 error %.2e, worst relative gradient errors %s"
+          % (res["loss"], loss_ref, worst_pred, cos, rl2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
+    gaps = _pin_gaps(rep[0], "full size bf16:")
+    assert all(g <= 2e-2 for g, _, _ in gaps.values()), gaps
+    assert abs(res["loss"] - loss_ref) <= 5e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    assert worst_pred <= 2e-2, worst_pred
+    assert cos >= 0.9999 and rl2 <= 2e-2, (cos, rl2)
+    bad = {n: e for n, e in abs_err.items() if e[0] > 2e-2 * e[1] + 1e-5 * gscale}
+    assert not bad, bad
+
+
 def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
     SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 4 keeps the [B*N*k, C] autograd oracle in memory."""
@@ -260,8 +331,7 @@ def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     # (two max-pools and 4-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 3.8e-2 from its fp64 one here)
     # (EMA bound 2e-4: with the point conv on 128-point tiles one of the 512 fc1 moving means -- four-row batch statistics -- sits 1.4e-5 from the
     #  fp64 value at |v| = 0.03, just outside 1e-4 |v| + 1e-5)
-    # measured: predictions 2.3e-4, loss 2e-6, EMA 4.1e-5, cosine 0.999965, relative L2 9.1e-3, worst tensor siamese_1/embedding/conv1/bn/beta 3.8e-2
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9999, rl2_bar=1.9e-2, tensor_bar=8e-2)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9995, rl2_bar=3e-2)
 
 
 def test_train_b2048_matches_autograd(gpu_required):
@@ -271,8 +341,7 @@ def test_train_b2048_matches_autograd(gpu_required):
     256 x 1024 test (the same 524 k points)."""
     cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
     # (2048-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 4e-2 from its fp64 one on the smallest gradients)
-    # measured: predictions 1.5e-4, loss 1e-6, EMA 8e-7, cosine 0.999979, relative L2 6.4e-3, worst tensor fc1/bn/beta 3.3e-2
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.99995, rl2_bar=1.3e-2, tensor_bar=7e-2)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.9995, rl2_bar=3e-2)
 
 
 def test_train_dgcnn_n4096_matches_autograd(gpu_required):
@@ -282,10 +351,12 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=4096, seed=9)
     # The fp32 kNN graph differs from the fp64 oracle's wherever the 20th and 21st neighbour of a query are closer than fp32 rounding of the
     # distance expression (N = 4096: dozens of queries per cloud), and four-row batch statistics in the heads amplify one changed neighbour
-    # into per cents on the smallest tensors (siamese/embedding/conv3/bn/beta: 0.42 of its 1e-3-sized entries): the per-tensor bar only
-    # bounds that tensor, the whole-gradient bars carry the comparison.
-    # measured: predictions 4.4e-3 (the fp32 oracle's own: 7.7e-3), loss 2.2e-4, EMA 2.3e-3, cosine 0.999856, relative L2 1.7e-2
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=9e-3, loss_tol=5e-4, ema_tol=5e-3, cos_bar=0.9997, rl2_bar=3.4e-2, tensor_bar=0.85)
+    # into per cents on the smallest tensors (siamese/embedding/conv3/bn/beta: 0.42 of its 1e-3-sized entries -- named, and left to the
+    # whole-gradient bars in the FREE comparison; every other tensor keeps the 8e-2 ceiling).  PINNED to the engine's graph, slots and
+    # winners the same step is compared at the sharp bars (1e-3 per tensor): the graph itself is checked there as a k-nearest set of
+    # every query in fp64 distances.
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=9e-3, loss_tol=5e-4, ema_tol=5e-3, cos_bar=0.9995, rl2_bar=3.5e-2,
+                                  tiny_tensors=("siamese/embedding/conv3/bn/beta",))
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):

@@ -109,3 +109,69 @@ def test_schedules_and_adam():
     w, m, v = R.adam_step(np.array([1.0]), np.array([0.5]), np.zeros(1), np.zeros(1), 1, 0.01)
     # first TF-Adam step moves by ~lr*sign(g)
     assert abs((1.0 - w[0]) - 0.01) < 1e-6
+
+
+def _loss_and_grads(tm, tp, td, tu):
+    for v in tp.values():
+        v.grad = None
+    loss = tm.loss(tm.forward(td["pcs1"], td["pcs2"], True, 0.5, tu), *[td[k] for k in LABELS])
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy().copy() for k, v in tp.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("backbone,N", [("pointnet", 64), ("dgcnn", 24)])
+def test_pinned_to_own_decisions_changes_nothing(backbone, N):
+    """Decision-pinned mode (oracle/alignnet_torch.py `pinned`): gathering at the oracle's OWN max-pool winners, neighbour slots,
+    neighbour table and yaw classes is the same function -- loss and every gradient equal the unpinned evaluation's, every
+    reported gap is zero.  (The tower layout of `pinned` is the engine's: [tower][...].)"""
+    spec, P, d, du = _setup(backbone, N)
+    td = {k: torch.tensor(v) for k, v in d.items()}
+    tu = {k: torch.tensor(v) for k, v in du.items()}
+    tp = T.to_torch(P, requires_grad=True)
+    tm = T.TorchTp8(spec, tp)
+    tm.record_decisions = True
+    loss0, g0 = _loss_and_grads(tm, tp, td, tu)
+    dec = tm.decisions
+    pinned = {"yaw": np.stack(dec["yaw"]), "pool": [np.stack(x) for x in dec["pool"]]}
+    if backbone == "dgcnn":
+        pinned["slot"] = [np.stack(x) for x in dec["slot"]]
+        pinned["knn"] = np.stack(dec["knn"])
+    tm2 = T.TorchTp8(spec, tp, pinned=pinned)
+    loss1, g1 = _loss_and_grads(tm2, tp, td, tu)
+    assert loss1 == loss0
+    for k in g0:
+        np.testing.assert_allclose(g1[k], g0[k], rtol=1e-12, atol=1e-15, err_msg=k)
+    assert tm2.pin_report and all(gap == 0.0 and differ == 0 for _, gap, _, differ, _ in tm2.pin_report), tm2.pin_report
+    kinds = {r[0].split(":")[0] for r in tm2.pin_report}
+    assert kinds == ({"yaw", "pool"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn"})
+
+
+def test_pinned_evaluation_is_continuous_where_the_free_one_jumps():
+    """Why the pin exists: move the inputs by 1e-7 and the free evaluation re-decides near-tied winners (its gradient moves by per cents
+    at full size); pinned to the unperturbed decisions the same perturbation moves the gradient by ~1e-6, and the report shows the
+    pinned winners are maxima of the perturbed values to within that perturbation.  A WRONG pin (a winner that is not a maximum) shows
+    up as a gap far above rounding."""
+    spec, P, d, du = _setup("pointnet", 64, B=6)
+    td = {k: torch.tensor(v) for k, v in d.items()}
+    tu = {k: torch.tensor(v) for k, v in du.items()}
+    tp = T.to_torch(P, requires_grad=True)
+    tm = T.TorchTp8(spec, tp)
+    tm.record_decisions = True
+    _, g0 = _loss_and_grads(tm, tp, td, tu)
+    pinned = {"yaw": np.stack(tm.decisions["yaw"]), "pool": [np.stack(x) for x in tm.decisions["pool"]]}
+    rng = np.random.default_rng(1)
+    td2 = dict(td)
+    for k in ("pcs1", "pcs2"):
+        td2[k] = td[k] + torch.tensor(rng.normal(scale=1e-7, size=td[k].shape))
+    tm2 = T.TorchTp8(spec, tp, pinned=pinned)
+    _, g1 = _loss_and_grads(tm2, tp, td2, tu)
+    gs = max(np.abs(v).max() for v in g0.values())
+    worst = max(np.abs(g1[k] - g0[k]).max() / gs for k in g0)
+    assert worst < 1e-4, worst
+    assert all(gap <= 1e-5 * max(scale, 1.0) for _, gap, scale, _, _ in tm2.pin_report), tm2.pin_report
+    bad = {"yaw": pinned["yaw"], "pool": [x.copy() for x in pinned["pool"]]}
+    bad["pool"][2][0, 0, :] = (bad["pool"][2][0, 0, :] + 17) % 64   # tower 0, pair 0 of the embedding stage: every winner moved to another point
+    tm3 = T.TorchTp8(spec, tp, pinned=bad)
+    _loss_and_grads(tm3, tp, td, tu)
+    gap = max(g for what, g, _, _, _ in tm3.pin_report if what == "pool:embedding:0")
+    assert gap > 1e-3, gap

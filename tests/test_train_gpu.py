@@ -14,10 +14,14 @@ pytestmark = pytest.mark.gpu
 LABELS = ("translations", "rel_angles", "pc1_centers", "pc2_centers", "pc1_angles", "pc2_angles")
 
 
-def _oracle(cfg, P32, d, du, decay, bf16_lift=False, dt=np.float64, checkpoint=False):
+def _oracle(cfg, P32, d, du, decay, bf16_lift=False, dt=np.float64, checkpoint=False, pinned=None, report=None):
+    """pinned: the engine's decisions (Engine.debug_train_decisions) -- the oracle gathers at them instead of deciding itself
+    (oracle/alignnet_torch.py); report: a list that receives the oracle's check of every pinned decision."""
     spec = R.NetSpec.from_cfg(cfg)
     tp = T.to_torch({k: v.astype(dt) for k, v in P32.items()}, dtype=torch.float64 if dt == np.float64 else torch.float32, requires_grad=True)
-    tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift, checkpoint=checkpoint)
+    tm = T.TorchTp8(spec, tp, bf16_lift=bf16_lift, checkpoint=checkpoint, pinned=pinned)
+    if report is not None:
+        report.append(tm.pin_report)   # (filled while forward / backward run)
     td = {k: torch.tensor(v.astype(dt)) for k, v in d.items()}
     tu = {k: torch.tensor(v.astype(dt)) for k, v in du.items()}
     ep = tm.forward(td["pcs1"], td["pcs2"], True, decay, tu)
