@@ -50,6 +50,8 @@ def average_ema_shadows(engine, dist=None):
     if engine.get_option("comm_world") > 1:
         engine.comm_average_shadows()
         return n
+    if dist is None or not dist.is_initialized() or dist.get_world_size() <= 1:
+        return 0   # one rank (no communicator, a world-1 communicator, or no process group): its shadows are the average
     import numpy as np
     import torch
     names = [(nm, s) for nm, s, trainable in engine.variables() if not trainable]

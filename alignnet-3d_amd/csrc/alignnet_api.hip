@@ -394,6 +394,8 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
     size_t o_out[8];
     const int widths[8] = {3, nb2, 3, 3, 3, 3, nb2, nb2};
     for (int i = 0; i < 8; ++i) { o_out[i] = tot; tot += al((size_t)B * widths[i]); }
+    // the split-K head layer adds onto hid_s, which only centroid_kernel clears -- as part of the range [pool1, hid_a) it zeroes per forward
+    if (!(o_hs >= o_p1 && o_hs + al(B2 * H) <= o_ha)) return fail(h, "workspace carve: hid_s must lie inside the range the centroid kernel clears ([pool1, hid_a))");
     HIP_TRY(h, hipMalloc(&w.d_all, tot * sizeof(float)));
     float* base = w.d_all;
     w.xform = base + o_xform; w.center_mean = base + o_cm; w.s1c = base + o_s1c; w.s2c = base + o_s2c;
@@ -630,9 +632,12 @@ static int run_head(alignnet_handle* h, const Stack& st, const float* in, long l
     float* dst = last ? out : pp[j & 1];
     const long ldd = last ? ldout : L.cout;
     // a deep first layer on few tiles (the pair head: K = 2048, 128 tiles) as two K halves onto the zeroed hid_s; the next layer finishes it
-    const bool split = j == 0 && !last && L.cin >= 2048 && ((L.cin / 8) % 2) == 0 && (L.cin % 8) == 0 && M <= rows_per_set &&
+    // (hid_s is zero exactly once per forward -- armed by forward_device behind the centroid kernel, consumed here: a second qualifying
+    //  layer in the same forward takes the one-piece path instead of summing onto the first one's partials)
+    const bool split = j == 0 && !last && L.cin >= 2048 && ((L.cin / 8) % 2) == 0 && (L.cin % 8) == 0 && M <= rows_per_set && h->ws.hid_s_zeroed &&
                        (long)((L.cout + 31) / 32) * ((M + 31) / 32) <= 128 && !(h->ab & (AB_FC_DIRECT | AB_FC_NO_SPLITK));
     if (split) {
+      h->ws.hid_s_zeroed = false;
       if (run_fc(h, L, cur, ldc, h->ws.hid_s, L.cout, M, rows_per_set, false, nullptr, 2)) return 1;
       cur = h->ws.hid_s; ldc = L.cout; split_bn = &L;
       continue;
@@ -663,6 +668,7 @@ static int forward_device(alignnet_handle* h, const float* p1, const float* p2, 
   // pool1 | pool2 | emb are carved back to back: the centroid kernel arms all three atomicMax targets (a slice per workgroup)
   hipLaunchKernelGGL(centroid_kernel, dim3(B2), dim3(256), 0, h->stream, p1, p2, B, N, w.xform, w.center_mean, w.pool1,
                      (size_t)((char*)w.hid_a - (char*)w.pool1) / sizeof(float));
+  w.hid_s_zeroed = true;   // (pool1 | pool2 | emb | hid_s: all cleared by that launch)
   if (dg) {   // static kNN graph (tp8.py:35-36), once per cloud in the mean-centred frame
     ProfScope prof_scope(h, PK_KNN, true);
     prof_scope.used = true;
@@ -937,6 +943,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   if (k == "ablate_mutation") { h->ablate_mutation = (int)value; return 0; }   // 1 = gather with the towers swapped, 2 = every rank keeps rank 0's rows of the loss gradient,
                                                                                // 3 = per-rank count behind a synchronised BatchNorm, 4 = a global weight-gradient term without 1 / world   // ablation build only: result-changing timing switches of the kernels
 #endif
+  if (const int rc = alignnet_train_set_option(h, k, value); rc >= 0) return rc;
   return fail(h, "alignnet_set_option: unknown key '" + k + "'");
 }
 
@@ -963,6 +970,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "last_backbone_kernel") { *value = h->last_kernel; return 0; }
   if (k == "last_train_kernel") { *value = h->last_train_kernel; return 0; }
   if (k == "train_fused_tail") { *value = h->fused_tail ? 1 : 0; return 0; }
+  if (const int rc = alignnet_train_get_option(h, k, value); rc >= 0) return rc;
   return fail(h, "alignnet_get_option: unknown key '" + k + "'");
 }
 

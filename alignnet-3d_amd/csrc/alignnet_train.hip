@@ -2027,7 +2027,9 @@ extern "C" int alignnet_grad_buffer(alignnet_handle* h, float** d_grad, size_t* 
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   TrainWS* w = tws(h);
   if (!w->grad && ensure_train_ws(h, 0)) return 1;
-  if (d_grad) *d_grad = w->grad;
+  // The caller may write through this pointer (an external all-reduce, a hand-made gradient): from here on the engine no longer knows the
+  // buffer to be all zeros, so the next backward clears it itself instead of trusting the optimiser's "consumed" state.
+  if (d_grad) { *d_grad = w->grad; w->grad_clean = false; }
   if (count) *count = h->n_trainable;
   return 0;
 }
@@ -2047,6 +2049,23 @@ extern "C" int alignnet_get_grad(alignnet_handle* h, const char* name, float* ds
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(dst, w->grad + p.offset, count * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
+}
+
+int alignnet_train_set_option(alignnet_handle* h, const std::string& k, int64_t value)
+{
+  if (k == "loopback_timeout_s") {   // rendezvous timeout of the in-process loopback groups (process-wide; csrc/comm_loopback.h)
+    if (value < 1) return fail(h, "loopback_timeout_s must be >= 1");
+    loop_timeout() = std::chrono::seconds(value);
+    return 0;
+  }
+  return -1;
+}
+
+int alignnet_train_get_option(alignnet_handle* h, const std::string& k, int64_t* value)
+{
+  (void)h;
+  if (k == "loopback_timeout_s") { *value = (int64_t)loop_timeout().count(); return 0; }
+  return -1;
 }
 
 // test hook (include/alignnet_hip.h): the discontinuous choices of the last training forward -- decoded yaw classes, the max-pool's

@@ -27,6 +27,10 @@
 namespace alignnet {
 
 constexpr int kLoopMaxWorld = 16;
+// How long a rank waits at a rendezvous before it declares the group broken.  Generous on purpose: a peer may legitimately stall for a
+// long time (first-step workspace allocation of 288 GB-sized shapes, a debugger, a profiler draining its buffers) and a timeout poisons
+// the group for good; alignnet_set_option("loopback_timeout_s") on any rank of the group changes it.
+inline std::chrono::seconds& loop_timeout() { static std::chrono::seconds t{600}; return t; }
 constexpr char kLoopMagic[8] = {'A', 'L', 'N', '3', 'L', 'O', 'O', 'P'};   // first bytes of a loopback id (alignnet_comm_loopback_id)
 
 struct LoopPtrs { void* p[kLoopMaxWorld]; };
@@ -71,13 +75,13 @@ struct LoopGroup {
     if (broken) return false;
     const unsigned long long my = gen;
     if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); return true; }
-    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != my || broken; })) { broken = true; cv.notify_all(); }
+    if (!cv.wait_for(lk, loop_timeout(), [&] { return gen != my || broken; })) { broken = true; cv.notify_all(); }
     return !broken;
   }
   void poison() { std::lock_guard<std::mutex> g(mu); broken = true; cv.notify_all(); }
 };
 
-struct LoopComm { std::shared_ptr<LoopGroup> g; int rank = 0; };
+struct LoopComm { std::shared_ptr<LoopGroup> g; int rank = 0; unsigned long long key = 0; };
 
 inline std::mutex& loop_registry_mutex() { static std::mutex m; return m; }
 inline std::map<unsigned long long, std::weak_ptr<LoopGroup>>& loop_registry() { static std::map<unsigned long long, std::weak_ptr<LoopGroup>> r; return r; }
@@ -108,21 +112,30 @@ inline LoopComm* loop_join(const unsigned char id[128], int rank, int world, int
     if (!g) { g = std::make_shared<LoopGroup>(); g->world = world; g->device = device; reg[key] = g; }
   }
   std::unique_lock<std::mutex> lk(g->mu);
-  if (g->world != world) { err = "loopback communicator: ranks disagree on the world size"; return nullptr; }
-  if (g->device != device) { err = "loopback communicator: all ranks must sit on one device"; return nullptr; }
-  if (g->ready[rank]) { err = "loopback communicator: rank " + std::to_string(rank) + " joined twice"; return nullptr; }
+  // every failure below breaks the group and wakes the peers: a rank that cannot join must not leave the others in the join
+  // rendezvous until their timeout
+  auto refuse = [&](const std::string& m) -> LoopComm* { err = m; g->broken = true; g->cv.notify_all(); return nullptr; };
+  if (rank < 0 || rank >= world) return refuse("loopback communicator: rank " + std::to_string(rank) + " outside the world of " + std::to_string(world));
+  if (g->world != world) return refuse("loopback communicator: ranks disagree on the world size");
+  if (g->device != device) return refuse("loopback communicator: all ranks must sit on one device");
+  if (g->ready[rank]) return refuse("loopback communicator: rank " + std::to_string(rank) + " joined twice");
   if (hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming) != hipSuccess) { err = "loopback communicator: hipEventCreate failed"; return nullptr; }
+      hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming) != hipSuccess) {
+    if (g->ready[rank]) { hipEventDestroy(g->ready[rank]); g->ready[rank] = nullptr; }
+    return refuse("loopback communicator: hipEventCreate failed");
+  }
   g->joined++;
   g->cv.notify_all();
   // like ncclCommInitRank, joining is itself a rendezvous: nobody leaves before all `world` ranks are in
-  if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->joined == g->world || g->broken; }) || g->broken) {
-    g->broken = true; g->cv.notify_all();
-    err = "loopback communicator: only " + std::to_string(g->joined) + " of " + std::to_string(world) + " ranks joined";
-    return nullptr;
+  if (!g->cv.wait_for(lk, loop_timeout(), [&] { return g->joined == g->world || g->broken; }) || g->broken) {
+    const int have = g->joined;
+    g->joined--;   // undo this rank's join: its events go, the (broken) group keeps no trace of it
+    hipEventDestroy(g->ready[rank]); g->ready[rank] = nullptr;
+    hipEventDestroy(g->done[rank]); g->done[rank] = nullptr;
+    return refuse("loopback communicator: only " + std::to_string(have) + " of " + std::to_string(world) + " ranks joined");
   }
   LoopComm* c = new LoopComm();
-  c->g = g; c->rank = rank;
+  c->g = g; c->rank = rank; c->key = key;
   return c;
 }
 
@@ -136,7 +149,11 @@ inline void loop_leave(LoopComm* c)
     if (c->g->ready[c->rank]) { hipEventDestroy(c->g->ready[c->rank]); c->g->ready[c->rank] = nullptr; }
     if (c->g->done[c->rank]) { hipEventDestroy(c->g->done[c->rank]); c->g->done[c->rank] = nullptr; }
   }
-  delete c;
+  const unsigned long long key = c->key;
+  delete c;   // (drops this rank's reference to the group)
+  std::lock_guard<std::mutex> lk(loop_registry_mutex());   // the last rank to leave takes the expired entry out of the registry
+  auto it = loop_registry().find(key);
+  if (it != loop_registry().end() && it->second.expired()) loop_registry().erase(it);
 }
 
 enum { kLoopSumF32 = 1, kLoopSumF64 = 2, kLoopGather = 3 };

@@ -51,6 +51,7 @@ struct Workspace {
   float *pool1, *pool2, *emb;      // [2B][C1], [2B][C2], [B][2*Cemb]
   float *hid_a, *hid_b;            // head hidden activations
   float* hid_s;                    // raw (pre-BatchNorm) output of a head layer run as two K halves (atomic adds onto zeros: cleared with the pooled buffers)
+  bool hid_s_zeroed = false;       // hid_s has been cleared by this forward's centroid kernel and not been added onto yet (alignnet_api.hip: run_head)
   float *o1, *o2, *o3;             // head outputs [2B][3], [2B][3+2nb], [B][3+2nb]
   float* outs[8];                  // device copies of the 8 prediction tensors
 };
@@ -84,7 +85,10 @@ static const struct { const char* key; unsigned bit; } kAbKeys[] = {
   {"ab_dg_sparse", AB_DG_SPARSE}, {"ab_no_glue_fold", AB_NO_GLUE_FOLD}, {"ab_gemm_jobs_ksplit", AB_GEMM_JOBS_KSPLIT}, {"ab_fc_direct", AB_FC_DIRECT}, {"ab_fc_no_splitk", AB_FC_NO_SPLITK}};
 struct alignnet_handle;
 bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out);   // alignnet_dataset.hip; false when none uploaded
-int alignnet_drain_profile(alignnet_handle* h);   // alignnet_api.hip: read back the pending profiling event pairs (synchronises the stream)
+int alignnet_drain_profile(alignnet_handle* h);
+// options that live with the training / communicator code (alignnet_train.hip); -1 = not one of its keys
+int alignnet_train_set_option(alignnet_handle* h, const std::string& key, int64_t value);
+int alignnet_train_get_option(alignnet_handle* h, const std::string& key, int64_t* value);   // alignnet_api.hip: read back the pending profiling event pairs (synchronises the stream)
 
 struct alignnet_handle {
   alignnet_config cfg;

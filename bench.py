@@ -43,6 +43,14 @@ FLOPS_PER_PAIR_TOTAL = 1_047_688_704
 FLOPS_PER_PAIR_TRAIN_SURVEY = 3.14e9   # dense forward + dX + dW, the count a layer-by-layer backward would execute
 N_POINTS = 1024
 PEAK_F32, PEAK_BF16 = 157.3, 2500.0    # TFLOP/s, dense (MI355X_MICROARCH.md)
+# Vector-instruction issue roofline (MI355X_MICROARCH.md, "Wave scheduling": a wave issues each VALU instruction over 2 cycles on its
+# SIMD-32; 256 CUs x 4 SIMDs at 2.4 GHz): the bound of a kernel whose time goes into vector instructions rather than into a matrix pipe
+PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-level VALU instructions / s
+# Static vector-instruction counts per wave and unit of work for the kernels DESIGN.md identifies as VALU-issue-bound, used when no
+# committed PMC pass (SQ_INSTS_VALU, profiles/r*_pmc_by_kernel.json) of the same command and shape is available:
+#   train_bwd_b2 (bf16 mode): ~1.1 k vector instructions per wave and 64-point tile, 4 waves per tile
+#   knn: ~700 vector instructions per query point, one wave per query
+VALU_INSTR_STATIC = {"train_bwd_b2": lambda n: 3 * ((n + 63) // 64) * 4 * 1100.0, "knn": lambda n: n * 700.0}   # per cloud (three stages / one graph)
 K_NEIGHBOURS = 20                      # models/tp8.py:33
 
 
@@ -137,6 +145,32 @@ def pmc_traffic(leg_tag, kernel_substr, shape):
             if any(alt in name for alt in kernel_substr.split("|")):
                 return {"bytes_per_step": v["hbm_bytes_per_step"], "bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(files[-1]),
                         "commit": j.get("commit")}
+    except Exception:
+        return None
+    return None
+
+
+def pmc_valu_instr(leg_tag, kernel_substr, shape):
+    """Wave-level VALU instructions per launch of one kernel (SQ_INSTS_VALU minus the MFMAs, which issue on the matrix pipe) from the
+    newest committed PMC summary of this leg at this shape, or None."""
+    pre = leg_tag + "_" if leg_tag else ""
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%spmc_by_kernel.json" % pre)) if re.fullmatch(r"r\d+_%spmc_by_kernel\.json" % pre, os.path.basename(f))]
+    files.sort(key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        return None
+    try:
+        tf = files[-1].replace("pmc_by_kernel", "pmc_traffic")
+        sh = (json.load(open(tf)).get("shape") or {}) if os.path.exists(tf) else {}
+        if (sh.get("pairs_per_gpu"), sh.get("num_points")) != tuple(shape):
+            return None
+        for name, v in json.load(open(files[-1])).items():
+            if any(alt in name for alt in kernel_substr.split("|")) and "SQ_INSTS_VALU" in v:
+                c = v["SQ_INSTS_VALU"]
+                mf = v.get("SQ_INSTS_MFMA")
+                per = c["sum"] / max(c["dispatches"], 1)
+                if mf:
+                    per -= mf["sum"] / max(mf["dispatches"], 1)
+                return {"instr_per_launch": per, "source": os.path.basename(files[-1])}
     except Exception:
         return None
     return None
@@ -396,10 +430,14 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short dgcnn / loader / icp legs the default --gpus 1 inference run appends")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal of the multi-GPU code path on ONE GPU: re-launch under torch.distributed.run with one rank and take every branch a "
+                         "--gpus N > 1 run takes (NCCL process group with device_id, the library's RCCL communicator, barriers, max over ranks, the "
+                         "sustained loop's flag all-reduce, per-rank spread); the line says so in `forced_dist`")
     args = ap.parse_args()
     refuse_stray_environment()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) here instead of silently running one
         raise SystemExit(self_launch(args.gpus))
 
@@ -412,6 +450,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist_on = world > 1 or args.force_dist   # every `world > 1` branch below; --force-dist takes them at world = 1
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -420,7 +459,7 @@ def main():
         # one rank per GPU is the contract; sharing a device would report n_gpus ranks' worth of throughput from fewer GPUs
         raise SystemExit(f"{local_world} ranks on this node but only {ndev} GPU(s) visible: refusing to share devices")
     dist = None
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -449,7 +488,7 @@ def main():
             eng.set_variable(name, np.ones(shp[0] * shp[1], np.float32))
 
     cpu_info = None
-    if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
+    if not dist_on and not args.no_cpu_baseline and args.mode == "infer":
         cpu_info = cpu_baseline(cfg)   # before the GPU legs: they then run back to back at the end of the process
 
     d = synth_pairs(B, npts, seed=1234 + rank, dtype=np.float32)
@@ -476,7 +515,32 @@ def main():
         if rccl_ranks != world:
             raise RuntimeError(f"RCCL communicator reports {rccl_ranks} ranks, expected {world}")
 
-    if world > 1 and args.mode == "train":
+    # which BatchNorm / loss semantics the training legs run in: "sync" = statistics and loss over the GLOBAL batch (the reference's
+    # single-device step at world x batch; engine options sync_bn + global_loss), "local" = every rank a reference run on its own shard
+    bn_mode = "sync" if (args.sync_bn and dist_on) else "local"
+
+    def per_rank_rates(per_rank_seconds, steps):
+        r = [B * steps / max(x, 1e-9) for x in per_rank_seconds]
+        return {"min": round(min(r), 1), "max": round(max(r), 1), "ranks": len(r)}
+
+    def sync_bn_fields():
+        """sync-BN mode on > 1 rank: the step's dependency-bound per-layer all-reduces (30 + 17 gathers) each cost one small
+        collective's latency; measured here with the same message size on the process group, the product is the floor they add to a step."""
+        if bn_mode != "sync":
+            return {}
+        n = eng.get_option("sync_collectives")
+        t = torch.zeros(2048, device=dev)
+        for _ in range(20):
+            dist.all_reduce(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(t)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 200
+        return {"sync_collectives_per_step": n, "small_allreduce_latency_us": round(lat * 1e6, 2), "sync_bn_latency_floor_ms": round(n * lat * 1e3, 4)}
+
+    if dist_on and args.mode == "train":
         init_rccl()   # the headline leg itself needs it: a failure here is fatal
 
     def train_step():
@@ -491,6 +555,15 @@ def main():
         t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def all_ranks(x):
+        """every rank's value of a scalar, in rank order (a straggler GPU shows up as a spread between min and max)"""
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
     def fence():
         eng.synchronize()
@@ -520,6 +593,7 @@ def main():
             kern = eng.profile_kernels()
             eng.profile_read(reset=True)
             eng.profile_enable(False)
+        time_leg.last_per_rank = all_ranks(dt)   # this rank's own wall time of the region, from every rank
         return max_over_ranks(dt), kern
 
     def steps_for(step, floor):
@@ -545,7 +619,7 @@ def main():
         ach = flops / (ms_step * 1e-3) / 1e12 if ms_step > 0 and flops > 0 else None
         prof_name = backbone_name if name == "backbone" else KERNEL_IN_PROFILE.get(name, name)
         tr = pmc_traffic(leg_tag, prof_name, (B, npts))
-        r = {"bound": "mfma" if name != "knn" else "valu", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        r = {"bound": "mfma", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": None if ach is None else round(ach / peak, 4),
              # HBM bytes of this kernel from the committed PMC passes ((2 FETCH_SIZE + WRITE_SIZE) KiB), per launch like `achieved`'s work
              "traffic": None if tr is None else tr["bytes_per_launch"], "traffic_per_step": None if tr is None else tr["bytes_per_step"],
@@ -557,6 +631,18 @@ def main():
             r["traffic_commit"] = tr["commit"]      # ... taken at this commit of the tree (not measured inside this run)
         if on_bf16 and name == "backbone":
             r["note"] = "peak = dense bf16 MFMA peak / 3 (three bf16 MFMAs per algorithmic fp32 product)"
+        if name == "knn" or (name == "train_bwd_b2" and bf16 and not dg):
+            # VALU-issue-bound kernels (~1.1 k vector instructions per wave-tile against 40 MFMAs in pass B2's bf16
+            # form, ~700 per kNN query): the matrix pipe is not what bounds them, so the roofline quoted is the vector-instruction issue
+            # rate -- wave-level VALU instructions per launch / the launch's duration against 1228.8 G instructions / s.  Instruction
+            # count: SQ_INSTS_VALU of the committed PMC pass of this command and shape, else the static per-tile count (`instr_source`).
+            pv = pmc_valu_instr(leg_tag, prof_name, (B, npts))
+            per_launch = pv["instr_per_launch"] if pv else VALU_INSTR_STATIC[name](npts) * 2 * B / max(launches / steps, 1)
+            g = per_launch * (launches / steps) / (ms_step * 1e-3) / 1e9 if ms_step > 0 else None
+            r["matrix_pipe"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"]}   # kept for continuity with rounds 1-4
+            r.update({"bound": "valu", "achieved": None if g is None else round(g, 1), "peak": PEAK_VALU_GINSTR, "unit": "Ginstr/s",
+                      "frac": None if g is None else round(g / PEAK_VALU_GINSTR, 4), "valu_instr_per_launch": per_launch,
+                      "instr_source": pv["source"] if pv else "static count (bench.py VALU_INSTR_STATIC, DESIGN.md 4.4 / 4.5)"})
         if name == "train_fwd_phase3":
             # extra passes never count as algorithmic work.  The Gram of h2 accumulated in this pass is this design's
             # substitute for the dense dW of the lift, so both fractions are quoted: with it (`frac`) and on the lift alone.
@@ -570,7 +656,11 @@ def main():
         eng.set_option("infer_matmul_bf16x3", 1)
     if args.mode == "train" and args.train_dtype == "bf16":
         eng.set_option("train_matmul_bf16", 1)
-    step = train_step if args.mode == "train" else infer_step
+    executed = [0]   # every call of the headline step in this process: what a rocprofv3 run of this command divides its dispatch counts by
+
+    def step():
+        executed[0] += 1
+        (train_step if args.mode == "train" else infer_step)()
     # clock spin-up, untimed and in addition to the W warm-up steps: the GPU sits in its low-power state (sclk ~100 MHz) while the CPU
     # baseline runs, and a short (W + K)-step run would be timed on the ramp
     spin_t0, spinup_steps = time.perf_counter(), 0
@@ -580,6 +670,7 @@ def main():
         eng.synchronize()
         spinup_steps += 8
     dt, kern = time_leg(step, args.steps, args.warmup)
+    head_per_rank = time_leg.last_per_rank
     dt_off, _ = time_leg(step, args.steps, 0, timers=False)   # (reported next to `value`, never instead of it: the same K steps without the kernel timers)
     head_bf16 = (args.mode == "train" and args.train_dtype == "bf16") or (args.mode == "infer" and args.infer_dtype == "bf16x3")
     backbone_kernel = eng.last_backbone_kernel().split("<")[0] if args.mode == "infer" else "train"
@@ -643,7 +734,7 @@ def main():
     train_info = None
     if args.mode == "infer" and want_train:
       try:   # (a secondary leg must not cost the headline line: the communicator is created here, after the inference legs)
-        if world > 1:
+        if dist_on:
             init_rccl()
         train_info = {}
         for tdtype in ("f32", "bf16"):
@@ -654,14 +745,16 @@ def main():
             leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
                    "ms_per_step_under_kernel_timers": round(tdt_on / ksteps * 1e3, 3), "steps": ksteps, "dtype": tdtype,
                    "roofline": roofline(tkern, ksteps, tdtype == "bf16", "train_bf16" if tdtype == "bf16" else "train", "train"),
-                   "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY,
+                   "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY, "bn_mode": bn_mode,
                    "what": "train step: batch-stat forward + loss + backward + " +
                            ("RCCL all-reduce (%s) + " % ("3 buckets overlapped with the backward" if args.allreduce_overlap else "one call after the backward")
-                            if world > 1 else "") + "Adam + EMA, " + ("sync-BN + global-loss data parallel (the single-device step at the global batch)" if args.sync_bn else "local-BN data parallel") +
+                            if dist_on else "") + "Adam + EMA, " + ("sync-BN + global-loss data parallel (the single-device step at the global batch)" if args.sync_bn else "local-BN data parallel") +
                            ("; MFMA convs on bf16 operands, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
-            if world > 1:
+            if dist_on:
                 leg["rccl_ranks"] = rccl_ranks
                 leg["allreduce_exposed_ms_per_step"] = round(tkern.get("allreduce", (0.0, 0))[0] / ksteps, 4)
+                leg["per_rank_pairs_per_s"] = per_rank_rates(time_leg.last_per_rank, ksteps)
+                leg.update(sync_bn_fields())
             if tdtype == "f32":
                 train_info = leg
             else:
@@ -700,7 +793,7 @@ def main():
                                           "H2D on a copy stream under the previous batch's forward, D2H on a third stream)"}
     # ---- short dgcnn / loader / icp legs (default one-GPU inference run only)
     extra = None
-    if world == 1 and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
+    if not dist_on and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
         extra = extra_legs(eng, local_rank, args.min_leg_seconds)
     if dist is not None:
         dist.barrier()
@@ -718,6 +811,9 @@ def main():
                        ("SynthCars widths, DGCNN edge-conv branch (k=20), inference, batch=%d pairs/GPU, N=%d, fp32 (BASELINE.json configs[4] shape)" % (B, npts)),
                        "pairs_per_gpu": B, "num_points": npts, "parallelism": f"batch-split x{world} (no collective)", "devices_used": world},
             "roofline": head_roof, "spinup_steps_untimed": spinup_steps,
+            # every call of the headline step in this process (spin-up, warm-up, the K timed steps, their repeat with the timers off, the
+            # sustained loop): tools/summarize_prof.py divides a profiled run's dispatch counts by THIS number
+            "steps_executed": executed[0],
             "without_kernel_timers": {"value": round(world * B * args.steps / dt_off, 1), "ms_per_step": round(dt_off / args.steps * 1e3, 4),
                                       "what": "the same K steps again with the per-kernel HIP-event timers off (`value` is the region they run in)"},
             "whole_path_tflops": round(FLOPS_PER_PAIR_TOTAL * B * args.steps / dt / 1e12 * 1.0, 2)
@@ -731,10 +827,16 @@ def main():
             if dg:
                 line["config"]["workload"] = ("training step, DGCNN edge-conv branch (k=20, SynthCars widths), batch=%d pairs/GPU, N=%d, %s "
                                               "(BASELINE.json configs[4] shape)" % (B, npts, "bf16 forward convs + h1 Q2, rest fp32" if args.train_dtype == "bf16" else "f32"))
-            line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients, %d ranks)" % rccl_ranks if world > 1 else "")
+            line["config"]["parallelism"] = f"data parallel x{world}" + (" (RCCL all-reduce of gradients, %d ranks)" % rccl_ranks if dist_on else "")
+            line["bn_mode"] = bn_mode
             line["flops_per_pair_survey"] = FLOPS_PER_PAIR_TRAIN_SURVEY if not dg and npts == N_POINTS else None
-            if world > 1:
+            if dist_on:
                 line["allreduce_exposed_ms_per_step"] = round(kern.get("allreduce", (0.0, 0))[0] / args.steps, 4)
+                line.update(sync_bn_fields())
+        if dist_on:
+            line["per_rank_pairs_per_s"] = per_rank_rates(head_per_rank, args.steps)
+        if args.force_dist:
+            line["forced_dist"] = "world-1 rehearsal of the multi-GPU code path (torch.distributed.run --nproc-per-node=1, NCCL process group, RCCL communicator of one rank)"
         if args.mode == "infer" and args.infer_dtype == "bf16x3":
             line["dtype"] = "bf16x3"
             line["metric"] += " [split-bf16 backbone]"
@@ -751,7 +853,7 @@ def main():
             line["cpu_baseline"] = cpu_info
         if extra is not None:
             line.update(extra_seconds=extra.pop("seconds"), **extra)
-        line["options"] = opts0
+        line["options"] = engine_options(eng)   # as the legs left them (allreduce_overlap, sync_bn, ... are set after the engine is created)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

@@ -35,8 +35,10 @@ def _check_common(d, steps, warmup):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == {"hbm": "GB/s", "mfma": "TFLOP/s", "valu": "Ginstr/s"}[r["bound"]]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0.0 < r["frac"] < 1.0
+    # every call of the headline step is accounted for (tools/summarize_prof.py normalises profiled runs by this number)
+    assert d["steps_executed"] >= d["spinup_steps_untimed"] + warmup + 2 * steps
 
 
 def test_default_line(gpu_required):
@@ -76,3 +78,32 @@ def test_other_lines(gpu_required, args, kernel):
     d = _run(*args, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--sustained-seconds", "0")
     _check_common(d, 5, 1)
     assert d["roofline"]["kernel"].startswith(kernel), d["roofline"]["kernel"]
+    if kernel == "train_bwd_b2":
+        # pass B2's bf16 form is vector-instruction-issue-bound: quoted against the VALU issue rate, the matrix-pipe figure kept beside it
+        r = d["roofline"]
+        assert r["bound"] == "valu" and r["peak"] == 1228.8 and r["matrix_pipe"]["unit"] == "TFLOP/s" and r["valu_instr_per_launch"] > 0
+        assert d["bn_mode"] == "local"
+    assert d["steps_executed"] == d["spinup_steps_untimed"] + 1 + 2 * 5
+
+
+@pytest.mark.parametrize("args", [("--mode", "train", "--train-dtype", "bf16", "--allreduce-overlap", "1"),
+                                  ("--mode", "train", "--sync-bn", "1", "--allreduce-overlap", "0"),
+                                  ("--min-leg-seconds", "0.05", "--no-split-leg", "--no-pcie-leg")])
+def test_force_dist_rehearsal_at_world_1(gpu_required, args):
+    """The code a --gpus N > 1 run takes -- bench.py re-launching itself under torch.distributed.run, init_process_group("nccl",
+    device_id=...), the library's RCCL communicator (alignnet3d.parallel.init_comm), barriers, max over ranks, the per-rank gather, the
+    sustained loop's flag all-reduce, the training headline and the training legs with both --allreduce-overlap values and
+    --sync-bn 1 -- rehearsed at world = 1 on this box's one GPU (--force-dist), so that the driver's 8-GPU node is not its first
+    execution.  What a 1-GPU box cannot show is xGMI itself: the scaling curve stays the driver's to measure."""
+    d = _run("--force-dist", *args, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--sustained-seconds", "0.6")
+    _check_common(d, 5, 1)
+    assert "forced_dist" in d and d["n_gpus"] == 1
+    assert d["per_rank_pairs_per_s"]["ranks"] == 1 and abs(d["per_rank_pairs_per_s"]["min"] - d["value"]) <= 2e-2 * d["value"]
+    assert d["sustained"]["steps"] > 5
+    if "--mode" in args:
+        assert "RCCL all-reduce of gradients, 1 ranks" in d["config"]["parallelism"] and "allreduce_exposed_ms_per_step" in d
+        assert d["bn_mode"] == ("sync" if "--sync-bn" in args else "local")
+        assert d["options"]["allreduce_overlap"] in (0, 1)
+    else:
+        for leg in (d["train"], d["train"]["bf16"]):
+            assert leg["rccl_ranks"] == 1 and leg["bn_mode"] == "local" and leg["per_rank_pairs_per_s"]["ranks"] == 1, leg

@@ -75,9 +75,49 @@ def test_pmc_traffic_per_step_is_per_launch_times_launches_per_step():
     assert abs(k["hbm_bytes_per_launch"] - (2 * 4540.0 + 1170.0) * 1024) < 1e-6
     assert abs(k["hbm_bytes_per_step"] - 3 * k["hbm_bytes_per_launch"]) < 1e-6
     assert abs(t["hbm_bytes_per_step"] - sum(v["hbm_bytes_per_step"] for v in t["kernels"].values())) < 1e-6
-    # and the committed summaries of this round obey it
+    # and the committed summaries obey it
     import glob
     import json
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r04_*pmc_traffic.json")):
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r0[45]_*pmc_traffic.json")):
         for name, v in json.load(open(f))["kernels"].items():
             assert abs(v["hbm_bytes_per_step"] - v["hbm_bytes_per_launch"] * v["launches_per_step"]) <= 1e-6 * max(1.0, v["hbm_bytes_per_step"]), (f, name)
+
+
+def test_steps_of_counts_every_step_the_profiled_process_ran(tmp_path):
+    """bench.py ran the K timed steps a second time with the kernel timers off and steps_of() did not count them, so every
+    per-step figure was inflated (the line said 3.0 launches per step, the summary 3.5).  The bench line now carries `steps_executed`;
+    older lines are rebuilt from their parts including the repeat."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import json
+    import summarize_prof as S
+    new = {"steps": 20, "warmup": 3, "spinup_steps_untimed": 96, "steps_executed": 139, "config": {"pairs_per_gpu": 256, "num_points": 1024}}
+    old = {"steps": 20, "warmup": 3, "spinup_steps_untimed": 96, "without_kernel_timers": {"value": 1.0}, "config": {"pairs_per_gpu": 256, "num_points": 1024}}
+    r3 = {"steps": 20, "warmup": 3, "spinup_steps_untimed": 96, "config": {"pairs_per_gpu": 256, "num_points": 1024}}
+    for j, want in ((new, 139), (old, 139), (r3, 119)):
+        p = tmp_path / "b.log"
+        p.write_text("noise\n" + json.dumps(j) + "\n")
+        n, shape = S.steps_of(str(p))
+        assert n == want and shape == {"pairs_per_gpu": 256, "num_points": 1024}
+
+
+def test_committed_summaries_agree_with_their_bench_lines_on_launches_per_step():
+    """Each committed PMC traffic summary of round 5 on: the dominant kernel's launches per step equals what the bench line of the same
+    profiled command reports (3.0 for the three-stage backbones) to 1 % -- the check that would have caught rounds 3 and 4."""
+    import glob
+    import json
+    import re
+    checked = 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        m = re.fullmatch(r"r(\d+)_(.*?)_?pmc_traffic\.json", os.path.basename(f))
+        if int(m.group(1)) < 5:
+            continue
+        line_f = os.path.join(ROOT, "profiles", "r%s_%sbench_under_rocprof.json" % (m.group(1), m.group(2) + "_" if m.group(2) else ""))
+        if not os.path.exists(line_f):
+            continue
+        roof = json.load(open(line_f))["roofline"]
+        kern = json.load(open(f))["kernels"]
+        hit = sum(v["launches_per_step"] for name, v in kern.items() if roof["kernel"] in name)   # (all instantiations of that kernel)
+        assert hit > 0, (f, roof["kernel"])
+        assert abs(hit - roof["launches_per_step"]) <= 0.01 * roof["launches_per_step"], (f, hit, roof["launches_per_step"])
+        checked += 1
+    print("summaries checked:", checked)

@@ -981,3 +981,66 @@ def test_global_loss_with_identical_virtual_ranks(gpu_required, backbone, bf16):
             worst = max(worst, err / (0.25 * float(np.abs(g0[n]).max())))
         assert err <= 0.25 * (rtol * float(np.abs(g0[n]).max()) + 1e-6 * gs), (n, err, float(np.abs(g0[n]).max()))
     print(backbone, "bf16" if bf16 else "fp32", "global_loss (2 identical virtual ranks): loss ratio %.7f, worst relative deviation of 4 x gradient %.2e" % (r1["loss"] / r0["loss"], worst))
+
+
+PINNED_CASES = {
+    # name: (backbone, widths, N, B, bf16, tail)
+    "pointnet": ("pointnet", dict(s1=(32, 64, 96), s2=(32, 64, 128), emb=(32, 64, 160)), 256, 16, 0, 1),
+    "pointnet_std": ("pointnet", STD, 192, 12, 0, 1),
+    "pointnet_std_bf16": ("pointnet", STD, 192, 48, 1, 1),
+    "pointnet_deep_tail": ("pointnet", GENERAL_DEPTH["default_json_like"], 128, 8, 0, 1),
+    "pointnet_deep_layerwise": ("pointnet", GENERAL_DEPTH["odd_shapes"], 128, 5, 0, 0),
+    "dgcnn": ("dgcnn", dict(s1=(32, 64, 96), s2=(32, 64, 128), emb=(64, 128, 160)), 128, 8, 0, 1),
+    "dgcnn_std_bf16": ("dgcnn", STD, 128, 16, 1, 1),
+    "dgcnn_general": ("dgcnn", DGCNN_GENERAL["mixed"], 128, 5, 0, 1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PINNED_CASES))
+def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
+    """Every training code path once more, with the oracle PINNED to the engine's own decisions (alignnet_debug_train_decisions: yaw
+    classes models/tp8.py:296, max-pool winners utils/tf_util.py:350-373, and for dgcnn the neighbour slots models/tp8.py:42 and the
+    neighbour table utils/tf_util_dgcnn.py:638-676) instead of re-deciding them in fp64.  Two checks:
+      * the decisions themselves: each engine winner must be a maximum of the oracle's own values (fp32: to within 1e-4 of their
+        scale -- rounding of the fp32 forward; bf16 convs: 2e-2, the operand rounding) and the neighbour table a k-nearest set in
+        fp64 distances -- this is the test of the arg-max / selection kernels, on the fused, hybrid and layer-by-layer paths;
+      * the continuous rest: with ties taken out of the comparison the bars do not need the conditioning allowances of the free
+        tests above (5e-4 .. 1e-2 depending on the batch): every tensor within 5e-4 of its largest entry in fp32 (the small-batch
+        BatchNorms of these shapes amplify the fp32 forward's rounding to ~1e-4), 2e-2 with bf16 convs."""
+    backbone, w, N, B, bf16, tail = PINNED_CASES[case]
+    cfg = small_cfg(N=N, nb=12, fc=(64, 32), backbone=backbone, **w)
+    cfg["training"]["batch_size"] = B
+    spec, P32 = oracle_params(cfg, seed=13)
+    d = R.synth_pairs(B, N, seed=13, dtype=np.float32)
+    rng = np.random.default_rng(13)
+    du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
+    eng = alignnet3d.Engine(cfg)
+    eng.set_variables(P32)
+    eng.set_option("train_fused_tail", tail)
+    eng.set_option("train_matmul_bf16", bf16)
+    res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    dec = eng.debug_train_decisions(B)
+    assert dec["yaw"].shape == (2, B) and dec["yaw"].min() >= 0 and dec["yaw"].max() < 12
+    for s_, a in enumerate(dec["pool"]):
+        assert a.min() >= 0 and a.max() < N, (s_, a.min(), a.max())
+    if backbone == "dgcnn":
+        assert dec["knn"].shape == (2, B, N, 20) and all(a.min() >= 0 and a.max() < 20 for a in dec["slot"])
+    rep = []
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=bool(bf16), pinned=dec, report=rep)
+    gap_bar, tol, ptol = (2e-2, 2e-2, 2e-2) if bf16 else (1e-4, 5e-4, 1e-4)
+    kinds = {}
+    for what, gap, scale, differ, total in rep[0]:
+        k = what.split(":")[0]
+        kinds[k] = max(kinds.get(k, 0.0), gap / max(scale, 1.0))
+    print(case, "pinned: worst decision gap / scale", kinds, "re-decided by the free oracle:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
+    assert set(kinds) == ({"yaw", "pool"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn"})
+    assert all(g <= gap_bar for g in kinds.values()), kinds
+    for k in ep_ref:
+        np.testing.assert_allclose(res[k], ep_ref[k], rtol=ptol, atol=ptol, err_msg=k)
+    assert abs(res["loss"] - loss_ref) <= (5e-3 if bf16 else 1e-5) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    bad, worst = _grad_check(eng, spec, grads, tol)
+    print(case, "pinned: loss", res["loss"], loss_ref, "worst relative gradient error", worst)
+    assert not bad, bad
+    with pytest.raises(alignnet3d.EngineError):
+        eng._check(eng._lib.alignnet_debug_train_decisions(eng._h, 1, 0, dec["yaw"].ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32)), 3))   # wrong count
+    eng.close()

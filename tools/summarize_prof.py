@@ -58,7 +58,15 @@ def steps_of(log):
         for line in open(log):
             if line.startswith("{"):
                 j = json.loads(line)
-                return (j["steps"] + j["warmup"] + j.get("spinup_steps_untimed", 0),
+                # bench.py counts every call of the headline step itself ("steps_executed": spin-up, warm-up, the K timed steps, their repeat
+                # with the kernel timers off, the sustained loop).  Lines of rounds 1 - 4 lack the field: their total is rebuilt from the parts,
+                # INCLUDING the timers-off repeat of the K steps that round 4's bench.py ran and round 4's steps_of() forgot (VERDICT round 4,
+                # weak 8: every per-step figure of profiles/r04_* is inflated by (W + S + 2 K) / (W + S + K)).
+                n = j.get("steps_executed")
+                if n is None:
+                    n = j["steps"] + j["warmup"] + j.get("spinup_steps_untimed", 0) + (j["steps"] if "without_kernel_timers" in j else 0) + \
+                        (j.get("sustained") or {}).get("steps", 0)
+                return (n,
                         {"pairs_per_gpu": j["config"].get("pairs_per_gpu"), "num_points": j["config"].get("num_points")})
     except OSError:
         pass
