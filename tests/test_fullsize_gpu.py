@@ -153,6 +153,28 @@ def test_bf16_training_learns_like_fp32(gpu_required):
     assert final[1][2] < 2.0 * final[0][2] + 0.05 and final[0][2] < 2.0 * final[1][2] + 0.05, final
 
 
+def test_bf16_converges_like_fp32(gpu_required):
+    """BASELINE.json configs[2] trains: a shortened run of tools/convergence_ab.py (the committed full A/B is profiles/r05_convergence.json:
+    3000 steps, three seeds each) -- 256 pairs x 1024 points per step from a fixed 2048-example dataset through the device sampler,
+    the reference's loop and schedules (train.py:335-383), held-out eval-mode metrics taken as evaluation.py:128-289 takes them.
+    bf16's final held-out translation and angle errors (mean over its seeds) must lie within the fp32 seeds' spread + 10 %, both must
+    have learnt (held-out errors far below the untrained net's), and every loss and prediction must be finite."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import convergence_ab as CA
+    res = CA.run_ab(steps=700, seeds=3, every=350, n_train=2048, n_held=512)
+    s = res["summary"]
+    print("convergence A/B (700 steps):", s)
+    for r in res["runs"]:
+        assert r["finite_losses"] and all(c["finite"] for c in r["curve"]), (r["dtype"], r["seed"])
+        first, last = r["curve"][0], r["curve"][-1]
+        assert last["train_loss_mean"] < first["train_loss_mean"], (r["dtype"], r["seed"], first["train_loss_mean"], last["train_loss_mean"])
+    for key in ("mean_dist_translation", "mean_dist_angle"):
+        assert s[key]["bf16"]["mean"] <= 1.10 * s[key]["f32"]["max"], (key, s[key])
+    assert s["mean_dist_translation"]["f32"]["mean"] < 0.25 and s["mean_dist_translation"]["bf16"]["mean"] < 0.25, s   # (translations are U(0, 1) m long: an untrained net sits at ~0.5 m)
+
+
 def test_dgcnn_training_learns(gpu_required):
     """The DGCNN branch (tp8.py:30-46) trains end to end: 120 Adam steps on fresh synthetic batches (32 pairs x 256 points,
     SynthCars widths, k = 20 graph rebuilt every step) cut the training loss by >= 25 % (mean of the first vs the last 10
