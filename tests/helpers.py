@@ -56,3 +56,22 @@ def compare_forward(ep_hip, ep_ref, nb, atol=1e-4, rtol=1e-4, margin_eps=1e-3):
         worst[k] = float(err.max()) if err.size else 0.0
         assert np.all(err <= atol + rtol * np.abs(b)), (k, worst[k])
     return worst, int((~stable).sum())
+
+
+def varied_pairs(B, N, seed=1234, dtype=np.float32, lo=0.4, hi=1.6):
+    """synth_pairs with objects of different size and proportions: every pair's box is stretched by its own U(lo, hi) factor per axis in
+    the object frame (both clouds of a pair show the same object; labels unchanged).  Why the tests want it: alignnet3d/synth.py draws ONE
+    box shape for every pair, so after stage 3's canonicalisation (models/tp8.py:122-127) all clouds of a batch look alike, the pooled
+    features differ between samples only by sampling noise, and the heads' batch normalisation (utils/tf_util.py:455-492) divides by that
+    small spread: the fp64 oracle's own gradient then moves by 1e-3 .. 1e-2 when its inputs move by one fp32 rounding
+    (tools/pinned_report.py prints it).  Real batches hold different objects; with varied boxes the same perturbation moves the
+    gradient by ~1e-5 .. 1e-4, and a sharp bar means something."""
+    rng = np.random.default_rng(seed + 77)
+    d = {k: v.astype(np.float64) for k, v in R.synth_pairs(B, N, seed=seed, dtype=np.float64).items()}
+    sc = rng.uniform(lo, hi, (B, 1, 3))
+    for k, c, a in (("pcs1", "pc1_centers", "pc1_angles"), ("pcs2", "pc2_centers", "pc2_angles")):
+        p = d[k] - d[c][:, None, :]
+        cs, sn = np.cos(d[a][:, 0])[:, None], np.sin(d[a][:, 0])[:, None]
+        q = np.stack([p[..., 0] * cs + p[..., 1] * sn, -p[..., 0] * sn + p[..., 1] * cs, p[..., 2]], -1) * sc   # object frame, stretched
+        d[k] = np.stack([q[..., 0] * cs - q[..., 1] * sn, q[..., 0] * sn + q[..., 1] * cs, q[..., 2]], -1) + d[c][:, None, :]
+    return {k: v.astype(dtype) for k, v in d.items()}
