@@ -1004,9 +1004,8 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
       * the decisions themselves: each engine winner must be a maximum of the oracle's own values (fp32: to within 1e-4 of their
         scale -- rounding of the fp32 forward; bf16 convs: 2e-2, the operand rounding) and the neighbour table a k-nearest set in
         fp64 distances -- this is the test of the arg-max / selection kernels, on the fused, hybrid and layer-by-layer paths;
-      * the continuous rest: with ties taken out of the comparison the bars do not need the conditioning allowances of the free
-        tests above (5e-4 .. 1e-2 depending on the batch): every tensor within 5e-4 of its largest entry in fp32 (the small-batch
-        BatchNorms of these shapes amplify the fp32 forward's rounding to ~1e-4), 2e-2 with bf16 convs."""
+      * the continuous rest, held to the oracle's own conditioning on the batch: every tensor and the whole gradient within
+        max(5e-4, 8 x what the pinned fp64 oracle itself moves by when its inputs move by one fp32 rounding) (bf16 convs: max(2e-2, 1.5 x))."""
     backbone, w, N, B, bf16, tail = PINNED_CASES[case]
     cfg = small_cfg(N=N, nb=12, fc=(64, 32), backbone=backbone, **w)
     cfg["training"]["batch_size"] = B
@@ -1027,20 +1026,32 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
         assert dec["knn"].shape == (2, B, N, 20) and all(a.min() >= 0 and a.max() < 20 for a in dec["slot"])
     rep = []
     ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], bf16_lift=bool(bf16), pinned=dec, report=rep)
-    gap_bar, tol, ptol = (2e-2, 2e-2, 2e-2) if bf16 else (1e-4, 5e-4, 1e-4)
+    gap_bar = 2e-2 if bf16 else 1e-4
     kinds = {}
     for what, gap, scale, differ, total in rep[0]:
         k = what.split(":")[0]
         kinds[k] = max(kinds.get(k, 0.0), gap / max(scale, 1.0))
-    print(case, "pinned: worst decision gap / scale", kinds, "re-decided by the free oracle:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
+    print(case, "pinned: worst decision gap / scale", kinds, "not the oracle's own first maximum:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
     assert set(kinds) == ({"yaw", "pool"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn"})
     assert all(g <= gap_bar for g in kinds.values()), kinds
-    for k in ep_ref:
-        np.testing.assert_allclose(res[k], ep_ref[k], rtol=ptol, atol=ptol, err_msg=k)
+    # the continuous rest against the oracle's own conditioning (tests/test_fullsize_gpu.py::_check_train_against_autograd has the story):
+    # the pinned oracle once more with its inputs moved by one fp32 rounding; the engine must be within max(floor, 8 x that movement)
+    from tests.test_fullsize_gpu import _grad_compare, _one_rounding
+    ep2, loss2, g2, _ = _oracle(cfg, P32, _one_rounding(d), du, eng.state()["bn_decay"], bf16_lift=bool(bf16), pinned=dec)
+    ge = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
+    _, relf, cos, rl2, _ = _grad_compare(ge.__getitem__, spec, grads)
+    _, sens, scos, srl2, _ = _grad_compare(lambda n: g2[n], spec, grads)
+    spred = max(float(np.abs(ep2[k] - ep_ref[k]).max()) for k in ep_ref)
+    pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
+    floor, kc = (2e-2, 1.5) if bf16 else (5e-4, 8.0)
+    bar_t, bar_l2, bar_p = max(floor, kc * max(sens.values())), max(floor, kc * srl2), max(2e-2 if bf16 else 1e-4, kc * spred)
+    print(case, "pinned: engine vs oracle: predictions %.2e, relative L2 %.2e, worst tensor %.2e (%s) | oracle under one input rounding: predictions %.2e, "
+          "relative L2 %.2e, worst tensor %.2e" % (pred, rl2, max(relf.values()), max(relf, key=relf.get), spred, srl2, max(sens.values())))
+    assert pred <= bar_p, (pred, bar_p)
     assert abs(res["loss"] - loss_ref) <= (5e-3 if bf16 else 1e-5) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
-    bad, worst = _grad_check(eng, spec, grads, tol)
-    print(case, "pinned: loss", res["loss"], loss_ref, "worst relative gradient error", worst)
-    assert not bad, bad
+    assert rl2 <= bar_l2, (rl2, bar_l2)
+    bad = {n: e for n, e in relf.items() if e > bar_t}
+    assert not bad, (bar_t, bad)
     with pytest.raises(alignnet3d.EngineError):
         eng._check(eng._lib.alignnet_debug_train_decisions(eng._h, 1, 0, dec["yaw"].ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32)), 3))   # wrong count
     eng.close()
