@@ -88,6 +88,7 @@ SYMBOLS = {
     "alignnet_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "alignnet_comm_loopback_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "alignnet_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "alignnet_comm_init_grad": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "alignnet_comm_allreduce_grads": (C.c_int, [H]),
     "alignnet_comm_average_shadows": (C.c_int, [H]),
     "alignnet_get_state": (C.c_int, [H, C.POINTER(State)]),

@@ -442,6 +442,11 @@ class Engine:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.alignnet_comm_init(self._h, rank, world, buf))
 
+    def comm_init_grad(self, rank, world, unique_id):
+        """A second communicator of the same ranks for the gradient buckets alone (include/alignnet_hip.h: alignnet_comm_init_grad)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.alignnet_comm_init_grad(self._h, rank, world, buf))
+
     def comm_allreduce_grads(self):
         self._check(self._lib.alignnet_comm_allreduce_grads(self._h))
 

@@ -68,11 +68,16 @@ def average_ema_shadows(engine, dist=None):
     return len(names)
 
 
-def init_comm(engine, dist, make_id=None):
-    """Create the RCCL communicator of `engine` across the ranks of the default process group."""
+def init_comm(engine, dist, make_id=None, grad_communicator=False):
+    """Create the RCCL communicator of `engine` across the ranks of the default process group.
+    grad_communicator: also a second communicator for the gradient buckets alone (Engine.comm_init_grad) -- with sync_bn the per-layer
+    sums and the buckets then do not serialise on one communicator."""
     make_id = make_id or type(engine).comm_unique_id
     uid = broadcast_bytes(dist, make_id() if dist.get_rank() == 0 else None)
     engine.comm_init(dist.get_rank(), dist.get_world_size(), uid)
+    if grad_communicator:
+        uid2 = broadcast_bytes(dist, make_id() if dist.get_rank() == 0 else None)
+        engine.comm_init_grad(dist.get_rank(), dist.get_world_size(), uid2)
     return uid
 
 

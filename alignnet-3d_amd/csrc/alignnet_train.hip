@@ -2065,6 +2065,7 @@ int alignnet_train_get_option(alignnet_handle* h, const std::string& k, int64_t*
 {
   (void)h;
   if (k == "loopback_timeout_s") { *value = (int64_t)loop_timeout().count(); return 0; }
+  if (k == "grad_communicator") { *value = h->comm_grad ? 1 : 0; return 0; }   // 1: the gradient buckets have a communicator of their own (alignnet_comm_init_grad)
   return -1;
 }
 
@@ -2153,11 +2154,13 @@ typedef int (*InitRankByValue)(void**, int, UniqueId, int);
 // W handles of one process on one device -- the multi-rank code paths with distinct shards on a 1-GPU box).
 struct CommImpl { void* nccl = nullptr; LoopComm* loop = nullptr; };
 static CommImpl* comm_of(const alignnet_handle* h) { return static_cast<CommImpl*>(h->comm); }
+// the communicator the gradient buckets travel on: the handle's second one when alignnet_comm_init_grad created it, else the first
+static CommImpl* grad_comm_of(const alignnet_handle* h) { return static_cast<CommImpl*>(h->comm_grad ? h->comm_grad : h->comm); }
 
 // sum of `n` floats / doubles over the ranks, in place, in stream order on `s`
-static int comm_allreduce(alignnet_handle* h, void* buf, size_t n, bool is_double, hipStream_t s, const char* what)
+static int comm_allreduce(alignnet_handle* h, void* buf, size_t n, bool is_double, hipStream_t s, const char* what, CommImpl* c = nullptr)
 {
-  CommImpl* c = comm_of(h);
+  if (!c) c = comm_of(h);
   if (c->loop) {
     std::string err;
     if (loop_collective(c->loop, is_double ? kLoopSumF64 : kLoopSumF32, buf, nullptr, n, s, err)) return fail(h, std::string(what) + ": " + err);
@@ -2187,6 +2190,7 @@ static int comm_allgather(alignnet_handle* h, const void* src, void* dst, size_t
 static void comm_poison(alignnet_handle* h)
 {
   if (h && h->comm && comm_of(h)->loop) comm_of(h)->loop->g->poison();
+  if (h && h->comm_grad && static_cast<CommImpl*>(h->comm_grad)->loop) static_cast<CommImpl*>(h->comm_grad)->loop->g->poison();
 }
 
 extern "C" int alignnet_comm_unique_id(uint8_t id[128])
@@ -2206,29 +2210,51 @@ extern "C" int alignnet_comm_loopback_id(uint8_t id[128])
   return 0;
 }
 
+static CommImpl* comm_create(alignnet_handle* h, int rank, int world, const uint8_t id[128])
+{
+  if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return nullptr; }
+  std::string err;
+  if (loop_is_id(id)) {
+    LoopComm* lc = loop_join(id, rank, world, h->cfg.device, err);
+    if (!lc) { h->err = err; return nullptr; }
+    CommImpl* c = new CommImpl(); c->loop = lc;
+    return c;
+  }
+  if (!load_rccl(err)) { h->err = err; return nullptr; }
+  UniqueId u;
+  std::memcpy(u.internal, id, 128);
+  void* comm = nullptr;
+  const int rc = reinterpret_cast<InitRankByValue>(g_rccl.CommInitRank)(&comm, world, u, rank);
+  if (rc != 0) { h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return nullptr; }
+  CommImpl* c = new CommImpl(); c->nccl = comm;
+  return c;
+}
+
 extern "C" int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128])
 {
   if (!h) return 1;
   if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, "alignnet_comm_init: bad arguments");
   if (h->comm) return fail(h, "alignnet_comm_init: this handle already has a communicator");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
-  if (loop_is_id(id)) {
-    std::string err;
-    LoopComm* lc = loop_join(id, rank, world, h->cfg.device, err);
-    if (!lc) return fail(h, err);
-    CommImpl* c = new CommImpl(); c->loop = lc;
-    h->comm = c; h->comm_world = world; h->comm_rank = rank;
-    return 0;
-  }
-  std::string err;
-  if (!load_rccl(err)) return fail(h, err);
-  UniqueId u;
-  std::memcpy(u.internal, id, 128);
-  void* comm = nullptr;
-  const int rc = reinterpret_cast<InitRankByValue>(g_rccl.CommInitRank)(&comm, world, u, rank);
-  if (rc != 0) return fail(h, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-  CommImpl* c = new CommImpl(); c->nccl = comm;
+  CommImpl* c = comm_create(h, rank, world, id);
+  if (!c) return 1;
   h->comm = c; h->comm_world = world; h->comm_rank = rank;
+  return 0;
+}
+
+// A SECOND communicator of the same ranks for the gradient buckets alone.  NCCL-style communicators serialise the collectives issued
+// on them whatever stream they are issued on: with "sync_bn" a per-layer sum of the NEXT stage's backward (compute stream) queues
+// behind the gradient bucket of the previous stage (comm stream) when both use one communicator, and the bucket no longer travels
+// under the backward but in front of it.  With their own communicator the buckets only meet the compute stream at the optimiser.
+extern "C" int alignnet_comm_init_grad(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128])
+{
+  if (!h) return 1;
+  if (!id) return fail(h, "alignnet_comm_init_grad: bad arguments");
+  if (!h->comm) return fail(h, "alignnet_comm_init_grad: create the handle's first communicator (alignnet_comm_init) before the gradient one");
+  if (h->comm_grad) return fail(h, "alignnet_comm_init_grad: this handle already has a gradient communicator");
+  if (world != h->comm_world || rank != h->comm_rank) return fail(h, "alignnet_comm_init_grad: rank / world differ from the first communicator's");
+  CommImpl* c = comm_create(h, rank, world, id);
+  if (!c) return 1;
+  h->comm_grad = c;
   return 0;
 }
 
@@ -2236,13 +2262,15 @@ extern "C" void alignnet_comm_free(alignnet_handle* h)
 {
   if (!h) return;
   if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
-  if (h->comm) {
-    CommImpl* c = comm_of(h);
+  for (void** slot : {&h->comm_grad, &h->comm}) {
+    if (!*slot) continue;
+    CommImpl* c = static_cast<CommImpl*>(*slot);
     if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
     if (c->loop) { if (h->stream) hipStreamSynchronize(h->stream); loop_leave(c->loop); }
     delete c;
-    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+    *slot = nullptr;
   }
+  h->comm_world = 1; h->comm_rank = 0;
   for (auto& e : h->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
   if (h->comm_stream) { hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
 }
@@ -2263,7 +2291,7 @@ static int comm_bucket(alignnet_handle* h, int stage, hipStream_t after)   // af
   if (hi <= lo || hi > h->n_trainable) return fail(h, "comm_bucket: gradient segments are not in stage order");
   HIP_TRY(h, hipEventRecord(h->comm_ev[stage], after ? after : h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ev[stage], 0));
-  if (comm_allreduce(h, w->grad + lo, hi - lo, false, h->comm_stream, "gradient bucket")) return 1;
+  if (comm_allreduce(h, w->grad + lo, hi - lo, false, h->comm_stream, "gradient bucket", grad_comm_of(h))) return 1;
   h->comm_buckets++;
   h->comm_order = h->comm_order * 10 + 4 + stage;
   return 0;
@@ -2333,7 +2361,7 @@ extern "C" int alignnet_comm_allreduce_grads(alignnet_handle* h)
   TrainWS* w = tws(h);
   if (!w->grad) return fail(h, "alignnet_comm_allreduce_grads: no gradients computed yet");
   // one bucket: the whole trainable vector (8.66 MB fp32 for the SynthCars widths), ncclFloat = 7, ncclSum = 0
-  return comm_allreduce(h, w->grad, h->n_trainable, false, h->stream, "gradient");
+  return comm_allreduce(h, w->grad, h->n_trainable, false, h->stream, "gradient", grad_comm_of(h));
 }
 
 // ---------------------------------------------------------------------------------

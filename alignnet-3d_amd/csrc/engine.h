@@ -138,6 +138,7 @@ struct alignnet_handle {
   // seed base of the device-side dropout stream at the current step counter (alignnet_train.hip: bn_args, dropout_uniforms_kernel)
   uint64_t dropout_seed_base() const { return (cfg.seed + dropout_stream * 0xD1B54A32D192ED03ull) * 0x9E3779B97F4A7C15ull + (uint64_t)step * 16; }
   void* comm = nullptr;            // alignnet_train.hip: CommImpl (RCCL communicator or a rank of an in-process loopback group)
+  void* comm_grad = nullptr;       // optional second communicator of the same ranks, used by the gradient buckets only (alignnet_comm_init_grad)
   int comm_world = 1, comm_rank = 0;
   // gradient all-reduce in three buckets (stage 3 | stage 2 | stage 1 segment of the flat gradient) on a side stream, each issued as
   // soon as that stage's backward has produced its segment; the optimiser waits for the last one (alignnet_train.hip: comm_bucket)

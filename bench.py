@@ -222,7 +222,7 @@ def engine_options(eng):
     """The option set the timed engine ran with (every key that changes which kernels run), for the JSON line."""
     import alignnet3d
     keys = ("train_matmul_bf16", "infer_matmul_bf16x3", "train_fused_tail", "train_phase3_tile64", "train_dw_side_stream", "allreduce_overlap",
-            "sync_bn", "global_loss", "ab_mask", "ab_tiles_per_wg")
+            "sync_bn", "global_loss", "grad_communicator", "ab_mask", "ab_tiles_per_wg")
     o = {k: eng.get_option(k) for k in keys}
     o["library"] = os.path.basename(alignnet3d.library_path())
     try:   # the ablation build (csrc/ablate.h) knows this key; the shipped library does not
@@ -430,6 +430,9 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short dgcnn / loader / icp legs the default --gpus 1 inference run appends")
+    ap.add_argument("--grad-communicator", type=int, default=0,
+                    help="data-parallel training: 1 = the gradient buckets travel on a second RCCL communicator of their own (alignnet_comm_init_grad), so that "
+                         "sync-BN's per-layer sums do not serialise behind them; 0 = one communicator for everything")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal of the multi-GPU code path on ONE GPU: re-launch under torch.distributed.run with one rank and take every branch a "
                          "--gpus N > 1 run takes (NCCL process group with device_id, the library's RCCL communicator, barriers, max over ranks, the "
@@ -507,7 +510,7 @@ def main():
         """Data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed."""
         nonlocal rccl_ranks
         from alignnet3d import parallel
-        parallel.init_comm(eng, dist)
+        parallel.init_comm(eng, dist, grad_communicator=bool(args.grad_communicator))
         eng.set_option("allreduce_overlap", args.allreduce_overlap)
         if args.sync_bn:
             eng.set_option("sync_bn", 1); eng.set_option("global_loss", 1)

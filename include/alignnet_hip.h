@@ -214,6 +214,11 @@ int alignnet_comm_unique_id(uint8_t id[128]);
  * the same order (as with RCCL); a rank that fails breaks the group, the others return an error instead of waiting. */
 int alignnet_comm_loopback_id(uint8_t id[128]);
 int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
+/* Optional: a SECOND communicator of the same ranks (its own id, same rank / world as the first) that carries the gradient buckets
+ * only.  NCCL-style communicators serialise the collectives issued on them across streams; with sync_bn a per-layer sum of the next
+ * stage's backward would otherwise queue behind the previous stage's gradient bucket.  Results are identical with and without it
+ * (tests/test_loopback_gpu.py); alignnet_get_option("grad_communicator") reads 1 when it exists. */
+int alignnet_comm_init_grad(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
 int alignnet_comm_allreduce_grads(alignnet_handle* h);
 /* Average the BatchNorm EMA shadows (the non-trainable variables) over the ranks, on the device: local-BN data parallelism updates them
  * from each rank's own shard (utils/tf_util.py:476-485); the drop-in train.py calls this once per epoch so that every rank's eval-mode

@@ -87,7 +87,7 @@ def test_other_lines(gpu_required, args, kernel):
 
 
 @pytest.mark.parametrize("args", [("--mode", "train", "--train-dtype", "bf16", "--allreduce-overlap", "1"),
-                                  ("--mode", "train", "--sync-bn", "1", "--allreduce-overlap", "0"),
+                                  ("--mode", "train", "--sync-bn", "1", "--allreduce-overlap", "0", "--grad-communicator", "1"),
                                   ("--min-leg-seconds", "0.05", "--no-split-leg", "--no-pcie-leg")])
 def test_force_dist_rehearsal_at_world_1(gpu_required, args):
     """The code a --gpus N > 1 run takes -- bench.py re-launching itself under torch.distributed.run, init_process_group("nccl",
@@ -103,7 +103,8 @@ def test_force_dist_rehearsal_at_world_1(gpu_required, args):
     if "--mode" in args:
         assert "RCCL all-reduce of gradients, 1 ranks" in d["config"]["parallelism"] and "allreduce_exposed_ms_per_step" in d
         assert d["bn_mode"] == ("sync" if "--sync-bn" in args else "local")
-        assert d["options"]["allreduce_overlap"] in (0, 1)
+        assert d["options"]["allreduce_overlap"] == int(args[args.index("--allreduce-overlap") + 1])
+        assert d["options"]["grad_communicator"] == (1 if "--grad-communicator" in args else 0)
     else:
         for leg in (d["train"], d["train"]["bf16"]):
             assert leg["rccl_ranks"] == 1 and leg["bn_mode"] == "local" and leg["per_rank_pairs_per_s"]["ranks"] == 1, leg

@@ -22,10 +22,11 @@ U = ("s1_0", "s2_0", "s1_1", "s2_1", "rem")
 STD = dict(s1=(64, 128, 96), s2=(64, 128, 128), emb=(64, 128, 160))
 
 
-def run_ranks(W, cfg, body, options=(), variables=None):
+def run_ranks(W, cfg, body, options=(), variables=None, grad_comm=False):
     """W ranks = W threads, each with its own Engine joined to one loopback group; returns [body(rank, engine)] or raises the
     first rank's exception (a failing rank breaks the group, so the others return with an error instead of waiting)."""
     uid = alignnet3d.Engine.comm_loopback_id()
+    uid2 = alignnet3d.Engine.comm_loopback_id() if grad_comm else None   # a second group for the gradient buckets alone
     out, err = [None] * W, [None] * W
 
     def worker(r):
@@ -37,7 +38,10 @@ def run_ranks(W, cfg, body, options=(), variables=None):
             for k, v in options:
                 eng.set_option(k, v)
             eng.comm_init(r, W, uid)
-            assert eng.get_option("comm_world") == W
+            assert eng.get_option("comm_world") == W and eng.get_option("grad_communicator") == 0
+            if grad_comm:
+                eng.comm_init_grad(r, W, uid2)
+                assert eng.get_option("grad_communicator") == 1
             out[r] = body(r, eng)
         except BaseException as e:  # noqa: BLE001
             err[r] = e
@@ -371,6 +375,35 @@ def test_shadow_average_on_the_device(gpu_required):
     for r in range(1, W):
         for k in ranks[0]["out"]:
             np.testing.assert_array_equal(ranks[r]["out"][k], ranks[0]["out"][k], err_msg=k)
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_gradient_buckets_on_their_own_communicator(gpu_required, bf16):
+    """alignnet_comm_init_grad: a second communicator of the same ranks that carries the gradient buckets only, so that under sync_bn the
+    per-layer sums (compute stream) and the buckets (comm stream) do not serialise on one NCCL-style communicator.
+    Four ranks with distinct shards, sync_bn + global_loss, three full train steps each way: parameters after the steps, losses and the
+    issue order (backward 3, bucket 3, backward 2, bucket 2, backward 1, bucket 1) are identical bit for bit with one communicator and
+    with two; a second gradient communicator on a handle, or one with another rank, is refused."""
+    W, N, B = 4, 128, 16
+    cfg, spec, P32, d, du = setup("pointnet", N, B)
+    opts = (("sync_bn", 1), ("global_loss", 1), ("train_matmul_bf16", bf16))
+
+    def body(r, eng):
+        ds, us, lo, hi = shard(d, du, r, W)
+        losses = [eng.train_step(ds["pcs1"], ds["pcs2"], ds, us)["loss"] for _ in range(3)]
+        if eng.get_option("grad_communicator"):
+            with pytest.raises(alignnet3d.EngineError, match="already has a gradient communicator"):
+                eng.comm_init_grad(r, W, alignnet3d.Engine.comm_loopback_id())
+        return losses, {n: eng.get_variable(n).copy() for n in trainable(eng)}, eng.get_option("comm_order"), eng.get_option("comm_buckets")
+
+    one = run_ranks(W, cfg, body, opts, variables=P32)
+    two = run_ranks(W, cfg, body, opts, variables=P32, grad_comm=True)
+    for r in range(W):
+        assert one[r][0] == two[r][0], (one[r][0], two[r][0])
+        assert one[r][2] == two[r][2] == 362514 and one[r][3] == two[r][3] == 3
+        for n in one[r][1]:
+            np.testing.assert_array_equal(one[r][1][n], two[r][1][n], err_msg=n)
+            np.testing.assert_array_equal(two[0][1][n], two[r][1][n], err_msg=n)   # every rank holds the same parameters
 
 
 def test_collective_mismatch_and_failed_rank_do_not_hang(gpu_required):
