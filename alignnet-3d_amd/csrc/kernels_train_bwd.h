@@ -105,13 +105,25 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     // ---- per-cloud hit list, ONE segment per tile (ordered by channel): wave w counts, then fills, the tiles t = w, w + 4, ... ----
     static_assert(!SPM || kTW == 4, "tiles are dealt to four waves");
     int* cnt = wtot;   // reuse: [ntiles] counts live in hoff's tail until the prefix sum  (hoff has kTW * (ntiles + 1) + kTW ints)
+    // the cloud's arg-extreme rows and gradients ONCE into registers (lane l holds channels l, 64 + l, ...; C3 <= 1024): the two passes
+    // below walk them per tile -- re-read from memory per (tile, chunk) they were 2 x (ntiles / 4) x C3 / 64 dependent L2 round trips per
+    // wave in front of the first tile
+    constexpr int kIdQ = 16;
+    int idt[kIdQ], idrow[kIdQ]; float idg[kIdQ];
+    const int nq = (a.C3 + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < kIdQ; ++q) {
+      const int c = q * 64 + lane;
+      const bool ok = q < nq && c < a.C3;
+      const int id = ok ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+      idg[q] = ok ? a.gs[(size_t)cloud * a.C3 + c] : 0.f;
+      idt[q] = id >= 0 ? id / kTT : -1; idrow[q] = id >= 0 ? id % kTT : 0;
+    }
     for (int t = wave; t < ntiles; t += kTW) {
       int n = 0;
-      for (int base = 0; base < a.C3; base += 64) {
-        const int c = base + lane;
-        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-        n += __popcll(__ballot(id >= 0 && (id / kTT) == t));
-      }
+#pragma unroll
+      for (int q = 0; q < kIdQ; ++q)
+        if (q < nq) n += __popcll(__ballot(idt[q] == t));
       if (lane == 0) hoff[ntiles + 1 + t] = n;
     }
     __syncthreads();
@@ -123,20 +135,20 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
     for (int t = wave; t < ntiles; t += kTW) {
       int pos = hoff[t];
-      for (int base = 0; base < a.C3; base += 64) {
-        const int c = base + lane;
-        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-        const bool m = id >= 0 && (id / kTT) == t;
-        const unsigned long long mask = __ballot(m);
-        if (m) {
-          const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
-          hit_e[p] = c | ((id % kTT) << 16);
-          const float g = a.gs[(size_t)cloud * a.C3 + c];   // split once: bf16 hi | lo << 16 (16 significant bits)
-          const unsigned vh = to_bf16_bits(g), vl = to_bf16_bits(g - __uint_as_float(vh << 16));
-          reinterpret_cast<unsigned*>(hit_g)[p] = vh | (vl << 16);
+#pragma unroll
+      for (int q = 0; q < kIdQ; ++q)
+        if (q < nq) {
+          const bool m = idt[q] == t;
+          const unsigned long long mask = __ballot(m);
+          if (m) {
+            const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+            hit_e[p] = (q * 64 + lane) | (idrow[q] << 16);
+            const float g = idg[q];   // split once: bf16 hi | lo << 16 (16 significant bits)
+            const unsigned vh = to_bf16_bits(g), vl = to_bf16_bits(g - __uint_as_float(vh << 16));
+            reinterpret_cast<unsigned*>(hit_g)[p] = vh | (vl << 16);
+          }
+          pos += __popcll(mask);
         }
-        pos += __popcll(mask);
-      }
     }
     (void)cnt;
   } else
@@ -244,6 +256,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       }
   };
 
+  // SPM: the per-column parameters of the two epilogues are tile-invariant; loaded once per cloud (left inside the tile loop hipcc sank each
+  // load into the exec-masked block of its first use -- a global round trip waited for on the spot, twice per tile)
+  float pc_sc = 0.f, pc_sh = 0.f, pc_qb = 0.f, pc_bias = 0.f, pc_mu = 0.f, pc_rs = 0.f;
+  if constexpr (SPM) {
+    pc_sc = a.sc2[tower * kC2 + col]; pc_sh = a.sh2[tower * kC2 + col]; pc_qb = a.q3b[tower * kC2 + col];
+    pc_bias = a.b2[col]; pc_mu = a.mean2[tower * kC2 + col]; pc_rs = a.rstd2[tower * kC2 + col];
+  }
   TilePoint nextp = GIVEN ? TilePoint{0.f, 0.f, 0.f} : tile_point_request(pc, a.N, 0, tid);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
@@ -314,8 +333,17 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
                               reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
-      const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
-      if (BF16) {
+      const float sc = SPM ? pc_sc : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : (live ? a.sh2[tower * kC2 + col] : 0.f);
+      if (SPM) {
+        // every column is live (C2 = 128 = 4 waves x 32) and rows past the cloud's end need no zeros: h2 only feeds h2 Q3 here, whose rows
+        // past nvalid are masked in the epilogue (h1 of those rows is 0, so h2 = relu(shift): finite).  Branch-free: with the row test
+        // hipcc built 32 exec-masked blocks (compare, save exec, branch, fma, max, convert, restore, store) per wave and tile.
+        unsigned short* Yh = reinterpret_cast<unsigned short*>(Y);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Yh[acc_row(m, r, lane) * ldbh + col] = to_bf16_bits(fmaxf(fmaf(z2[m][r], sc, sh), 0.f));
+      } else if (BF16) {
         if (col < K16b) {   // h2 as a bf16 tile in the Y region (row stride K16(C2) + 8 elements)
           unsigned short* Yh = reinterpret_cast<unsigned short*>(Y);
 #pragma unroll
@@ -423,7 +451,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
     if (ct < CT2) {
-      const float qb = live ? a.q3b[tower * kC2 + col] : 0.f;
+      const float qb = SPM ? pc_qb : (live ? a.q3b[tower * kC2 + col] : 0.f);
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -458,9 +486,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           sp_mfma(he - hb, acc);
         }
       }
-      const float sc = live ? a.sc2[tower * kC2 + col] : 0.f, sh = live ? a.sh2[tower * kC2 + col] : 0.f;
-      const float bias = live ? a.b2[col] : 0.f, mu = live ? a.mean2[tower * kC2 + col] : 0.f;
-      const float rs = live ? a.rstd2[tower * kC2 + col] : 0.f;
+      const float sc = SPM ? pc_sc : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : (live ? a.sh2[tower * kC2 + col] : 0.f);
+      const float bias = SPM ? pc_bias : (live ? a.b2[col] : 0.f), mu = SPM ? pc_mu : (live ? a.mean2[tower * kC2 + col] : 0.f);
+      const float rs = SPM ? pc_rs : (live ? a.rstd2[tower * kC2 + col] : 0.f);
       float lb = 0.f, lg = 0.f;
       const float isc = GIVEN ? 1.0f / sc : 0.f;
 #pragma unroll

@@ -443,6 +443,11 @@ def main():
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) here instead of silently running one
         raise SystemExit(self_launch(args.gpus))
+    # The contract is ONE line on stdout.  Libraries write there too (librccl prints a version banner on its first communicator -- found by the
+    # world-1 rehearsal, round 5): everything this process and its libraries print goes to stderr, the JSON line alone to the real stdout.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import torch
     import alignnet3d
@@ -857,7 +862,8 @@ def main():
         if extra is not None:
             line.update(extra_seconds=extra.pop("seconds"), **extra)
         line["options"] = engine_options(eng)   # as the legs left them (allreduce_overlap, sync_bn, ... are set after the engine is created)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -1045,6 +1045,16 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
     floor, kc = (2e-2, 1.5) if bf16 else (5e-4, 8.0)
     bar_t, bar_l2, bar_p = max(floor, kc * max(sens.values())), max(floor, kc * srl2), max(2e-2 if bf16 else 1e-4, kc * spred)
+    if not bf16:
+        # second probe of the batch's conditioning: the SAME pinned oracle evaluated in float32 (torch, another summation order) against its
+        # fp64 self -- the noise of an independent fp32 evaluation, which rounds every intermediate and not only the inputs (measured: up to
+        # 100 x the input-rounding probe where a BatchNorm channel is nearly constant over the batch).  The engine -- fp32 products, fp64
+        # statistics -- may be up to 3 x as far from fp64 as that evaluation is.
+        ep3, _, g3, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=dec, dt=np.float32)
+        _, n32, _, n32rl2, _ = _grad_compare(lambda n: np.asarray(g3[n], np.float64), spec, grads)
+        print(case, "pinned: the fp32 evaluation of the pinned oracle vs its fp64 one: relative L2 %.2e, worst tensor %.2e" % (n32rl2, max(n32.values())))
+        bar_t, bar_l2 = max(bar_t, 3.0 * max(n32.values())), max(bar_l2, 3.0 * n32rl2)
+        bar_p = max(bar_p, 3.0 * max(float(np.abs(ep3[k] - ep_ref[k]).max()) for k in ep_ref))
     print(case, "pinned: engine vs oracle: predictions %.2e, relative L2 %.2e, worst tensor %.2e (%s) | oracle under one input rounding: predictions %.2e, "
           "relative L2 %.2e, worst tensor %.2e" % (pred, rl2, max(relf.values()), max(relf, key=relf.get), spred, srl2, max(sens.values())))
     assert pred <= bar_p, (pred, bar_p)
