@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   // SPM: the per-column parameters of the two epilogues are tile-invariant; loaded once per cloud (left inside the tile loop hipcc sank each
   // load into the exec-masked block of its first use -- a global round trip waited for on the spot, twice per tile)
   float pc_sc = 0.f, pc_sh = 0.f, pc_qb = 0.f, pc_bias = 0.f, pc_mu = 0.f, pc_rs = 0.f;
-  if constexpr (SPM) {
+  if constexpr (SPM) {   // (the fp32 instantiation sits at 247 VGPRs: six more registers across the tile loop spill)
     pc_sc = a.sc2[tower * kC2 + col]; pc_sh = a.sh2[tower * kC2 + col]; pc_qb = a.q3b[tower * kC2 + col];
     pc_bias = a.b2[col]; pc_mu = a.mean2[tower * kC2 + col]; pc_rs = a.rstd2[tower * kC2 + col];
   }

@@ -1043,7 +1043,7 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     _, sens, scos, srl2, _ = _grad_compare(lambda n: g2[n], spec, grads)
     spred = max(float(np.abs(ep2[k] - ep_ref[k]).max()) for k in ep_ref)
     pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
-    floor, kc = (2e-2, 1.5) if bf16 else (5e-4, 8.0)
+    floor, kc = (2e-2, 1.5) if bf16 else (5e-4 if B >= 8 else 3e-3, 8.0)   # (B < 8: five-row batch statistics in the heads; the free tests allow 1e-2 there)
     bar_t, bar_l2, bar_p = max(floor, kc * max(sens.values())), max(floor, kc * srl2), max(2e-2 if bf16 else 1e-4, kc * spred)
     if not bf16:
         # second probe of the batch's conditioning: the SAME pinned oracle evaluated in float32 (torch, another summation order) against its
