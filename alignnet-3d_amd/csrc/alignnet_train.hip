@@ -1347,7 +1347,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
-  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) : 0);
+  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0);
   { ProfScope prof_scope(h, PK_TRAIN_B2, true);
   if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
   else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
@@ -1528,7 +1528,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     bh.v2imgh = w->b1imgh; bh.q2imgh = w->b1imgh + 2 * kV2h; bh.v2_stride = (long)kV2h; bh.q2_stride = (long)kQ2h; bh.q2b = w->q2b;
     bh.dy2_store = reinterpret_cast<const unsigned short*>(w->dy2);
     bh.u2_part = b1.u2_part; bh.g1_part = b1.g1_part; bh.pdy_part = w->pdy_part;
-    const size_t ldsh = (size_t)kTT * 4 * sizeof(float) + ((size_t)kTT * 72 * 2 + (size_t)kTT * 136 + (size_t)128 * 72) * sizeof(unsigned short);
+    const size_t ldsh = (size_t)kTT * 4 * sizeof(float) + ((size_t)kTT * 72 * 2 + (size_t)kTT * 136 + (size_t)128 * 72) * sizeof(unsigned short) +
+                        (size_t)(2 * 8 + 2 * 4) * 64 * 16;   // + the bf16 operand images of V2 and Q2 (kernels_train_bwd.h: Vl, Ql)
     ProfScope prof_scope(h, PK_TRAIN_B1, true);
     TIMED_LAUNCH(train_bwd_b1_bf16, dim3(2 * B), dim3(kTW * 64), ldsh, bh);
   } else

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
   int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
   int* wtot = hoff + kTW * (ntiles + 1);                       // [8] segment sizes
+  float* l1par = reinterpret_cast<float*>(wtot + kTW);          // SPM: [5][64] first-layer weights / scale / shift of this tower + the cloud's frame [12] (filled once per cloud)
   const int KG2 = (kC1 + 7) >> 3, CT1 = (kC1 + 31) >> 5, CT2 = (kC2 + 31) >> 5, KGq = (kC2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
   const int sG = max(1, (kTW * 64) / kC1);
@@ -102,6 +103,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* my_g1 = a.g1_part + (size_t)cloud * kC1 * kC1;
 
   if constexpr (SPM) {
+    if (tid < 12) l1par[320 + tid] = xf[tid];   // the cloud's frame: read from here per tile (from memory it was a round trip in front of every tile's first barrier)
+    if (tid < 64) {
+      l1par[tid] = a.w1[tid]; l1par[64 + tid] = a.w1[kC1 + tid]; l1par[128 + tid] = a.w1[2 * kC1 + tid];
+      l1par[192 + tid] = a.sc1[tower * kC1 + tid]; l1par[256 + tid] = a.sh1[tower * kC1 + tid];
+    }
     // ---- per-cloud hit list, ONE segment per tile (ordered by channel): wave w counts, then fills, the tiles t = w, w + 4, ... ----
     static_assert(!SPM || kTW == 4, "tiles are dealt to four waves");
     int* cnt = wtot;   // reuse: [ntiles] counts live in hoff's tail until the prefix sum  (hoff has kTW * (ntiles + 1) + kTW ints)
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   }
 
   f32x16 z2[2];   // [row group]
+  bf16x8 w2f[SPM ? 4 : 1], q3f[SPM ? 8 : 1];   // SPM: weight fragments requested a phase ahead of their MFMAs (see the tile loop)
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool live = col < kC2;
   double db = 0.0, dg = 0.0, s1c = 0.0;
@@ -193,6 +200,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   // SPM: tiles of one chunk of hits [hb, he), he - hb <= kSpH.  Thread roles -- gather: hit pair p = tid & 31, columns 16 q .. 16 q + 15
   // (q = tid >> 5); S build: row r = tid >> 2, hit octets 2 (tid & 3), 2 (tid & 3) + 1.
   unsigned spg0[8], spg1[8];   // the gathered 2 x 32 bytes of round(W3)^T, hits 2 p and 2 p + 1 (requested early, written into R^T by sp_write)
+  unsigned spma = 0u, spmb = 0u;   // all-ones where the hit exists: applied when the rows are WRITTEN (masked here, right behind the loads, each
+                                   // request waited for its four loads on the spot -- an L2 round trip in front of every tile's lift)
   auto sp_request = [&](int hb, int he) {
     const int pj = (tid & 31) * 2, q = tid >> 5;
     const int ha = hb + pj, hbb = hb + pj + 1;
@@ -200,9 +209,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     const uint4* sa = reinterpret_cast<const uint4*>(a.w3th + (size_t)max(ca, 0) * kC2 + q * 16);
     const uint4* sb = reinterpret_cast<const uint4*>(a.w3th + (size_t)max(cb, 0) * kC2 + q * 16);
     const uint4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
-    const unsigned ma = ca >= 0 ? 0xffffffffu : 0u, mb = cb >= 0 ? 0xffffffffu : 0u;
-    spg0[0] = a0.x & ma; spg0[1] = a0.y & ma; spg0[2] = a0.z & ma; spg0[3] = a0.w & ma; spg0[4] = a1.x & ma; spg0[5] = a1.y & ma; spg0[6] = a1.z & ma; spg0[7] = a1.w & ma;
-    spg1[0] = b0.x & mb; spg1[1] = b0.y & mb; spg1[2] = b0.z & mb; spg1[3] = b0.w & mb; spg1[4] = b1.x & mb; spg1[5] = b1.y & mb; spg1[6] = b1.z & mb; spg1[7] = b1.w & mb;
+    spma = ca >= 0 ? 0xffffffffu : 0u; spmb = cb >= 0 ? 0xffffffffu : 0u;
+    spg0[0] = a0.x; spg0[1] = a0.y; spg0[2] = a0.z; spg0[3] = a0.w; spg0[4] = a1.x; spg0[5] = a1.y; spg0[6] = a1.z; spg0[7] = a1.w;
+    spg1[0] = b0.x; spg1[1] = b0.y; spg1[2] = b0.z; spg1[3] = b0.w; spg1[4] = b1.x; spg1[5] = b1.y; spg1[6] = b1.z; spg1[7] = b1.w;
   };
   auto sp_write = [&](int hb, int he) {
     {   // R^T[n][j]: one dword = hits (2 p, 2 p + 1) of column n; the two half-waves of a wave walk i in opposite halves (bank spread)
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       // below is a compile-time constant (hipcc folds an if / else over the two orders into one loop with a run-time index -> scratch)
       unsigned r0[8], r1[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { r0[k] = hsel ? spg0[(k + 4) & 7] : spg0[k]; r1[k] = hsel ? spg1[(k + 4) & 7] : spg1[k]; }
+      for (int k = 0; k < 8; ++k) { r0[k] = (hsel ? spg0[(k + 4) & 7] : spg0[k]) & spma; r1[k] = (hsel ? spg1[(k + 4) & 7] : spg1[k]) & spmb; }
       unsigned short* base = spRT + (q * 16) * kSpLd + pj;
 #pragma unroll
       for (int ii = 0; ii < 16; ++ii) {
@@ -298,11 +307,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
       }
     } else {
-    tile_point_store(nextp, xf, xs, tid);
+    tile_point_store(nextp, SPM ? l1par + 320 : xf, xs, tid);
     if (tile + 1 < ntiles) nextp = tile_point_request(pc, a.N, tile + 1, tid);   // in flight for the whole of this tile
+    if constexpr (SPM) {   // the hidden layer's four weight fragments: requested here, in flight under the barrier and the lift
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) w2f[kg] = reinterpret_cast<const bf16x8*>(a.wp2h)[((size_t)ct * 4 + kg) * 64 + lane];
+    }
     __syncthreads();
     B2_STAMP(1);
-    if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
+    if (SPM) {
+      float cst[4] = {0.f, 0.f, 0.f, 0.f};
+      layer1_to_lds_bf16_par(xs, l1par, reinterpret_cast<unsigned short*>(X), ld0h, nvalid, tid, &cst);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s1v[j] += (double)cst[j];
+      __syncthreads();
+    } else if (BF16 && !ACCUM) {   // h1 straight as a bf16 tile (the fp32 tile, its conversion pass and a barrier were 3.2 k of a tile's 19 k cycles)
       float cst[4] = {0.f, 0.f, 0.f, 0.f};
       layer1_to_lds_bf16_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, reinterpret_cast<unsigned short*>(X + (SPM ? 0 : kTT * ld0)), ld0h, K16a,
                                 nvalid, tid, &cst);
@@ -328,7 +347,22 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     // ---- layer 2 forward: z2 (pre-BN, minus bias) stays in registers, h2 -> Y.  Wave w owns channel tile w and both
     //      32-row groups (one weight fragment feeds two MFMAs; C2 <= 128 -> CT2 <= 4 waves) ----
     if (ct < CT2) {
-      if (BF16)
+      if constexpr (SPM) {
+        const unsigned short* arow = reinterpret_cast<const unsigned short*>(X) + (lane & 31) * ld0h + (lane >> 5) * 8;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z2[m][r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            z2[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + m * 32 * ld0h + kg * 16), w2f[kg], z2[m], 0, 0, 0);
+        // the first four of Q3's eight fragments for the product behind the next barrier: requested now, in flight under the h2 store and the
+        // S / R^T build (all eight here: 256 registers and two spills)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) q3f[kg] = reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride)[((size_t)ct * 8 + kg) * 64 + lane];
+      } else if (BF16)
         mfma_rows_bf16_all<2>(reinterpret_cast<const unsigned short*>(X + (SPM ? 0 : kTT * ld0)), ld0h,
                               reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
@@ -469,7 +503,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           }
         asm volatile("" ::: "memory");
       }
-      if (BF16)
+      if constexpr (SPM) {
+        const unsigned short* arow = reinterpret_cast<const unsigned short*>(Y) + (lane & 31) * ldbh + (lane >> 5) * 8;
+#pragma unroll
+        for (int kg = 4; kg < 8; ++kg) q3f[kg] = reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride)[((size_t)ct * 8 + kg) * 64 + lane];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + m * 32 * ldbh + kg * 16), q3f[kg], acc[m], 0, 0, 0);
+      } else if (BF16)
         mfma_rows_bf16_all<2, false>(reinterpret_cast<const unsigned short*>(Y), ldbh,
                                      reinterpret_cast<const bf16x8*>(a.q3imgh + tower * a.q3imgh_stride) + (size_t)ct * (K16b >> 4) * 64, K16b >> 4, lane, acc);
       else
@@ -777,7 +820,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 // Pdy = x'^T dy1 (3 x C1) and sum dy1 stay in fp32 on the VALU (four FMAs per accumulator element; x' in bf16 would put
 // 3-digit coordinates into the first layer's weight and frame gradients).  The backward treats the operand rounding as identity,
 // like the rest of the bf16 mode.
-// LDS (bf16): Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | xs fp32 [64][4] = 55 KiB: two workgroups per CU.
+// LDS (bf16): xs fp32 [64][4] | Xh [64][72] | XhT [64][72] | Yh [64][136] | YhT [128][72] | V2 image 16 KB | Q2 image 8 KB = 78 KiB: two workgroups per CU.
 // ---------------------------------------------------------------------------------
 constexpr int kPackBf16Jobs = 16;
 struct PackBf16Jobs {
@@ -836,14 +879,24 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
+  const XForm XF = xform_load(xf);
   float* xs = smem;                                                        // [64][4] fp32
   unsigned short* Xh = reinterpret_cast<unsigned short*>(smem + kTT * 4);   // h1    [64][72]
   unsigned short* XhT = Xh + kTT * ldx;                                     // h1^T  [64][72]
   unsigned short* Yh = XhT + C1 * ldT;                                      // dy2   [64][136]
   unsigned short* YhT = Yh + kTT * ldy;                                     // dy2^T [128][72]
+  // The operand images of V2 (128 -> 64: 16 KB) and Q2 (64 -> 64: 8 KB) of this tower, copied into LDS once per cloud: requested from
+  // memory by every wave for every tile (twelve fragments, waited for right in front of their MFMAs) they were two exposed L2 round trips
+  // per tile.  79.9 KB per workgroup: still two per CU.
+  bf16x8* Vl = reinterpret_cast<bf16x8*>(YhT + C2 * ldT);                   // [2 channel tiles][8 k-groups][64 lanes]
+  bf16x8* Ql = Vl + 2 * (C2 / 16) * 64;                                      // [2][4][64]
   const int ntiles = (a.N + kTT - 1) / kTT;
-  const bf16x8* v2img = reinterpret_cast<const bf16x8*>(a.v2imgh + tower * a.v2_stride);
-  const bf16x8* q2img = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2_stride);
+  {
+    const bf16x8* v2img = reinterpret_cast<const bf16x8*>(a.v2imgh + tower * a.v2_stride);
+    const bf16x8* q2img = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2_stride);
+    for (int i = tid; i < 2 * (C2 / 16) * 64; i += kTW * 64) Vl[i] = v2img[i];
+    for (int i = tid; i < 2 * (C1 / 16) * 64; i += kTW * 64) Ql[i] = q2img[i];
+  }
   const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
   // register-resident blocks for the whole cloud: U2 (2 x 4 blocks) and, unless the forward kept it, the upper blocks of Gram(h1) (3)
   constexpr int kAccSlots = 3, CT1 = 2, CT2 = 4;
@@ -874,7 +927,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     __syncthreads();
-    tile_point_store(npt, xf, xs, tid);
+    tile_point_store(npt, XF, xs, tid);
     {   // dy2 tile: lane = row, wave-uniform 8-channel chunk; row-major 16-byte write + eight transposed 2-byte writes (consecutive lanes)
       const int row = lane;
 #pragma unroll
@@ -903,7 +956,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
           const int row = r0 * 8 + e;
           const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
           const float acc = fmaf(p[2], l1w.wb[g], fmaf(p[1], l1w.wa[g], p[0] * l1w.w0[g]));
-          hv[e] = row < nvalid ? to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) : (unsigned short)0;
+          // rows past the cloud's end must read 0 (they are contracted over in U2 / Gram): an and-mask, not a branch -- written as a
+          // conditional hipcc built sixteen exec-masked blocks (point read, lift, convert) per thread and tile
+          hv[e] = (unsigned short)(to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) & (row < nvalid ? 0xffffu : 0u));
           Xh[row * ldx + c] = hv[e];
         }
         uint4 pk;
@@ -939,8 +994,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
       f32x16 acc[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] = qb;
-      mfma_rows_bf16_all<1, false>(Yh + rg * 32 * ldy, ldy, v2img + (size_t)ct * (C2 / 16) * 64, C2 / 16, lane, acc);
-      mfma_rows_bf16_all<1, false>(Xh + rg * 32 * ldx, ldx, q2img + (size_t)ct * (C1 / 16) * 64, C1 / 16, lane, acc);
+      {
+        const unsigned short* ay = Yh + (rg * 32 + (lane & 31)) * ldy + half * 8;
+        const unsigned short* ax = Xh + (rg * 32 + (lane & 31)) * ldx + half * 8;
+#pragma unroll
+        for (int kg = 0; kg < C2 / 16; ++kg)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ay + kg * 16), Vl[(ct * (C2 / 16) + kg) * 64 + lane], acc[0], 0, 0, 0);
+#pragma unroll
+        for (int kg = 0; kg < C1 / 16; ++kg)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ax + kg * 16), Ql[(ct * (C1 / 16) + kg) * 64 + lane], acc[0], 0, 0, 0);
+      }
       float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -114,6 +114,27 @@ __device__ __forceinline__ void tile_point_store(const TilePoint& p, const float
   }
 }
 
+// The cloud's frame (centre + rotation, 12 floats) once per workgroup in scalar registers: read through the pointer, tile_point_store
+// fetched it from memory for every tile -- a vector load of a uniform address waited for on the spot by wave 0, with the other waves at
+// the next barrier (~700 cycles per tile in every training pass).
+struct XForm { float v[12]; };
+__device__ __forceinline__ XForm xform_load(const float* __restrict__ xf)
+{
+  XForm X;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) X.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xf[i])));
+  return X;
+}
+__device__ __forceinline__ void tile_point_store(const TilePoint& p, const XForm& X, float* __restrict__ xs, int tid)
+{
+  if (tid < kTT) {
+    const float x = p.x - X.v[0], y = p.y - X.v[1], z = p.z - X.v[2];
+    xs[tid * 4 + 0] = x * X.v[3] + y * X.v[6] + z * X.v[9];
+    xs[tid * 4 + 1] = x * X.v[4] + y * X.v[7] + z * X.v[10];
+    xs[tid * 4 + 2] = x * X.v[5] + y * X.v[8] + z * X.v[11];
+  }
+}
+
 // layer 1 on the VALU: out[row][c] = relu((x' . w[:,c]) * sc + sh); rows >= nvalid are written as 0.
 // Layer1W holds the thread's weights / scale / shift for its (<= 4) channel groups c0, c0 + 32, ...: loaded once per
 // workgroup (layer1_load) instead of once per tile -- the reload put an L2 round trip in front of every tile's first barrier.
@@ -245,6 +266,31 @@ __device__ __forceinline__ void layer1_to_lds_bf16_global(const float* __restric
   }
 }
 
+// the same lift with the thread's weights / scale / shift read from an LDS table par[5][64] = {w0, wa, wb, scale, shift} (C1 = 64) that the
+// workgroup filled once per cloud: pass B2 has neither the registers for Layer1W nor the time for five global loads per tile
+__device__ __forceinline__ void layer1_to_lds_bf16_par(const float* __restrict__ xs, const float* __restrict__ par, unsigned short* __restrict__ out16,
+                                                       int ldh, int nvalid, int tid, float (*csum)[4])
+{
+  constexpr int kRowsPerPass = kTW * 2;
+  const int c0 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = c0 + 32 * g;
+    const float w0 = par[c], wa = par[64 + c], wb = par[128 + c], s = par[192 + c], t = par[256 + c];
+    float cs = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+      const int row = rr * kRowsPerPass + r0;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+      const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+      const unsigned short hb = row < nvalid ? to_bf16_bits(fmaxf(fmaf(acc, s, t), 0.f)) : (unsigned short)0;
+      out16[row * ldh + c] = hb;
+      cs += __uint_as_float((unsigned)hb << 16);
+    }
+    (*csum)[g] = cs;
+  }
+}
+
 __device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---- bf16 operands (BASELINE.json configs[2]: "training ... bf16 with grad step"): the 128 -> C3 lift, 90 % of the
@@ -329,6 +375,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
+  const XForm XF = xform_load(xf);
   float* xs = smem;
   float* buf0 = smem + kTT * 4;
   const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
@@ -443,7 +490,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
       }
     } else {
     if (kPfPts) {
-      tile_point_store(npt, xf, xs, tid);
+      tile_point_store(npt, XF, xs, tid);
       if (tile + 1 < ntiles) npt = tile_point_request(pc, a.N, tile + 1, tid);
     } else load_tile_xform(pc, xf, a.N, tile, xs, tid);
     __syncthreads();

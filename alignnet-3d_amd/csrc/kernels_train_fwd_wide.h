@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
+  const XForm XF = xform_load(xf);   // (scalar registers: store_xs read the frame from memory for every tile)
   float* xs = smem;
   const int off0 = kWT * 4, off1 = kWT * 4 + kWT * ld0;   // integer offsets keep the LDS address space visible (ds_read_b128)
   const int CT3 = (a.C3 + 31) >> 5;
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   };
   auto store_xs = [&]() {
     if (tid < kWT) {
-      const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
-      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+      const float x = nx - XF.v[0], y = ny - XF.v[1], z = nz - XF.v[2];
+      xs[tid * 4 + 0] = x * XF.v[3] + y * XF.v[6] + z * XF.v[9];
+      xs[tid * 4 + 1] = x * XF.v[4] + y * XF.v[7] + z * XF.v[10];
+      xs[tid * 4 + 2] = x * XF.v[5] + y * XF.v[8] + z * XF.v[11];
     }
   };
   // The K = 3 lift of tile t + 1 runs INSIDE the lift of tile t (behind the wave's first channel tile): h1's buffer is free once the hidden
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
+  const XForm XF = xform_load(xf);   // (scalar registers: store_xs read the frame from memory for every tile)
   float* xs = smem;
   unsigned short* h1h = reinterpret_cast<unsigned short*>(smem + kWT * 4);
   unsigned short* h2h = h1h + kWT * ld0h;            // two tiles
@@ -349,10 +351,10 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
   };
   auto store_xs = [&]() {
     if (tid < kWT) {
-      const float x = nx - xf[0], y = ny - xf[1], z = nz - xf[2];
-      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+      const float x = nx - XF.v[0], y = ny - XF.v[1], z = nz - XF.v[2];
+      xs[tid * 4 + 0] = x * XF.v[3] + y * XF.v[6] + z * XF.v[9];
+      xs[tid * 4 + 1] = x * XF.v[4] + y * XF.v[7] + z * XF.v[10];
+      xs[tid * 4 + 2] = x * XF.v[5] + y * XF.v[8] + z * XF.v[11];
     }
   };
   // K = 3 lift of tile t -> h1h (bf16; rows past the cloud's end are zero)

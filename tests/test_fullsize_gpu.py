@@ -250,16 +250,33 @@ def _pin_gaps(report, tag):
 
 
 def _one_rounding(d, seed=99):
-    """the batch with its point coordinates moved by one fp32 rounding (6e-8 relative, in float64): what an fp32 evaluation cannot tell apart"""
+    """the batch with every point coordinate moved to a NEIGHBOURING fp32 value (+- 1 ulp, random sign): what an fp32 evaluation cannot
+    tell apart from the batch itself"""
     rng = np.random.default_rng(seed)
-    out = {k: v.astype(np.float64) for k, v in d.items()}
+    out = dict(d)
     for k in ("pcs1", "pcs2"):
-        out[k] = out[k] * (1 + 6e-8 * rng.standard_normal(out[k].shape))
+        x = np.asarray(d[k], np.float32)
+        out[k] = np.nextafter(x, x + np.where(rng.random(x.shape) < 0.5, -1, 1).astype(np.float32)).astype(np.float32)
     return out
 
 
+def _oracle_noise_floor(oracle, d, spec, grads, ep_ref, trials):
+    """How far the PINNED fp64 oracle moves from itself when its inputs move by one ulp, worst of `trials` draws: (relative L2 of the
+    whole gradient, worst tensor, predictions).  What is left undecided after the pins are the SIGNS of the relu pre-activations
+    (utils/tf_util.py:152,339: ~10^6 .. 10^8 per step); the handful that sit within one rounding of zero flip between any two
+    evaluations, and a flip on a row that wins many max-pool channels re-routes ~1 % of a weight column's gradient.  Measured at
+    16 x 256 points: the draws give 3e-5 .. 1e-2 (one seed) and 3e-5 .. 5e-2 (another) in QUANTISED steps -- the same flip recurring --
+    so one draw says little and the worst of several is the floor."""
+    worst = [0.0, 0.0, 0.0]
+    for t in range(trials):
+        ep2, _, g2, _ = oracle(_one_rounding(d, 99 + t))
+        _, sens_f, _, srl2, _ = _grad_compare(lambda n: g2[n], spec, grads)
+        worst = [max(worst[0], srl2), max(worst[1], max(sens_f.values())), max(worst[2], max(float(np.abs(ep2[k] - ep_ref[k]).max()) for k in ep_ref))]
+    return worst
+
+
 def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar=8e-2,
-                                  tiny_tensors=(), free=True, bf16=False, gap_bar=1e-4, floor=1e-3, k_cond=8.0, sens=True):
+                                  tiny_tensors=(), free=True, bf16=False, gap_bar=1e-4, floor=1e-3, k_cond=3.0, sens=2):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
     torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`):
 
@@ -270,16 +287,15 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol
         and 512 yaw classes models/tp8.py:296 at 256 x 1024; neighbour slots and the kNN table for dgcnn) after checking that every one
         of them is a maximum of the oracle's own values to within `gap_bar` of their scale -- THAT is the test of the arg-max kernels, and
         it is sharp (measured: 1e-6).
-    (3) What round 5 found: with the decisions pinned the gradient difference does NOT drop (256 x 1024: relative L2 1.30e-2 free, 1.24e-2
-        pinned) -- re-decided winners were never the floor.  The floor is CONDITIONING: the pinned fp64 oracle's own gradient moves by
-        2e-3 .. 5e-3 (relative L2; worst tensors 6e-3 .. 5e-2) when its inputs move by ONE fp32 rounding (clouds 4 - 20 m from the origin
-        are resolved to 1e-6 m, the re-centred objects are ~2 m, and the heads batch-normalise rows of nearly equal pooled features).
-        No fp32 evaluation can be held to 1e-3 on such a batch, so the continuous part is held to the oracle's OWN measured conditioning:
-        whole-gradient relative L2 and every tensor (error over max(the tensor's largest entry, 2 % of the gradient's)) within
-        max(`floor`, `k_cond` x the same measure of the oracle's movement under one input rounding).  The bar comes from the oracle, not
-        from this implementation; a wrong index, a dropped term or a 1 / world slip moves a tensor by O(1), 10 - 100 x above it.
-        (`sens` = False skips that third oracle run -- the suite's time -- and holds the pinned comparison to fixed bars: relative L2 2e-2,
-        per tensor 8e-2, i.e. four times what the sensitivity runs of the other shapes measure, 5e-3 / 1e-2 .. 1.5e-2.)"""
+    (3) What round 5 found: with those decisions pinned the gradient difference does NOT drop (256 x 1024: relative L2 1.30e-2 free,
+        1.24e-2 pinned) -- re-decided pool winners were never the floor.  What remains undecided are the relu SIGNS (see
+        _oracle_noise_floor): the pinned fp64 oracle's own gradient moves by 2e-3 .. 5e-3 at these sizes (1e-2 .. 5e-2 at 16 x 256) when
+        its inputs move by one ulp, in quantised steps.  No fp32 evaluation can be held to 1e-3 on such a batch, so the continuous
+        part is held to the oracle's OWN measured floor: whole-gradient relative L2 and every tensor (error over max(the tensor's
+        largest entry, 2 % of the gradient's)) within max(`floor`, `k_cond` x the worst of `sens` one-ulp draws).  The bar comes from
+        the oracle, not from this implementation; a wrong index, a dropped term or a 1 / world slip moves a tensor by O(1).
+        (`sens` = 0 skips the extra oracle runs -- the suite's time -- and holds the pinned comparison to fixed bars: relative L2 2e-2,
+        per tensor 8e-2, i.e. four times what the draws of the other shapes measure.)"""
     from tests import test_train_gpu as TT
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     Bt = d["pcs1"].shape[0]
@@ -323,14 +339,12 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol
             bad = {n: e for n, e in relf.items() if e > 8e-2}
             if bad: failures.append(("pinned tensors", bad))
             continue
-        # the oracle's own conditioning on this batch: the same pinned evaluation with the inputs moved by one fp32 rounding
-        ep2, loss2, g2, _ = TT._oracle(cfg, P32, _one_rounding(d), du, decay, bf16_lift=bf16, checkpoint=True, pinned=decisions)
-        _, sens_f, scos, srl2, _ = _grad_compare(lambda n: g2[n], spec, grads)
-        spred = max(float(np.abs(ep2[k] - ep_ref[k]).max()) for k in ep_ref)
-        bar_rl2, bar_t = max(floor, k_cond * srl2), max(floor, k_cond * max(sens_f.values()))
-        print("%s: the pinned oracle under one fp32 rounding of its inputs: predictions %.2e, whole gradient cosine %.8f, relative L2 %.2e, worst tensor %.2e "
+        # the oracle's own floor on this batch: the same pinned evaluation with the inputs moved by one ulp, worst of `sens` draws
+        srl2, stens, spred = _oracle_noise_floor(lambda dd: TT._oracle(cfg, P32, dd, du, decay, bf16_lift=bf16, checkpoint=True, pinned=decisions), d, spec, grads, ep_ref, sens)
+        bar_rl2, bar_t = max(floor, k_cond * srl2), max(floor, k_cond * stens)
+        print("%s: the pinned oracle under one-ulp moves of its inputs (worst of %d): predictions %.2e, whole gradient relative L2 %.2e, worst tensor %.2e "
               "-> bars: relative L2 %.2e, per tensor %.2e; engine: relative L2 %.2e, worst tensor %.2e (%s)"
-              % (tag, spred, scos, srl2, max(sens_f.values()), bar_rl2, bar_t, rl2, max(relf.values()), max(relf, key=relf.get)))
+              % (tag, sens, spred, srl2, stens, bar_rl2, bar_t, rl2, max(relf.values()), max(relf, key=relf.get)))
         if rl2 > bar_rl2: failures.append(("pinned whole gradient beyond the oracle's conditioning", rl2, bar_rl2))
         bad = {n: e for n, e in relf.items() if e > bar_t}
         if bad: failures.append(("pinned tensors beyond the oracle's conditioning", bar_t, bad))
@@ -362,7 +376,7 @@ def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
     and per tensor), the decision gaps 2e-2 of their scale (operand rounding), predictions 1e-1 as in the unpinned test."""
     cfg, spec, P32, d, du = _train_setup()
     _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=1e-1, loss_tol=5e-3, ema_tol=1e-2, cos_bar=0.0, rl2_bar=1.0,
-                                  free=False, bf16=True, gap_bar=2e-2, floor=2e-2, k_cond=1.5)
+                                  free=False, bf16=True, gap_bar=2e-2, floor=2e-2, k_cond=1.5, sens=1)
 
 
 def test_train_dgcnn_n1024_matches_autograd(gpu_required):
@@ -372,7 +386,7 @@ def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     # (two max-pools and 4-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 3.8e-2 from its fp64 one here)
     # (EMA bound 2e-4: with the point conv on 128-point tiles one of the 512 fc1 moving means -- four-row batch statistics -- sits 1.4e-5 from the
     #  fp64 value at |v| = 0.03, just outside 1e-4 |v| + 1e-5)
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=False)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=0)
 
 
 def test_train_b2048_matches_autograd(gpu_required):
@@ -382,7 +396,7 @@ def test_train_b2048_matches_autograd(gpu_required):
     256 x 1024 test (the same 524 k points)."""
     cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
     # (2048-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 4e-2 from its fp64 one on the smallest gradients)
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=False)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=0)
 
 
 def test_train_dgcnn_n4096_matches_autograd(gpu_required):
@@ -397,7 +411,7 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     # winners the same step is compared at the sharp bars (1e-3 per tensor): the graph itself is checked there as a k-nearest set of
     # every query in fp64 distances.
     _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=9e-3, loss_tol=5e-4, ema_tol=5e-3, cos_bar=0.9995, rl2_bar=3.5e-2,
-                                  tiny_tensors=("siamese/embedding/conv3/bn/beta",))
+                                  tiny_tensors=("siamese/embedding/conv3/bn/beta",), sens=1)
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):
