@@ -276,7 +276,7 @@ def _oracle_noise_floor(oracle, d, spec, grads, ep_ref, trials):
 
 
 def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar=8e-2,
-                                  tiny_tensors=(), free=True, bf16=False, gap_bar=1e-4, floor=1e-3, k_cond=4.0, sens=2):
+                                  tiny_tensors=(), free=True, bf16=False, gap_bar=1e-4, floor=1e-3, k_cond=4.0, sens=1):
     """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
     torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`):
 
