@@ -1347,7 +1347,8 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
-  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0);
+  const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0) +
+                        ((std_w && !b2_accum && !h->train_bf16 && !given) ? (size_t)(5 * 64 + 16 + 6 * 128) * sizeof(float) : 0);   // STDF: the LDS parameter tables
   { ProfScope prof_scope(h, PK_TRAIN_B2, true);
   if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
   else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);

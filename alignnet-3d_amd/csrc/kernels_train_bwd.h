@@ -81,6 +81,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   // S is built as two bf16 tiles hi + lo (16 significant bits of the gradient), and 16 MFMAs per wave add the product to the
   // accumulators that take h2 Q3.  The scatter it replaces gave every row to one wave (rows that win many channels: up to several
   // hundred hits on one wave) and was half of the kernel.  Deterministic: fixed summation order.
+  // STDF: the fp32 instantiation of the shipped widths.  Like SPM it keeps what is tile-invariant in an LDS table filled once per cloud -- the
+  // first layer's weights / scale / shift, the cloud's frame, the six per-column parameters of the two epilogues -- instead of reading each
+  // from memory in every tile right where it is used (the registers to hold them across the tile loop do not exist at 247 VGPRs)
+  constexpr bool STDF = !BF16 && !ACCUM && !GIVEN && C1T == 64 && C2T == 128;
   constexpr bool SPM = BF16 && !ACCUM && !GIVEN && C1T == 64 && C2T == 128;   // (on given features -- the dgcnn point conv -- it was measured too: 12 spilled registers next to the feature prefetch, 266 vs 249 us per launch)
   constexpr int kSpH = 64, kSpLd = kSpH + 8;                 // hits per chunk; row stride of the S / R^T tiles (conflict-free 16-byte reads)
   constexpr int kXbytes = SPM ? (kTT * 72 + 128 * kSpLd + kTT * kSpLd) * 2 : 0;   // h1 bf16 | R^T | S lo   (X region of the SPM layout)
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* hit_g = reinterpret_cast<float*>(hit_e + a.C3);          // [C3] k3*g0 of that channel
   int* hoff = reinterpret_cast<int*>(hit_g + a.C3);               // [8 waves][ntiles + 1] offsets into the wave's segment
   int* wtot = hoff + kTW * (ntiles + 1);                       // [8] segment sizes
-  float* l1par = reinterpret_cast<float*>(wtot + kTW);          // SPM: [5][64] first-layer weights / scale / shift of this tower + the cloud's frame [12] (filled once per cloud)
+  float* l1par = reinterpret_cast<float*>(wtot + kTW);          // SPM / STDF: [5][64] first-layer weights / scale / shift of this tower + the cloud's frame [12] (filled once per cloud)
+  float* cpar = l1par + 336;                                   // STDF: [6][128] sc2, sh2, q3b, b2, mean2, rstd2 of this tower
   const int KG2 = (kC1 + 7) >> 3, CT1 = (kC1 + 31) >> 5, CT2 = (kC2 + 31) >> 5, KGq = (kC2 + 7) >> 3;
   const f32x4* q3img = reinterpret_cast<const f32x4*>(a.q3img + tower * a.q3img_stride);
   const int sG = max(1, (kTW * 64) / kC1);
@@ -102,6 +107,17 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   float* my_u2 = a.u2_part + (size_t)cloud * kC1 * kC2;
   float* my_g1 = a.g1_part + (size_t)cloud * kC1 * kC1;
 
+  if constexpr (STDF) {
+    if (tid < 12) l1par[320 + tid] = xf[tid];
+    if (tid < 64) {
+      l1par[tid] = a.w1[tid]; l1par[64 + tid] = a.w1[kC1 + tid]; l1par[128 + tid] = a.w1[2 * kC1 + tid];
+      l1par[192 + tid] = a.sc1[tower * kC1 + tid]; l1par[256 + tid] = a.sh1[tower * kC1 + tid];
+    }
+    if (tid < 128) {
+      cpar[tid] = a.sc2[tower * kC2 + tid]; cpar[128 + tid] = a.sh2[tower * kC2 + tid]; cpar[256 + tid] = a.q3b[tower * kC2 + tid];
+      cpar[384 + tid] = a.b2[tid]; cpar[512 + tid] = a.mean2[tower * kC2 + tid]; cpar[640 + tid] = a.rstd2[tower * kC2 + tid];
+    }
+  }
   if constexpr (SPM) {
     if (tid < 12) l1par[320 + tid] = xf[tid];   // the cloud's frame: read from here per tile (from memory it was a round trip in front of every tile's first barrier)
     if (tid < 64) {
@@ -161,12 +177,21 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   // ---- per-cloud hit lists: wave w owns the arg-extreme rows with (row & 7) == w, ordered by tile then channel
   //      (fixed order => deterministic summation); built once, consumed tile by tile ----
   {
-    int cntw = 0;
-    for (int base = 0; base < a.C3; base += 64) {
-      const int c = base + lane;
-      const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-      cntw += __popcll(__ballot(id >= 0 && (id & (kTW - 1)) == wave));
+    // (the cloud's arg-extreme rows once into registers, as in the SPM branch: re-read per (tile, chunk) they were (ntiles + 1) x C3 / 64
+    //  dependent L2 round trips per wave in front of the first tile)
+    constexpr int kIdQ = 16;
+    int idr[kIdQ];
+    const int nq = (a.C3 + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < kIdQ; ++q) {
+      const int c = q * 64 + lane;
+      const int id = (q < nq && c < a.C3) ? a.idx[(size_t)cloud * a.C3 + c] : -1;
+      idr[q] = (id >= 0 && (id & (kTW - 1)) == wave) ? id : -1;   // this wave's rows only
     }
+    int cntw = 0;
+#pragma unroll
+    for (int q = 0; q < kIdQ; ++q)
+      if (q < nq) cntw += __popcll(__ballot(idr[q] >= 0));
     if (lane == 0) wtot[wave] = cntw;
     __syncthreads();
     int woff = 0;
@@ -174,18 +199,19 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     int pos = 0;
     for (int t = 0; t < ntiles; ++t) {
       if (lane == 0) hoff[wave * (ntiles + 1) + t] = woff + pos;
-      for (int base = 0; base < a.C3; base += 64) {
-        const int c = base + lane;
-        const int id = c < a.C3 ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-        const bool m = id >= 0 && (id / kTT) == t && (id & (kTW - 1)) == wave;
-        const unsigned long long mask = __ballot(m);
-        if (m) {
-          const int p = woff + pos + __popcll(mask & ((1ull << lane) - 1ull));
-          hit_e[p] = c | ((id % kTT) << 16);
-          hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
+#pragma unroll
+      for (int q = 0; q < kIdQ; ++q)
+        if (q < nq) {
+          const bool m = idr[q] >= 0 && (idr[q] / kTT) == t;
+          const unsigned long long mask = __ballot(m);
+          if (m) {
+            const int p = woff + pos + __popcll(mask & ((1ull << lane) - 1ull));
+            const int c = q * 64 + lane;
+            hit_e[p] = c | ((idr[q] % kTT) << 16);
+            hit_g[p] = a.gs[(size_t)cloud * a.C3 + c];
+          }
+          pos += __popcll(mask);
         }
-        pos += __popcll(mask);
-      }
     }
     if (lane == 0) hoff[wave * (ntiles + 1) + ntiles] = woff + pos;
   }
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
         *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = v;
       }
     } else {
-    tile_point_store(nextp, SPM ? l1par + 320 : xf, xs, tid);
+    tile_point_store(nextp, (SPM || STDF) ? l1par + 320 : xf, xs, tid);
     if (tile + 1 < ntiles) nextp = tile_point_request(pc, a.N, tile + 1, tid);   // in flight for the whole of this tile
     if constexpr (SPM) {   // the hidden layer's four weight fragments: requested here, in flight under the barrier and the lift
 #pragma unroll
@@ -328,6 +354,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) s1v[j] += (double)cst[j];
       __syncthreads();
+    } else if (STDF) {
+    layer1_to_lds_par(xs, l1par, X, ld0, nvalid, tid);
+    __syncthreads();
     } else {
     layer1_to_lds_global(xs, a.w1, kC1, a.sc1 + tower * kC1, a.sh1 + tower * kC1, X, ld0, nvalid, tid);
     __syncthreads();
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
                               reinterpret_cast<const bf16x8*>(a.wp2h) + (size_t)ct * (K16a >> 4) * 64, K16a >> 4, lane, z2);
       else
         mfma_rows<2, true, false>(X, ld0, reinterpret_cast<const f32x4*>(a.wp2) + (size_t)ct * KG2 * 64, KG2, lane, z2);
-      const float sc = SPM ? pc_sc : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : (live ? a.sh2[tower * kC2 + col] : 0.f);
+      const float sc = SPM ? pc_sc : STDF ? cpar[col] : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : STDF ? cpar[128 + col] : (live ? a.sh2[tower * kC2 + col] : 0.f);
       if (SPM) {
         // every column is live (C2 = 128 = 4 waves x 32) and rows past the cloud's end need no zeros: h2 only feeds h2 Q3 here, whose rows
         // past nvalid are masked in the epilogue (h1 of those rows is 0, so h2 = relu(shift): finite).  Branch-free: with the row test
@@ -485,7 +514,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(6);
     // ---- dh2 = sparse + q3b + h2 Q3 ; dy2 = dh2 * [y2 > 0] ; reductions ----
     if (ct < CT2) {
-      const float qb = SPM ? pc_qb : (live ? a.q3b[tower * kC2 + col] : 0.f);
+      const float qb = SPM ? pc_qb : STDF ? cpar[256 + col] : (live ? a.q3b[tower * kC2 + col] : 0.f);
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -529,9 +558,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           sp_mfma(he - hb, acc);
         }
       }
-      const float sc = SPM ? pc_sc : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : (live ? a.sh2[tower * kC2 + col] : 0.f);
-      const float bias = SPM ? pc_bias : (live ? a.b2[col] : 0.f), mu = SPM ? pc_mu : (live ? a.mean2[tower * kC2 + col] : 0.f);
-      const float rs = SPM ? pc_rs : (live ? a.rstd2[tower * kC2 + col] : 0.f);
+      const float sc = SPM ? pc_sc : STDF ? cpar[col] : (live ? a.sc2[tower * kC2 + col] : 0.f), sh = SPM ? pc_sh : STDF ? cpar[128 + col] : (live ? a.sh2[tower * kC2 + col] : 0.f);
+      const float bias = SPM ? pc_bias : STDF ? cpar[384 + col] : (live ? a.b2[col] : 0.f), mu = SPM ? pc_mu : STDF ? cpar[512 + col] : (live ? a.mean2[tower * kC2 + col] : 0.f);
+      const float rs = SPM ? pc_rs : STDF ? cpar[640 + col] : (live ? a.rstd2[tower * kC2 + col] : 0.f);
       float lb = 0.f, lg = 0.f;
       const float isc = GIVEN ? 1.0f / sc : 0.f;
 #pragma unroll
@@ -677,12 +706,37 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
   }
+  const XForm XF = xform_load(xf);                        // the cloud's frame in scalar registers; the tile's points one tile ahead
+  TilePoint npt = tile_point_request(pc, a.N, 0, tid);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool first = tile == 0;
     __syncthreads();
-    load_tile_xform(pc, xf, a.N, tile, xs, tid);
-    {
+    if constexpr (C2T != 0) {
+      if (!a.dy2_bf16) {
+        // the fp32 dy2 tile (64 rows x C2 floats from HBM): ALL of a thread's pieces requested before the first is stored.  Written as
+        // `if (row < nvalid) v = load` inside the store loop, every piece was an exec-masked block of its own -- load, wait for it, store --
+        // i.e. kTT C2 / 1024 HBM round trips in a row at the head of every tile (eight for C2 = 128: a quarter of this pass).
+        constexpr int c4 = C2T >> 2, kIt = kTT * c4 / (kTW * 64);
+        const float* src = a.dy2_store + ((size_t)cloud * a.N + (size_t)tile * kTT) * C2T;
+        f32x4 v[kIt];
+#pragma unroll
+        for (int j = 0; j < kIt; ++j) {
+          const int i = tid + j * kTW * 64, row = i / c4, q = i % c4;
+          v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)min(row, nvalid - 1) * C2T + q * 4);
+        }
+        tile_point_store(npt, XF, xs, tid);
+        if (tile + 1 < ntiles) npt = tile_point_request(pc, a.N, tile + 1, tid);
+#pragma unroll
+        for (int j = 0; j < kIt; ++j) {
+          const int i = tid + j * kTW * 64, row = i / c4, q = i % c4;
+          *reinterpret_cast<f32x4*>(Y + row * ldb + q * 4) = row < nvalid ? v[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if (C2T == 0 || a.dy2_bf16) {
+      tile_point_store(npt, XF, xs, tid);
+      if (tile + 1 < ntiles) npt = tile_point_request(pc, a.N, tile + 1, tid);
       if (a.dy2_bf16) {
         const unsigned short* srch = reinterpret_cast<const unsigned short*>(a.dy2_store) + ((size_t)cloud * a.N + (size_t)tile * kTT) * kC2;
         const int c8 = kC2 >> 3;

@@ -266,6 +266,25 @@ __device__ __forceinline__ void layer1_to_lds_bf16_global(const float* __restric
   }
 }
 
+// fp32 lift from the LDS parameter table par[5][64] (see layer1_to_lds_bf16_par; pass B2, fp32, shipped widths)
+__device__ __forceinline__ void layer1_to_lds_par(const float* __restrict__ xs, const float* __restrict__ par, float* __restrict__ out, int ldo, int nvalid, int tid)
+{
+  constexpr int kRowsPerPass = kTW * 2;
+  const int c0 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = c0 + 32 * g;
+    const float w0 = par[c], wa = par[64 + c], wb = par[128 + c], s = par[192 + c], t = par[256 + c];
+#pragma unroll
+    for (int rr = 0; rr < kTT / kRowsPerPass; ++rr) {
+      const int row = rr * kRowsPerPass + r0;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+      const float acc = fmaf(p[2], wb, fmaf(p[1], wa, p[0] * w0));
+      out[row * ldo + c] = row < nvalid ? fmaxf(fmaf(acc, s, t), 0.f) : 0.f;
+    }
+  }
+}
+
 // the same lift with the thread's weights / scale / shift read from an LDS table par[5][64] = {w0, wa, wb, scale, shift} (C1 = 64) that the
 // workgroup filled once per cloud: pass B2 has neither the registers for Layer1W nor the time for five global loads per tile
 __device__ __forceinline__ void layer1_to_lds_bf16_par(const float* __restrict__ xs, const float* __restrict__ par, unsigned short* __restrict__ out16,

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
         const int row = rr * (kWW * 2) + r0;
         const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
         const float acc = fmaf(p[2], l1w.wb[g], fmaf(p[1], l1w.wa[g], p[0] * l1w.w0[g]));
-        h1h[row * ld0h + c] = row < nvalid ? to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) : (unsigned short)0;
+        // (and-mask, not a conditional: hipcc turned the conditional into an exec-masked block -- point read, lift, convert -- per element)
+        h1h[row * ld0h + c] = (unsigned short)(to_bf16_bits(fmaxf(fmaf(acc, l1w.s[g], l1w.t[g]), 0.f)) & (row < nvalid ? 0xffffu : 0u));
       }
     }
   };
