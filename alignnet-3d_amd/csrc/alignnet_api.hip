@@ -482,7 +482,24 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
     static PerDeviceOnce sattr;
     if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
-    if (sc1 == 64 && sc2 == 128 && !(h->ab & AB_NO_LD_CONST)) {
+    if (sc1 == 64 && sc2 == 128 && sa.C3 % 64 == 0 && sa.C3 >= 256 && split_persist_lds(sa.C3).total_bytes <= 160 * 1024 && !(h->ab & (AB_NO_LD_CONST | AB_SPLIT_TILEWISE))) {
+      // persistent workgroups, one per CU (108 KB of activation tiles + the parameter tables: one resident workgroup per CU either way)
+      static PerDeviceOnce pattr;
+      static int cus[64];
+      if (pattr.need(h->cfg.device)) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split_persist<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int n = 0;
+        HIP_TRY(h, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+        cus[h->cfg.device & 63] = n > 0 ? n : 256;
+        pattr.mark(h->cfg.device);
+      }
+      const long tiles = (long)2 * B * ((a.N + kSplitTP - 1) / kSplitTP);
+      const int wgs = (int)std::min<long>(tiles, cus[h->cfg.device & 63]);
+      if (sa.C3 >= 512) { TIMED_LAUNCH(pointnet_split_persist<4>, dim3(wgs), dim3(kWaves * 64), (size_t)split_persist_lds(sa.C3).total_bytes, sa); }
+      else { TIMED_LAUNCH(pointnet_split_persist<2>, dim3(wgs), dim3(kWaves * 64), (size_t)split_persist_lds(sa.C3).total_bytes, sa); }
+      h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_PERSIST;
+    } else if (sc1 == 64 && sc2 == 128 && !(h->ab & AB_NO_LD_CONST)) {
       static PerDeviceOnce sattr;
       if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }
       TIMED_LAUNCH((pointnet_split<64, 128>), dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, sa);

@@ -77,12 +77,13 @@ enum AbBit : unsigned {
   AB_NO_GLUE_FOLD = 1u << 9,      // the glue between the stages' backwards as separate launches
   AB_FC_DIRECT = 1u << 11,        // eval head layers: the A operand read straight into the MFMA layout instead of through the per-wave LDS tile
   AB_FC_NO_SPLITK = 1u << 12,     // eval pair head: the first layer (K = 2048) in one piece on 128 workgroups instead of two K halves on 256
+  AB_SPLIT_TILEWISE = 1u << 13,   // split-bf16 eval PointNet backbone: one workgroup per 128-point tile (pointnet_split<64, 128>) instead of the persistent one
   AB_GEMM_JOBS_KSPLIT = 1u << 10, // the deferred weight-gradient products on the K-split 32 x 32 tiles (gemm_small_jobs) instead of the 64 x 64 ones
 };
 static const struct { const char* key; unsigned bit; } kAbKeys[] = {
   {"ab_no_ld_const", AB_NO_LD_CONST}, {"ab_infer_tile64", AB_INFER_TILE64}, {"ab_phase2_legacy", AB_PHASE2_LEGACY}, {"ab_b1_legacy", AB_B1_LEGACY},
   {"ab_b1_fp32", AB_B1_FP32}, {"ab_p3_bf16_generic", AB_P3BF16_GENERIC}, {"ab_p3_nogram", AB_P3_NOGRAM}, {"ab_no_defer", AB_NO_DEFER},
-  {"ab_dg_sparse", AB_DG_SPARSE}, {"ab_no_glue_fold", AB_NO_GLUE_FOLD}, {"ab_gemm_jobs_ksplit", AB_GEMM_JOBS_KSPLIT}, {"ab_fc_direct", AB_FC_DIRECT}, {"ab_fc_no_splitk", AB_FC_NO_SPLITK}};
+  {"ab_dg_sparse", AB_DG_SPARSE}, {"ab_no_glue_fold", AB_NO_GLUE_FOLD}, {"ab_gemm_jobs_ksplit", AB_GEMM_JOBS_KSPLIT}, {"ab_fc_direct", AB_FC_DIRECT}, {"ab_fc_no_splitk", AB_FC_NO_SPLITK}, {"ab_split_tilewise", AB_SPLIT_TILEWISE}};
 struct alignnet_handle;
 bool alignnet_dataset_tables(alignnet_handle* h, alignnet::DatasetTables* out);   // alignnet_dataset.hip; false when none uploaded
 int alignnet_drain_profile(alignnet_handle* h);

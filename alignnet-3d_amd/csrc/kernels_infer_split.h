@@ -236,4 +236,228 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   }
 }
 
+// ---- round 5: the shipped widths (64, 128) as a PERSISTENT workgroup with a two-channel-tile register block in the last layer ----
+// What the one-tile-per-workgroup kernel above loses: (1) with 108 KB of LDS there is one workgroup per CU, so every
+// 128-point tile pays the workgroup launch, the cold xyz round trip and the first weight fragments' round trip with nothing to run under
+// them (~2 of the ~3.9 us a tile spends before its last layer); (2) in the last layer every wave reads the whole h2 tile (hi + lo, 64 KB)
+// from LDS for each 32-channel tile: 2 ds_read_b128 per 3 MFMAs = the LDS pipe 67 % busy next to a matrix pipe that wants 100 %.
+// Here a workgroup walks tiles t = blockIdx.x, + gridDim.x, ...: the next tile's points are requested before the last layer and sit in three
+// registers under it, the rolling weight ring runs across the tile boundary (the first item's fragments are the same for every tile), the
+// per-column parameters of all three layers live in LDS tables filled once per workgroup; and a wave's item in the last layer is TWO channel
+// tiles x MR row blocks (MR = 4: all 128 rows, C3 >= 512; MR = 2: a 64-row half, so that C3 = 256 still has eight items), each A fragment
+// feeding 6 MFMAs instead of 3: LDS reads per MFMA halve.  The weight ring holds R k-blocks (x 2 channel tiles x hi / lo) instead of a whole
+// channel tile, so 128 accumulator registers fit.  Same arithmetic, same order of accumulation per output as pointnet_split<64, 128>:
+// results are bit-identical to it.
+constexpr int split_ring(int MR) { return MR == 4 ? 2 : 4; }   // k-blocks of weight fragments in flight per wave: what 256 registers leave
+
+struct SplitPersistLds {   // float offsets of the tables behind the activation tiles
+  int p1, p2, p3, total_bytes;
+};
+__host__ __device__ inline SplitPersistLds split_persist_lds(int C3)
+{
+  SplitPersistLds o;
+  const int act = kSplitTP * 4 + (2 * kSplitTP * (72 + 136)) / 2;   // xs + h1 hi / lo + h2 hi / lo, in floats
+  o.p1 = act; o.p2 = o.p1 + 2 * 5 * 64; o.p3 = o.p2 + 2 * 2 * 128;
+  o.total_bytes = (o.p3 + 2 * 2 * C3) * 4;
+  return o;
+}
+
+template <int MR, int R>
+__device__ __forceinline__ void split_last_layer(const SplitArgs& a, const unsigned short* s16, const float* p3, __amdgpu_buffer_rsrc_t w3r, int CT3, int wave, int lane,
+                                                 int tower, float* dst, bf16x8 (&bh)[2][R], bf16x8 (&bl)[2][R])
+{
+  constexpr int ld2 = 136, o2h = 2 * kSplitTP * 72, o2l = o2h + kSplitTP * ld2, KB2 = 8;
+  const int half = lane >> 5;
+  const unsigned loff = (unsigned)lane * 16u;
+  const int nitems = MR == 4 ? (CT3 >> 1) : CT3;        // (pair) or (pair, 64-row half)
+  for (int item = wave; item < nitems; item += kWaves) {
+    const int pair = MR == 4 ? item : (item >> 1), rg = MR == 4 ? 0 : (item & 1);
+    const int nitem = item + kWaves < nitems ? item + kWaves : wave;     // past this tile's last item: the next tile's first
+    const int npair = MR == 4 ? nitem : (nitem >> 1);
+    const int arow = (rg * 64 + (lane & 31)) * ld2 + half * 8;
+    f32x16 acc[2][MR];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB2; ++kb) {
+      const int slot = kb % R;
+      bf16x8 ah[MR], al[MR];
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o2h + arow + m * 32 * ld2 + kb * 16);
+        al[m] = *reinterpret_cast<const bf16x8*>(s16 + o2l + arow + m * 32 * ld2 + kb * 16);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) split_mfma<MR>(ah, al, bh[c][slot], bl[c][slot], acc[c]);
+      const int qp = kb + R < KB2 ? pair : npair, qk = (kb + R) % KB2;     // this slot's next user: R k-blocks on
+      // buffer loads: resource + scalar offset + one 32-bit lane offset, no 64-bit address pair per stream
+      const unsigned wq = (unsigned)(((2 * qp) * KB2 + qk) * 2048);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bh[c][slot] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w3r, loff, wq + c * KB2 * 2048, 0));
+        bl[c][slot] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w3r, loff, wq + c * KB2 * 2048 + 1024, 0));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = (2 * pair + c) * 32 + (lane & 31);
+      const float sc = p3[(tower * 2 + 0) * a.C3 + col], sh = p3[(tower * 2 + 1) * a.C3 + col];
+      float hi = -INFINITY, lo = INFINITY;
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(acc[c][m][r]), "v"(acc[c][m][r + 1]));
+          asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(acc[c][m][r]), "v"(acc[c][m][r + 1]));
+        }
+      float mx = fmaxf(fmaxf(fmaf(hi, sc, sh), fmaf(lo, sc, sh)), 0.f);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (lane < 32) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
+    }
+  }
+}
+
+// grid = (workgroups, 1); C1 = 64, C2 = 128, C3 a multiple of 64, >= 512 for MR = 4 (an item is a channel-tile pair over all 128 rows) and
+// >= 256 for MR = 2; dynamic LDS = split_persist_lds(C3).total_bytes
+template <int MR>
+static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(const SplitArgs a)
+{
+  constexpr int kC1 = 64, kC2 = 128, ld1 = 72, ld2 = 136, KB1 = 4, KB2 = 8, R = split_ring(MR);
+  constexpr int o1h = 0, o1l = kSplitTP * ld1, o2h = 2 * kSplitTP * ld1, o2l = o2h + kSplitTP * ld2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* xs = smem;
+  unsigned short* s16 = reinterpret_cast<unsigned short*>(smem + kSplitTP * 4);
+  const SplitPersistLds L = split_persist_lds(a.C3);
+  float* p1 = smem + L.p1;   // [tower][w0, w1, w2, sc, sh][64]
+  float* p2 = smem + L.p2;   // [tower][sc, sh][128]
+  float* p3 = smem + L.p3;   // [tower][sc, sh][C3]
+  const int CT3 = a.C3 >> 5;
+  const int tiles_per_cloud = (a.N + kSplitTP - 1) / kSplitTP, ntiles = 2 * a.B * tiles_per_cloud;
+  const bf16x8* img2 = reinterpret_cast<const bf16x8*>(a.w2s);
+  const bf16x8* img3 = reinterpret_cast<const bf16x8*>(a.w3s);
+  constexpr bool wide = MR == 4;
+  // the W3 image as a buffer resource (raw, dword-3 flags of gfx9: 32-bit data format), CT3 x 8 k-blocks x (hi, lo) x 1 KB
+  const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w3s), 0, CT3 * KB2 * 2048, 0x00020000);
+  const int first_pair = wide ? wave : (wave >> 1);
+
+  // the ring's first R k-blocks of this wave's first item: in flight under the table fill and the first tile's prologue
+  bf16x8 bh[2][R], bl[2][R];
+#pragma unroll
+  for (int kb = 0; kb < R; ++kb)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bh[c][kb] = img3[(((size_t)(2 * first_pair + c) * KB2 + kb) * 2) * 64 + lane];
+      bl[c][kb] = img3[(((size_t)(2 * first_pair + c) * KB2 + kb) * 2 + 1) * 64 + lane];
+    }
+  int t = blockIdx.x;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (t < ntiles && tid < kSplitTP) {
+    const int cloud = t / tiles_per_cloud, tile = t - cloud * tiles_per_cloud, tower = cloud >= a.B, b = cloud - tower * a.B;
+    const float* p = a.pcs[tower] + ((size_t)b * a.N + min(tile * kSplitTP + tid, a.N - 1)) * 3;
+    px = p[0]; py = p[1]; pz = p[2];
+  }
+  for (int i = tid; i < 2 * 5 * 64; i += kWaves * 64) {
+    const int tw = i / 320, j = i - tw * 320, which = j >> 6, c = j & 63;
+    p1[i] = which < 3 ? a.w1[which * kC1 + c] : (which == 3 ? a.sc1 : a.sh1)[tw * kC1 + c];
+  }
+  for (int i = tid; i < 2 * 2 * 128; i += kWaves * 64) {
+    const int tw = i >> 8, which = (i >> 7) & 1, c = i & 127;
+    p2[i] = (which ? a.sh2 : a.sc2)[tw * kC2 + c];
+  }
+  for (int i = tid; i < 4 * a.C3; i += kWaves * 64) {
+    const int tw = i / (2 * a.C3), j = i - tw * 2 * a.C3, which = j >= a.C3, c = j - which * a.C3;
+    p3[i] = (which ? a.sh3 : a.sc3)[tw * a.C3 + c];
+  }
+
+  for (; t < ntiles; t += gridDim.x) {
+    const int cloud = t / tiles_per_cloud, tower = cloud >= a.B, b = cloud - tower * a.B;
+    // the hidden layer's fragments (this wave's item): requested here, used two barriers on
+    bf16x8 w2h[KB1], w2l[KB1];
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+      w2h[kb] = img2[(((size_t)(wave >> 1) * KB1 + kb) * 2) * 64 + lane];
+      w2l[kb] = img2[(((size_t)(wave >> 1) * KB1 + kb) * 2 + 1) * 64 + lane];
+    }
+    // ---- p' = (p - c) @ R from the points requested one tile ago ----
+    if (tid < kSplitTP) {
+      const float* xf = a.xform + (size_t)cloud * 12;
+      const float x = px - xf[0], y = py - xf[1], z = pz - xf[2];
+      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
+      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
+      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+    }
+    __syncthreads();   // also: the tables (first tile)
+    // ---- layer 1 (K = 3, VALU, fp32) -> h1 hi / lo ----
+    {
+      const int c0 = tid & 31, r0 = tid >> 5;
+      const float* q = p1 + tower * 320;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = c0 + 32 * cc;
+        const float w0 = q[c], w1 = q[64 + c], w2 = q[128 + c], sc = q[192 + c], sh = q[256 + c];
+#pragma unroll
+        for (int rr = 0; rr < kSplitTP / 16; ++rr) {
+          const int row = rr * 16 + r0;
+          const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+          const float v = fmaxf(fmaf(fmaf(p[2], w2, fmaf(p[1], w1, p[0] * w0)), sc, sh), 0.f);
+          unsigned short hi, lo;
+          split_bf16(v, hi, lo);
+          s16[o1h + row * ld1 + c] = hi;
+          s16[o1l + row * ld1 + c] = lo;
+        }
+      }
+    }
+    __syncthreads();   // h1 complete; every wave has left the previous tile's last layer (h2 may be overwritten)
+    // ---- the next tile's points: three registers under the hidden layer and the last layer ----
+    {
+      // unconditional on a clamped tile and row (a conditional load is waited for inside its exec-masked block)
+      const int tn = min(t + (int)gridDim.x, ntiles - 1);
+      const int cn = tn / tiles_per_cloud, tile = tn - cn * tiles_per_cloud, twn = cn >= a.B, bn = cn - twn * a.B;
+      const float* p = a.pcs[twn] + ((size_t)bn * a.N + min(tile * kSplitTP + (tid & (kSplitTP - 1)), a.N - 1)) * 3;
+      px = p[0]; py = p[1]; pz = p[2];
+    }
+    // ---- layer 2: wave = (channel tile, 64-row half) ----
+    {
+      const int ct = wave >> 1, rg = wave & 1;
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      const int arow = (rg * 64 + (lane & 31)) * ld1 + half * 8;
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb) {
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o1h + arow + m * 32 * ld1 + kb * 16);
+          al[m] = *reinterpret_cast<const bf16x8*>(s16 + o1l + arow + m * 32 * ld1 + kb * 16);
+        }
+        split_mfma<2>(ah, al, w2h[kb], w2l[kb], acc);
+      }
+      const int col = ct * 32 + (lane & 31);
+      const float sc = p2[tower * 256 + col], sh = p2[tower * 256 + 128 + col];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rg * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          unsigned short hi, lo;
+          split_bf16(fmaxf(fmaf(acc[m][r], sc, sh), 0.f), hi, lo);
+          s16[o2h + row * ld2 + col] = hi;
+          s16[o2l + row * ld2 + col] = lo;
+        }
+    }
+    __syncthreads();
+    float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
+    split_last_layer<MR, R>(a, s16, p3, w3r, CT3, wave, lane, tower, dst, bh, bl);
+  }
+}
+
 }  // namespace alignnet

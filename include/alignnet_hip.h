@@ -347,6 +347,7 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
 #define ALIGNNET_KERNEL_POINTNET_FUSED_TP64 4       /* pointnet_fused<64> (ALIGNNET_TILE=64) */
 #define ALIGNNET_KERNEL_POINTNET_SPLIT 5            /* pointnet_split<> */
 #define ALIGNNET_KERNEL_POINTNET_SPLIT_64_128 6     /* pointnet_split<64, 128> */
+#define ALIGNNET_KERNEL_POINTNET_SPLIT_PERSIST 7    /* pointnet_split_persist: shipped widths, persistent workgroups */
 #define ALIGNNET_KERNEL_DGCNN_FUSED 10              /* dgcnn_fused<> */
 #define ALIGNNET_KERNEL_DGCNN_FUSED_64_128 11       /* dgcnn_fused<68, 132> */
 #define ALIGNNET_KERNEL_DGCNN_SPLIT 12              /* dgcnn_split<> */
