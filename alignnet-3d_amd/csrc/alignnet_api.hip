@@ -477,6 +477,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     sa.pcs[0] = p1; sa.pcs[1] = p2; sa.xform = a.xform; sa.pooled = pooled; sa.tower_stride = tower_stride; sa.row_stride = row_stride;
     sa.B = B; sa.N = a.N; sa.C1 = sc1; sa.C2 = sc2; sa.C3 = h->layers[st.first + 2].cout;
     sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
+    sa.dbg = h->ablate_dbg;
     sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
     const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);

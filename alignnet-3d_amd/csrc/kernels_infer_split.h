@@ -54,6 +54,7 @@ struct SplitArgs {
   const unsigned short* w2s;        // split image of W2 [C1][C2]
   const unsigned short* w3s;        // split image of W3 [C2][C3]
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // folded BN [2 towers][C]
+  int dbg = 0;                      // ablation build only (ablate.h): 1 = last layer without its LDS reads, 2 = without its weight requests, 4 = no lift / hidden layer, 8 = no last layer
 };
 
 // acc[m] += A[rows 32 m ..][16 kb ..] * W block, three bf16 MFMAs per product
@@ -236,6 +237,18 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   }
 }
 
+// two fp32 -> (hi, lo) bf16 pairs: hi = RNE(x) (one v_cvt_pk_bf16_f32 for both), lo = RNE(x - hi); the same values split_bf16 gives
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi, unsigned& lo)
+{
+  const f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
+}
+
 // ---- round 5: the shipped widths (64, 128) as a PERSISTENT workgroup with a two-channel-tile register block in the last layer ----
 // What the one-tile-per-workgroup kernel above loses: (1) with 108 KB of LDS there is one workgroup per CU, so every
 // 128-point tile pays the workgroup launch, the cold xyz round trip and the first weight fragments' round trip with nothing to run under
@@ -286,13 +299,19 @@ __device__ __forceinline__ void split_last_layer(const SplitArgs& a, const unsig
     for (int kb = 0; kb < KB2; ++kb) {
       const int slot = kb % R;
       bf16x8 ah[MR], al[MR];
+      if (ALN_ABL(a.dbg, 1)) {
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o2h + arow + m * 32 * ld2 + kb * 16);
-        al[m] = *reinterpret_cast<const bf16x8*>(s16 + o2l + arow + m * 32 * ld2 + kb * 16);
+        for (int m = 0; m < MR; ++m) { ah[m] = bh[0][m % R]; al[m] = bl[0][m % R]; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o2h + arow + m * 32 * ld2 + kb * 16);
+          al[m] = *reinterpret_cast<const bf16x8*>(s16 + o2l + arow + m * 32 * ld2 + kb * 16);
+        }
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c) split_mfma<MR>(ah, al, bh[c][slot], bl[c][slot], acc[c]);
+      if (ALN_ABL(a.dbg, 2)) continue;
       const int qp = kb + R < KB2 ? pair : npair, qk = (kb + R) % KB2;     // this slot's next user: R k-blocks on
       // buffer loads: resource + scalar offset + one 32-bit lane offset, no 64-bit address pair per stream
       const unsigned wq = (unsigned)(((2 * qp) * KB2 + qk) * 2048);
@@ -394,23 +413,25 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
     }
     __syncthreads();   // also: the tables (first tile)
     // ---- layer 1 (K = 3, VALU, fp32) -> h1 hi / lo ----
-    {
-      const int c0 = tid & 31, r0 = tid >> 5;
-      const float* q = p1 + tower * 320;
+    if (!(ALN_ABL(a.dbg, 4))) {
+      // a thread = four adjacent columns x four rows: parameters as five 16-byte LDS reads, h1 leaves as 8-byte packed stores
+      const int cg = (tid & 15) * 4, r0 = tid >> 4;
+      const float* q = p1 + tower * 320 + cg;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(q), w1 = *reinterpret_cast<const f32x4*>(q + 64), w2 = *reinterpret_cast<const f32x4*>(q + 128);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(q + 192), sh = *reinterpret_cast<const f32x4*>(q + 256);
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int c = c0 + 32 * cc;
-        const float w0 = q[c], w1 = q[64 + c], w2 = q[128 + c], sc = q[192 + c], sh = q[256 + c];
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 32 + r0;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
+        float v[4];
 #pragma unroll
-        for (int rr = 0; rr < kSplitTP / 16; ++rr) {
-          const int row = rr * 16 + r0;
-          const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
-          const float v = fmaxf(fmaf(fmaf(p[2], w2, fmaf(p[1], w1, p[0] * w0)), sc, sh), 0.f);
-          unsigned short hi, lo;
-          split_bf16(v, hi, lo);
-          s16[o1h + row * ld1 + c] = hi;
-          s16[o1l + row * ld1 + c] = lo;
-        }
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(fmaf(p[2], w2[j], fmaf(p[1], w1[j], p[0] * w0[j])), sc[j], sh[j]), 0.f);
+        unsigned h0, l0, h1, l1;
+        split_bf16_pair(v[0], v[1], h0, l0);
+        split_bf16_pair(v[2], v[3], h1, l1);
+        const u32x2 hi = {h0, h1}, lo = {l0, l1};
+        *reinterpret_cast<u32x2*>(s16 + o1h + row * ld1 + cg) = hi;
+        *reinterpret_cast<u32x2*>(s16 + o1l + row * ld1 + cg) = lo;
       }
     }
     __syncthreads();   // h1 complete; every wave has left the previous tile's last layer (h2 may be overwritten)
@@ -423,7 +444,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
       px = p[0]; py = p[1]; pz = p[2];
     }
     // ---- layer 2: wave = (channel tile, 64-row half) ----
-    {
+    if (!(ALN_ABL(a.dbg, 4))) {
       const int ct = wave >> 1, rg = wave & 1;
       f32x16 acc[2];
 #pragma unroll
@@ -439,24 +460,37 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
           ah[m] = *reinterpret_cast<const bf16x8*>(s16 + o1h + arow + m * 32 * ld1 + kb * 16);
           al[m] = *reinterpret_cast<const bf16x8*>(s16 + o1l + arow + m * 32 * ld1 + kb * 16);
         }
-        split_mfma<2>(ah, al, w2h[kb], w2l[kb], acc);
+        // TRANSPOSED product (weights as the A operand): a lane ends up with one point and sixteen channels, four adjacent ones per
+        // accumulator quad -- h2 leaves as 8-byte packed stores.  Same products in the same order per output as split_mfma.
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], al[m], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[kb], ah[m], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], ah[m], acc[m], 0, 0, 0);
       }
-      const int col = ct * 32 + (lane & 31);
-      const float sc = p2[tower * 256 + col], sh = p2[tower * 256 + 128 + col];
+      const float* q2 = p2 + tower * 256 + ct * 32 + 4 * half;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(q2 + 8 * qd), sh = *reinterpret_cast<const f32x4*>(q2 + 128 + 8 * qd);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rg * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          unsigned short hi, lo;
-          split_bf16(fmaxf(fmaf(acc[m][r], sc, sh), 0.f), hi, lo);
-          s16[o2h + row * ld2 + col] = hi;
-          s16[o2l + row * ld2 + col] = lo;
+        for (int m = 0; m < 2; ++m) {
+          const int row = rg * 64 + m * 32 + (lane & 31), col = ct * 32 + 8 * qd + 4 * half;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[m][4 * qd + j], sc[j], sh[j]), 0.f);
+          unsigned h0, l0, h1, l1;
+          split_bf16_pair(v[0], v[1], h0, l0);
+          split_bf16_pair(v[2], v[3], h1, l1);
+          const u32x2 hi = {h0, h1}, lo = {l0, l1};
+          *reinterpret_cast<u32x2*>(s16 + o2h + row * ld2 + col) = hi;
+          *reinterpret_cast<u32x2*>(s16 + o2l + row * ld2 + col) = lo;
         }
+      }
     }
     __syncthreads();
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
-    split_last_layer<MR, R>(a, s16, p3, w3r, CT3, wave, lane, tower, dst, bh, bl);
+    if (!(ALN_ABL(a.dbg, 8))) split_last_layer<MR, R>(a, s16, p3, w3r, CT3, wave, lane, tower, dst, bh, bl);
   }
 }
 
