@@ -477,7 +477,8 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     sa.pcs[0] = p1; sa.pcs[1] = p2; sa.xform = a.xform; sa.pooled = pooled; sa.tower_stride = tower_stride; sa.row_stride = row_stride;
     sa.B = B; sa.N = a.N; sa.C1 = sc1; sa.C2 = sc2; sa.C3 = h->layers[st.first + 2].cout;
     sa.w1 = a.L[0].w; sa.w2s = h->d_wps + h->off_wps[st.first + 1]; sa.w3s = h->d_wps + h->off_wps[st.first + 2];
-    sa.dbg = h->ablate_dbg;
+    sa.dbg = h->ablate_dbg & 0xff;
+    if (h->ablate_dbg >> 8) sa.prio_mask = (h->ablate_dbg >> 8) & 0xff;   // ablation build: ALIGNNET_DBG bits 8 .. 15
     sa.sc1 = a.L[0].scale; sa.sh1 = a.L[0].shift; sa.sc2 = a.L[1].scale; sa.sh2 = a.L[1].shift; sa.sc3 = a.L[2].scale; sa.sh3 = a.L[2].shift;
     const int ld1s = ((sc1 + 15) & ~15) + 8, ld2s = ((sc2 + 15) & ~15) + 8;
     const size_t slds = (size_t)kSplitTP * 4 * sizeof(float) + (size_t)2 * kSplitTP * (ld1s + ld2s) * sizeof(unsigned short);
@@ -497,9 +498,26 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
       }
       const long tiles = (long)2 * B * ((a.N + kSplitTP - 1) / kSplitTP);
       const int wgs = (int)std::min<long>(tiles, cus[h->cfg.device & 63]);
+      {
+#ifdef ALIGNNET_ABLATE
+      if ((sa.dbg & 64) && sa.C3 == 1024) { sa.stamps = reinterpret_cast<long long*>(h->ws.hid_a); hipMemsetAsync(sa.stamps, 0, 8 * 16 * sizeof(long long), h->stream); }
+#endif
       if (sa.C3 >= 512) { TIMED_LAUNCH(pointnet_split_persist<4>, dim3(wgs), dim3(kWaves * 64), (size_t)split_persist_lds(sa.C3).total_bytes, sa); }
       else { TIMED_LAUNCH(pointnet_split_persist<2>, dim3(wgs), dim3(kWaves * 64), (size_t)split_persist_lds(sa.C3).total_bytes, sa); }
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT_PERSIST;
+#ifdef ALIGNNET_ABLATE
+      if (sa.stamps) {
+        long long hs[8 * 16];
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(hs, sa.stamps, sizeof(hs), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w) {
+          std::fprintf(stderr, "psp wave %d: start +%lld |", w, hs[w * 16] - hs[0]);
+          for (int i = 1; i < 7; ++i) std::fprintf(stderr, " %lld", hs[w * 16 + i] - hs[w * 16 + i - 1]);
+          std::fprintf(stderr, "   (xs+barrier, lift, barrier, hidden, barrier, last layer)\n");
+        }
+      }
+#endif
+      }
     } else if (sc1 == 64 && sc2 == 128 && !(h->ab & AB_NO_LD_CONST)) {
       static PerDeviceOnce sattr;
       if (sattr.need(h->cfg.device)) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_split<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr.mark(h->cfg.device); }

@@ -54,16 +54,18 @@ struct SplitArgs {
   const unsigned short* w2s;        // split image of W2 [C1][C2]
   const unsigned short* w3s;        // split image of W3 [C2][C3]
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // folded BN [2 towers][C]
+  int prio_mask = 0x7f;             // pointnet_split_persist: the k-blocks of an item in which waves 0 .. 3 run at priority 2 (else 0; waves 4 .. 7 at 1)
+  long long* stamps = nullptr;      // ablation build only, dbg & 64: cycle stamps of workgroup 0's waves at the phase boundaries of its third tile
   int dbg = 0;                      // ablation build only (ablate.h): 1 = last layer without its LDS reads, 2 = without its weight requests, 4 = no lift / hidden layer, 8 = no last layer
 };
 
 // acc[m] += A[rows 32 m ..][16 kb ..] * W block, three bf16 MFMAs per product
-template <int MR>
+template <int MR, bool PRIO = true>
 __device__ __forceinline__ void split_mfma(const bf16x8 (&ah)[MR], const bf16x8 (&al)[MR], const bf16x8& bh, const bf16x8& bl,
                                            f32x16 (&acc)[MR])
 {
 #ifdef ALIGNNET_SETPRIO
-  __builtin_amdgcn_s_setprio(1);
+  if (PRIO) __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void split_mfma(const bf16x8 (&ah)[MR], const bf16x8 
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
 #ifdef ALIGNNET_SETPRIO
-  __builtin_amdgcn_s_setprio(0);
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
@@ -116,9 +118,9 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
     const float* p = a.pcs[tower] + ((size_t)b * a.N + n) * 3;
     const float* xf = a.xform + (size_t)cloud * 12;
     const float x = p[0] - xf[0], y = p[1] - xf[1], z = p[2] - xf[2];
-    xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-    xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-    xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+    xs[tid * 4 + 0] = fmaf(z, xf[9], fmaf(y, xf[6], x * xf[3]));
+    xs[tid * 4 + 1] = fmaf(z, xf[10], fmaf(y, xf[7], x * xf[4]));
+    xs[tid * 4 + 2] = fmaf(z, xf[11], fmaf(y, xf[8], x * xf[5]));
   }
   __syncthreads();
 
@@ -240,6 +242,7 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
 // two fp32 -> (hi, lo) bf16 pairs: hi = RNE(x) (one v_cvt_pk_bf16_f32 for both), lo = RNE(x - hi); the same values split_bf16 gives
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi, unsigned& lo)
 {
@@ -288,6 +291,7 @@ __device__ __forceinline__ void split_last_layer(const SplitArgs& a, const unsig
     const int nitem = item + kWaves < nitems ? item + kWaves : wave;     // past this tile's last item: the next tile's first
     const int npair = MR == 4 ? nitem : (nitem >> 1);
     const int arow = (rg * 64 + (lane & 31)) * ld2 + half * 8;
+    float hi0 = -INFINITY, lo0 = INFINITY;
     f32x16 acc[2][MR];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -309,8 +313,32 @@ __device__ __forceinline__ void split_last_layer(const SplitArgs& a, const unsig
           al[m] = *reinterpret_cast<const bf16x8*>(s16 + o2l + arow + m * 32 * ld2 + kb * 16);
         }
       }
+      // Issue arbitration is oldest-first at equal priority: left alone, waves 0 .. 3 take the matrix pipe whenever they can and finish a
+      // tile's last layer ~10 k cycles before waves 4 .. 7 of the same SIMDs, which then run alone at half the pipe's rate (cycle stamps,
+      // DESIGN.md 4.1b).  The older wave alternates between priority 2 and 0 per k-block, the younger one stays at 1: each wins half the ties.
+      if (wave < 4) { if ((a.prio_mask >> kb) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+      else if (kb == 0) __builtin_amdgcn_s_setprio(1);
+      split_mfma<MR, false>(ah, al, bh[0][slot], bl[0][slot], acc[0]);
+      if (kb < KB2 - 1) {
+        split_mfma<MR, false>(ah, al, bh[1][slot], bl[1][slot], acc[1]);
+      } else {
+        // channel tile 0 is complete: its maxima / minima go BETWEEN channel tile 1's last 3 MR MFMAs (a wave's epilogue is otherwise time
+        // in which it issues no MFMA, and the SIMD's other wave reaches its own epilogue at the same moment): same MFMA order as split_mfma
 #pragma unroll
-      for (int c = 0; c < 2; ++c) split_mfma<MR>(ah, al, bh[c][slot], bl[c][slot], acc[c]);
+        for (int g = 0; g < 3 * MR; ++g) {
+          const int m = g % MR, prod = g / MR;
+          acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(prod == 0 ? al[m] : ah[m], prod == 1 ? bl[1][slot] : bh[1][slot], acc[1][m], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 8 * MR; ++st)
+            if ((3 * st) / 8 == g) {
+              const int mm = st / 8, r = 2 * (st % 8);
+              hi0 = fmaxf(fmaxf(hi0, acc[0][mm][r]), acc[0][mm][r + 1]);
+              lo0 = fminf(fminf(lo0, acc[0][mm][r]), acc[0][mm][r + 1]);
+            }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+      }
       if (ALN_ABL(a.dbg, 2)) continue;
       const int qp = kb + R < KB2 ? pair : npair, qk = (kb + R) % KB2;     // this slot's next user: R k-blocks on
       // buffer loads: resource + scalar offset + one 32-bit lane offset, no 64-bit address pair per stream
@@ -325,14 +353,17 @@ __device__ __forceinline__ void split_last_layer(const SplitArgs& a, const unsig
     for (int c = 0; c < 2; ++c) {
       const int col = (2 * pair + c) * 32 + (lane & 31);
       const float sc = p3[(tower * 2 + 0) * a.C3 + col], sh = p3[(tower * 2 + 1) * a.C3 + col];
-      float hi = -INFINITY, lo = INFINITY;
+      float hi = hi0, lo = lo0;
+      if (c == 1) {
+        hi = -INFINITY; lo = INFINITY;
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(acc[c][m][r]), "v"(acc[c][m][r + 1]));
-          asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(acc[c][m][r]), "v"(acc[c][m][r + 1]));
-        }
+          for (int r = 0; r < 16; r += 2) {
+            hi = fmaxf(fmaxf(hi, acc[1][m][r]), acc[1][m][r + 1]);
+            lo = fminf(fminf(lo, acc[1][m][r]), acc[1][m][r + 1]);
+          }
+      }
       float mx = fmaxf(fmaxf(fmaf(hi, sc, sh), fmaf(lo, sc, sh)), 0.f);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (lane < 32) atomicMax(reinterpret_cast<int*>(dst + col), __float_as_int(mx));
@@ -394,7 +425,9 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
     p3[i] = (which ? a.sh3 : a.sc3)[tw * a.C3 + c];
   }
 
+#define PSP_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && lane == 0 && t == 2 * (int)gridDim.x) a.stamps[wave * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   for (; t < ntiles; t += gridDim.x) {
+    PSP_STAMP(0);
     const int cloud = t / tiles_per_cloud, tower = cloud >= a.B, b = cloud - tower * a.B;
     // the hidden layer's fragments (this wave's item): requested here, used two barriers on
     bf16x8 w2h[KB1], w2l[KB1];
@@ -407,11 +440,12 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
     if (tid < kSplitTP) {
       const float* xf = a.xform + (size_t)cloud * 12;
       const float x = px - xf[0], y = py - xf[1], z = pz - xf[2];
-      xs[tid * 4 + 0] = x * xf[3] + y * xf[6] + z * xf[9];
-      xs[tid * 4 + 1] = x * xf[4] + y * xf[7] + z * xf[10];
-      xs[tid * 4 + 2] = x * xf[5] + y * xf[8] + z * xf[11];
+      xs[tid * 4 + 0] = fmaf(z, xf[9], fmaf(y, xf[6], x * xf[3]));
+      xs[tid * 4 + 1] = fmaf(z, xf[10], fmaf(y, xf[7], x * xf[4]));
+      xs[tid * 4 + 2] = fmaf(z, xf[11], fmaf(y, xf[8], x * xf[5]));
     }
     __syncthreads();   // also: the tables (first tile)
+    PSP_STAMP(1);
     // ---- layer 1 (K = 3, VALU, fp32) -> h1 hi / lo ----
     if (!(ALN_ABL(a.dbg, 4))) {
       // a thread = four adjacent columns x four rows: parameters as five 16-byte LDS reads, h1 leaves as 8-byte packed stores
@@ -434,7 +468,9 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
         *reinterpret_cast<u32x2*>(s16 + o1l + row * ld1 + cg) = lo;
       }
     }
+    PSP_STAMP(2);
     __syncthreads();   // h1 complete; every wave has left the previous tile's last layer (h2 may be overwritten)
+    PSP_STAMP(3);
     // ---- the next tile's points: three registers under the hidden layer and the last layer ----
     {
       // unconditional on a clamped tile and row (a conditional load is waited for inside its exec-masked block)
@@ -488,9 +524,12 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
         }
       }
     }
+    PSP_STAMP(4);
     __syncthreads();
+    PSP_STAMP(5);
     float* dst = a.pooled + tower * a.tower_stride + b * a.row_stride;
     if (!(ALN_ABL(a.dbg, 8))) split_last_layer<MR, R>(a, s16, p3, w3r, CT3, wave, lane, tower, dst, bh, bl);
+    PSP_STAMP(6);
   }
 }
 

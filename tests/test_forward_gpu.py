@@ -71,23 +71,28 @@ def test_forward_split_bf16_synthcars_widths_n1024(gpu_required):
     assert LAST_KERNEL == "pointnet_split_persist", LAST_KERNEL
 
 
-@pytest.mark.parametrize("N,B", [(1024, 8), (1000, 3), (333, 70), (128, 1), (4096, 2)])
+@pytest.mark.parametrize("N,B", [(1024, 8), (1000, 3), (333, 70), (128, 1), (4096, 2), (1024, 300)])
 def test_split_persistent_kernel_is_bit_identical_to_the_tilewise_one(gpu_required, N, B):
-    """pointnet_split_persist (persistent workgroups, two channel tiles per wave in the last layer, C3 = 256 / 512 / 1024 in the three
-    stages of the shipped widths) accumulates every output in the order pointnet_split<64, 128> does: identical bits, on ragged tiles
-    (N not a multiple of 128), fewer tiles than CUs and more tiles than one pass of the grid."""
+    """pointnet_split_persist (persistent workgroups, two channel tiles per wave in the last layer, the hidden layer as the transposed product
+    with packed stores; C3 = 256 / 512 / 1024 in the three stages of the shipped widths) accumulates every output in the order
+    pointnet_split<64, 128> does: identical bits, on ragged tiles (N not a multiple of 128), fewer tiles than CUs and several passes of the
+    grid; a second launch (the weight ring and the point prefetch start over) gives the same bits again."""
     cfg = alignnet3d.default_model_config()
     cfg["model"]["num_points"] = N
     spec, P32 = oracle_params(cfg)
     d = R.synth_pairs(B, N, seed=77, dtype=np.float32)
     out = {}
-    for mode in ("persist", "tilewise"):
+    for mode, kernel in (("tilewise", "pointnet_split<64,128>"), ("persist", "pointnet_split_persist")):
         eng = alignnet3d.Engine(cfg)
         eng.set_variables(P32)
         eng.set_option("infer_matmul_bf16x3", 1)
         eng.set_option("ab_split_tilewise", int(mode == "tilewise"))
         out[mode] = eng.forward(d["pcs1"], d["pcs2"])
-        assert eng.last_backbone_kernel() == ("pointnet_split_persist" if mode == "persist" else "pointnet_split<64,128>")
+        if mode == "persist":
+            again = eng.forward(d["pcs1"], d["pcs2"])
+            for k in again:
+                np.testing.assert_array_equal(again[k], out[mode][k], err_msg=k)
+        assert eng.last_backbone_kernel() == kernel
         eng.close()
     for k in out["persist"]:
         np.testing.assert_array_equal(out["persist"][k], out["tilewise"][k], err_msg=k)
