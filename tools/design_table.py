@@ -72,7 +72,7 @@ if b:
             % (x["mfma_busy"], x["lds_conflict_share"] or 0, x["fetch_MB_per_launch"], x["write_MB_per_launch"]), "`profiles/%s_pmc_by_kernel.json`" % R)
     if "infer_bf16x3" in b:
         s = b["infer_bf16x3"]
-        add("opt-in split-bf16 backbone (never the headline)", "%.0f k pairs/s (%.2f ms/step), `pointnet_split` at %.2f of (bf16 peak / 3)" % (s["value"] / 1e3, s["ms_per_step"], s["roofline"]["frac"]), "bench `infer_bf16x3`")
+        add("opt-in split-bf16 backbone (never the headline)", "%.0f k pairs/s (%.2f ms/step), `%s` at %.2f of (bf16 peak / 3)" % (s["value"] / 1e3, s["ms_per_step"], s["roofline"].get("kernel", "pointnet_split"), s["roofline"]["frac"]), "bench `infer_bf16x3`")
     if "pcie_inclusive" in b:
         pc = b["pcie_inclusive"]
         add("host to host, blocking `alignnet_forward` (pageable buffers; the reference's own timing, train.py:447-449)", "%.1f k pairs/s (%.2f ms/step)" % (pc["value"] / 1e3, pc["ms_per_step"]), "bench `pcie_inclusive`; never `value`")

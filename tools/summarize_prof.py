@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 rocpd databases (gpurun_out/prof_<tag>) into small text files for profiles/.
 Usage: tools/summarize_prof.py gpurun_out/prof_r01 r01 [dest_dir]"""
-import glob, json, os, sqlite3, sys
+import re, glob, json, os, sqlite3, sys
 from collections import defaultdict
 
 if __name__ != "__main__":   # imported by tests/test_bench_launcher_cpu.py for traffic_summary(): nothing to read
@@ -12,7 +12,10 @@ else:
     os.makedirs(dst, exist_ok=True)
 
 def short(n):
-    return n.split("(")[0].replace("alignnet::", "")
+    n = n.split("(")[0].replace("alignnet::", "")
+    # instantiations that are ONE kernel to bench.py (its kernel timers and `roofline.launches_per_step` count them together): the
+    # persistent split-bf16 backbone runs as <4> (C3 >= 512) and <2> (C3 = 256) within one step
+    return re.sub(r"pointnet_split_persist<\d+>", "pointnet_split_persist", n)
 
 # 1. kernel-trace stats (rocprofv3 --kernel-trace --stats)
 for db in (glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True) if out else []):
