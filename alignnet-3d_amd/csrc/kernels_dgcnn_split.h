@@ -72,6 +72,57 @@ __device__ __forceinline__ void dg_lift_split(const DgcnnSplitArgs& a, int tower
   }
 }
 
+// The same lift on the matrix pipe for Ca = 64 (round 5; dgcnn_fused's shipped shape has lifted this way since round 3): k padded to 8 with
+// zero weights (the caller zeroes es columns 6 / 7 once), the [64 rows][64 channels] output cut into 16 x 16 tiles of
+// v_mfma_f32_16x16x4_f32 (two instructions per tile), two tiles per wave -- as the TRANSPOSED product (weights as the A operand), so a lane
+// ends up with one row and four adjacent channels: one v_cvt_pk pair and one 8-byte store each for the hi and the lo tile.  Per thread and
+// slot 2 x (two 4-byte LDS reads, two MFMAs, 22 vector instructions, two 8-byte stores) instead of 8 x (14 vector instructions, two 2-byte
+// stores) + eight 16-byte reads: the VALU lift was what the edge phase waited for (~1800 vector instructions per SIMD and slot pair next
+// to 3 k cycles of MFMA).
+struct DgLiftMS { float w[2][2]; float sc[2][4], sh[2][4]; };
+
+__device__ __forceinline__ DgLiftMS dg_liftms_load(const DgcnnSplitArgs& a, int tower, int wave, int lane)
+{
+  DgLiftMS L;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ctile = (2 * wave + i) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = 4 * ks + (lane >> 4);
+      L.w[i][ks] = kk < 6 ? a.w1[kk * 64 + 16 * ctile + (lane & 15)] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      L.sc[i][r] = a.sc1[tower * 64 + 16 * ctile + 4 * (lane >> 4) + r];
+      L.sh[i][r] = a.sh1[tower * 64 + 16 * ctile + 4 * (lane >> 4) + r];
+    }
+  }
+  return L;
+}
+
+__device__ __forceinline__ void dg_liftms(const DgLiftMS& L, const float* es, unsigned short* th, unsigned short* tl, int wave, int lane)
+{
+  constexpr int lda = 72;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = 2 * wave + i, rt = t >> 2, ctile = t & 3;
+    const float* ar = es + (16 * rt + (lane & 15)) * 8 + (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w[i][0], ar[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w[i][1], ar[4], acc, 0, 0, 0);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[r], L.sc[i][r], L.sh[i][r]), 0.f);
+    unsigned h0, l0, h1, l1;
+    split_bf16_pair(v[0], v[1], h0, l0);
+    split_bf16_pair(v[2], v[3], h1, l1);
+    const int o = (16 * rt + (lane & 15)) * lda + 16 * ctile + 4 * (lane >> 4);
+    *reinterpret_cast<u32x2*>(th + o) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(tl + o) = u32x2{l0, l1};
+  }
+}
+
 // CaT / CbT != 0: the shipped edge widths compiled in (strides, k-depths and tile counts become constants)
 template <int CaT = 0, int CbT = 0>
 static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const DgcnnSplitArgs a0)
@@ -171,15 +222,26 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void dgcnn_split(const Dgcnn
   };
   // two neighbour slots per iteration (slot s -> es / tile buffer 0, slot s+1 -> es' / tile buffer 1): publish both edge
   // features, lift both, run both edge convs -- three barriers per two slots instead of four
-  const DgLiftW LW = dg_lift_weights(a, tower, tid);
+  constexpr bool kLiftM = CaT == 64;                       // the lift on the matrix pipe (dg_liftms)
+  DgLiftW LW;
+  DgLiftMS LM;
+  if constexpr (kLiftM) {
+    LM = dg_liftms_load(a, tower, wave, lane);
+    if (tid < kDgTile) { es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f; es2[tid * 8 + 6] = 0.f; es2[tid * 8 + 7] = 0.f; }   // k padding: never written again
+  } else LW = dg_lift_weights(a, tower, tid);
   for (int slot = 0; slot < a.k; slot += 2) {
     const bool two = slot + 1 < a.k;
     write_es(slot);
     if (two) write_es(slot + 1);
     __syncthreads();
     if (!(ALN_ABL(a.dbg, 2))) {
-      dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
-      if (two) dg_lift_split(a, tower, LW, es2, s16 + 2 * tsz, s16 + 3 * tsz, lda, Ka, tid);
+      if constexpr (kLiftM) {
+        dg_liftms(LM, es, s16, s16 + tsz, wave, lane);
+        if (two) dg_liftms(LM, es2, s16 + 2 * tsz, s16 + 3 * tsz, wave, lane);
+      } else {
+        dg_lift_split(a, tower, LW, es, s16, s16 + tsz, lda, Ka, tid);
+        if (two) dg_lift_split(a, tower, LW, es2, s16 + 2 * tsz, s16 + 3 * tsz, lda, Ka, tid);
+      }
     }
     __syncthreads();
     if (!(ALN_ABL(a.dbg, 1))) {
