@@ -2,6 +2,7 @@
 declares.  No compute calls here (there is no GPU and no CPU fallback)."""
 import os
 import re
+import sys
 
 import pytest
 
@@ -185,3 +186,32 @@ def test_shipped_library_reads_no_environment_and_carries_no_ablation_switch():
             for m in re.finditer(r"getenv\(", text):
                 guard = text.rfind("#ifdef ALIGNNET_ABLATE", 0, m.start())
                 assert guard >= 0 and text.find("#endif", guard, m.start()) < 0, f"{f}: getenv outside an ALIGNNET_ABLATE block"
+
+
+def test_kernel_ids_and_option_keys_agree_between_header_engine_and_python():
+    """`last_backbone_kernel` reports an ALIGNNET_KERNEL_* number (include/alignnet_hip.h); the Python side maps it to a name the -m gpu tests
+    assert on (alignnet3d/engine.py KERNEL_IDS).  Every id of the header has exactly one name and vice versa, and every `ab_*` key the
+    header's option list names is one csrc/engine.h dispatches on."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "alignnet-3d_amd"))
+    from alignnet3d.engine import KERNEL_IDS
+    hdr = open(os.path.join(ROOT, "include", "alignnet_hip.h")).read()
+    ids = {name: int(num) for name, num in re.findall(r"#define ALIGNNET_KERNEL_(\w+) (\d+)", hdr)}
+    assert sorted(ids.values()) == sorted(KERNEL_IDS.values()), (ids, KERNEL_IDS)
+    assert len(set(KERNEL_IDS.values())) == len(KERNEL_IDS)
+    eng = open(os.path.join(ROOT, "alignnet-3d_amd", "csrc", "engine.h")).read()
+    keys = set(re.findall(r'\{"(ab_\w+)", AB_\w+\}', eng))
+    named = set(re.findall(r'"(ab_\w+)"', hdr)) - {"ab_tiles_per_wg", "ab_mask"}
+    assert named <= keys, named - keys
+    assert "ab_split_tilewise" in keys
+
+
+def test_profile_summaries_count_the_persistent_split_kernel_once():
+    """tools/summarize_prof.py folds pointnet_split_persist<4> / <2> into one kernel name: bench.py's timers and `roofline.launches_per_step`
+    (3 per step) count the backbone launches together, and tests/test_bench_launcher_cpu.py compares the two."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+    sp = importlib.import_module("summarize_prof")
+    assert sp.short("void alignnet::pointnet_split_persist<4>(alignnet::SplitArgs)") == "void pointnet_split_persist"
+    assert sp.short("void alignnet::pointnet_split_persist<2>(alignnet::SplitArgs)") == "void pointnet_split_persist"
+    assert sp.short("void alignnet::pointnet_split<64, 128>(alignnet::SplitArgs)") == "void pointnet_split<64, 128>"
