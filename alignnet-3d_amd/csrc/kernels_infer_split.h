@@ -256,7 +256,8 @@ __device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi
 // What the one-tile-per-workgroup kernel above loses: (1) with 108 KB of LDS there is one workgroup per CU, so every
 // 128-point tile pays the workgroup launch, the cold xyz round trip and the first weight fragments' round trip with nothing to run under
 // them (~2 of the ~3.9 us a tile spends before its last layer); (2) in the last layer every wave reads the whole h2 tile (hi + lo, 64 KB)
-// from LDS for each 32-channel tile: 2 ds_read_b128 per 3 MFMAs = the LDS pipe 67 % busy next to a matrix pipe that wants 100 %.
+// from LDS for each 32-channel tile: 2 ds_read_b128 per 3 MFMAs = the LDS pipe 67 % busy next to a matrix pipe that wants 100 % (the ablation
+// build later showed these reads are not what the last layer waits for: what the two-tile block buys is the smaller weight ring).
 // Here a workgroup walks tiles t = blockIdx.x, + gridDim.x, ...: the next tile's points are requested before the last layer and sit in three
 // registers under it, the rolling weight ring runs across the tile boundary (the first item's fragments are the same for every tile), the
 // per-column parameters of all three layers live in LDS tables filled once per workgroup; and a wave's item in the last layer is TWO channel
