@@ -398,10 +398,14 @@ class Engine:
         self._check(self._lib.alignnet_debug_knn_graph(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
         return a
 
-    def debug_train_decisions(self, B):
+    def debug_train_decisions(self, B, relu=False):
         """What the last training forward (of B pairs) decided -- the graph's discontinuous choices, for decision-pinned parity tests
         (include/alignnet_hip.h: alignnet_debug_train_decisions).  dict: "yaw" int32 [2, B]; "pool" list over the three stages of
-        [2, B, C_last]; dgcnn engines also "slot" list of [2, B, N, C_edge] and "knn" [2, B, N, 20].  Tower outermost."""
+        [2, B, C_last]; dgcnn engines also "slot" list of [2, B, N, C_edge] and "knn" [2, B, N, 20].  Tower outermost.
+        relu=True adds "relu": the sign every relu of that step saw (alignnet_debug_train_relu_mask), keyed as oracle/alignnet_torch.py keys
+        its layers -- "<tower>:<scope>/conv<l>" bool [B*N(*k), C] (the conv in front of a max: at the winner), "<tower>:<scope>/fc<j>" [B, C],
+        "p:fc<j>" for the pair head.  Call it right after train_forward_backward (the masks of recomputed layers are rebuilt from the
+        step's parameters and statistics)."""
         o, n = self.cfg["model"]["options"], self.num_points
         convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
         ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
@@ -414,6 +418,42 @@ class Engine:
         if self.cfg["model"]["backbone"] == "dgcnn":
             out["slot"] = [get(2, s, (2, B, n, convs[s][-2])) for s in range(3)]
             out["knn"] = get(3, 0, (2, B, n, 20))
+        if relu:
+            out["relu"] = self.debug_train_relu_masks(B)
+        return out
+
+    def debug_train_relu_masks(self, B):
+        o, n = self.cfg["model"]["options"], self.num_points
+        dg = self.cfg["model"]["backbone"] == "dgcnn"
+        convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
+        fcs = [list(o["s1transformer"][1][0]), list(o["s2transformer"][1][0]), list(o["remaining_transform_prediction"][0])]
+        scopes = ["transformer1/embedding", "transformer2/embedding", "embedding"]
+        heads = ["transformer1/mlp/", "transformer2/mlp/", ""]
+
+        def get(kind, stage, layer, shape):
+            a = np.empty(shape, np.uint8)
+            self._check(self._lib.alignnet_debug_train_relu_mask(self._h, kind, stage, layer, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size))
+            return a.astype(bool)
+        out = {}
+        for s in range(3):
+            nl = len(convs[s])
+            for l, c in enumerate(convs[s]):
+                if l == nl - 1:
+                    shape = (2, B, c)                 # at the winning point
+                elif dg and l == nl - 2:
+                    shape = (2, B * n, c)             # at the winning neighbour slot
+                else:
+                    shape = (2, B * n * (20 if dg else 1), c)
+                m = get(0, s, l, shape)
+                for t in range(2):
+                    out[f"{t}:{scopes[s]}/conv{l + 1}"] = m[t]
+            for j, c in enumerate(fcs[s]):
+                if s < 2:
+                    m = get(1, s, j, (2, B, c))
+                    for t in range(2):
+                        out[f"{t}:{heads[s]}fc{j + 1}"] = m[t]
+                else:
+                    out[f"p:fc{j + 1}"] = get(1, s, j, (B, c))
         return out
 
     def grad_buffer(self):

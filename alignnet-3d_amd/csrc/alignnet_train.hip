@@ -8,6 +8,7 @@
 #include "kernels_train_dgcnn.h"
 #include "kernels_train_generic.h"
 #include "comm_loopback.h"
+#include "kernels_debug.h"
 
 #include <algorithm>
 #include <cmath>
@@ -94,6 +95,7 @@ struct TrainWS {
   int cap = 0;
   char* base = nullptr; size_t bytes = 0;
   float* d_pcs[2] = {nullptr, nullptr};
+  const float* last_pcs[2] = {nullptr, nullptr};   // the point clouds (device) of the last training forward (alignnet_debug_train_relu_mask)
   float* labels[6];              // device copies of the label tensors
   float* dropout_u;              // host-supplied uniforms (device copy), [sum over heads]
   float* center_mean; float* s1c; float* s2c; float* theta; int* cls;
@@ -1591,6 +1593,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   if (set_lds_attrs(h)) return 1;
   h->sync_collectives = 0;
   h->last_train_B = B;
+  w->last_pcs[0] = p1; w->last_pcs[1] = p2;
   if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;   // (as the eval forward does: ~15 event pairs per profiled step)
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
@@ -2113,6 +2116,94 @@ extern "C" int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, 
     return 0;
   }
   return fail(h, "alignnet_debug_train_decisions: unknown kind");
+}
+
+// test hook (include/alignnet_hip.h): the sign every relu of the last training forward / backward saw, one byte per element (kernels_debug.h)
+extern "C" int alignnet_debug_train_relu_mask(alignnet_handle* h, int32_t kind, int32_t stage, int32_t layer, uint8_t* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!dst) return fail(h, "alignnet_debug_train_relu_mask: null argument");
+  TrainWS* w = static_cast<TrainWS*>(h->train_ws);
+  const int B = h->last_train_B, N = h->cfg.num_points;
+  if (!w || !w->base || B < 1) return fail(h, "alignnet_debug_train_relu_mask: no training forward has run on this handle");
+  if (stage < 0 || stage > 2) return fail(h, "alignnet_debug_train_relu_mask: stage must be 0, 1 or 2");
+  const bool dg = h->cfg.backbone == 1, was_bf16 = (h->last_train_kernel & 2) != 0;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  size_t n = 0;
+  unsigned char* d = nullptr;
+  auto begin = [&](size_t elems) -> int {
+    n = elems;
+    if (count != n) return fail(h, "alignnet_debug_train_relu_mask: count does not match the requested array (" + std::to_string(n) + " elements)");
+    HIP_TRY(h, hipMalloc(&d, n));
+    return 0;
+  };
+  auto finish = [&]() -> int {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIP_TRY(h, e);
+    return 0;
+  };
+  const dim3 blk(256);
+  auto grid_of = [](size_t elems) { return dim3((unsigned)((elems + 255) / 256)); };
+  if (kind == ALIGNNET_RELU_HEAD) {
+    const Stack& fs = fc_of(h, stage);
+    if (layer < 0 || layer >= fs.n - 1) return fail(h, "alignnet_debug_train_relu_mask: the head has no hidden layer of that index");
+    const Layer& L = h->layers[fs.first + layer];
+    const HeadLayerWS& HL = w->hl[stage][layer];
+    const int M = stage < 2 ? 2 * B : B, rows_per_set = B;
+    if (begin((size_t)M * L.cout)) return 1;
+    const int s1 = L.p_bn[1][0] >= 0 ? 1 : 0;
+    hipLaunchKernelGGL(dbg_mask_head_kernel, grid_of(n), blk, 0, h->stream, HL.z, HL.mean, HL.var, P(h, L.p_bn[0][1]), P(h, L.p_bn[s1][1]),
+                       P(h, L.p_bn[0][0]), P(h, L.p_bn[s1][0]), M, L.cout, rows_per_set, d);
+    return finish();
+  }
+  if (kind != ALIGNNET_RELU_CONV) return fail(h, "alignnet_debug_train_relu_mask: unknown kind");
+  const Stack& st = conv_of(h, stage);
+  if (layer < 0 || layer >= st.n) return fail(h, "alignnet_debug_train_relu_mask: the stage has no conv layer of that index");
+  const bool gen = stage_generic(h, stage), hyb = stage_hybrid(h, stage);
+  const StageWS& S = w->st[stage];
+  const TrainWS::GenStage& Gs = w->gen[stage];
+  const Layer& L = h->layers[st.first + layer];
+  const size_t B2 = 2 * (size_t)B, rowsN = (size_t)B * N;   // rows per tower over the points
+  if (layer == st.n - 1) {   // the conv in front of the max over the points: the sign at the winner = the sign of the pooled feature
+    if (begin(B2 * L.cout)) return 1;
+    hipLaunchKernelGGL(dbg_mask_pooled_kernel, grid_of(n), blk, 0, h->stream, S.pooled, S.tower_stride, S.row_stride, B, L.cout, d);
+    return finish();
+  }
+  if (dg && layer == st.n - 2) {   // the last edge conv, in front of the max over the k neighbours: the sign of the pooled edge feature
+    if (begin(2 * rowsN * L.cout)) return 1;
+    hipLaunchKernelGGL(dbg_mask_rows_kernel<float>, grid_of(n), blk, 0, h->stream, gen ? Gs.P : S.h2, nullptr, nullptr, rowsN, L.cout, d);
+    return finish();
+  }
+  const size_t rows = dg ? rowsN * kDgK : rowsN;
+  if (begin(2 * rows * L.cout)) return 1;
+  if (gen) {   // layer by layer (also the front of a hybrid stage): the pre-BatchNorm activations and the batch-statistics scale / shift are in the workspace
+    hipLaunchKernelGGL(dbg_mask_rows_kernel<float>, grid_of(n), blk, 0, h->stream, Gs.Z[layer], Gs.scale[layer], Gs.shift[layer], rows, L.cout, d);
+    return finish();
+  }
+  (void)hyb;
+  if (layer == 1) {   // fused PointNet stage: the stored h2 (bf16 in the bf16 step)
+    if (was_bf16) hipLaunchKernelGGL(dbg_mask_rows_kernel<unsigned short>, grid_of(n), blk, 0, h->stream, reinterpret_cast<const unsigned short*>(S.h2), nullptr, nullptr, rows, L.cout, d);
+    else hipLaunchKernelGGL(dbg_mask_rows_kernel<float>, grid_of(n), blk, 0, h->stream, S.h2, nullptr, nullptr, rows, L.cout, d);
+    return finish();
+  }
+  // layer 0 of a fused stage: recomputed from xyz by every pass -- here by the passes' own device functions
+  const float* p1 = w->last_pcs[0]; const float* p2 = w->last_pcs[1];   // (a device-pointer step: the caller's buffers, which must still hold that batch)
+  const int C1 = L.cout;
+  if (dg) {
+    DbgEdge1Args a{{p1, p2}, S.xform, w->nn, B, N, kDgK, P(h, L.p_w), S.scale[0], S.shift[0], d};
+    const size_t lds = ((size_t)kTT * 8 + (size_t)kTT * (C1 + 4)) * sizeof(float);
+    if (C1 == 64) hipLaunchKernelGGL(dbg_mask_edge1_kernel<64>, dim3(2 * B), dim3(kTW * 64), lds, h->stream, a);
+    else hipLaunchKernelGGL(dbg_mask_edge1_kernel<32>, dim3(2 * B), dim3(kTW * 64), lds, h->stream, a);
+  } else {
+    const int ld0 = ((C1 + 7) & ~7) + 4;
+    DbgLayer1Args a{{p1, p2}, S.xform, B, N, C1, ld0, P(h, L.p_w), S.scale[0], S.shift[0], d};
+    hipLaunchKernelGGL(dbg_mask_layer1_kernel, dim3(2 * B), dim3(kTW * 64), ((size_t)kTT * 4 + (size_t)kTT * ld0) * sizeof(float), h->stream, a);
+  }
+  return finish();
 }
 
 // ---------------------------------------------------------------------------------

@@ -411,6 +411,9 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
   const int r0 = set * a.rows_per_set, r1 = min(a.M, r0 + a.rows_per_set), R = r1 - r0;
   float mf = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
   if (c < a.C) { mf = a.mean[set * a.C + c]; rstd = 1.0f / sqrtf(a.var[set * a.C + c] + kBnEps); gam = a.gamma[set][c]; bet = a.beta[set][c]; }
+  // the relu mask [y > 0] from the expression bn_rows_fwd_kernel evaluated (y = relu(fma(z, inv, sh))): written as fma(zhat, gamma, beta) it
+  // disagreed with the forward on pre-activations within a rounding of zero -- a unit "on" in the forward and "off" in the backward
+  const float inv_f = gam * rstd, sh_f = bet - mf * inv_f;
   double sb = 0.0, sg = 0.0;
   float zh0[kBnU], g0[kBnU];   // zhat and the masked gradient of the first trip's rows, kept for the second pass (see bn_rows_fwd_kernel)
   bool have0 = false;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
         float zh = 0.f, g = 0.f;
         if (ru < r1) {
           zh = (zv[u] - mf) * rstd;
-          g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
+          g = fmaf(zv[u], inv_f, sh_f) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;   // the FORWARD's expression: the same sign bit for bit
           sb += g; sg += (double)g * zh;
         }
         if (first) { zh0[u] = zh; g0[u] = g; }
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kBnCols * kBnGroups) void bn_rows_bwd_kernel(const 
       const int ru = r + u * kBnGroups;
       if (ru < r1) {
         const float zh = (zv[u] - mf) * rstd;
-        const float g = fmaf(zh, gam, bet) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
+        const float g = fmaf(zv[u], inv_f, sh_f) > 0.f ? dv[u] * dropout_scale(a, set, ru - r0, c) : 0.f;
         b.dz[(size_t)ru * a.C + c] = k * (g - mb - zh * mg);
       }
     }

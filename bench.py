@@ -803,6 +803,8 @@ def main():
     extra = None
     if not dist_on and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
         extra = extra_legs(eng, local_rank, args.min_leg_seconds)
+    # the headline training leg's sync-BN latency probe is a collective: EVERY rank runs it (only rank 0 writes the line)
+    head_sync_bn = sync_bn_fields() if (dist_on and args.mode == "train") else {}
     if dist is not None:
         dist.barrier()
 
@@ -840,7 +842,7 @@ def main():
             line["flops_per_pair_survey"] = FLOPS_PER_PAIR_TRAIN_SURVEY if not dg and npts == N_POINTS else None
             if dist_on:
                 line["allreduce_exposed_ms_per_step"] = round(kern.get("allreduce", (0.0, 0))[0] / args.steps, 4)
-                line.update(sync_bn_fields())
+                line.update(head_sync_bn)
         if dist_on:
             line["per_rank_pairs_per_s"] = per_rank_rates(head_per_rank, args.steps)
         if args.force_dist:

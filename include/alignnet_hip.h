@@ -202,6 +202,24 @@ int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
 #define ALIGNNET_DECISION_EDGE_SLOT 2
 #define ALIGNNET_DECISION_KNN_GRAPH 3
 int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, int32_t stage, int32_t* dst, size_t count);
+/* Test hook: the SIGN every relu of the last training step saw (utils/tf_util.py:167-168,345-346), one byte (0 / 1) per element.  What the
+ * decisions above leave undecided are these signs: a pre-activation within one rounding of zero is "on" in one evaluation and "off" in another,
+ * and on a row that wins many max-pool channels that re-routes per cents of a weight column's gradient.  A parity test pins the oracle to the
+ * masks too (y = bn(z) * mask, after checking that every disagreeing pre-activation is rounding-sized) and the whole step becomes a smooth
+ * function of its inputs (oracle/alignnet_torch.py `pinned["relu"]`, tests/test_fullsize_gpu.py).  Towers outermost, as above:
+ *   ALIGNNET_RELU_CONV  stage 0..2, layer l of the stage's conv stack (models/tp8.py:30-59):
+ *        hidden layers                       [2][B][N][C_l]        (dgcnn edge convs: [2][B][N][20][C_l])
+ *        dgcnn, last edge conv (l = n - 2)   [2][B][N][C_l]        at the winning neighbour slot (max and relu commute)
+ *        last conv (l = n - 1)               [2][B][C_l]           at the winning point
+ *   ALIGNNET_RELU_HEAD  stage 0..2 = s1 head, s2 head, pair head (models/tp8.py:75-82), hidden layer j: [2][B][C_j] ([B][C_j] for the pair head)
+ * Stored activations are read back; activations the passes recompute from xyz (conv1 of the fused stages) are recomputed by the same
+ * device functions from the frame, weights and batch statistics of that step and its point clouds (after alignnet_train_step_device:
+ * the caller's device buffers, which must still hold that batch).  Call it after alignnet_train_forward_backward, before the optimiser
+ * changes the parameters (alignnet_apply_gradients) and before the next step.  count must equal the element count
+ * of the requested array. */
+#define ALIGNNET_RELU_CONV 0
+#define ALIGNNET_RELU_HEAD 1
+int alignnet_debug_train_relu_mask(alignnet_handle* h, int32_t kind, int32_t stage, int32_t layer, uint8_t* dst, size_t count);
 
 /* ---- multi-GPU (not in the reference, which is single-device: train.py:189).
  *      One process per GPU; RCCL communicator over xGMI for the gradient all-reduce. */

@@ -49,12 +49,17 @@ class TorchTp8:
         # sits on the noise floor of re-decided near-ties.  Each pinned decision is first checked against the oracle's own values:
         # pin_report collects (what, worst gap between the true extreme and the value at the pinned index, scale of the values,
         # number of entries whose index differs from the oracle's own first maximum) -- the caller asserts that the gaps are rounding.
+        # "relu" (optional): {key: bool array} -- the SIGNS the other evaluation used at every relu (utils/tf_util.py:167-168,345-346): key =
+        # "<tower>:<layer scope>" ("p:<scope>" for the pair head), hidden conv layers [rows, C], the conv in front of a max-pool [R, C] AT THE
+        # WINNER (max and relu commute), head layers [B, C].  The oracle then evaluates y = bn(z) * mask instead of relu(bn(z)): with winners,
+        # classes and signs pinned the whole step is a smooth function of its inputs.  Each mask is checked first: where it disagrees with
+        # the oracle's own sign, |bn(z)| must be rounding-sized (pin_report entry "relu:<key>": worst such |bn(z)|, scale, disagreements).
         self.pinned = pinned
         self.pin_report = []
         # record_decisions = True: the unpinned evaluation writes its own choices into self.decisions in the layout of `pinned`
         # (tests/test_oracle.py: pinning the oracle to its own decisions must change nothing)
         self.record_decisions = False
-        self.decisions = {"yaw": [None, None], "pool": [[None, None] for _ in range(3)], "slot": [[None, None] for _ in range(3)], "knn": [None, None]}
+        self.decisions = {"yaw": [None, None], "pool": [[None, None] for _ in range(3)], "slot": [[None, None] for _ in range(3)], "knn": [None, None], "relu": {}}
         # sync: data-parallel protocol of the engine's "sync_bn" / "global_loss" options restated (tests/test_parallel_cpu.py): an object with
         # .world, .rank, .allreduce(t) (differentiable sum over the ranks) and .gather(t) (list of every rank's tensor, no gradient).
         # BatchNorm moments are then those of the global batch; loss_global() evaluates the loss on the gathered batch, with the
@@ -100,14 +105,35 @@ class TorchTp8:
             return y
         return F.batch_norm(z, P[base + "/moving_mean"], P[base + "/moving_var"], g, b, False, 0.0, BN_EPS)
 
-    def _layer(self, x, wbase, bnbase, training, decay, act=True, round_operands=False):
+    def _relu_mask(self, key):
+        if self.pinned is None or "relu" not in self.pinned or key is None:
+            return None
+        m = self.pinned["relu"].get(key)
+        return None if m is None else torch.as_tensor(np.asarray(m)).to(torch.bool)
+
+    def _relu(self, z, key):
+        """relu(z) -- or, with the signs pinned, z * mask (after checking the mask against z)."""
+        m = self._relu_mask(key)
+        if m is None:
+            if self.record_decisions and key is not None:
+                with torch.no_grad():
+                    self.decisions["relu"][key] = (z > 0).numpy()
+            return torch.relu(z)
+        m = m.reshape(z.shape)
+        with torch.no_grad():
+            differ = (z > 0) != m
+            nd = int(differ.sum())
+            self.pin_report.append((f"relu:{key}", float(z[differ].abs().max()) if nd else 0.0, float(z.abs().max()), nd, m.numel()))
+        return z * m.to(z.dtype)
+
+    def _layer(self, x, wbase, bnbase, training, decay, act=True, round_operands=False, relu_key=None):
         w = self.P[wbase + "/weights"]
         if round_operands:
             x, w = self._round_bf16_st(x), self._round_bf16_st(w)
         z = F.linear(x, w.t(), self.P[wbase + "/biases"])
         if bnbase is not None:
             z = self._bn(z, bnbase, training, decay)
-        return torch.relu(z) if act else z
+        return self._relu(z, relu_key) if act else z
 
     @staticmethod
     def bf16_conv_layers(widths):
@@ -128,8 +154,10 @@ class TorchTp8:
         rounded = self.bf16_conv_layers(list(widths)) if (self.bf16_lift and training) else set()
         for i in range(len(widths)):
             nm = f"{scope}/conv{i+1}"
-            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay, round_operands=i in rounded)
-        return self._max_over(h.reshape(B, N, -1), "pool", scope, tower)
+            # the last conv's relu is applied AFTER the max-pool (max_n relu(v_n) = relu(max_n v_n)): one sign per (cloud, channel)
+            h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay, round_operands=i in rounded,
+                            act=i < len(widths) - 1, relu_key=f"{tower}:{nm}")
+        return self._relu(self._max_over(h.reshape(B, N, -1), "pool", scope, tower), f"{tower}:{scope}/conv{len(widths)}")
 
     def _pin(self, kind, scope, tower):
         if self.pinned is None or kind not in self.pinned:
@@ -179,13 +207,14 @@ class TorchTp8:
             nm = f"{scope}/conv{i+1}"
             # bf16 option with the dgcnn backbone: the edge convs behind the K = 6 lift and the point conv below take rounded
             # operands (the whole backward stays fp32 in the engine: DESIGN.md 4.5b)
+            # (the relu in front of a max -- last edge conv, point conv -- is applied behind it: one sign per winner)
             h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
-                            round_operands=self.bf16_lift and training and i >= 1)
-        h = self._max_over(h.reshape(B * N, k, -1), "slot", scope, tower)
+                            round_operands=self.bf16_lift and training and i >= 1, act=i < len(widths) - 2, relu_key=f"{tower}:{nm}")
+        h = self._relu(self._max_over(h.reshape(B * N, k, -1), "slot", scope, tower), f"{tower}:{scope}/conv{len(widths) - 1}")
         nm = f"{scope}/conv{len(widths)}"
         h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
-                        round_operands=self.bf16_lift and training)
-        return self._max_over(h.reshape(B, N, -1), "pool", scope, tower)
+                        round_operands=self.bf16_lift and training, act=False)
+        return self._relu(self._max_over(h.reshape(B, N, -1), "pool", scope, tower), f"{tower}:{nm}")
 
     def _backbone(self, *a):
         fn = self._pointnet if self.spec.backbone == "pointnet" else self._dgcnn
@@ -199,9 +228,9 @@ class TorchTp8:
         for j in range(len(widths) - 1):
             nm = f"{scope}/fc{j+1}" if scope else f"fc{j+1}"
             if tower is None:
-                h = self._layer(h, nm, nm + "/bn", training, decay)
+                h = self._layer(h, nm, nm + "/bn", training, decay, relu_key=f"p:{nm}")
             else:
-                h = self._layer(h, "siamese/" + nm, f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay)
+                h = self._layer(h, "siamese/" + nm, f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay, relu_key=f"{tower}:{nm}")
         if keep is not None and training:
             kp = float(np.float32(keep))   # keep_prob enters the TF graph as a float32 constant
             h = h / kp * torch.floor(kp + u)
