@@ -338,6 +338,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   f32x16 gacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+  // The cloud's Gram blocks in fp64, in LDS (one [16][64] slab per owning wave, touched by that wave only: no barrier): the fp32 MFMA
+  // accumulators are folded in at the end of every tile (k slots x 64 rows).  Carried in fp32 for the whole cloud -- N k = 82 k rows at
+  // N = 4096 -- each element collects ~40 k roundings at the magnitude of the running sum, and the statistics of z2 derived from the Gram
+  // (stat2_from_gram_kernel: w^T G w / M - mean^2) divide by variances that can be 1e-3 of its entries: at N = 4096 the step sat 8x further
+  // from the fp64 oracle than a plain fp32 evaluation of the graph (profiles/r06_relu_pin_diag_dg.log).
+  double* const gsum = reinterpret_cast<double*>(BF16 ? reinterpret_cast<float*>(hbuf + 2 * kBufH) : xbuf + 2 * kTT * ld0) + (size_t)wave * 16 * 64 + lane;
+  if (wave < nG) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gsum[r * 64] = 0.0;
+  }
   f32x16 best[2];
   int bk[2][16];
 
@@ -454,6 +464,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 #pragma unroll 8
       for (int r = 0; r < kTT; r += 2) gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc, 0, 0, 0);
       }
+      if (slot == a.k - 1) {   // end of the tile: fp32 block -> the cloud's fp64 block
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gsum[r * 64] += (double)gacc[r]; gacc[r] = 0.f; }
+      }
     }
     FE_STAMP(2);
     {   // column sums of h1 (rows past nvalid are zero): thread = (4 columns, one of kQG row groups), float4 reads
@@ -479,6 +493,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   }
   if (wave < nG) {
     const float zero[16] = {};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[r] = (float)(gsum[r * 64] + (double)gacc[r]);   // (gacc is zero unless the ablation switch skipped the folds)
     tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
   if (ALN_STAMPS(a.stamps) && tid == 0) {   // stamps 8 / 9 / 10: longest and (2^40 - shortest) workgroup, workgroup 0 -- zeroed by the host

@@ -859,6 +859,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
     bit[q] = it; bjt[q] = it + rem;
   }
   double s1c = 0.0;
+  // The cloud's blocks in fp64: every tile's fp32 MFMA block (32 accumulation steps) is folded in and cleared.  Carried in fp32 for the whole
+  // cloud an element collects N / 2 roundings at the magnitude of the running sum (~1e-6 relative at N = 1024), and the variance of a channel
+  // of z2 = h1 W2 can be 1e-3 of w^T G w's terms: on a batch of differently sized objects the step's gradient sat 4e-4 from the fully pinned
+  // fp64 oracle where a plain fp32 evaluation of the graph sits at 1e-5 (profiles/r06_relu_pin_diag.log; ab_phase2_legacy -- the direct
+  // statistics of z2 -- was at 4e-5).  Folded per tile the Gram is good to ~1e-7.
+  double gd[kSlots][16];
+#pragma unroll
+  for (int q = 0; q < kSlots; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gd[q][r] = 0.0;
   for (int tile = 0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     __syncthreads();
@@ -873,6 +883,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
         const float* pb = X + half * ld0 + bjt[q] * 32 + (lane & 31);
 #pragma unroll 8
         for (int r = 0; r < kTT; r += 2) gacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[r * ld0], pb[r * ld0], gacc[q], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gd[q][r] += (double)gacc[q][r]; gacc[q][r] = 0.f; }
       }
     if (tid < sG * C1) {   // column sums of h1: sG row groups x C1 columns (rows past nvalid are zero)
       const int c = tid % C1, g = tid / C1;
@@ -885,6 +897,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   for (int q = 0; q < kSlots; ++q)
     if (wave + q * kTW < nblk) {
       const float zero[16] = {};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gacc[q][r] = (float)gd[q][r];
       tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, bit[q], bjt[q], C1, C1, gacc[q], lane, zero);
     }
   if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
