@@ -167,18 +167,20 @@ class TorchTp8:
         return torch.as_tensor(np.asarray(a[tower]), dtype=torch.long)
 
     def _max_over(self, hh, kind, scope, tower):
-        """max over dim 1 of hh [R, n, C] (utils/tf_util.py:350-373) -- or, pinned, the gather at the given winners [R, C]."""
+        """max over dim 1 of hh [R, n, C] (utils/tf_util.py:350-373) -- or, pinned, the gather at the given winners [R, C].  The callers apply
+        the layer's relu BEHIND this max (max_n relu(v_n) = relu(max_n v_n)), so a pinned winner is checked on the relu'd values: in a channel
+        whose values are all negative every point is a maximum of relu(v) = 0."""
         idx = self._pin(kind, scope, tower)
         if idx is None:
             if self.record_decisions:
                 with torch.no_grad():
-                    self.decisions[kind][self.STAGES[scope]][tower] = hh.argmax(dim=1).numpy()
+                    self.decisions[kind][self.STAGES[scope]][tower] = torch.relu(hh).argmax(dim=1).numpy()
             return hh.amax(dim=1)
         idx = idx.reshape(hh.shape[0], hh.shape[2])
         out = hh.gather(1, idx[:, None, :])[:, 0]
         with torch.no_grad():
-            top, own = hh.max(dim=1)
-            self.pin_report.append((f"{kind}:{scope}:{tower}", float((top - out).max()), float(top.abs().max()), int((own != idx).sum()), idx.numel()))
+            top, own = torch.relu(hh).max(dim=1)
+            self.pin_report.append((f"{kind}:{scope}:{tower}", float((top - torch.relu(out)).max()), float(top.abs().max()), int((own != idx).sum()), idx.numel()))
         return out
 
     def _dgcnn(self, x, scope, widths, tower, training, decay):

@@ -124,10 +124,13 @@ def test_deep_heads_flush_their_jobs_in_chunks(gpu_required):
         eng = alignnet3d.Engine(cfg)
         eng.set_variables(P32)
         eng.set_option("ab_no_defer", nodefer)
-        if not nodefer:
-            _, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
         got.append({n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)})
+        if not nodefer:
+            # the oracle PINNED to this step's decisions and relu signs (a unit of one of the 36 sixteen-row BatchNorms within a rounding of zero is
+            # "on" in one evaluation and "off" in the other, and a free comparison then reads 1e-2: measured when the head backward's mask
+            # expression changed in round 6)
+            _, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))
         assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
         eng.close()
     # six BatchNorm'd layers on 16-row statistics are badly conditioned (gradient entries of several hundred, the fp32 forward's rounding amplified
@@ -1048,7 +1051,8 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     print(case, "pinned: engine vs oracle: predictions %.2e, relative L2 %.2e, worst tensor %.2e (%s) | oracle under one-ulp input moves (worst of 4): predictions %.2e, "
           "relative L2 %.2e, worst tensor %.2e" % (pred, rl2, max(relf.values()), max(relf, key=relf.get), spred, srl2, stens))
     assert pred <= bar_p, (pred, bar_p)
-    assert abs(res["loss"] - loss_ref) <= (5e-3 if bf16 else 1e-5) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
+    # (bf16 convs: the loss follows the predictions, which the rounded oracle itself moves by `spred` -- 7e-2 on the five-pair dgcnn case -- under one-ulp moves)
+    assert abs(res["loss"] - loss_ref) <= (max(5e-3, 0.2 * spred) if bf16 else 1e-5) * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
     assert rl2 <= bar_l2, (rl2, bar_l2)
     bad = {n: e for n, e in relf.items() if e > bar_t}
     assert not bad, (bar_t, bad)
