@@ -1,7 +1,7 @@
 """GPU: BASELINE.json's full sizes.  Inference (configs[1]: SynthCars widths, B = 256, N = 1024): every pair against the fp64 oracle
 plus size-independent properties of the path.  Training (configs[2], [3]'s global batch, [4]'s N): every gradient against fp64
-autograd, once with the oracle deciding for itself and once PINNED to the engine's decisions (max-pool winners, yaw classes,
-neighbour slots, kNN graph), where the comparison is continuous and the bars are sharp."""
+autograd PINNED to the engine's decisions (max-pool winners, yaw classes, neighbour slots, kNN graph) AND to the sign every relu saw,
+where the step is a smooth function of its inputs and the bars are sharp: relative L2 1e-4 on the whole gradient, 1e-3 per tensor."""
 import numpy as np
 import pytest
 
@@ -275,27 +275,26 @@ def _oracle_noise_floor(oracle, d, spec, grads, ep_ref, trials):
     return worst
 
 
-def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, cos_bar, rl2_bar, tensor_bar=8e-2,
-                                  tiny_tensors=(), free=True, bf16=False, gap_bar=1e-4, floor=1e-3, k_cond=4.0, sens=1):
-    """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the
-    torch-autograd oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`):
+def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol, loss_tol, ema_tol, rl2_bar=1e-4, tensor_bar=1e-3, cos_bar=None,
+                                  free=None, bf16=False, gap_bar=1e-4, relu_gap_bar=1e-4, relu_differ_bar=1e-5, tag="full size"):
+    """Train-mode forward (batch statistics over all 2 x B x N points, EMA), loss and every parameter gradient against the torch-autograd
+    oracle in fp64 (backbones recomputed in the backward: oracle/alignnet_torch.py `checkpoint`), FULLY PINNED to the engine's step:
 
-    (1) FREE (where `free`): the oracle takes its own decisions.  Fixed bars, not derived from this implementation's numbers: every tensor
-        within 8e-2 of its own largest entry (`tiny_tensors`: tensors named by the caller whose entries are 1e-3 of the gradient's scale
-        are held to the whole-gradient bars only), whole-gradient cosine / relative L2 as given.
-    (2) PINNED: the oracle gathers at the ENGINE's decisions (Engine.debug_train_decisions: 0.9 M max-pool winners utils/tf_util.py:350-373
-        and 512 yaw classes models/tp8.py:296 at 256 x 1024; neighbour slots and the kNN table for dgcnn) after checking that every one
-        of them is a maximum of the oracle's own values to within `gap_bar` of their scale -- THAT is the test of the arg-max kernels, and
-        it is sharp (measured: 1e-6).
-    (3) What round 5 found: with those decisions pinned the gradient difference does NOT drop (256 x 1024: relative L2 1.30e-2 free,
-        1.24e-2 pinned) -- re-decided pool winners were never the floor.  What remains undecided are the relu SIGNS (see
-        _oracle_noise_floor): the pinned fp64 oracle's own gradient moves by 2e-3 .. 5e-3 at these sizes (1e-2 .. 5e-2 at 16 x 256) when
-        its inputs move by one ulp, in quantised steps.  No fp32 evaluation can be held to 1e-3 on such a batch, so the continuous
-        part is held to the oracle's OWN measured floor: whole-gradient relative L2 and every tensor (error over max(the tensor's
-        largest entry, 2 % of the gradient's)) within max(`floor`, `k_cond` x the worst of `sens` one-ulp draws).  The bar comes from
-        the oracle, not from this implementation; a wrong index, a dropped term or a 1 / world slip moves a tensor by O(1).
-        (`sens` = 0 skips the extra oracle runs -- the suite's time -- and holds the pinned comparison to fixed bars: relative L2 2e-2,
-        per tensor 8e-2, i.e. four times what the draws of the other shapes measure.)"""
+    (1) the DECISIONS (Engine.debug_train_decisions: 0.9 M max-pool winners utils/tf_util.py:350-373 and 512 yaw classes models/tp8.py:296
+        at 256 x 1024; neighbour slots and the kNN table for dgcnn): the oracle gathers at them after checking that each is a maximum of its
+        own values to within `gap_bar` of their scale (measured 1e-6) -- the test of the arg-max / selection kernels;
+    (2) the SIGN every relu saw (alignnet_debug_train_relu_mask: 6e8 bits at 256 x 1024, utils/tf_util.py:167-168,345-346): the oracle
+        evaluates y = bn(z) * mask after checking that wherever the mask disagrees with its own sign |bn(z)| <= `relu_gap_bar` of the layer's
+        scale and that at most `relu_differ_bar` of the signs disagree (measured: ~600 of 6e8, |bn(z)| 4e-6 of scale) -- the test of the BatchNorm /
+        relu arithmetic of every pass;
+    (3) with (1) and (2) fixed the step is a SMOOTH function of its inputs and the comparison is sharp: whole-gradient relative L2 <= 1e-4,
+        every tensor within 1e-3 of max(its largest entry, 2 % of the gradient's largest).  Round 5 stopped at (1) and found the distance
+        unchanged at 1e-2: the undecided rest were the relu signs within a rounding of zero (~600 flips re-route per cents of a weight column's
+        gradient).  Pinned, a plain fp32 evaluation of the graph (torch, tools/relu_pin_diag.py) sits 1e-5 .. 3e-5 from the fp64 one; round 6's
+        first run of this comparison put the engine at 4.4e-4 on the `varied` batch, which led to the fp32-accumulated Gram behind the z2
+        statistics (kernels_train_fwd.h train_fwd_gram1: now folded into fp64 per tile -> 8e-6).
+    `free`: additionally the oracle deciding everything for itself, held to the loose fixed bars given (cos, rl2, per tensor) -- one case keeps
+    it so that the unpinned agreement stays on record; its floor is the re-decided signs, not this implementation."""
     from tests import test_train_gpu as TT
     us = [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")]
     Bt = d["pcs1"].shape[0]
@@ -305,13 +304,14 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol
     decay = eng.state()["bn_decay"]
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, us)
     assert eng.get_option("last_train_kernel") == expect_kernel
-    decisions = eng.debug_train_decisions(Bt)
+    decisions = eng.debug_train_decisions(Bt, relu=True)
     ge = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
     bn_bias = {(f"siamese/{L.name}" if L.siamese else L.name) + "/biases" for L in R.layer_table(spec) if L.bn}
     assert all(np.abs(ge[n]).max() == 0.0 for n in bn_bias)
     ema_got = None
     failures = []
-    tag = "full size%s" % (" bf16" if bf16 else "")
+    if bf16:
+        tag += " bf16"
     for mode in (("free",) if free else ()) + ("pinned",):
         rep = []
         ep_ref, loss_ref, grads, ema_ref = TT._oracle(cfg, P32, d, du, decay, bf16_lift=bf16, checkpoint=True, pinned=decisions if mode == "pinned" else None, report=rep)
@@ -321,97 +321,90 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol
         worst_ema = max(float(np.abs(ema_got[k] - v).max()) for k, v in ema_ref.items())
         ema_fail = [k for k, v in ema_ref.items() if not np.allclose(ema_got[k], v, rtol=ema_tol, atol=0.1 * ema_tol)]
         rel, relf, cos, rl2, gscale = _grad_compare(ge.__getitem__, spec, grads)
-        print("%s (%s): loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, whole gradient: cosine %.8f, relative L2 error %.2e, "
-              "worst relative gradient errors %s" % (tag, mode, res["loss"], loss_ref, worst_pred, worst_ema, cos, rl2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]))
+        print("%s (%s): loss %.6f (oracle %.6f), worst prediction err %.2e, worst EMA err %.2e, whole gradient: cosine %.10f, relative L2 error %.2e, "
+              "worst tensors (error / max(own largest, 2 %% of the gradient's)) %s" % (tag, mode, res["loss"], loss_ref, worst_pred, worst_ema, cos, rl2,
+                                                                                    [(k, float("%.2g" % v)) for k, v in sorted(relf.items(), key=lambda kv: -kv[1])[:4]]))
         if worst_pred > pred_tol: failures.append((mode + " predictions", worst_pred))
         if abs(res["loss"] - loss_ref) > loss_tol * max(1.0, abs(loss_ref)): failures.append((mode + " loss", res["loss"], loss_ref))
         if ema_fail: failures.append((mode + " EMA", ema_fail[:4]))
         if mode == "free":
-            if cos < cos_bar or rl2 > rl2_bar: failures.append(("free whole gradient", cos, rl2))
-            bad = {n: e for n, e in rel.items() if e > tensor_bar and relf[n] > 1e-3 and n not in tiny_tensors}
+            if cos < free["cos"] or rl2 > free["rl2"]: failures.append(("free whole gradient", cos, rl2))
+            bad = {n: e for n, e in rel.items() if e > free["tensor"] and relf[n] > 1e-3}
             if bad: failures.append(("free tensors", bad))
             continue
         gaps = _pin_gaps(rep[0], tag + ":")
-        if any(g > gap_bar for g, _, _ in gaps.values()): failures.append(("a pinned decision is not a maximum of the oracle's values", gaps))
-        if not sens:
-            print("%s: engine vs pinned oracle: relative L2 %.2e, worst tensor %.2e (%s); fixed bars 2e-2 / 8e-2" % (tag, rl2, max(relf.values()), max(relf, key=relf.get)))
-            if rl2 > 2e-2: failures.append(("pinned whole gradient", rl2))
-            bad = {n: e for n, e in relf.items() if e > 8e-2}
-            if bad: failures.append(("pinned tensors", bad))
-            continue
-        # the oracle's own floor on this batch: the same pinned evaluation with the inputs moved by one ulp, worst of `sens` draws
-        srl2, stens, spred = _oracle_noise_floor(lambda dd: TT._oracle(cfg, P32, dd, du, decay, bf16_lift=bf16, checkpoint=True, pinned=decisions), d, spec, grads, ep_ref, sens)
-        bar_rl2, bar_t = max(floor, k_cond * srl2), max(floor, k_cond * stens)
-        print("%s: the pinned oracle under one-ulp moves of its inputs (worst of %d): predictions %.2e, whole gradient relative L2 %.2e, worst tensor %.2e "
-              "-> bars: relative L2 %.2e, per tensor %.2e; engine: relative L2 %.2e, worst tensor %.2e (%s)"
-              % (tag, sens, spred, srl2, stens, bar_rl2, bar_t, rl2, max(relf.values()), max(relf, key=relf.get)))
-        if rl2 > bar_rl2: failures.append(("pinned whole gradient beyond the oracle's conditioning", rl2, bar_rl2))
-        bad = {n: e for n, e in relf.items() if e > bar_t}
-        if bad: failures.append(("pinned tensors beyond the oracle's conditioning", bar_t, bad))
+        if any(g > (relu_gap_bar if k == "relu" else gap_bar) for k, (g, _, _) in gaps.items()): failures.append(("a pinned decision / sign is not the oracle's to within rounding", gaps))
+        if "relu" not in gaps or gaps["relu"][1] > relu_differ_bar * gaps["relu"][2]: failures.append(("relu signs", gaps.get("relu")))
+        if rl2 > rl2_bar: failures.append(("pinned whole gradient", rl2, rl2_bar))
+        if cos_bar is not None and cos < cos_bar: failures.append(("pinned cosine", cos, cos_bar))
+        bad = {n: e for n, e in relf.items() if e > tensor_bar}
+        if bad: failures.append(("pinned tensors", tensor_bar, bad))
     eng.close()
     assert not failures, failures
 
 
+def _varied_setup(backbone="pointnet", Bt=B, Nt=N, seed=5):
+    """_train_setup on a batch of differently sized objects (tests/helpers.varied_pairs: real batches hold different objects; with ONE box shape
+    every canonicalised cloud looks alike and the heads' batch normalisation divides by sampling noise)"""
+    from tests.helpers import varied_pairs
+    cfg, spec, P32, _, du = _train_setup(backbone, Bt, Nt, seed)
+    return cfg, spec, P32, varied_pairs(Bt, Nt, seed=seed, dtype=np.float32), du
+
+
 def test_train_fp32_full_size_matches_autograd(gpu_required):
     """BASELINE.json configs[2]'s shape in fp32: SynthCars widths, 256 pairs x 1024 points -- the kernel instantiations with the
-    widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256."""
+    widths compiled in, whole-cloud tile walks, 512 workgroups, the B x B loss terms at B = 256.  Measured pinned: relative L2 2.3e-5
+    (a plain torch fp32 evaluation: 2.8e-5).  Also FREE, at the loose bars of the re-decided signs (measured 1.3e-2)."""
     cfg, spec, P32, d, du = _train_setup()
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, cos_bar=0.9995, rl2_bar=3e-2)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5,
+                                  free={"cos": 0.9995, "rl2": 3e-2, "tensor": 8e-2})
 
 
-def test_train_bf16_full_size_matches_rounded_oracle(gpu_required):
-    """BASELINE.json configs[2] at its own size: bf16 MFMA convs, 256 pairs x 1024 points, against the oracle that models the
-    operand rounding (same criteria as tests/test_train_gpu.py::test_bf16_lift_matches_rounded_oracle)."""
-    from tests import test_train_gpu as TT
-    cfg, spec, P32, d, du = _train_setup()
-    TT.bf16_check(cfg, spec, P32, d, du, B, expect_kernel=3, checkpoint=True)
+def test_train_fp32_full_size_varied_objects(gpu_required):
+    """The same step on 256 differently sized objects: the batch on which round 5's report had the engine at 5.4 x the oracle's own noise.  Fully
+    pinned: 8e-6 (torch fp32: 1.2e-5) -- after the Gram(h1) fold; 4.4e-4 before it (profiles/r06_relu_pin_diag.log)."""
+    cfg, spec, P32, d, du = _varied_setup()
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, tag="full size, varied objects")
 
 
 def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
-    """configs[2] at its own size against the rounded-operand oracle PINNED to the engine's max-pool winners and yaw classes.  Unpinned
-    (the test above) the two sit at cosine 0.97; pinned at 0.992 -- and the rounded oracle ITSELF moves by that much (cosine 0.988,
-    relative L2 0.16) when its inputs move by one fp32 rounding: every rounding of an operand to bf16 is a small decision of its own
-    (2^-8 of one of 128 product terms), and a billion of them pass through the heads' ill-conditioned batch normalisations.  So the
-    engine is as close to the rounded oracle as the rounded oracle is to itself; the bars are 1.5 x that self-distance (whole gradient
-    and per tensor), the decision gaps 2e-2 of their scale (operand rounding), predictions 1e-1 as in the unpinned test."""
-    cfg, spec, P32, d, du = _train_setup()
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=1e-1, loss_tol=5e-3, ema_tol=1e-2, cos_bar=0.0, rl2_bar=1.0,
-                                  free=False, bf16=True, gap_bar=2e-2, floor=2e-2, k_cond=1.5, sens=1)
+    """configs[2] at its own size (bf16 MFMA convs, 256 differently sized objects x 1024 points) against the rounded-operand oracle pinned to
+    the engine's winners, classes and relu signs.  What stays undecided here is every ROUNDING of an operand to bf16 (2^-8 of one of 128
+    product terms, a billion per step): the rounded oracle itself moves by relative L2 0.12 under one-ulp moves of its inputs even fully
+    pinned (profiles/r06_relu_pin_full2.log), so the bars are those of the engine's measured agreement with margin, not 1e-4: measured
+    cosine 0.99995, relative L2 1.0e-2, worst tensor 7.4e-2 (round 5, winners only: cosine 0.992, 0.138, 0.249); decision gaps 2e-2 of
+    their scale (operand rounding).  That the mode TRAINS is test_bf16_converges_like_fp32's statement."""
+    cfg, spec, P32, d, du = _varied_setup()
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=1e-1, loss_tol=5e-3, ema_tol=1e-2, rl2_bar=2e-2, tensor_bar=1.5e-1, cos_bar=0.9998,
+                                  bf16=True, gap_bar=2e-2, relu_gap_bar=2e-2, relu_differ_bar=1e-3, tag="full size, varied objects")
 
 
 def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
-    SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 4 keeps the [B*N*k, C] autograd oracle in memory."""
-    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=1024, seed=7)
-    # (two max-pools and 4-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 3.8e-2 from its fp64 one here)
-    # (EMA bound 2e-4: with the point conv on 128-point tiles one of the 512 fc1 moving means -- four-row batch statistics -- sits 1.4e-5 from the
-    #  fp64 value at |v| = 0.03, just outside 1e-4 |v| + 1e-5)
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=0)
+    SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 8 differently sized objects keep the [B*N*k, C] autograd
+    oracle in memory.  Measured pinned: 2.4e-5 (torch fp32 2.5e-5)."""
+    cfg, spec, P32, d, du = _varied_setup("dgcnn", Bt=8, Nt=1024, seed=7)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, tag="dgcnn N=1024")
 
 
 def test_train_b2048_matches_autograd(gpu_required):
     """BASELINE.json configs[3]'s arithmetic on ONE GPU: the global batch of 2048 pairs (KITTITrackletsCarsPersonsHard: SynthCars
     widths) in a single step -- the [B, B] loss terms of models/tp8.py:279,327 at 4 M entries, the whole-batch tf.cond (:288), the
     4096-row head BatchNorms, 4096 workgroups per backbone launch.  N = 128 keeps the fp64 autograd oracle at the cost of the
-    256 x 1024 test (the same 524 k points)."""
-    cfg, spec, P32, d, du = _train_setup(Bt=2048, Nt=128, seed=11)
-    # (2048-row batch statistics in the heads: the fp32 evaluation of the oracle itself is 4e-2 from its fp64 one on the smallest gradients)
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, cos_bar=0.9995, rl2_bar=3e-2, free=False, sens=0)
+    256 x 1024 test (the same 524 k points).  Measured pinned: 6.9e-5."""
+    cfg, spec, P32, d, du = _varied_setup(Bt=2048, Nt=128, seed=11)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, tag="B=2048")
 
 
 def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     """BASELINE.json configs[4]'s training half at its own N: DGCNN at N = 4096 (knn_kernel<64>, 64 tiles per cloud, SynthCars
-    widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 4 (655 k edge rows, [2B, N, N] distance
-    matrices in the oracle; two-row batch statistics in the heads are singular, so not B = 2)."""
-    cfg, spec, P32, d, du = _train_setup("dgcnn", Bt=4, Nt=4096, seed=9)
-    # The fp32 kNN graph differs from the fp64 oracle's wherever the 20th and 21st neighbour of a query are closer than fp32 rounding of the
-    # distance expression (N = 4096: dozens of queries per cloud), and four-row batch statistics in the heads amplify one changed neighbour
-    # into per cents on the smallest tensors (siamese/embedding/conv3/bn/beta: 0.42 of its 1e-3-sized entries -- named, and left to the
-    # whole-gradient bars in the FREE comparison; every other tensor keeps the 8e-2 ceiling).  PINNED to the engine's graph, slots and
-    # winners the same step is compared at the sharp bars (1e-3 per tensor): the graph itself is checked there as a k-nearest set of
-    # every query in fp64 distances.
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=9e-3, loss_tol=5e-4, ema_tol=5e-3, cos_bar=0.9995, rl2_bar=3.5e-2,
-                                  tiny_tensors=("siamese/embedding/conv3/bn/beta",), sens=1)
+    widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>) against fp64 autograd; B = 4 differently sized objects (655 k edge rows,
+    [2B, N, N] distance matrices in the oracle).  The fp32 kNN graph differs from an fp64 one wherever the 20th and 21st neighbour of a
+    query are closer than fp32 rounding of the distance expression (dozens of queries per cloud): pinned, the engine's table is checked as
+    a k-nearest SET of every query in fp64 distances (gap 1e-6 of the largest k-th distance) and the step is compared on it.  Measured pinned:
+    5.0e-5 -- and 4.2e-3 before round 6 folded Gram(h1), accumulated over a cloud's 82 k edge rows in fp32, into fp64 per tile."""
+    cfg, spec, P32, d, du = _varied_setup("dgcnn", Bt=4, Nt=4096, seed=9)
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=5e-5, ema_tol=5e-4, tag="dgcnn N=4096")
 
 
 def test_train_dgcnn_n4096_b512_runs(gpu_required):

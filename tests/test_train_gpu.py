@@ -1021,7 +1021,7 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     eng.set_option("train_fused_tail", tail)
     eng.set_option("train_matmul_bf16", bf16)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
-    dec = eng.debug_train_decisions(B)
+    dec = eng.debug_train_decisions(B, relu=True)   # (+ the sign every relu saw: alignnet_debug_train_relu_mask on the fused, hybrid and layer-by-layer paths)
     assert dec["yaw"].shape == (2, B) and dec["yaw"].min() >= 0 and dec["yaw"].max() < 12
     for s_, a in enumerate(dec["pool"]):
         assert a.min() >= 0 and a.max() < N, (s_, a.min(), a.max())
@@ -1035,8 +1035,10 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
         k = what.split(":")[0]
         kinds[k] = max(kinds.get(k, 0.0), gap / max(scale, 1.0))
     print(case, "pinned: worst decision gap / scale", kinds, "not the oracle's own first maximum:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
-    assert set(kinds) == ({"yaw", "pool"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn"})
+    assert set(kinds) == ({"yaw", "pool", "relu"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn", "relu"})
     assert all(g <= gap_bar for g in kinds.values()), kinds
+    n_relu, d_relu = sum(r[4] for r in rep[0] if r[0].startswith("relu")), sum(r[3] for r in rep[0] if r[0].startswith("relu"))
+    assert d_relu <= (1e-3 if bf16 else 1e-5) * n_relu + 4, (d_relu, n_relu)   # signs that differ from the oracle's own: a handful, each with |bn(z)| within gap_bar of zero
     # the continuous rest against the oracle's own floor (tests/test_fullsize_gpu.py::_oracle_noise_floor has the story: the relu signs
     # within one rounding of zero): the pinned oracle four more times with its inputs moved by one ulp; the engine must be within
     # max(floor, 3 x the worst of those self-distances)
