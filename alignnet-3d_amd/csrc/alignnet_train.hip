@@ -60,6 +60,7 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float* h2;                     // [2B*N][C2]
   float *gram2, *s2, *m2;        // [2][C2*C2] centred Gram of h2, [2][C2] column sums, [2][C2] column means
   float* gram2raw;               // [2][C2*C2] Gram as reduced over the clouds (upper blocks), before centring
+  double *gram2raw64, *s264, *g1f64, *s1e64;   // gram2raw | s2 and g1f | s1e as the fp64 reductions left them (each pair back to back): what the statistics kernels read
   float* pooled; long tower_stride, row_stride;    // forward output (layout of the consumer)
   float* dP;                     // dL/dpooled, same layout
   float *gx, *grot;              // [2B][3], [2B]
@@ -365,6 +366,8 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.argk = reinterpret_cast<unsigned char*>(take(dgb ? MN * C[1] : 0));
       (void)gen;
       S.mom = D(B2 * kDgMom); S.s1e = F(2 * C[0]); S.g1f = F(2 * (size_t)C[0] * C[0]);
+      S.gram2raw64 = D(2 * (size_t)C[1] * C[1] + 2 * C[1]); S.s264 = S.gram2raw64 ? S.gram2raw64 + 2 * (size_t)C[1] * C[1] : nullptr;
+      S.g1f64 = D(2 * (size_t)C[0] * C[0] + 2 * C[0]); S.s1e64 = S.g1f64 ? S.g1f64 + 2 * (size_t)C[0] * C[0] : nullptr;
       S.gs = F(B2 * C[2]); S.E3 = F(2 * C[2]); S.kdb3 = F(2 * C[2]); S.Sp = F(2 * (size_t)C[1] * C[2]); S.GW = F(2 * (size_t)C[1] * C[2]);
       S.u2_part = F(B2 * (size_t)C[0] * C[1]); S.g1_part = F(B2 * (size_t)C[0] * C[0]); S.p_part = F(B2 * 6 * C[0]);
       S.u2 = F(2 * (size_t)C[0] * C[1]); S.g1 = F(2 * (size_t)C[0] * C[0]); S.s1 = F(2 * C[0]); S.m1 = F(2 * C[0]);
@@ -897,11 +900,20 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     hipLaunchKernelGGL(stat_finish_kernel, grid, dim3(1024), 0, h->stream, f);
     return 0;
   };
+  // sync_bn: a reduced (Gram | column sums) pair is added over the ranks in fp64 and its float copy (what the backward reads) rewritten from the sum
+  // (d64 = [na | nb] back to back; the float copies fa, fb live wherever the carve put them)
+  auto sync_gram = [&](double* d64, float* fa, size_t na, float* fb, size_t nb) -> int {
+    if (sync_sum(h, d64, na + nb, true)) return 1;
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, d64, fa, na);
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, d64 + na, fb, nb);
+    return 0;
+  };
   // the reductions of the Gram / column-sum partials of h2 over the clouds (the last layer's statistics follow from them: stat3 below)
   auto finish_and_reduce = [&](ReduceJob ja, ReduceJob jb) -> int {
     ja.out = S.gram2raw; ja.upper_c = C2;   // (only the upper 32 x 32 blocks of the per-cloud Grams are valid -- and read)
+    ja.out64 = S.gram2raw64; jb.out64 = S.s264;   // the statistics read the unrounded totals
     launch_reduce_multi(h, 2, ja, jb);
-    if (sync && (sync_sum2(h, S.gram2raw, (size_t)2 * C2 * C2, S.s2, (size_t)2 * C2))) return 1;
+    if (sync && sync_gram(S.gram2raw64, S.gram2raw, (size_t)2 * C2 * C2, S.s2, (size_t)2 * C2)) return 1;
     return 0;
   };
   if (dg) {
@@ -939,9 +951,11 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
-      launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sGe, (long)(C1), S.s1e));
-      if (sync && (sync_sum2(h, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1))) return 1;
-      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, ecount * W,
+      ReduceJob jg = rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * sGe, (long)(C1), S.s1e);
+      jg.out64 = S.g1f64; js.out64 = S.s1e64;
+      launch_reduce_multi(h, 2, jg, js);
+      if (sync && sync_gram(S.g1f64, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1)) return 1;
+      hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f64, S.s1e64, P(h, L[1]->p_w), a.b2, C1, C2, ecount * W,
                          h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
     if (finish(1, C2, 1, ecount, 1, true)) return 1;
@@ -1040,14 +1054,16 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     else if (C1 == 64) hipLaunchKernelGGL((train_fwd_gram1<false, 64>), dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
-    launch_reduce_multi(h, 2, rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), rjob(w->s1_part, B * sG1, (long)(C1), S.s1e));
-    if (sync && (sync_sum2(h, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1))) return 1;
+    ReduceJob jg = rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * sG1, (long)(C1), S.s1e);
+    jg.out64 = S.g1f64; js.out64 = S.s1e64;
+    launch_reduce_multi(h, 2, jg, js);
+    if (sync && sync_gram(S.g1f64, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1)) return 1;
     // (statistics from the Gram and their finish in one launch; ab_phase2_legacy keeps the pass, ab_no_glue_fold the two launches)
     if (!(h->ab & AB_NO_GLUE_FOLD))
-      hipLaunchKernelGGL(stat2_from_gram_finish_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
+      hipLaunchKernelGGL(stat2_from_gram_finish_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f64, S.s1e64, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
                          h->train_bf16 ? 1 : 0, fin_args(1, C2, 1, count, 1));
     else {
-    hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f, S.s1e, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
+    hipLaunchKernelGGL(stat2_from_gram_kernel, dim3(C2, 2), dim3(256), 0, h->stream, S.g1f64, S.s1e64, P(h, L[1]->p_w), a.b2, C1, C2, count * W,
                        h->train_bf16 ? 1 : 0, w->stat_part);
     if (finish(1, C2, 1, count, 1, true)) return 1;
     }
@@ -1096,7 +1112,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   }
   {   // statistics of the last layer from the Gram, EMA, pooled features, centred Gram + column means for the backward: one launch
     Stat3Args f;
-    f.G = S.gram2raw; f.s = S.s2; f.W = P(h, L[2]->p_w); f.C2 = C2; f.C3 = C3; f.M = count * W;
+    f.G = S.gram2raw64; f.s = S.s264; f.W = P(h, L[2]->p_w); f.C2 = C2; f.C3 = C3; f.M = count * W;
     f.round_w = (h->train_bf16 && (!(dg || hyb) || tail_bf16)) ? 1 : 0;   // the lift ran on bf16 operands
     for (int t = 0; t < 2; ++t) {
       f.beta[t] = P(h, L[2]->p_bn[t][0]); f.gamma[t] = P(h, L[2]->p_bn[t][1]);

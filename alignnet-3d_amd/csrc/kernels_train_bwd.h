@@ -1236,7 +1236,9 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const T* __restrict
 // Several slice reductions in one launch (every launch costs >= 4.7 us on the one stream of a step, whatever its work):
 // grid (max over jobs of ceil(n/32), 2 towers, jobs).  Same summation order as reduce_slices_kernel.
 struct ReduceJob { const void* part; int is_double; int S; long n; float* out; float alpha; int towers;
-                   int upper_c = 0; };   // upper_c = C > 0: the columns are a C x C matrix of which only the 32 x 32 blocks on / above the block diagonal are summed (Gram partials)
+                   int upper_c = 0;      // upper_c = C > 0: the columns are a C x C matrix of which only the 32 x 32 blocks on / above the block diagonal are summed (Gram partials)
+                   double* out64 = nullptr; };   // optional: the same totals unrounded (the statistics derived from a Gram divide by variances that can be 1e-4 of its entries)
+//   // upper_c = C > 0: the columns are a C x C matrix of which only the 32 x 32 blocks on / above the block diagonal are summed (Gram partials)
 constexpr int kReduceJobs = 16;
 struct ReduceJobs { ReduceJob j[kReduceJobs]; };
 __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx, int t, int bz)
@@ -1277,6 +1279,7 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += wred[k][threadIdx.x];
       jb.out[(size_t)t * jb.n + c0 + threadIdx.x] = (float)tot * jb.alpha;
+      if (jb.out64) jb.out64[(size_t)t * jb.n + c0 + threadIdx.x] = tot * (double)jb.alpha;
     }
     return;
   }
@@ -1314,7 +1317,14 @@ __device__ __forceinline__ void reduce_multi_body(const ReduceJobs& jobs, int bx
 #pragma unroll
     for (int k = 0; k < 32; ++k) tot += red[k][cl];
     jb.out[(size_t)t * jb.n + i] = (float)tot * jb.alpha;
+    if (jb.out64) jb.out64[(size_t)t * jb.n + i] = tot * (double)jb.alpha;
   }
+}
+// [n] doubles -> floats (sync_bn: the all-reduced fp64 Gram / column sums back into the float copies the backward reads)
+__global__ void cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
 }
 __global__ __launch_bounds__(1024) void reduce_multi_kernel(const ReduceJobs jobs) { reduce_multi_body(jobs, blockIdx.x, blockIdx.y, blockIdx.z); }
 
@@ -1375,8 +1385,8 @@ __global__ __launch_bounds__(256) void gram_pool_finish_kernel(float* __restrict
 // [C2][8] doubles, s [C2] doubles.
 // ---------------------------------------------------------------------------------
 struct Stat3Args {
-  const float* G;        // [2][C2*C2] reduced Gram, 32 x 32 blocks on / above the block diagonal valid
-  const float* s;        // [2][C2] reduced column sums
+  const double* G;       // [2][C2*C2] reduced Gram, 32 x 32 blocks on / above the block diagonal valid -- fp64 as the reduction left it: rounded to
+  const double* s;       // [2][C2] reduced column sums        float (6e-8 of entries ~1e3 x a small channel variance) the statistics lost three digits
   const float* W;        // [C2][C3]
   int C2, C3; double M; int round_w;
   const float* beta[2]; const float* gamma[2]; float* mov_mean[2]; float* mov_var[2];
@@ -1400,12 +1410,12 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   __shared__ float cst[4][kS3C];       // mean, var, scale, shift of the block's channels
   const int C2 = a.C2, C3 = a.C3, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * kS3C, cj = lane & 15, kq = lane >> 4, c = c0 + cj;
-  const float* G = a.G + (size_t)t * C2 * C2;
-  const float* sv = a.s + (size_t)t * C2;
+  const double* G = a.G + (size_t)t * C2 * C2;
+  const double* sv = a.s + (size_t)t * C2;
   const double invM = 1.0 / a.M;
   auto ghat = [&](int i, int j) -> double {   // centred Gram from the reduced upper 32 x 32 blocks
-    const float raw = (i >> 5) <= (j >> 5) ? G[(size_t)i * C2 + j] : G[(size_t)j * C2 + i];
-    return (double)raw - (double)sv[i] * ((double)sv[j] * invM);
+    const double raw = (i >> 5) <= (j >> 5) ? G[(size_t)i * C2 + j] : G[(size_t)j * C2 + i];
+    return raw - sv[i] * (sv[j] * invM);
   };
   // the pooled-feature part below does not depend on the statistics until its last step: its first eight clouds per thread are requested
   // now and travel under the Gram loads and the MFMAs
@@ -1423,8 +1433,8 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   // centred Gram that goes back to HBM, the finishing threads' parameters, the pooled part's sign and bias
   const int gper = (C2 + (int)gridDim.x - 1) / (int)gridDim.x, gr0 = blockIdx.x * gper, gr1 = min(C2, gr0 + gper), gne = (gr1 - gr0) * C2;
   const int ge_i = gr0 + min(tid, max(gne - 1, 0)) / C2, ge_j = min(tid, max(gne - 1, 0)) % C2;
-  const float ge_raw = (ge_i >> 5) <= (ge_j >> 5) ? G[(size_t)ge_i * C2 + ge_j] : G[(size_t)ge_j * C2 + ge_i];
-  const float ge_si = sv[ge_i], ge_sj = sv[ge_j];
+  const double ge_raw = (ge_i >> 5) <= (ge_j >> 5) ? G[(size_t)ge_i * C2 + ge_j] : G[(size_t)ge_j * C2 + ge_i];
+  const double ge_si = sv[ge_i], ge_sj = sv[ge_j];
   const int fcc = min(c0 + (tid & (kS3C - 1)), C3 - 1);
   const float f_bias = a.pa.bias[fcc], f_gamma = a.gamma[t][fcc], f_beta = a.beta[t][fcc];
   const float f_mm = a.update_ema ? a.mov_mean[t][fcc] : 0.f, f_mv = a.update_ema ? a.mov_var[t][fcc] : 0.f;
@@ -1434,8 +1444,9 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
     const int i = wave * 16 + cj;          // A row of this lane
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     // every operand of the wave's C2 / 4 MFMAs is requested before the first one issues (C2 <= 128: 32 Gram + 32 weight + 32 column-sum values per lane)
-    float gr[32], wr[32], sr[32];
-    const float si = sv[i];
+    double gr[32], sr[32];
+    float wr[32];
+    const double si = sv[i];
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
       const int k = min(4 * m + kq, C2 - 1);
@@ -1443,7 +1454,7 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
       wr[m] = c < C3 ? a.W[(size_t)k * C3 + c] : 0.f;
       sr[m] = sv[k];
     }
-    float wd[4], sd[4];   // the D rows' weights and column sums (needed right behind the MFMAs)
+    float wd[4]; double sd[4];   // the D rows' weights and column sums (needed right behind the MFMAs)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ir = wave * 16 + kq + 4 * r;
@@ -1455,7 +1466,7 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
       if (4 * m < C2) {
         float w = wr[m];
         if (a.round_w) w = __uint_as_float((unsigned)to_bf16_bits(w) << 16);
-        const double av = (double)gr[m] - (double)si * ((double)sr[m] * invM);
+        const double av = gr[m] - si * (sr[m] * invM);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (double)w, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -1464,7 +1475,7 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
       if (a.round_w) wf = __uint_as_float((unsigned)to_bf16_bits(wf) << 16);
       const double w = (double)wf;
       qp += w * acc[r];
-      swp += (double)sd[r] * w;
+      swp += sd[r] * w;
     }
   }
   qp += __shfl_xor(qp, 16); qp += __shfl_xor(qp, 32);
@@ -1472,12 +1483,12 @@ __global__ __launch_bounds__(512) void stat3_pool_finish_kernel(const Stat3Args 
   if (lane < kS3C) { red[wave][0][lane] = qp; red[wave][1][lane] = swp; }
   // rows [r0, r1) of the centred Gram (all blocks) and the column means go to HBM for the backward
   {
-    if (tid < gne) a.Gc[(size_t)t * C2 * C2 + (size_t)ge_i * C2 + ge_j] = (float)((double)ge_raw - (double)ge_si * ((double)ge_sj * invM));   // (= ghat(i, j))
+    if (tid < gne) a.Gc[(size_t)t * C2 * C2 + (size_t)ge_i * C2 + ge_j] = (float)(ge_raw - ge_si * (ge_sj * invM));   // (= ghat(i, j))
     for (int e = tid + 512; e < gne; e += 512) {
       const int i = gr0 + e / C2, j = e % C2;
       a.Gc[(size_t)t * C2 * C2 + (size_t)i * C2 + j] = (float)ghat(i, j);
     }
-    if (blockIdx.x == 0) for (int i = tid; i < C2; i += 512) a.m2[t * C2 + i] = (float)((double)sv[i] * invM);
+    if (blockIdx.x == 0) for (int i = tid; i < C2; i += 512) a.m2[t * C2 + i] = (float)(sv[i] * invM);
   }
   __syncthreads();
   if (tid < kS3C && c0 + tid < C3) {

@@ -904,43 +904,47 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
 }
 
-// (sum z2, sum z2^2) per tower and channel from the reduced s1 [2][C1] and G1 [2][C1*C1] (upper 32 x 32 blocks valid), fp64.
+// (sum z2, sum (z2 - mean)^2) per tower and channel from the reduced s1 [2][C1] and G1 [2][C1*C1] (upper 32 x 32 blocks valid), fp64.
 // round_w: the hidden layer runs on bf16 operands -- W2 as rounded.  grid (C2, 2), block 256.  out: [2][C2][2] doubles.
-// (thread 0 returns true with the channel's (sum z2, sum z2^2) in *o0 / *o1)
-__device__ __forceinline__ bool stat2_from_gram_body(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+// (thread 0 returns true with the channel's (sum z2, centred sum of squares) in *o0 / *o1)
+__device__ __forceinline__ bool stat2_from_gram_body(const double* __restrict__ G1, const double* __restrict__ s1, const float* __restrict__ W2,
                                                      const float* __restrict__ b2, int C1, int C2, double M, int round_w, int c, int t, double* o0, double* o1)
 {
   __shared__ double red[4][2];
   const int tid = threadIdx.x;
   auto wv = [&](int i) { const float w = W2[(size_t)i * C2 + c]; return (double)(round_w ? __uint_as_float((unsigned)to_bf16_bits(w) << 16) : w); };
-  const float* G = G1 + (size_t)t * C1 * C1;
+  // CENTRED form: w^T (G - s s^T / M) w.  (Uncentred -- sum z^2 - (sum z)^2 / M afterwards -- the two terms agree to all but a few digits for a
+  // channel whose mean is tens of its deviation; the fp64 reduction's totals are read unrounded for the same reason.)
+  const double* G = G1 + (size_t)t * C1 * C1;
+  const double* sv = s1 + (size_t)t * C1;
+  const double invM = 1.0 / M;
   double q = 0.0, sw = 0.0;
   for (int e = tid; e < C1 * C1; e += 256) {
     const int i = e / C1, j = e % C1;
-    const double g = (i >> 5) <= (j >> 5) ? (double)G[(size_t)i * C1 + j] : (double)G[(size_t)j * C1 + i];
+    const double g = ((i >> 5) <= (j >> 5) ? G[(size_t)i * C1 + j] : G[(size_t)j * C1 + i]) - sv[i] * (sv[j] * invM);
     q += wv(i) * g * wv(j);
   }
-  for (int i = tid; i < C1; i += 256) sw += (double)s1[t * C1 + i] * wv(i);
+  for (int i = tid; i < C1; i += 256) sw += sv[i] * wv(i);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); sw += __shfl_xor(sw, o); }
   if ((tid & 63) == 0) { red[tid >> 6][0] = q; red[tid >> 6][1] = sw; }
   __syncthreads();
   if (tid == 0) {
     const double Q = red[0][0] + red[1][0] + red[2][0] + red[3][0], S = red[0][1] + red[1][1] + red[2][1] + red[3][1], bb = (double)b2[c];
-    *o0 = S + M * bb;
-    *o1 = Q + 2.0 * bb * S + M * bb * bb;
+    *o0 = S + M * bb;          // sum z2
+    *o1 = Q;                   // sum (z2 - mean)^2: the centred quadratic form
     return true;
   }
   return false;
 }
-__global__ __launch_bounds__(256) void stat2_from_gram_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+__global__ __launch_bounds__(256) void stat2_from_gram_kernel(const double* __restrict__ G1, const double* __restrict__ s1, const float* __restrict__ W2,
                                                               const float* __restrict__ b2, int C1, int C2, double M, int round_w,
                                                               double* __restrict__ out)
 {
   double v0, v1;
   if (stat2_from_gram_body(G1, s1, W2, b2, C1, C2, M, round_w, blockIdx.x, blockIdx.y, &v0, &v1)) {
     out[((size_t)blockIdx.y * C2 + blockIdx.x) * 2] = v0;
-    out[((size_t)blockIdx.y * C2 + blockIdx.x) * 2 + 1] = v1;
+    out[((size_t)blockIdx.y * C2 + blockIdx.x) * 2 + 1] = v1 + v0 * (v0 / M);   // stat_finish_kernel takes (sum, sum of squares): fp64 carries the 1e-16 (mean / deviation)^2 this costs
   }
 }
 
@@ -1094,7 +1098,7 @@ __global__ __launch_bounds__(1024) void stat_finish_kernel(const StatFinishArgs 
 
 // The hidden layer's statistics from Gram(h1) AND their finish in one launch (fp32 training; they were stat2_from_gram_kernel + stat_finish_kernel on a
 // [2][C2][2] "partial" table: a launch whose 16 workgroups each read two doubles per channel).  grid (C2, 2), block 256; f.part / B / slices unused.
-__global__ __launch_bounds__(256) void stat2_from_gram_finish_kernel(const float* __restrict__ G1, const float* __restrict__ s1, const float* __restrict__ W2,
+__global__ __launch_bounds__(256) void stat2_from_gram_finish_kernel(const double* __restrict__ G1, const double* __restrict__ s1, const float* __restrict__ W2,
                                                                      const float* __restrict__ b2, int C1, int C2, double M, int round_w, const StatFinishArgs a)
 {
   const int c = blockIdx.x, t = blockIdx.y;
@@ -1103,7 +1107,7 @@ __global__ __launch_bounds__(256) void stat2_from_gram_finish_kernel(const float
   double s, ss;
   if (!stat2_from_gram_body(G1, s1, W2, b2, C1, C2, M, round_w, c, t, &s, &ss)) return;
   const double mean = s / a.count;
-  const double var = fmax(ss / a.count - mean * mean, 0.0);
+  const double var = fmax(ss / a.count, 0.0);   // (ss: the centred sum of squares)
   const float mf = (float)mean, vf = (float)var;
   a.mean[t * a.C + c] = mf;
   a.var[t * a.C + c] = vf;

@@ -82,8 +82,8 @@ def test_gradients_match_autograd(gpu_required, N, B, tol, std):
     cfg, spec, P32, d, du = _setup(N, B, std=std)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
-    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     report, bad = {}, {}
     bn_bias = set()
@@ -321,14 +321,14 @@ def test_dgcnn_gradients_match_autograd(gpu_required, N, B, tol, std):
     cfg, spec, P32, d, du = _setup_dgcnn(N, B, std=std)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
-    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
+    eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    _, _, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     rel32 = 0.0
     if std:
-        _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32)
+        _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32, pinned=eng.debug_train_decisions(B, relu=True))
         gs = max(float(np.abs(v).max()) for v in grads.values())
         rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs) for k in grads)
         tol = max(tol, 2.0 * rel32)
-    eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     gscale = max(float(np.abs(v).max()) for v in grads.values())
     report, bad = {}, {}
     bn_bias = set()
@@ -426,8 +426,8 @@ def test_negative_gammas(gpu_required, backbone):
             P32[k] = (P32[k] * rng.choice([-1.0, 1.0], size=P32[k].shape)).astype(np.float32)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
-    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     for k in ep_ref:
         np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
     assert abs(res["loss"] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (res["loss"], loss_ref)
@@ -463,8 +463,8 @@ def test_gradients_wide_first_layers(gpu_required):
     du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
-    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    ep_ref, loss_ref, grads, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     for k in ep_ref:
         np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
     gscale = max(float(np.abs(v).max()) for v in grads.values())
@@ -535,8 +535,8 @@ def test_general_depth_backbones_train(gpu_required, case, N, B, tail):
     eng.set_variables(P32)
     assert eng.get_option("train_fused_tail") == 1
     eng.set_option("train_fused_tail", tail)
-    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     assert eng.get_option("last_train_kernel") & 8, "the general-depth path did not run"
     assert bool(eng.get_option("last_train_kernel") & 16) == (tail == 1 and case != "odd_shapes"), eng.get_option("last_train_kernel")
     for k in ep_ref:
@@ -666,8 +666,8 @@ def test_dgcnn_general_widths_and_depth_train(gpu_required, case, N, B):
     du = {k: rng.uniform(size=(B, 32)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
-    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+    ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
     assert eng.get_option("last_train_kernel") & 12 == 12, "the layer-by-layer dgcnn path did not run"
     for k in ep_ref:
         np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
@@ -676,7 +676,7 @@ def test_dgcnn_general_widths_and_depth_train(gpu_required, case, N, B):
         np.testing.assert_allclose(eng.get_variable(k), v, rtol=1e-4, atol=1e-5, err_msg=k)
     # (k-max per point and channel: the fp32 evaluation of the oracle itself is 1e-2 .. 3e-2 away from the fp64 one where a near-tie
     # routes a gradient to another edge row -- test_dgcnn_gradients_match_autograd; bound: twice the fp32 oracle's own error)
-    _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32)
+    _, _, g32, _ = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], dt=np.float32, pinned=eng.debug_train_decisions(B, relu=True))
     gs = max(float(np.abs(v).max()) for v in grads.values())
     rel32 = max(float(np.abs(g32[k].astype(np.float64) - grads[k]).max()) / (float(np.abs(grads[k]).max()) + 1e-5 * gs) for k in grads)
     bad, worst = _grad_check(eng, spec, grads, min(max(3e-3 if B >= 8 else 1e-2, 2.0 * rel32), 8e-2))   # (capped: "mixed" at B = 5 has an fp32-oracle error of 0.26)
@@ -717,8 +717,8 @@ def test_general_depth_smaller_batch_after_larger(gpu_required, tail):
             eng = alignnet3d.Engine(cfg)
             eng.set_option("train_fused_tail", tail)
         eng.set_variables(P32)      # (the EMA shadows too: every call starts from the same state as its oracle)
-        ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"])
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+        ep_ref, loss_ref, grads, ema_ref = _oracle(cfg, P32, d, du, eng.state()["bn_decay"], pinned=eng.debug_train_decisions(B, relu=True))   # (pinned to this step's decisions and relu signs)
         assert eng.get_option("last_train_kernel") & 8
         for k in ep_ref:
             np.testing.assert_allclose(res[k], ep_ref[k], rtol=2e-4, atol=2e-4, err_msg="B=%d %s" % (B, k))

@@ -3,7 +3,7 @@
 decisions AND relu signs (a smooth function of its inputs) is evaluated in fp64 and -- the same torch graph, the same pins -- in fp32: the
 second is what a straightforward fp32 evaluation of the reference graph gives on this batch.  Prints whole-gradient relative L2 of
 engine-vs-fp64 and torch-fp32-vs-fp64 and the worst tensors of each (error over max(own largest entry, 2 % of the gradient's)).
-Usage: python tools/relu_pin_diag.py CASE [CASE ...]   CASE = backbone:B:N:same|varied:f32|bf16"""
+Usage: python tools/relu_pin_diag.py CASE [CASE ...]   CASE = backbone:B:N:same|varied:f32|bf16[:seed]"""
 import os
 import sys
 
@@ -19,13 +19,13 @@ from tests.test_fullsize_gpu import _grad_compare  # noqa: E402
 
 
 def diag(case):
-    backbone, B, N, kind, dtype = case.split(":")
-    B, N, bf16 = int(B), int(N), dtype == "bf16"
+    backbone, B, N, kind, dtype, seed = (case.split(":") + ["5"])[:6]
+    B, N, bf16, seed = int(B), int(N), dtype == "bf16", int(seed)
     cfg = alignnet3d.default_model_config()
     cfg["model"]["num_points"], cfg["model"]["backbone"], cfg["training"]["batch_size"] = N, backbone, B
-    spec, P32 = oracle_params(cfg, seed=5)
-    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=5, dtype=np.float32)
-    rng = np.random.default_rng(5)
+    spec, P32 = oracle_params(cfg, seed=seed)
+    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
     du = {k: rng.uniform(size=(B, 256)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
@@ -69,13 +69,13 @@ def same_pins(a, b):
 
 def variants(case, vs):
     """the same step under engine options (kernel variants of the same arithmetic): which one moves the distance from the pinned oracle?"""
-    backbone, B, N, kind, dtype = case.split(":")
-    B, N, bf16 = int(B), int(N), dtype == "bf16"
+    backbone, B, N, kind, dtype, seed = (case.split(":") + ["5"])[:6]
+    B, N, bf16, seed = int(B), int(N), dtype == "bf16", int(seed)
     cfg = alignnet3d.default_model_config()
     cfg["model"]["num_points"], cfg["model"]["backbone"], cfg["training"]["batch_size"] = N, backbone, B
-    spec, P32 = oracle_params(cfg, seed=5)
-    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=5, dtype=np.float32)
-    rng = np.random.default_rng(5)
+    spec, P32 = oracle_params(cfg, seed=seed)
+    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
     du = {k: rng.uniform(size=(B, 256)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     cache = []
     for v in vs:
