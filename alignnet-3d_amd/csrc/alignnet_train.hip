@@ -1367,12 +1367,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.dy2_store = w->dy2; b2.dbg2_part = w->dbg2_part; b2.u2_part = S.u2_part; b2.g1_part = S.g1_part;
   b2.s1_part = (!given && !h->train_bf16 && !b2_accum && !(h->ab & AB_PHASE2_LEGACY)) ? nullptr : w->s1_part;   // null: the forward kept the column sums of h1
   const size_t b2_extra = (size_t)C3 * 8 + (size_t)(kTW * ((N + kTT - 1) / kTT + 1) + kTW) * 4;
-  if (lds_train(b2.ldb, b2.ldb) + b2_extra > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0) +
                         ((std_w && !b2_accum && !h->train_bf16 && !given) ? (size_t)(5 * 64 + 16 + 6 * 128) * sizeof(float) : 0);   // STDF: the LDS parameter tables
+  if (b2_lds > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");   // (on the final size: the parameter tables count)
   { ProfScope prof_scope(h, PK_TRAIN_B2, true);
   if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
   else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);

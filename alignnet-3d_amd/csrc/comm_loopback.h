@@ -115,10 +115,12 @@ inline LoopComm* loop_join(const unsigned char id[128], int rank, int world, int
   // every failure below breaks the group and wakes the peers: a rank that cannot join must not leave the others in the join
   // rendezvous until their timeout
   auto refuse = [&](const std::string& m) -> LoopComm* { err = m; g->broken = true; g->cv.notify_all(); return nullptr; };
-  if (rank < 0 || rank >= world) return refuse("loopback communicator: rank " + std::to_string(rank) + " outside the world of " + std::to_string(world));
-  if (g->world != world) return refuse("loopback communicator: ranks disagree on the world size");
-  if (g->device != device) return refuse("loopback communicator: all ranks must sit on one device");
-  if (g->ready[rank]) return refuse("loopback communicator: rank " + std::to_string(rank) + " joined twice");
+  // (a group that is already complete is not the stray caller's to break: it is turned away, the joined ranks go on)
+  auto turn_away = [&](const std::string& m) -> LoopComm* { if (g->joined == g->world && !g->broken) { err = m; return nullptr; } return refuse(m); };
+  if (rank < 0 || rank >= world) return turn_away("loopback communicator: rank " + std::to_string(rank) + " outside the world of " + std::to_string(world));
+  if (g->world != world) return turn_away("loopback communicator: ranks disagree on the world size");
+  if (g->device != device) return turn_away("loopback communicator: all ranks must sit on one device");
+  if (g->ready[rank]) return turn_away("loopback communicator: rank " + std::to_string(rank) + " joined twice");
   if (hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming) != hipSuccess) {
     if (g->ready[rank]) { hipEventDestroy(g->ready[rank]); g->ready[rank] = nullptr; }

@@ -437,9 +437,16 @@ def main():
                     help="rehearsal of the multi-GPU code path on ONE GPU: re-launch under torch.distributed.run with one rank and take every branch a "
                          "--gpus N > 1 run takes (NCCL process group with device_id, the library's RCCL communicator, barriers, max over ranks, the "
                          "sustained loop's flag all-reduce, per-rank spread); the line says so in `forced_dist`")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="rehearsal of the --gpus W > 1 code path on ONE GPU: W ranks as host threads of this process, each with its own engine on device 0, the "
+                         "library's in-process loopback communicator standing where RCCL stands and a thread rendezvous where torch.distributed stands.  Every "
+                         "world > 1 branch runs -- collectives that must be entered by EVERY rank, the per-rank gather, rccl_ranks, the exposed all-reduce -- so "
+                         "that the driver's multi-GPU node is not the first to run them.  NOT a measurement: W ranks share one device (the line says so)")
     args = ap.parse_args()
     refuse_stray_environment()
 
+    if args.rehearse_world > 1:
+        raise SystemExit(rehearse(args))
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) here instead of silently running one
         raise SystemExit(self_launch(args.gpus))
@@ -448,26 +455,113 @@ def main():
     real_stdout = os.dup(1)
     sys.stdout.flush()
     os.dup2(2, 1)
+    run_rank(args, real_stdout, None)
 
+
+class ThreadRanks:
+    """What bench.py uses of torch.distributed, for W ranks that are THREADS of one process (--rehearse-world): one instance per rank over a shared
+    rendezvous.  A collective that not every rank enters does not complete: the barrier times out and the run fails (the defect class of
+    round 5's rank-0-only sync-BN probe)."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    class Shared:
+        def __init__(self, world, timeout):
+            import threading
+            self.world, self.timeout = world, timeout
+            self.barrier = threading.Barrier(world, timeout=timeout)
+            self.slots = [None] * world
+
+    def __init__(self, rank, shared):
+        self.rank, self.shared = rank, shared
+
+    def get_rank(self): return self.rank
+    def get_world_size(self): return self.shared.world
+    def get_backend(self): return "loopback-threads"
+    def is_initialized(self): return True
+    def barrier(self): self.shared.barrier.wait()
+    def destroy_process_group(self): pass
+
+    def _exchange(self, value):
+        sh = self.shared
+        sh.barrier.wait()              # (the previous collective's readers are done with the slots)
+        sh.slots[self.rank] = value
+        sh.barrier.wait()
+        return list(sh.slots)
+
+    def all_reduce(self, t, op="sum"):
+        import torch
+        vals = self._exchange(t.detach().clone())
+        st = torch.stack(vals)
+        t.copy_(st.max(0).values if op == "max" else st.sum(0))
+
+    def all_gather(self, out, t):
+        vals = self._exchange(t.detach().clone())
+        for o, v in zip(out, vals):
+            o.copy_(v)
+
+    def broadcast_object_list(self, box, src=0):
+        vals = self._exchange(box[0])
+        box[0] = vals[src]
+
+
+def rehearse(args):
+    """--rehearse-world W: run_rank on W threads (one engine each, device 0), joined by ThreadRanks + the loopback communicator."""
+    import threading
+    W = args.rehearse_world
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    shared = ThreadRanks.Shared(W, timeout=float(os.environ.get("BENCH_REHEARSAL_TIMEOUT_S", "180")))
+    errors = []
+
+    def body(r):
+        try:
+            run_rank(args, real_stdout, ThreadRanks(r, shared))
+        except BaseException as e:   # noqa: BLE001 -- a failed rank must take the others' barriers down with it
+            errors.append((r, "%s: %s" % (type(e).__name__, e)))
+            shared.barrier.abort()
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r, e in sorted(errors):
+        sys.stderr.write("bench.py --rehearse-world: rank %d failed: %s\n" % (r, e))
+    return 1 if errors else 0
+
+
+def run_rank(args, real_stdout, threads):
+    """One rank of the bench: a process under torch.distributed.run (threads is None) or a thread of --rehearse-world (threads: its ThreadRanks)."""
     import torch
     import alignnet3d
     from alignnet3d.synth import synth_pairs  # synthetic input generator (SURVEY 8d recipe); the oracle is only imported by cpu_baseline()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if threads is not None:
+        rank, local_rank, world = threads.get_rank(), 0, threads.get_world_size()
+        args.gpus = world                         # (what the line reports as ranks; devices_used says one)
+        args.no_cpu_baseline = args.no_pcie_leg = args.no_extra_legs = True
+        args.sustained_seconds = min(args.sustained_seconds, 0.5)
+    else:
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist_on = world > 1 or args.force_dist   # every `world > 1` branch below; --force-dist takes them at world = 1
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    local_world = 1 if threads is not None else int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if local_world > ndev:
         # one rank per GPU is the contract; sharing a device would report n_gpus ranks' worth of throughput from fewer GPUs
         raise SystemExit(f"{local_world} ranks on this node but only {ndev} GPU(s) visible: refusing to share devices")
     dist = None
-    if dist_on:
+    if threads is not None:
+        dist = threads
+        torch.cuda.set_device(0)
+    elif dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -515,7 +609,7 @@ def main():
         """Data-parallel training: RCCL communicator over xGMI inside the library; the 128-byte id travels via torch.distributed."""
         nonlocal rccl_ranks
         from alignnet3d import parallel
-        parallel.init_comm(eng, dist, grad_communicator=bool(args.grad_communicator))
+        parallel.init_comm(eng, dist, make_id=type(eng).comm_loopback_id if threads is not None else None, grad_communicator=bool(args.grad_communicator))
         eng.set_option("allreduce_overlap", args.allreduce_overlap)
         if args.sync_bn:
             eng.set_option("sync_bn", 1); eng.set_option("global_loss", 1)
@@ -688,6 +782,34 @@ def main():
         leg_tag = "train_dgcnn" if dg else ("train_bf16" if args.train_dtype == "bf16" else "train")
     head_roof = roofline(kern, args.steps, head_bf16, leg_tag, backbone_kernel)
 
+    # ---- world > 1: what ONE rank of this very run does with the node to itself -- the N = 1 value this line scales from (rank 0 steps alone, the
+    #      other ranks wait at the fence), so that the scaling efficiency value / (n_gpus x this) is computable from this one line
+    single_rank = None
+    if dist is not None and world > 1:
+        fence()
+        if rank == 0:
+            e1 = eng
+            if args.mode == "train":   # (an engine of its own: the headline engine's step joins the communicator's collectives)
+                e1 = alignnet3d.Engine(cfg, device=local_rank, seed=0)
+                e1.set_option("train_matmul_bf16", int(args.train_dtype == "bf16"))
+                step1 = lambda: e1.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
+            else:
+                step1 = infer_step
+            for _ in range(max(args.warmup, 3)):
+                step1()
+            e1.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            e1.synchronize()
+            d1 = time.perf_counter() - t1
+            single_rank = {"value": round(B * args.steps / d1, 1), "unit": "pairs/s", "ms_per_step": round(d1 / args.steps * 1e3, 4), "steps": args.steps, "n_gpus": 1,
+                           "what": "rank 0 alone, the other ranks idle at a barrier: the same step" + (" on a fresh engine without a communicator (local-BN, no all-reduce)" if args.mode == "train" else "") +
+                                   "; scaling efficiency of this line = value / (n_gpus x this value)"}
+            if e1 is not eng:
+                e1.close()
+        fence()
+
     # ---- the same step, back to back for >= --sustained-seconds: the K-step region above is a burst of tens of milliseconds; this one
     #      is long enough for the clocks to settle (sclk sampled from rocm-smi while the queue is full, first and last chunk)
     sustained = None
@@ -845,6 +967,14 @@ def main():
                 line.update(head_sync_bn)
         if dist_on:
             line["per_rank_pairs_per_s"] = per_rank_rates(head_per_rank, args.steps)
+        if single_rank is not None:
+            line["single_rank_reference"] = single_rank
+            line["scaling_efficiency_vs_single_rank"] = round(value / (world * single_rank["value"]), 4)
+        if threads is not None:
+            line["n_gpus"] = 1
+            line["config"]["devices_used"] = 1
+            line["rehearsal"] = ("%d ranks as host threads on ONE GPU, in-process loopback communicator in place of RCCL, thread rendezvous in place of torch.distributed: "
+                                 "exercises the world > 1 code path; NOT a throughput measurement (the ranks share the device)" % world)
         if args.force_dist:
             line["forced_dist"] = "world-1 rehearsal of the multi-GPU code path (torch.distributed.run --nproc-per-node=1, NCCL process group, RCCL communicator of one rank)"
         if args.mode == "infer" and args.infer_dtype == "bf16x3":

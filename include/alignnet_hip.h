@@ -235,7 +235,11 @@ int alignnet_comm_init(alignnet_handle* h, int32_t rank, int32_t world, const ui
 /* Optional: a SECOND communicator of the same ranks (its own id, same rank / world as the first) that carries the gradient buckets
  * only.  NCCL-style communicators serialise the collectives issued on them across streams; with sync_bn a per-layer sum of the next
  * stage's backward would otherwise queue behind the previous stage's gradient bucket.  Results are identical with and without it
- * (tests/test_loopback_gpu.py); alignnet_get_option("grad_communicator") reads 1 when it exists. */
+ * (tests/test_loopback_gpu.py); alignnet_get_option("grad_communicator") reads 1 when it exists.
+ * HAZARD (why it is opt-in and off in bench.py): two RCCL communicators then have collectives in flight on two streams of one device at the
+ * same time.  NCCL / RCCL document that as deadlock-prone when the device-side execution order of the two collectives differs between ranks
+ * (each needs all ranks' kernels resident to progress).  It has run on the in-process loopback backend only, never on real links: validate it
+ * on a multi-GPU node before relying on it. */
 int alignnet_comm_init_grad(alignnet_handle* h, int32_t rank, int32_t world, const uint8_t id[128]);
 int alignnet_comm_allreduce_grads(alignnet_handle* h);
 /* Average the BatchNorm EMA shadows (the non-trainable variables) over the ranks, on the device: local-BN data parallelism updates them

@@ -108,3 +108,35 @@ def test_force_dist_rehearsal_at_world_1(gpu_required, args):
     else:
         for leg in (d["train"], d["train"]["bf16"]):
             assert leg["rccl_ranks"] == 1 and leg["bn_mode"] == "local" and leg["per_rank_pairs_per_s"]["ranks"] == 1, leg
+
+
+@pytest.mark.parametrize("args", [("--mode", "train", "--train-dtype", "bf16", "--sync-bn", "1"),
+                                  ("--mode", "train", "--allreduce-overlap", "0"),
+                                  ("--min-leg-seconds", "0.05", "--no-split-leg")])
+def test_world_2_rehearsal_on_one_gpu(gpu_required, args):
+    """bench.py's world > 1 code with TWO ranks on this box's one GPU (--rehearse-world 2: the ranks are host threads, the library's in-process loopback
+    communicator stands where RCCL stands, a thread rendezvous where torch.distributed stands).  What the world-1 rehearsal cannot catch -- a
+    collective that only rank 0 enters (round 5: the sync-BN latency probe of the training headline sat inside `if rank == 0`) -- hangs
+    here until the rendezvous times out and fails the run.  Checks the line's multi-rank fields: per-rank gather over 2 ranks, the communicator's
+    rank count, the exposed all-reduce, the single-rank reference the line scales from."""
+    env = dict(os.environ, BENCH_REHEARSAL_TIMEOUT_S="120")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-world", "2", *args, "--steps", "5", "--warmup", "1", "--sustained-seconds", "0.3"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert "rehearsal" in d and d["n_gpus"] == 1 and d["config"]["devices_used"] == 1
+    assert d["per_rank_pairs_per_s"]["ranks"] == 2
+    ref = d["single_rank_reference"]
+    assert ref["n_gpus"] == 1 and ref["value"] > 0 and abs(d["scaling_efficiency_vs_single_rank"] - d["value"] / (2 * ref["value"])) < 1e-3
+    if "--mode" in args:
+        assert "2 ranks" in d["config"]["parallelism"] and "allreduce_exposed_ms_per_step" in d
+        if "--sync-bn" in args:
+            assert d["bn_mode"] == "sync" and d["sync_collectives_per_step"] > 0 and d["sync_bn_latency_floor_ms"] > 0
+    else:
+        for leg in (d["train"], d["train"]["bf16"]):
+            assert leg["rccl_ranks"] == 2 and leg["per_rank_pairs_per_s"]["ranks"] == 2, leg

@@ -121,3 +121,42 @@ def test_committed_summaries_agree_with_their_bench_lines_on_launches_per_step()
         assert abs(hit - roof["launches_per_step"]) <= 0.01 * roof["launches_per_step"], (f, hit, roof["launches_per_step"])
         checked += 1
     print("summaries checked:", checked)
+
+
+def test_thread_ranks_rendezvous_and_missing_rank():
+    """bench.py --rehearse-world: the stand-in for torch.distributed among rank THREADS (max / sum all-reduce, all-gather, object broadcast), and its
+    point -- a collective that one rank does not enter times out instead of completing."""
+    import threading
+    import torch
+    m = _bench_module()
+    W = 3
+    shared = m.ThreadRanks.Shared(W, timeout=20.0)
+    got = [None] * W
+
+    def body(r):
+        d = m.ThreadRanks(r, shared)
+        t = torch.tensor([float(r + 1)], dtype=torch.float64)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        s = torch.tensor([float(r + 1)])
+        d.all_reduce(s)
+        out = [torch.empty(1) for _ in range(W)]
+        d.all_gather(out, torch.tensor([10.0 * r]))
+        box = ["id-from-0" if r == 0 else None]
+        d.broadcast_object_list(box, src=0)
+        d.barrier()
+        got[r] = (float(t), float(s), [float(o) for o in out], box[0], d.get_rank(), d.get_world_size())
+    th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for r in range(W):
+        assert got[r] == (3.0, 6.0, [0.0, 10.0, 20.0], "id-from-0", r, W), got[r]
+    # rank 1 skips the collective: the others must fail, not wait for ever
+    shared2 = m.ThreadRanks.Shared(2, timeout=1.0)
+    failed = []
+
+    def lonely():
+        try:
+            m.ThreadRanks(0, shared2).all_reduce(torch.zeros(1))
+        except threading.BrokenBarrierError:
+            failed.append(True)
+    t = threading.Thread(target=lonely); t.start(); t.join(30)
+    assert failed == [True]
