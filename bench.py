@@ -515,6 +515,13 @@ def rehearse(args):
     os.dup2(2, 1)
     shared = ThreadRanks.Shared(W, timeout=float(os.environ.get("BENCH_REHEARSAL_TIMEOUT_S", "180")))
     errors = []
+    import torch
+    import alignnet3d
+    if torch.cuda.device_count() < 1:   # (the device runtime and the library are initialised here, once, not by W threads at the same time)
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.init()
+    torch.zeros(1, device="cuda:0")
+    alignnet3d.load_library()
 
     def body(r):
         try:
