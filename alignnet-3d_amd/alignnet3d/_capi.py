@@ -133,7 +133,13 @@ def load_library():
                       "There is no CPU fallback.")
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        try:
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        except AttributeError:
+            # an A/B build of an EARLIER revision (ALIGNNET_HIP_LIB, tools/ab_build.sh) may predate a test hook; the in-tree library must export everything
+            if os.environ.get("ALIGNNET_HIP_LIB") and name.startswith("alignnet_debug_"):
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     if lib.alignnet_abi_version() != ABI_VERSION:
