@@ -139,6 +139,38 @@ def test_small_step_kernels_use_no_scratch():
     assert seen == set(keys), sorted(set(keys) - seen)
 
 
+def test_big_training_passes_stay_within_their_scratch_budget():
+    """The long passes of the training step in their SHIPPED instantiations (widths 64 / 128 compiled in): register file full (two waves per SIMD by LDS
+    anyway), scratch zero or the two-to-seven spilled registers measured in round 6 -- a regression guard, since a change that pushes one of them into tens of
+    spills (B2's run-time-width form sits at 78 - 81) costs 10 - 20 % of the pass and fails no numerical test.  VERDICT round 5, next 2 (i)."""
+    import re
+    path = os.path.join(ROOT, "alignnet-3d_amd", "csrc", "alignnet_train.remarks")
+    if not os.path.exists(path):
+        pytest.skip("no resource remarks next to the objects (library built by an older Makefile)")
+    rows = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)",
+                      open(path).read(), re.S)
+    budget = {   # mangled-name fragment -> (max scratch bytes / lane, max spilled VGPRs)
+        "train_bwd_b2ILb0ELb1ELb0ELi64ELi128EE": (12, 2),     # pass B2, bf16, shipped widths (configs[2]'s longest kernel)
+        "train_bwd_b2ILb0ELb0ELb0ELi64ELi128EE": (0, 0),      # pass B2, fp32
+        "train_bwd_b2ILb0ELb0ELb1ELi64ELi128EE": (0, 0),      # pass B2 on given features (dgcnn point conv), fp32
+        "train_bwd_b2ILb0ELb1ELb1ELi64ELi128EE": (0, 0),      # ... bf16
+        "train_bwd_b1_bf16E": (0, 0),
+        "train_bwd_b1ILi64ELi128ELb1EE": (0, 0),
+        "dg_train_bwd_edgeILi64ELi128ELb0EE": (12, 2),         # configs[4]: 45 % of the fp32 dgcnn step
+        "dg_train_bwd_edgeILi64ELi128ELb1EE": (0, 0),
+        "dg_train_bwd_edge_denseILi64ELi128EE": (0, 0),
+        "dg_train_fwdILi64ELb0EE": (32, 7),
+        "dg_train_fwdILi64ELb1EE": (0, 0),
+    }
+    seen = set()
+    for name, vgpr, scratch, occ, spill in rows:
+        for frag, (smax, pmax) in budget.items():
+            if frag in name:
+                seen.add(frag)
+                assert int(scratch) <= smax and int(spill) <= pmax and int(occ) >= 2, (name, vgpr, scratch, occ, spill)
+    assert seen == set(budget), sorted(set(budget) - seen)
+
+
 def test_no_register_is_rewritten_while_a_load_into_it_is_in_flight():
     """The hand-issued weight stream of csrc/kernels_infer.h (mfma_rows: asm `global_load_dwordx4` retired by counted asm waits) is invisible to
     the compiler's wait bookkeeping, so only the source's data flow keeps the allocator from giving a stream register to a new value before the
