@@ -371,11 +371,11 @@ def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
     """configs[2] at its own size (bf16 MFMA convs, 256 differently sized objects x 1024 points) against the rounded-operand oracle pinned to
     the engine's winners, classes and relu signs.  What stays undecided here is every ROUNDING of an operand to bf16 (2^-8 of one of 128
     product terms, a billion per step): the rounded oracle itself moves by relative L2 0.12 under one-ulp moves of its inputs even fully
-    pinned (profiles/r06_relu_pin_full2.log), so the bars are those of the engine's measured agreement with margin, not 1e-4: measured
-    cosine 0.99995, relative L2 1.0e-2, worst tensor 7.4e-2 (round 5, winners only: cosine 0.992, 0.138, 0.249); decision gaps 2e-2 of
+    pinned (profiles/r06_relu_pin_full2.log), so the bars are those of the engine's measured agreement with a factor of two, not 1e-4: cosine >= 0.9999, relative
+    L2 <= 2e-2, every tensor <= 4e-2 of max(own, 2 %) -- measured cosine 0.99995, 1.0e-2, 1.6e-2 (round 5, winners only: cosine 0.992, 0.138, 0.249); decision gaps 2e-2 of
     their scale (operand rounding).  That the mode TRAINS is test_bf16_converges_like_fp32's statement."""
     cfg, spec, P32, d, du = _varied_setup()
-    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=1e-1, loss_tol=5e-3, ema_tol=1e-2, rl2_bar=2e-2, tensor_bar=1.5e-1, cos_bar=0.9998,
+    _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=1e-1, loss_tol=5e-3, ema_tol=1e-2, rl2_bar=2e-2, tensor_bar=4e-2, cos_bar=0.9999,
                                   bf16=True, gap_bar=2e-2, relu_gap_bar=2e-2, relu_differ_bar=1e-3, tag="full size, varied objects")
 
 
