@@ -1060,4 +1060,21 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     assert not bad, (bar_t, bad)
     with pytest.raises(alignnet3d.EngineError):
         eng._check(eng._lib.alignnet_debug_train_decisions(eng._h, 1, 0, dec["yaw"].ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32)), 3))   # wrong count
+    # the relu-mask hook: shapes as documented (include/alignnet_hip.h), and its refusals
+    import ctypes as C
+    o = cfg["model"]["options"]
+    convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
+    scopes = ["transformer1/embedding", "transformer2/embedding", "embedding"]
+    for s_ in range(3):
+        nl = len(convs[s_])
+        for l, c in enumerate(convs[s_]):
+            rows = B if l == nl - 1 else (B * N if (backbone != "dgcnn" or l == nl - 2) else B * N * 20)
+            for t in range(2):
+                m = dec["relu"][f"{t}:{scopes[s_]}/conv{l + 1}"]
+                assert m.shape == (rows, c) and m.dtype == bool and (l == nl - 1 or 0 < m.mean() < 1), (s_, l, t, m.shape, m.mean())
+    assert dec["relu"]["p:fc1"].shape == (B, 64) and dec["relu"]["0:transformer1/mlp/fc2"].shape == (B, 32)
+    buf = np.empty(8, np.uint8)
+    for kind, stage, layer in ((0, 3, 0), (0, 0, 99), (1, 0, 2), (7, 0, 0), (0, 0, 0)):   # bad stage, bad conv layer, no such hidden head layer, bad kind, wrong count
+        with pytest.raises(alignnet3d.EngineError):
+            eng._check(eng._lib.alignnet_debug_train_relu_mask(eng._h, kind, stage, layer, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size))
     eng.close()

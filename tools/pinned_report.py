@@ -5,7 +5,7 @@ the step is then a smooth function of its inputs), and each pinned oracle agains
 relative): what any fp32 evaluation of this batch can be expected to reproduce.  PINNED_MODES=free,pinned,... selects; RELU_DETAIL=1 lists
 the layers whose mask disagrees with the oracle's own signs.  Prints per case: predictions, loss, whole-gradient
 cosine / relative L2, the worst tensors, the decision gaps.
-Usage: python tools/pinned_report.py CASE [CASE ...]   CASE = backbone:B:N:kind:dtype, e.g. pointnet:256:1024:varied:f32"""
+Usage: python tools/pinned_report.py CASE [CASE ...]   CASE = backbone:B:N:kind:dtype[:seed], e.g. pointnet:256:1024:varied:f32"""
 import os
 import sys
 import time
@@ -30,13 +30,13 @@ def grad_cmp(ga, gb, spec):
 
 
 def report(case):
-    backbone, B, N, kind, dtype = case.split(":")
-    B, N, bf16 = int(B), int(N), dtype == "bf16"
+    backbone, B, N, kind, dtype, seed = (case.split(":") + ["5"])[:6]
+    B, N, bf16, seed = int(B), int(N), dtype == "bf16", int(seed)
     cfg = alignnet3d.default_model_config()
     cfg["model"]["num_points"], cfg["model"]["backbone"], cfg["training"]["batch_size"] = N, backbone, B
-    spec, P32 = oracle_params(cfg, seed=5)
-    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=5, dtype=np.float32)
-    rng = np.random.default_rng(5)
+    spec, P32 = oracle_params(cfg, seed=seed)
+    d = (varied_pairs if kind == "varied" else R.synth_pairs)(B, N, seed=seed, dtype=np.float32)
+    rng = np.random.default_rng(seed)
     du = {k: rng.uniform(size=(B, 256)).astype(np.float32) for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")}
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
