@@ -420,6 +420,8 @@ class Engine:
             out["knn"] = get(3, 0, (2, B, n, 20))
         if relu:
             out["relu"] = self.debug_train_relu_masks(B)
+            # (with the signs: the classes of the loss's target angles, models/tp8.py:193-199 -- [2, B] per tower term, [2, B, B] for the pair term)
+            out["loss_cls"] = [get(4, 0, (2, B)), get(4, 1, (2, B)), get(4, 2, (2, B, B))]
         return out
 
     def debug_train_relu_masks(self, B):

@@ -97,6 +97,7 @@ struct TrainWS {
   char* base = nullptr; size_t bytes = 0;
   float* d_pcs[2] = {nullptr, nullptr};
   const float* last_pcs[2] = {nullptr, nullptr};   // the point clouds (device) of the last training forward (alignnet_debug_train_relu_mask)
+  const float* last_ang[2] = {nullptr, nullptr};   // its yaw labels pc1_angles / pc2_angles (alignnet_debug_train_decisions: ALIGNNET_DECISION_ANGLE_CLASS)
   float* labels[6];              // device copies of the label tensors
   float* dropout_u;              // host-supplied uniforms (device copy), [sum over heads]
   float* center_mean; float* s1c; float* s2c; float* theta; int* cls;
@@ -1616,6 +1617,7 @@ static int fwd_bwd_device(alignnet_handle* h, const float* p1, const float* p2, 
   h->sync_collectives = 0;
   h->last_train_B = B;
   w->last_pcs[0] = p1; w->last_pcs[1] = p2;
+  w->last_ang[0] = lab[4]; w->last_ang[1] = lab[5];
   if (h->prof_pending.size() > 4096 && alignnet_drain_profile(h)) return 1;   // (as the eval forward does: ~15 event pairs per profiled step)
   {
     bool std_all = true;   // all three backbones on the instantiations with the widths (64, 128) compiled in
@@ -2115,6 +2117,22 @@ extern "C" int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, 
     return 0;
   };
   if (kind == ALIGNNET_DECISION_YAW_CLASS) return copy_i32(w->cls, B2);
+  if (kind == ALIGNNET_DECISION_ANGLE_CLASS) {
+    // the class tf_angle2class (models/tp8.py:193-199) put every target angle of the loss into -- for the pair term a [B, B] matrix (:327) --
+    // recomputed by the loss kernels' own device function from the step's labels and decoded yaws
+    if (stage < 0 || stage > 2) return fail(h, "alignnet_debug_train_decisions: the loss has angle terms 0 (tower 1), 1 (tower 2), 2 (pair)");
+    const size_t W = stage == 2 ? (size_t)B : 1, n = 2 * (size_t)B * W;
+    if (count != n) return fail(h, "alignnet_debug_train_decisions: count does not match the requested array (" + std::to_string(n) + " elements)");
+    if (!w->last_ang[0] || !w->last_ang[1]) return fail(h, "alignnet_debug_train_decisions: no labels seen yet");
+    int* d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, n * sizeof(int)));
+    hipLaunchKernelGGL(dbg_angle_class_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, w->last_ang[0], w->last_ang[1], w->theta, B, h->cfg.num_bins, stage, d);
+    hipError_t e = hipMemcpyAsync(dst, d, n * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIP_TRY(h, e);
+    return 0;
+  }
   if (kind == ALIGNNET_DECISION_KNN_GRAPH) {
     if (!dg) return fail(h, "alignnet_debug_train_decisions: the neighbour table exists for the dgcnn backbone only");
     return copy_i32(w->nn, B2 * N * kDgK);

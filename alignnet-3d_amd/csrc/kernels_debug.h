@@ -8,6 +8,7 @@
 #pragma once
 #include "kernels_train_fwd.h"
 #include "kernels_train_dgcnn.h"
+#include "kernels_train_head.h"
 
 namespace alignnet {
 
@@ -106,6 +107,23 @@ __global__ __launch_bounds__(kTW * 64) void dbg_mask_edge1_kernel(const DbgEdge1
     }
     __syncthreads();
   }
+}
+
+// the classes of the loss's target angles (ALIGNNET_DECISION_ANGLE_CLASS): out [2 variants: theta, theta + pi][B][W], W = B for the pair term
+// (entry (i, j): label difference of row i against the decoded yaw difference of column j, models/tp8.py:327), 1 otherwise
+__global__ void dbg_angle_class_kernel(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ theta, int B, int nb, int term,
+                                       int* __restrict__ out)
+{
+  const size_t W = term == 2 ? (size_t)B : 1, idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= 2 * (size_t)B * W) return;
+  const int v = (int)(idx / (B * W)), i = (int)((idx / W) % B), j = (int)(idx % W);
+  const float pi = 3.14159274101257324f;
+  const float dth = theta[B + j] - theta[j];
+  const float a1i = a1[i], a2i = a2[i];
+  int c; float r;
+  if (term < 2) angle2class((term == 0 ? a1i : a2i) + (v ? pi : 0.f), nb, &c, &r);   // (the expressions of loss_pairs_body, kernels_train_head.h)
+  else angle2class((a2i - a1i) - dth + (v ? pi : 0.f), nb, &c, &r);
+  out[idx] = c;
 }
 
 }  // namespace alignnet

@@ -196,11 +196,17 @@ int alignnet_debug_knn_graph(alignnet_handle* h, int32_t* dst, size_t count);
  *   ALIGNNET_DECISION_POOL_POINT  stage 0..2       [2][B][C_last]      arg-max point of the max over points, utils/tf_util.py:350-373 / models/tp8.py:58
  *   ALIGNNET_DECISION_EDGE_SLOT   stage 0..2, dgcnn [2][B][N][C_edge]  arg-max neighbour slot of the max over k, models/tp8.py:42
  *   ALIGNNET_DECISION_KNN_GRAPH   (stage ignored), dgcnn [2][B][N][20] the neighbour table the step used (slot = position in the row)
+ *   ALIGNNET_DECISION_ANGLE_CLASS stage = loss term 0 (tower 1), 1 (tower 2): [2][B]; 2 (pair): [2][B][B] -- the class tf_angle2class
+ *                                 (models/tp8.py:193-199) put each target angle of the loss into, for the target and for target + pi (:286);
+ *                                 the pair term's target is the [B, B] matrix of :327, entry (i, j) = labels of row i against the decoded yaws of
+ *                                 column j.  The residual label res = sh - centre(class) is a sawtooth in the angle: an entry within a rounding of
+ *                                 a class boundary lands on the other tooth in another evaluation (label off by 2 in units of pi / num_bins).
  * count must equal the element count of the requested array. */
 #define ALIGNNET_DECISION_YAW_CLASS 0
 #define ALIGNNET_DECISION_POOL_POINT 1
 #define ALIGNNET_DECISION_EDGE_SLOT 2
 #define ALIGNNET_DECISION_KNN_GRAPH 3
+#define ALIGNNET_DECISION_ANGLE_CLASS 4
 int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, int32_t stage, int32_t* dst, size_t count);
 /* Test hook: the SIGN every relu of the last training step saw (utils/tf_util.py:167-168,345-346), one byte (0 / 1) per element.  What the
  * decisions above leave undecided are these signs: a pre-activation within one rounding of zero is "on" in one evaluation and "off" in another,

@@ -289,13 +289,29 @@ class TorchTp8:
         }
 
     # -- loss ---------------------------------------------------------------
-    def _angle_loss(self, logits, target):
+    def _angle_loss(self, logits, target, pin=None, what=""):
         nb = self.spec.num_bins
         twopi = torch.tensor(np.float32(2 * np.pi), dtype=logits.dtype)
         apc = twopi / nb
         sh = torch.remainder(torch.remainder(target, twopi) + apc / 2, twopi)
         cls = (sh / apc).to(torch.int32)
-        res = sh - (cls.to(logits.dtype) * apc + apc / 2)
+        if pin is not None:
+            # the class each target angle falls into is a DECISION (models/tp8.py:197: int32(shifted / angle_per_class)), taken for every entry
+            # of the pair term's [B, B] target (:327): the residual label is a sawtooth in the angle, and an entry within a rounding of a class
+            # boundary sits on the other tooth in another evaluation (label off by 2 pi / nb / (pi / nb) = 2).  Pinned: the other evaluation's
+            # class, after checking that wherever it differs from this one's the angle is within rounding of the boundary between the two;
+            # the residual then follows continuously (wrapped, since the last class's upper boundary is the wrap of the shifted angle).
+            pc = torch.as_tensor(np.asarray(pin), dtype=torch.int32).reshape(cls.shape)
+            with torch.no_grad():
+                differ = pc != cls
+                nd = int(differ.sum())
+                frac = sh / apc - torch.round(sh / apc)   # distance to the nearest class boundary, in classes
+                self.pin_report.append((f"losscls:{what}", float(frac[differ].abs().max()) if nd else 0.0, 1.0, nd, pc.numel()))
+            cls = pc
+            res = sh - (cls.to(logits.dtype) * apc + apc / 2)
+            res = res - twopi * torch.round(res / twopi)
+        else:
+            res = sh - (cls.to(logits.dtype) * apc + apc / 2)
         cls0 = cls[:, 0].long()
         ce = F.cross_entropy(logits[:, :nb], cls0)
         pick = (logits[:, nb:] * F.one_hot(cls0, nb).to(logits.dtype)).sum(1)  # [B]
@@ -304,10 +320,13 @@ class TorchTp8:
         rl = F.huber_loss(err, torch.zeros_like(err), delta=1.0)
         return torch.stack([ce + 20.0 * rl, ce, rl])
 
-    def _angle_losses(self, logits, target):
-        a = self._angle_loss(logits, target)
+    def _angle_losses(self, logits, target, term=None):
+        pin = None
+        if term is not None and self.pinned is not None and "loss_cls" in self.pinned:
+            pin = self.pinned["loss_cls"][term]   # [2 variants: target, target + pi][B] or [2][B][B]
+        a = self._angle_loss(logits, target, None if pin is None else pin[0], f"{term}:0")
         if self.spec.accept_inverted_angle:
-            b = self._angle_loss(logits, target + float(np.float32(np.pi)))
+            b = self._angle_loss(logits, target + float(np.float32(np.pi)), None if pin is None else pin[1], f"{term}:1")
             return a if bool(a[0] > b[0]) else b
         return a
 
@@ -316,12 +335,12 @@ class TorchTp8:
         hub = lambda e, d: F.huber_loss(e, torch.zeros_like(e), delta=d)
         s1 = (hub(ep["pred_s1_pc1centers"] - c1, 1.0) + hub(ep["pred_s1_pc2centers"] - c2, 1.0)) / 2
         s2 = (hub(ep["pred_s2_pc1centers"] - c1, 1.0) + hub(ep["pred_s2_pc2centers"] - c2, 1.0)) / 2
-        la1 = self._angle_losses(ep["pred_pc1angle_logits"], ang1)
-        la2 = self._angle_losses(ep["pred_pc2angle_logits"], ang2)
+        la1 = self._angle_losses(ep["pred_pc1angle_logits"], ang1, 0)
+        la2 = self._angle_losses(ep["pred_pc2angle_logits"], ang2, 1)
         s3t = hub(ep["pred_translations"] - translations, 2.0)
         p1, p2 = self.angles(ep["pred_pc1angle_logits"], 0), self.angles(ep["pred_pc2angle_logits"], 1)
         tgt = (ang2 - ang1) - (p2 - p1)  # [B,1]-[B] -> [B,B]
-        la3 = self._angle_losses(ep["pred_remaining_angle_logits"], tgt)
+        la3 = self._angle_losses(ep["pred_remaining_angle_logits"], tgt, 2)
         lt = s.early_stage_factor * (s1 + s2) + s3t
         la = s.early_stage_factor * ((la1[0] + la2[0]) / 2) + la3[0]
         return (lt + s.angle_factor * la) / translations.shape[0]

@@ -282,7 +282,11 @@ def _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel, pred_tol
 
     (1) the DECISIONS (Engine.debug_train_decisions: 0.9 M max-pool winners utils/tf_util.py:350-373 and 512 yaw classes models/tp8.py:296
         at 256 x 1024; neighbour slots and the kNN table for dgcnn): the oracle gathers at them after checking that each is a maximum of its
-        own values to within `gap_bar` of their scale (measured 1e-6) -- the test of the arg-max / selection kernels;
+        own values to within `gap_bar` of their scale (measured 1e-6) -- the test of the arg-max / selection kernels; and the class
+        tf_angle2class (models/tp8.py:193-199) put every target angle of the loss into -- 2 x 65,536 of them in the pair term's [B, B] target
+        (:327): the residual label is a sawtooth in the angle, one entry within a rounding of a class boundary lands on the other tooth in
+        another evaluation, and that one flip moved the whole gradient by 4e-4 on the `same` batch of seed 1 (profiles/r06_relu_pin_seeds.log);
+        checked: differing entries within `gap_bar` classes of the boundary;
     (2) the SIGN every relu saw (alignnet_debug_train_relu_mask: 6e8 bits at 256 x 1024, utils/tf_util.py:167-168,345-346): the oracle
         evaluates y = bn(z) * mask after checking that wherever the mask disagrees with its own sign |bn(z)| <= `relu_gap_bar` of the layer's
         scale and that at most `relu_differ_bar` of the signs disagree (measured: ~600 of 6e8, |bn(z)| 4e-6 of scale) -- the test of the BatchNorm /

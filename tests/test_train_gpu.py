@@ -1035,7 +1035,7 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
         k = what.split(":")[0]
         kinds[k] = max(kinds.get(k, 0.0), gap / max(scale, 1.0))
     print(case, "pinned: worst decision gap / scale", kinds, "not the oracle's own first maximum:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
-    assert set(kinds) == ({"yaw", "pool", "relu"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn", "relu"})
+    assert set(kinds) == ({"yaw", "pool", "relu", "losscls"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn", "relu", "losscls"})
     assert all(g <= gap_bar for g in kinds.values()), kinds
     n_relu, d_relu = sum(r[4] for r in rep[0] if r[0].startswith("relu")), sum(r[3] for r in rep[0] if r[0].startswith("relu"))
     assert d_relu <= (1e-3 if bf16 else 1e-5) * n_relu + 4, (d_relu, n_relu)   # signs that differ from the oracle's own: a handful, each with |bn(z)| within gap_bar of zero
