@@ -386,7 +386,7 @@ def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
 def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
     SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 8 differently sized objects keep the [B*N*k, C] autograd
-    oracle in memory.  Measured pinned: 2.4e-5 (torch fp32 2.5e-5)."""
+    oracle in memory.  Measured pinned: 1.9e-5 (torch fp32 2.5e-5)."""
     cfg, spec, P32, d, du = _varied_setup("dgcnn", Bt=8, Nt=1024, seed=7)
     _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=1e-5, ema_tol=2e-4, tag="dgcnn N=1024")
 
@@ -395,7 +395,7 @@ def test_train_b2048_matches_autograd(gpu_required):
     """BASELINE.json configs[3]'s arithmetic on ONE GPU: the global batch of 2048 pairs (KITTITrackletsCarsPersonsHard: SynthCars
     widths) in a single step -- the [B, B] loss terms of models/tp8.py:279,327 at 4 M entries, the whole-batch tf.cond (:288), the
     4096-row head BatchNorms, 4096 workgroups per backbone launch.  N = 128 keeps the fp64 autograd oracle at the cost of the
-    256 x 1024 test (the same 524 k points).  Measured pinned: 6.9e-5."""
+    256 x 1024 test (the same 524 k points).  Measured pinned: 1.1e-5 (7.1e-5 before the 2 x 4 M angle classes of the pair term were pinned)."""
     cfg, spec, P32, d, du = _varied_setup(Bt=2048, Nt=128, seed=11)
     _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=3e-4, loss_tol=1e-5, ema_tol=2e-5, tag="B=2048")
 
@@ -407,7 +407,7 @@ def test_train_dgcnn_n4096_matches_autograd(gpu_required):
     pinned graph 1.5e-4 from the fp64 one -- tools/relu_pin_diag.py -- and the engine at 2.2e-4).  The fp32 kNN graph differs from an fp64 one wherever the 20th and 21st neighbour of a
     query are closer than fp32 rounding of the distance expression (dozens of queries per cloud): pinned, the engine's table is checked as
     a k-nearest SET of every query in fp64 distances (gap 1e-6 of the largest k-th distance) and the step is compared on it.  Measured pinned:
-    2.0e-5 -- the B = 4 `same` batch sat at 4.2e-3 before round 6 folded Gram(h1), accumulated over a cloud's 82 k edge rows in fp32, into fp64 per tile."""
+    1.4e-5 (torch fp32 1.5e-5) -- the B = 4 `same` batch sat at 4.2e-3 before round 6 folded Gram(h1), accumulated over a cloud's 82 k edge rows in fp32, into fp64 per tile."""
     cfg, spec, P32, d, du = _varied_setup("dgcnn", Bt=8, Nt=4096, seed=9)
     _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=5, pred_tol=5e-4, loss_tol=5e-5, ema_tol=5e-4, tag="dgcnn N=4096")
 
