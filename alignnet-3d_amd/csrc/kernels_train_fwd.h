@@ -860,10 +860,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   }
   double s1c = 0.0;
   // The cloud's blocks in fp64: every tile's fp32 MFMA block (32 accumulation steps) is folded in and cleared.  Carried in fp32 for the whole
-  // cloud an element collects N / 2 roundings at the magnitude of the running sum (~1e-6 relative at N = 1024), and the variance of a channel
-  // of z2 = h1 W2 can be 1e-3 of w^T G w's terms: on a batch of differently sized objects the step's gradient sat 4e-4 from the fully pinned
-  // fp64 oracle where a plain fp32 evaluation of the graph sits at 1e-5 (profiles/r06_relu_pin_diag.log; ab_phase2_legacy -- the direct
-  // statistics of z2 -- was at 4e-5).  Folded per tile the Gram is good to ~1e-7.
+  // cloud an element collects N / 2 roundings at the magnitude of the running sum (tools/microbench/mfma_round.hip: sequential round-to-nearest);
+  // on the dgcnn edge rows (82 k per cloud at N = 4096, dg_train_fwd) that put the step 4.2e-3 from the pinned fp64 oracle.  At N = 1024 the
+  // effect is below what the fully pinned comparison resolves (profiles/r06_gramfix_ab.log); folded per tile the chain length no longer grows with N.
   double gd[kSlots][16];
 #pragma unroll
   for (int q = 0; q < kSlots; ++q)
