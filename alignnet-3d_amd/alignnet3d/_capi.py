@@ -86,6 +86,7 @@ SYMBOLS = {
     "alignnet_debug_knn_graph": (C.c_int, [H, C.POINTER(C.c_int32), C.c_size_t]),
     "alignnet_debug_train_decisions": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_size_t]),
     "alignnet_debug_train_relu_mask": (C.c_int, [H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_size_t]),
+    "alignnet_debug_train_rounded": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(C.c_uint16), C.c_size_t]),
     "alignnet_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "alignnet_comm_loopback_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "alignnet_comm_init": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),

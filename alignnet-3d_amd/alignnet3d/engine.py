@@ -424,6 +424,22 @@ class Engine:
             out["loss_cls"] = [get(4, 0, (2, B)), get(4, 1, (2, B)), get(4, 2, (2, B, B))]
         return out
 
+    def debug_train_rounded(self, B):
+        """bf16 step, fused PointNet stages: the bf16-rounded h1 / h2 the step's MFMA convs multiplied (alignnet_debug_train_rounded), keyed like the relu masks
+        by the conv layer that CONSUMES them: "<tower>:<scope>/conv2" -> h1 as float32 [B*N, C1], "<tower>:<scope>/conv3" -> h2 [B*N, C2]."""
+        o, n = self.cfg["model"]["options"], self.num_points
+        convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
+        scopes = ["transformer1/embedding", "transformer2/embedding", "embedding"]
+        out = {}
+        for s in range(3):
+            for l in range(2):
+                a = np.empty((2, B * n, convs[s][l]), np.uint16)
+                self._check(self._lib.alignnet_debug_train_rounded(self._h, s, l, a.ctypes.data_as(C.POINTER(C.c_uint16)), a.size))
+                f = (a.astype(np.uint32) << 16).view(np.float32)
+                for t in range(2):
+                    out[f"{t}:{scopes[s]}/conv{l + 2}"] = f[t]
+        return out
+
     def debug_train_relu_masks(self, B):
         o, n = self.cfg["model"]["options"], self.num_points
         dg = self.cfg["model"]["backbone"] == "dgcnn"

@@ -2246,6 +2246,41 @@ extern "C" int alignnet_debug_train_relu_mask(alignnet_handle* h, int32_t kind, 
   return finish();
 }
 
+// test hook (include/alignnet_hip.h): the bf16-rounded activations the last bf16 training step multiplied (fused PointNet stages)
+extern "C" int alignnet_debug_train_rounded(alignnet_handle* h, int32_t stage, int32_t layer, uint16_t* dst, size_t count)
+{
+  if (!h) return 1;
+  if (!dst) return fail(h, "alignnet_debug_train_rounded: null argument");
+  TrainWS* w = static_cast<TrainWS*>(h->train_ws);
+  const int B = h->last_train_B, N = h->cfg.num_points;
+  if (!w || !w->base || B < 1) return fail(h, "alignnet_debug_train_rounded: no training forward has run on this handle");
+  if (!(h->last_train_kernel & 2)) return fail(h, "alignnet_debug_train_rounded: the last training step did not run with train_matmul_bf16");
+  if (stage < 0 || stage > 2 || h->cfg.backbone == 1 || stage_generic(h, stage)) return fail(h, "alignnet_debug_train_rounded: fused PointNet stages 0..2 only");
+  if (layer < 0 || layer > 1) return fail(h, "alignnet_debug_train_rounded: layer 0 (h1, input of the hidden conv) or 1 (h2, input of the lift)");
+  const Stack& st = conv_of(h, stage);
+  const Layer& L = h->layers[st.first + layer];
+  const StageWS& S = w->st[stage];
+  const size_t n = 2 * (size_t)B * N * L.cout;
+  if (count != n) return fail(h, "alignnet_debug_train_rounded: count does not match the requested array (" + std::to_string(n) + " elements)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (layer == 1) {   // the stored h2 IS the rounded tile
+    HIP_TRY(h, hipMemcpy(dst, S.h2, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  unsigned short* d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, n * sizeof(uint16_t)));
+  const int C1 = L.cout, ld0 = ((C1 + 7) & ~7) + 4;
+  DbgRound1Args a{{w->last_pcs[0], w->last_pcs[1]}, S.xform, B, N, C1, ld0, P(h, L.p_w), S.scale[0], S.shift[0], d};
+  hipLaunchKernelGGL(dbg_rounded_layer1_kernel, dim3(2 * B), dim3(kTW * 64), ((size_t)kTT * 4 + (size_t)kTT * ld0) * sizeof(float), h->stream, a);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d);
+  HIP_TRY(h, e);
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------
 // RCCL (loaded lazily so that single-GPU use does not depend on librccl)
 // ---------------------------------------------------------------------------------

@@ -109,6 +109,32 @@ __global__ __launch_bounds__(kTW * 64) void dbg_mask_edge1_kernel(const DbgEdge1
   }
 }
 
+// bf16 step (train_matmul_bf16): the ROUNDED h1 the hidden conv multiplied, as bf16 bits [2B N][C1] -- the passes' own lift (layer1_to_lds<ROUND>:
+// relu(fma(x' . w, sc, sh)) rounded by to_bf16_bits).  grid 2B, block kTW * 64; LDS as dbg_mask_layer1_kernel
+struct DbgRound1Args { const float* pcs[2]; const float* xform; int B, N, C1, ld0; const float* w1; const float *sc1, *sh1; unsigned short* out; };
+__global__ __launch_bounds__(kTW * 64) void dbg_rounded_layer1_kernel(const DbgRound1Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem; float* h1 = smem + kTT * 4;
+  const int tid = threadIdx.x, cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const XForm X = xform_load(a.xform + (size_t)cloud * 12);
+  const Layer1W L = layer1_load(a.w1, a.C1, a.sc1 + tower * a.C1, a.sh1 + tower * a.C1, tid);
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nvalid = min(kTT, a.N - tile * kTT);
+    tile_point_store(tile_point_request(pc, a.N, tile, tid), X, xs, tid);
+    __syncthreads();
+    layer1_to_lds<true>(xs, L, a.C1, h1, a.ld0, nvalid, tid);
+    __syncthreads();
+    for (int e = tid; e < nvalid * a.C1; e += kTW * 64) {
+      const int row = e / a.C1, c = e - row * a.C1;
+      a.out[((size_t)cloud * a.N + (size_t)tile * kTT + row) * a.C1 + c] = (unsigned short)(__float_as_uint(h1[row * a.ld0 + c]) >> 16);
+    }
+    __syncthreads();
+  }
+}
+
 // the classes of the loss's target angles (ALIGNNET_DECISION_ANGLE_CLASS): out [2 variants: theta, theta + pi][B][W], W = B for the pair term
 // (entry (i, j): label difference of row i against the decoded yaw difference of column j, models/tp8.py:327), 1 otherwise
 __global__ void dbg_angle_class_kernel(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ theta, int B, int nb, int term,

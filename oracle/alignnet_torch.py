@@ -75,9 +75,31 @@ class TorchTp8:
         # as identity (straight-through).
         self.bf16_lift = bf16_lift
 
-    @staticmethod
-    def _round_bf16_st(x):
-        return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+    def _round_bf16_st(self, x, key=None):
+        """x rounded to bf16, straight-through.  pinned["round"][key] (optional): ANOTHER evaluation's rounded values of this tensor -- every rounding to bf16 is a
+        decision of its own, 2^-8 of the value; the other evaluation's value is taken after checking that it is one of the two bf16 neighbours of x
+        (pin_report "round:<key>": worst |pinned - x| in bf16 ulps of x, entries that differ from this evaluation's own rounding)."""
+        own = x.detach().to(torch.bfloat16).to(x.dtype)
+        r = None
+        if key is not None and self.pinned is not None and "round" in self.pinned:
+            r = self.pinned["round"].get(key)
+        if r is None:
+            return x + (own - x.detach())
+        r = torch.as_tensor(np.asarray(r)).to(x.dtype).reshape(x.shape)
+        with torch.no_grad():
+            xd = x.detach()
+            # bf16 spacing is 2^-7 .. 2^-8 of the value; near zero (a relu output that is 1e-9 here and 1e-6 there) the two evaluations differ by
+            # their own rounding of the pre-activation, not by a bf16 step: floor of 1e-5 of the tensor's scale
+            ulp = torch.maximum(torch.abs(xd), torch.abs(r)) * 2.0 ** -7 + 1e-5 * float(xd.abs().max())
+            d = torch.abs(r - xd) / ulp
+            differ = r != own
+            nd = int(differ.sum())
+            self.pin_report.append((f"round:{key}", float(d[differ].max()) if nd else 0.0, 1.0, nd, r.numel()))
+            # ... and how many sit further than 1.5 steps away (the other evaluation's OWN passes recompute h1 from xyz in separately compiled copies of
+            # one expression; where two copies differ by an fp32 rounding that crosses a bf16 boundary, the h2 row behind it moves by a bf16 step of one input)
+            far = int((d > 1.5).sum())
+            self.pin_report.append((f"roundtail:{key}", far / r.numel(), 1.0, far, r.numel()))
+        return x + (r - x.detach())
 
     # -- layers ---------------------------------------------------------
     def _bn(self, z, base, training, decay):
@@ -129,7 +151,7 @@ class TorchTp8:
     def _layer(self, x, wbase, bnbase, training, decay, act=True, round_operands=False, relu_key=None):
         w = self.P[wbase + "/weights"]
         if round_operands:
-            x, w = self._round_bf16_st(x), self._round_bf16_st(w)
+            x, w = self._round_bf16_st(x, relu_key), self._round_bf16_st(w)   # (relu_key = "<tower>:<layer scope>": the layer that consumes x)
         z = F.linear(x, w.t(), self.P[wbase + "/biases"])
         if bnbase is not None:
             z = self._bn(z, bnbase, training, decay)

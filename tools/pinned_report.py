@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU: one training step of the engine against fp64 autograd -- FREE (the oracle decides for itself), PINNED to the engine's
-decisions (alignnet_debug_train_decisions), RELU = pinned to the decisions and to the sign every relu saw (alignnet_debug_train_relu_mask:
-the step is then a smooth function of its inputs), and each pinned oracle against ITSELF with its inputs moved by one fp32 rounding (6e-8
+decisions (alignnet_debug_train_decisions), RELU = pinned to the decisions (incl. the loss's angle classes) and to the sign every relu saw (alignnet_debug_train_relu_mask:
+the step is then a smooth function of its inputs), ROUND (bf16 cases) = also to the bf16-rounded activations (alignnet_debug_train_rounded), and each pinned oracle against ITSELF with its inputs moved by one fp32 rounding (6e-8
 relative): what any fp32 evaluation of this batch can be expected to reproduce.  PINNED_MODES=free,pinned,... selects; RELU_DETAIL=1 lists
 the layers whose mask disagrees with the oracle's own signs.  Prints per case: predictions, loss, whole-gradient
 cosine / relative L2, the worst tensors, the decision gaps.
@@ -43,7 +43,10 @@ def report(case):
     eng.set_option("train_matmul_bf16", int(bf16))
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     dec = eng.debug_train_decisions(B, relu=True)
-    dec_nr = {k: v for k, v in dec.items() if k != "relu"}
+    dec_nr = {k: v for k, v in dec.items() if k not in ("relu", "loss_cls")}
+    dec_round = None
+    if bf16 and backbone == "pointnet" and any(m.startswith("round") for m in MODES):
+        dec_round = dict(dec, round=eng.debug_train_rounded(B))   # + the bf16-rounded h1 / h2 the step multiplied
     ge = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
     decay = eng.state()["bn_decay"]
     eng.close()
@@ -57,7 +60,7 @@ def report(case):
             r2 = np.random.default_rng(99)
             for k in ("pcs1", "pcs2"):
                 dd[k] = dd[k] * (1 + 6e-8 * r2.standard_normal(dd[k].shape))
-        ep, loss, g, _ = TT._oracle(cfg, P32, dd, du, decay, bf16_lift=bf16, checkpoint=True, pinned=None if mode == "free" else (dec if mode.startswith("relu") else dec_nr), report=rep)
+        ep, loss, g, _ = TT._oracle(cfg, P32, dd, du, decay, bf16_lift=bf16, checkpoint=True, pinned=None if mode == "free" else (dec_round if mode.startswith("round") and dec_round else dec if mode.startswith(("relu", "round")) else dec_nr), report=rep)
         out[mode] = (ep, loss, g)
         ref = (res, res["loss"], ge) if not mode.endswith("+1ulp") else out[mode[:-5]]
         what = "engine vs oracle" if not mode.endswith("+1ulp") else "oracle vs oracle"
