@@ -87,6 +87,8 @@ def variants(case, vs):
             eng.set_option(k, int(val))
         eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
         dec = eng.debug_train_decisions(B, relu=True)
+        if bf16 and backbone == "pointnet":
+            dec["round"] = eng.debug_train_rounded(B)   # (bf16: the operand roundings pinned too)
         ge = {n: eng.get_gradient(n).astype(np.float64) for n in R.trainable_names(spec)}
         decay = eng.state()["bn_decay"]
         eng.close()
