@@ -1022,6 +1022,11 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     eng.set_option("train_matmul_bf16", bf16)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     dec = eng.debug_train_decisions(B, relu=True)   # (+ the sign every relu saw: alignnet_debug_train_relu_mask on the fused, hybrid and layer-by-layer paths)
+    round_pin = bool(bf16) and backbone == "pointnet"
+    if round_pin:
+        dec["round"] = eng.debug_train_rounded(B)     # bf16, fused PointNet stages: the operand roundings pinned too (alignnet_debug_train_rounded)
+        with pytest.raises(alignnet3d.EngineError):
+            eng._check(eng._lib.alignnet_debug_train_rounded(eng._h, 0, 2, None, 0))   # no such layer
     assert dec["yaw"].shape == (2, B) and dec["yaw"].min() >= 0 and dec["yaw"].max() < 12
     for s_, a in enumerate(dec["pool"]):
         assert a.min() >= 0 and a.max() < N, (s_, a.min(), a.max())
@@ -1035,7 +1040,10 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
         k = what.split(":")[0]
         kinds[k] = max(kinds.get(k, 0.0), gap / max(scale, 1.0))
     print(case, "pinned: worst decision gap / scale", kinds, "not the oracle's own first maximum:", sum(r[3] for r in rep[0]), "of", sum(r[4] for r in rep[0]))
-    assert set(kinds) == ({"yaw", "pool", "relu", "losscls"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn", "relu", "losscls"})
+    assert set(kinds) == ({"yaw", "pool", "relu", "losscls"} if backbone == "pointnet" else {"yaw", "pool", "slot", "knn", "relu", "losscls"}) | ({"round", "roundtail"} if round_pin else set())
+    if round_pin:   # every rounded value a bf16 neighbour of the oracle's (a handful of h2 rows further: oracle/alignnet_torch.py _round_bf16_st); the other gaps are then fp32-sized
+        assert kinds.pop("round") <= 64.0 and kinds.pop("roundtail") <= 1e-4, kinds
+        gap_bar = 1e-3
     assert all(g <= gap_bar for g in kinds.values()), kinds
     n_relu, d_relu = sum(r[4] for r in rep[0] if r[0].startswith("relu")), sum(r[3] for r in rep[0] if r[0].startswith("relu"))
     assert d_relu <= (1e-3 if bf16 else 1e-5) * n_relu + 4, (d_relu, n_relu)   # signs that differ from the oracle's own: a handful, each with |bn(z)| within gap_bar of zero
@@ -1049,7 +1057,9 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     srl2, stens, spred = _oracle_noise_floor(lambda dd: _oracle(cfg, P32, dd, du, decay, bf16_lift=bool(bf16), pinned=dec), d, spec, grads, ep_ref, 4)
     pred = max(float(np.abs(res[k] - ep_ref[k]).max()) for k in ep_ref)
     floor, kc = (2e-2, 1.5) if bf16 else (5e-4 if B >= 8 else 3e-3, 3.0)   # (B < 8: five-row batch statistics in the heads; the free tests allow 1e-2 there)
-    bar_t, bar_l2, bar_p = max(floor, kc * stens), max(floor, kc * srl2), max(2e-2 if bf16 else 1e-4, kc * spred)
+    if round_pin:
+        floor = 1.5e-2   # (roundings pinned: the oracle's self-distance is ~1e-6 and the bar is this floor -- the backward's own bf16 roundings; measured 5e-3 at full size)
+    bar_t, bar_l2, bar_p = max(floor, kc * stens), max(floor, kc * srl2), max((2e-4 if round_pin else 2e-2) if bf16 else 1e-4, kc * spred)   # (roundings pinned: the bf16 forward at fp32 level)
     print(case, "pinned: engine vs oracle: predictions %.2e, relative L2 %.2e, worst tensor %.2e (%s) | oracle under one-ulp input moves (worst of 4): predictions %.2e, "
           "relative L2 %.2e, worst tensor %.2e" % (pred, rl2, max(relf.values()), max(relf, key=relf.get), spred, srl2, stens))
     assert pred <= bar_p, (pred, bar_p)
