@@ -431,9 +431,10 @@ class Engine:
         convs = [list(o["s1transformer"][0]), list(o["s2transformer"][0]), list(o["embedding"])]
         scopes = ["transformer1/embedding", "transformer2/embedding", "embedding"]
         out = {}
+        dg = self.cfg["model"]["backbone"] == "dgcnn"
         for s in range(3):
             for l in range(2):
-                a = np.empty((2, B * n, convs[s][l]), np.uint16)
+                a = np.empty((2, B * n * (20 if dg and l == 0 else 1), convs[s][l]), np.uint16)
                 self._check(self._lib.alignnet_debug_train_rounded(self._h, s, l, a.ctypes.data_as(C.POINTER(C.c_uint16)), a.size))
                 f = (a.astype(np.uint32) << 16).view(np.float32)
                 for t in range(2):

@@ -2255,24 +2255,34 @@ extern "C" int alignnet_debug_train_rounded(alignnet_handle* h, int32_t stage, i
   const int B = h->last_train_B, N = h->cfg.num_points;
   if (!w || !w->base || B < 1) return fail(h, "alignnet_debug_train_rounded: no training forward has run on this handle");
   if (!(h->last_train_kernel & 2)) return fail(h, "alignnet_debug_train_rounded: the last training step did not run with train_matmul_bf16");
-  if (stage < 0 || stage > 2 || h->cfg.backbone == 1 || stage_generic(h, stage)) return fail(h, "alignnet_debug_train_rounded: fused PointNet stages 0..2 only");
+  if (stage < 0 || stage > 2 || stage_generic(h, stage)) return fail(h, "alignnet_debug_train_rounded: fused stages 0..2 only");
   if (layer < 0 || layer > 1) return fail(h, "alignnet_debug_train_rounded: layer 0 (h1, input of the hidden conv) or 1 (h2, input of the lift)");
+  const bool dg = h->cfg.backbone == 1;
   const Stack& st = conv_of(h, stage);
   const Layer& L = h->layers[st.first + layer];
   const StageWS& S = w->st[stage];
-  const size_t n = 2 * (size_t)B * N * L.cout;
+  const size_t n = 2 * (size_t)B * N * L.cout * ((dg && layer == 0) ? kDgK : 1);
   if (count != n) return fail(h, "alignnet_debug_train_rounded: count does not match the requested array (" + std::to_string(n) + " elements)");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (layer == 1) {   // the stored h2 IS the rounded tile
+  if (layer == 1 && !dg) {   // the stored h2 IS the rounded tile
     HIP_TRY(h, hipMemcpy(dst, S.h2, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     return 0;
   }
   unsigned short* d = nullptr;
   HIP_TRY(h, hipMalloc(&d, n * sizeof(uint16_t)));
   const int C1 = L.cout, ld0 = ((C1 + 7) & ~7) + 4;
+  if (dg && layer == 1)   // the pooled edge features p (fp32 in the workspace), rounded as the bf16 point conv rounds them while staging
+    hipLaunchKernelGGL(dbg_round_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S.h2, d, n);
+  else if (dg) {
+    DbgEdgeR1Args a{{w->last_pcs[0], w->last_pcs[1]}, S.xform, w->nn, B, N, kDgK, P(h, L.p_w), S.scale[0], S.shift[0], d};
+    const size_t lds = ((size_t)kTT * 8 + (size_t)kTT * (C1 + 4)) * sizeof(float);
+    if (C1 == 64) hipLaunchKernelGGL(dbg_rounded_edge1_kernel<64>, dim3(2 * B), dim3(kTW * 64), lds, h->stream, a);
+    else hipLaunchKernelGGL(dbg_rounded_edge1_kernel<32>, dim3(2 * B), dim3(kTW * 64), lds, h->stream, a);
+  } else {
   DbgRound1Args a{{w->last_pcs[0], w->last_pcs[1]}, S.xform, B, N, C1, ld0, P(h, L.p_w), S.scale[0], S.shift[0], d};
   hipLaunchKernelGGL(dbg_rounded_layer1_kernel, dim3(2 * B), dim3(kTW * 64), ((size_t)kTT * 4 + (size_t)kTT * ld0) * sizeof(float), h->stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

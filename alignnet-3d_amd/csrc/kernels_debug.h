@@ -135,6 +135,47 @@ __global__ __launch_bounds__(kTW * 64) void dbg_rounded_layer1_kernel(const DbgR
   }
 }
 
+// dgcnn, bf16 step: the rounded output of the K = 6 lift (input of the second edge conv) as bf16 bits [2B][N][k][C1]: dgt_liftm's fp32 value through
+// to_bf16_bits -- what dgt_liftm_bf16 stores (the same expression on the same accumulator).  Launch as dbg_mask_edge1_kernel.
+struct DbgEdgeR1Args { const float* pcs[2]; const float* xform; const int* nn; int B, N, k; const float* w1; const float *sc1, *sh1; unsigned short* out; };
+template <int C1>
+__global__ __launch_bounds__(kTW * 64) void dbg_rounded_edge1_kernel(const DbgEdgeR1Args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* es = smem; float* h1 = smem + kTT * 8;
+  constexpr int ld0 = C1 + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
+  const float* xf = a.xform + (size_t)cloud * 12;
+  const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
+  const DgtLiftM<C1, kTW> lw = dgt_liftm_load<C1, kTW>(a.w1, a.sc1 + tower * C1, a.sh1 + tower * C1, wave, lane);
+  if (tid < kTT) { es[tid * 8 + 6] = 0.f; es[tid * 8 + 7] = 0.f; }
+  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  for (int j = 0; j < total; ++j) {
+    const int tile = j / a.k, slot = j - tile * a.k, nvalid = min(kTT, a.N - tile * kTT);
+    if (tid < kTT) {
+      float v[6];
+      dgt_points(pc, a.N, a.k, j, tid, dgt_index(nnc, a.N, a.k, j, tid), v);
+      dg_edge_to_lds(xf, v, es + tid * 8);
+    }
+    __syncthreads();
+    dgt_liftm<C1, kTW>(lw, es, h1, ld0, nvalid, wave, lane);
+    __syncthreads();
+    for (int e = tid; e < nvalid * C1; e += kTW * 64) {
+      const int row = e / C1, c = e - row * C1;
+      a.out[(((size_t)cloud * a.N + (size_t)tile * kTT + row) * a.k + slot) * C1 + c] = to_bf16_bits(h1[row * ld0 + c]);
+    }
+    __syncthreads();
+  }
+}
+// [n] floats -> bf16 bits (the pooled edge features p as the bf16 point conv rounds them while staging)
+__global__ void dbg_round_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n)
+{
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = to_bf16_bits(src[i]);
+}
+
 // the classes of the loss's target angles (ALIGNNET_DECISION_ANGLE_CLASS): out [2 variants: theta, theta + pi][B][W], W = B for the pair term
 // (entry (i, j): label difference of row i against the decoded yaw difference of column j, models/tp8.py:327), 1 otherwise
 __global__ void dbg_angle_class_kernel(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ theta, int B, int nb, int term,

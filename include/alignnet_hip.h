@@ -226,8 +226,9 @@ int alignnet_debug_train_decisions(alignnet_handle* h, int32_t kind, int32_t sta
 #define ALIGNNET_RELU_CONV 0
 #define ALIGNNET_RELU_HEAD 1
 int alignnet_debug_train_relu_mask(alignnet_handle* h, int32_t kind, int32_t stage, int32_t layer, uint8_t* dst, size_t count);
-/* Test hook, bf16 step only (train_matmul_bf16, fused PointNet stages): the bf16-ROUNDED activations the last training step fed to its MFMA convs, as bf16
- * bits, towers outermost: layer 0 = h1 [2][B][N][C1] (input of the hidden conv), layer 1 = h2 [2][B][N][C2] (input of the lift).  Every rounding of an
+/* Test hook, bf16 step only (train_matmul_bf16, fused stages): the bf16-ROUNDED activations the last training step fed to its MFMA convs, as bf16
+ * bits, towers outermost: layer 0 = h1 [2][B][N][C1] (input of the hidden conv; dgcnn: the lifted edge features [2][B][N][20][C1], input of the second edge
+ * conv), layer 1 = h2 [2][B][N][C2] (input of the lift; dgcnn: the pooled edge features, input of the point conv).  Every rounding of an
  * operand to bf16 is a small decision of its own (2^-8 of the value, a billion per step): an oracle that models the operand rounding (oracle/alignnet_torch.py
  * `bf16_lift`) and takes THESE rounded values -- after checking each is one of the two bf16 neighbours of its own value -- is a smooth function of its inputs,
  * as with the decisions and signs above.  Same calling window as alignnet_debug_train_relu_mask. */

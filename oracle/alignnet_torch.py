@@ -237,7 +237,7 @@ class TorchTp8:
         h = self._relu(self._max_over(h.reshape(B * N, k, -1), "slot", scope, tower), f"{tower}:{scope}/conv{len(widths) - 1}")
         nm = f"{scope}/conv{len(widths)}"
         h = self._layer(h, f"siamese/{nm}", f"{TOWER_PREFIX[tower]}/{nm}/bn", training, decay,
-                        round_operands=self.bf16_lift and training, act=False)
+                        round_operands=self.bf16_lift and training, act=False, relu_key=f"{tower}:{nm}")   # (act=False: the key only names the rounded input)
         return self._relu(self._max_over(h.reshape(B, N, -1), "pool", scope, tower), f"{tower}:{nm}")
 
     def _backbone(self, *a):

@@ -1022,7 +1022,7 @@ def test_gradients_match_autograd_with_pinned_decisions(gpu_required, case):
     eng.set_option("train_matmul_bf16", bf16)
     res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
     dec = eng.debug_train_decisions(B, relu=True)   # (+ the sign every relu saw: alignnet_debug_train_relu_mask on the fused, hybrid and layer-by-layer paths)
-    round_pin = bool(bf16) and backbone == "pointnet"
+    round_pin = bool(bf16)   # (every bf16 case of PINNED_CASES runs on fused stages)
     if round_pin:
         dec["round"] = eng.debug_train_rounded(B)     # bf16, fused PointNet stages: the operand roundings pinned too (alignnet_debug_train_rounded)
         with pytest.raises(alignnet3d.EngineError):
