@@ -967,6 +967,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
     return 0;
   }
   if (k == "ab_tiles_per_wg") { if (value < 0) return fail(h, "ab_tiles_per_wg must be >= 0"); h->ab_tiles_per_wg = (int)value; return 0; }
+  if (k == "dg_cloud_parts") { if (value < 0 || value > 8) return fail(h, "dg_cloud_parts must be 0 (automatic) .. 8"); h->dg_parts_opt = (int)value; return 0; }
   for (const auto& ak : kAbKeys)
     if (k == ak.key) {
       const unsigned before = h->ab;
@@ -1000,6 +1001,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "comm_order") { *value = h->comm_order; return 0; }
   if (k == "sync_collectives") { *value = h->sync_collectives; return 0; }
   if (k == "ab_tiles_per_wg") { *value = h->ab_tiles_per_wg; return 0; }
+  if (k == "dg_cloud_parts") { *value = h->dg_parts_opt; return 0; }
   if (k == "ab_mask") { *value = h->ab; return 0; }
   for (const auto& ak : kAbKeys) if (k == ak.key) { *value = (h->ab & ak.bit) ? 1 : 0; return 0; }
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }

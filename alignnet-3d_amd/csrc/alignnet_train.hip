@@ -180,6 +180,20 @@ extern "C" void alignnet_train_ws_free(alignnet_handle* h)
   h->train_ws = nullptr;
 }
 
+// dgcnn edge kernels (dg_train_fwd, dg_train_bwd_edge*): workgroups per cloud.  One workgroup per cloud fills the chip from 2B = 256 clouds (the backward:
+// one eight-wave workgroup per CU) / 512 (the forward: two four-wave workgroups per CU); below that a cloud's tiles are dealt to several workgroups
+// whose partial sums meet in the reductions that follow anyway (B = 64, N = 4096: the forward ran on a quarter of the CUs, the backward on half).
+constexpr int kDgMaxParts = 8, kDgPartSlices = 512;   // at most 2B * parts <= 512 workgroups when parts > 1: the per-workgroup partial buffers are carved for max(2B, 512) slices
+static int dg_parts(const alignnet_handle* h, int B, int per_cu)
+{
+  const int ntiles = (h->cfg.num_points + kTT - 1) / kTT, slots = 256 * per_cu;
+  const int cap = std::max(1, std::min(std::min(kDgMaxParts, ntiles), kDgPartSlices / (2 * B)));
+  if (h->dg_parts_opt > 0) return std::min(h->dg_parts_opt, cap);
+  int p = 1;
+  while (p * 2 <= cap && 2 * B * p * 2 <= slots) p *= 2;
+  return p;
+}
+
 static const Stack& conv_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_conv : s == 1 ? h->s2_conv : h->emb_conv; }
 static const Stack& fc_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_fc : s == 1 ? h->s2_fc : h->rem_fc; }
 static float keep_of(const alignnet_handle* h, int s) { return s == 0 ? h->cfg.s1_keep : s == 1 ? h->cfg.s2_keep : h->cfg.rem_keep; }
@@ -370,7 +384,8 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.gram2raw64 = D(2 * (size_t)C[1] * C[1] + 2 * C[1]); S.s264 = S.gram2raw64 ? S.gram2raw64 + 2 * (size_t)C[1] * C[1] : nullptr;
       S.g1f64 = D(2 * (size_t)C[0] * C[0] + 2 * C[0]); S.s1e64 = S.g1f64 ? S.g1f64 + 2 * (size_t)C[0] * C[0] : nullptr;
       S.gs = F(B2 * C[2]); S.E3 = F(2 * C[2]); S.kdb3 = F(2 * C[2]); S.Sp = F(2 * (size_t)C[1] * C[2]); S.GW = F(2 * (size_t)C[1] * C[2]);
-      S.u2_part = F(B2 * (size_t)C[0] * C[1]); S.g1_part = F(B2 * (size_t)C[0] * C[0]); S.p_part = F(B2 * 6 * C[0]);
+      const size_t dgs = h->cfg.backbone == 1 ? std::max(B2, (size_t)kDgPartSlices) : B2;   // dgcnn: one partial per WORKGROUP of the edge kernels (dg_parts)
+      S.u2_part = F(dgs * (size_t)C[0] * C[1]); S.g1_part = F(dgs * (size_t)C[0] * C[0]); S.p_part = F(B2 * 6 * C[0]);
       S.u2 = F(2 * (size_t)C[0] * C[1]); S.g1 = F(2 * (size_t)C[0] * C[0]); S.s1 = F(2 * C[0]); S.m1 = F(2 * C[0]);
       S.E2 = F(2 * C[1]); S.kdb2 = F(2 * C[1]); S.k2 = F(2 * C[1]); S.GW2 = F(2 * (size_t)C[0] * C[1]);
       if (hyb && pass) {   // the fused tail reads the statistics of the layers in front of it where the fused stages keep theirs
@@ -403,8 +418,9 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
-    w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(B2 * 4 * 7 * maxC1);
-    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(B2 * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
+    const size_t dgs = h->cfg.backbone == 1 ? std::max(B2, (size_t)kDgPartSlices) : B2;
+    w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(dgs * 4 * 7 * maxC1);
+    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(dgs * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1);
     w->W3E = F(2 * (size_t)maxC2 * maxC3);
     w->W3T = F((size_t)maxC2 * maxC3); w->Q3 = F(2 * (size_t)maxC2 * maxC2); w->q3b = F(2 * maxC2);
@@ -925,6 +941,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     d.w1 = a.w1; d.b1 = a.b1; d.wp2 = a.wp2; d.b2 = a.b2; d.sc1 = a.sc1; d.sh1 = a.sh1; d.sc2 = a.sc2; d.sh2 = a.sh2;
     d.mom = S.mom; d.stat_part = w->stat_part; d.p_store = S.h2; d.argk = S.argk; d.colsum_part = w->colsum_part; d.s1_part = w->s1_part; d.g1_part = S.g1_part;
     d.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr;
+    d.parts = dg_parts(h, B, 2);
     const int nG1 = ((C1 + 31) / 32) * ((C1 + 31) / 32 + 1) / 2;   // upper 32 x 32 blocks of Gram(h1), one fp64 slab [16][64] each behind the tiles
     const size_t dlds = (h->train_bf16 ? (size_t)2 * kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * sizeof(unsigned short)
                                        : ((size_t)2 * kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float))   // two edge-feature buffers | two lift buffers
@@ -936,10 +953,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     d.dbg = a.dbg;
     if (d.stamps) hipMemsetAsync(d.stamps + 8, 0, 3 * sizeof(long long), h->stream);
   { ProfScope prof_scope(h, PK_DG_FWD, true);
-    if (h->train_bf16 && C1 == 64) TIMED_LAUNCH((dg_train_fwd<64, true>), dim3(2 * B), dim3(kTW * 64), dlds, d);
-    else if (h->train_bf16) TIMED_LAUNCH((dg_train_fwd<32, true>), dim3(2 * B), dim3(kTW * 64), dlds, d);
-    else if (C1 == 64) TIMED_LAUNCH(dg_train_fwd<64>, dim3(2 * B), dim3(kTW * 64), dlds, d);
-    else TIMED_LAUNCH(dg_train_fwd<32>, dim3(2 * B), dim3(kTW * 64), dlds, d);
+    if (h->train_bf16 && C1 == 64) TIMED_LAUNCH((dg_train_fwd<64, true>), dim3(2 * B * d.parts), dim3(kTW * 64), dlds, d);
+    else if (h->train_bf16) TIMED_LAUNCH((dg_train_fwd<32, true>), dim3(2 * B * d.parts), dim3(kTW * 64), dlds, d);
+    else if (C1 == 64) TIMED_LAUNCH(dg_train_fwd<64>, dim3(2 * B * d.parts), dim3(kTW * 64), dlds, d);
+    else TIMED_LAUNCH(dg_train_fwd<32>, dim3(2 * B * d.parts), dim3(kTW * 64), dlds, d);
   }
     if (d.stamps) {
       long long sv[11];
@@ -952,7 +969,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     {   // statistics of z2 from s1 = sum h1 and G1 = sum h1^T h1 over the edge rows (both kept for the backward)
       const int sGe = 1024 / C1;   // row groups of dg_train_fwd's column sums
-      ReduceJob jg = rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * sGe, (long)(C1), S.s1e);
+      ReduceJob jg = rjob(S.g1_part, B * d.parts, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * d.parts * sGe, (long)(C1), S.s1e);   // (one slice per workgroup)
       jg.out64 = S.g1f64; js.out64 = S.s1e64;
       launch_reduce_multi(h, 2, jg, js);
       if (sync && sync_gram(S.g1f64, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1)) return 1;
@@ -1404,8 +1421,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !(h->ab & AB_PHASE2_LEGACY);   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
   bool u2_prescaled = false;
+  int u2_slices = B;   // per-workgroup partials of U2 per tower (dgcnn: B x workgroups per cloud, set where the edge pass is launched)
   auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
-    def_reduce(h, w, rjob(S.u2_part, B, (long)(C1 * C2), S.u2));
+    def_reduce(h, w, rjob(S.u2_part, u2_slices, (long)(C1 * C2), S.u2));
     if (fwd_gram || dg) def_reduce(h, w, rjob(S.g1f, 1, (long)(C1 * C1), S.g1));
     else {
       def_reduce(h, w, rjob(S.g1_part, B, (long)(C1 * C1), S.g1));
@@ -1489,7 +1507,9 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     e.q2imgh = w->b1imgh; e.q2imgh_stride = (long)kQ2hMax;
     e.dyp = w->dy2; e.argk = S.argk; e.u2_part = S.u2_part; e.g1_part = nullptr; e.pdy_part = w->pdy_part;   // Gram(h1): the forward's
     e.stamps = (b2.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) : nullptr;
-    const dim3 eg(2 * B), eb(kBEW * 64);
+    e.parts = dg_parts(h, B, 1);
+    u2_slices = B * e.parts;
+    const dim3 eg(2 * B * e.parts), eb(kBEW * 64);
     const size_t el = dg_bwd_edge_lds(C1, C2, dg_bf16);
     const bool dense = dg_bf16 && !(h->ab & AB_DG_SPARSE);   // bf16 mode: both dy2_s products as dense bf16 MFMAs on per-slot tiles
     e.k2 = S.k2; e.w2th = w->w2th[s];
@@ -1522,7 +1542,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     }
     layer2_weight_grad();
     DgB0Args z;
-    z.pdy_part = w->pdy_part; z.slices = 4; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.pdy_part = w->pdy_part; z.slices = 4 * e.parts; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);   // ([cloud][part][4] partials: 4 parts contiguous slices per cloud)
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N * kDgK; z.count = Me;
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;

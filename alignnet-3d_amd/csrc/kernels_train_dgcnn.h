@@ -48,6 +48,10 @@ struct DgTrainArgs {
   double* s1_part;                // [2B][1024 / C1][C1]  column sums of h1 over all (point, slot) rows, per row group
   long long* stamps;              // debug (ALIGNNET_DBG & 32): cycle stamps of thread 0 / block 0, iteration 25
   int dbg = 0;                    // ablation (timing only): bit 0 = no Gram(h1) MFMAs in dg_train_fwd
+  // parts > 1: a cloud's tiles are dealt to `parts` workgroups (grid 2B * parts, workgroup = cloud * parts + part, tiles [part nt / parts, (part + 1) nt / parts)):
+  // one workgroup per cloud leaves three quarters of the chip idle at 128 clouds (B = 64).  Everything a workgroup hands on is a per-workgroup PARTIAL
+  // (g1_part, s1_part: indexed by the workgroup, reduced over B * parts slices) or per point (p_store, argk), so nothing else changes.
+  int parts = 1;
 };
 #define FE_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const long long t_begin = ALN_STAMPS(a.stamps) ? (long long)__builtin_readcyclecounter() : 0;   // (debug: whole-kernel cycles per workgroup)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   float* const xbuf = smem + 2 * kTT * 8;   // behind the two edge-feature buffers
   unsigned short* hbuf = reinterpret_cast<unsigned short*>(xbuf);
   const int CT2 = (a.C2 + 31) >> 5;
-  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int it0 = (part * ntiles / a.parts) * a.k, total = ((part + 1) * ntiles / a.parts) * a.k;   // this workgroup's (tile, slot) range [it0, total); it0 is even (k = 20)
   const int ct = wave, col = ct * 32 + (lane & 31);
   const bool mine = ct < CT2, live = mine && col < a.C2;
   // max_k relu(g zhat + b) = relu(g zhat* + b) with zhat* the extreme of sign(g) z over the slots: the sign of gamma2 is known
@@ -368,19 +373,19 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   if (tid < kTT) {
     smem[tid * 8 + 6] = 0.f; smem[tid * 8 + 7] = 0.f;   // k padding of the MFMA lift in both buffers: never written again
     smem[kTT * 8 + tid * 8 + 6] = 0.f; smem[kTT * 8 + tid * 8 + 7] = 0.f;
-    dgt_points(pc, a.N, a.k, 0, tid, dgt_index(nnc, a.N, a.k, 0, tid), v);
-    dg_edge_to_lds(xf, v, es_of(0) + tid * 8);
-    if (total > 1) {
-      dgt_points(pc, a.N, a.k, 1, tid, dgt_index(nnc, a.N, a.k, 1, tid), v);
-      dg_edge_to_lds(xf, v, es_of(1) + tid * 8);
+    dgt_points(pc, a.N, a.k, it0, tid, dgt_index(nnc, a.N, a.k, it0, tid), v);
+    dg_edge_to_lds(xf, v, es_of(it0) + tid * 8);
+    if (total > it0 + 1) {
+      dgt_points(pc, a.N, a.k, it0 + 1, tid, dgt_index(nnc, a.N, a.k, it0 + 1, tid), v);
+      dg_edge_to_lds(xf, v, es_of(it0 + 1) + tid * 8);
     }
-    if (total > 2) dgt_points(pc, a.N, a.k, 2, tid, dgt_index(nnc, a.N, a.k, 2, tid), v);
-    if (total > 3) jnext = dgt_index(nnc, a.N, a.k, 3, tid);
+    if (total > it0 + 2) dgt_points(pc, a.N, a.k, it0 + 2, tid, dgt_index(nnc, a.N, a.k, it0 + 2, tid), v);
+    if (total > it0 + 3) jnext = dgt_index(nnc, a.N, a.k, it0 + 3, tid);
   }
   __syncthreads();
-  lift_slot(0);
+  lift_slot(it0);
   __syncthreads();
-  for (int it = 0; it < total; ++it) {
+  for (int it = it0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
     FE_STAMP(0);
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     const float zero[16] = {};
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[r] = (float)(gsum[r * 64] + (double)gacc[r]);   // (gacc is zero unless the ablation switch skipped the folds)
-    tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
+    tile_commit(a.g1_part + (size_t)vcloud * C1 * C1, C1, git, gjt, C1, C1, gacc, lane, zero);
   }
   if (ALN_STAMPS(a.stamps) && tid == 0) {   // stamps 8 / 9 / 10: longest and (2^40 - shortest) workgroup, workgroup 0 -- zeroed by the host
     const long long d = (long long)__builtin_readcyclecounter() - t_begin;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
     constexpr int kQ = C1 / 4, kQG = (kTW * 64) / kQ;
     const int cq = tid % kQ, g = tid / kQ;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a.s1_part[((size_t)cloud * kQG + g) * C1 + cq * 4 + e] = s1q[e];
+    for (int e = 0; e < 4; ++e) a.s1_part[((size_t)vcloud * kQG + g) * C1 + cq * 4 + e] = s1q[e];
   }
 }
 
@@ -591,6 +596,7 @@ struct DgBwdArgs {
   float* u2_part; float* g1_part;      // [2B][C1*C2], [2B][C1*C1] (upper blocks)
   double* pdy_part;                    // [2B][4 = 2 row groups x 2 halves][7][C1]: sum e_d dy1 (d < 6), sum dy1
   long long* stamps;                   // debug: cycle stamps of thread 0 / block 0 at the phase boundaries of iteration 25
+  int parts = 1;                       // as DgTrainArgs::parts: u2_part / pdy_part are per-workgroup partials ([2B * parts] slices)
 };
 #define BE_STAMP(i) do { if (ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && it == 25) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // stamps 10..15: the tile-start block of iteration 40; stamp 16: iteration 45 (20 iterations = one tile after stamp 0)
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
@@ -633,7 +639,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   constexpr int ldh = C1 + 8, KG16 = C1 / 16;
   unsigned short* Xh = reinterpret_cast<unsigned short*>(SOc + C2 * 24);   // bf16 mode: h1 [64][C1 + 8]  (all sizes above are multiples of 16 bytes)
   constexpr int CT1 = (C1 + 31) >> 5, KGq = (C1 + 7) >> 3;
-  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int it0 = (part * ntiles / a.parts) * a.k, total = ((part + 1) * ntiles / a.parts) * a.k;   // this workgroup's (tile, slot) range; it0 is even (k = 20)
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
@@ -687,10 +694,10 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   float v[6];
   int jnext = 0;
   if (tid < kTT) {
-    dgt_gather(pc, nnc, a.N, a.k, min(tid, a.N - 1), 0, v);
-    if (total > 1) jnext = dgt_index(nnc, a.N, a.k, 1, tid);
+    dgt_points(pc, a.N, a.k, it0, tid, dgt_index(nnc, a.N, a.k, it0, tid), v);
+    if (total > it0 + 1) jnext = dgt_index(nnc, a.N, a.k, it0 + 1, tid);
   }
-  for (int it = 0; it < total; ++it) {
+  for (int it = it0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool more = it + 1 < total;
@@ -908,12 +915,12 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge(const DgBwdArgs a
   }
   if (p2on) {
 #pragma unroll
-    for (int i = 0; i < kP2W; ++i) a.u2_part[((size_t)cloud * C1 + p2j * kP2W + i) * C2 + p2c] = u2[i];
+    for (int i = 0; i < kP2W; ++i) a.u2_part[((size_t)vcloud * C1 + p2j * kP2W + i) * C2 + p2c] = u2[i];
   }
   if (wave < nitems) {
     const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
     if (col < C1) {
-      double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + half) * 7 * C1 + col;
+      double* dst = a.pdy_part + ((size_t)vcloud * 4 + rg * 2 + half) * 7 * C1 + col;
 #pragma unroll
       for (int d = 0; d < 7; ++d) {
         const int q = d - 4 * half;   // this half-wave holds d = 4 half .. 4 half + 3 (d = 7 does not exist); the rest of the slice is zero
@@ -969,7 +976,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int* nnc = a.nn + (size_t)cloud * a.N * a.k;
@@ -983,7 +990,8 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
   unsigned short* PlT = PhT + C2 * ldT;
   unsigned char* AK = reinterpret_cast<unsigned char*>(PlT + C2 * ldT);   // [64][ldak]
   unsigned char* AKT = AK + kTT * ldak;                                    // [C2][ldT]
-  const int ntiles = (a.N + kTT - 1) / kTT, total = ntiles * a.k;
+  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int it0 = (part * ntiles / a.parts) * a.k, total = ((part + 1) * ntiles / a.parts) * a.k;   // this workgroup's (tile, slot) range; it0 is even (k = 20)
   const float* sc1 = a.sc1 + tower * C1;
   const float* sh1 = a.sh1 + tower * C1;
   const DgtLiftM<C1, kBEW> lw = dgt_liftm_load<C1, kBEW>(a.w1, sc1, sh1, wave, lane);
@@ -1029,17 +1037,17 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
   float v[6];
   int jnext = 0;   // neighbour index of slot it + 3 at the top of iteration it: one step ahead of the point loads that need it
   if (tid < kTT) {
-    dgt_points(pc, a.N, a.k, 0, tid, dgt_index(nnc, a.N, a.k, 0, tid), v);
+    dgt_points(pc, a.N, a.k, it0, tid, dgt_index(nnc, a.N, a.k, it0, tid), v);
     dg_edge_to_lds(xf, v, smem + tid * 8);
-    if (total > 1) dgt_points(pc, a.N, a.k, 1, tid, dgt_index(nnc, a.N, a.k, 1, tid), v);
-    if (total > 2) jnext = dgt_index(nnc, a.N, a.k, 2, tid);
+    if (total > it0 + 1) dgt_points(pc, a.N, a.k, it0 + 1, tid, dgt_index(nnc, a.N, a.k, it0 + 1, tid), v);
+    if (total > it0 + 2) jnext = dgt_index(nnc, a.N, a.k, it0 + 2, tid);
   }
   __syncthreads();
-  for (int it = 0; it < total; ++it) {
+  for (int it = it0; it < total; ++it) {
     const int tile = it / a.k, slot = it - tile * a.k;
     const int nvalid = min(kTT, a.N - tile * kTT);
     const bool more = it + 1 < total;
-    float* es = smem + (it % 3) * kTT * 8;
+    float* es = smem + ((it - it0) % 3) * kTT * 8;   // (the three edge-feature buffers rotate from this workgroup's first slot)
     unsigned short* Xh = Xb + (it & 1) * kXbuf;
     unsigned short* XhT = Xh + kTT * ldh;
     if (slot == 0) {
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
     unsigned short hv[NCT][4];
     dgt_liftm_bf16_keep<C1, kBEW>(lw, es, Xh, ldh, XhT, ldT, nvalid, wave, lane, hv);   // (this h1 buffer's readers, two slots back, are behind the last barrier)
     if (more && tid < kTT) {
-      dg_edge_to_lds(xf, v, smem + ((it + 1) % 3) * kTT * 8 + tid * 8);
+      dg_edge_to_lds(xf, v, smem + ((it + 1 - it0) % 3) * kTT * 8 + tid * 8);
       if (it + 2 < total) dgt_points(pc, a.N, a.k, it + 2, tid, jnext, v);
       if (it + 3 < total) jnext = dgt_index(nnc, a.N, a.k, it + 3, tid);
     }
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
         float other[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) other[r] = red[((jt2 * CT1 + it2) * 16 + r) * 64 + lane];
-        tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, it2, jt2, C1, C2, uacc[it2], lane, other);
+        tile_commit(a.u2_part + (size_t)vcloud * C1 * C2, C2, it2, jt2, C1, C2, uacc[it2], lane, other);
       }
     }
   }
@@ -1193,7 +1201,7 @@ __global__ __launch_bounds__(kBEW * 64) void dg_train_bwd_edge_dense(const DgBwd
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int d = 4 * g4 + q;
-        if (d < 7) a.pdy_part[(((size_t)cloud * 4 + rg) * 7 + d) * C1 + col] = pd[j2][q];
+        if (d < 7) a.pdy_part[(((size_t)vcloud * 4 + rg) * 7 + d) * C1 + col] = pd[j2][q];
       }
     }
   }

@@ -361,7 +361,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  * "ab_*" (0/1, default 0): A/B dispatch overrides -- each selects an earlier kernel variant of the SAME arithmetic for same-box comparisons
  *   (results agree up to summation order; tests/test_train_gpu.py runs them against the default): "ab_no_ld_const", "ab_infer_tile64",
  *   "ab_phase2_legacy", "ab_b1_legacy", "ab_b1_fp32", "ab_p3_bf16_generic", "ab_p3_nogram", "ab_no_defer", "ab_dg_sparse",
- *   "ab_no_glue_fold", "ab_gemm_jobs_ksplit", "ab_fc_direct", "ab_fc_no_splitk", "ab_split_tilewise" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic).
+ *   "ab_no_glue_fold", "ab_gemm_jobs_ksplit", "ab_fc_direct", "ab_fc_no_splitk", "ab_split_tilewise" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic);
+ *   "dg_cloud_parts" (dgcnn training: workgroups per cloud of the edge kernels, 0 = as many as fill the chip at this batch, 1 .. 8 = fixed; results agree up to the grouping of partial sums).
  *   "ab_mask" (read-only) = the bits that are set; bench.py prints it.  The library reads NO environment variable; result-changing
  *   ablation switches exist only in the separate ablation build (csrc/ablate.h, `make ablate`).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped
