@@ -968,6 +968,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
   }
   if (k == "ab_tiles_per_wg") { if (value < 0) return fail(h, "ab_tiles_per_wg must be >= 0"); h->ab_tiles_per_wg = (int)value; return 0; }
   if (k == "dg_cloud_parts") { if (value < 0 || value > 8) return fail(h, "dg_cloud_parts must be 0 (automatic) .. 8"); h->dg_parts_opt = (int)value; return 0; }
+  if (k == "pn_cloud_parts") { if (value < 0 || value > 8) return fail(h, "pn_cloud_parts must be 0 (automatic) .. 8"); h->pn_parts_opt = (int)value; return 0; }
   for (const auto& ak : kAbKeys)
     if (k == ak.key) {
       const unsigned before = h->ab;
@@ -1002,6 +1003,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "sync_collectives") { *value = h->sync_collectives; return 0; }
   if (k == "ab_tiles_per_wg") { *value = h->ab_tiles_per_wg; return 0; }
   if (k == "dg_cloud_parts") { *value = h->dg_parts_opt; return 0; }
+  if (k == "pn_cloud_parts") { *value = h->pn_parts_opt; return 0; }
   if (k == "ab_mask") { *value = h->ab; return 0; }
   for (const auto& ak : kAbKeys) if (k == ak.key) { *value = (h->ab & ak.bit) ? 1 : 0; return 0; }
   if (k == "comm_buckets") { *value = h->comm_buckets; return 0; }

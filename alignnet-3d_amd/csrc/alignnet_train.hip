@@ -194,6 +194,19 @@ static int dg_parts(const alignnet_handle* h, int B, int per_cu)
   return p;
 }
 
+// PointNet per-cloud kernels that only leave SUMS behind (phase 2 / the first-layer Gram, passes B2 and B1): the same split.  They run two four-wave
+// workgroups per CU, so 2B = 512 clouds fill the chip; the reference's shipped configs (batch 128 x 512 points) bring 256.  Phase 3 keeps one workgroup
+// per cloud (its per-cloud maxima and Gram would need a merge step).
+static int pn_parts(const alignnet_handle* h, int B)
+{
+  const int ntiles = (h->cfg.num_points + kTT - 1) / kTT;
+  const int cap = std::max(1, std::min(std::min(kDgMaxParts, ntiles), kDgPartSlices / (2 * B)));
+  if (h->pn_parts_opt > 0) return std::min(h->pn_parts_opt, cap);
+  int p = 1;
+  while (p * 2 <= cap && 2 * B * p * 2 <= 512) p *= 2;
+  return p;
+}
+
 static const Stack& conv_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_conv : s == 1 ? h->s2_conv : h->emb_conv; }
 static const Stack& fc_of(const alignnet_handle* h, int s) { return s == 0 ? h->s1_fc : s == 1 ? h->s2_fc : h->rem_fc; }
 static float keep_of(const alignnet_handle* h, int s) { return s == 0 ? h->cfg.s1_keep : s == 1 ? h->cfg.s2_keep : h->cfg.rem_keep; }
@@ -384,7 +397,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       S.gram2raw64 = D(2 * (size_t)C[1] * C[1] + 2 * C[1]); S.s264 = S.gram2raw64 ? S.gram2raw64 + 2 * (size_t)C[1] * C[1] : nullptr;
       S.g1f64 = D(2 * (size_t)C[0] * C[0] + 2 * C[0]); S.s1e64 = S.g1f64 ? S.g1f64 + 2 * (size_t)C[0] * C[0] : nullptr;
       S.gs = F(B2 * C[2]); S.E3 = F(2 * C[2]); S.kdb3 = F(2 * C[2]); S.Sp = F(2 * (size_t)C[1] * C[2]); S.GW = F(2 * (size_t)C[1] * C[2]);
-      const size_t dgs = h->cfg.backbone == 1 ? std::max(B2, (size_t)kDgPartSlices) : B2;   // dgcnn: one partial per WORKGROUP of the edge kernels (dg_parts)
+      const size_t dgs = std::max(B2, (size_t)kDgPartSlices);   // one partial per WORKGROUP of the split per-cloud kernels (dg_parts, pn_parts)
       S.u2_part = F(dgs * (size_t)C[0] * C[1]); S.g1_part = F(dgs * (size_t)C[0] * C[0]); S.p_part = F(B2 * 6 * C[0]);
       S.u2 = F(2 * (size_t)C[0] * C[1]); S.g1 = F(2 * (size_t)C[0] * C[0]); S.s1 = F(2 * C[0]); S.m1 = F(2 * C[0]);
       S.E2 = F(2 * C[1]); S.kdb2 = F(2 * C[1]); S.k2 = F(2 * C[1]); S.GW2 = F(2 * (size_t)C[0] * C[1]);
@@ -416,11 +429,11 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     }
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
-    w->stat_part = D(B2 * 4 * maxC * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
+    const size_t dgs = std::max(B2, (size_t)kDgPartSlices);
+    w->stat_part = D(std::max(B2 * 4 * maxC, dgs * 4 * maxC2) * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
-    const size_t dgs = h->cfg.backbone == 1 ? std::max(B2, (size_t)kDgPartSlices) : B2;
     w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(dgs * 4 * 7 * maxC1);
-    w->dbg2_part = D(B2 * 4 * maxC2 * 2); w->dbg1_part = D(B2 * 4 * maxC1 * 2); w->s1_part = D(dgs * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
+    w->dbg2_part = D(dgs * 4 * maxC2 * 2); w->dbg1_part = D(dgs * 4 * maxC1 * 2); w->s1_part = D(dgs * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
     w->dbg2 = F(4 * maxC2); w->dbg1 = F(4 * maxC1);
     w->W3E = F(2 * (size_t)maxC2 * maxC3);
     w->W3T = F((size_t)maxC2 * maxC3); w->Q3 = F(2 * (size_t)maxC2 * maxC2); w->q3b = F(2 * maxC2);
@@ -1067,12 +1080,14 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     Gram1Args g;
     g.pcs[0] = p1; g.pcs[1] = p2; g.xform = S.xform; g.B = B; g.N = N; g.C1 = C1; g.ld0 = a.ld[0];
     g.w1 = a.w1; g.sc1 = a.sc1; g.sh1 = a.sh1; g.g1_part = S.g1_part; g.s1_part = w->s1_part;
+    const int pp = pn_parts(h, B);
+    g.parts = pp;
     const size_t glds = ((size_t)kTT * 4 + (size_t)kTT * g.ld0) * sizeof(float);
-    if (h->train_bf16) hipLaunchKernelGGL(train_fwd_gram1<true>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
-    else if (C1 == 64) hipLaunchKernelGGL((train_fwd_gram1<false, 64>), dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
-    else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B), dim3(kTW * 64), glds, h->stream, g);
+    if (h->train_bf16) hipLaunchKernelGGL(train_fwd_gram1<true>, dim3(2 * B * pp), dim3(kTW * 64), glds, h->stream, g);
+    else if (C1 == 64) hipLaunchKernelGGL((train_fwd_gram1<false, 64>), dim3(2 * B * pp), dim3(kTW * 64), glds, h->stream, g);
+    else hipLaunchKernelGGL(train_fwd_gram1<false>, dim3(2 * B * pp), dim3(kTW * 64), glds, h->stream, g);
     const int sG1 = std::max(1, 256 / C1);
-    ReduceJob jg = rjob(S.g1_part, B, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * sG1, (long)(C1), S.s1e);
+    ReduceJob jg = rjob(S.g1_part, B * pp, (long)(C1 * C1), S.g1f), js = rjob(w->s1_part, B * pp * sG1, (long)(C1), S.s1e);
     jg.out64 = S.g1f64; js.out64 = S.s1e64;
     launch_reduce_multi(h, 2, jg, js);
     if (sync && sync_gram(S.g1f64, S.g1f, (size_t)2 * C1 * C1, S.s1e, (size_t)2 * C1)) return 1;
@@ -1086,13 +1101,16 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (finish(1, C2, 1, count, 1, true)) return 1;
     }
   } else {
+  const int pp = pn_parts(h, B);
+  a.parts = pp;
   { ProfScope prof_scope(h, PK_TRAIN_PHASE2, true);
-  if (h->train_bf16 && std_w) TIMED_LAUNCH((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
-  else if (h->train_bf16) TIMED_LAUNCH((train_fwd_phase23<2, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
-  else if (std_w) TIMED_LAUNCH((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
-  else TIMED_LAUNCH(train_fwd_phase23<2>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  if (h->train_bf16 && std_w) TIMED_LAUNCH((train_fwd_phase23<2, true, false, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else if (h->train_bf16) TIMED_LAUNCH((train_fwd_phase23<2, true>), dim3(2 * B * pp), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else if (std_w) TIMED_LAUNCH((train_fwd_phase23<2, false, false, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
+  else TIMED_LAUNCH(train_fwd_phase23<2>, dim3(2 * B * pp), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
   }
-  if (finish(1, C2, 4, count)) return 1;
+  if (finish(1, C2, 4 * pp, count)) return 1;
+  a.parts = 1;
   }
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
@@ -1388,20 +1406,22 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
+  const int pp = (given || dg || b2_accum) ? 1 : pn_parts(h, B);   // workgroups per cloud of passes B2 and B1 (their outputs are sums the reductions below fold anyway)
+  b2.parts = pp;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0) +
                         ((std_w && !b2_accum && !h->train_bf16 && !given) ? (size_t)(5 * 64 + 16 + 6 * 128) * sizeof(float) : 0);   // STDF: the LDS parameter tables
   if (b2_lds > 160 * 1024) return fail(h, "training: num_points too large for the B2 hit-list LDS budget");   // (on the final size: the parameter tables count)
   { ProfScope prof_scope(h, PK_TRAIN_B2, true);
-  if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (given && std_w) TIMED_LAUNCH((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (given) TIMED_LAUNCH((train_bwd_b2<false, false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (std_w && !b2_accum && h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (std_w && !b2_accum) TIMED_LAUNCH((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (h->train_bf16 && b2_accum) TIMED_LAUNCH((train_bwd_b2<true, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true>), dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else if (b2_accum) TIMED_LAUNCH(train_bwd_b2<true>, dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
-  else TIMED_LAUNCH(train_bwd_b2<false>, dim3(2 * B), dim3(kTW * 64), b2_lds, b2);
+  if (given_bf16 && std_w) TIMED_LAUNCH((train_bwd_b2<false, true, true, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (given_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, true>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (given && std_w) TIMED_LAUNCH((train_bwd_b2<false, false, true, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (given) TIMED_LAUNCH((train_bwd_b2<false, false, true>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (std_w && !b2_accum && h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true, false, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (std_w && !b2_accum) TIMED_LAUNCH((train_bwd_b2<false, false, false, 64, 128>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (h->train_bf16 && b2_accum) TIMED_LAUNCH((train_bwd_b2<true, true>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (h->train_bf16) TIMED_LAUNCH((train_bwd_b2<false, true>), dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else if (b2_accum) TIMED_LAUNCH(train_bwd_b2<true>, dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
+  else TIMED_LAUNCH(train_bwd_b2<false>, dim3(2 * B * pp), dim3(kTW * 64), b2_lds, b2);
   }
   if (b2.stamps) {
     long long st[11];
@@ -1421,12 +1441,12 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const bool acc_in_b1 = CT1 * CT2 + CT1 * (CT1 + 1) / 2 <= 3 * kTW;   // register-resident blocks in B1 (every shipped config)
   const bool fwd_gram = !dg && !h->train_bf16 && acc_in_b1 && !(h->ab & AB_PHASE2_LEGACY);   // the forward kept s1 and Gram(h1) (backbone_fwd_train)
   bool u2_prescaled = false;
-  int u2_slices = B;   // per-workgroup partials of U2 per tower (dgcnn: B x workgroups per cloud, set where the edge pass is launched)
+  int u2_slices = B * pp;   // per-workgroup partials of U2 per tower (dgcnn: B x workgroups per cloud, set where the edge pass is launched)
   auto layer2_weight_grad = [&]() {   // (deferred: dW2 = U2 diag(k2) - m1 (k db)^T + (Ghat1 W2) diag(E2))
     def_reduce(h, w, rjob(S.u2_part, u2_slices, (long)(C1 * C2), S.u2));
     if (fwd_gram || dg) def_reduce(h, w, rjob(S.g1f, 1, (long)(C1 * C1), S.g1));
     else {
-      def_reduce(h, w, rjob(S.g1_part, B, (long)(C1 * C1), S.g1));
+      def_reduce(h, w, rjob(S.g1_part, B * pp, (long)(C1 * C1), S.g1));
       if (sync) {   // Gram(h1) of all ranks (the forward's, in the other two cases, already is)
         w->defer.sync_after_red.push_back({S.g1, (size_t)2 * C1 * C1});
       }
@@ -1442,7 +1462,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   const int sG = (h->train_bf16 && !b2_accum && !given) ? 8 : std::max(1, 256 / C1);   // row-group slices of B2's column sums of h1 (bf16: the lift's eight)
   {   // totals of (dbeta2, dgamma2) over the clouds + the hidden layer's backward coefficients, and s1 / m1 = s1 / M (qbias needs it before B1): one launch
     PrepHiddenArgs ph;
-    ph.part = w->dbg2_part; ph.S = 2 * B; ph.var = S.var[1]; ph.gamma[0] = P(h, L[1]->p_bn[0][1]); ph.gamma[1] = P(h, L[1]->p_bn[1][1]); ph.C = C2; ph.M = Me;
+    ph.part = w->dbg2_part; ph.S = 2 * B * pp; ph.var = S.var[1]; ph.gamma[0] = P(h, L[1]->p_bn[0][1]); ph.gamma[1] = P(h, L[1]->p_bn[1][1]); ph.C = C2; ph.M = Me;
     for (int t = 0; t < 2; ++t) { ph.dbeta[t] = G(h, w, L[1]->p_bn[t][0]); ph.dgamma[t] = G(h, w, L[1]->p_bn[t][1]); }
     ph.E = S.E2; ph.kdb = S.kdb2; ph.kk = S.k2; ph.rstd = w->rstd2;
     ReduceJobs J{};
@@ -1450,7 +1470,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (sync) {
       // local (dbeta2, dgamma2) -> gradients + totals; s1 of this rank; then both over all ranks; then the coefficients and m1 = s1 / M
       if (dg || fwd_gram) J.j[0] = rjob(S.s1e, 1, (long)(C1), S.s1);   // (already the global sums: the forward all-reduced them)
-      else J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1);
+      else J.j[0] = rjob(w->s1_part, B * pp * sG, (long)(C1), S.s1);
       ph.mode = 1; ph.totals = h->sync_buf;
       hipLaunchKernelGGL(prep_hidden_reduce_kernel, pgrid, dim3(1024), 0, h->stream, ph, J);
       if (sync_sum(h, h->sync_buf, (size_t)2 * C2 * 2, true)) return 1;
@@ -1462,7 +1482,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (dg || fwd_gram) {   // the forward kept the column sums of h1 (DGCNN: over all edge rows)
       J.j[0] = rjob(S.s1e, 1, (long)(C1), S.s1); J.j[1] = rjob(S.s1e, 1, (long)(C1), S.m1, (float)(1.0 / Me));
     } else {
-      J.j[0] = rjob(w->s1_part, B * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * sG, (long)(C1), S.m1, (float)(1.0 / Me));
+      J.j[0] = rjob(w->s1_part, B * pp * sG, (long)(C1), S.s1); J.j[1] = rjob(w->s1_part, B * pp * sG, (long)(C1), S.m1, (float)(1.0 / Me));
     }
     hipLaunchKernelGGL(prep_hidden_reduce_kernel, pgrid, dim3(1024), 0, h->stream, ph, J);
     }
@@ -1564,7 +1584,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b1.u2_part = acc_in_b1 ? S.u2_part : nullptr; b1.g1_part = (acc_in_b1 && !fwd_gram) ? S.g1_part : nullptr;
   // (the legacy train_bwd_b1<64, 128> with compile-time widths unrolls further and spills 67 registers -- the generic one is kept)
   const bool pdy = C1 <= 64 && acc_in_b1 && !(h->ab & AB_B1_LEGACY);   // one dh1 item per wave: no stored dy1, no pass B0
-  b1.pdy_part = w->pdy_part;
+  b1.pdy_part = w->pdy_part; b1.parts = pp;
   const bool b1h = pdy && std_w && h->train_bf16 && !(h->ab & AB_B1_FP32);
   if (b1h) {
     // bf16 pass B1 (kernels_train_bwd.h: train_bwd_b1_bf16); the bf16 images of V2 / Q2 and the bias row came out of the Q2 launch above
@@ -1573,24 +1593,24 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     bh.w1 = P(h, L[0]->p_w); bh.sc1 = S.scale[0]; bh.sh1 = S.shift[0];
     bh.v2imgh = w->b1imgh; bh.q2imgh = w->b1imgh + 2 * kV2h; bh.v2_stride = (long)kV2h; bh.q2_stride = (long)kQ2h; bh.q2b = w->q2b;
     bh.dy2_store = reinterpret_cast<const unsigned short*>(w->dy2);
-    bh.u2_part = b1.u2_part; bh.g1_part = b1.g1_part; bh.pdy_part = w->pdy_part;
+    bh.u2_part = b1.u2_part; bh.g1_part = b1.g1_part; bh.pdy_part = w->pdy_part; bh.parts = pp;
     const size_t ldsh = (size_t)kTT * 4 * sizeof(float) + ((size_t)kTT * 72 * 2 + (size_t)kTT * 136 + (size_t)128 * 72) * sizeof(unsigned short) +
                         (size_t)(2 * 8 + 2 * 4) * 64 * 16;   // + the bf16 operand images of V2 and Q2 (kernels_train_bwd.h: Vl, Ql)
     ProfScope prof_scope(h, PK_TRAIN_B1, true);
-    TIMED_LAUNCH(train_bwd_b1_bf16, dim3(2 * B), dim3(kTW * 64), ldsh, bh);
+    TIMED_LAUNCH(train_bwd_b1_bf16, dim3(2 * B * pp), dim3(kTW * 64), ldsh, bh);
   } else
   { ProfScope prof_scope(h, PK_TRAIN_B1, true);
-  if (pdy && std_w) TIMED_LAUNCH((train_bwd_b1<64, 128, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
-  else if (pdy) TIMED_LAUNCH((train_bwd_b1<0, 0, true>), dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
-  else TIMED_LAUNCH(train_bwd_b1<>, dim3(2 * B), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
+  if (pdy && std_w) TIMED_LAUNCH((train_bwd_b1<64, 128, true>), dim3(2 * B * pp), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
+  else if (pdy) TIMED_LAUNCH((train_bwd_b1<0, 0, true>), dim3(2 * B * pp), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
+  else TIMED_LAUNCH(train_bwd_b1<>, dim3(2 * B * pp), dim3(kTW * 64), lds_train(b1.ld0, b1.ldb), b1);
   }
   if (acc_in_b1) layer2_weight_grad();
   if (pdy) {
     // first layer from the reduced quantities (kernels_train_dgcnn.h, D = 3)
     DgB0Args z;
-    z.pdy_part = w->pdy_part; z.slices = 4; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
+    z.pdy_part = w->pdy_part; z.slices = 4 * pp; z.mom = S.mom; z.w1 = P(h, L[0]->p_w); z.b1 = P(h, L[0]->p_b);
     z.mean1 = S.mean[0]; z.rstd1 = S.rstd[0]; z.k1 = S.kk[0]; z.B = B; z.C1 = C1; z.rows = N; z.count = M;
-    if (b1h) z.slices = 1;   // train_bwd_b1_bf16 reduces the four partials itself
+    if (b1h) z.slices = pp;   // train_bwd_b1_bf16 reduces the four partials itself
     for (int t = 0; t < 2; ++t) { z.dbeta[t] = G(h, w, L[0]->p_bn[t][0]); z.dgamma[t] = G(h, w, L[0]->p_bn[t][1]); }
     z.dbg1 = w->dbg1; z.p_part = S.p_part; z.gx = S.gx; z.grot = S.grot;
     set_glue(z);
@@ -1601,7 +1621,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
     HIP_TRY(h, hipGetLastError());
     return 0;
   }
-  launch_reduce<double>(h, w->dbg1_part, 4 * B, (long)(C1 * 2), w->dbg1);
+  launch_reduce<double>(h, w->dbg1_part, 4 * B * pp, (long)(C1 * 2), w->dbg1);
   hipLaunchKernelGGL(prep_hidden_kernel, dim3((C1 + 127) / 128, 2), dim3(128), 0, h->stream, w->dbg1, S.var[0], P(h, L[0]->p_bn[0][1]),
                      P(h, L[0]->p_bn[1][1]), C1, M, G(h, w, L[0]->p_bn[0][0]), G(h, w, L[0]->p_bn[1][0]), G(h, w, L[0]->p_bn[0][1]),
                      G(h, w, L[0]->p_bn[1][1]), (float*)nullptr, (float*)nullptr, w->k1, w->rstd1);

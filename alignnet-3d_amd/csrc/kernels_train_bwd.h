@@ -43,6 +43,8 @@ struct BwdB2Args {
   const unsigned short* w3th;   // bf16 [C3][C2]: round(W3)^T, rows gathered by the sparse part of the shipped-width bf16 instantiation
   float* dy2_store;             // [2B*N][C2]
   double* dbg2_part;            // [2B][2 halves][C2][2]  (dbeta2, dgamma2)
+  int parts = 1;                // > 1 (never with ACCUM): a cloud's tiles are dealt to `parts` workgroups (grid 2B * parts, workgroup = cloud * parts + part); dbg2_part / s1_part are per-WORKGROUP
+                                // partials then ([2B * parts] slices) -- one workgroup per cloud leaves the chip half empty below 2B = 512 clouds (the reference's shipped batch: 128)
   float* u2_part;               // [2B][C1*C2]
   float* g1_part;               // [2B][C1*C1]
   double* s1_part;              // [2B][G = 256 / C1 row groups][C1]
@@ -68,12 +70,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const int kC1 = C1T ? C1T : a.C1, kC2 = C2T ? C2T : a.C2;
   const int ld0 = C1T ? C1T + 4 : a.ld0, ldb = (C1T && C2T) ? (C1T > C2T ? C1T : C2T) + 4 : a.ldb;
   const int ntiles = (a.N + kTT - 1) / kTT;
+  const int tile0 = part * ntiles / a.parts, tile_end = (part + 1) * ntiles / a.parts;   // this workgroup's tiles (the hit lists below are built for the whole cloud: absolute tile indices)
   // SPM (the shipped widths in bf16 mode): the sparse rows of dh2 -- one non-zero of dy3 per (cloud, channel), at the arg-extreme row --
   // as a small dense product on the matrix pipe instead of a read-modify-write scatter on the VALU:
   //     dh2_sparse[64 rows, :] = S [64 x hits] . R [hits x C2],   S[row_j, j] = k3 g0 of hit j,   R[j, :] = round(W3)^T[c_j, :]
@@ -298,10 +301,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     pc_sc = a.sc2[tower * kC2 + col]; pc_sh = a.sh2[tower * kC2 + col]; pc_qb = a.q3b[tower * kC2 + col];
     pc_bias = a.b2[col]; pc_mu = a.mean2[tower * kC2 + col]; pc_rs = a.rstd2[tower * kC2 + col];
   }
-  TilePoint nextp = GIVEN ? TilePoint{0.f, 0.f, 0.f} : tile_point_request(pc, a.N, 0, tid);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  TilePoint nextp = GIVEN ? TilePoint{0.f, 0.f, 0.f} : tile_point_request(pc, a.N, tile0, tid);
+  for (int tile = tile0; tile < tile_end; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
-    const bool first = tile == 0;
+    const bool first = tile == tile0;
     __syncthreads();
     B2_STAMP(0);
     const int sp_h0 = SPM ? hoff[tile] : 0, sp_h1 = SPM ? hoff[tile + 1] : 0;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       }
     } else {
     tile_point_store(nextp, (SPM || STDF) ? l1par + 320 : xf, xs, tid);
-    if (tile + 1 < ntiles) nextp = tile_point_request(pc, a.N, tile + 1, tid);   // in flight for the whole of this tile
+    if (tile + 1 < tile_end) nextp = tile_point_request(pc, a.N, tile + 1, tid);   // in flight for the whole of this tile
     if constexpr (SPM) {   // the hidden layer's four weight fragments: requested here, in flight under the barrier and the lift
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) w2f[kg] = reinterpret_cast<const bf16x8*>(a.wp2h)[((size_t)ct * 4 + kg) * 64 + lane];
@@ -633,16 +636,16 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     B2_STAMP(10);
   }
   if (ct < CT2 && live) {
-    double* d = a.dbg2_part + (((size_t)cloud * 2 + half) * kC2 + col) * 2;   // slice (half)
+    double* d = a.dbg2_part + (((size_t)vcloud * 2 + half) * kC2 + col) * 2;   // slice (half)
     d[0] = db; d[1] = dg;
   }
   if (!GIVEN && BF16 && !ACCUM && a.s1_part) {   // [cloud][8 row groups][C1]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = (tid & 31) + 32 * j;
-      if (c < kC1) a.s1_part[((size_t)cloud * 8 + (tid >> 5)) * kC1 + c] = s1v[j];
+      if (c < kC1) a.s1_part[((size_t)vcloud * 8 + (tid >> 5)) * kC1 + c] = s1v[j];
     }
-  } else if (!GIVEN && a.s1_part && tid < sG * kC1) a.s1_part[(size_t)cloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
+  } else if (!GIVEN && a.s1_part && tid < sG * kC1) a.s1_part[(size_t)vcloud * sG * kC1 + tid] = s1c;   // [cloud][group][C1]
 }
 
 // ---------------------------------------------------------------------------------
@@ -661,6 +664,7 @@ struct BwdB1Args {
   float* u2_part; float* g1_part;                    // [2B][C1*C2], [2B][C1*C1] (upper blocks) or null: accumulated in B2
   int dy2_bf16;                                      // dy2_store holds bf16 (train_matmul_bf16)
   double* pdy_part;                                  // PDY variant: [2B][4 = 2 row groups x 2 halves][4][C1]: sum x'_d dy1 (d < 3), sum dy1
+  int parts = 1;                                     // as BwdB2Args::parts: dbg1_part / u2_part / g1_part / pdy_part are per-workgroup partials
 };
 
 // PDY (C1 <= 64, one item per wave): dy1 is not stored and dbeta1 / dgamma1 are not reduced here.  The first layer is linear in
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   const int ld0 = C1T ? C1T + 4 : a.ld0, ldb = C2T ? C2T + 4 : a.ldb;
   float* Y = X + kTT * ld0;             // dy2  [64][ldb]
   const int CT1 = (kC1 + 31) >> 5, KGv = (kC2 + 7) >> 3, KGq = (kC1 + 7) >> 3;
-  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int nt_all = (a.N + kTT - 1) / kTT, tile0 = part * nt_all / a.parts, ntiles = (part + 1) * nt_all / a.parts;   // this workgroup's tiles [tile0, ntiles)
   const f32x4* v2img = reinterpret_cast<const f32x4*>(a.v2img + tower * a.v2img_stride);
   const f32x4* q2img = reinterpret_cast<const f32x4*>(a.q2img + tower * a.q2img_stride);
   // items: (column tile ct, 32-row group rg)
@@ -707,10 +711,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
   }
   const XForm XF = xform_load(xf);                        // the cloud's frame in scalar registers; the tile's points one tile ahead
-  TilePoint npt = tile_point_request(pc, a.N, 0, tid);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  TilePoint npt = tile_point_request(pc, a.N, tile0, tid);
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
-    const bool first = tile == 0;
+    const bool first = tile == tile0;
     __syncthreads();
     if constexpr (C2T != 0) {
       if (!a.dy2_bf16) {
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
         for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
         continue;
       }
-      double* dslice = a.dbg1_part + (((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * kC1 + (live ? col : 0)) * 2;   // slice (rg, half)
+      double* dslice = a.dbg1_part + (((size_t)vcloud * 4 + rg * 2 + (lane >> 5)) * kC1 + (live ? col : 0)) * 2;   // slice (rg, half)
       const double o0 = (first || !live) ? 0.0 : dslice[0], o1 = (first || !live) ? 0.0 : dslice[1];
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
   if (PDY && wave < nitems) {
     const int ct = wave >> 1, rg = wave & 1, col = ct * 32 + (lane & 31);
     if (col < kC1) {
-      double* dst = a.pdy_part + ((size_t)cloud * 4 + rg * 2 + (lane >> 5)) * 4 * kC1 + col;
+      double* dst = a.pdy_part + ((size_t)vcloud * 4 + rg * 2 + (lane >> 5)) * 4 * kC1 + col;
 #pragma unroll
       for (int d = 0; d < 4; ++d) dst[(size_t)d * kC1] = pd[d];   // the upper half-wave's slice is zero
     }
@@ -853,11 +857,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1(const BwdB1Args a)
     if (item < nblk) {
       const float zero[16] = {};
       if (item < nblk_u) {
-        tile_commit(a.u2_part + (size_t)cloud * kC1 * kC2, kC2, item / CT2, item % CT2, kC1, kC2, gacc[q], lane, zero);
+        tile_commit(a.u2_part + (size_t)vcloud * kC1 * kC2, kC2, item / CT2, item % CT2, kC1, kC2, gacc[q], lane, zero);
       } else {
         int rem = item - nblk_u, it = 0;
         while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
-        tile_commit(a.g1_part + (size_t)cloud * kC1 * kC1, kC1, it, it + rem, kC1, kC1, gacc[q], lane, zero);
+        tile_commit(a.g1_part + (size_t)vcloud * kC1 * kC1, kC1, it, it + rem, kC1, kC1, gacc[q], lane, zero);
       }
     }
   }
@@ -922,6 +926,7 @@ struct BwdB1hArgs {
   const unsigned short* dy2_store;                          // [2B*N][128] bf16
   float* u2_part; float* g1_part;                           // [2B][64*128], [2B][64*64] (upper blocks) or null (the forward kept Gram(h1))
   double* pdy_part;                                         // [2B][4][64]: one slice per cloud (DgB0Args.slices = 1)
+  int parts = 1;                                            // as BwdB2Args::parts: u2_part / g1_part / pdy_part are per-workgroup partials (DgB0Args.slices = parts)
 };
 
 __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArgs a)
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const XForm XF = xform_load(xf);
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   // per tile.  79.9 KB per workgroup: still two per CU.
   bf16x8* Vl = reinterpret_cast<bf16x8*>(YhT + C2 * ldT);                   // [2 channel tiles][8 k-groups][64 lanes]
   bf16x8* Ql = Vl + 2 * (C2 / 16) * 64;                                      // [2][4][64]
-  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int nt_all = (a.N + kTT - 1) / kTT, tile0 = part * nt_all / a.parts, ntiles = (part + 1) * nt_all / a.parts;   // this workgroup's tiles [tile0, ntiles)
   {
     const bf16x8* v2img = reinterpret_cast<const bf16x8*>(a.v2imgh + tower * a.v2_stride);
     const bf16x8* q2img = reinterpret_cast<const bf16x8*>(a.q2imgh + tower * a.q2_stride);
@@ -966,7 +971,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
   // the tile's points and its dy2 rows (16 KB of bf16 from HBM) are requested one tile ahead: loaded at the head of the tile, their round trip
   // sat exposed in front of the first barrier of each of a cloud's 16 tiles
   constexpr int kDyIt = (C2 / 8) / kTW;
-  TilePoint npt = tile_point_request(pc, a.N, 0, tid);
+  TilePoint npt = tile_point_request(pc, a.N, tile0, tid);
   uint4 ndy[kDyIt];
   auto dy_request = [&](int tile) {
     const int nv = min(kTT, a.N - tile * kTT);
@@ -977,8 +982,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
       if (lane < nv) ndy[it] = *reinterpret_cast<const uint4*>(src + (size_t)lane * C2 + (wave + it * kTW) * 8);
     }
   };
-  dy_request(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  dy_request(tile0);
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     __syncthreads();
     tile_point_store(npt, XF, xs, tid);
@@ -1082,7 +1087,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
     }
     __syncthreads();
     if (rg == 0 && half == 0) {
-      double* dst = a.pdy_part + (size_t)cloud * 4 * C1 + col;
+      double* dst = a.pdy_part + (size_t)vcloud * 4 * C1 + col;
 #pragma unroll
       for (int d = 0; d < 4; ++d) dst[(size_t)d * C1] = pd[d] + red[(ct * 4 + d) * 32 + (lane & 31)];
     }
@@ -1092,11 +1097,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b1_bf16(const BwdB1hArg
     const int item = wave + q * kTW;
     if (item < nblk) {
       const float zero[16] = {};
-      if (item < nblk_u) tile_commit(a.u2_part + (size_t)cloud * C1 * C2, C2, item / CT2, item % CT2, C1, C2, gacc[q], lane, zero);
+      if (item < nblk_u) tile_commit(a.u2_part + (size_t)vcloud * C1 * C2, C2, item / CT2, item % CT2, C1, C2, gacc[q], lane, zero);
       else {
         int rem = item - nblk_u, it = 0;
         while (rem >= CT1 - it) { rem -= CT1 - it; ++it; }
-        tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, it, it + rem, C1, C1, gacc[q], lane, zero);
+        tile_commit(a.g1_part + (size_t)vcloud * C1 * C1, C1, it, it + rem, C1, C1, gacc[q], lane, zero);
       }
     }
   }

@@ -49,6 +49,8 @@ struct TrainFwdArgs {
   int gram_inline;         // fp32 phase 3: 1 = accumulate the Gram per tile in this kernel (fallback), 0 = gram_h2_kernel does it
   int dbg;                 // debug/ablation flags (0 in production)
   long long* stamps;       // debug (dbg & 32): cycle stamps of thread 0 / block 0 at the phase boundaries of tile 3
+  int parts = 1;           // PHASE 2 only: a cloud's tiles dealt to `parts` workgroups (grid 2B * parts, workgroup = cloud * parts + part); stat_part is then a per-WORKGROUP
+                           // partial ([2B * parts][4] slices).  One workgroup per cloud leaves the chip half empty below 512 clouds (the reference's shipped batch is 128).
 };
 #define P3_STAMP(i) do { if (PHASE == 3 && ALN_STAMPS(a.stamps) && blockIdx.x == 0 && tid == 0 && tile == 3) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, pparts = PHASE == 2 ? a.parts : 1, cloud = vcloud / pparts, part = vcloud - cloud * pparts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const XForm XF = xform_load(xf);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   unsigned short* bufT = buf1h + kTT * ldh;
   const int KG2 = (kC1 + 7) >> 3, CT2 = (kC2 + 31) >> 5;
   const int KG3 = (kC2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
-  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int nt_all = (a.N + kTT - 1) / kTT, tile0 = part * nt_all / pparts, ntiles = (part + 1) * nt_all / pparts;   // this workgroup's tiles [tile0, ntiles) (phase 3: all of them)
   float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
   float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * kC2 * kC2 : nullptr;
@@ -457,10 +459,10 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   // phase 3 has no register to spare for it (see kRegSums)
   constexpr bool kPfPts = PHASE == 2 && !GIVEN;
   TilePoint npt = {0.f, 0.f, 0.f};
-  if (kPfPts) npt = tile_point_request(pc, a.N, 0, tid);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  if (kPfPts) npt = tile_point_request(pc, a.N, tile0, tid);
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
-    const bool first = tile == 0;
+    const bool first = tile == tile0;
     __syncthreads();   // previous tile's readers are done with xs/buf0/buf1
     P3_STAMP(0);
     if (GIVEN && BF16) {
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         const int ct = item >> 1, rg = item & 1, col = ct * 32 + (lane & 31);
         if (col < kC2) {
           if (PHASE == 2) {
-            double* st = a.stat_part + (((size_t)cloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half)
+            double* st = a.stat_part + (((size_t)vcloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half) of this workgroup
             st[0] = l2s[q2]; st[1] = l2ss[q2];
           } else {
             a.colsum_part[((size_t)cloud * 4 + rg * 2 + half) * kC2 + col] = l2s[q2];
@@ -830,6 +832,7 @@ struct Gram1Args {
   const float* w1; const float *sc1, *sh1;
   float* g1_part;      // [2B][C1*C1] upper blocks
   double* s1_part;     // [2B][sG][C1]
+  int parts = 1;       // as TrainFwdArgs::parts: g1_part / s1_part per workgroup
 };
 
 template <bool BF16, int C1T = 0>   // C1T: compile-time width (0 = from the arguments)
@@ -838,13 +841,13 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts, part = vcloud - cloud * a.parts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   float* xs = smem;
   float* X = smem + kTT * 4;
   const int ld0 = C1T ? C1T + 4 : a.ld0, C1 = C1T ? C1T : a.C1, CT1 = (C1 + 31) >> 5, nblk = CT1 * (CT1 + 1) / 2;
-  const int ntiles = (a.N + kTT - 1) / kTT;
+  const int nt_all = (a.N + kTT - 1) / kTT, tile0 = part * nt_all / a.parts, ntiles = (part + 1) * nt_all / a.parts;   // this workgroup's tiles [tile0, ntiles)
   const int sG = max(1, (kTW * 64) / C1);
   const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
   constexpr int kSlots = 3;
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
   for (int q = 0; q < kSlots; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gd[q][r] = 0.0;
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int nvalid = min(kTT, a.N - tile * kTT);
     __syncthreads();
     load_tile_xform(pc, xf, a.N, tile, xs, tid);
@@ -898,9 +901,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_gram1(const Gram1Args a
       const float zero[16] = {};
 #pragma unroll
       for (int r = 0; r < 16; ++r) gacc[q][r] = (float)gd[q][r];
-      tile_commit(a.g1_part + (size_t)cloud * C1 * C1, C1, bit[q], bjt[q], C1, C1, gacc[q], lane, zero);
+      tile_commit(a.g1_part + (size_t)vcloud * C1 * C1, C1, bit[q], bjt[q], C1, C1, gacc[q], lane, zero);
     }
-  if (tid < sG * C1) a.s1_part[(size_t)cloud * sG * C1 + tid] = s1c;
+  if (tid < sG * C1) a.s1_part[(size_t)vcloud * sG * C1 + tid] = s1c;
 }
 
 // (sum z2, sum (z2 - mean)^2) per tower and channel from the reduced s1 [2][C1] and G1 [2][C1*C1] (upper 32 x 32 blocks valid), fp64.

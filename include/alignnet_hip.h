@@ -362,7 +362,9 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   (results agree up to summation order; tests/test_train_gpu.py runs them against the default): "ab_no_ld_const", "ab_infer_tile64",
  *   "ab_phase2_legacy", "ab_b1_legacy", "ab_b1_fp32", "ab_p3_bf16_generic", "ab_p3_nogram", "ab_no_defer", "ab_dg_sparse",
  *   "ab_no_glue_fold", "ab_gemm_jobs_ksplit", "ab_fc_direct", "ab_fc_no_splitk", "ab_split_tilewise" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic);
- *   "dg_cloud_parts" (dgcnn training: workgroups per cloud of the edge kernels, 0 = as many as fill the chip at this batch, 1 .. 8 = fixed; results agree up to the grouping of partial sums).
+ *   "dg_cloud_parts" (dgcnn training: workgroups per cloud of the edge kernels, 0 = as many as fill the chip at this batch, 1 .. 8 = fixed; results agree up to the grouping of partial sums);
+ *   "pn_cloud_parts" (PointNet training: the same split for phase 2 / the first-layer Gram and passes B2, B1 -- they run two workgroups per CU, so the chip is
+ *   full from 2B = 512 clouds and the reference's shipped batch of 128 brings 256; phase 3 keeps one workgroup per cloud).
  *   "ab_mask" (read-only) = the bits that are set; bench.py prints it.  The library reads NO environment variable; result-changing
  *   ablation switches exist only in the separate ablation build (csrc/ablate.h, `make ablate`).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped

@@ -103,3 +103,33 @@ def test_dgcnn_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, N, 
         else:      # (the bars of the other variants: same fp32 arithmetic, another grouping of the partial sums, eight-row head statistics)
             assert dp <= 1e-4 and rl2 <= 2e-2, (parts, dp, rl2)
             assert np.array_equal(dd["slot"][0], d1["slot"][0])   # stage 1 sees the same frame in every run: its neighbour slots are bit-equal
+
+
+@pytest.mark.parametrize("bf16,N,B", [(0, 320, 8), (1, 320, 8), (0, 200, 8), (1, 512, 16)])
+def test_pointnet_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, N, B):
+    """PointNet training: phase 2 (bf16) / the first-layer Gram (fp32) and passes B2, B1 deal a cloud's tiles to several workgroups below 2B = 512 clouds
+    (alignnet_train.hip pn_parts; the reference's shipped configs train at batch 128 x 512 points = 256 clouds).  Everything those kernels leave behind is a
+    per-workgroup partial SUM (statistics, Gram(h1), column sums, U2, Pdy, (dbeta, dgamma)) or per-row (dy2): same step up to the grouping of the sums; the
+    pooled maxima come from phase 3, which is not split, so the forward's winners only move if a regrouped statistic moves them."""
+    cfg, spec, P32, d, du = TT._setup(N, B, std=True)
+    runs = {}
+    for parts in (1, 2, 4, 0):
+        eng = alignnet3d.Engine(cfg)
+        eng.set_variables(P32)
+        eng.set_option("train_matmul_bf16", bf16)
+        eng.set_option("pn_cloud_parts", parts)
+        assert eng.get_option("pn_cloud_parts") == parts
+        res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
+        names = [n for n, _, tr in eng.variables() if tr]
+        runs[parts] = (res, np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names]))
+        eng.close()
+    r1, g1 = runs[1]
+    for parts in (2, 4, 0):
+        r, g = runs[parts]
+        rl2 = float(np.linalg.norm(g - g1) / np.linalg.norm(g1))
+        dp = max(float(np.abs(np.asarray(r[k]) - np.asarray(r1[k])).max()) for k in alignnet3d.OUTPUT_NAMES)
+        print("pointnet bf16=%d N=%d parts %d vs 1: predictions %.1e, gradient relative L2 %.1e" % (bf16, N, parts, dp, rl2))
+        if bf16:
+            assert dp <= 5e-2 and rl2 <= 0.3, (parts, dp, rl2)
+        else:
+            assert dp <= 1e-4 and rl2 <= 2e-2, (parts, dp, rl2)
