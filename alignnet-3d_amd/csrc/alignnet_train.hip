@@ -56,6 +56,7 @@ struct StageWS {                 // one backbone stage (T1, T2, embedding)
   float *rstd[3], *kk[3];                          // [2][C_l]: rsqrt(var+eps), gamma*rsqrt(var+eps)
   float* sgn3;                   // [2][C3]
   float* ext; int* idx2;          // [2B][2 halves][C3] per-half extremes
+  float* extp; int* idxp;         // [<= 512 workgroups][2 halves][C3]: the same per WORKGROUP when phase 3 deals a cloud to several (p3_parts)
   int* idx; float* zhat_star;     // [2B][C3] final arg-extreme index, zhat at the extreme
   float* h2;                     // [2B*N][C2]
   float *gram2, *s2, *m2;        // [2][C2*C2] centred Gram of h2, [2][C2] column sums, [2][C2] column means
@@ -204,6 +205,18 @@ static int pn_parts(const alignnet_handle* h, int B)
   if (h->pn_parts_opt > 0) return std::min(h->pn_parts_opt, cap);
   int p = 1;
   while (p * 2 <= cap && 2 * B * p * 2 <= 512) p *= 2;
+  return p;
+}
+
+// Phase 3 (lift to C3, running arg-extreme, Gram): `slots` workgroups fill the chip (256 for the 128-point-tile kernels: one per CU; 512 for the 64-point
+// ones), `tile` = points per tile.  The parts' extremes are folded by merge_ext_parts_kernel (exact), Gram / column sums by the reductions.
+static int p3_parts(const alignnet_handle* h, int B, int slots, int tile)
+{
+  const int ntiles = (h->cfg.num_points + tile - 1) / tile;
+  const int cap = std::max(1, std::min(std::min(kDgMaxParts, ntiles), kDgPartSlices / (2 * B)));
+  if (h->pn_parts_opt > 0) return std::min(h->pn_parts_opt, cap);
+  int p = 1;
+  while (p * 2 <= cap && 2 * B * p * 2 <= slots) p *= 2;
   return p;
 }
 
@@ -383,7 +396,9 @@ static int ensure_train_ws(alignnet_handle* h, int B)
       }
       for (int l = 0; l < 3; ++l) { S.mean[l] = F(2 * C[l]); S.var[l] = F(2 * C[l]); S.scale[l] = F(2 * C[l]); S.shift[l] = F(2 * C[l]); S.rstd[l] = F(2 * C[l]); S.kk[l] = F(2 * C[l]); }
       S.sgn3 = F(2 * C[2]);
-      S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]); S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
+      S.ext = F(B2 * 2 * C[2]); S.idx2 = I(B2 * 2 * C[2]);
+      S.idx = I(B2 * C[2]); S.zhat_star = F(B2 * C[2]);
+      S.extp = F((size_t)kDgPartSlices * 2 * C[2]); S.idxp = I((size_t)kDgPartSlices * 2 * C[2]);   // phase 3 split over workgroups (p3_parts: only below 512 of them)
       S.h2 = F((gen && !hyb) ? 8 : MN * C[1]);
       S.gram2 = F(2 * (size_t)C[1] * C[1]); S.gram2raw = F(2 * (size_t)C[1] * C[1]); S.s2 = F(2 * C[1]); S.m2 = F(2 * C[1]);
       S.pooled = F(B2 * C[2]); S.dP = F(B2 * C[2]);
@@ -430,7 +445,7 @@ static int ensure_train_ws(alignnet_handle* h, int B)
     w->d_s1c = F(B2 * 3); w->d_s2c = F(B2 * 3);
     w->loss_out = F(32); w->loss_scratch = F(loss_scratch_floats(B));
     const size_t dgs = std::max(B2, (size_t)kDgPartSlices);
-    w->stat_part = D(std::max(B2 * 4 * maxC, dgs * 4 * maxC2) * 2); w->gram_part = F(B2 * (size_t)maxC2 * maxC2); w->colsum_part = D(B2 * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
+    w->stat_part = D(std::max(B2 * 4 * maxC, dgs * 4 * maxC2) * 2); w->gram_part = F(dgs * (size_t)maxC2 * maxC2); w->colsum_part = D(dgs * std::max((size_t)4 * maxC2, (size_t)1024));   // [2B][slices][C2]: 4 slices (PointNet), 1024 / C2 (bf16 point conv of the dgcnn branch)
     w->dy2 = F(MN * maxC2); w->dy1 = F(h->cfg.backbone == 1 ? 0 : MN * maxC1);
     w->nn = I(h->cfg.backbone == 1 ? MN * kDgK : 0); w->pdy_part = D(dgs * 4 * 7 * maxC1);
     w->dbg2_part = D(dgs * 4 * maxC2 * 2); w->dbg1_part = D(dgs * 4 * maxC1 * 2); w->s1_part = D(dgs * 1024);   // [2B][row groups][C1]: 256 / C1 groups (PointNet kernels), 1024 / C1 (dg_train_fwd)
@@ -946,6 +961,18 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (sync && sync_gram(S.gram2raw64, S.gram2raw, (size_t)2 * C2 * C2, S.s2, (size_t)2 * C2)) return 1;
     return 0;
   };
+  // phase 3 over p3 workgroups per cloud: the kernels write per-workgroup extremes to S.extp / S.idxp, folded into S.ext / S.idx2 right behind them
+  auto p3_split = [&](int slots, int tile) -> int {
+    const int p3 = p3_parts(h, B, slots, tile);
+    a.parts3 = p3;
+    if (p3 > 1) { a.ext = S.extp; a.idx = S.idxp; }
+    return p3;
+  };
+  auto p3_merge = [&](int p3) {
+    if (p3 <= 1) return;
+    const size_t n = (size_t)2 * B * 2 * C3;
+    hipLaunchKernelGGL(merge_ext_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S.extp, S.idxp, p3, C3, n, S.ext, S.idx2);
+  };
   if (dg) {
     // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
     const double ecount = count * kDgK;
@@ -1011,20 +1038,24 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
       a.wp3h = w->wp3h[s];
       const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                           ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
+      const int p3 = p3_split(512, kTT);
       { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
-      if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
-      else TIMED_LAUNCH((train_fwd_phase23<3, true, true>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
+      if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, true, true, 64, 128>), dim3(2 * B * p3), dim3(kTW * 64), ldsh, a);
+      else TIMED_LAUNCH((train_fwd_phase23<3, true, true>), dim3(2 * B * p3), dim3(kTW * 64), ldsh, a);
       }
-      if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B, (long)(C2), S.s2))) return 1;
+      p3_merge(p3);
+      if (finish_and_reduce(rjob(w->gram_part, B * p3, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (1024 / C2) * B * p3, (long)(C2), S.s2))) return 1;
     } else {
+    const int p3 = wide_gram ? p3_split(256, kWT) : 1;
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
-    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<true, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<true, true>), dim3(2 * B * p3), dim3(kWW * 64), lds_p3_wide_f32(), a);
     else if (wide) TIMED_LAUNCH((train_fwd_phase3_wide<true, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
     else if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, false, true, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
     else TIMED_LAUNCH((train_fwd_phase23<3, false, true>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
   }
+    p3_merge(p3);
     #ifdef ALIGNNET_ABLATE
-    if (wide_gram && getenv("ALIGNNET_P3_EXTCHECK")) {   // debug: ext / idx of the GRAM variant against the plain one
+    if (wide_gram && p3 == 1 && getenv("ALIGNNET_P3_EXTCHECK")) {   // debug: ext / idx of the GRAM variant against the plain one
       std::vector<float> ea((size_t)2 * B * 2 * C3), eb(ea.size());
       std::vector<int> ia(ea.size()), ib(ea.size());
       hipStreamSynchronize(h->stream);
@@ -1038,7 +1069,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                    first == (size_t)-1 ? 0 : first / (2 * C3), first == (size_t)-1 ? 0 : (first / C3) & 1, first == (size_t)-1 ? 0 : first % C3,
                    first == (size_t)-1 ? 0.f : ea[first], first == (size_t)-1 ? 0.f : eb[first]);
     }
-    if (wide_gram && getenv("ALIGNNET_P3_GRAMCHECK")) {   // debug: the in-kernel Gram against gram_h2_kernel's, block by block
+    if (wide_gram && p3 == 1 && getenv("ALIGNNET_P3_GRAMCHECK")) {   // debug: the in-kernel Gram against gram_h2_kernel's, block by block
       std::vector<float> ga((size_t)2 * B * C2 * C2), gb(ga.size());
       hipStreamSynchronize(h->stream);
       hipMemcpy(ga.data(), w->gram_part, ga.size() * 4, hipMemcpyDeviceToHost);
@@ -1063,7 +1094,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM, true);
     TIMED_LAUNCH(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), S.h2, N, C2, w->gram_part);
     }
-    if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;
+    if (finish_and_reduce(rjob(w->gram_part, B * p3, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;   // (column sums: the producer's)
     }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)
@@ -1112,14 +1143,17 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
   if (finish(1, C2, 4 * pp, count)) return 1;
   a.parts = 1;
   }
+  int p3 = 1;   // workgroups per cloud of phase 3 (the 128-point-tile kernels with the Gram in the same pass)
   if (h->train_bf16) {
     a.wp3h = w->wp3h[s];
     const size_t ldsh = ((size_t)kTT * 4 + (size_t)kTT * a.ld[0]) * sizeof(float) +
                         ((size_t)kTT * (C2 + 8) + (size_t)C2 * (kTT + 8)) * sizeof(unsigned short);
+    const bool wide_bf16 = std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64;
+    if (wide_bf16) p3 = p3_split(256, kWT);
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
     // shipped widths: 128-point tiles, the next tile's prologue under the lift (kernels_train_fwd_wide.h)
-    if (std_w && C3 <= 32 * kWW * kWSlots && !h->p3_tile64)
-      TIMED_LAUNCH(train_fwd_phase3_wide_bf16, dim3(2 * B), dim3(kWW * 64), lds_p3_wide_bf16(), a);
+    if (wide_bf16)
+      TIMED_LAUNCH(train_fwd_phase3_wide_bf16, dim3(2 * B * p3), dim3(kWW * 64), lds_p3_wide_bf16(), a);
     else if (std_w && !(h->ab & AB_P3BF16_GENERIC)) TIMED_LAUNCH((train_fwd_phase23<3, true, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
     else TIMED_LAUNCH((train_fwd_phase23<3, true>), dim3(2 * B), dim3(kTW * 64), ldsh, a);
   }
@@ -1131,9 +1165,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                    sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] - sv[6]);
     }
   } else {
+    if (wide_gram) p3 = p3_split(256, kWT);
   { ProfScope prof_scope(h, PK_TRAIN_PHASE3, true);
     // shipped widths: 128-point tiles (a weight fragment of the lift feeds four row tiles; kernels_train_fwd_wide.h)
-    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<false, true>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
+    if (wide_gram) TIMED_LAUNCH((train_fwd_phase3_wide<false, true>), dim3(2 * B * p3), dim3(kWW * 64), lds_p3_wide_f32(), a);
     else if (wide) TIMED_LAUNCH((train_fwd_phase3_wide<false, false>), dim3(2 * B), dim3(kWW * 64), lds_p3_wide_f32(), a);
     else if (std_w) TIMED_LAUNCH((train_fwd_phase23<3, false, false, 64, 128>), dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
     else TIMED_LAUNCH(train_fwd_phase23<3>, dim3(2 * B), dim3(kTW * 64), lds_train(a.ld[0], a.ld[1]), a);
@@ -1144,7 +1179,8 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                          w->gram_part);
     }
   }
-  if (finish_and_reduce(rjob(w->gram_part, B, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B, (long)(C2), S.s2))) return 1;
+  p3_merge(p3);
+  if (finish_and_reduce(rjob(w->gram_part, B * p3, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, 4 * B * p3, (long)(C2), S.s2))) return 1;
   }
   {   // statistics of the last layer from the Gram, EMA, pooled features, centred Gram + column means for the backward: one launch
     Stat3Args f;
@@ -1406,7 +1442,7 @@ static int backbone_bwd_train(alignnet_handle* h, int s, const float* p1, const 
   b2.wp2h = h->train_bf16 ? w->wp2h[s] : nullptr; b2.q3imgh = w->q3imgh; b2.q3imgh_stride = (long)qimgh;
   b2.h2_given = S.h2;
   b2.w3th = spm ? w->w3th[s] : nullptr;
-  const int pp = (given || dg || b2_accum) ? 1 : pn_parts(h, B);   // workgroups per cloud of passes B2 and B1 (their outputs are sums the reductions below fold anyway)
+  const int pp = b2_accum ? 1 : pn_parts(h, B);   // workgroups per cloud of passes B2 and B1 (their outputs are sums the reductions below fold anyway)
   b2.parts = pp;
   const size_t b2_lds = lds_train(b2.ldb, b2.ldb) + b2_extra + (spm ? (size_t)(kTT * 72 + 128 * 72 + kTT * 72) * 2 - (size_t)kTT * b2.ldb * sizeof(float) + (5 * 64 + 16) * sizeof(float) : 0) +
                         ((std_w && !b2_accum && !h->train_bf16 && !given) ? (size_t)(5 * 64 + 16 + 6 * 128) * sizeof(float) : 0);   // STDF: the LDS parameter tables

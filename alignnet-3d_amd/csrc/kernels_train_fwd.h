@@ -49,6 +49,8 @@ struct TrainFwdArgs {
   int gram_inline;         // fp32 phase 3: 1 = accumulate the Gram per tile in this kernel (fallback), 0 = gram_h2_kernel does it
   int dbg;                 // debug/ablation flags (0 in production)
   long long* stamps;       // debug (dbg & 32): cycle stamps of thread 0 / block 0 at the phase boundaries of tile 3
+  int parts3 = 1;          // phase 3 (all three kernels): the same split; ext / idx / gram_part / colsum_part are per-WORKGROUP then ([2B * parts3] slices) and
+                           // merge_ext_parts_kernel folds the running extremes of a cloud's parts (exactly: a scan in tile order) before anything reads them
   int parts = 1;           // PHASE 2 only: a cloud's tiles dealt to `parts` workgroups (grid 2B * parts, workgroup = cloud * parts + part); stat_part is then a per-WORKGROUP
                            // partial ([2B * parts][4] slices).  One workgroup per cloud leaves the chip half empty below 512 clouds (the reference's shipped batch is 128).
 };
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int vcloud = blockIdx.x, pparts = PHASE == 2 ? a.parts : 1, cloud = vcloud / pparts, part = vcloud - cloud * pparts, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, pparts = PHASE == 2 ? a.parts : a.parts3, cloud = vcloud / pparts, part = vcloud - cloud * pparts, tower = cloud >= a.B, b = cloud - tower * a.B;
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const XForm XF = xform_load(xf);
@@ -411,9 +413,9 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   const int KG2 = (kC1 + 7) >> 3, CT2 = (kC2 + 31) >> 5;
   const int KG3 = (kC2 + 7) >> 3, CT3 = (a.C3 + 31) >> 5;
   const int nt_all = (a.N + kTT - 1) / kTT, tile0 = part * nt_all / pparts, ntiles = (part + 1) * nt_all / pparts;   // this workgroup's tiles [tile0, ntiles) (phase 3: all of them)
-  float* my_ext = PHASE == 3 ? a.ext + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
-  int* my_idx = PHASE == 3 ? a.idx + ((size_t)cloud * 2 + half) * a.C3 : nullptr;
-  float* my_gram = PHASE == 3 ? a.gram_part + (size_t)cloud * kC2 * kC2 : nullptr;
+  float* my_ext = PHASE == 3 ? a.ext + ((size_t)vcloud * 2 + half) * a.C3 : nullptr;
+  int* my_idx = PHASE == 3 ? a.idx + ((size_t)vcloud * 2 + half) * a.C3 : nullptr;
+  float* my_gram = PHASE == 3 ? a.gram_part + (size_t)vcloud * kC2 * kC2 : nullptr;
 
   // Two workgroups share a CU and run identical per-tile timelines; started together they stay in lockstep and
   // their non-MFMA phases coincide.  Stagger the second resident wave of workgroups by about half a tile.
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
         }
         if (kRegSums) l2s[q2] += (double)lsum;   // phase 3: the column sum of h2
         else if (live) {
-          double* cs = a.colsum_part + ((size_t)cloud * 4 + rg * 2 + half) * kC2 + col;
+          double* cs = a.colsum_part + ((size_t)vcloud * 4 + rg * 2 + half) * kC2 + col;
           *cs = first ? (double)lsum : *cs + (double)lsum;
         }
       }
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
             double* st = a.stat_part + (((size_t)vcloud * 4 + rg * 2 + half) * kC2 + col) * 2;   // slice (rg, half) of this workgroup
             st[0] = l2s[q2]; st[1] = l2ss[q2];
           } else {
-            a.colsum_part[((size_t)cloud * 4 + rg * 2 + half) * kC2 + col] = l2s[q2];
+            a.colsum_part[((size_t)vcloud * 4 + rg * 2 + half) * kC2 + col] = l2s[q2];
           }
         }
       }
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_fwd_phase23(const TrainFwdA
   if (PHASE == 3 && BF16 && GIVEN) {   // colsum_part [cloud][256 / (C2 / 4) row groups][C2]
     const int c4 = kC2 >> 2, q = tid % c4, g = tid / c4, slices = (kTW * 64) / c4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a.colsum_part[((size_t)cloud * slices + g) * kC2 + q * 4 + e] = gcs[e];
+    for (int e = 0; e < 4; ++e) a.colsum_part[((size_t)vcloud * slices + g) * kC2 + q * 4 + e] = gcs[e];
   }
   if (PHASE == 3 && BF16) {
 #pragma unroll
@@ -1143,6 +1145,24 @@ __global__ void rstd_k_kernel(const float* __restrict__ var, const float* __rest
 
 // pooled[t,b,c] = relu(scale*(sgn*ext - bias) + shift);  also keeps zhat* = (z* - mean)*rsqrt(var+eps) and the
 // final arg-extreme index (combining the two half-wave slices; first occurrence wins ties)
+// Phase 3 split over `parts` workgroups per cloud (TrainFwdArgs::parts3): fold the parts' running extremes per (cloud, lane half, channel).  A part
+// scanned its tiles keeping the first of equal values (strictly greater wins); folding the parts in tile order under the same rule IS the scan over
+// the whole cloud -- bit-equal (ext, idx) to one workgroup per cloud.  n = 2B * 2 * C3 outputs.
+static __global__ __launch_bounds__(256) void merge_ext_parts_kernel(const float* __restrict__ extp, const int* __restrict__ idxp, int parts, int C3, size_t n,
+                                                                     float* __restrict__ ext, int* __restrict__ idx)
+{
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t per = (size_t)2 * C3, cloud = i / per, rem = i - cloud * per;
+  const size_t o = cloud * parts * per + rem;
+  float e = extp[o]; int bi = idxp[o];
+  for (int p = 1; p < parts; ++p) {
+    const float v = extp[o + p * per];
+    if (v > e) { e = v; bi = idxp[o + p * per]; }
+  }
+  ext[i] = e; idx[i] = bi;
+}
+
 struct PoolFinishArgs {
   const float* ext; const int* idx2; const float* sgn; const float* bias; const float* scale; const float* shift; const float* mean; const float* var;
   int B, C; float* pooled; long tower_stride, row_stride; float* zhat_star; int* idx;

@@ -72,14 +72,14 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   constexpr int C1 = 64, C2 = 128, ld0 = C1 + 4, ld1 = C2 + 4, KG2 = C1 / 8, KG3 = C2 / 8;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts3, part = vcloud - cloud * a.parts3, tower = cloud >= a.B, b = cloud - tower * a.B;   // (TrainFwdArgs::parts3)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const XForm XF = xform_load(xf);   // (scalar registers: store_xs read the frame from memory for every tile)
   float* xs = smem;
   const int off0 = kWT * 4, off1 = kWT * 4 + kWT * ld0;   // integer offsets keep the LDS address space visible (ds_read_b128)
   const int CT3 = (a.C3 + 31) >> 5;
-  const int ntiles = (a.N + kWT - 1) / kWT;
+  const int nt_all = (a.N + kWT - 1) / kWT, tile0 = part * nt_all / a.parts3, ntiles = (part + 1) * nt_all / a.parts3;   // this workgroup's tiles [tile0, ntiles)
 
   Layer1W l1w = {};
   if (!GIVEN) l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
@@ -126,13 +126,13 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
   // The K = 3 lift of tile t + 1 runs INSIDE the lift of tile t (behind the wave's first channel tile): h1's buffer is free once the hidden
   // layer of tile t is done, so the points -> barrier -> lift -> barrier chain no longer sits in front of every tile's first MFMA.
   if (!GIVEN) {
-    request_xyz(0);
+    request_xyz(tile0);
     store_xs();
-    if (ntiles > 1) request_xyz(1);
+    if (tile0 + 1 < ntiles) request_xyz(tile0 + 1);
     __syncthreads();
     layer1_wide(xs, l1w, smem + off0, tid);
   }
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int nvalid = min(kWT, a.N - tile * kWT);
     __syncthreads();            // h1 of this tile is complete; the previous tile's readers are done with h2
     if (GIVEN) {
@@ -250,17 +250,17 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide(const Train
     }
   }
   {
-    float* my_ext = a.ext + ((size_t)cloud * 2 + half) * a.C3;
-    int* my_idx = a.idx + ((size_t)cloud * 2 + half) * a.C3;
+    float* my_ext = a.ext + ((size_t)vcloud * 2 + half) * a.C3;
+    int* my_idx = a.idx + ((size_t)vcloud * 2 + half) * a.C3;
 #pragma unroll
     for (int q = 0; q < kWSlots; ++q) {
       const int col = (wave + q * kWW) * 32 + (lane & 31);
       if (col < a.C3 && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = be[q]; my_idx[col] = min(bi[q], a.N - 1); }
     }
-    if (!GIVEN) a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+    if (!GIVEN) a.colsum_part[((size_t)vcloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
   }
   if (GRAM) {
-    float* my_gram = a.gram_part + (size_t)cloud * C2 * C2;
+    float* my_gram = a.gram_part + (size_t)vcloud * C2 * C2;
     const float zero[16] = {};
     tile_commit(my_gram, C2, git, gjt, C2, C2, gacc[0], lane, zero);
     __syncthreads();                       // every wave is done with the last tile's LDS reads
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
   constexpr int C1 = 64, C2 = 128, ld0h = C1 + 8, ldh = C2 + 8, ldT = kWT + 8, KG2 = C1 / 16, KG3 = C2 / 16;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
+  const int vcloud = blockIdx.x, cloud = vcloud / a.parts3, part = vcloud - cloud * a.parts3, tower = cloud >= a.B, b = cloud - tower * a.B;   // (TrainFwdArgs::parts3)
   const float* pc = a.pcs[tower] + (size_t)b * a.N * 3;
   const float* xf = a.xform + (size_t)cloud * 12;
   const XForm XF = xform_load(xf);   // (scalar registers: store_xs read the frame from memory for every tile)
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
   const int CT3 = (a.C3 + 31) >> 5;
   const int nct = (CT3 - wave + kWW - 1) / kWW;       // channel tiles wave, wave + 8, ... of this wave (<= kWSlots)
   const int nA = (nct + 1) >> 1;                      // ... of which the first nA are lifted in S0, the rest in S1
-  const int ntiles = (a.N + kWT - 1) / kWT;
+  const int nt_all = (a.N + kWT - 1) / kWT, tile0 = part * nt_all / a.parts3, ntiles = (part + 1) * nt_all / a.parts3;   // this workgroup's tiles [tile0, ntiles)
   const bool early = wave < kWW / 2;                  // prologue piece first
 
   const Layer1W l1w = layer1_load(a.w1, C1, a.sc1 + tower * C1, a.sh1 + tower * C1, tid);
@@ -514,16 +514,16 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
   auto pieceA = [&](int t, bool more) { if (!(ALN_ABL(a.dbg, 64))) gram(); if (!(ALN_ABL(a.dbg, 2))) store_h2(t); if (more && !(ALN_ABL(a.dbg, 256))) lift(t + 1); };
 
   // ---- prologue of tile 0 (not overlapped) ----
-  request_xyz(0);
+  request_xyz(tile0);
   store_xs();
-  if (ntiles > 1) request_xyz(1);
+  if (tile0 + 1 < ntiles) request_xyz(tile0 + 1);
   __syncthreads();
-  lift(0);
+  lift(tile0);
   __syncthreads();
-  if (ntiles > 1) store_xs();
-  hidden(0);
+  if (tile0 + 1 < ntiles) store_xs();
+  hidden(tile0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tile0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
     // ---- S0 ----
     if (early) pieceA(t, more);
@@ -539,15 +539,15 @@ __global__ __launch_bounds__(kWW * 64, 2) void train_fwd_phase3_wide_bf16(const 
     __syncthreads();
   }
   {
-    float* my_ext = a.ext + ((size_t)cloud * 2 + half) * a.C3;
-    int* my_idx = a.idx + ((size_t)cloud * 2 + half) * a.C3;
+    float* my_ext = a.ext + ((size_t)vcloud * 2 + half) * a.C3;
+    int* my_idx = a.idx + ((size_t)vcloud * 2 + half) * a.C3;
 #pragma unroll
     for (int q = 0; q < kWSlots; ++q) {
       const int col = (wave + q * kWW) * 32 + (lane & 31);
       if (col < a.C3 && !(ALN_ABL(a.dbg, 4))) { my_ext[col] = rbe[q]; my_idx[col] = rbi[q]; }
     }
-    a.colsum_part[((size_t)cloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
-    float* my_gram = a.gram_part + (size_t)cloud * C2 * C2;
+    a.colsum_part[((size_t)vcloud * 4 + rg2 * 2 + half) * C2 + col2] = cs2;
+    float* my_gram = a.gram_part + (size_t)vcloud * C2 * C2;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int item = wave + q * kWW;

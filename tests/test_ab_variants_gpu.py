@@ -85,6 +85,7 @@ def test_dgcnn_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, N, 
         eng.set_variables(P32)
         eng.set_option("train_matmul_bf16", bf16)
         eng.set_option("dg_cloud_parts", parts)
+        eng.set_option("pn_cloud_parts", parts)   # (the point conv on the pooled edge features -- phase 3 -- and pass B2 follow this one)
         assert eng.get_option("dg_cloud_parts") == parts
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
         dec = eng.debug_train_decisions(B)
@@ -107,10 +108,10 @@ def test_dgcnn_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, N, 
 
 @pytest.mark.parametrize("bf16,N,B", [(0, 320, 8), (1, 320, 8), (0, 200, 8), (1, 512, 16)])
 def test_pointnet_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, N, B):
-    """PointNet training: phase 2 (bf16) / the first-layer Gram (fp32) and passes B2, B1 deal a cloud's tiles to several workgroups below 2B = 512 clouds
-    (alignnet_train.hip pn_parts; the reference's shipped configs train at batch 128 x 512 points = 256 clouds).  Everything those kernels leave behind is a
-    per-workgroup partial SUM (statistics, Gram(h1), column sums, U2, Pdy, (dbeta, dgamma)) or per-row (dy2): same step up to the grouping of the sums; the
-    pooled maxima come from phase 3, which is not split, so the forward's winners only move if a regrouped statistic moves them."""
+    """PointNet training: phase 2 (bf16) / the first-layer Gram (fp32), phase 3 and passes B2, B1 deal a cloud's tiles to several workgroups below a full chip
+    (alignnet_train.hip pn_parts / p3_parts; the reference's shipped configs train at batch 128 x 512 points = 256 clouds).  Everything those kernels leave behind is a
+    per-workgroup partial SUM (statistics, Gram(h1), Gram(h2), column sums, U2, Pdy, (dbeta, dgamma)), per-row (h2, dy2), or a running extreme that
+    merge_ext_parts_kernel folds in tile order (exactly the one-workgroup scan): same step up to the grouping of the sums."""
     cfg, spec, P32, d, du = TT._setup(N, B, std=True)
     runs = {}
     for parts in (1, 2, 4, 0):
@@ -121,15 +122,21 @@ def test_pointnet_cloud_parts_match_one_workgroup_per_cloud(gpu_required, bf16, 
         assert eng.get_option("pn_cloud_parts") == parts
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, [du[k] for k in ("s1_0", "s2_0", "s1_1", "s2_1", "rem")])
         names = [n for n, _, tr in eng.variables() if tr]
-        runs[parts] = (res, np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names]))
+        runs[parts] = (res, np.concatenate([eng.get_gradient(n).astype(np.float64).ravel() for n in names]), eng.debug_train_decisions(B)["pool"][0])
         eng.close()
-    r1, g1 = runs[1]
+    r1, g1, w1 = runs[1]
     for parts in (2, 4, 0):
-        r, g = runs[parts]
+        r, g, win = runs[parts]
         rl2 = float(np.linalg.norm(g - g1) / np.linalg.norm(g1))
         dp = max(float(np.abs(np.asarray(r[k]) - np.asarray(r1[k])).max()) for k in alignnet3d.OUTPUT_NAMES)
-        print("pointnet bf16=%d N=%d parts %d vs 1: predictions %.1e, gradient relative L2 %.1e" % (bf16, N, parts, dp, rl2))
+        moved = float((win != w1).mean())
+        print("pointnet bf16=%d N=%d parts %d vs 1: predictions %.1e, gradient relative L2 %.1e, stage-1 max-pool winners that moved %.1e" % (bf16, N, parts, dp, rl2, moved))
         if bf16:
+            # stage 1 sees the same points, its hidden-layer statistics are fp64 partials (regrouping them is exact), so the rounded h2 and the lift are
+            # bit-equal and the folded running extremes must pick the SAME winners; what differs is Gram(h2) (fp32 per workgroup), i.e. the last layer's
+            # scale / shift in the last bits -> the later stages' points move by ~1e-7 and bf16 operands fall on the other side of a rounding boundary
+            assert moved == 0.0, (parts, moved)
             assert dp <= 5e-2 and rl2 <= 0.3, (parts, dp, rl2)
         else:
+            assert moved <= 2e-3, (parts, moved)   # (fp32: the first-layer Gram is regrouped too -- h2 in the last bits, near-ties may fall the other way)
             assert dp <= 1e-4 and rl2 <= 2e-2, (parts, dp, rl2)

@@ -620,6 +620,7 @@ def test_phase3_tile_shapes_agree(gpu_required, N, B, bf16):
         eng.set_variables(P32)
         eng.set_option("train_phase3_tile64", t64)
         eng.set_option("train_matmul_bf16", bf16)
+        eng.set_option("pn_cloud_parts", 1)   # one workgroup per cloud in both: the tile shapes are what is compared (the split: test_ab_variants_gpu.py)
         assert eng.get_option("train_phase3_tile64") == t64
         res = eng.train_forward_backward(d["pcs1"], d["pcs2"], d, ul)
         out.append((res, {n: eng.get_gradient(n).copy() for n in R.trainable_names(spec)},
