@@ -973,6 +973,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t n = (size_t)2 * B * 2 * C3;
     hipLaunchKernelGGL(merge_ext_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S.extp, S.idxp, p3, C3, n, S.ext, S.idx2);
   };
+  int pool_parts = 1;   // dg_pool_finish: workgroups per cloud (its column-sum slices)
   if (dg) {
     // edge part (kernels_train_dgcnn.h): statistics over the B*N*k edge rows, then p = max_k h2 -> S.h2, arg-k -> S.argk
     const double ecount = count * kDgK;
@@ -986,7 +987,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     const size_t dlds = (h->train_bf16 ? (size_t)2 * kTT * 8 * sizeof(float) + 2 * ((size_t)kTT * (C1 + 8) + (size_t)C1 * (kTT + 8)) * sizeof(unsigned short)
                                        : ((size_t)2 * kTT * 8 + 2 * (size_t)kTT * d.ld0) * sizeof(float))   // two edge-feature buffers | two lift buffers
                         + (size_t)nG1 * 16 * 64 * sizeof(double);
-    hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(256), 0, h->stream, d);
+    hipLaunchKernelGGL(dg_train_phase1, dim3(2 * B), dim3(kP1T), 0, h->stream, d);
     if (finish(0, C1, 1, ecount)) return 1;
     for (int t = 0; t < 2; ++t) d.gamma2[t] = P(h, L[1]->p_bn[t][1]);
     d.stamps = (a.dbg & 32) ? reinterpret_cast<long long*>(w->loss_scratch) + 48 : nullptr;
@@ -1017,7 +1018,10 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
                          h->train_bf16 ? 1 : 0, w->stat_part);   // bf16 mode: Gram and sums are those of the rounded h1, W2 is rounded here
     }
     if (finish(1, C2, 1, ecount, 1, true)) return 1;
-    hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part);
+    // (a stream over the cloud's rows: four workgroups per CU fill the chip; 2B * parts slices of 2 C2 doubles fit the max(2B, 512) x 1024 carve up to C2 = 256)
+    pool_parts = std::max(1, std::min(std::min(8, 1024 / (2 * B)), N / 64));
+    if ((size_t)2 * B * pool_parts * 2 * C2 > std::max((size_t)2 * B, (size_t)kDgPartSlices) * 1024) pool_parts = 1;
+    hipLaunchKernelGGL(dg_pool_finish, dim3(2 * B * pool_parts), dim3(256), 0, h->stream, S.h2, B, N, C2, S.scale[1], S.shift[1], w->colsum_part, pool_parts);
   } else if (hyb) {
     // layers 1 .. n - 1 layer by layer, then h = relu(bn(Z_{n-1})) once, with its column sums; sign(gamma) of the last layer
     if (backbone_fwd_generic(h, s, p1, p2, B, bn_decay, update_ema, st.n - 1)) return 1;
@@ -1094,7 +1098,7 @@ static int backbone_fwd_train(alignnet_handle* h, int s, const float* p1, const 
     if (!wide_gram) { ProfScope prof_scope(h, PK_TRAIN_GRAM, true);
     TIMED_LAUNCH(C2 == 128 ? gram_h2_kernel<128> : gram_h2_kernel<0>, dim3(2 * B), dim3(kTW * 64), (size_t)2 * kTT * (C2 + 4) * sizeof(float), S.h2, N, C2, w->gram_part);
     }
-    if (finish_and_reduce(rjob(w->gram_part, B * p3, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 : 1) * B, (long)(C2), S.s2))) return 1;   // (column sums: the producer's)
+    if (finish_and_reduce(rjob(w->gram_part, B * p3, (long)(C2 * C2), S.gram2), rjob(w->colsum_part, (dg ? 2 * pool_parts : 1) * B, (long)(C2), S.s2))) return 1;   // (column sums: the producer's)
     }
   } else {
   // phase 1 from the cloud's moments of x' (kept in S.mom for the first-layer backward)

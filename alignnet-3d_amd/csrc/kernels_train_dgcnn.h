@@ -83,11 +83,14 @@ __device__ __forceinline__ void dgt_points(const float* __restrict__ pc, int N, 
 }
 
 // ---------------------------------------------------------------------------------
-// phase 1: moments of e per cloud -> statistics of z1.   grid 2B, block 256
+// phase 1: moments of e per cloud -> statistics of z1.   grid 2B, block kP1T
+// (a gather-latency chain per edge row: sixteen waves per cloud instead of four -- at N = 4096, 128 clouds of 256 threads left most of the chip's wave
+//  slots empty; the fp64 moments are summed in another grouping, nothing else changes)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dg_train_phase1(const DgTrainArgs a)
+constexpr int kP1T = 1024;
+__global__ __launch_bounds__(kP1T) void dg_train_phase1(const DgTrainArgs a)
 {
-  __shared__ double red[4][kDgMom];
+  __shared__ double red[kP1T / 64][kDgMom];
   __shared__ double tot[kDgMom];
   const int cloud = blockIdx.x, tower = cloud >= a.B, b = cloud - tower * a.B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void dg_train_phase1(const DgTrainArgs a)
 #pragma unroll
   for (int i = 0; i < kDgMom; ++i) m[i] = 0.0;
   const int rows = a.N * a.k;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += kP1T) {
     const int n = r / a.k, slot = r - n * a.k;
     float v[6], e[6];
     dgt_gather(pc, nnc, a.N, a.k, n, slot, v);
@@ -120,12 +123,14 @@ __global__ __launch_bounds__(256) void dg_train_phase1(const DgTrainArgs a)
   }
   __syncthreads();
   if (threadIdx.x < kDgMom) {
-    const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    double t = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < kP1T / 64; ++wv) t += red[wv][threadIdx.x];
     tot[threadIdx.x] = t;
     a.mom[(size_t)cloud * kDgMom + threadIdx.x] = t;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < a.C1; c += 256) {
+  for (int c = threadIdx.x; c < a.C1; c += kP1T) {
     double w[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) w[d] = (double)a.w1[d * a.C1 + c];
@@ -516,29 +521,32 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
   }
 }
 
-// p = relu(scale * acc* + shift) in place over the cloud's [N][C2] rows, and the column sums of p.  grid 2B, block 256
+// p = relu(scale * acc* + shift) in place over the cloud's [N][C2] rows, and the column sums of p.  grid 2B * parts, block 256: workgroup = cloud * parts + part
+// streams rows [N part / parts, N (part + 1) / parts) and leaves its own column-sum slice (a pure stream: 4 MB per cloud at N = 4096 -- one workgroup per cloud is
+// 128 of them on 256 CUs at B = 64)
 __global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int B, int N, int C2, const float* __restrict__ sc2,
-                                                      const float* __restrict__ sh2, double* __restrict__ colsum_part)
+                                                      const float* __restrict__ sh2, double* __restrict__ colsum_part, int parts)
 {
   __shared__ double red[256][4];
-  const int cloud = blockIdx.x, tower = cloud >= B, tid = threadIdx.x;
+  const int vcloud = blockIdx.x, cloud = vcloud / parts, part = vcloud - cloud * parts, tower = cloud >= B, tid = threadIdx.x;
   const int c4 = C2 >> 2, G = 256 / c4, q = tid % c4, g = tid / c4;
   float* base = p + (size_t)cloud * N * C2;
+  const int rbeg = (int)((long)N * part / parts), rend = (int)((long)N * (part + 1) / parts);
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (g < G) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(sc2 + tower * C2 + q * 4), sh = *reinterpret_cast<const f32x4*>(sh2 + tower * C2 + q * 4);
-    for (int r0 = g; r0 < N; r0 += G * 4) {
+    for (int r0 = rbeg + g; r0 < rend; r0 += G * 4) {
       f32x4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = r0 + u * G;
-        v[u] = r < N ? *reinterpret_cast<const f32x4*>(base + (size_t)r * C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[u] = r < rend ? *reinterpret_cast<const f32x4*>(base + (size_t)r * C2 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = r0 + u * G;
-        if (r < N) {
+        if (r < rend) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = fmaxf(fmaf(v[u][e], sc[e], sh[e]), 0.f); ps[e] += o[e]; }
@@ -557,8 +565,8 @@ __global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int
     for (int e = 0; e < 4; ++e) {
       double t = 0.0;
       for (int gg = 0; gg < G; ++gg) t += red[gg * c4 + tid][e];
-      colsum_part[((size_t)cloud * 2) * C2 + tid * 4 + e] = t;
-      colsum_part[((size_t)cloud * 2 + 1) * C2 + tid * 4 + e] = 0.0;
+      colsum_part[((size_t)vcloud * 2) * C2 + tid * 4 + e] = t;
+      colsum_part[((size_t)vcloud * 2 + 1) * C2 + tid * 4 + e] = 0.0;
     }
   }
 }
