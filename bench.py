@@ -29,6 +29,7 @@ import math
 import os
 import re
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -429,6 +430,9 @@ def main():
                                                              "(engine options sync_bn + global_loss: the reference's single-device semantics); 0 = local BN / local loss")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step back to back for at least this long (clock-settled rate + sclk readings); 0 = off")
+    ap.add_argument("--secondary-timeout", type=float, default=240.0,
+                    help="--gpus > 1 under torch.distributed.run: if the legs AFTER the headline measurement (single-rank reference, sustained loop, training legs over "
+                         "RCCL) have not finished after this many seconds, rank 0 prints the line with what is complete and every rank exits (0 = no watchdog)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short dgcnn / loader / icp legs the default --gpus 1 inference run appends")
     ap.add_argument("--grad-communicator", type=int, default=0,
                     help="data-parallel training: 1 = the gradient buckets travel on a second RCCL communicator of their own (alignnet_comm_init_grad), so that "
@@ -789,155 +793,14 @@ def run_rank(args, real_stdout, threads):
         leg_tag = "train_dgcnn" if dg else ("train_bf16" if args.train_dtype == "bf16" else "train")
     head_roof = roofline(kern, args.steps, head_bf16, leg_tag, backbone_kernel)
 
-    # ---- world > 1: what ONE rank of this very run does with the node to itself -- the N = 1 value this line scales from (rank 0 steps alone, the
-    #      other ranks wait at the fence), so that the scaling efficiency value / (n_gpus x this) is computable from this one line
-    single_rank = None
-    if dist is not None and world > 1:
-        fence()
-        if rank == 0:
-            e1 = eng
-            if args.mode == "train":   # (an engine of its own: the headline engine's step joins the communicator's collectives)
-                e1 = alignnet3d.Engine(cfg, device=local_rank, seed=0)
-                e1.set_option("train_matmul_bf16", int(args.train_dtype == "bf16"))
-                step1 = lambda: e1.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
-            else:
-                step1 = infer_step
-            for _ in range(max(args.warmup, 3)):
-                step1()
-            e1.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step1()
-            e1.synchronize()
-            d1 = time.perf_counter() - t1
-            single_rank = {"value": round(B * args.steps / d1, 1), "unit": "pairs/s", "ms_per_step": round(d1 / args.steps * 1e3, 4), "steps": args.steps, "n_gpus": 1,
-                           "what": "rank 0 alone, the other ranks idle at a barrier: the same step" + (" on a fresh engine without a communicator (local-BN, no all-reduce)" if args.mode == "train" else "") +
-                                   "; scaling efficiency of this line = value / (n_gpus x this value)"}
-            if e1 is not eng:
-                e1.close()
-        fence()
+    # ---- from here on the headline (`value`, `roofline`) is measured.  On real ranks (one process per GPU) the legs below are the first thing that ever runs over
+    #      RCCL at world > 1 on this code base's behalf: a watchdog makes sure a leg that hangs there costs the leg, not the line.
+    single_rank = sustained = split_info = train_info = pcie_info = extra = None
+    head_sync_bn = {}
+    line_lock, line_written = threading.Lock(), [False]
 
-    # ---- the same step, back to back for >= --sustained-seconds: the K-step region above is a burst of tens of milliseconds; this one
-    #      is long enough for the clocks to settle (sclk sampled from rocm-smi while the queue is full, first and last chunk)
-    sustained = None
-    if args.sustained_seconds > 0:
-        per = max(dt / args.steps, 1e-5)
-        chunk = max(1, int(0.25 / per))
-        clk = [None, None]
-        fence()
-        n_s, t0 = 0, time.perf_counter()
-        while True:
-            for _ in range(chunk):
-                step()
-            n_s += chunk
-            if clk[0] is None and rank == 0:
-                clk[0] = sclk_mhz(local_rank) or 0
-            eng.synchronize()
-            last = time.perf_counter() - t0 >= args.sustained_seconds
-            if dist is not None:   # every rank leaves the loop in the same round
-                flag = torch.tensor([1.0 if last else 0.0], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                last = bool(flag.item() > 0)
-            if last:
-                for _ in range(chunk):
-                    step()
-                n_s += chunk
-                if rank == 0:
-                    clk[1] = sclk_mhz(local_rank)
-                break
-        fence()
-        sdt_all = max_over_ranks(time.perf_counter() - t0)
-        sustained = {"value": round(world * B * n_s / sdt_all, 1), "unit": "pairs/s", "ms_per_step": round(sdt_all / n_s * 1e3, 4), "steps": n_s,
-                     "seconds": round(sdt_all, 2), "sclk_mhz_first_chunk": clk[0] or None, "sclk_mhz_last_chunk": clk[1],
-                     "what": "the headline step back to back (chunks of %d steps, one host synchronisation and two rocm-smi reads in between); "
-                             "`value` of the line stays the K-step figure" % chunk}
-
-    # ------------------------------------------------- secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline)
-    split_info = None
-    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_split_leg:
-        ref_out = {k: v.clone() for k, v in outs.items()}
-        eng.set_option("infer_matmul_bf16x3", 1)
-        ksteps = steps_for(infer_step, 10)
-        sdt, skern = time_leg(infer_step, ksteps, 2)
-        diff = max(float((outs[k] - ref_out[k]).abs().max().item()) for k in outs)
-        split_info = {"value": round(world * B * ksteps / sdt, 1), "unit": "pairs/s", "ms_per_step": round(sdt / ksteps * 1e3, 4), "steps": ksteps,
-                      "dtype": "bf16x3 (x = hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate)",
-                      "roofline": roofline(skern, ksteps, True, "split", eng.last_backbone_kernel().split("<")[0]),
-                      "max_abs_diff_vs_exact_fp32_outputs": diff,
-                      "what": "opt-in inference mode alignnet_set_option(infer_matmul_bf16x3); parity bar 1e-4 (tests/test_forward_gpu.py)"}
-        eng.set_option("infer_matmul_bf16x3", 0)
-
-    # ------------------------------- secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA)
-    train_info = None
-    if args.mode == "infer" and want_train:
-      try:   # (a secondary leg must not cost the headline line: the communicator is created here, after the inference legs)
-        if dist_on:
-            init_rccl()
-        train_info = {}
-        for tdtype in ("f32", "bf16"):
-            eng.set_option("train_matmul_bf16", int(tdtype == "bf16"))
-            ksteps = steps_for(train_step, 5)
-            tdt, _ = time_leg(train_step, ksteps, 1, timers=False)     # the leg's value: the step as a user runs it
-            tdt_on, tkern = time_leg(train_step, ksteps, 1)              # the same K steps again under the kernel timers: roofline, step_share
-            leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
-                   "ms_per_step_under_kernel_timers": round(tdt_on / ksteps * 1e3, 3), "steps": ksteps, "dtype": tdtype,
-                   "roofline": roofline(tkern, ksteps, tdtype == "bf16", "train_bf16" if tdtype == "bf16" else "train", "train"),
-                   "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY, "bn_mode": bn_mode,
-                   "what": "train step: batch-stat forward + loss + backward + " +
-                           ("RCCL all-reduce (%s) + " % ("3 buckets overlapped with the backward" if args.allreduce_overlap else "one call after the backward")
-                            if dist_on else "") + "Adam + EMA, " + ("sync-BN + global-loss data parallel (the single-device step at the global batch)" if args.sync_bn else "local-BN data parallel") +
-                           ("; MFMA convs on bf16 operands, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
-            if dist_on:
-                leg["rccl_ranks"] = rccl_ranks
-                leg["allreduce_exposed_ms_per_step"] = round(tkern.get("allreduce", (0.0, 0))[0] / ksteps, 4)
-                leg["per_rank_pairs_per_s"] = per_rank_rates(time_leg.last_per_rank, ksteps)
-                leg.update(sync_bn_fields())
-            if tdtype == "f32":
-                train_info = leg
-            else:
-                train_info["bf16"] = leg
-        eng.set_option("train_matmul_bf16", 0)
-      except Exception as e:   # noqa: BLE001 -- reported in the line, the other legs stand
-        train_info = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # -------------- secondary leg: PCIe-inclusive inference, the reference's own timing methodology (train.py:447-449), rank 0's GPU only
-    pcie_info = None
-    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_pcie_leg and rank == 0:
-        for _ in range(2):
-            eng.forward(d["pcs1"], d["pcs2"])
-        kp = max(10, int(math.ceil(args.min_leg_seconds / 2.5e-3)))
-        t0 = time.perf_counter()
-        for _ in range(kp):
-            eng.forward(d["pcs1"], d["pcs2"])
-        pdt = time.perf_counter() - t0
-        pcie_info = {"value": round(B * kp / pdt, 1), "unit": "pairs/s", "ms_per_step": round(pdt / kp * 1e3, 4), "steps": kp, "n_gpus": 1,
-                     "what": "pageable host buffers in (2 x %.1f MB) and out, blocking alignnet_forward per batch -- the feed copy is inside the "
-                             "timed region as in the reference's timing (train.py:447-449); not the headline value" % (B * npts * 12 / 1e6)}
-        # the same host-to-host work through the pipelined path: pinned staging, copy-in of batch i + 1 under the forward of batch i
-        for _ in range(3):
-            eng.forward_submit(d["pcs1"], d["pcs2"]); eng.forward_wait()
-        t0 = time.perf_counter()
-        inflight = 0
-        for _ in range(kp):
-            if inflight == 2:
-                eng.forward_wait(); inflight -= 1
-            eng.forward_submit(d["pcs1"], d["pcs2"]); inflight += 1
-        while inflight:
-            eng.forward_wait(); inflight -= 1
-        qdt = time.perf_counter() - t0
-        pcie_info["pipelined"] = {"value": round(B * kp / qdt, 1), "unit": "pairs/s", "ms_per_step": round(qdt / kp * 1e3, 4), "steps": kp,
-                                  "what": "alignnet_forward_submit / _wait: the same pageable buffers in and out, two batches in flight (pinned staging, "
-                                          "H2D on a copy stream under the previous batch's forward, D2H on a third stream)"}
-    # ---- short dgcnn / loader / icp legs (default one-GPU inference run only)
-    extra = None
-    if not dist_on and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
-        extra = extra_legs(eng, local_rank, args.min_leg_seconds)
-    # the headline training leg's sync-BN latency probe is a collective: EVERY rank runs it (only rank 0 writes the line)
-    head_sync_bn = sync_bn_fields() if (dist_on and args.mode == "train") else {}
-    if dist is not None:
-        dist.barrier()
-
-    if rank == 0:
+    def write_line(note=None):
+        """rank 0: the one JSON line, from whatever legs have completed (all of them unless the watchdog calls)"""
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         line = {
@@ -1000,9 +863,181 @@ def run_rank(args, real_stdout, threads):
             line["cpu_baseline"] = cpu_info
         if extra is not None:
             line.update(extra_seconds=extra.pop("seconds"), **extra)
-        line["options"] = engine_options(eng)   # as the legs left them (allreduce_overlap, sync_bn, ... are set after the engine is created)
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if note is None:
+            line["options"] = engine_options(eng)   # as the legs left them (allreduce_overlap, sync_bn, ... are set after the engine is created)
+        else:
+            line["incomplete"] = note   # (written from the watchdog thread: the engine may be inside the call that hangs -- not asked for its options)
+        with line_lock:
+            if line_written[0]:
+                return
+            line_written[0] = True
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+    watchdog = None
+    if dist is not None and (world > 1 or args.force_dist) and threads is None and args.secondary_timeout > 0:
+        def fire():
+            if rank == 0:
+                try:
+                    write_line(note="watchdog: the legs after the headline measurement did not finish within %.0f s; the headline fields were measured normally, "
+                                    "sections that had completed are included" % args.secondary_timeout)
+                except Exception as e:   # noqa: BLE001
+                    sys.stderr.write("bench.py watchdog: could not write the line: %s\n" % e)
+            else:
+                time.sleep(2.0)   # rank 0 writes first
+            os._exit(0 if rank else (0 if line_written[0] else 1))
+        watchdog = threading.Timer(args.secondary_timeout, fire)
+        watchdog.daemon = True
+        watchdog.start()
+        if os.environ.get("BENCH_TEST_HANG_AFTER_HEADLINE"):   # test hook (tests/test_bench_contract_gpu.py): stand for a collective that never returns
+            time.sleep(3600)
+
+    # ---- world > 1: what ONE rank of this very run does with the node to itself -- the N = 1 value this line scales from (rank 0 steps alone, the
+    #      other ranks wait at the fence), so that the scaling efficiency value / (n_gpus x this) is computable from this one line
+    if dist is not None and world > 1:
+        fence()
+        if rank == 0:
+            e1 = eng
+            if args.mode == "train":   # (an engine of its own: the headline engine's step joins the communicator's collectives)
+                e1 = alignnet3d.Engine(cfg, device=local_rank, seed=0)
+                e1.set_option("train_matmul_bf16", int(args.train_dtype == "bf16"))
+                step1 = lambda: e1.train_step_device(p1.data_ptr(), p2.data_ptr(), lab_ptrs, B)
+            else:
+                step1 = infer_step
+            for _ in range(max(args.warmup, 3)):
+                step1()
+            e1.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            e1.synchronize()
+            d1 = time.perf_counter() - t1
+            single_rank = {"value": round(B * args.steps / d1, 1), "unit": "pairs/s", "ms_per_step": round(d1 / args.steps * 1e3, 4), "steps": args.steps, "n_gpus": 1,
+                           "what": "rank 0 alone, the other ranks idle at a barrier: the same step" + (" on a fresh engine without a communicator (local-BN, no all-reduce)" if args.mode == "train" else "") +
+                                   "; scaling efficiency of this line = value / (n_gpus x this value)"}
+            if e1 is not eng:
+                e1.close()
+        fence()
+
+    # ---- the same step, back to back for >= --sustained-seconds: the K-step region above is a burst of tens of milliseconds; this one
+    #      is long enough for the clocks to settle (sclk sampled from rocm-smi while the queue is full, first and last chunk)
+    if args.sustained_seconds > 0:
+        per = max(dt / args.steps, 1e-5)
+        chunk = max(1, int(0.25 / per))
+        clk = [None, None]
+        fence()
+        n_s, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(chunk):
+                step()
+            n_s += chunk
+            if clk[0] is None and rank == 0:
+                clk[0] = sclk_mhz(local_rank) or 0
+            eng.synchronize()
+            last = time.perf_counter() - t0 >= args.sustained_seconds
+            if dist is not None:   # every rank leaves the loop in the same round
+                flag = torch.tensor([1.0 if last else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                last = bool(flag.item() > 0)
+            if last:
+                for _ in range(chunk):
+                    step()
+                n_s += chunk
+                if rank == 0:
+                    clk[1] = sclk_mhz(local_rank)
+                break
+        fence()
+        sdt_all = max_over_ranks(time.perf_counter() - t0)
+        sustained = {"value": round(world * B * n_s / sdt_all, 1), "unit": "pairs/s", "ms_per_step": round(sdt_all / n_s * 1e3, 4), "steps": n_s,
+                     "seconds": round(sdt_all, 2), "sclk_mhz_first_chunk": clk[0] or None, "sclk_mhz_last_chunk": clk[1],
+                     "what": "the headline step back to back (chunks of %d steps, one host synchronisation and two rocm-smi reads in between); "
+                             "`value` of the line stays the K-step figure" % chunk}
+
+    # ------------------------------------------------- secondary leg: the opt-in split-bf16 backbone on the same batch (never the headline)
+    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_split_leg:
+        ref_out = {k: v.clone() for k, v in outs.items()}
+        eng.set_option("infer_matmul_bf16x3", 1)
+        ksteps = steps_for(infer_step, 10)
+        sdt, skern = time_leg(infer_step, ksteps, 2)
+        diff = max(float((outs[k] - ref_out[k]).abs().max().item()) for k in outs)
+        split_info = {"value": round(world * B * ksteps / sdt, 1), "unit": "pairs/s", "ms_per_step": round(sdt / ksteps * 1e3, 4), "steps": ksteps,
+                      "dtype": "bf16x3 (x = hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate)",
+                      "roofline": roofline(skern, ksteps, True, "split", eng.last_backbone_kernel().split("<")[0]),
+                      "max_abs_diff_vs_exact_fp32_outputs": diff,
+                      "what": "opt-in inference mode alignnet_set_option(infer_matmul_bf16x3); parity bar 1e-4 (tests/test_forward_gpu.py)"}
+        eng.set_option("infer_matmul_bf16x3", 0)
+
+    # ------------------------------- secondary leg: full training step (fwd with batch statistics + loss + bwd + all-reduce + Adam + EMA)
+    if args.mode == "infer" and want_train:
+      try:   # (a secondary leg must not cost the headline line: the communicator is created here, after the inference legs)
+        if dist_on:
+            init_rccl()
+        train_info = {}
+        for tdtype in ("f32", "bf16"):
+            eng.set_option("train_matmul_bf16", int(tdtype == "bf16"))
+            ksteps = steps_for(train_step, 5)
+            tdt, _ = time_leg(train_step, ksteps, 1, timers=False)     # the leg's value: the step as a user runs it
+            tdt_on, tkern = time_leg(train_step, ksteps, 1)              # the same K steps again under the kernel timers: roofline, step_share
+            leg = {"value": round(world * B * ksteps / tdt, 1), "unit": "pairs/s", "ms_per_step": round(tdt / ksteps * 1e3, 3),
+                   "ms_per_step_under_kernel_timers": round(tdt_on / ksteps * 1e3, 3), "steps": ksteps, "dtype": tdtype,
+                   "roofline": roofline(tkern, ksteps, tdtype == "bf16", "train_bf16" if tdtype == "bf16" else "train", "train"),
+                   "flops_per_pair_survey": FLOPS_PER_PAIR_TRAIN_SURVEY, "bn_mode": bn_mode,
+                   "what": "train step: batch-stat forward + loss + backward + " +
+                           ("RCCL all-reduce (%s) + " % ("3 buckets overlapped with the backward" if args.allreduce_overlap else "one call after the backward")
+                            if dist_on else "") + "Adam + EMA, " + ("sync-BN + global-loss data parallel (the single-device step at the global batch)" if args.sync_bn else "local-BN data parallel") +
+                           ("; MFMA convs on bf16 operands, fp32 accumulate (BASELINE.json configs[2])" if tdtype == "bf16" else "")}
+            if dist_on:
+                leg["rccl_ranks"] = rccl_ranks
+                leg["allreduce_exposed_ms_per_step"] = round(tkern.get("allreduce", (0.0, 0))[0] / ksteps, 4)
+                leg["per_rank_pairs_per_s"] = per_rank_rates(time_leg.last_per_rank, ksteps)
+                leg.update(sync_bn_fields())
+            if tdtype == "f32":
+                train_info = leg
+            else:
+                train_info["bf16"] = leg
+        eng.set_option("train_matmul_bf16", 0)
+      except Exception as e:   # noqa: BLE001 -- reported in the line, the other legs stand
+        train_info = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # -------------- secondary leg: PCIe-inclusive inference, the reference's own timing methodology (train.py:447-449), rank 0's GPU only
+    if args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_pcie_leg and rank == 0:
+        for _ in range(2):
+            eng.forward(d["pcs1"], d["pcs2"])
+        kp = max(10, int(math.ceil(args.min_leg_seconds / 2.5e-3)))
+        t0 = time.perf_counter()
+        for _ in range(kp):
+            eng.forward(d["pcs1"], d["pcs2"])
+        pdt = time.perf_counter() - t0
+        pcie_info = {"value": round(B * kp / pdt, 1), "unit": "pairs/s", "ms_per_step": round(pdt / kp * 1e3, 4), "steps": kp, "n_gpus": 1,
+                     "what": "pageable host buffers in (2 x %.1f MB) and out, blocking alignnet_forward per batch -- the feed copy is inside the "
+                             "timed region as in the reference's timing (train.py:447-449); not the headline value" % (B * npts * 12 / 1e6)}
+        # the same host-to-host work through the pipelined path: pinned staging, copy-in of batch i + 1 under the forward of batch i
+        for _ in range(3):
+            eng.forward_submit(d["pcs1"], d["pcs2"]); eng.forward_wait()
+        t0 = time.perf_counter()
+        inflight = 0
+        for _ in range(kp):
+            if inflight == 2:
+                eng.forward_wait(); inflight -= 1
+            eng.forward_submit(d["pcs1"], d["pcs2"]); inflight += 1
+        while inflight:
+            eng.forward_wait(); inflight -= 1
+        qdt = time.perf_counter() - t0
+        pcie_info["pipelined"] = {"value": round(B * kp / qdt, 1), "unit": "pairs/s", "ms_per_step": round(qdt / kp * 1e3, 4), "steps": kp,
+                                  "what": "alignnet_forward_submit / _wait: the same pageable buffers in and out, two batches in flight (pinned staging, "
+                                          "H2D on a copy stream under the previous batch's forward, D2H on a third stream)"}
+    # ---- short dgcnn / loader / icp legs (default one-GPU inference run only)
+    if not dist_on and args.mode == "infer" and not dg and args.infer_dtype == "f32" and not args.no_extra_legs:
+        extra = extra_legs(eng, local_rank, args.min_leg_seconds)
+    # the headline training leg's sync-BN latency probe is a collective: EVERY rank runs it (only rank 0 writes the line)
+    head_sync_bn = sync_bn_fields() if (dist_on and args.mode == "train") else {}
+    if dist is not None:
+        dist.barrier()
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        write_line()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

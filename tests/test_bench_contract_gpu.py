@@ -14,8 +14,8 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline")
 
 
-def _run(*args):
-    env = dict(os.environ)
+def _run(*args, **extra_env):
+    env = dict(os.environ, **extra_env)
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -108,6 +108,16 @@ def test_force_dist_rehearsal_at_world_1(gpu_required, args):
     else:
         for leg in (d["train"], d["train"]["bf16"]):
             assert leg["rccl_ranks"] == 1 and leg["bn_mode"] == "local" and leg["per_rank_pairs_per_s"]["ranks"] == 1, leg
+
+
+def test_a_hung_secondary_leg_costs_the_leg_not_the_line(gpu_required):
+    """Real ranks (torch.distributed.run): everything after the headline measurement -- the single-rank reference, the sustained loop, the training legs over
+    RCCL -- runs under a watchdog (--secondary-timeout).  With a stand-in for a collective that never returns (BENCH_TEST_HANG_AFTER_HEADLINE) rank 0 still
+    prints the one line, complete in its contract fields and marked `incomplete`, and the processes exit 0."""
+    d = _run("--force-dist", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--secondary-timeout", "3", BENCH_TEST_HANG_AFTER_HEADLINE="1")
+    _check_common(d, 5, 1)
+    assert "watchdog" in d["incomplete"] and "train" not in d and "sustained" not in d
+    assert d["roofline"]["frac"] > 0.5 and d["per_rank_pairs_per_s"]["ranks"] == 1
 
 
 @pytest.mark.parametrize("args", [("--mode", "train", "--train-dtype", "bf16", "--sync-bn", "1"),
