@@ -363,8 +363,9 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   "ab_phase2_legacy", "ab_b1_legacy", "ab_b1_fp32", "ab_p3_bf16_generic", "ab_p3_nogram", "ab_no_defer", "ab_dg_sparse",
  *   "ab_no_glue_fold", "ab_gemm_jobs_ksplit", "ab_fc_direct", "ab_fc_no_splitk", "ab_split_tilewise" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic);
  *   "dg_cloud_parts" (dgcnn training: workgroups per cloud of the edge kernels, 0 = as many as fill the chip at this batch, 1 .. 8 = fixed; results agree up to the grouping of partial sums);
- *   "pn_cloud_parts" (PointNet training: the same split for phase 2 / the first-layer Gram and passes B2, B1 -- they run two workgroups per CU, so the chip is
- *   full from 2B = 512 clouds and the reference's shipped batch of 128 brings 256; phase 3 keeps one workgroup per cloud).
+ *   "pn_cloud_parts" (the same split for the per-cloud kernels both backbones share: phase 2 / the first-layer Gram, phase 3 -- the lift to C3 with its running
+ *   arg-extreme and Gram, the parts' extremes folded exactly in tile order -- and passes B2, B1; the chip is full from 2B = 256 (128-point-tile kernels) or 512
+ *   clouds, the reference's shipped batch of 128 brings 256; 0 = automatic, 1 .. 8 = fixed).
  *   "ab_mask" (read-only) = the bits that are set; bench.py prints it.  The library reads NO environment variable; result-changing
  *   ablation switches exist only in the separate ablation build (csrc/ablate.h, `make ablate`).
  * Read-only keys (alignnet_get_option; parity tests use them to assert which kernel instantiation ran, since the shipped

@@ -1,5 +1,5 @@
 # Run ON THE GPU BOX (via gpurun): every bench line and rocprofv3 summary that profiles/<round>_* holds, in one call.
-# Usage: bash tools/refresh_profiles.sh r02 [quick]
+# Usage: bash tools/refresh_profiles.sh r02 [lines]
 set -u
 R=${1:-r04}
 mkdir -p gpurun_out/fin
@@ -14,6 +14,9 @@ python bench.py --mode train --workload dgcnn --batch 512 --steps 2 --warmup 1 -
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --points 1024 --steps 10 --warmup 2 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n1024.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 64 --steps 5 --warmup 1 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b64.json 2>/dev/null
 python bench.py --mode train --workload dgcnn --train-dtype bf16 --batch 512 --steps 3 --warmup 1 --sustained-seconds 0 > gpurun_out/fin/${R}_bench_train_dgcnn_bf16_n4096_b512.json 2>/dev/null
+if [ "${2:-}" = "lines" ]; then   # bench lines only (no rocprofv3 passes): after a change that leaves the profiled kernels alone
+  mkdir -p gpurun_out/profiles_${R}; cp gpurun_out/fin/${R}_bench*.json gpurun_out/profiles_${R}/; ls gpurun_out/profiles_${R}; cut -c1-180 gpurun_out/fin/${R}_bench.json; exit 0
+fi
 Q="--no-cpu-baseline --no-train-leg --no-split-leg --no-pcie-leg --no-extra-legs --sustained-seconds 0"
 S="--sustained-seconds 0"
 bash tools/profile.sh ${R} --steps 20 --warmup 3 $Q > gpurun_out/fin/p_${R}.log 2>&1
