@@ -27,6 +27,52 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned
   lo = to_bf16_bits(x - __uint_as_float((unsigned)hi << 16));
 }
 
+// two fp32 -> (hi, lo) bf16 pairs: hi = RNE(x) (one v_cvt_pk_bf16_f32 for both), lo = RNE(x - hi); the same values split_bf16 gives
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi, unsigned& lo)
+{
+  const f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
+}
+
+// The K = 3 lift of a 128-point tile for C1 = 64 on the matrix pipe (round 6; the DGCNN kernels lift this way since rounds 3 / 5): k padded to 4 -- xs rows are
+// {x', y', z', 0} and the weight fragment of the fourth k is zero -- and the [128 rows][64 channels] output cut into 16 x 16 tiles of v_mfma_f32_16x16x4_f32, ONE
+// instruction per tile: wave w takes rows 16 w .. 16 w + 15 and the four channel tiles, as the TRANSPOSED product (weights as the A operand), so a lane ends up with
+// one row and four adjacent channels -- one v_cvt_pk pair and one 8-byte store each for the hi and the lo tile.  Per lane and tile: one 4-byte LDS read, four
+// MFMAs, 4 x (two 16-byte parameter reads, ~20 vector instructions, two 8-byte stores) instead of 16 x (5 vector instructions) + the splits of the VALU form.
+// w1 [3][64], sc / sh [64] (LDS tables or global memory); th / tl: the tile's hi / lo images, row stride 72.  Both split kernels of the shipped widths call
+// this, so they stay bit-identical to each other (tests/test_forward_gpu.py); against the VALU lift the products are summed by the MFMA's own chain (the 1e-4
+// oracle bar holds with three decimal orders to spare).
+__device__ __forceinline__ void split_lift64_mfma(const float* __restrict__ xs, const float* __restrict__ w1, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                  unsigned short* __restrict__ th, unsigned short* __restrict__ tl, int wave, int lane)
+{
+  constexpr int ld1 = 72;
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  const int n = lane & 15, kq = lane >> 4, row = 16 * wave + n;
+  const float b = xs[row * 4 + kq];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const float wv = w1[min(kq, 2) * 64 + 16 * ct + n];
+    f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kq < 3 ? wv : 0.f, b, acc, 0, 0, 0);
+    const f32x4_ s4 = *reinterpret_cast<const f32x4_*>(sc + 16 * ct + 4 * kq), t4 = *reinterpret_cast<const f32x4_*>(sh + 16 * ct + 4 * kq);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[r], s4[r], t4[r]), 0.f);
+    unsigned h0, l0, h1, l1;
+    split_bf16_pair(v[0], v[1], h0, l0);
+    split_bf16_pair(v[2], v[3], h1, l1);
+    const int o = row * ld1 + 16 * ct + 4 * kq;
+    *reinterpret_cast<u32x2*>(th + o) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(tl + o) = u32x2{l0, l1};
+  }
+}
+
 // Ws[ct][kb][part][lane][8], part 0 = hi, 1 = lo;  element k = 16 kb + 8 (lane >> 5) + s, c = 32 ct + (lane & 31)
 static __global__ void pack_weights_split_kernel(const float* __restrict__ W, int K, int C, unsigned short* __restrict__ Ws)
 {
@@ -121,11 +167,13 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
     xs[tid * 4 + 0] = fmaf(z, xf[9], fmaf(y, xf[6], x * xf[3]));
     xs[tid * 4 + 1] = fmaf(z, xf[10], fmaf(y, xf[7], x * xf[4]));
     xs[tid * 4 + 2] = fmaf(z, xf[11], fmaf(y, xf[8], x * xf[5]));
+    xs[tid * 4 + 3] = 0.f;   // (the k = 4 padding of the matrix-pipe lift)
   }
   __syncthreads();
 
-  // ---- layer 1 (K = 3, VALU, fp32) -> h1 as hi / lo bf16 tiles; columns C1 .. K1 are zero padding ----
-  {
+  // ---- layer 1 (K = 3, fp32) -> h1 as hi / lo bf16 tiles; columns C1 .. K1 are zero padding ----
+  if (C1T == 64) split_lift64_mfma(xs, a.w1, a.sc1 + tower * 64, a.sh1 + tower * 64, s16 + o1h, s16 + o1l, wave, lane);   // shipped width: on the matrix pipe
+  else {
     const int c0 = tid & 31, r0 = tid >> 5;
     for (int c = c0; c < K1; c += 32) {
       const bool live = c < kC1;
@@ -239,18 +287,6 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split(const Sp
   }
 }
 
-// two fp32 -> (hi, lo) bf16 pairs: hi = RNE(x) (one v_cvt_pk_bf16_f32 for both), lo = RNE(x - hi); the same values split_bf16 gives
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi, unsigned& lo)
-{
-  const f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
-}
 
 // ---- round 5: the shipped widths (64, 128) as a PERSISTENT workgroup with a two-channel-tile register block in the last layer ----
 // What the one-tile-per-workgroup kernel above loses: (1) with 108 KB of LDS there is one workgroup per CU, so every
@@ -441,33 +477,15 @@ static __global__ __launch_bounds__(kWaves * 64, 2) void pointnet_split_persist(
     if (tid < kSplitTP) {
       const float* xf = a.xform + (size_t)cloud * 12;
       const float x = px - xf[0], y = py - xf[1], z = pz - xf[2];
-      xs[tid * 4 + 0] = fmaf(z, xf[9], fmaf(y, xf[6], x * xf[3]));
-      xs[tid * 4 + 1] = fmaf(z, xf[10], fmaf(y, xf[7], x * xf[4]));
-      xs[tid * 4 + 2] = fmaf(z, xf[11], fmaf(y, xf[8], x * xf[5]));
+      const f32x4 pr = {fmaf(z, xf[9], fmaf(y, xf[6], x * xf[3])), fmaf(z, xf[10], fmaf(y, xf[7], x * xf[4])), fmaf(z, xf[11], fmaf(y, xf[8], x * xf[5])), 0.f};
+      *reinterpret_cast<f32x4*>(xs + tid * 4) = pr;   // {x', y', z', 0}: the k = 4 padding of the matrix-pipe lift
     }
     __syncthreads();   // also: the tables (first tile)
     PSP_STAMP(1);
-    // ---- layer 1 (K = 3, VALU, fp32) -> h1 hi / lo ----
+    // ---- layer 1 (K = 3, fp32, matrix pipe: split_lift64_mfma) -> h1 hi / lo ----
     if (!(ALN_ABL(a.dbg, 4))) {
-      // a thread = four adjacent columns x four rows: parameters as five 16-byte LDS reads, h1 leaves as 8-byte packed stores
-      const int cg = (tid & 15) * 4, r0 = tid >> 4;
-      const float* q = p1 + tower * 320 + cg;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(q), w1 = *reinterpret_cast<const f32x4*>(q + 64), w2 = *reinterpret_cast<const f32x4*>(q + 128);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(q + 192), sh = *reinterpret_cast<const f32x4*>(q + 256);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = rr * 32 + r0;
-        const f32x4 p = *reinterpret_cast<const f32x4*>(xs + row * 4);
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(fmaf(p[2], w2[j], fmaf(p[1], w1[j], p[0] * w0[j])), sc[j], sh[j]), 0.f);
-        unsigned h0, l0, h1, l1;
-        split_bf16_pair(v[0], v[1], h0, l0);
-        split_bf16_pair(v[2], v[3], h1, l1);
-        const u32x2 hi = {h0, h1}, lo = {l0, l1};
-        *reinterpret_cast<u32x2*>(s16 + o1h + row * ld1 + cg) = hi;
-        *reinterpret_cast<u32x2*>(s16 + o1l + row * ld1 + cg) = lo;
-      }
+      const float* q = p1 + tower * 320;
+      split_lift64_mfma(xs, q, q + 192, q + 256, s16 + o1h, s16 + o1l, wave, lane);
     }
     PSP_STAMP(2);
     __syncthreads();   // h1 complete; every wave has left the previous tile's last layer (h2 may be overwritten)
