@@ -997,6 +997,11 @@ PINNED_CASES = {
     "dgcnn": ("dgcnn", dict(s1=(32, 64, 96), s2=(32, 64, 128), emb=(64, 128, 160)), 128, 8, 0, 1),
     "dgcnn_std_bf16": ("dgcnn", STD, 128, 16, 1, 1),
     "dgcnn_general": ("dgcnn", DGCNN_GENERAL["mixed"], 128, 5, 0, 1),
+    # ragged tiles (N = 200: 64-point tiles 3 + 8 rows, 128-point tiles 1 + 72 rows) with every per-cloud kernel dealt to several workgroups per cloud
+    # (B this small leaves the chip empty: pn_parts / p3_parts / dg_parts pick up to four parts) -- the split against the ORACLE, not against parts = 1
+    "pointnet_std_ragged": ("pointnet", STD, 200, 12, 0, 1),
+    "pointnet_std_bf16_ragged": ("pointnet", STD, 200, 24, 1, 1),
+    "dgcnn_std_ragged": ("dgcnn", STD, 200, 6, 0, 1),
 }
 
 
