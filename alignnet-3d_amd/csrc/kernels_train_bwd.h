@@ -144,7 +144,8 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
       idg[q] = ok ? a.gs[(size_t)cloud * a.C3 + c] : 0.f;
       idt[q] = id >= 0 ? id / kTT : -1; idrow[q] = id >= 0 ? id % kTT : 0;
     }
-    for (int t = wave; t < ntiles; t += kTW) {
+    // (only this workgroup's tiles [tile0, tile_end): with the cloud dealt to several workgroups the others' hits are not its business)
+    for (int t = tile0 + wave; t < tile_end; t += kTW) {
       int n = 0;
 #pragma unroll
       for (int q = 0; q < kIdQ; ++q)
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     __syncthreads();
     if (tid == 0) {
       int acc0 = 0;
-      for (int t = 0; t < ntiles; ++t) { hoff[t] = acc0; acc0 += hoff[ntiles + 1 + t]; }
-      hoff[ntiles] = acc0;
+      for (int t = tile0; t < tile_end; ++t) { hoff[t] = acc0; acc0 += hoff[ntiles + 1 + t]; }
+      hoff[tile_end] = acc0;
     }
     __syncthreads();
-    for (int t = wave; t < ntiles; t += kTW) {
+    for (int t = tile0 + wave; t < tile_end; t += kTW) {
       int pos = hoff[t];
 #pragma unroll
       for (int q = 0; q < kIdQ; ++q)
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     for (int q = 0; q < kIdQ; ++q) {
       const int c = q * 64 + lane;
       const int id = (q < nq && c < a.C3) ? a.idx[(size_t)cloud * a.C3 + c] : -1;
-      idr[q] = (id >= 0 && (id & (kTW - 1)) == wave) ? id : -1;   // this wave's rows only
+      idr[q] = (id >= 0 && (id & (kTW - 1)) == wave && id >= tile0 * kTT && id < tile_end * kTT) ? id : -1;   // this wave's rows of this workgroup's tiles only
     }
     int cntw = 0;
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += wtot[w];
     int pos = 0;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tile0; t < tile_end; ++t) {
       if (lane == 0) hoff[wave * (ntiles + 1) + t] = woff + pos;
 #pragma unroll
       for (int q = 0; q < kIdQ; ++q)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void train_bwd_b2(const BwdB2Args a)
           pos += __popcll(mask);
         }
     }
-    if (lane == 0) hoff[wave * (ntiles + 1) + ntiles] = woff + pos;
+    if (lane == 0) hoff[wave * (ntiles + 1) + tile_end] = woff + pos;
   }
 
   f32x16 z2[2];   // [row group]
