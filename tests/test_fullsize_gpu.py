@@ -389,6 +389,20 @@ def test_train_bf16_full_size_pinned_to_engine_decisions(gpu_required):
                                   bf16=True, gap_bar=1e-4, relu_gap_bar=1e-3, relu_differ_bar=1e-5, round_pin=True, round_gap_bar=64.0, tag="full size, varied objects")
 
 
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_train_reference_shipped_shape_matches_autograd(gpu_required, bf16):
+    """The shape the reference's own config files train at (configs/*.json: batch_size 128, num_points 512; every one but default.json): 256 clouds do
+    not fill the chip's 512 two-per-CU workgroup slots, so phase 2 / the first-layer Gram and passes B2, B1 run with TWO workgroups per cloud (alignnet_train.hip
+    pn_parts; phase 3, one workgroup per CU, stays whole) -- the split at scale, against the fully pinned fp64 oracle on 128 differently sized objects, at the
+    bars of the 256 x 1024 tests."""
+    cfg, spec, P32, d, du = _varied_setup(Bt=128, Nt=512, seed=21)
+    if bf16:
+        _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=3, pred_tol=2e-4, loss_tol=1e-6, ema_tol=5e-5, rl2_bar=1e-2, tensor_bar=2e-2, cos_bar=0.99995,
+                                      bf16=True, gap_bar=1e-4, relu_gap_bar=1e-3, relu_differ_bar=1e-5, round_pin=True, round_gap_bar=64.0, tag="128 x 512, varied objects")
+    else:
+        _check_train_against_autograd(cfg, spec, P32, d, du, expect_kernel=1, pred_tol=2.5e-4, loss_tol=1e-5, ema_tol=5e-5, tag="128 x 512, varied objects")
+
+
 def test_train_dgcnn_n1024_matches_autograd(gpu_required):
     """DGCNN training at N = 1024 (the kNN kernel's 16-slot instantiation at its limit, 16 tiles per cloud, 20 neighbour slots,
     SynthCars widths -> dg_train_fwd<64> / dg_train_bwd_edge<64, 128>): B = 8 differently sized objects keep the [B*N*k, C] autograd
