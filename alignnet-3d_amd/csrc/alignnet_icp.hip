@@ -7,10 +7,14 @@
 // restated in oracle/icp_ref.py, which this kernel follows step for step (same order of evaluate / estimate / stop).
 //
 // One workgroup per pair, all arithmetic in fp64 (Open3D computes in double; nearest-neighbour decisions then agree
-// with the oracle).  The target cloud sits in LDS (structure of arrays, every lane reads the same point: broadcast),
+// with the oracle).  The target cloud sits in LDS as doubles (structure of arrays: no conversion in the inner loop),
 // the source cloud is re-read from HBM/L2 each iteration (a few thousand points).  Brute force n1 x n2 per
 // iteration: at the datasets' cloud sizes that is a few million distance evaluations per pair -- a KD-tree would be
 // slower to build than this is to run.
+// Round 6: sixteen waves per pair instead of four, and FOUR LANES PER SOURCE POINT (lane s of a quad scans targets s, s + 4, ...; the
+// quad's (distance, index) minima meet in two shuffles, equal distances going to the lower index = the oracle's argmin): 256 pairs x 256
+// threads put one wave on every SIMD and 1500 points on 256 threads (six rounds of a serial 1500-long scan each); now a CU holds four
+// waves per SIMD and a scan is 375 long.
 #include "engine.h"
 #include <cmath>
 #include <vector>
@@ -25,7 +29,7 @@ int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1;
     if (e_ != hipSuccess) return fail(h, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
-constexpr int kIcpThreads = 256, kIcpSums = 12;
+constexpr int kIcpThreads = 1024, kIcpSums = 12, kIcpSplit = 4;   // threads per pair; lanes per source point
 
 struct IcpArgs {
   const float* pts[2];          // point blobs
@@ -38,7 +42,7 @@ struct IcpArgs {
   double* fitness; double* rmse; int* iters;   // [B] each, may be null
 };
 
-__device__ __forceinline__ void block_reduce(double (&v)[kIcpSums], double* red /*[4][kIcpSums]*/, double* tot /*[kIcpSums]*/)
+__device__ __forceinline__ void block_reduce(double (&v)[kIcpSums], double* red /*[waves][kIcpSums]*/, double* tot /*[kIcpSums]*/)
 {
 #pragma unroll
   for (int k = 0; k < kIcpSums; ++k)
@@ -58,10 +62,10 @@ __device__ __forceinline__ void block_reduce(double (&v)[kIcpSums], double* red 
 
 __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) float tgt[];   // [3][lds_points]
+  extern __shared__ __attribute__((aligned(16))) double tgt[];   // [3][lds_points]
   __shared__ double T[12];            // rows 0..2 of the 4x4
-  __shared__ double red[4 * kIcpSums], tot[kIcpSums];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[(kIcpThreads / 64) * kIcpSums], tot[kIcpSums];
+  const int b = blockIdx.x, tid = threadIdx.x, sub = tid & (kIcpSplit - 1);
   const long long row = a.rows ? a.rows[b] : b;
   const long long s_lo = a.off[row * 2], n1 = a.off[(row + 1) * 2] - s_lo;
   const long long t_lo = a.off[row * 2 + 1], n2 = a.off[(row + 1) * 2 + 1] - t_lo;
@@ -69,7 +73,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
   const float* dst = a.pts[1] + t_lo * 3;
   if (tid < 12) T[tid] = a.init[(size_t)b * 16 + tid];
   const int nl = (int)min((long long)a.lds_points, n2);
-  for (int j = tid; j < nl; j += kIcpThreads) { tgt[j] = dst[j * 3]; tgt[a.lds_points + j] = dst[j * 3 + 1]; tgt[2 * a.lds_points + j] = dst[j * 3 + 2]; }
+  const double* tx = tgt; const double* ty = tgt + a.lds_points; const double* tz = tgt + 2 * a.lds_points;
+  for (int j = tid; j < nl; j += kIcpThreads) { tgt[j] = (double)dst[j * 3]; tgt[a.lds_points + j] = (double)dst[j * 3 + 1]; tgt[2 * a.lds_points + j] = (double)dst[j * 3 + 2]; }
   __syncthreads();
   const double r2 = a.radius * a.radius;
   double fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;
@@ -80,26 +85,38 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
       double v[kIcpSums];
 #pragma unroll
       for (int q = 0; q < kIcpSums; ++q) v[q] = 0.0;
-      for (long long i = tid; i < n1; i += kIcpThreads) {
-        const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
+      for (long long i0 = 0; i0 < n1; i0 += kIcpThreads / kIcpSplit) {
+        const long long i = i0 + (tid / kIcpSplit);
+        const bool active = i < n1;                      // (inactive quads run along on the last point: the shuffles below want every lane)
+        const long long ic = active ? i : n1 - 1;
+        const double sx = src[ic * 3], sy = src[ic * 3 + 1], sz = src[ic * 3 + 2];
         const double px = T[0] * sx + T[1] * sy + T[2] * sz + T[3];
         const double py = T[4] * sx + T[5] * sy + T[6] * sz + T[7];
         const double pz = T[8] * sx + T[9] * sy + T[10] * sz + T[11];
-        double best = 1e300; long long bj = 0;
-        for (int j = 0; j < nl; ++j) {
-          const double dx = px - (double)tgt[j], dy = py - (double)tgt[a.lds_points + j], dz = pz - (double)tgt[2 * a.lds_points + j];
+        double best = 1e300; int bj = 0x7fffffff;
+#pragma unroll 2
+        for (int j = sub; j < nl; j += kIcpSplit) {
+          const double dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
           const double d = dx * dx + dy * dy + dz * dz;
-          if (d < best) { best = d; bj = j; }   // strict: the first index wins ties (oracle: argmin)
+          if (d < best) { best = d; bj = j; }   // strict: the first index of this lane's slice wins ties
         }
-        for (long long j = nl; j < n2; ++j) {   // clouds larger than the LDS budget: the tail comes from L2
+#pragma unroll 1
+        for (long long j = nl + sub; j < n2; j += kIcpSplit) {   // clouds larger than the LDS budget: the tail comes from L2
           const double dx = px - (double)dst[j * 3], dy = py - (double)dst[j * 3 + 1], dz = pz - (double)dst[j * 3 + 2];
           const double d = dx * dx + dy * dy + dz * dz;
-          if (d < best) { best = d; bj = j; }
+          if (d < best) { best = d; bj = (int)j; }
         }
-        if (best <= r2) {
-          const double qx = bj < nl ? (double)tgt[bj] : (double)dst[bj * 3];
-          const double qy = bj < nl ? (double)tgt[a.lds_points + bj] : (double)dst[bj * 3 + 1];
-          const double qz = bj < nl ? (double)tgt[2 * a.lds_points + bj] : (double)dst[bj * 3 + 2];
+        // the quad's minimum; equal distances go to the lower index (oracle: argmin = the first index)
+#pragma unroll
+        for (int o = 1; o < kIcpSplit; o <<= 1) {
+          const double ob = __shfl_xor(best, o);
+          const int oj = __shfl_xor(bj, o);
+          if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (active && sub == 0 && best <= r2) {
+          const double qx = bj < nl ? tx[bj] : (double)dst[(long long)bj * 3];
+          const double qy = bj < nl ? ty[bj] : (double)dst[(long long)bj * 3 + 1];
+          const double qz = bj < nl ? tz[bj] : (double)dst[(long long)bj * 3 + 2];
           v[0] += 1.0; v[1] += px; v[2] += py; v[3] += pz; v[4] += qx; v[5] += qy; v[6] += qz;
           v[7] += px * qx + py * qy; v[8] += px * qy - py * qx; v[9] += best;
         }
@@ -155,7 +172,7 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
   HIP_TRY(h, hipMemcpyAsync(d_init, init, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   IcpArgs a;
   a.pts[0] = d_p0; a.pts[1] = d_p1; a.off = d_off; a.rows = d_rows; a.init = d_init; a.radius = radius; a.its = its;
-  const long long budget = (150 * 1024) / 12;   // floats x 3 per point within one CU's LDS
+  const long long budget = (150 * 1024) / 24;   // doubles x 3 per point within one CU's LDS
   a.lds_points = (int)std::max<long long>(1, std::min(budget, max_n2));
   a.out = d_out; a.fitness = d_fr; a.rmse = d_fr + B; a.iters = d_it;
   static alignnet::PerDeviceOnce attr;
@@ -163,7 +180,7 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
     attr.mark(h->cfg.device);
   }
-  hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 12, h->stream, a);
+  hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 24, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, d_out, (size_t)B * 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (fitness) HIP_TRY(h, hipMemcpyAsync(fitness, d_fr, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -216,7 +233,7 @@ extern "C" int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* ro
   HIP_TRY(h, hipMalloc(&d_rows, (size_t)B * sizeof(int)));
   HIP_TRY(h, hipMemcpyAsync(d_rows, rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
   // the largest target cloud is not known on the host: size the LDS stage for the budget, the kernel clamps per pair
-  const int rc = run_icp(h, t.pts[0], t.pts[1], t.off, d_rows, (150 * 1024) / 12, B, init, radius, its, out, fitness, rmse, iterations);
+  const int rc = run_icp(h, t.pts[0], t.pts[1], t.off, d_rows, (150 * 1024) / 24, B, init, radius, its, out, fitness, rmse, iterations);
   hipFree(d_rows);
   return rc;
 }
