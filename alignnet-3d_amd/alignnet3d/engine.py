@@ -28,7 +28,7 @@ SUMMARY_NAMES = (
 
 # include/alignnet_hip.h ALIGNNET_KERNEL_*: which backbone instantiation an eval forward launched (get_option("last_backbone_kernel"))
 KERNEL_IDS = {"pointnet_fused": 1, "pointnet_fused<64,128>": 2, "pointnet_fused<64,128,k16>": 3, "pointnet_fused<tp64>": 4,
-              "pointnet_split": 5, "pointnet_split<64,128>": 6, "pointnet_split_persist": 7, "dgcnn_fused": 10, "dgcnn_fused<64,128>": 11,
+              "pointnet_split": 5, "pointnet_split<64,128>": 6, "pointnet_split_persist": 7, "pointnet_fused<64,128,k16,tp64>": 8, "dgcnn_fused": 10, "dgcnn_fused<64,128>": 11,
               "dgcnn_split": 12, "dgcnn_split<64,128>": 13}
 KERNEL_NAMES = {v: k for k, v in KERNEL_IDS.items()}
 

@@ -418,11 +418,21 @@ static int ensure_ws(alignnet_handle* h, int B, bool need_inputs)
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-static int infer_tile_pts(const alignnet_handle* h) { return (h->ab & AB_INFER_TILE64) ? 64 : 128; }
-
-static size_t backbone_lds_bytes(const alignnet_handle* h, const Stack& st, int ld[2])
+// Points per workgroup tile of the fused PointNet backbone.  A tile's time is set by its last layer (43 us at C3 = 1024 on 128 points) whatever the batch, so a
+// batch whose 128-point tiles cover at most half of the 256 CUs is served sooner on twice as many 64-point tiles: 0.189 -> 0.134 ms per step at B = 1,
+// 0.198 -> 0.142 at B = 8 (N = 1024); from one 128-point tile per CU on (B = 16: 0.207 against 0.221 ms; B = 32: 0.338 against 0.356) the 128-point tiling
+// is the faster one again (a weight fragment feeds four row tiles instead of two).
+static int infer_tile_pts(const alignnet_handle* h, int B)
 {
-  const int kTilePts = infer_tile_pts(h);
+  if (h->ab & AB_INFER_TILE64) return 64;
+  if (h->infer_tile_opt) return h->infer_tile_opt;
+  const long tiles128 = (long)2 * B * ((h->cfg.num_points + 127) / 128);
+  return tiles128 <= 128 ? 64 : 128;
+}
+
+static size_t backbone_lds_bytes(const alignnet_handle* h, const Stack& st, int ld[2], int B)
+{
+  const int kTilePts = infer_tile_pts(h, B);
   int w[2] = {8, 8};
   for (int i = 0; i < st.n - 1; ++i) w[i & 1] = std::max(w[i & 1], (h->layers[st.first + i].cout + 7) & ~7);
   ld[0] = w[0] + 4; ld[1] = w[1] + 4;
@@ -436,7 +446,7 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
   a.pcs[0] = p1; a.pcs[1] = p2; a.xform = h->ws.xform; a.pooled = pooled;
   a.tower_stride = tower_stride; a.row_stride = row_stride;
   a.B = B; a.N = h->cfg.num_points; a.nlayers = st.n;
-  const size_t lds = backbone_lds_bytes(h, st, a.ld);
+  const size_t lds = backbone_lds_bytes(h, st, a.ld, B);
   if (lds > 160 * 1024) return fail(h, "backbone hidden widths need more than 160 KiB of LDS per 128-point tile");
   for (int i = 0; i < st.n; ++i) {
     const Layer& L = h->layers[st.first + i];
@@ -458,9 +468,10 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<128, 68, 132, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_fused<64, 68, 132, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.mark(h->cfg.device);
   }
-  const int TP = infer_tile_pts(h);
+  const int TP = infer_tile_pts(h, B);
   // tiles per workgroup: as many as still leave every CU several workgroups (the pooled max is published once per workgroup)
   const int ntiles = (a.N + TP - 1) / TP;
   int per = ntiles;
@@ -527,6 +538,9 @@ static int run_backbone(alignnet_handle* h, const Stack& st, const float* p1, co
       TIMED_LAUNCH(pointnet_split<>, dim3((a.N + kSplitTP - 1) / kSplitTP, 2 * B), dim3(kWaves * 64), slds, sa);
       h->last_kernel = ALIGNNET_KERNEL_POINTNET_SPLIT;
     }
+  } else if (TP == 64 && !(h->ab & AB_INFER_TILE64) && a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !(h->ab & AB_NO_LD_CONST)) {
+    TIMED_LAUNCH((pointnet_fused<64, 68, 132, 16>), grid, dim3(kWaves * 64), lds, a);   // the shipped shape on 64-point tiles (small batches)
+    h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16_TP64;
   } else if (TP == 64) { TIMED_LAUNCH(pointnet_fused<64>, grid, dim3(kWaves * 64), lds, a); h->last_kernel = ALIGNNET_KERNEL_POINTNET_FUSED_TP64; }
   else if (a.ld[0] == 68 && a.ld[1] == 132 && st.n == 3 && h->layers[st.first + 2].cin == 128 && !(h->ab & AB_NO_LD_CONST)) {
     TIMED_LAUNCH((pointnet_fused<128, 68, 132, 16>), grid, dim3(kWaves * 64), lds, a);
@@ -967,6 +981,7 @@ extern "C" int alignnet_set_option(alignnet_handle* h, const char* key, int64_t 
     return 0;
   }
   if (k == "ab_tiles_per_wg") { if (value < 0) return fail(h, "ab_tiles_per_wg must be >= 0"); h->ab_tiles_per_wg = (int)value; return 0; }
+  if (k == "infer_tile_points") { if (value != 0 && value != 64 && value != 128) return fail(h, "infer_tile_points must be 0 (automatic), 64 or 128"); h->infer_tile_opt = (int)value; return 0; }
   if (k == "dg_cloud_parts") { if (value < 0 || value > 8) return fail(h, "dg_cloud_parts must be 0 (automatic) .. 8"); h->dg_parts_opt = (int)value; return 0; }
   if (k == "pn_cloud_parts") { if (value < 0 || value > 8) return fail(h, "pn_cloud_parts must be 0 (automatic) .. 8"); h->pn_parts_opt = (int)value; return 0; }
   for (const auto& ak : kAbKeys)
@@ -1003,6 +1018,7 @@ extern "C" int alignnet_get_option(alignnet_handle* h, const char* key, int64_t*
   if (k == "sync_collectives") { *value = h->sync_collectives; return 0; }
   if (k == "ab_tiles_per_wg") { *value = h->ab_tiles_per_wg; return 0; }
   if (k == "dg_cloud_parts") { *value = h->dg_parts_opt; return 0; }
+  if (k == "infer_tile_points") { *value = h->infer_tile_opt; return 0; }
   if (k == "pn_cloud_parts") { *value = h->pn_parts_opt; return 0; }
   if (k == "ab_mask") { *value = h->ab; return 0; }
   for (const auto& ak : kAbKeys) if (k == ak.key) { *value = (h->ab & ak.bit) ? 1 : 0; return 0; }

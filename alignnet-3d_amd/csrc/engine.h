@@ -152,6 +152,7 @@ struct alignnet_handle {
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int dw_side = 0;                 // alignnet_set_option("train_dw_side_stream"): 0 = off, 1 = every stage, 2 = stage 3 only
   unsigned ab = 0;                 // AbBit mask (alignnet_set_option "ab_*")
+  int infer_tile_opt = 0;          // "infer_tile_points": eval PointNet backbone tile (0 = from the batch: alignnet_api.hip infer_tile_pts; 64 / 128 fixed)
   int dg_parts_opt = 0;            // "dg_cloud_parts": dgcnn training, workgroups per cloud of the edge kernels (0 = chosen from the batch: alignnet_train.hip dg_parts)
   int pn_parts_opt = 0;            // "pn_cloud_parts": PointNet training, workgroups per cloud of phase 2 / passes B2, B1 (0 = chosen from the batch: alignnet_train.hip pn_parts)
   int ab_tiles_per_wg = 0;         // "ab_tiles_per_wg": eval PointNet backbone, point tiles per workgroup (0 = chosen from the grid size)

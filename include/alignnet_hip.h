@@ -363,6 +363,8 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
  *   "ab_phase2_legacy", "ab_b1_legacy", "ab_b1_fp32", "ab_p3_bf16_generic", "ab_p3_nogram", "ab_no_defer", "ab_dg_sparse",
  *   "ab_no_glue_fold", "ab_gemm_jobs_ksplit", "ab_fc_direct", "ab_fc_no_splitk", "ab_split_tilewise" (csrc/engine.h: AbBit), and "ab_tiles_per_wg" (eval PointNet backbone: point tiles per workgroup, 0 = automatic);
  *   "dg_cloud_parts" (dgcnn training: workgroups per cloud of the edge kernels, 0 = as many as fill the chip at this batch, 1 .. 8 = fixed; results agree up to the grouping of partial sums);
+ *   "infer_tile_points" (eval PointNet backbone: points per workgroup tile; 0 = automatic -- 64-point tiles while the 128-point tiling would cover at most half of the
+ *   256 CUs (2B x ceil(N / 128) <= 128: B <= 8 at N = 1024; 0.19 -> 0.134 ms per step at B = 1, 0.198 -> 0.142 at B = 8), 128 otherwise; 64 / 128 = fixed; bit-identical outputs);
  *   "pn_cloud_parts" (the same split for the per-cloud kernels both backbones share: phase 2 / the first-layer Gram, phase 3 -- the lift to C3 with its running
  *   arg-extreme and Gram, the parts' extremes folded exactly in tile order -- and passes B2, B1; the chip is full from 2B = 256 (128-point-tile kernels) or 512
  *   clouds, the reference's shipped batch of 128 brings 256; 0 = automatic, 1 .. 8 = fixed).
@@ -384,6 +386,7 @@ int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* rows, int32_t
 #define ALIGNNET_KERNEL_POINTNET_FUSED_64_128 2     /* pointnet_fused<128, 68, 132> */
 #define ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16 3 /* pointnet_fused<128, 68, 132, 16>: the shipped 3-layer shape */
 #define ALIGNNET_KERNEL_POINTNET_FUSED_TP64 4       /* pointnet_fused<64> (ALIGNNET_TILE=64) */
+#define ALIGNNET_KERNEL_POINTNET_FUSED_64_128_K16_TP64 8 /* pointnet_fused<64, 68, 132, 16>: the shipped shape on 64-point tiles (small batches: "infer_tile_points") */
 #define ALIGNNET_KERNEL_POINTNET_SPLIT 5            /* pointnet_split<> */
 #define ALIGNNET_KERNEL_POINTNET_SPLIT_64_128 6     /* pointnet_split<64, 128> */
 #define ALIGNNET_KERNEL_POINTNET_SPLIT_PERSIST 7    /* pointnet_split_persist: shipped widths, persistent workgroups */

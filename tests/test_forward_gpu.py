@@ -10,10 +10,13 @@ from tests.helpers import small_cfg, oracle_params, compare_forward
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, B, seed=1234, split=False):
+def _run(cfg, B, seed=1234, split=False, options=()):
     spec, P32 = oracle_params(cfg)
     eng = alignnet3d.Engine(cfg)
     eng.set_variables(P32)
+    for k, v in options:
+        eng.set_option(k, v)
+        assert eng.get_option(k) == v
     if split:
         eng.set_option("infer_matmul_bf16x3", 1)
         assert eng.get_option("infer_matmul_bf16x3") == 1
@@ -39,13 +42,38 @@ def test_forward_small_widths(gpu_required, N, B):
     assert unstable <= max(1, B // 4)
 
 
-def test_forward_synthcars_widths_n1024(gpu_required):
+@pytest.mark.parametrize("tile,B,kernel", [(128, 8, "pointnet_fused<64,128,k16>"),          # the instantiation bench.py times (B = 256 picks it by itself)
+                                           (0, 8, "pointnet_fused<64,128,k16,tp64>"),      # automatic at a serving-size batch: 64-point tiles
+                                           (0, 40, "pointnet_fused<64,128,k16>")])         # automatic at 2B x 8 = 640 tiles of 128 points
+def test_forward_synthcars_widths_n1024(gpu_required, tile, B, kernel):
+    """The shipped widths at N = 1024 against the fp64 oracle, on both tile shapes of the fused backbone ("infer_tile_points": 0 = from the batch -- 64-point tiles
+    while the 128-point tiling would cover at most half of the CUs)."""
     cfg = alignnet3d.default_model_config()
-    ep, ref, spec = _run(cfg, 8)
+    ep, ref, spec = _run(cfg, B, options=(("infer_tile_points", tile),))
     worst, unstable = compare_forward(ep, ref, spec.num_bins)
-    print("worst abs err", worst, "unstable pairs", unstable)
-    assert unstable <= 2
-    assert LAST_KERNEL == "pointnet_fused<64,128,k16>", LAST_KERNEL   # the instantiation bench.py times
+    print("tile option", tile, "B", B, "worst abs err", worst, "unstable pairs", unstable)
+    assert unstable <= max(2, B // 4)
+    assert LAST_KERNEL == kernel, LAST_KERNEL
+
+
+def test_forward_tile_shapes_are_bit_identical(gpu_required):
+    """64- and 128-point tiles run the same MFMA k-order per output and a max over the same values: identical bits (so the automatic choice by batch size
+    never changes a result), on a ragged cloud size and both batch regimes."""
+    cfg = alignnet3d.default_model_config()
+    cfg["model"]["num_points"] = 1000
+    spec, P32 = oracle_params(cfg)
+    for B in (3, 40):
+        d = R.synth_pairs(B, 1000, seed=5, dtype=np.float32)
+        outs = {}
+        for tile in (64, 128, 0):
+            eng = alignnet3d.Engine(cfg)
+            eng.set_variables(P32)
+            eng.set_option("infer_tile_points", tile)
+            outs[tile] = eng.forward(d["pcs1"], d["pcs2"])
+            eng.close()
+        for tile in (128, 0):
+            for k in outs[64]:
+                np.testing.assert_array_equal(outs[tile][k], outs[64][k], err_msg="%s tile %d B %d" % (k, tile, B))
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (100, 3), (256, 33), (37, 1)])
