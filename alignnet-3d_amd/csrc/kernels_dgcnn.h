@@ -20,7 +20,7 @@ namespace alignnet {
 constexpr int kKnnMaxPerLane = 64;   // N <= 64 * 64 = 4096 candidates per query
 constexpr int kKnnList = 128;        // survivors of the first bound that are selected from LDS
 constexpr int kKnnWaves = 8;         // waves per workgroup, one query point per wave and round
-constexpr int kKnnQueries = 256;     // query points per workgroup (the cloud's candidate table is built once for all of them)
+constexpr int kKnnQueries = 256;     // query points per workgroup (the cloud's candidate table is built once for all of them); fewer when the grid would not fill the chip (launch_knn)
 
 // order-preserving map float -> uint32 (handles the slightly negative "distances" the TF formula can produce) and its inverse
 __device__ __forceinline__ uint32_t fkey(float f)
@@ -37,7 +37,7 @@ __device__ long long g_knn_stamp[8];
 #define KNN_STAMP(i) do {} while (0)
 #endif
 
-// grid: (ceil(N / kKnnQueries), 2B), block 512 = 8 waves.  PER: candidate slots per lane compiled in (N <= 64 PER).
+// grid: (ceil(N / qpw), 2B), block 512 = 8 waves; qpw = query points per workgroup.  PER: candidate slots per lane compiled in (N <= 64 PER).
 //
 // The workgroup first builds the cloud's candidate table in LDS -- mean-centred x, y, z and |x|^2 per point, 16 bytes each, rows past
 // N padded with |x|^2 = +inf -- laid out for packed-fp32 arithmetic: entry (t2, lane) holds the candidates of slots 2 t2 and 2 t2 + 1
@@ -53,7 +53,7 @@ __device__ long long g_knn_stamp[8];
 //  scalar / vector chains -- then ran unhidden and the kernel was no faster than the first form: DESIGN.md 4.5.)
 template <int PER = kKnnMaxPerLane>
 [[maybe_unused]] static __global__ __launch_bounds__(kKnnWaves * 64, 4) void knn_kernel(const float* __restrict__ pcs1, const float* __restrict__ pcs2,
-                                                 const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn)
+                                                 const float* __restrict__ center, int B, int N, int k, int* __restrict__ nn, int qpw)
 {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float knn_smem[];
@@ -80,8 +80,8 @@ template <int PER = kKnnMaxPerLane>
   __syncthreads();
   KNN_STAMP(1);
   const int per2 = (N + 127) >> 7;     // populated pair slots
-  const int qend = min(N, (int)(blockIdx.x + 1) * kKnnQueries);
-  for (int q = blockIdx.x * kKnnQueries + wave; q < qend; q += kKnnWaves) {
+  const int qend = min(N, (int)(blockIdx.x + 1) * qpw);
+  for (int q = blockIdx.x * qpw + wave; q < qend; q += kKnnWaves) {
     // ---- 1. distances of the wave's query to every candidate; per-lane minimum ----
     KNN_STAMP(7);
     float d[PER];
@@ -218,7 +218,11 @@ constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t
 [[maybe_unused]] static hipError_t launch_knn(int device, hipStream_t stream, const float* p1, const float* p2, const float* center, int B, int N,
                                               int k, int* nn, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)   // (t0, t1: optional kernel timer, engine.h ProfScope)
 {
-  const dim3 grid((N + kKnnQueries - 1) / kKnnQueries, 2 * B), block(kKnnWaves * 64);
+  // 256 queries per workgroup amortise the candidate table (64 KB at N = 4096: ~3 us to build); a serving-size batch would then be 32 workgroups walking
+  // 32 rounds each (157 us at B = 1 .. 4, N = 4096) -- fewer queries per workgroup until the grid has two workgroups per CU
+  int qpw = kKnnQueries;
+  while (qpw > 32 && (long)2 * B * ((N + qpw - 1) / qpw) < 512) qpw >>= 1;
+  const dim3 grid((N + qpw - 1) / qpw, 2 * B), block(kKnnWaves * 64);
   static PerDeviceOnce attr_done;
   if (attr_done.need(device)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes(16));
@@ -227,9 +231,9 @@ constexpr size_t knn_lds_bytes(int per) { return (size_t)per * 64 * 16 + (size_t
     if (e != hipSuccess) return e;
     attr_done.mark(device);
   }
-  if (N <= 1024) hipExtLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
-  else if (N <= 2048) hipExtLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
-  else hipExtLaunchKernelGGL(knn_kernel<64>, grid, block, knn_lds_bytes(64), stream, t0, t1, 0, p1, p2, center, B, N, k, nn);
+  if (N <= 1024) hipExtLaunchKernelGGL(knn_kernel<16>, grid, block, knn_lds_bytes(16), stream, t0, t1, 0, p1, p2, center, B, N, k, nn, qpw);
+  else if (N <= 2048) hipExtLaunchKernelGGL(knn_kernel<32>, grid, block, knn_lds_bytes(32), stream, t0, t1, 0, p1, p2, center, B, N, k, nn, qpw);
+  else hipExtLaunchKernelGGL(knn_kernel<64>, grid, block, knn_lds_bytes(64), stream, t0, t1, 0, p1, p2, center, B, N, k, nn, qpw);
   return hipGetLastError();
 }
 
