@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void dg_train_fwd(const DgTrainArgs a)
 __global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int B, int N, int C2, const float* __restrict__ sc2,
                                                       const float* __restrict__ sh2, double* __restrict__ colsum_part, int parts)
 {
-  __shared__ double red[256][4];
+  __shared__ double red[4][256];   // [e][thread]: consecutive lanes on consecutive banks (as [thread][4] every lane of a store sat on the same eight banks: conflict share 0.56)
   const int vcloud = blockIdx.x, cloud = vcloud / parts, part = vcloud - cloud * parts, tower = cloud >= B, tid = threadIdx.x;
   const int c4 = C2 >> 2, G = 256 / c4, q = tid % c4, g = tid / c4;
   float* base = p + (size_t)cloud * N * C2;
@@ -558,13 +558,13 @@ __global__ __launch_bounds__(256) void dg_pool_finish(float* __restrict__ p, int
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[tid][e] = g < G ? s[e] : 0.0;
+  for (int e = 0; e < 4; ++e) red[e][tid] = g < G ? s[e] : 0.0;
   __syncthreads();
   if (tid < c4) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       double t = 0.0;
-      for (int gg = 0; gg < G; ++gg) t += red[gg * c4 + tid][e];
+      for (int gg = 0; gg < G; ++gg) t += red[e][gg * c4 + tid];
       colsum_part[((size_t)vcloud * 2) * C2 + tid * 4 + e] = t;
       colsum_part[((size_t)vcloud * 2 + 1) * C2 + tid * 4 + e] = 0.0;
     }
