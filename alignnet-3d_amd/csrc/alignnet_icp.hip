@@ -15,6 +15,13 @@
 // quad's (distance, index) minima meet in two shuffles, equal distances going to the lower index = the oracle's argmin): 256 pairs x 256
 // threads put one wave on every SIMD and 1500 points on 256 threads (six rounds of a serial 1500-long scan each); now a CU holds four
 // waves per SIMD and a scan is 375 long.
+// And the scan is CERTIFIED in fp32 before it is decided in fp64: one pass takes, per lane, the smallest and second smallest fp32 distance of its slice
+// (packed arithmetic, two targets per instruction) and where the smallest sits; the quad's minimum m gives a threshold m + 4 eps with
+// eps >= |fp32 distance - exact distance| for every target that can matter (icp_prefilter_eps: the rounding of the transformed source point to fp32, of
+// the differences, of the three products and sums).  Any target whose fp64 distance equals the minimum has an fp32 distance under the threshold, so: a
+// lane whose smallest is under it and whose second smallest is not evaluates that ONE target in fp64 (the old arithmetic); a lane with two or more under
+// it (a near-tie inside its slice: rare) walks its slice in fp64 as before; the quad's (distance, index) minima meet as before.  Same decisions as the
+// all-fp64 scan at a third of its vector-issue time (a first form with the fp64 evaluation inside the scan loop spilled around the branch: 7.7 ms).
 #include "engine.h"
 #include <cmath>
 #include <vector>
@@ -30,6 +37,22 @@ int fail(const alignnet_handle* h, const std::string& m) { h->err = m; return 1;
   } while (0)
 
 constexpr int kIcpThreads = 1024, kIcpSums = 12, kIcpSplit = 4;   // threads per pair; lanes per source point
+constexpr float kIcpFar = 1e18f;      // padding of the fp32 slices: a distance of 3e36, under no threshold
+typedef float icp_f32x2 __attribute__((ext_vector_type(2)));
+
+// slice-major fp32 copy of the LDS-resident targets: lane s of a quad reads targets s, s + 4, ... as consecutive floats, two per 8-byte read
+__host__ __device__ constexpr int icp_slice_len(int lds_points) { return (((lds_points + 3) / 4 + 1) & ~1) + 2; }
+constexpr size_t icp_lds_bytes(int lds_points) { return (size_t)lds_points * 24 + (size_t)3 * kIcpSplit * icp_slice_len(lds_points) * 4; }
+
+// eps >= |e32 - d| for a target at exact squared distance d <= M from a source point with |coordinates| <= P (u = 2^-24): the source point is rounded to
+// fp32 (u P per coordinate), each difference once more (u (P + a) in all, a = |difference|), so a squared difference moves by <= 2 a u (P + a) + u^2 (P + a)^2,
+// and the product and two fmas round the running sum three times (3 u d): eps = u (2 sqrt(3) P sqrt(d) + 5 d) + 3 u^2 (P + sqrt(d))^2.  Returned with room:
+// 2^-23 (4 P sqrt(M) + 6 M) + 2^-44 (P + sqrt(M))^2.
+__device__ __forceinline__ float icp_prefilter_eps(float P, float M)
+{
+  const float r = sqrtf(M);
+  return 1.1920929e-7f * (4.f * P * r + 6.f * M) + 5.6843419e-14f * (P + r) * (P + r);
+}
 
 struct IcpArgs {
   const float* pts[2];          // point blobs
@@ -62,7 +85,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[kIcpSums], double* red 
 
 __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) double tgt[];   // [3][lds_points]
+  extern __shared__ __attribute__((aligned(16))) double tgt[];   // [3][lds_points] doubles | [3][4 slices][S4] floats
   __shared__ double T[12];            // rows 0..2 of the 4x4
   __shared__ double red[(kIcpThreads / 64) * kIcpSums], tot[kIcpSums];
   const int b = blockIdx.x, tid = threadIdx.x, sub = tid & (kIcpSplit - 1);
@@ -74,8 +97,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
   if (tid < 12) T[tid] = a.init[(size_t)b * 16 + tid];
   const int nl = (int)min((long long)a.lds_points, n2);
   const double* tx = tgt; const double* ty = tgt + a.lds_points; const double* tz = tgt + 2 * a.lds_points;
-  for (int j = tid; j < nl; j += kIcpThreads) { tgt[j] = (double)dst[j * 3]; tgt[a.lds_points + j] = (double)dst[j * 3 + 1]; tgt[2 * a.lds_points + j] = (double)dst[j * 3 + 2]; }
+  const int S4 = icp_slice_len(a.lds_points);
+  float* t32 = reinterpret_cast<float*>(tgt + 3 * (size_t)a.lds_points);   // [coordinate][slice][S4]
+  for (int j = tid; j < 3 * kIcpSplit * S4; j += kIcpThreads) t32[j] = kIcpFar;
   __syncthreads();
+  for (int j = tid; j < nl; j += kIcpThreads) {
+    const float x = dst[j * 3], y = dst[j * 3 + 1], z = dst[j * 3 + 2];
+    tgt[j] = (double)x; tgt[a.lds_points + j] = (double)y; tgt[2 * a.lds_points + j] = (double)z;
+    const int o = (j & (kIcpSplit - 1)) * S4 + (j >> 2);
+    t32[o] = x; t32[kIcpSplit * S4 + o] = y; t32[2 * kIcpSplit * S4 + o] = z;
+  }
+  __syncthreads();
+  const int Lp = ((nl + kIcpSplit - 1) / kIcpSplit + 1) & ~1;   // slice positions walked (even; the padding behind a slice's end is kIcpFar)
+  const float* s32x = t32 + sub * S4; const float* s32y = s32x + kIcpSplit * S4; const float* s32z = s32y + kIcpSplit * S4;
   const double r2 = a.radius * a.radius;
   double fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;
   int k = 0;
@@ -94,11 +128,46 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
         const double py = T[4] * sx + T[5] * sy + T[6] * sz + T[7];
         const double pz = T[8] * sx + T[9] * sy + T[10] * sz + T[11];
         double best = 1e300; int bj = 0x7fffffff;
-#pragma unroll 2
-        for (int j = sub; j < nl; j += kIcpSplit) {
-          const double dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
-          const double d = dx * dx + dy * dy + dz * dz;
-          if (d < best) { best = d; bj = j; }   // strict: the first index of this lane's slice wins ties
+        {
+          // one fp32 pass over the slice: its smallest distance m1 with the position it sits at, and its second smallest m2 (v_med3 of the
+          // ordered pair and the newcomer) -- four vector instructions per target next to the packed arithmetic, no branch
+          const float pxf = (float)px, pyf = (float)py, pzf = (float)pz;
+          const icp_f32x2 qx2 = {pxf, pxf}, qy2 = {pyf, pyf}, qz2 = {pzf, pzf};
+          float m1 = 3.0e38f, m2 = 3.0e38f;
+          int im = 0;
+#pragma unroll 4
+          for (int m = 0; m < Lp; m += 2) {
+            const icp_f32x2 X = *reinterpret_cast<const icp_f32x2*>(s32x + m), Y = *reinterpret_cast<const icp_f32x2*>(s32y + m), Z = *reinterpret_cast<const icp_f32x2*>(s32z + m);
+            const icp_f32x2 dx = qx2 - X, dy = qy2 - Y, dz = qz2 - Z;
+            const icp_f32x2 e = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const bool lt = e[u] < m1;
+              m2 = __builtin_amdgcn_fmed3f(m1, m2, e[u]);   // m1 <= m2: the median of the three is the new second smallest
+              im = lt ? m + u : im;
+              m1 = fminf(m1, e[u]);
+            }
+          }
+          float qm = fminf(m1, __shfl_xor(m1, 1));
+          qm = fminf(qm, __shfl_xor(qm, 2));
+          const float P = fabsf(pxf) + fabsf(pyf) + fabsf(pzf) + 1e-30f;
+          const float thr = qm + 4.f * icp_prefilter_eps(P, 1.01f * qm + 1e-6f * P * P);
+          // every target whose fp64 distance is the minimum has an fp32 distance <= thr.  A lane with ONE such target decides it in fp64; a lane
+          // with two or more (a near-tie inside its slice: rare) walks its slice in fp64 as the all-fp64 kernel did
+          if (m2 <= thr) {
+#pragma unroll 1
+            for (int j = sub; j < nl; j += kIcpSplit) {
+              const double ddx = px - tx[j], ddy = py - ty[j], ddz = pz - tz[j];
+              const double d = ddx * ddx + ddy * ddy + ddz * ddz;
+              if (d < best) { best = d; bj = j; }   // strict: the first index of this lane's slice wins ties
+            }
+          } else if (m1 <= thr) {
+            const int j = sub + kIcpSplit * im;
+            if (j < nl) {
+              const double ddx = px - tx[j], ddy = py - ty[j], ddz = pz - tz[j];
+              best = ddx * ddx + ddy * ddy + ddz * ddz; bj = j;
+            }
+          }
         }
 #pragma unroll 1
         for (long long j = nl + sub; j < n2; j += kIcpSplit) {   // clouds larger than the LDS budget: the tail comes from L2
@@ -172,7 +241,7 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
   HIP_TRY(h, hipMemcpyAsync(d_init, init, (size_t)B * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   IcpArgs a;
   a.pts[0] = d_p0; a.pts[1] = d_p1; a.off = d_off; a.rows = d_rows; a.init = d_init; a.radius = radius; a.its = its;
-  const long long budget = (150 * 1024) / 24;   // doubles x 3 per point within one CU's LDS
+  const long long budget = (150 * 1024) / 36;   // doubles x 3 + floats x 3 per point within one CU's LDS
   a.lds_points = (int)std::max<long long>(1, std::min(budget, max_n2));
   a.out = d_out; a.fitness = d_fr; a.rmse = d_fr + B; a.iters = d_it;
   static alignnet::PerDeviceOnce attr;
@@ -180,7 +249,7 @@ int run_icp(alignnet_handle* h, const float* d_p0, const float* d_p1, const long
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
     attr.mark(h->cfg.device);
   }
-  hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), (size_t)a.lds_points * 24, h->stream, a);
+  hipLaunchKernelGGL(icp_kernel, dim3(B), dim3(kIcpThreads), icp_lds_bytes(a.lds_points), h->stream, a);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, d_out, (size_t)B * 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (fitness) HIP_TRY(h, hipMemcpyAsync(fitness, d_fr, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -233,7 +302,7 @@ extern "C" int alignnet_icp_refine_dataset(alignnet_handle* h, const int32_t* ro
   HIP_TRY(h, hipMalloc(&d_rows, (size_t)B * sizeof(int)));
   HIP_TRY(h, hipMemcpyAsync(d_rows, rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
   // the largest target cloud is not known on the host: size the LDS stage for the budget, the kernel clamps per pair
-  const int rc = run_icp(h, t.pts[0], t.pts[1], t.off, d_rows, (150 * 1024) / 24, B, init, radius, its, out, fitness, rmse, iterations);
+  const int rc = run_icp(h, t.pts[0], t.pts[1], t.off, d_rows, (150 * 1024) / 36, B, init, radius, its, out, fitness, rmse, iterations);
   hipFree(d_rows);
   return rc;
 }
