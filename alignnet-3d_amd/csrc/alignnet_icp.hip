@@ -111,6 +111,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
   const int Lp = ((nl + kIcpSplit - 1) / kIcpSplit + 1) & ~1;   // slice positions walked (even; the padding behind a slice's end is kIcpFar)
   const float* s32x = t32 + sub * S4; const float* s32y = s32x + kIcpSplit * S4; const float* s32z = s32y + kIcpSplit * S4;
   const double r2 = a.radius * a.radius;
+  // the correspondence sums are taken about a pivot near the clouds (the first target point), not about the origin: one-pass centring
+  // sum p q - n mean(p) mean(q) cancels |offset|^2 / extent^2 of its digits (a cloud 4 km from the origin: the rotation came out 6e-8 off
+  // Open3D's two-pass estimate, tests/test_icp_gpu.py::test_icp_exact_ties_and_far_frames); about the pivot the terms are of the clouds' size
+  const double cx = n2 > 0 ? (double)dst[0] : 0.0, cy = n2 > 0 ? (double)dst[1] : 0.0, cz = n2 > 0 ? (double)dst[2] : 0.0;
   double fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;
   int k = 0;
   if (n1 > 0 && n2 > 0)
@@ -186,8 +190,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
           const double qx = bj < nl ? tx[bj] : (double)dst[(long long)bj * 3];
           const double qy = bj < nl ? ty[bj] : (double)dst[(long long)bj * 3 + 1];
           const double qz = bj < nl ? tz[bj] : (double)dst[(long long)bj * 3 + 2];
-          v[0] += 1.0; v[1] += px; v[2] += py; v[3] += pz; v[4] += qx; v[5] += qy; v[6] += qz;
-          v[7] += px * qx + py * qy; v[8] += px * qy - py * qx; v[9] += best;
+          const double ax = px - cx, ay = py - cy, az = pz - cz, bx = qx - cx, by = qy - cy, bz = qz - cz;
+          v[0] += 1.0; v[1] += ax; v[2] += ay; v[3] += az; v[4] += bx; v[5] += by; v[6] += bz;
+          v[7] += ax * bx + ay * by; v[8] += ax * by - ay * bx; v[9] += best;
         }
       }
       block_reduce(v, red, tot);
@@ -199,12 +204,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_kernel(const IcpArgs a)
       fit_prev = fit; rmse_prev = rmse;
       // ---- estimate: rotation about z + translation minimising sum |Rz p + t - q|^2 over the correspondences ----
       if (tid == 0 && cnt > 0.0) {
-        const double mpx = tot[1] / cnt, mpy = tot[2] / cnt, mpz = tot[3] / cnt;
-        const double mqx = tot[4] / cnt, mqy = tot[5] / cnt, mqz = tot[6] / cnt;
-        const double sxx = tot[7] - cnt * (mpx * mqx + mpy * mqy);
-        const double sxy = tot[8] - cnt * (mpx * mqy - mpy * mqx);
+        const double apx = tot[1] / cnt, apy = tot[2] / cnt, apz = tot[3] / cnt;   // means about the pivot
+        const double aqx = tot[4] / cnt, aqy = tot[5] / cnt, aqz = tot[6] / cnt;
+        const double sxx = tot[7] - cnt * (apx * aqx + apy * aqy);
+        const double sxy = tot[8] - cnt * (apx * aqy - apy * aqx);
         const double th = atan2(sxy, sxx), c = cos(th), s = sin(th);
-        const double tx = mqx - (c * mpx - s * mpy), ty = mqy - (s * mpx + c * mpy), tz = mqz - mpz;
+        const double mpx = cx + apx, mpy = cy + apy, mqx = cx + aqx, mqy = cy + aqy;
+        const double tx = mqx - (c * mpx - s * mpy), ty = mqy - (s * mpx + c * mpy), tz = aqz - apz;
         // T <- U T,  U = [[c,-s,0,tx],[s,c,0,ty],[0,0,1,tz]]
         double n[12];
         for (int col = 0; col < 4; ++col) {

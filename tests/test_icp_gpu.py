@@ -72,3 +72,34 @@ def test_icp_rows_and_large_cloud(gpu_required):
     np.testing.assert_allclose(res["transforms"][0], T, rtol=0, atol=1e-9)
     assert res["fitness"][0] == fit and res["iterations"][0] == it
     eng.close()
+
+
+@pytest.mark.parametrize("offset", [0.0, 512.0, 4096.0])
+def test_icp_exact_ties_and_far_frames(gpu_required, offset):
+    """The nearest-neighbour scan is certified in fp32 before it is decided in fp64 (alignnet_icp.hip: icp_prefilter_eps); this is the case it must not lose:
+    a lattice target (spacing 2^-4, exactly representable also `offset` metres from the origin, where an fp32 coordinate carries 2^-15 .. 2^-12 of absolute
+    rounding -- three to four orders above the 1e-9 the transforms are held to) and source points on the cell centres of its faces, so that every source
+    point has FOUR exactly equidistant nearest targets in the first evaluation (the oracle's argmin takes the first index); plus duplicated target points
+    (exact ties inside one lane's slice and across lanes).  Far from the origin ONE estimate is compared (its = 1: the transform is a function of the first
+    evaluation's correspondences alone, i.e. of the tie-breaking) -- from the second evaluation on, the four candidates of a source point differ by fractions
+    of an ulp of the transformed point, and which one wins depends on whether T p was formed with fused multiply-adds (the kernel) or not (NumPy): the all-fp64
+    kernel of the commit before disagrees with the oracle there in the same way.  At the origin the whole iteration is compared."""
+    eng = alignnet3d.Engine(small_cfg(N=64, nb=12))
+    g = np.arange(12, dtype=np.float64) / 16.0
+    lat = np.stack(np.meshgrid(g, g, g[:5], indexing="ij"), -1).reshape(-1, 3) + offset            # 720 lattice points
+    rng = np.random.default_rng(3)
+    lat = lat[rng.permutation(len(lat))]                                                            # index order unrelated to position
+    dst = np.concatenate([lat, lat[:97]]).astype(np.float32)                                        # + 97 duplicates
+    assert np.array_equal(dst.astype(np.float64)[: len(lat)], lat)                                  # exactly representable
+    src = (lat[(lat[:, 0] < offset + 10 / 16) & (lat[:, 1] < offset + 10 / 16)] + [1 / 32, 1 / 32, 0.0]).astype(np.float32)
+    inits = [np.eye(4)]   # (exact T p: the ties of the first evaluation are exact)
+    if offset == 0.0:
+        inits.append(I.get_mat_angle(np.array([1e-3, -2e-3, 0.0]), 5e-4, rotation_center=dst.mean(0).astype(np.float64)))
+    for init in inits:
+        for radius, its in (((0.1, 30), (0.05, 5)) if offset == 0.0 else ((0.1, 1), (0.05, 1))):
+            res = eng.icp_refine([src], [dst], [init], radius=radius, its=its)
+            T, fit, rmse, it = I.icp_p2point_z(src, dst, init, radius, its)
+            np.testing.assert_allclose(res["transforms"][0], T, rtol=0, atol=1e-9 * max(1.0, offset))
+            rtol = 1e-12 if offset == 0.0 else 1e-9   # (far frames: the second evaluation's distances carry ulp(offset) = 1e-13 .. 1e-12 of the transformed points' rounding)
+            assert res["fitness"][0] == fit and abs(res["rmse"][0] - rmse) < rtol and res["iterations"][0] == it, (offset, res["iterations"][0], it, res["fitness"][0], fit)
+    eng.close()
